@@ -1,0 +1,226 @@
+"""ctypes binding of libauxssm.so (include/auxssm.h) and the thin device-memory layer on top of it.
+
+No PyTorch / JAX anywhere on this path: Python host code -> ctypes -> hand-written HIP kernels.
+The library is REQUIRED: there is no CPU fallback.  If it is missing or no GPU is present the product
+raises; only the test oracle (oracle/) computes on the CPU, and the product never imports it.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libauxssm.so")
+
+F32, F64 = 0, 1
+NAN_REFERENCE, NAN_MASKED = 0, 1
+KMODEL_LG_CONCAT = 1
+(K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
+ K_CSMC_BWD) = range(9)
+
+
+class AuxSSMError(RuntimeError):
+    pass
+
+
+class Arr(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("sc", C.c_int64), ("st", C.c_int64), ("sb", C.c_int64)]
+
+
+class Lgssm(C.Structure):
+    _fields_ = [(n, Arr) for n in ("m0", "P0", "Fs", "Qs", "bs", "Hs", "Rs", "cs")]
+
+
+class Dims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("C", "T", "B", "dx", "dy")]
+
+
+_lib = None
+
+
+def load():
+    """Load libauxssm.so (once).  Fails loudly: the HIP extension is the product, not an accelerator option."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise AuxSSMError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          f"(or `make -C aux_ssm_samplers_amd/csrc -j8`). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, dbl = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_double
+    P = C.POINTER
+    sig = {
+        "auxssm_version": ([], C.c_int),
+        "auxssm_last_error": ([], C.c_char_p),
+        "auxssm_device_count": ([P(C.c_int)], C.c_int),
+        "auxssm_create": ([i32, P(vp)], C.c_int),
+        "auxssm_destroy": ([vp], C.c_int),
+        "auxssm_sync": ([vp], C.c_int),
+        "auxssm_stream": ([vp, P(vp)], C.c_int),
+        "auxssm_malloc": ([vp, C.c_size_t, P(vp)], C.c_int),
+        "auxssm_free": ([vp, vp], C.c_int),
+        "auxssm_memcpy_h2d": ([vp, vp, vp, C.c_size_t], C.c_int),
+        "auxssm_memcpy_d2h": ([vp, vp, vp, C.c_size_t], C.c_int),
+        "auxssm_memcpy_d2d": ([vp, vp, vp, C.c_size_t], C.c_int),
+        "auxssm_memset": ([vp, vp, i32, C.c_size_t], C.c_int),
+        "auxssm_prof_enable": ([vp, i32, i32], C.c_int),
+        "auxssm_prof_read": ([vp, P(C.c_int), P(dbl)], C.c_int),
+        "auxssm_prof_disable": ([vp], C.c_int),
+        "auxssm_kalman_filter": ([vp, i32, P(Dims), P(Lgssm), P(Arr), i32, vp, vp, vp], C.c_int),
+        "auxssm_kalman_sample": ([vp, i32, P(Dims), P(Lgssm), vp, vp, vp, i32, vp], C.c_int),
+        "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
+        "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
+        "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
+    }
+    for name, (argtypes, restype) in sig.items():
+        fn = getattr(lib, name)  # AttributeError here = the .so does not export what include/auxssm.h declares
+        fn.argtypes = argtypes
+        fn.restype = restype
+    lib._auxssm_signatures = sig
+    _lib = lib
+    return lib
+
+
+def exported_symbols():
+    """Names include/auxssm.h declares (used by the CPU test that checks the .so exports all of them)."""
+    return sorted(load()._auxssm_signatures)
+
+
+def check(rc):
+    if rc != 0:
+        msg = load().auxssm_last_error().decode(errors="replace")
+        if rc in (-1, -2):
+            raise ValueError(f"auxssm: {msg}")
+        if rc == -4:
+            raise MemoryError(f"auxssm: {msg}")
+        raise AuxSSMError(f"auxssm (status {rc}): {msg}")
+
+
+def dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise ValueError(f"dtype must be float32 or float64, got {dt}")
+
+
+class Handle:
+    """One HIP device + one stream (auxssm_create)."""
+
+    def __init__(self, device=0):
+        lib = load()
+        h = C.c_void_p()
+        check(lib.auxssm_create(int(device), C.byref(h)))
+        self.lib, self.h, self.device = lib, h, int(device)
+
+    def close(self):
+        if self.h:
+            self.lib.auxssm_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        check(self.lib.auxssm_sync(self.h))
+
+    # ---- memory ----
+    def empty(self, shape, dtype):
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, a, dtype=None):
+        a = np.ascontiguousarray(a, dtype=dtype)
+        d = DeviceArray(self, a.shape, a.dtype)
+        if a.nbytes:
+            check(self.lib.auxssm_memcpy_h2d(self.h, d.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+        return d
+
+    def zeros(self, shape, dtype):
+        d = DeviceArray(self, shape, dtype)
+        if d.nbytes:
+            check(self.lib.auxssm_memset(self.h, d.ptr, 0, d.nbytes))
+        return d
+
+    # ---- profiling (HIP events on the handle's stream, around one kernel kind) ----
+    def prof_enable(self, kernel_id, max_launches):
+        check(self.lib.auxssm_prof_enable(self.h, kernel_id, max_launches))
+
+    def prof_read(self):
+        n, ms = C.c_int(), C.c_double()
+        check(self.lib.auxssm_prof_read(self.h, C.byref(n), C.byref(ms)))
+        return n.value, ms.value
+
+    def prof_disable(self):
+        check(self.lib.auxssm_prof_disable(self.h))
+
+    # ---- RNG fill ----
+    def rng_normal(self, key, stream, shape, dtype):
+        out = self.empty(shape, dtype)
+        check(self.lib.auxssm_rng_normal(self.h, dtype_code(dtype), key[0], key[1], stream, out.size, out.ptr))
+        return out
+
+    def rng_uniform(self, key, stream, shape, dtype):
+        out = self.empty(shape, dtype)
+        check(self.lib.auxssm_rng_uniform(self.h, dtype_code(dtype), key[0], key[1], stream, out.size, out.ptr))
+        return out
+
+
+class DeviceArray:
+    """A dense, C-contiguous array in HBM owned by Python (auxssm_malloc / auxssm_free)."""
+
+    def __init__(self, handle, shape, dtype):
+        self.handle = handle
+        self.shape = tuple(int(s) for s in np.atleast_1d(shape)) if not isinstance(shape, tuple) else tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.size = int(np.prod(self.shape, dtype=np.int64)) if len(self.shape) else 1
+        self.nbytes = self.size * self.dtype.itemsize
+        p = C.c_void_p()
+        check(handle.lib.auxssm_malloc(handle.h, self.nbytes, C.byref(p)))
+        self.ptr = p
+
+    def __del__(self):
+        try:
+            if self.ptr and self.handle.h:
+                self.handle.lib.auxssm_free(self.handle.h, self.ptr)
+            self.ptr = None
+        except Exception:
+            pass
+
+    def to_host(self):
+        out = np.empty(self.shape, self.dtype)
+        if self.nbytes:
+            check(self.handle.lib.auxssm_memcpy_d2h(self.handle.h, out.ctypes.data_as(C.c_void_p), self.ptr, self.nbytes))
+        return out
+
+    def copy_from_host(self, a):
+        a = np.ascontiguousarray(a, dtype=self.dtype)
+        if a.shape != self.shape:
+            raise ValueError(f"shape mismatch {a.shape} vs {self.shape}")
+        if a.nbytes:
+            check(self.handle.lib.auxssm_memcpy_h2d(self.handle.h, self.ptr, a.ctypes.data_as(C.c_void_p), a.nbytes))
+
+    def copy_from(self, other):
+        if other.nbytes != self.nbytes:
+            raise ValueError("size mismatch")
+        check(self.handle.lib.auxssm_memcpy_d2d(self.handle.h, self.ptr, other.ptr, self.nbytes))
+
+    def arr(self, sc, st, sb=0):
+        return Arr(self.ptr.value, int(sc), int(st), int(sb))
+
+
+_default_handles = {}
+
+
+def default_handle(device=None):
+    """Per-process handle for `device` (default: $LOCAL_RANK, else 0) -- one process per GPU."""
+    if device is None:
+        device = int(os.environ.get("AUXSSM_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    h = _default_handles.get(device)
+    if h is None:
+        h = _default_handles[device] = Handle(device)
+    return h

@@ -1,0 +1,653 @@
+// api.hip -- the C ABI of libauxssm.so (include/auxssm.h): handle, workspace, dispatch, the fused
+// auxiliary-Kalman sweep and the Threefry fill kernels.
+#include <cstdarg>
+#include <cstring>
+
+#include "ctx.h"
+#include "rng.h"
+
+namespace ax {
+
+static thread_local std::string g_err;
+void set_error(const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+}
+
+int ws_reserve(auxssm_ctx* h, size_t bytes) {
+    h->ws_off = 0;
+    if (bytes <= h->ws_bytes) return AUXSSM_OK;
+    if (h->ws) {
+        AX_HIP(hipStreamSynchronize(h->stream));
+        AX_HIP(hipFree(h->ws));
+        h->ws = nullptr;
+        h->ws_bytes = 0;
+    }
+    const size_t want = bytes + bytes / 8 + (1u << 20);
+    hipError_t e = hipMalloc((void**)&h->ws, want);
+    if (e != hipSuccess) {
+        set_error("workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+        return AUXSSM_ERR_NOMEM;
+    }
+    h->ws_bytes = want;
+    return AUXSSM_OK;
+}
+void* ws_take(auxssm_ctx* h, size_t bytes) {
+    const size_t off = (h->ws_off + 255) & ~(size_t)255;
+    if (off + bytes > h->ws_bytes) {
+        set_error("internal: workspace overrun (%zu + %zu > %zu)", off, bytes, h->ws_bytes);
+        return nullptr;
+    }
+    h->ws_off = off + bytes;
+    return h->ws + off;
+}
+
+ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
+    ScanPlan p;
+    if (!parallel || n <= 2) {
+        p.E = n > 0 ? n : 1;
+        p.nchunk = 1;
+        return p;
+    }
+    const long long target = (long long)h->num_cu * 4 * 64 * 2;  // two waves per SIMD
+    long long E = ((long long)S * n + target - 1) / target;
+    long long emin = (long long)(sqrt((double)n / 43.0) + 0.5);
+    if (emin < 2) emin = 2;
+    if (emin > 32) emin = 32;
+    if (E < emin) E = emin;
+    if (E > 512) E = 512;
+    p.E = (int)E;
+    p.nchunk = (int)((n + E - 1) / E);
+    return p;
+}
+
+// instantiation units
+#define AX_DECL_UNIT(NAME) \
+    const KalmanEntry* kalman_unit_##NAME(int P); \
+    const SampleEntry* sample_unit_##NAME();
+AX_DECL_UNIT(f32_d1) AX_DECL_UNIT(f32_d2) AX_DECL_UNIT(f32_d3) AX_DECL_UNIT(f32_d4)
+AX_DECL_UNIT(f64_d1) AX_DECL_UNIT(f64_d2) AX_DECL_UNIT(f64_d3) AX_DECL_UNIT(f64_d4)
+
+const KalmanEntry* kalman_entry(int dtype, int D, int P) {
+    if (dtype == AUXSSM_F32) {
+        switch (D) {
+            case 1: return kalman_unit_f32_d1(P);
+            case 2: return kalman_unit_f32_d2(P);
+            case 3: return kalman_unit_f32_d3(P);
+            case 4: return kalman_unit_f32_d4(P);
+        }
+    } else if (dtype == AUXSSM_F64) {
+        switch (D) {
+            case 1: return kalman_unit_f64_d1(P);
+            case 2: return kalman_unit_f64_d2(P);
+            case 3: return kalman_unit_f64_d3(P);
+            case 4: return kalman_unit_f64_d4(P);
+        }
+    }
+    return nullptr;
+}
+const SampleEntry* sample_entry(int dtype, int D) {
+    if (dtype == AUXSSM_F32) {
+        switch (D) {
+            case 1: return sample_unit_f32_d1();
+            case 2: return sample_unit_f32_d2();
+            case 3: return sample_unit_f32_d3();
+            case 4: return sample_unit_f32_d4();
+        }
+    } else if (dtype == AUXSSM_F64) {
+        switch (D) {
+            case 1: return sample_unit_f64_d1();
+            case 2: return sample_unit_f64_d2();
+            case 3: return sample_unit_f64_d3();
+            case 4: return sample_unit_f64_d4();
+        }
+    }
+    return nullptr;
+}
+
+static inline Arr cv(const auxssm_arr& a) { return Arr{a.ptr, (long long)a.sc, (long long)a.st, (long long)a.sb}; }
+static inline Arr dense(const void* p, const KDims& d, long long rec) {
+    return Arr{p, (long long)d.T * d.B * rec, (long long)d.B * rec, rec};
+}
+
+static int check_dims(const auxssm_dims* d, bool need_dy) {
+    if (!d) {
+        set_error("dims is NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (d->C < 1 || d->T < 1 || d->B < 1 || d->dx < 1 || (need_dy && d->dy < 1)) {
+        set_error("bad dims C=%d T=%d B=%d dx=%d dy=%d (all must be >= 1)", d->C, d->T, d->B, d->dx, d->dy);
+        return AUXSSM_ERR_ARG;
+    }
+    if ((long long)d->C * d->B > (1ll << 24)) {
+        set_error("C*B = %lld sequences is beyond the supported 2^24", (long long)d->C * d->B);
+        return AUXSSM_ERR_ARG;
+    }
+    return AUXSSM_OK;
+}
+static int check_dtype(int dtype) {
+    if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
+        set_error("dtype must be AUXSSM_F32 (0) or AUXSSM_F64 (1), got %d", dtype);
+        return AUXSSM_ERR_ARG;
+    }
+    return AUXSSM_OK;
+}
+static int check_lgssm(const auxssm_lgssm* g, int T) {
+    if (!g) {
+        set_error("lgssm is NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (!g->m0.ptr || !g->P0.ptr || !g->Hs.ptr || !g->Rs.ptr || !g->cs.ptr) {
+        set_error("lgssm has a NULL m0/P0/Hs/Rs/cs pointer");
+        return AUXSSM_ERR_ARG;
+    }
+    if (T > 1 && (!g->Fs.ptr || !g->Qs.ptr || !g->bs.ptr)) {
+        set_error("lgssm has a NULL Fs/Qs/bs pointer with T > 1");
+        return AUXSSM_ERR_ARG;
+    }
+    return AUXSSM_OK;
+}
+static const KalmanEntry* need_kalman(int dtype, int D, int P) {
+    const KalmanEntry* e = (D >= 1 && D <= MAX_D) ? kalman_entry(dtype, D, P) : nullptr;
+    if (!e) set_error("(dx=%d, dy=%d) is not instantiated in this build (dx <= %d, dy <= %d)", D, P, MAX_D, MAX_P);
+    return e;
+}
+
+static void fill_filter_args(FilterArgs& a, const auxssm_dims* d, const auxssm_lgssm* g, const auxssm_arr* ys, void* ms, void* Ps) {
+    a.d = KDims{d->C, d->T, d->B};
+    a.m0 = cv(g->m0); a.P0 = cv(g->P0); a.Fs = cv(g->Fs); a.Qs = cv(g->Qs); a.bs = cv(g->bs);
+    a.Hs = cv(g->Hs); a.Rs = cv(g->Rs); a.cs = cv(g->cs); a.ys = cv(*ys);
+    a.ms = ms; a.Ps = Ps; a.elem = nullptr; a.ell0 = nullptr;
+}
+static void fill_logpdf_args(LogpdfArgs& a, const auxssm_dims* d, const auxssm_lgssm* g, const Arr& ys, const Arr& xs, int pol) {
+    a.d = KDims{d->C, d->T, d->B};
+    a.m0 = cv(g->m0); a.P0 = cv(g->P0); a.Fs = cv(g->Fs); a.Qs = cv(g->Qs); a.bs = cv(g->bs);
+    a.Hs = cv(g->Hs); a.Rs = cv(g->Rs); a.cs = cv(g->cs); a.ys = ys; a.xs = xs; a.nan_policy = pol;
+}
+
+// ---- sweep helper kernels (pure data movement / reductions; runtime sizes) --------------------------------
+
+// concatenated observation model of AUXSSM_KMODEL_LG_CONCAT, chain-shared part: H = [I; Hobs], R = blkdiag(d/2 I, Robs), c = [0; cobs]
+template <typename R>
+__global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cobs, R half_delta, R* Hc, R* Rc, R* cc) {
+    const int P = D + PO;
+    const int per_t = P * D + P * P + P;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)T * per_t) return;
+    const long long t = g / per_t;
+    int r = (int)(g % per_t);
+    if (r < P * D) {
+        const int k = r / D, j = r % D;
+        Hc[t * P * D + r] = k < D ? (k == j ? (R)1 : (R)0) : at<R>(Hobs, 0, t, 0)[(k - D) * D + j];
+    } else if ((r -= P * D) < P * P) {
+        const int k = r / P, l = r % P;
+        R v = 0;
+        if (k < D && l < D) v = (k == l) ? half_delta : (R)0;
+        else if (k >= D && l >= D) v = at<R>(Robs, 0, t, 0)[(k - D) * PO + (l - D)];
+        Rc[t * P * P + r] = v;
+    } else {
+        r -= P * P;
+        cc[t * P + r] = r < D ? (R)0 : at<R>(cobs, 0, t, 0)[r - D];
+    }
+}
+// u = x + sqrt(d/2) eps ; ys_c[c,t,:] = [u ; yobs_t]
+template <typename R>
+__global__ void k_concat_obs(int C, int T, int D, int PO, const R* x, const R* eps, R shd, Arr yobs, R* u, R* ysc) {
+    const int P = D + PO;
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)C * T * P) return;
+    const int k = (int)(g % P);
+    const long long ct = g / P;
+    const int c = (int)(ct / T);
+    const long long t = ct % T;
+    if (k < D) {
+        const R v = x[ct * D + k] + shd * eps[ct * D + k];
+        u[ct * D + k] = v;
+        ysc[g] = v;
+    } else {
+        ysc[g] = at<R>(yobs, c, t, 0)[k - D];
+    }
+}
+// corr[c] = sum_{t,k} ((xp-u)^2 - (x-u)^2) / delta     (generic.py:103-105), one workgroup per chain
+template <typename R> __global__ void __launch_bounds__(256) k_correction(long long TD, const R* x, const R* xp, const R* u, R inv_delta, R* out) {
+    __shared__ R sh[256];
+    const int c = blockIdx.x;
+    const long long base = (long long)c * TD;
+    R v = 0;
+    for (long long k = threadIdx.x; k < TD; k += 256) {
+        const R a = xp[base + k] - u[base + k], b = x[base + k] - u[base + k];
+        v += (a * a - b * b) * inv_delta;
+    }
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[c] = sh[0];
+}
+// _get_alpha + bernoulli (generic.py:70-73, 98-106)
+template <typename R>
+__global__ void k_accept(int C, const R* jp_prop, const R* jp_rev, const R* ell_prop, const R* ell_rev, const R* lt_prop,
+                         const R* lt_rev, const R* corr, const R* u_acc, int32_t* accepted, R* logs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const R lp_prop = jp_prop[c] - ell_prop[c];
+    const R lp_rev = jp_rev[c] - ell_rev[c];
+    R la = lt_prop[c] - lt_rev[c];
+    la += lp_rev - lp_prop;
+    la -= corr[c];
+    const R alpha = exp_(min_(la, (R)0));
+    accepted[c] = (u_acc[c] < alpha) ? 1 : 0;  // NaN alpha -> reject, as jax.random.bernoulli(key, nan)
+    if (logs) {
+        logs[c * 5 + 0] = la;
+        logs[c * 5 + 1] = lp_prop;
+        logs[c * 5 + 2] = lp_rev;
+        logs[c * 5 + 3] = lt_prop[c];
+        logs[c * 5 + 4] = lt_rev[c];
+    }
+}
+template <typename R> __global__ void k_select(long long TD, long long total, const int32_t* accepted, const R* xp, R* x) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    if (accepted[g / TD]) x[g] = xp[g];
+}
+
+template <typename R>
+static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
+                           double delta, int parallel, int nan_policy, void* x, const void* eps_aux, const void* eps_samp,
+                           const void* u_acc, int32_t* accepted, void* logs) {
+    const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy, P = D + PO;
+    const KalmanEntry* ke = need_kalman(dtype, D, P);
+    const KalmanEntry* ko = need_kalman(dtype, D, PO);
+    const SampleEntry* se = sample_entry(dtype, D);
+    if (!ke || !ko || !se) return AUXSSM_ERR_UNSUPPORTED;
+    const KDims kd{C, T, 1};
+    const size_t sR = sizeof(R);
+    const size_t CT = (size_t)C * T;
+    size_t need = 0;
+    auto add = [&](size_t b) { need += b + 256; };
+    add(CT * P * sR);                                  // ys_c
+    add((size_t)T * (P * D + P * P + P) * sR);         // Hc, Rc, cc (three takes)
+    add(512);
+    add(CT * D * sR);                                  // u
+    add(CT * D * sR);                                  // ms
+    add(CT * D * D * sR);                              // Ps
+    add(CT * D * sR);                                  // x_prop
+    add((size_t)C * 8 * sR + 2048);                    // scalars
+    add(ke->filter_ws(h, kd, parallel));
+    add(se->sample_ws(h, kd, parallel));
+    add(ke->logpdf_ws(h, kd));
+    int rc = ws_reserve(h, need);
+    if (rc) return rc;
+    R* ysc = (R*)ws_take(h, CT * P * sR);
+    R* Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
+    R* Rc = (R*)ws_take(h, (size_t)T * P * P * sR);
+    R* cc = (R*)ws_take(h, (size_t)T * P * sR);
+    R* u = (R*)ws_take(h, CT * D * sR);
+    R* ms = (R*)ws_take(h, CT * D * sR);
+    R* Ps = (R*)ws_take(h, CT * D * D * sR);
+    R* xp = (R*)ws_take(h, CT * D * sR);
+    R* ell = (R*)ws_take(h, C * sR);
+    R* jp_prop = (R*)ws_take(h, C * sR);
+    R* jp_rev = (R*)ws_take(h, C * sR);
+    R* lt_prop = (R*)ws_take(h, C * sR);
+    R* lt_rev = (R*)ws_take(h, C * sR);
+    R* corr = (R*)ws_take(h, C * sR);
+    const size_t mark = h->ws_off;
+
+    // observations_factory / dynamics_factory of the LG_CONCAT device model
+    {
+        const long long n1 = (long long)T * (P * D + P * P + P);
+        hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
+                           cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
+        const long long n2 = (long long)CT * P;
+        hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, T, D, PO,
+                           (const R*)x, (const R*)eps_aux, (R)sqrt(0.5 * delta), cv(*yobs), u, ysc);
+    }
+    auxssm_lgssm gc = *model;
+    gc.Hs = auxssm_arr{Hc, 0, (int64_t)P * D, 0};
+    gc.Rs = auxssm_arr{Rc, 0, (int64_t)P * P, 0};
+    gc.cs = auxssm_arr{cc, 0, (int64_t)P, 0};
+    const auxssm_arr ysc_arr{ysc, (int64_t)T * P, (int64_t)P, 0};
+    auxssm_dims dc = *dims;
+    dc.dy = P;
+    dc.B = 1;
+
+    // proposal LGSSM: filter + pathwise sample (generic.py:80-86).  The factories of this model do not depend on the
+    // linearisation point, so the reverse LGSSM (generic.py:67) is the same one and its filter pass is not repeated.
+    FilterArgs fa;
+    fill_filter_args(fa, &dc, &gc, &ysc_arr, ms, Ps);
+    rc = ke->filter(h, fa, parallel, ell);
+    if (rc) return rc;
+    h->ws_off = mark;
+    SampleArgs sa;
+    sa.d = kd;
+    sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
+    sa.ms = ms; sa.Ps = Ps; sa.eps = eps_samp; sa.xs = xp; sa.elem = nullptr;
+    rc = se->sample(h, sa, parallel);
+    if (rc) return rc;
+    h->ws_off = mark;
+
+    // proposal log-densities (generic.py:88) and targets (generic.py:89)
+    const Arr x_arr = dense(x, kd, D), xp_arr = dense(xp, kd, D);
+    LogpdfArgs la;
+    fill_logpdf_args(la, &dc, &gc, cv(ysc_arr), xp_arr, nan_policy);
+    rc = ke->logpdf(h, la, jp_prop);
+    if (rc) return rc;
+    h->ws_off = mark;
+    la.xs = x_arr;
+    rc = ke->logpdf(h, la, jp_rev);
+    if (rc) return rc;
+    h->ws_off = mark;
+    auxssm_dims dobs = *dims;
+    dobs.B = 1;
+    fill_logpdf_args(la, &dobs, model, cv(*yobs), xp_arr, nan_policy);
+    rc = ko->logpdf(h, la, lt_prop);
+    if (rc) return rc;
+    h->ws_off = mark;
+    la.xs = x_arr;
+    rc = ko->logpdf(h, la, lt_rev);
+    if (rc) return rc;
+    h->ws_off = mark;
+
+    hipLaunchKernelGGL((k_correction<R>), dim3(C), dim3(256), 0, h->stream, (long long)T * D, (const R*)x, (const R*)xp,
+                       (const R*)u, (R)(1.0 / delta), corr);
+    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)jp_prop, (const R*)jp_rev,
+                       (const R*)ell, (const R*)ell, (const R*)lt_prop, (const R*)lt_rev, (const R*)corr, (const R*)u_acc,
+                       accepted, (R*)logs);
+    const long long total = (long long)CT * D;
+    hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, (long long)T * D, total,
+                       (const int32_t*)accepted, (const R*)xp, (R*)x);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+// ---- RNG fill -----------------------------------------------------------------------------------------------------
+template <typename R, bool NORMAL>
+__global__ void k_rng_fill(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t x0 = (uint32_t)(i & 0xffffffffu), x1 = stream ^ (uint32_t)((unsigned long long)i >> 32 << 16);
+    threefry2x32(k0, k1, x0, x1);
+    out[i] = NORMAL ? bits_to_normal<R>(x0, x1) : bits_to_uniform<R>(x0);
+}
+
+}  // namespace ax
+
+using namespace ax;
+
+extern "C" {
+
+int auxssm_version(void) { return AUXSSM_VERSION; }
+const char* auxssm_last_error(void) { return g_err.c_str(); }
+
+int auxssm_device_count(int* count) {
+    if (!count) return AUXSSM_ERR_ARG;
+    AX_HIP(hipGetDeviceCount(count));
+    return AUXSSM_OK;
+}
+
+int auxssm_create(int device, auxssm_handle* out) {
+    if (!out) {
+        set_error("out is NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    int n = 0;
+    AX_HIP(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) {
+        set_error("device %d out of range (have %d)", device, n);
+        return AUXSSM_ERR_ARG;
+    }
+    AX_HIP(hipSetDevice(device));
+    auxssm_ctx* h = new auxssm_ctx();
+    h->device = device;
+    hipDeviceProp_t prop;
+    AX_HIP(hipGetDeviceProperties(&prop, device));
+    h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    AX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    *out = h;
+    return AUXSSM_OK;
+}
+
+int auxssm_destroy(auxssm_handle h) {
+    if (!h) return AUXSSM_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    auxssm_prof_disable(h);
+    if (h->ws) (void)hipFree(h->ws);
+    (void)hipStreamDestroy(h->stream);
+    delete h;
+    return AUXSSM_OK;
+}
+
+#define AX_NEED_H(h)                         \
+    do {                                     \
+        if (!(h)) {                          \
+            set_error("handle is NULL");     \
+            return AUXSSM_ERR_ARG;           \
+        }                                    \
+        AX_HIP(hipSetDevice((h)->device));   \
+    } while (0)
+
+int auxssm_sync(auxssm_handle h) {
+    AX_NEED_H(h);
+    AX_HIP(hipStreamSynchronize(h->stream));
+    return AUXSSM_OK;
+}
+int auxssm_stream(auxssm_handle h, void** stream) {
+    AX_NEED_H(h);
+    if (!stream) return AUXSSM_ERR_ARG;
+    *stream = (void*)h->stream;
+    return AUXSSM_OK;
+}
+int auxssm_malloc(auxssm_handle h, size_t bytes, void** dptr) {
+    AX_NEED_H(h);
+    if (!dptr) return AUXSSM_ERR_ARG;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 1);
+    if (e != hipSuccess) {
+        set_error("hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+        return AUXSSM_ERR_NOMEM;
+    }
+    return AUXSSM_OK;
+}
+int auxssm_free(auxssm_handle h, void* dptr) {
+    AX_NEED_H(h);
+    if (dptr) {
+        AX_HIP(hipStreamSynchronize(h->stream));
+        AX_HIP(hipFree(dptr));
+    }
+    return AUXSSM_OK;
+}
+int auxssm_memcpy_h2d(auxssm_handle h, void* dst, const void* src, size_t bytes) {
+    AX_NEED_H(h);
+    AX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, h->stream));
+    AX_HIP(hipStreamSynchronize(h->stream));
+    return AUXSSM_OK;
+}
+int auxssm_memcpy_d2h(auxssm_handle h, void* dst, const void* src, size_t bytes) {
+    AX_NEED_H(h);
+    AX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
+    AX_HIP(hipStreamSynchronize(h->stream));
+    return AUXSSM_OK;
+}
+int auxssm_memcpy_d2d(auxssm_handle h, void* dst, const void* src, size_t bytes) {
+    AX_NEED_H(h);
+    AX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, h->stream));
+    return AUXSSM_OK;
+}
+int auxssm_memset(auxssm_handle h, void* dst, int value, size_t bytes) {
+    AX_NEED_H(h);
+    AX_HIP(hipMemsetAsync(dst, value, bytes, h->stream));
+    return AUXSSM_OK;
+}
+
+int auxssm_prof_disable(auxssm_handle h) {
+    if (!h) return AUXSSM_ERR_ARG;
+    Prof& p = h->prof;
+    for (auto e : p.start) (void)hipEventDestroy(e);
+    for (auto e : p.stop) (void)hipEventDestroy(e);
+    p.start.clear();
+    p.stop.clear();
+    p.kernel_id = 0;
+    p.max_launches = 0;
+    p.used = 0;
+    return AUXSSM_OK;
+}
+int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches) {
+    AX_NEED_H(h);
+    if (max_launches < 1 || max_launches > (1 << 16)) {
+        set_error("max_launches must be in [1, 65536]");
+        return AUXSSM_ERR_ARG;
+    }
+    auxssm_prof_disable(h);
+    Prof& p = h->prof;
+    p.start.resize(max_launches);
+    p.stop.resize(max_launches);
+    for (int i = 0; i < max_launches; ++i) {
+        AX_HIP(hipEventCreate(&p.start[i]));
+        AX_HIP(hipEventCreate(&p.stop[i]));
+    }
+    p.kernel_id = kernel_id;
+    p.max_launches = max_launches;
+    p.used = 0;
+    return AUXSSM_OK;
+}
+int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms) {
+    AX_NEED_H(h);
+    AX_HIP(hipStreamSynchronize(h->stream));
+    Prof& p = h->prof;
+    double tot = 0;
+    for (int i = 0; i < p.used; ++i) {
+        float ms = 0;
+        AX_HIP(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+        tot += ms;
+    }
+    if (launches) *launches = p.used;
+    if (total_ms) *total_ms = tot;
+    p.used = 0;
+    return AUXSSM_OK;
+}
+
+int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
+                         const auxssm_arr* ys, int parallel, void* ms, void* Ps, void* ell) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true)) || (rc = check_lgssm(lgssm, dims->T))) return rc;
+    if (!ys || !ys->ptr || !ms || !Ps || !ell) {
+        set_error("ys/ms/Ps/ell must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    const KalmanEntry* e = need_kalman(dtype, dims->dx, dims->dy);
+    if (!e) return AUXSSM_ERR_UNSUPPORTED;
+    const KDims kd{dims->C, dims->T, dims->B};
+    if ((rc = ws_reserve(h, e->filter_ws(h, kd, parallel) + 4096))) return rc;
+    FilterArgs a;
+    fill_filter_args(a, dims, lgssm, ys, ms, Ps);
+    return e->filter(h, a, parallel, ell);
+}
+
+int auxssm_kalman_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
+                         const void* ms, const void* Ps, const void* eps, int parallel, void* xs) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, false))) return rc;
+    if (!lgssm || !ms || !Ps || !eps || !xs || (dims->T > 1 && (!lgssm->Fs.ptr || !lgssm->Qs.ptr || !lgssm->bs.ptr))) {
+        set_error("lgssm(Fs,Qs,bs)/ms/Ps/eps/xs must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    const SampleEntry* e = (dims->dx <= MAX_D) ? sample_entry(dtype, dims->dx) : nullptr;
+    if (!e) {
+        set_error("dx=%d is not instantiated in this build (dx <= %d)", dims->dx, MAX_D);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    const KDims kd{dims->C, dims->T, dims->B};
+    if ((rc = ws_reserve(h, e->sample_ws(h, kd, parallel) + 4096))) return rc;
+    SampleArgs a;
+    a.d = kd;
+    a.Fs = cv(lgssm->Fs); a.Qs = cv(lgssm->Qs); a.bs = cv(lgssm->bs);
+    a.ms = ms; a.Ps = Ps; a.eps = eps; a.xs = xs; a.elem = nullptr;
+    return e->sample(h, a, parallel);
+}
+
+int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
+                               const auxssm_arr* ys, const auxssm_arr* xs, int nan_policy, void* out) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true)) || (rc = check_lgssm(lgssm, dims->T))) return rc;
+    if (!ys || !ys->ptr || !xs || !xs->ptr || !out) {
+        set_error("ys/xs/out must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (nan_policy != AUXSSM_NAN_REFERENCE && nan_policy != AUXSSM_NAN_MASKED) {
+        set_error("nan_policy must be 0 (reference) or 1 (masked)");
+        return AUXSSM_ERR_ARG;
+    }
+    const KalmanEntry* e = need_kalman(dtype, dims->dx, dims->dy);
+    if (!e) return AUXSSM_ERR_UNSUPPORTED;
+    const KDims kd{dims->C, dims->T, dims->B};
+    if ((rc = ws_reserve(h, e->logpdf_ws(h, kd) + 4096))) return rc;
+    LogpdfArgs a;
+    fill_logpdf_args(a, dims, lgssm, cv(*ys), cv(*xs), nan_policy);
+    return e->logpdf(h, a, out);
+}
+
+int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
+                        const auxssm_arr* yobs, double delta, int parallel, int nan_policy, void* x, const void* eps_aux,
+                        const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true)) || (rc = check_lgssm(model, dims->T))) return rc;
+    if (model_kind != AUXSSM_KMODEL_LG_CONCAT) {
+        set_error("unknown model_kind %d", model_kind);
+        return AUXSSM_ERR_ARG;
+    }
+    if (dims->B != 1) {
+        set_error("auxssm_kalman_sweep needs B == 1");
+        return AUXSSM_ERR_ARG;
+    }
+    if (!(delta > 0)) {
+        set_error("delta must be > 0");
+        return AUXSSM_ERR_ARG;
+    }
+    if (!yobs || !yobs->ptr || !x || !eps_aux || !eps_samp || !u_acc || !accepted) {
+        set_error("yobs/x/eps_aux/eps_samp/u_acc/accepted must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (dtype == AUXSSM_F32)
+        return sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
+    return sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
+}
+
+static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32_t k1, uint32_t stream, int64_t n, void* out) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype))) return rc;
+    if (n < 0 || !out) {
+        set_error("n must be >= 0 and out non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (n == 0) return AUXSSM_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (dtype == AUXSSM_F32) {
+        if (normal) hipLaunchKernelGGL((k_rng_fill<float, true>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
+        else hipLaunchKernelGGL((k_rng_fill<float, false>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
+    } else {
+        if (normal) hipLaunchKernelGGL((k_rng_fill<double, true>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
+        else hipLaunchKernelGGL((k_rng_fill<double, false>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
+    }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+int auxssm_rng_normal(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out) {
+    return rng_fill(h, dtype, true, key0, key1, stream, n, out);
+}
+int auxssm_rng_uniform(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out) {
+    return rng_fill(h, dtype, false, key0, key1, stream, n, out);
+}
+
+}  // extern "C"

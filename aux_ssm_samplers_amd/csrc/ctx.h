@@ -1,0 +1,97 @@
+// ctx.h -- handle, workspace and type-erased launch records shared by api.hip and the instantiation units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "../../include/auxssm.h"
+#include "kalman_bodies.h"
+
+namespace ax {
+
+void set_error(const char* fmt, ...);
+
+#define AX_HIP(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            ax::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return AUXSSM_ERR_HIP;                                                           \
+        }                                                                                    \
+    } while (0)
+
+struct Prof {
+    int kernel_id = 0;
+    int max_launches = 0;
+    int used = 0;
+    std::vector<hipEvent_t> start, stop;
+};
+
+}  // namespace ax
+
+struct auxssm_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    // workspace: one slab, bump-allocated per API call, grown on demand
+    char* ws = nullptr;
+    size_t ws_bytes = 0;
+    size_t ws_off = 0;
+    ax::Prof prof;
+    int num_cu = 256;
+};
+
+namespace ax {
+
+// Reserve the slab for one API call (sum of the call's needs), then carve from it.
+int ws_reserve(auxssm_ctx* h, size_t bytes);
+void* ws_take(auxssm_ctx* h, size_t bytes);
+
+struct ProfScope {
+    auxssm_ctx* h;
+    int slot;
+    ProfScope(auxssm_ctx* h_, int kernel_id) : h(h_), slot(-1) {
+        Prof& p = h->prof;
+        if (p.kernel_id == kernel_id && p.used < p.max_launches) {
+            slot = p.used++;
+            (void)hipEventRecord(p.start[slot], h->stream);
+        }
+    }
+    ~ProfScope() {
+        if (slot >= 0) (void)hipEventRecord(h->prof.stop[slot], h->stream);
+    }
+};
+
+// ---- type-erased launch entry points, one set per (dtype, D) instantiation unit ---------------------
+struct ScanPlan {
+    int E;       // elements per thread chunk
+    int nchunk;  // chunks per sequence
+};
+ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel);
+
+typedef int (*filter_fn)(auxssm_ctx*, const FilterArgs&, int parallel, void* ell_out /*[C]*/);
+typedef int (*sample_fn)(auxssm_ctx*, const SampleArgs&, int parallel);
+typedef int (*logpdf_fn)(auxssm_ctx*, const LogpdfArgs&, void* out /*[C]*/);
+typedef size_t (*filter_ws_fn)(const auxssm_ctx*, const KDims&, int parallel);
+typedef size_t (*sample_ws_fn)(const auxssm_ctx*, const KDims&, int parallel);
+typedef size_t (*logpdf_ws_fn)(const auxssm_ctx*, const KDims&);
+
+struct KalmanEntry {
+    filter_fn filter;
+    filter_ws_fn filter_ws;
+    logpdf_fn logpdf;
+    logpdf_ws_fn logpdf_ws;
+};
+struct SampleEntry {
+    sample_fn sample;
+    sample_ws_fn sample_ws;
+};
+
+constexpr int MAX_D = 4;
+constexpr int MAX_P = 8;
+
+// defined by the instantiation units (inst_*.hip); nullptr entries = not built
+const KalmanEntry* kalman_entry(int dtype, int D, int P);
+const SampleEntry* sample_entry(int dtype, int D);
+
+}  // namespace ax

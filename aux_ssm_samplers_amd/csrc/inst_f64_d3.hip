@@ -1,0 +1,3 @@
+// instantiation unit: real = double, dx = 3, every dy in 1..8 (filter, log-likelihood pass, joint logpdf) + the sampler
+#include "kernels.hip.h"
+AX_DEFINE_UNIT(f64_d3, double, 3)

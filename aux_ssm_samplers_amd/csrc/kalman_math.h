@@ -1,0 +1,593 @@
+// kalman_math.h -- per-lane bodies of the auxiliary-Kalman hot path (one lane = one time step or one
+// scan element).  Reference semantics: aux_samplers/_primitives/kalman/{filtering,sampling,base}.py and
+// _primitives/math/mvn/base.py; the citations below are relative to /root/reference/aux_samplers.
+#pragma once
+#include "smallmat.h"
+
+namespace ax {
+
+// ------------------------------------------------------------------------------------------------
+// Scan element of the parallel filter: (A, b, C, eta, J), C and J symmetric-packed.
+// Memory record: [A (D*D) | b (D) | C (DS) | eta (D) | J (DS)], padded to FE_PAD reals.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int D> struct FiltElem {
+    static constexpr int DS = symsize(D);
+    static constexpr int N = D * D + 2 * D + 2 * DS;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
+    R A[D * D];
+    R b[D];
+    R C[DS];
+    R eta[D];
+    R J[DS];
+};
+// Reduced prefix that the final pass carries: only (b, C) = filtered (mean, cov) (filtering.py:55 discards the rest)
+template <typename R, int D> struct FiltPre {
+    static constexpr int DS = symsize(D);
+    static constexpr int N = D + DS;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
+    R b[D];
+    R C[DS];
+};
+
+template <typename R, int D> AX_HD void fe_store(R* __restrict__ p, const FiltElem<R, D>& e) {
+    constexpr int DS = symsize(D);
+    st<R, D * D>(p, e.A);
+    st<R, D>(p + D * D, e.b);
+    st<R, DS>(p + D * D + D, e.C);
+    st<R, D>(p + D * D + D + DS, e.eta);
+    st<R, DS>(p + D * D + 2 * D + DS, e.J);
+}
+template <typename R, int D> AX_HD void fe_load(const R* __restrict__ p, FiltElem<R, D>& e) {
+    constexpr int DS = symsize(D);
+    ld<R, D * D>(p, e.A);
+    ld<R, D>(p + D * D, e.b);
+    ld<R, DS>(p + D * D + D, e.C);
+    ld<R, D>(p + D * D + D + DS, e.eta);
+    ld<R, DS>(p + D * D + 2 * D + DS, e.J);
+}
+template <typename R, int D> AX_HD void fe_identity(FiltElem<R, D>& e) {
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.A[i] = (i / D == i % D) ? (R)1 : (R)0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.b[i] = 0, e.eta[i] = 0;
+#pragma unroll
+    for (int i = 0; i < symsize(D); ++i) e.C[i] = 0, e.J[i] = 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Observation masking (filtering.py:89-100, :204-213): missing components (non-finite y) lose their rows
+// of H and c; the matching rows/cols of S are treated as deleted by chol_packed(skip=nan).
+// ------------------------------------------------------------------------------------------------
+template <typename R, int D, int P>
+AX_HD bool obs_mask(const R* y, const R* H, const R* c, bool* nan, R* H_, R* c_) {
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        nan[k] = !finite_(y[k]);
+        any = any || !nan[k];
+        c_[k] = nan[k] ? (R)0 : c[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) H_[k * D + j] = nan[k] ? (R)0 : H[k * D + j];
+    }
+    return any;
+}
+
+// S = H_ P H_^T + R_ (packed), PHt = P H_^T.  Rm is read from memory entry by entry (keeps R out of VGPRs).
+template <typename R, int D, int P>
+AX_HD void innovation_cov(const R* Pd, const R* H_, const R* __restrict__ Rm, const bool* nan, R* PHt, R* S) {
+    mmt<R, D, D, P>(Pd, H_, PHt);  // PHt[i][k] = sum_j P[i][j] H_[k][j]
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+#pragma unroll
+        for (int l = k; l < P; ++l) {
+            R s = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) s += H_[k * D + j] * PHt[j * P + l];
+            const R r = (nan[k] || nan[l]) ? (R)0 : Rm[k * P + l];
+            S[sidx_u(P, k, l)] = s + r;
+        }
+}
+
+// sequential_update (filtering.py:83-130).  m, Pd (dense) updated in place; returns ell increment.
+template <typename R, int D, int P>
+AX_HD R kalman_update(R* m, R* Pd, const R* H, const R* c, const R* __restrict__ Rm, const R* y) {
+    bool nan[P];
+    R H_[P * D], c_[P];
+    const bool any = obs_mask<R, D, P>(y, H, c, nan, H_, c_);
+    if (!any) return (R)0;  // _passthrough :127-130
+    R yd[P];
+    int dim = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        R yh = c_[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) yh += H_[k * D + j] * m[j];
+        yd[k] = nan[k] ? (R)0 : y[k] - yh;
+        dim += nan[k] ? 0 : 1;
+    }
+    R PHt[D * P], S[symsize(P)], L[symsize(P)];
+    innovation_cov<R, D, P>(Pd, H_, Rm, nan, PHt, S);
+    R G[D * P];
+    R ell;
+    if constexpr (P == 1) {  // scalar branch :108-111
+        const R s = S[0];
+        const R sd = sqrt_(s);
+        const R z = yd[0] / sd;
+        ell = (R)-0.5 * z * z - log_(sd) - (R)(0.5 * LOG_2PI);
+#pragma unroll
+        for (int i = 0; i < D; ++i) G[i] = PHt[i] / s;
+    } else {
+        const bool ok = chol_packed<R, P>(S, L, nan);
+        R z[P];
+        R logdet = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            z[k] = yd[k];
+            logdet += nan[k] ? (R)0 : log_(L[lidx(k, k)]);
+        }
+        lsolve<R, P>(L, z);
+        R q = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) q += z[k] * z[k];
+        ell = (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim;
+        if (!ok) ell = r_nan<R>();
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R g[P];
+#pragma unroll
+            for (int k = 0; k < P; ++k) g[k] = PHt[i * P + k];
+            cho_solve<R, P>(L, g);
+#pragma unroll
+            for (int k = 0; k < P; ++k) G[i * P + k] = ok ? g[k] : r_nan<R>();
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R s = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) s += G[i * P + k] * yd[k];
+        m[i] += s;
+    }
+    // P - G S0 G^T with S0 G^T = (H_ P) on the observed block  (== PHt^T)
+    R Pn[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) s += G[i * P + k] * PHt[j * P + k];
+            Pn[i * D + j] = Pd[i * D + j] - s;
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pd[i * D + j] = (i == j) ? Pn[i * D + i] : (R)0.5 * (Pn[i * D + j] + Pn[j * D + i]);
+    return isnan_(ell) ? (R)0 : ell;
+}
+
+// sequential_predict (filtering.py:134-139)
+template <typename R, int D> AX_HD void kalman_predict(R* m, R* Pd, const R* F, const R* b, const R* Q) {
+    R t[D], FP[D * D], Pn[D * D];
+    mv<R, D, D>(F, m, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) m[i] = t[i] + b[i];
+    mm<R, D, D, D>(F, Pd, FP);
+    mmt<R, D, D, D>(FP, F, Pn);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) Pn[i] += Q[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) Pd[i * D + j] = (i == j) ? Pn[i * D + i] : (R)0.5 * (Pn[i * D + j] + Pn[j * D + i]);
+}
+
+// _filtering_init_one (filtering.py:196-250).  (m_, P_) are the *predicted* moments the element is built
+// around: predict(m0+, P0+) for the first transition, (b, Q) for every other one (:188-192).
+template <typename R, int D, int P>
+AX_HD void filter_elem(const R* F, const R* bdyn, const R* m_, const R* P_, const R* H, const R* c,
+                       const R* __restrict__ Rm, const R* y, FiltElem<R, D>& e) {
+    bool nan[P];
+    R H_[P * D], c_[P];
+    const bool any = obs_mask<R, D, P>(y, H, c, nan, H_, c_);
+    if (!any) {  // _passthrough :239-248
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) e.A[i] = F[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) e.b[i] = m_[i], e.eta[i] = 0;
+        sympack<R, D>(P_, e.C);
+#pragma unroll
+        for (int i = 0; i < symsize(D); ++i) e.J[i] = 0;
+        return;
+    }
+    R PHt[D * P], S[symsize(P)];
+    innovation_cov<R, D, P>(P_, H_, Rm, nan, PHt, S);
+    R Z[P * D];  // S^{-1} H_
+    if constexpr (P == 1) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) Z[j] = H_[j] / S[0];
+    } else {
+        R L[symsize(P)];
+        const bool ok = chol_packed<R, P>(S, L, nan);
+#pragma unroll
+        for (int i = 0; i < P * D; ++i) Z[i] = H_[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) cho_solve_col<R, P, D>(L, Z, j);
+        if (!ok) {
+#pragma unroll
+            for (int i = 0; i < P * D; ++i) Z[i] = r_nan<R>();
+        }
+    }
+    R ydm[P], ydb[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        R hm = c_[k], hb = c_[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) hm += H_[k * D + j] * m_[j], hb += H_[k * D + j] * bdyn[j];
+        ydm[k] = nan[k] ? (R)0 : y[k] - hm;
+        ydb[k] = nan[k] ? (R)0 : y[k] - hb;
+    }
+    R K[D * P];
+    mmt<R, D, D, P>(P_, Z, K);  // K = P_ Z^T
+    R HF[P * D];
+    mm<R, P, D, D>(H_, F, HF);
+    // A = F - K H_ F
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) s += K[i * P + k] * HF[k * D + j];
+            e.A[i * D + j] = F[i * D + j] - s;
+        }
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R s = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) s += K[i * P + k] * ydm[k];
+        e.b[i] = m_[i] + s;
+    }
+    // C = P_ - K S0 K^T, with S0 K^T = H_ P_ on the observed block (= PHt^T)
+    R Cd[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) s += K[i * P + k] * PHt[j * P + k];
+            Cd[i * D + j] = P_[i * D + j] - s;
+        }
+    sympack<R, D>(Cd, e.C);
+    R ZF[P * D];
+    mm<R, P, D, D>(Z, F, ZF);  // temp^T = Z F
+    tmv<R, D, P>(ZF, ydb, e.eta);
+    R Jd[D * D];
+    tmm<R, D, P, D>(ZF, HF, Jd);
+    sympack<R, D>(Jd, e.J);
+}
+
+// ------------------------------------------------------------------------------------------------
+// _filtering_op_impl (filtering.py:163-183), a1 = earlier prefix, a2 = later element.
+// The reference forms M = A2 (I + C1 J2)^-1 and Nn = A1^T (I + J2 C1)^-1 with two LU solves.  Since
+// (I + J2 C1) = (I + C1 J2)^T for symmetric C1, J2, one factorisation of W = I + C1 J2 serves both:
+//     X = W^-1 A1,  Y = W^-1 C1,  z = W^-1 (b1 + C1 eta2)
+//     A = A2 X;  b = A2 z + b2;  C = A2 Y A2^T + C2;  eta = X^T (eta2 - J2 b1) + eta1;  J = X^T (J2 A1) + J1
+// (same values, rounding-level differences).  d = 1 uses divisions (:171-173).
+// ------------------------------------------------------------------------------------------------
+template <typename R, int D>
+AX_HD void filter_combine(const FiltElem<R, D>& a1, const FiltElem<R, D>& a2, FiltElem<R, D>& o) {
+    if constexpr (D == 1) {
+        const R w = (R)1 + a1.C[0] * a2.J[0];
+        const R M = a2.A[0] / w, Nn = a1.A[0] / w;
+        o.A[0] = M * a1.A[0];
+        o.b[0] = M * (a1.b[0] + a1.C[0] * a2.eta[0]) + a2.b[0];
+        o.C[0] = M * (a1.C[0] * a2.A[0]) + a2.C[0];
+        o.eta[0] = Nn * (a2.eta[0] - a2.J[0] * a1.b[0]) + a1.eta[0];
+        o.J[0] = Nn * (a2.J[0] * a1.A[0]) + a1.J[0];
+    } else {
+        constexpr int NR = 2 * D + 1;
+        R W[D * D], B[D * NR];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                R s = (i == j) ? (R)1 : (R)0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += a1.C[sidx(D, i, k)] * a2.J[sidx(D, k, j)];
+                W[i * D + j] = s;
+            }
+        R v[D];
+        symv<R, D>(a1.C, a2.eta, v);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                B[i * NR + j] = a1.A[i * D + j];
+                B[i * NR + D + j] = a1.C[sidx(D, i, j)];
+            }
+            B[i * NR + 2 * D] = a1.b[i] + v[i];
+        }
+        lu_solve<R, D, NR>(W, B);  // B = [X | Y | z]
+        R JA[D * D];
+        symm<R, D, D>(a2.J, a1.A, JA);
+        R w[D];
+        symv<R, D>(a2.J, a1.b, w);
+#pragma unroll
+        for (int i = 0; i < D; ++i) w[i] = a2.eta[i] - w[i];
+        R AY[D * D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R sb = a2.b[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                R sa = 0, sy = 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    sa += a2.A[i * D + k] * B[k * NR + j];
+                    sy += a2.A[i * D + k] * B[k * NR + D + j];
+                }
+                o.A[i * D + j] = sa;
+                AY[i * D + j] = sy;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) sb += a2.A[i * D + k] * B[k * NR + 2 * D];
+            o.b[i] = sb;
+        }
+        R Cd[D * D], Jd[D * D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R se = a1.eta[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                R sc = a2.C[sidx(D, i, j)], sj = a1.J[sidx(D, i, j)];
+#pragma unroll
+                for (int k = 0; k < D; ++k) {
+                    sc += AY[i * D + k] * a2.A[j * D + k];
+                    sj += B[k * NR + i] * JA[k * D + j];
+                }
+                Cd[i * D + j] = sc;
+                Jd[i * D + j] = sj;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) se += B[k * NR + i] * w[k];
+            o.eta[i] = se;
+        }
+        sympack<R, D>(Cd, o.C);
+        sympack<R, D>(Jd, o.J);
+    }
+}
+
+// The (b, C) half of the same combine: all the final pass needs, because (b, C) of a1 (+) a2 depend on a1
+// only through (b1, C1).
+template <typename R, int D>
+AX_HD void filter_apply(const FiltPre<R, D>& p, const FiltElem<R, D>& a2, FiltPre<R, D>& o) {
+    if constexpr (D == 1) {
+        const R w = (R)1 + p.C[0] * a2.J[0];
+        const R M = a2.A[0] / w;
+        o.b[0] = M * (p.b[0] + p.C[0] * a2.eta[0]) + a2.b[0];
+        o.C[0] = M * (p.C[0] * a2.A[0]) + a2.C[0];
+    } else {
+        constexpr int NR = D + 1;
+        R W[D * D], B[D * NR];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                R s = (i == j) ? (R)1 : (R)0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) s += p.C[sidx(D, i, k)] * a2.J[sidx(D, k, j)];
+                W[i * D + j] = s;
+            }
+        R v[D];
+        symv<R, D>(p.C, a2.eta, v);
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+#pragma unroll
+            for (int j = 0; j < D; ++j) B[i * NR + j] = p.C[sidx(D, i, j)];
+            B[i * NR + D] = p.b[i] + v[i];
+        }
+        lu_solve<R, D, NR>(W, B);  // [Y | z]
+        R AY[D * D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R sb = a2.b[i];
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                R sy = 0;
+#pragma unroll
+                for (int k = 0; k < D; ++k) sy += a2.A[i * D + k] * B[k * NR + j];
+                AY[i * D + j] = sy;
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) sb += a2.A[i * D + k] * B[k * NR + D];
+            o.b[i] = sb;
+        }
+        R Cd[D * D];
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) {
+                R sc = a2.C[sidx(D, i, j)];
+#pragma unroll
+                for (int k = 0; k < D; ++k) sc += AY[i * D + k] * a2.A[j * D + k];
+                Cd[i * D + j] = sc;
+            }
+        sympack<R, D>(Cd, o.C);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pathwise sampler (sampling.py).  Scan element (G, e): memory record [G (D*D) | e (D)] padded.
+// ------------------------------------------------------------------------------------------------
+template <typename R, int D> struct SampElem {
+    static constexpr int N = D * D + D;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
+    R G[D * D];
+    R e[D];
+};
+template <typename R, int D> struct SampPre {
+    static constexpr int N = D;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
+    R e[D];
+};
+
+template <typename R> AX_HD R nan_to_num(R x) {
+    if (isnan_(x)) return (R)0;
+    if (!finite_(x)) return x > 0 ? (R)(sizeof(R) == 4 ? 3.4028234663852886e38 : 1.7976931348623157e308)
+                                  : (R)(sizeof(R) == 4 ? -3.4028234663852886e38 : -1.7976931348623157e308);
+    return x;
+}
+
+// lower Cholesky of a packed-symmetric matrix into a DENSE lower-triangular D x D, jnp semantics followed by
+// nan_to_num (sampling.py:100-104, :117-121): a failed factorisation is all-NaN, hence all-zero.
+template <typename R, int D> AX_HD void chol_nan_to_num(const R* Spacked, R* Ld) {
+    if constexpr (D == 1) {
+        Ld[0] = nan_to_num(sqrt_(Spacked[0]));
+    } else {
+        R L[symsize(D)];
+        const bool ok = chol_packed<R, D>(Spacked, L, nullptr);
+#pragma unroll
+        for (int i = 0; i < D; ++i)
+#pragma unroll
+            for (int j = 0; j < D; ++j) Ld[i * D + j] = (j <= i && ok) ? nan_to_num(L[lidx(i, j)]) : (R)0;
+    }
+}
+
+// mean_and_chol + _sampling_init_one (sampling.py:60-112) for t < T-1
+template <typename R, int D>
+AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* Pd, const R* eps, SampElem<R, D>& e) {
+    R FP[D * D], Sd[D * D], S[symsize(D)];
+    mm<R, D, D, D>(F, Pd, FP);
+    mmt<R, D, D, D>(FP, F, Sd);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) Sd[i] += Q[i];
+    sympack<R, D>(Sd, S);
+    if constexpr (D == 1) {
+        e.G[0] = Pd[0] * F[0] / S[0];
+    } else {
+        R L[symsize(D)];
+        const bool ok = chol_packed<R, D>(S, L, nullptr);
+        R X[D * D];  // S^-1 F
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) X[i] = F[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) cho_solve_col<R, D, D>(L, X, j);
+        mmt<R, D, D, D>(Pd, X, e.G);  // gain = P X^T
+        if (!ok) {
+#pragma unroll
+            for (int i = 0; i < D * D; ++i) e.G[i] = r_nan<R>();
+        }
+    }
+    // inc_Sig = sym(P - gain S gain^T)
+    R gS[D * D], Sg[D * D], Sig[symsize(D)];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += e.G[i * D + k] * S[sidx(D, k, j)];
+            gS[i * D + j] = s;
+        }
+    mmt<R, D, D, D>(gS, e.G, Sg);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) Sg[i] = Pd[i] - Sg[i];
+    sympack<R, D>(Sg, Sig);
+    R Lc[D * D];
+    chol_nan_to_num<R, D>(Sig, Lc);
+    R pm[D], t[D];
+    mv<R, D, D>(F, m, pm);
+#pragma unroll
+    for (int i = 0; i < D; ++i) pm[i] += b[i];
+    mv<R, D, D>(e.G, pm, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R s = m[i] - t[i];
+#pragma unroll
+        for (int k = 0; k <= i; ++k) s += Lc[i * D + k] * eps[k];
+        e.e[i] = s;
+    }
+}
+// _sample_last_step (sampling.py:115-124)
+template <typename R, int D> AX_HD void sample_last(const R* m, const R* Pd, const R* eps, SampElem<R, D>& e) {
+    R S[symsize(D)], Lc[D * D];
+    sympack<R, D>(Pd, S);
+    chol_nan_to_num<R, D>(S, Lc);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.G[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R s = m[i];
+#pragma unroll
+        for (int k = 0; k <= i; ++k) s += Lc[i * D + k] * eps[k];
+        e.e[i] = s;
+    }
+}
+// _sampling_op_impl (sampling.py:51-55): acc = later times already composed, cur = this time step
+template <typename R, int D>
+AX_HD void sample_combine(const SampElem<R, D>& acc, const SampElem<R, D>& cur, SampElem<R, D>& o) {
+    mm<R, D, D, D>(cur.G, acc.G, o.G);
+    R t[D];
+    mv<R, D, D>(cur.G, acc.e, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) o.e[i] = t[i] + cur.e[i];
+}
+template <typename R, int D>
+AX_HD void sample_apply(const SampPre<R, D>& p, const SampElem<R, D>& cur, SampPre<R, D>& o) {
+    R t[D];
+    mv<R, D, D>(cur.G, p.e, t);
+#pragma unroll
+    for (int i = 0; i < D; ++i) o.e[i] = t[i] + cur.e[i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// mvn.logpdf of a residual r with covariance given densely (math/mvn/base.py:15-58), N = dimension.
+//   drop_nonfinite: a non-finite residual component makes the reference's result NaN, which its nansum
+//   then drops -> return 0.  `skip` (may be null) deletes components (MASKED policy).
+// ------------------------------------------------------------------------------------------------
+template <typename R, int N>
+AX_HD R gauss_logpdf(const R* r, const R* __restrict__ cov, const bool* skip) {
+    R res[N];
+    int dim = 0;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool sk = skip ? skip[k] : false;
+        res[k] = sk ? (R)0 : r[k];
+        bad = bad || !finite_(res[k]);
+        dim += sk ? 0 : 1;
+    }
+    R out;
+    if constexpr (N == 1) {
+        const R sd = sqrt_(cov[0]);
+        const R z = res[0] / sd;
+        out = (R)-0.5 * z * z - log_(sd) - (R)(0.5 * LOG_2PI);
+        if (skip && skip[0]) out = 0;
+    } else {
+        R S[symsize(N)], L[symsize(N)];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = i; j < N; ++j) S[sidx_u(N, i, j)] = cov[i * N + j];
+        const bool ok = chol_packed<R, N>(S, L, skip);
+        R logdet = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) logdet += (skip && skip[k]) ? (R)0 : log_(L[lidx(k, k)]);
+        lsolve<R, N>(L, res);
+        R q = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) q += res[k] * res[k];
+        out = (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim;
+        if (!ok) out = r_nan<R>();
+    }
+    if (bad || isnan_(out)) return (R)0;
+    return out;
+}
+
+}  // namespace ax

@@ -1,0 +1,330 @@
+// kernels.hip.h -- __global__ wrappers, the three-launch chunked associative scan, and the templated
+// launchers that the instantiation units (inst_*.hip) expose through the tables in ctx.h.
+//
+// Scan structure (both the filter's (A,b,C,eta,J) scan and the sampler's (G,e) scan):
+//   1. k_scan_reduce : one lane per chunk of E consecutive elements, sequential combine in registers
+//                      -> one aggregate per chunk.
+//   2. k_scan_aggs   : one workgroup per sequence scans the chunk aggregates (per-lane sequential +
+//                      Kogge-Stone across the workgroup through LDS) and writes, per chunk, only the
+//                      reduced exclusive prefix the final pass needs ((b,C) resp. e).
+//   3. k_scan_down   : one lane per chunk re-walks its elements with the cheap "apply" form of the combine
+//                      and writes the outputs in the caller's dense layout.
+// No inter-workgroup communication inside a launch, so no spin-waits and a deterministic combination tree.
+#pragma once
+#include "ctx.h"
+
+namespace ax {
+
+constexpr int TB_ELEM = 128;  // elementwise kernels: threads per workgroup
+constexpr int TB_SCAN = 64;   // chunk kernels: one wave per workgroup
+constexpr int TB_AGGS = 128;  // aggregate scan: threads per sequence
+
+// ---- block-wide deterministic sum (fixed tree) ------------------------------------------------------------
+template <typename R, int TB> __device__ __forceinline__ R block_sum(R v, R* sh) {
+    const int tid = threadIdx.x;
+    sh[tid] = v;
+    __syncthreads();
+#pragma unroll
+    for (int off = TB / 2; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] += sh[tid + off];
+        __syncthreads();
+    }
+    const R r = sh[0];
+    __syncthreads();
+    return r;
+}
+
+// ---- Kalman elementwise kernels -----------------------------------------------------------------------------
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_t0(FilterArgs a) {
+    const int s = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (s < a.d.S()) body_filter_t0<R, D, P>(a, s);
+}
+
+// grid = ntile * S, sequence index fastest so that workgroups of different chains touching the same time
+// tile (hence the same chain-shared model parameters) are co-scheduled and share them through L2.
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_init(FilterArgs a) {
+    const int S = a.d.S();
+    const int s = blockIdx.x % S;
+    const int i = (blockIdx.x / S) * TB_ELEM + threadIdx.x;
+    if (i < a.d.n()) body_filter_init<R, D, P>(a, s, i);
+}
+
+template <typename R, int D, int P>
+__global__ void __launch_bounds__(TB_ELEM) k_filter_ell(FilterArgs a, R* __restrict__ part, int ntile) {
+    __shared__ R sh[TB_ELEM];
+    const int S = a.d.S();
+    const int s = blockIdx.x % S;
+    const int tile = blockIdx.x / S;
+    const int i = tile * TB_ELEM + threadIdx.x;
+    R v = 0;
+    if (i < a.d.n()) v = body_filter_ell<R, D, P>(a, s, i);
+    const R tot = block_sum<R, TB_ELEM>(v, sh);
+    if (threadIdx.x == 0) part[(long long)s * ntile + tile] = tot;
+}
+
+template <typename R, int D, int P>
+__global__ void __launch_bounds__(TB_ELEM) k_joint_logpdf(LogpdfArgs a, R* __restrict__ part, int ntile) {
+    __shared__ R sh[TB_ELEM];
+    const int S = a.d.S();
+    const int s = blockIdx.x % S;
+    const int tile = blockIdx.x / S;
+    const int t = tile * TB_ELEM + threadIdx.x;
+    R v = 0;
+    if (t < a.d.T) v = body_joint_logpdf<R, D, P>(a, s, t);
+    const R tot = block_sum<R, TB_ELEM>(v, sh);
+    if (threadIdx.x == 0) part[(long long)s * ntile + tile] = tot;
+}
+
+// out[c] = sum_b ( add0[c*B+b] + sum_tile part[(c*B+b)*ntile + tile] ), fixed order.  One workgroup per chain.
+template <typename R>
+__global__ void __launch_bounds__(TB_ELEM) k_reduce_rows(const R* __restrict__ part, const R* __restrict__ add0,
+                                                          int B, int ntile, R* __restrict__ out) {
+    __shared__ R sh[TB_ELEM];
+    const int c = blockIdx.x;
+    const long long base = (long long)c * B * ntile;
+    const long long tot_n = (long long)B * ntile;
+    R v = 0;
+    for (long long k = threadIdx.x; k < tot_n; k += TB_ELEM) v += part[base + k];
+    if (add0)
+        for (int b = threadIdx.x; b < B; b += TB_ELEM) v += add0[(long long)c * B + b];
+    const R tot = block_sum<R, TB_ELEM>(v, sh);
+    if (threadIdx.x == 0) out[c] = tot;
+}
+
+template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample_init(SampleArgs a) {
+    const int S = a.d.S();
+    const int s = blockIdx.x % S;
+    const int j = (blockIdx.x / S) * TB_ELEM + threadIdx.x;
+    if (j < a.d.T) body_sample_init<R, D>(a, s, j);
+}
+
+// ---- generic chunked scan ---------------------------------------------------------------------------------------
+template <class Op>
+__global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, ScanBufs sb, int S, int n, int E, int nchunk) {
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    const long long g = (long long)blockIdx.x * TB_SCAN + threadIdx.x;
+    if (g >= (long long)S * nchunk) return;
+    const int s = (int)(g / nchunk), ch = (int)(g % nchunk);
+    const int i0 = ch * E;
+    const int i1 = min(n, i0 + E);
+    Full acc, cur, nxt;
+    Op::load(a, s, i0, acc);
+    if (i0 + 1 < i1) Op::load(a, s, i0 + 1, nxt);
+    for (int i = i0 + 1; i < i1; ++i) {
+        cur = nxt;
+        if (i + 1 < i1) Op::load(a, s, i + 1, nxt);  // software prefetch of the next element
+        Full o;
+        Op::combine(acc, cur, o);
+        acc = o;
+    }
+    Op::store_rec((R*)sb.agg + g * Full::NPAD, acc);
+}
+
+template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanBufs sb, int nchunk) {
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    using Pre = typename Op::Pre;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lds = (R*)smem;
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int E2 = (nchunk + TB_AGGS - 1) / TB_AGGS;
+    const int j0 = min(nchunk, tid * E2), j1 = min(nchunk, j0 + E2);
+    const R* agg = (const R*)sb.agg + (long long)s * nchunk * Full::NPAD;
+    R* pre = (R*)sb.pre + (long long)s * nchunk * Pre::NPAD;
+    Full acc;
+    Op::identity(acc);
+    if (j0 < j1) Op::load_rec(agg + (long long)j0 * Full::NPAD, acc);
+    for (int j = j0 + 1; j < j1; ++j) {
+        Full e, o;
+        Op::load_rec(agg + (long long)j * Full::NPAD, e);
+        Op::combine(acc, e, o);
+        acc = o;
+    }
+    // Kogge-Stone inclusive scan of the per-lane totals
+    for (int off = 1; off < TB_AGGS; off <<= 1) {
+        Op::store_rec(lds + tid * Full::NPAD, acc);
+        __syncthreads();
+        Full left;
+        if (tid >= off) Op::load_rec(lds + (tid - off) * Full::NPAD, left);
+        __syncthreads();
+        if (tid >= off) {
+            Full o;
+            Op::combine(left, acc, o);
+            acc = o;
+        }
+    }
+    Op::store_rec(lds + tid * Full::NPAD, acc);
+    __syncthreads();
+    Full ex;
+    Op::identity(ex);
+    if (tid > 0) Op::load_rec(lds + (tid - 1) * Full::NPAD, ex);
+    for (int j = j0; j < j1; ++j) {
+        Pre p;
+        Op::to_pre(ex, p);
+        Op::store_pre(pre + (long long)j * Pre::NPAD, p);
+        if (j + 1 < j1) {
+            Full e, o;
+            Op::load_rec(agg + (long long)j * Full::NPAD, e);
+            Op::combine(ex, e, o);
+            ex = o;
+        }
+    }
+}
+
+template <class Op>
+__global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, ScanBufs sb, int S, int n, int E, int nchunk) {
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    using Pre = typename Op::Pre;
+    const long long g = (long long)blockIdx.x * TB_SCAN + threadIdx.x;
+    if (g >= (long long)S * nchunk) return;
+    const int s = (int)(g / nchunk), ch = (int)(g % nchunk);
+    const int i0 = ch * E;
+    const int i1 = min(n, i0 + E);
+    Pre p;
+    if (nchunk > 1) {
+        Op::load_pre((const R*)sb.pre + g * Pre::NPAD, p);
+    } else {
+        Full id;
+        Op::identity(id);
+        Op::to_pre(id, p);
+    }
+    Full cur, nxt;
+    if (i0 < i1) Op::load(a, s, i0, nxt);
+    for (int i = i0; i < i1; ++i) {
+        cur = nxt;
+        if (i + 1 < i1) Op::load(a, s, i + 1, nxt);
+        Pre o;
+        Op::apply(p, cur, o);
+        p = o;
+        Op::write_out(a, s, i, p);
+    }
+}
+
+template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
+    const ScanPlan pl = plan_scan(h, S, n, parallel);
+    if (pl.nchunk <= 1) return 0;
+    return (size_t)S * pl.nchunk * (Op::Full::NPAD + Op::Pre::NPAD) * sizeof(typename Op::R) + 512;
+}
+
+template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n, int parallel) {
+    using R = typename Op::R;
+    if (n <= 0 || S <= 0) return AUXSSM_OK;
+    const ScanPlan pl = plan_scan(h, S, n, parallel);
+    ScanBufs sb{nullptr, nullptr};
+    const long long nthreads = (long long)S * pl.nchunk;
+    const unsigned grid = (unsigned)((nthreads + TB_SCAN - 1) / TB_SCAN);
+    if (pl.nchunk > 1) {
+        sb.agg = ws_take(h, (size_t)S * pl.nchunk * Op::Full::NPAD * sizeof(R));
+        sb.pre = ws_take(h, (size_t)S * pl.nchunk * Op::Pre::NPAD * sizeof(R));
+        hipLaunchKernelGGL((k_scan_reduce<Op>), dim3(grid), dim3(TB_SCAN), 0, h->stream, a, sb, S, n, pl.E, pl.nchunk);
+        const size_t lds = (size_t)TB_AGGS * Op::Full::NPAD * sizeof(R);
+        hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, pl.nchunk);
+    }
+    hipLaunchKernelGGL((k_scan_down<Op>), dim3(grid), dim3(TB_SCAN), 0, h->stream, a, sb, S, n, pl.E, pl.nchunk);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+inline int ntiles(int n) { return (n + TB_ELEM - 1) / TB_ELEM; }
+
+template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
+    const int S = d.S(), n = d.n();
+    size_t b = 0;
+    b += (size_t)S * (n > 0 ? n : 1) * FiltElem<R, D>::NPAD * sizeof(R) + 256;
+    b += (size_t)S * sizeof(R) + 256;                           // ell0
+    b += (size_t)S * (ntiles(n) + 1) * sizeof(R) + 256;         // ell partials
+    b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
+    return b;
+}
+
+template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterArgs& a_in, int parallel, void* ell_out) {
+    FilterArgs a = a_in;
+    const int S = a.d.S(), n = a.d.n();
+    a.elem = ws_take(h, (size_t)S * (n > 0 ? n : 1) * FiltElem<R, D>::NPAD * sizeof(R));
+    a.ell0 = ws_take(h, (size_t)S * sizeof(R));
+    const int nt = ntiles(n);
+    R* part = (R*)ws_take(h, (size_t)S * (nt + 1) * sizeof(R));
+    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
+    if (n > 0) {
+        {
+            ProfScope ps(h, AUXSSM_K_FILTER_INIT);
+            hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3((unsigned)nt * S), dim3(TB_ELEM), 0, h->stream, a);
+        }
+        {
+            ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n, parallel);
+            if (rc) return rc;
+        }
+        {
+            ProfScope ps(h, AUXSSM_K_FILTER_ELL);
+            hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3((unsigned)nt * S), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+        }
+    }
+    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0,
+                       a.d.B, n > 0 ? nt : 0, (R*)ell_out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+template <typename R, int D> size_t sample_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
+    const int S = d.S();
+    return (size_t)S * d.T * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel);
+}
+
+template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_in, int parallel) {
+    SampleArgs a = a_in;
+    const int S = a.d.S(), T = a.d.T;
+    a.elem = ws_take(h, (size_t)S * T * SampElem<R, D>::NPAD * sizeof(R));
+    {
+        ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
+        hipLaunchKernelGGL((k_sample_init<R, D>), dim3((unsigned)ntiles(T) * S), dim3(TB_ELEM), 0, h->stream, a);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
+        const int rc = run_scan<SampleOp<R, D>>(h, a, S, T, parallel);
+        if (rc) return rc;
+    }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+template <typename R, int D, int P> size_t logpdf_ws(const auxssm_ctx*, const KDims& d) {
+    return (size_t)d.S() * ntiles(d.T) * sizeof(R) + 256;
+}
+
+template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfArgs& a, void* out) {
+    const int S = a.d.S(), T = a.d.T;
+    const int nt = ntiles(T);
+    R* part = (R*)ws_take(h, (size_t)S * nt * sizeof(R));
+    ProfScope ps(h, AUXSSM_K_LOGPDF);
+    hipLaunchKernelGGL((k_joint_logpdf<R, D, P>), dim3((unsigned)nt * S), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr,
+                       a.d.B, nt, (R*)out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+// one instantiation unit = one (dtype, D): all P for the filter / logpdf, plus the sampler
+#define AX_KALMAN_ENTRY(R, D, P) \
+    { &run_filter<R, D, P>, &filter_ws<R, D, P>, &run_logpdf<R, D, P>, &logpdf_ws<R, D, P> }
+
+#define AX_DEFINE_UNIT(NAME, R, D)                                                                   \
+    namespace ax {                                                                                   \
+    const KalmanEntry* kalman_unit_##NAME(int P) {                                                   \
+        static const KalmanEntry tab[MAX_P] = {AX_KALMAN_ENTRY(R, D, 1), AX_KALMAN_ENTRY(R, D, 2),  \
+                                               AX_KALMAN_ENTRY(R, D, 3), AX_KALMAN_ENTRY(R, D, 4),  \
+                                               AX_KALMAN_ENTRY(R, D, 5), AX_KALMAN_ENTRY(R, D, 6),  \
+                                               AX_KALMAN_ENTRY(R, D, 7), AX_KALMAN_ENTRY(R, D, 8)}; \
+        return (P >= 1 && P <= MAX_P) ? &tab[P - 1] : nullptr;                                       \
+    }                                                                                                \
+    const SampleEntry* sample_unit_##NAME() {                                                        \
+        static const SampleEntry e = {&run_sample<R, D>, &sample_ws<R, D>};                          \
+        return &e;                                                                                   \
+    }                                                                                                \
+    }
+
+}  // namespace ax

@@ -1,0 +1,167 @@
+"""Auxiliary Kalman sampler (reference: aux_samplers/kalman/generic.py).
+
+get_kernel(dynamics_factory, observations_factory, log_likelihood_fn, parallel) -> (init, kernel), the same
+names, argument order and (init, kernel) return order as the reference (generic.py:19-46, :95).
+
+Two execution paths, same semantics:
+  * device sweep: the three callables are the bound methods of one built-in device model (models.py); the whole
+    sweep -- auxiliary draw, proposal LGSSM, filter scan, pathwise sample scan, log-densities, MH accept -- is one
+    auxssm_kalman_sweep call, for C chains at once, state resident in HBM.
+  * host-factory path: arbitrary NumPy factories run on the host each sweep; filtering / sampling / log-densities
+    run on the GPU through the primitives.
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass
+from typing import Any
+
+import numpy as np
+
+from .. import _lib, random as _random
+from .._primitives.base import SamplerState
+from .._primitives.kalman import LGSSM, filtering, sampling, posterior_logpdf
+
+
+@dataclass
+class KalmanSampler(SamplerState):
+    x: Any
+    updated: Any
+
+
+def get_kernel(dynamics_factory, observations_factory, log_likelihood_fn, parallel):
+    """See module docstring.  Returns (init, kernel)."""
+    model = _same_device_model(dynamics_factory, observations_factory, log_likelihood_fn)
+    if model is not None:
+        return _get_device_kernel(model, parallel)
+    return _get_host_kernel(dynamics_factory, observations_factory, log_likelihood_fn, parallel)
+
+
+def _same_device_model(*fns):
+    owners = [getattr(f, "__self__", None) for f in fns]
+    names = [getattr(f, "__name__", "") for f in fns]
+    from .models import LGConcatModel
+    if (isinstance(owners[0], LGConcatModel) and all(o is owners[0] for o in owners)
+            and names == ["dynamics_factory", "observations_factory", "log_likelihood_fn"]):
+        return owners[0]
+    return None
+
+
+# ------------------------------------------------------------------------------------------------
+# host-factory path (generic.py:53-106 line by line, heavy lifting on the GPU)
+# ------------------------------------------------------------------------------------------------
+def _get_host_kernel(dynamics_factory, observations_factory, log_likelihood_fn, parallel):
+    def kernel(key, state, delta, noise=None):
+        """noise: optional dict(eps_aux, eps_samp, u_accept) of explicit draws (parity tests)."""
+        x = np.asarray(state.x)
+        handle = _lib.default_handle()
+        k_aux, k_samp, k_acc = _random.split(key, 3) if noise is None else (None, None, None)
+        if noise is None:
+            eps_aux = handle.rng_normal(k_aux, 0, x.shape, x.dtype).to_host()
+            eps_samp = handle.rng_normal(k_samp, 0, x.shape, x.dtype).to_host()
+            u_acc = _random.uniform_scalar(k_acc)
+        else:
+            eps_aux, eps_samp, u_acc = noise["eps_aux"], noise["eps_samp"], noise["u_accept"]
+        u = x + math.sqrt(0.5 * delta) * eps_aux
+
+        def do_one(xlin, x_prop=None):
+            m0, P0, Fs, Qs, bs, *_ = dynamics_factory(xlin)
+            ys, Hs, Rs, cs, *_ = observations_factory(xlin, u, delta)
+            lgssm = LGSSM(m0, P0, Fs, Qs, bs, Hs, Rs, cs)
+            ms, Ps, ell = filtering(ys, lgssm, parallel)
+            if x_prop is None:
+                x_prop = sampling(None, ms, Ps, lgssm, parallel, eps=eps_samp)
+            return posterior_logpdf(ys, x_prop, ell, lgssm), log_likelihood_fn(x_prop), x_prop
+
+        lp_prop, lt_prop, x_prop = do_one(x)
+        lp_rev, lt_rev, _ = do_one(x_prop, x)
+        log_alpha = _log_alpha(lp_prop, lp_rev, lt_prop, lt_rev, math.sqrt(delta), u, x, x_prop)
+        alpha = math.exp(min(0.0, log_alpha)) if not math.isnan(log_alpha) else float("nan")
+        accept = bool(u_acc < alpha)
+        out = KalmanSampler(x=x_prop if accept else x, updated=accept)
+        out.log_alpha = log_alpha
+        return out
+
+    def init(x):
+        return KalmanSampler(x=x, updated=True)
+
+    return init, kernel
+
+
+def _log_alpha(lp_prop, lp_rev, lt_prop, lt_rev, sqrt_delta, u, x, x_prop):
+    # generic.py:98-106
+    la = lt_prop - lt_rev
+    la += lp_rev - lp_prop
+    dp, dc = (x_prop - u) / sqrt_delta, (x - u) / sqrt_delta
+    la -= float(np.sum(dp ** 2 - dc ** 2))
+    return float(la)
+
+
+# ------------------------------------------------------------------------------------------------
+# device sweep
+# ------------------------------------------------------------------------------------------------
+class DeviceChains:
+    """C chains' trajectories resident in HBM: x (C, T, dx)."""
+
+    def __init__(self, handle, x, dtype=None):
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[None]
+        self.handle = handle
+        self.x = handle.to_device(x, dtype or x.dtype)
+        self.C, self.T, self.dx = self.x.shape
+        self.dtype = self.x.dtype
+        self.accepted = handle.zeros((self.C,), np.int32)
+        self.logs = handle.zeros((self.C, 5), self.dtype)
+
+    def to_host(self):
+        return self.x.to_host()
+
+
+def _get_device_kernel(model, parallel, nan_policy="reference"):
+    pol = {"reference": _lib.NAN_REFERENCE, "masked": _lib.NAN_MASKED}[nan_policy]
+
+    def sweep(handle, chains, delta, eps_aux, eps_samp, u_acc):
+        """One auxssm_kalman_sweep on resident buffers (all DeviceArray). Asynchronous."""
+        dl, ybuf, yarr = model.device(handle, chains.dtype)
+        dims = _lib.Dims(chains.C, chains.T, 1, chains.dx, model.p_obs)
+        _lib.check(handle.lib.auxssm_kalman_sweep(
+            handle.h, _lib.dtype_code(chains.dtype), _lib.KMODEL_LG_CONCAT, C.byref(dims), C.byref(dl.c), C.byref(yarr),
+            float(delta), int(bool(parallel)), pol, chains.x.ptr, eps_aux.ptr, eps_samp.ptr, u_acc.ptr,
+            chains.accepted.ptr, chains.logs.ptr))
+
+    def draw(handle, key, chains):
+        k_aux, k_samp, k_acc = _random.split(key, 3)
+        shape = (chains.C, chains.T, chains.dx)
+        return (handle.rng_normal(k_aux, 0, shape, chains.dtype), handle.rng_normal(k_samp, 0, shape, chains.dtype),
+                handle.rng_uniform(k_acc, 0, (chains.C,), chains.dtype))
+
+    def kernel(key, state, delta, noise=None):
+        """state.x: ndarray (T, dx) [one chain], ndarray (C, T, dx) or DeviceChains (resident, updated in place)."""
+        handle = _lib.default_handle()
+        resident = isinstance(state.x, DeviceChains)
+        chains = state.x if resident else DeviceChains(handle, state.x)
+        if noise is None:
+            eps_aux, eps_samp, u_acc = draw(handle, key, chains)
+        else:
+            shape = (chains.C, chains.T, chains.dx)
+            eps_aux = handle.to_device(np.asarray(noise["eps_aux"], chains.dtype).reshape(shape))
+            eps_samp = handle.to_device(np.asarray(noise["eps_samp"], chains.dtype).reshape(shape))
+            u_acc = handle.to_device(np.asarray(noise["u_accept"], chains.dtype).reshape(chains.C))
+        sweep(handle, chains, delta, eps_aux, eps_samp, u_acc)
+        if resident:
+            return KalmanSampler(x=chains, updated=chains.accepted)
+        acc = chains.accepted.to_host().astype(bool)
+        x = chains.to_host()
+        out = KalmanSampler(x=x[0] if np.ndim(state.x) == 2 else x, updated=bool(acc[0]) if np.ndim(state.x) == 2 else acc)
+        logs = chains.logs.to_host()
+        out.log_alpha = float(logs[0, 0]) if np.ndim(state.x) == 2 else logs[:, 0]
+        out.logs = logs
+        return out
+
+    kernel.sweep = sweep
+    kernel.draw = draw
+
+    def init(x):
+        return KalmanSampler(x=x, updated=True)
+
+    return init, kernel

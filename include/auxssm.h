@@ -1,0 +1,154 @@
+/*
+ * auxssm.h -- C ABI of libauxssm.so: MI355X (gfx950) native auxiliary-Kalman / conditional-SMC hot path.
+ *
+ * This is the drop-in boundary for AdrienCorenflos/aux-ssm-samplers.  The reference has no FFI of its
+ * own (it is pure Python on JAX); every entry point below replaces the body of one reference function
+ * and is what a ctypes binding of that function binds.  See INTEGRATION.md for the reference-side stub.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no C++/torch types.  All functions return 0 on success and a
+ *     negative auxssm_status otherwise; auxssm_last_error() returns the message for the calling thread.
+ *   - Data pointers of compute entry points are DEVICE pointers (hipMalloc'd, or from auxssm_malloc).
+ *     The library never frees caller memory; scratch lives in the handle's workspace, grown on demand.
+ *   - One handle = one HIP device + one stream.  Calls on one handle are serialised by the caller and are
+ *     asynchronous w.r.t. the host unless stated; auxssm_sync() waits for the handle's stream.
+ *   - Shapes.  C = independent chains, T = time steps, B = batched independent LGSSMs (reference
+ *     _primitives/kalman/base.py:40-49), dx = state dim, dy = observation dim.  Every array is described by
+ *     an auxssm_arr {ptr, chain stride, time stride, batch stride} in ELEMENTS; the trailing matrix/vector
+ *     axes are dense row-major.  A stride of 0 broadcasts (e.g. model parameters shared by all chains, or
+ *     time-invariant F).  The natural dense layout is (C, T, B, ...).
+ *   - dtype: AUXSSM_F32 or AUXSSM_F64 for every real array of a call; ancestors are int32.
+ */
+#ifndef AUXSSM_H
+#define AUXSSM_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AUXSSM_VERSION 100
+
+typedef struct auxssm_ctx* auxssm_handle;
+
+typedef enum { AUXSSM_F32 = 0, AUXSSM_F64 = 1 } auxssm_dtype;
+
+typedef enum {
+    AUXSSM_OK = 0,
+    AUXSSM_ERR_ARG = -1,      /* bad argument / shape (Python glue raises ValueError) */
+    AUXSSM_ERR_UNSUPPORTED = -2, /* (dx, dy) not instantiated in this build */
+    AUXSSM_ERR_HIP = -3,      /* HIP runtime error */
+    AUXSSM_ERR_NOMEM = -4
+} auxssm_status;
+
+/* nansum policy of log_likelihood (reference base.py:137-166): REFERENCE drops a whole time step whose
+ * residual has any non-finite component (what jnp.nansum over per-step logpdfs does); MASKED scores the
+ * finite components of a partially observed step. */
+typedef enum { AUXSSM_NAN_REFERENCE = 0, AUXSSM_NAN_MASKED = 1 } auxssm_nan_policy;
+
+typedef struct {
+    const void* ptr;
+    int64_t sc; /* chain stride  (elements) */
+    int64_t st; /* time stride   (elements) */
+    int64_t sb; /* batch stride  (elements) */
+} auxssm_arr;
+
+/* LGSSM parameter bundle == reference `LGSSM` NamedTuple (_primitives/kalman/base.py:12-69).
+ * m0 (dx) P0 (dx,dx) [no time axis: st ignored]; Fs,Qs (T-1,dx,dx) bs (T-1,dx); Hs (T,dy,dx) Rs (T,dy,dy) cs (T,dy). */
+typedef struct {
+    auxssm_arr m0, P0, Fs, Qs, bs, Hs, Rs, cs;
+} auxssm_lgssm;
+
+typedef struct {
+    int32_t C, T, B, dx, dy;
+} auxssm_dims;
+
+/* ---- lifecycle ------------------------------------------------------------------------------- */
+int auxssm_version(void);
+const char* auxssm_last_error(void);
+int auxssm_device_count(int* count);
+int auxssm_create(int device, auxssm_handle* out);
+int auxssm_destroy(auxssm_handle h);
+int auxssm_sync(auxssm_handle h);
+/* the hipStream_t the handle launches on (as an opaque pointer) */
+int auxssm_stream(auxssm_handle h, void** stream);
+
+/* ---- device memory owned by the caller --------------------------------------------------------- */
+int auxssm_malloc(auxssm_handle h, size_t bytes, void** dptr);
+int auxssm_free(auxssm_handle h, void* dptr);
+int auxssm_memcpy_h2d(auxssm_handle h, void* dst, const void* src, size_t bytes); /* synchronous */
+int auxssm_memcpy_d2h(auxssm_handle h, void* dst, const void* src, size_t bytes); /* synchronous */
+int auxssm_memcpy_d2d(auxssm_handle h, void* dst, const void* src, size_t bytes); /* async on stream */
+int auxssm_memset(auxssm_handle h, void* dst, int value, size_t bytes);           /* async on stream */
+
+/* ---- in-library kernel timing with HIP events on the handle's stream ----------------------------
+ * kernel_id: one of AUXSSM_K_*.  While enabled, every launch of that kernel is bracketed by a pair of
+ * events from a pool of `max_launches`; read() synchronises and returns the count and the summed ms. */
+typedef enum {
+    AUXSSM_K_NONE = 0,
+    AUXSSM_K_FILTER_INIT = 1,
+    AUXSSM_K_FILTER_SCAN = 2, /* the three launches of the filter's associative scan, timed as one unit */
+    AUXSSM_K_FILTER_ELL = 3,
+    AUXSSM_K_SAMPLE_INIT = 4,
+    AUXSSM_K_SAMPLE_SCAN = 5,
+    AUXSSM_K_LOGPDF = 6,
+    AUXSSM_K_CSMC_FWD = 7,
+    AUXSSM_K_CSMC_BWD = 8
+} auxssm_kernel_id;
+int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches);
+int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms);
+int auxssm_prof_disable(auxssm_handle h);
+
+/* ---- Kalman primitives --------------------------------------------------------------------------
+ * auxssm_kalman_filter  == filtering(ys, lgssm, parallel)        (_primitives/kalman/filtering.py:18-46)
+ *   ys (C,T,B,dy) -> ms (C,T,B,dx), Ps (C,T,B,dx,dx) dense outputs, ell (C) [summed over B, :43-45].
+ *   parallel != 0: associative scan over T (filtering.py:49-63); 0: the same kernels run the scan with one
+ *   chunk per sequence, i.e. the sequential recursion (filtering.py:66-79).  NaN observations = missing.
+ */
+int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
+                         const auxssm_arr* ys, int parallel, void* ms, void* Ps, void* ell);
+
+/* auxssm_kalman_sample  == sampling(key, ms, Ps, lgssm, parallel) (_primitives/kalman/sampling.py:11-40)
+ *   with the N(0,I) draws given explicitly: eps (C,T,B,dx) dense == jax.random.normal(key, ms.shape) (:128).
+ *   ms, Ps dense as produced by auxssm_kalman_filter.  -> xs (C,T,B,dx) dense. */
+int auxssm_kalman_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
+                         const void* ms, const void* Ps, const void* eps, int parallel, void* xs);
+
+/* auxssm_kalman_joint_logpdf == log_likelihood(ys, xs, lgssm) + prior_logpdf(xs, lgssm)
+ *   (_primitives/kalman/base.py:99-166); posterior_logpdf (:72-96) is this minus ell.
+ *   xs (C,T,B,dx) described by an auxssm_arr; out (C). */
+int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
+                               const auxssm_arr* ys, const auxssm_arr* xs, int nan_policy, void* out);
+
+/* ---- one auxiliary-Kalman MH sweep, fully on device ------------------------------------------------
+ * == kernel(key, state, delta) of aux_samplers.kalman.get_kernel (kalman/generic.py:53-76) for models whose
+ * factories are the built-in device factory below, for C chains at once.
+ *
+ * Device factory AUXSSM_KMODEL_LG_CONCAT (linear-Gaussian model, auxiliary observations concatenated with
+ * the real ones, the pattern of examples/lorenz/auxiliary_kalman.py:26-35):
+ *   dynamics_factory(x)          -> (m0, P0, Fs, Qs, bs)  = `model` dynamics, independent of x
+ *   observations_factory(x,u,d)  -> ys = [u_t ; y_t], Hs = [I ; Hobs_t], Rs = blkdiag(d/2 I, Robs_t), cs = [0 ; cobs_t]
+ *   log_likelihood_fn(x)         -> prior_logpdf(x) + sum_t log N(y_t; Hobs_t x_t + cobs_t, Robs_t)
+ * `model` holds the dynamics and the REAL observation model (dy = dims->dy = p_obs); yobs (T, p_obs).
+ *
+ * Noise is explicit (the parity contract): eps_aux, eps_samp (C,T,dx) ~ N(0,I), u_acc (C) ~ U[0,1).
+ * x (C,T,dx) is updated in place; accepted (C) int32; logs (C,5) = log_alpha, lp_prop, lp_rev, lt_prop, lt_rev
+ * (may be NULL).  B must be 1.
+ */
+typedef enum { AUXSSM_KMODEL_LG_CONCAT = 1 } auxssm_kalman_model;
+int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims,
+                        const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, int parallel,
+                        int nan_policy, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
+                        int32_t* accepted, void* logs);
+
+/* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
+ * out[i], i < n, is a pure function of (key0, key1, stream, i): see oracle/rng_np.py for the restatement. */
+int auxssm_rng_normal(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);
+int auxssm_rng_uniform(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AUXSSM_H */

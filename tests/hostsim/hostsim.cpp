@@ -1,0 +1,165 @@
+// hostsim.cpp -- TEST INFRASTRUCTURE ONLY.  Compiles the product's per-lane kernel bodies
+// (aux_ssm_samplers_amd/csrc/kalman_bodies.h, AX_HD) for the host and runs them in plain loops, with the
+// same chunked three-pass scan structure as kernels.hip.h (chunk reduce -> aggregate scan -> cheap re-walk),
+// so that the math and the indexing of the HIP path can be checked against the oracle in the build container,
+// which has no GPU.  It is never loaded by the product package: the product fails loudly without libauxssm.so.
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../aux_ssm_samplers_amd/csrc/kalman_bodies.h"
+
+using namespace ax;
+
+struct HsArr { const void* ptr; long long sc, st, sb; };
+static Arr cv(const HsArr& a) { return Arr{a.ptr, a.sc, a.st, a.sb}; }
+
+template <class Op> static void scan_host(typename Op::Args& a, int S, int n, int E) {
+    using Full = typename Op::Full;
+    using Pre = typename Op::Pre;
+    if (n <= 0) return;
+    if (E <= 0 || E > n) E = n;
+    const int nchunk = (n + E - 1) / E;
+    std::vector<Full> agg((size_t)S * nchunk);
+    std::vector<Pre> pre((size_t)S * nchunk);
+    for (int s = 0; s < S; ++s)
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int i0 = ch * E, i1 = std::min(n, i0 + E);
+            Full acc;
+            Op::load(a, s, i0, acc);
+            for (int i = i0 + 1; i < i1; ++i) {
+                Full e, o;
+                Op::load(a, s, i, e);
+                Op::combine(acc, e, o);
+                acc = o;
+            }
+            agg[(size_t)s * nchunk + ch] = acc;
+        }
+    for (int s = 0; s < S; ++s) {
+        Full ex;
+        Op::identity(ex);
+        for (int ch = 0; ch < nchunk; ++ch) {
+            Op::to_pre(ex, pre[(size_t)s * nchunk + ch]);
+            Full o;
+            Op::combine(ex, agg[(size_t)s * nchunk + ch], o);
+            ex = o;
+        }
+    }
+    for (int s = 0; s < S; ++s)
+        for (int ch = 0; ch < nchunk; ++ch) {
+            const int i0 = ch * E, i1 = std::min(n, i0 + E);
+            Pre p = pre[(size_t)s * nchunk + ch];
+            for (int i = i0; i < i1; ++i) {
+                Full e;
+                Pre o;
+                Op::load(a, s, i, e);
+                Op::apply(p, e, o);
+                p = o;
+                Op::write_out(a, s, i, p);
+            }
+        }
+}
+
+template <typename R, int D, int P>
+static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell) {
+    FilterArgs a;
+    a.d = KDims{C, T, B};
+    a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
+    a.Hs = cv(g[5]); a.Rs = cv(g[6]); a.cs = cv(g[7]); a.ys = cv(*ys);
+    a.ms = ms; a.Ps = Ps;
+    const int S = C * B, n = T - 1;
+    std::vector<R> elem((size_t)S * std::max(n, 1) * FiltElem<R, D>::NPAD), ell0(S);
+    a.elem = elem.data();
+    a.ell0 = ell0.data();
+    for (int s = 0; s < S; ++s) body_filter_t0<R, D, P>(a, s);
+    for (int s = 0; s < S; ++s)
+        for (int i = 0; i < n; ++i) body_filter_init<R, D, P>(a, s, i);
+    scan_host<FilterOp<R, D>>(a, S, n, E);
+    for (int c = 0; c < C; ++c) {
+        R tot = 0;
+        for (int b = 0; b < B; ++b) {
+            const int s = c * B + b;
+            R e = ell0[s];
+            for (int i = 0; i < n; ++i) e += body_filter_ell<R, D, P>(a, s, i);
+            tot += e;
+        }
+        ((R*)ell)[c] = tot;
+    }
+    return 0;
+}
+
+template <typename R, int D>
+static int sample_T(int C, int T, int B, const HsArr* g, const void* ms, const void* Ps, const void* eps, int E, void* xs) {
+    SampleArgs a;
+    a.d = KDims{C, T, B};
+    a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
+    a.ms = ms; a.Ps = Ps; a.eps = eps; a.xs = xs;
+    const int S = C * B;
+    std::vector<R> elem((size_t)S * T * SampElem<R, D>::NPAD);
+    a.elem = elem.data();
+    for (int s = 0; s < S; ++s)
+        for (int j = 0; j < T; ++j) body_sample_init<R, D>(a, s, j);
+    scan_host<SampleOp<R, D>>(a, S, T, E);
+    return 0;
+}
+
+template <typename R, int D, int P>
+static int logpdf_T(int C, int T, int B, const HsArr* g, const HsArr* ys, const HsArr* xs, int pol, void* out) {
+    LogpdfArgs a;
+    a.d = KDims{C, T, B};
+    a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
+    a.Hs = cv(g[5]); a.Rs = cv(g[6]); a.cs = cv(g[7]); a.ys = cv(*ys); a.xs = cv(*xs);
+    a.nan_policy = pol;
+    for (int c = 0; c < C; ++c) {
+        R tot = 0;
+        for (int b = 0; b < B; ++b)
+            for (int t = 0; t < T; ++t) tot += body_joint_logpdf<R, D, P>(a, c * B + b, t);
+        ((R*)out)[c] = tot;
+    }
+    return 0;
+}
+
+#define HS_P_SWITCH(CALL, R, D)                                           \
+    switch (P) {                                                          \
+        case 1: return CALL(R, D, 1); case 2: return CALL(R, D, 2);       \
+        case 3: return CALL(R, D, 3); case 4: return CALL(R, D, 4);       \
+        case 5: return CALL(R, D, 5); case 6: return CALL(R, D, 6);       \
+        case 7: return CALL(R, D, 7); case 8: return CALL(R, D, 8);       \
+        default: return -2;                                               \
+    }
+#define HS_D_SWITCH(CALL, R)                                              \
+    switch (D) {                                                          \
+        case 1: HS_P_SWITCH(CALL, R, 1) case 2: HS_P_SWITCH(CALL, R, 2)   \
+        case 3: HS_P_SWITCH(CALL, R, 3) case 4: HS_P_SWITCH(CALL, R, 4)   \
+        default: return -2;                                               \
+    }
+
+extern "C" {
+
+int hs_filter(int dtype, int D, int P, int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell) {
+#define CALL(R, D, P) filter_T<R, D, P>(C, T, B, g, ys, E, ms, Ps, ell)
+    if (dtype == 0) { HS_D_SWITCH(CALL, float) } else { HS_D_SWITCH(CALL, double) }
+#undef CALL
+}
+
+int hs_sample(int dtype, int D, int C, int T, int B, const HsArr* g, const void* ms, const void* Ps, const void* eps, int E, void* xs) {
+#define CALLS(R)                                                                        \
+    switch (D) {                                                                        \
+        case 1: return sample_T<R, 1>(C, T, B, g, ms, Ps, eps, E, xs);                  \
+        case 2: return sample_T<R, 2>(C, T, B, g, ms, Ps, eps, E, xs);                  \
+        case 3: return sample_T<R, 3>(C, T, B, g, ms, Ps, eps, E, xs);                  \
+        case 4: return sample_T<R, 4>(C, T, B, g, ms, Ps, eps, E, xs);                  \
+        default: return -2;                                                             \
+    }
+    if (dtype == 0) { CALLS(float) } else { CALLS(double) }
+#undef CALLS
+}
+
+int hs_logpdf(int dtype, int D, int P, int C, int T, int B, const HsArr* g, const HsArr* ys, const HsArr* xs, int pol, void* out) {
+#define CALL(R, D, P) logpdf_T<R, D, P>(C, T, B, g, ys, xs, pol, out)
+    if (dtype == 0) { HS_D_SWITCH(CALL, float) } else { HS_D_SWITCH(CALL, double) }
+#undef CALL
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+"""CPU check of the HIP path's per-lane math: the product's kernel bodies (csrc/kalman_bodies.h) compiled for the
+host (tests/hostsim) vs the NumPy oracle, on the reference's own seeded test inputs and on chain-batched /
+broadcast layouts.  The same comparisons run against the real HIP library in tests/test_gpu_kalman.py."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import kalman_np as K
+from tests import hostsim as H
+from tests.helpers import ref_lgssm_inputs, ref_batched_inputs, lg_model
+
+TOL64 = dict(rtol=1e-8, atol=1e-10)
+
+
+@pytest.mark.parametrize("seed", [0, 1234])
+@pytest.mark.parametrize("T", [5, 7])
+@pytest.mark.parametrize("dx", [1, 2])
+@pytest.mark.parametrize("dy", [1, 3])
+@pytest.mark.parametrize("E", [0, 2])  # 0 = sequential (one chunk), 2 = chunked scan
+@pytest.mark.parametrize("nan_index", [True, False])
+def test_filter_vs_oracle(seed, T, dx, dy, E, nan_index):
+    ys, lg = ref_lgssm_inputs(seed, T, dx, dy, nan_index)
+    ms, Ps, ell = H.filtering(ys, lg, E)
+    oms, oPs, oell = K.filtering(ys, lg, E != 0)
+    npt.assert_allclose(ms, oms, **TOL64)
+    npt.assert_allclose(Ps, oPs, **TOL64)
+    npt.assert_allclose(ell, oell, **TOL64)
+
+
+@pytest.mark.parametrize("seed", [0, 1234])
+@pytest.mark.parametrize("dx,dy", [(1, 1), (2, 3), (1, 3), (2, 1)])
+@pytest.mark.parametrize("E", [0, 2])
+def test_filter_batched(seed, dx, dy, E):
+    T, B = 5, 3
+    (bys, blg), (ys, lg) = ref_batched_inputs(seed, T, dx, dy, B)
+    bms, bPs, bell = H.filtering(bys, blg, E)
+    oms, oPs, oell = K.filtering(bys, blg, True)
+    npt.assert_allclose(bms, oms, **TOL64)
+    npt.assert_allclose(bPs, oPs, **TOL64)
+    npt.assert_allclose(bell, oell, **TOL64)
+
+
+@pytest.mark.parametrize("seed", [42, 666])
+@pytest.mark.parametrize("T", [3, 5, 17])
+@pytest.mark.parametrize("dx", [1, 2])
+@pytest.mark.parametrize("E", [0, 3])
+def test_sampler_vs_oracle(seed, T, dx, E):
+    ys, lg = ref_lgssm_inputs(seed, T, dx, 3)
+    ms, Ps, _ = K.filtering(ys, lg, False)
+    eps = np.random.default_rng(seed).standard_normal((T, dx))
+    xs = H.sampling(eps, ms, Ps, lg, E)
+    npt.assert_allclose(xs, K.sampling(eps, ms, Ps, lg, True), **TOL64)
+
+
+@pytest.mark.parametrize("seed", [42, 666])
+def test_sampler_batched_equals_block_diag(seed):
+    T, dx, dy, B = 5, 2, 3, 3
+    (bys, blg), (ys, lg) = ref_batched_inputs(seed, T, dx, dy, B)
+    bms, bPs, _ = K.filtering(bys, blg, False)
+    eps = np.random.default_rng(seed).standard_normal((T, B, dx))
+    xs = H.sampling(eps, bms, bPs, blg, 2)
+    npt.assert_allclose(xs, K.sampling(eps, bms, bPs, blg, False), atol=1e-10, rtol=1e-10)
+
+
+@pytest.mark.parametrize("nan_index", [True, False])
+@pytest.mark.parametrize("dx,dy", [(1, 1), (2, 3), (1, 3), (2, 1)])
+def test_joint_logpdf(nan_index, dx, dy):
+    T = 7
+    ys, lg = ref_lgssm_inputs(5, T, dx, dy, nan_index)
+    xs = np.random.default_rng(0).standard_normal((T, dx))
+    want = K.log_likelihood(ys, xs, lg) + K.prior_logpdf(xs, lg)
+    npt.assert_allclose(H.joint_logpdf(ys, xs, lg), want, **TOL64)
+
+
+@pytest.mark.parametrize("d", [1, 2, 4])
+@pytest.mark.parametrize("dtype,tol", [(np.float64, TOL64), (np.float32, dict(rtol=2e-3, atol=2e-3))])
+def test_chain_batched_broadcast_layout(d, dtype, tol):
+    """C chains share time-invariant (stride-0) model parameters; only ys varies per chain."""
+    T, C = 40, 3
+    m = lg_model(T, d)
+    delta = 0.5
+    P = 2 * d
+    rng = np.random.default_rng(3)
+    u = rng.standard_normal((C, T, d))
+    ys = np.concatenate([u, np.broadcast_to(m["y"], (C, T, d))], axis=-1)
+    H_ = np.concatenate([np.eye(d), m["Hobs"]])
+    R_ = np.zeros((P, P))
+    R_[:d, :d] = 0.5 * delta * np.eye(d)
+    R_[d:, d:] = m["Robs"]
+    bt = np.broadcast_to
+    lg = (m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
+          bt(H_, (T, P, d)), bt(R_, (T, P, P)), bt(np.zeros(P), (T, P)))
+    ms, Ps, ell = H.filtering(ys, lg, 4, dtype=dtype, chains=True, chain_axis=False)
+    eps = rng.standard_normal((C, T, d))
+    xs = H.sampling(eps, ms, Ps, lg, 4, dtype=dtype, chains=True)
+    for c in range(C):
+        oms, oPs, oell = K.filtering(ys[c], lg, True)
+        npt.assert_allclose(ms[c], oms, **tol)
+        npt.assert_allclose(Ps[c], oPs, **tol)
+        npt.assert_allclose(ell[c], oell, rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
+        npt.assert_allclose(xs[c], K.sampling(eps[c], oms, oPs, lg, True), rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
