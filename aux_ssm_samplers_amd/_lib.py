@@ -31,6 +31,22 @@ class Lgssm(C.Structure):
     _fields_ = [(n, Arr) for n in ("m0", "P0", "Fs", "Qs", "bs", "Hs", "Rs", "cs")]
 
 
+class FkModel(C.Structure):
+    _fields_ = [("proposal", C.c_int32), ("potential", C.c_int32), ("dx", C.c_int32), ("reserved", C.c_int32),
+                ("m0", C.c_void_p), ("chol_P0", C.c_void_p), ("F", C.c_void_p), ("b", C.c_void_p), ("chol_Q", C.c_void_p),
+                ("y", C.c_void_p), ("sig_y", C.c_double)]
+
+
+class CsmcNoise(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("key0", C.c_uint32), ("key1", C.c_uint32), ("reserved", C.c_int32),
+                ("eps_aux", C.c_void_p), ("eps_prop", C.c_void_p), ("u_res", C.c_void_p), ("u_bwd", C.c_void_p)]
+
+
+PROP_BOOTSTRAP_LG, PROP_AUX_INDEPENDENT = 0, 1
+POT_FLAT, POT_GAUSS_OBS, POT_SV = 0, 1, 2
+NOISE_EXPLICIT, NOISE_THREEFRY = 0, 1
+
+
 class Dims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("C", "T", "B", "dx", "dy")]
 
@@ -70,6 +86,7 @@ def load():
         "auxssm_kalman_sample": ([vp, i32, P(Dims), P(Lgssm), vp, vp, vp, i32, vp], C.c_int),
         "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
     }

@@ -1,0 +1,141 @@
+"""Host driver of auxssm_csmc_sweep: model description, noise, buffers."""
+import ctypes as C
+
+import numpy as np
+
+from .. import _lib, random as _random
+from .models import GaussianInit, LinearGaussianDynamics, FlatPotential, GaussianObsPotential, SVPotential
+
+_UNSUPPORTED = ("{what} is a Python object the HIP kernels cannot evaluate. The cSMC kernels run the closed model family "
+                "of aux_ssm_samplers_amd.csmc.models (GaussianInit, LinearGaussianDynamics, FlatPotential, "
+                "GaussianObsPotential, SVPotential) in-kernel; there is no CPU fallback.")
+
+
+class FkDesc:
+    def __init__(self, proposal, potential, m0, chol_P0, F, b, chol_Q, y, sig_y):
+        self.proposal, self.potential, self.sig_y = proposal, potential, float(sig_y)
+        self.m0 = np.ascontiguousarray(m0, np.float64).reshape(-1)
+        self.dx = self.m0.shape[0]
+        d = self.dx
+        self.chol_P0 = np.ascontiguousarray(chol_P0, np.float64).reshape(d, d)
+        self.F = np.ascontiguousarray(F, np.float64).reshape(d, d)
+        self.b = np.ascontiguousarray(b, np.float64).reshape(d)
+        self.chol_Q = np.ascontiguousarray(chol_Q, np.float64).reshape(d, d)
+        self.y = None if y is None else np.asarray(y)
+        self._ydev = {}
+
+    def ydev(self, handle, dtype):
+        if self.y is None:
+            return None
+        key = (id(handle), np.dtype(dtype).str)
+        if key not in self._ydev:
+            self._ydev[key] = handle.to_device(self.y, dtype)
+        return self._ydev[key]
+
+
+def _potential(G0, Gt, d):
+    if type(G0) is not type(Gt) and not (isinstance(G0, GaussianInit) and isinstance(Gt, GaussianObsPotential)):
+        raise NotImplementedError(_UNSUPPORTED.format(what=f"G0={type(G0).__name__} with Gt={type(Gt).__name__}"))
+    if isinstance(Gt, FlatPotential):
+        return _lib.POT_FLAT, None, 1.0
+    if isinstance(Gt, (GaussianObsPotential, SVPotential)):
+        y0 = G0.m0 if isinstance(G0, GaussianInit) else G0.y
+        if y0 is None or Gt.params is None:
+            raise ValueError("the potential needs y (G0.y = ys[0]) and params (Gt.params = ys[1:])")
+        y = np.concatenate([np.reshape(y0, (1, d)), np.reshape(Gt.params, (-1, d))], axis=0)
+        if isinstance(Gt, SVPotential):
+            return _lib.POT_SV, y, 1.0
+        sig = Gt.sig
+        if isinstance(G0, GaussianInit):
+            s0 = float(np.sqrt(np.reshape(G0.P0, -1)[0]))
+            if abs(s0 - sig) > 1e-12 * sig:
+                raise NotImplementedError("G0 and Gt must share the observation noise scale")
+        return _lib.POT_GAUSS_OBS, y, sig
+    raise NotImplementedError(_UNSUPPORTED.format(what=f"Gt={type(Gt).__name__}"))
+
+
+def _dyn(M0, Mt):
+    if not isinstance(M0, GaussianInit):
+        raise NotImplementedError(_UNSUPPORTED.format(what=f"M0={type(M0).__name__}"))
+    if not isinstance(Mt, LinearGaussianDynamics):
+        raise NotImplementedError(_UNSUPPORTED.format(what=f"Mt={type(Mt).__name__}"))
+    return M0, Mt
+
+
+def describe_bootstrap(M0, G0, Mt, Gt, Pt):
+    """_primitives.csmc.get_kernel: M0/Mt are the proposals, G0/Gt the potentials."""
+    M0, Mt = _dyn(M0, Mt)
+    if Pt is not None and Pt is not Mt and not (isinstance(Pt, LinearGaussianDynamics) and np.array_equal(Pt.F, Mt.F)
+                                                   and np.array_equal(Pt.Q, Mt.Q) and np.array_equal(Pt.b, Mt.b)):
+        raise NotImplementedError("backward sampling with Pt != Mt is not supported by the bootstrap device kernel")
+    d = np.size(M0.m0)
+    pot, y, sig = _potential(G0, Gt, d)
+    return FkDesc(_lib.PROP_BOOTSTRAP_LG, pot, M0.m0, M0.chol(), Mt.F, Mt.b, Mt.chol(), y, sig)
+
+
+def describe_independent(M0, G0, Mt, Gt, Pt):
+    """csmc.get_independent_kernel (classical): proposals N(u_t, delta_t/2 I); M0/Mt enter the weights."""
+    M0, Mt = _dyn(M0, Mt)
+    if Pt is not None and Pt is not Mt:
+        raise NotImplementedError("Pt must be the model dynamics Mt")
+    d = np.size(M0.m0)
+    pot, y, sig = _potential(G0, Gt, d)
+    return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), Mt.F, Mt.b, Mt.chol(), y, sig)
+
+
+def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, want_history=False):
+    """x: (T, d) one chain or (C, T, d).  noise: dict of explicit arrays (eps_prop, u_res, u_bwd[, eps_aux]) or None -> Threefry(key).
+    Returns (x_new, ancestors, history dict or None)."""
+    handle = handle or _lib.default_handle()
+    x = np.asarray(x)
+    single = x.ndim == 2
+    xc = x[None] if single else x
+    Cn, T, d = xc.shape
+    if d != fk.dx:
+        raise ValueError(f"state dimension {d} != model dimension {fk.dx}")
+    dtype = np.dtype(np.float32) if xc.dtype == np.float32 else np.dtype(np.float64)
+    xd = handle.to_device(xc, dtype)
+    anc = handle.zeros((Cn, T), np.int32)
+    m = _lib.FkModel(fk.proposal, fk.potential, d, 0, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
+                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
+    yd = fk.ydev(handle, dtype)
+    if yd is not None:
+        if yd.shape[0] != T:
+            raise ValueError(f"observations have {yd.shape[0]} time steps, state has {T}")
+        m.y = yd.ptr.value
+    shd = None
+    if fk.proposal == _lib.PROP_AUX_INDEPENDENT:
+        if delta is None:
+            raise ValueError("delta is required")
+        shd_h = np.sqrt(0.5 * np.asarray(delta, np.float64)) * np.ones(T)  # csmc/generic.py:61-63
+        shd = handle.to_device(shd_h, dtype)
+    keep = []
+    nz = _lib.CsmcNoise()
+    if noise is None:
+        k = _random.as_key(key)
+        nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(k[0]), int(k[1])
+    else:
+        nz.mode = _lib.NOISE_EXPLICIT
+        shapes = dict(eps_prop=(Cn, T, N, d), u_res=(Cn, max(T - 1, 0), N), u_bwd=(Cn, T), eps_aux=(Cn, T, d))
+        for name, shp in shapes.items():
+            a = noise.get(name)
+            if a is None:
+                continue
+            buf = handle.to_device(np.asarray(a, dtype).reshape(shp))
+            keep.append(buf)
+            setattr(nz, name, buf.ptr.value)
+    hist = None
+    xs = lws = As = None
+    if want_history:
+        xs = handle.empty((Cn, T, N, d), dtype)
+        lws = handle.empty((Cn, T, N), dtype)
+        As = handle.zeros((Cn, max(T - 1, 1), N), np.int32)
+    _lib.check(handle.lib.auxssm_csmc_sweep(
+        handle.h, _lib.dtype_code(dtype), C.byref(m), Cn, T, N, int(bool(backward)), shd.ptr if shd is not None else None,
+        xd.ptr, C.byref(nz), anc.ptr, xs.ptr if xs else None, lws.ptr if lws else None, As.ptr if As else None))
+    xo, ao = xd.to_host(), anc.to_host()
+    if want_history:
+        hist = dict(xs=xs.to_host(), log_ws=lws.to_host(), As=As.to_host()[:, :T - 1])
+        if single:
+            hist = {k_: v[0] for k_, v in hist.items()}
+    return (xo[0], ao[0], hist) if single else (xo, ao, hist)

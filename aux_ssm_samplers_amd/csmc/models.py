@@ -1,0 +1,56 @@
+"""The closed Feynman-Kac model family the HIP cSMC kernels evaluate in-kernel (include/auxssm.h, auxssm_fk_model).
+
+They subclass the reference's protocol classes so they can be passed wherever the reference takes
+(M0, G0, Mt, Gt, Pt); the kernels read their parameters, they never call Python methods on the hot path."""
+from dataclasses import dataclass, field
+from typing import Any, Optional
+
+import numpy as np
+
+from .._primitives.csmc.base import Distribution, UnivariatePotential, Dynamics, Potential
+
+
+@dataclass
+class GaussianInit(Distribution, UnivariatePotential):
+    """M0 = N(m0, P0) (e.g. test_csmc/common.py:34-49; examples/stochastic_volatility/auxiliary_csmc.py:21-27).
+    Used as a potential it is log N(x; m0, P0)."""
+    m0: Any
+    P0: Any
+
+    def chol(self):
+        return np.linalg.cholesky(np.atleast_2d(np.asarray(self.P0, np.float64)))
+
+
+@dataclass
+class LinearGaussianDynamics(Dynamics, Potential):
+    """x_{t+1} | x_t ~ N(F x_t + b, Q), time-invariant (test_csmc/common.py:11-31; SV auxiliary_csmc.py:29-37)."""
+    F: Any
+    b: Any
+    Q: Any
+    params: Optional[Any] = None
+
+    def chol(self):
+        return np.linalg.cholesky(np.atleast_2d(np.asarray(self.Q, np.float64)))
+
+
+@dataclass
+class FlatPotential(UnivariatePotential, Potential):
+    """G = 0 (test_csmc/common.py:61-75)."""
+    params: Optional[Any] = None
+
+
+@dataclass
+class GaussianObsPotential(UnivariatePotential, Potential):
+    """log N(y_t; x_t, sig^2 I).  As G0 give y=(d,) [the reference uses GaussianDistribution(mu=y0, sig) there,
+    test_csmc.py:88]; as Gt give params = ys[1:] (test_csmc/common.py:52-58)."""
+    sig: float = 1.0
+    y: Optional[Any] = None
+    params: Optional[Any] = None
+
+
+@dataclass
+class SVPotential(UnivariatePotential, Potential):
+    """sum_k log N(y_{t,k}; 0, exp(x_{t,k})) (examples/stochastic_volatility/auxiliary_csmc.py:39-46).
+    As G0 give y = ys[0]; as Gt give params = ys[1:]."""
+    y: Optional[Any] = None
+    params: Optional[Any] = None

@@ -1,0 +1,570 @@
+// csmc.hip -- conditional SMC (particle Gibbs) sweep: reference aux_samplers/_primitives/csmc/csmc.py,
+// resamplings.py::multinomial, math/utils.py::normalize, and the auxiliary wrappers csmc/generic.py and
+// csmc/independent.py (classical, non-gradient branch).  Compiled with -ffp-contract=off; every multiply-add that
+// is meant to be fused is an explicit fma so that the CPU oracle reproduces the arithmetic bit for bit.
+//
+// Execution model: ONE workgroup per chain, one lane per particle (N <= 1024), a persistent loop over the T
+// time steps (the recursion is sequential in t; throughput comes from running >= 256 chains side by side).
+// Per step: block inclusive scan of the normalised weights (wave-level Kogge-Stone with shuffles + ordered wave
+// totals through LDS) -> N binary searches in LDS (conditional multinomial resampling, index 0 pinned) -> gather
+// parents from LDS -> propagate -> pin particle 0 to the reference trajectory -> log-weights -> block max / sum
+// -> normalise.  xs, log_ws, As stream to HBM with the particle index fastest (coalesced).
+//
+// Reduction orders (the contract the oracle restates, SURVEY 7 "bit-exact ancestors"):
+//   cumsum : inside each group of 64 consecutive particles a Kogge-Stone scan (offsets 1,2,..,32); group totals are
+//            added left to right; c_i = (t_0 + t_1 + ... + t_{g-1}) + local_i.
+//   sum    : balanced binary tree inside each group of 64 (== last element of that Kogge-Stone scan), then left to
+//            right over groups.   max : exact.
+#include "ctx.h"
+#include "det_math.h"
+#include "rng.h"
+
+namespace ax {
+
+constexpr int CS_MAXD = 4;
+
+template <typename R> struct FkDev {
+    int proposal, potential, D, pad;
+    R m0[CS_MAXD], LP0[CS_MAXD * CS_MAXD], F[CS_MAXD * CS_MAXD], b[CS_MAXD], LQ[CS_MAXD * CS_MAXD];
+    R c_init, c_trans, c_obs, inv_sig_y;  // additive constants: -sum log L_kk - D/2 log 2pi, etc.
+};
+
+struct CsmcArgs {
+    int C, T, N, backward;
+    const void* y;       // (T, D) shared by chains (may be null for the flat potential)
+    const void* shd;     // (T) sqrt(delta_t / 2), AUX proposal only
+    void* x;             // (C, T, D) reference trajectory in, new trajectory out
+    void* u;             // (C, T, D) auxiliary variables (workspace), AUX only
+    void* xs;            // (C, T, N, D)
+    void* lws;           // (C, T, N)
+    int32_t* As;         // (C, T-1, N) or null
+    void* wT;            // (C, N)
+    int32_t* anc;        // (C, T)
+    int noise_mode;      // 0 explicit arrays, 1 Threefry
+    uint32_t key0, key1;
+    const void* eps_aux;   // (C, T, D)
+    const void* eps_prop;  // (C, T, N, D)
+    const void* u_res;     // (C, T-1, N)
+    const void* u_bwd;     // (C, T)
+};
+
+enum { STREAM_EPS_AUX = 1, STREAM_EPS_PROP = 2, STREAM_U_RES = 3, STREAM_U_BWD = 4 };
+
+template <typename R> __device__ __forceinline__ R noise_normal(const CsmcArgs& a, const void* arr, uint32_t stream, long long idx) {
+    if (a.noise_mode == 0) return ((const R*)arr)[idx];
+    uint32_t x0 = (uint32_t)(idx & 0xffffffffll), x1 = stream ^ (uint32_t)((unsigned long long)idx >> 32 << 16);
+    threefry2x32(a.key0, a.key1, x0, x1);
+    return bits_to_normal<R>(x0, x1);
+}
+template <typename R> __device__ __forceinline__ R noise_uniform(const CsmcArgs& a, const void* arr, uint32_t stream, long long idx) {
+    if (a.noise_mode == 0) return ((const R*)arr)[idx];
+    uint32_t x0 = (uint32_t)(idx & 0xffffffffll), x1 = stream ^ (uint32_t)((unsigned long long)idx >> 32 << 16);
+    threefry2x32(a.key0, a.key1, x0, x1);
+    return bits_to_uniform<R>(x0);
+}
+
+AXD_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }
+AXD_HD double fma_(double a, double b, double c) { return fma(a, b, c); }
+
+// log N(x; mean, L L^T) = cst - 0.5 |L^-1 (x - mean)|^2, forward substitution in a fixed order
+template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mean, const R* L, R cst) {
+    R z[D];
+    R q = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        R acc = x[k] - mean[k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc = fma_(-L[k * CS_MAXD + j], z[j], acc);
+        z[k] = acc / L[k * CS_MAXD + k];
+        q = fma_(z[k], z[k], q);
+    }
+    return fma_((R)-0.5, q, cst);
+}
+template <typename R, int D> AXD_HD void trans_mean(const FkDev<R>& m, const R* xp, R* mu) {
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        R acc = m.b[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc = fma_(m.F[k * CS_MAXD + j], xp[j], acc);
+        mu[k] = acc;
+    }
+}
+// potential g_t(x_t) (csmc test fixtures test_csmc/common.py:52-75; SV examples/stochastic_volatility/auxiliary_csmc.py:40-46)
+template <typename R, int D> AXD_HD R potential(const FkDev<R>& m, const R* x, const R* y) {
+    if (m.potential == 0) return (R)0;
+    if (m.potential == 1) {  // y ~ N(x, sig_y^2 I)
+        R q = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const R z = (y[k] - x[k]) * m.inv_sig_y;
+            q = fma_(z, z, q);
+        }
+        return fma_((R)-0.5, q, m.c_obs);
+    }
+    // stochastic volatility: y_k ~ N(0, exp(x_k)):  -0.5 (y^2 e^{-x} + x) - 0.5 log 2pi, NaN terms -> 0
+    R acc = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R e = det_exp(-x[k]);
+        const R s = fma_(y[k] * y[k], e, x[k]);
+        const R v = fma_((R)-0.5, s, m.c_obs);
+        acc += (v == v) ? v : (R)0;
+    }
+    return acc;
+}
+
+// ---- block primitives (TB threads = NW waves) ---------------------------------------------------------------------
+template <typename R> __device__ __forceinline__ R wave_max(R v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const R o = __shfl_xor(v, off, 64);
+        v = v > o ? v : o;  // NaN-agnostic: weights are never NaN for valid models
+    }
+    return v;
+}
+template <typename R> __device__ __forceinline__ R wave_sum_tree(R v) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+template <typename R> __device__ __forceinline__ R wave_scan_ks(R v, int lane) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const R o = __shfl_up(v, off, 64);
+        if (lane >= off) v += o;
+    }
+    return v;
+}
+
+struct Smem {
+    // carved from dynamic LDS
+    char* base;
+};
+
+// normalize (math/utils.py:23-39): w = exp(lw - logsumexp(lw)); logsumexp = log(sum(exp(lw - max))) + max
+template <typename R> __device__ __forceinline__ R block_normalize(R lw, R* red, int tid, int nw) {
+    const int lane = tid & 63, wv = tid >> 6;
+    R m = wave_max(lw);
+    if (lane == 0) red[wv] = m;
+    __syncthreads();
+    m = red[0];
+    for (int k = 1; k < nw; ++k) m = m > red[k] ? m : red[k];
+    __syncthreads();
+    if (!(m - m == 0)) m = 0;  // non-finite max -> 0 (jax logsumexp)
+    const R e = det_exp(lw - m);
+    R s = wave_sum_tree(e);
+    if (lane == 0) red[wv] = s;
+    __syncthreads();
+    s = red[0];
+    for (int k = 1; k < nw; ++k) s += red[k];
+    __syncthreads();
+    const R lse = det_log(s) + m;
+    return det_exp(lw - lse);
+}
+
+// inclusive cumsum of w into c[]; returns nothing, c[] valid after the trailing barrier
+template <typename R> __device__ __forceinline__ void block_cumsum(R w, R* c, R* red, int tid, int nw) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const R v = wave_scan_ks(w, lane);
+    if (lane == 63) red[wv] = v;
+    __syncthreads();
+    R pre = 0;
+    if (wv > 0) {
+        pre = red[0];
+        for (int k = 1; k < wv; ++k) pre += red[k];
+    }
+    c[tid] = wv > 0 ? pre + v : v;
+    __syncthreads();
+}
+
+// first index j in [0, n) with c[j] >= r  (jnp.searchsorted side='left'); n if none
+template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int n, R r) {
+    int lo = 0, hi = n;
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (c[mid] < r) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ---- prologue: u = x + sqrt(delta_t/2) eps   (csmc/generic.py:67) ------------------------------------------------------
+template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long total = (long long)a.C * a.T * D;
+    if (g >= total) return;
+    const long long t = (g / D) % a.T;
+    const R e = noise_normal<R>(a, a.eps_aux, STREAM_EPS_AUX, g);
+    ((R*)a.u)[g] = fma_(((const R*)a.shd)[t], e, ((const R*)a.x)[g]);
+}
+
+// ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
+template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
+    R* c = (R*)smem;              // [TB]
+    R* xprev = c + TB;            // [TB][D]
+    R* red = xprev + TB * D;      // [16]
+    const int ch = blockIdx.x;
+    const bool live = tid < N;
+    const R* xstar = (const R*)a.x + (long long)ch * T * D;
+    const R* uaux = (const R*)a.u + (long long)ch * T * D;
+    const R* yv = (const R*)a.y;
+    R* xs = (R*)a.xs + (long long)ch * T * N * D;
+    R* lws = (R*)a.lws + (long long)ch * T * N;
+    int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
+    const long long eps_base = (long long)ch * T * N * D;
+    const long long ures_base = (long long)ch * (T - 1) * N;
+    const R ninf = -INFINITY;
+
+    // t = 0  (csmc.py:74-80)
+    R x[D], eps[D], ycur[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        eps[k] = live ? noise_normal<R>(a, a.eps_prop, STREAM_EPS_PROP, eps_base + (long long)tid * D + k) : (R)0;
+        ycur[k] = yv ? yv[k] : (R)0;
+    }
+    if (m.proposal == 0) {  // M0 = N(m0, P0)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            R acc = m.m0[k];
+#pragma unroll
+            for (int j = 0; j <= k; ++j) acc = fma_(m.LP0[k * CS_MAXD + j], eps[j], acc);
+            x[k] = acc;
+        }
+    } else {  // AuxiliaryM0: N(u_0, delta_0/2 I)  (independent.py:143-158)
+        const R s0 = ((const R*)a.shd)[0];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = fma_(s0, eps[k], uaux[k]);
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = xstar[k];
+    }
+    R lw;
+    {
+        R g = potential<R, D>(m, x, ycur);
+        if (m.proposal == 1) g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+        lw = live ? g : ninf;
+    }
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) xs[(long long)tid * D + k] = x[k];
+        lws[tid] = lw;
+    }
+    R w = block_normalize<R>(lw, red, tid, nw);
+
+    for (int t = 1; t < T; ++t) {
+        // issue this step's independent loads first
+        R un = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            eps[k] = live ? noise_normal<R>(a, a.eps_prop, STREAM_EPS_PROP, eps_base + ((long long)t * N + tid) * D + k) : (R)0;
+            ycur[k] = yv ? yv[(long long)t * D + k] : (R)0;
+        }
+        if (live) un = noise_uniform<R>(a, a.u_res, STREAM_U_RES, ures_base + (long long)(t - 1) * N + tid);
+        // conditional multinomial resampling (resamplings.py:14-37 -> jax.random.choice: cumsum, r = c[-1] (1-u), searchsorted)
+#pragma unroll
+        for (int k = 0; k < D; ++k) xprev[tid * D + k] = x[k];
+        block_cumsum<R>(w, c, red, tid, nw);  // trailing barrier also publishes xprev
+        const R tot = c[N - 1];
+        int idx = 0;
+        if (live && tid > 0) {
+            const R r = tot * ((R)1 - un);
+            idx = lower_bound<R>(c, N, r);
+            idx = idx < N - 1 ? idx : N - 1;
+        }
+        R xp[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
+        // propagate (csmc.py:91-92)
+        if (m.proposal == 0) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                R acc = m.b[k];
+#pragma unroll
+                for (int j = 0; j < D; ++j) acc = fma_(m.F[k * CS_MAXD + j], xp[j], acc);
+#pragma unroll
+                for (int j = 0; j <= k; ++j) acc = fma_(m.LQ[k * CS_MAXD + j], eps[j], acc);
+                x[k] = acc;
+            }
+        } else {  // AuxiliaryMtDynamics: N(u_t, delta_t/2 I), independent of the parent (independent.py:192-198)
+            const R st = ((const R*)a.shd)[t];
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = fma_(st, eps[k], uaux[(long long)t * D + k]);
+        }
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) x[k] = xstar[(long long)t * D + k];
+        }
+        // weights (csmc.py:95-96)
+        {
+            R g = potential<R, D>(m, x, ycur);
+            if (m.proposal == 1) {  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
+                R mu[D];
+                trans_mean<R, D>(m, xp, mu);
+                g = gauss_chol_logpdf<R, D>(x, mu, m.LQ, m.c_trans) + g;
+            }
+            lw = live ? g : ninf;
+        }
+        if (live) {
+            const long long o = (long long)t * N + tid;
+#pragma unroll
+            for (int k = 0; k < D; ++k) xs[o * D + k] = x[k];
+            lws[o] = lw;
+            if (As) As[(long long)(t - 1) * N + tid] = idx;
+        }
+        __syncthreads();  // everyone is done reading c / xprev
+        w = block_normalize<R>(lw, red, tid, nw);
+    }
+    if (live) ((R*)a.wT)[(long long)ch * N + tid] = w;
+}
+
+// ---- backward passes (csmc.py:110-149) ------------------------------------------------------------------------------------
+template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
+    R* c = (R*)smem;
+    R* red = c + TB;
+    int& sB = *(int*)(red + 16);
+    const int ch = blockIdx.x;
+    const bool live = tid < N;
+    const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
+    const R* lws = (const R*)a.lws + (long long)ch * T * N;
+    const int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
+    R* xout = (R*)a.x + (long long)ch * T * D;
+    int32_t* anc = a.anc + (long long)ch * T;
+    const long long ub_base = (long long)ch * T;
+    const R ninf = -INFINITY;
+
+    // B_T ~ choice(w_T)   (csmc.py:111 / :131)
+    R w = live ? ((const R*)a.wT)[(long long)ch * N + tid] : (R)0;
+    block_cumsum<R>(w, c, red, tid, nw);
+    if (tid == 0) {
+        const R un = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 1));
+        const R r = c[N - 1] * ((R)1 - un);
+        int B = lower_bound<R>(c, N, r);
+        sB = B < N - 1 ? B : N - 1;
+    }
+    __syncthreads();
+    int B = sB;
+    R xn[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) xn[k] = xs[((long long)(T - 1) * N + B) * D + k];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) xout[(long long)(T - 1) * D + k] = xn[k];
+        anc[T - 1] = B;
+    }
+    if (!a.backward) {
+        // ancestor tracing: B_{t-1} = A_t[B_t]  (csmc.py:114-121); a dependent pointer chase, one lane
+        if (tid == 0) {
+            for (int t = T - 1; t >= 1; --t) {
+                B = As[(long long)(t - 1) * N + B];
+#pragma unroll
+                for (int k = 0; k < D; ++k) xout[(long long)(t - 1) * D + k] = xs[((long long)(t - 1) * N + B) * D + k];
+                anc[t - 1] = B;
+            }
+        }
+        return;
+    }
+    // backward sampling (Whiteley), csmc.py:134-146
+    for (int t = T - 2; t >= 0; --t) {
+        R lw = ninf;
+        if (live) {
+            R xi[D], mu[D];
+#pragma unroll
+            for (int k = 0; k < D; ++k) xi[k] = xs[((long long)t * N + tid) * D + k];
+            trans_mean<R, D>(m, xi, mu);
+            lw = gauss_chol_logpdf<R, D>(xn, mu, m.LQ, m.c_trans) + lws[(long long)t * N + tid];
+        }
+        __syncthreads();  // c / sB of the previous iteration fully consumed
+        w = block_normalize<R>(lw, red, tid, nw);
+        block_cumsum<R>(w, c, red, tid, nw);
+        if (tid == 0) {
+            const R un = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + t);
+            const R r = c[N - 1] * ((R)1 - un);
+            int Bt = lower_bound<R>(c, N, r);
+            sB = Bt < N - 1 ? Bt : N - 1;
+        }
+        __syncthreads();
+        B = sB;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xn[k] = xs[((long long)t * N + B) * D + k];
+        if (tid == 0) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) xout[(long long)t * D + k] = xn[k];
+            anc[t] = B;
+        }
+    }
+}
+
+template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model* fk, const double* host) {
+    // host = [m0 (D) | chol_P0 (D*D) | F (D*D) | b (D) | chol_Q (D*D)] as doubles
+    const int D = fk->dx;
+    memset(&m, 0, sizeof(m));
+    m.proposal = fk->proposal;
+    m.potential = fk->potential;
+    m.D = D;
+    const double* p = host;
+    for (int k = 0; k < D; ++k) m.m0[k] = (R)p[k];
+    p += D;
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) m.LP0[i * CS_MAXD + j] = (R)p[i * D + j];
+    p += D * D;
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) m.F[i * CS_MAXD + j] = (R)p[i * D + j];
+    p += D * D;
+    for (int k = 0; k < D; ++k) m.b[k] = (R)p[k];
+    p += D;
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) m.LQ[i * CS_MAXD + j] = (R)p[i * D + j];
+    // additive constants, computed once on the host in precision R (they enter both the GPU and the oracle as data)
+    R ci = 0, ct = 0;
+    for (int k = 0; k < D; ++k) {
+        ci -= det_log(m.LP0[k * CS_MAXD + k]);
+        ct -= det_log(m.LQ[k * CS_MAXD + k]);
+    }
+    const R half_log_2pi = (R)0.91893853320467274178;
+    m.c_init = ci - (R)D * half_log_2pi;
+    m.c_trans = ct - (R)D * half_log_2pi;
+    if (fk->potential == 1) {
+        m.inv_sig_y = (R)1 / (R)fk->sig_y;
+        m.c_obs = -(R)D * det_log((R)fk->sig_y) - (R)D * half_log_2pi;
+    } else {
+        m.inv_sig_y = 0;
+        m.c_obs = -half_log_2pi;
+    }
+}
+
+template <typename R, int D>
+static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host_model, CsmcArgs& a) {
+    FkDev<R> m;
+    fill_model<R>(m, fk, host_model);
+    const int TB = (a.N + 63) / 64 * 64;
+    if (fk->proposal == 1) {
+        const long long total = (long long)a.C * a.T * D;
+        hipLaunchKernelGGL((k_csmc_aux<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a, D);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_CSMC_FWD);
+        const size_t lds = (size_t)TB * (1 + D) * sizeof(R) + 16 * sizeof(R) + 64;
+        hipLaunchKernelGGL((k_csmc_fwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_CSMC_BWD);
+        const size_t lds = (size_t)TB * sizeof(R) + 16 * sizeof(R) + 64;
+        hipLaunchKernelGGL((k_csmc_bwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+    }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+}  // namespace ax
+
+using namespace ax;
+
+extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* fk, int32_t C, int32_t T, int32_t N,
+                                 int32_t backward, const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise,
+                                 int32_t* ancestors, void* xs_out, void* log_ws_out, int32_t* As_out) {
+    if (!h) {
+        set_error("handle is NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    AX_HIP(hipSetDevice(h->device));
+    if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
+        set_error("dtype must be 0 (f32) or 1 (f64)");
+        return AUXSSM_ERR_ARG;
+    }
+    if (!fk || !x || !noise || !ancestors) {
+        set_error("model/x/noise/ancestors must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (C < 1 || T < 1 || N < 2 || N > 1024) {
+        set_error("need C >= 1, T >= 1, 2 <= N <= 1024 (got C=%d T=%d N=%d)", C, T, N);
+        return AUXSSM_ERR_ARG;
+    }
+    const int D = fk->dx;
+    if (D < 1 || D > CS_MAXD) {
+        set_error("dx=%d not instantiated (1..%d)", D, CS_MAXD);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    if (fk->proposal != AUXSSM_PROP_BOOTSTRAP_LG && fk->proposal != AUXSSM_PROP_AUX_INDEPENDENT) {
+        set_error("unknown proposal kind %d", fk->proposal);
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->potential < AUXSSM_POT_FLAT || fk->potential > AUXSSM_POT_SV) {
+        set_error("unknown potential kind %d", fk->potential);
+        return AUXSSM_ERR_ARG;
+    }
+    if (!fk->m0 || !fk->chol_P0 || !fk->F || !fk->b || !fk->chol_Q) {
+        set_error("model has a NULL m0/chol_P0/F/b/chol_Q host pointer");
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->potential != AUXSSM_POT_FLAT && !fk->y) {
+        set_error("potential needs observations y");
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->potential == AUXSSM_POT_GAUSS_OBS && !(fk->sig_y > 0)) {
+        set_error("sig_y must be > 0");
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->proposal == AUXSSM_PROP_AUX_INDEPENDENT && !sqrt_half_delta) {
+        set_error("the auxiliary proposal needs sqrt_half_delta (T)");
+        return AUXSSM_ERR_ARG;
+    }
+    if (noise->mode == AUXSSM_NOISE_EXPLICIT) {
+        if (!noise->eps_prop || !noise->u_bwd || (T > 1 && !noise->u_res) ||
+            (fk->proposal == AUXSSM_PROP_AUX_INDEPENDENT && !noise->eps_aux)) {
+            set_error("explicit noise needs eps_prop, u_res, u_bwd (and eps_aux for the auxiliary proposal)");
+            return AUXSSM_ERR_ARG;
+        }
+    } else if (noise->mode != AUXSSM_NOISE_THREEFRY) {
+        set_error("unknown noise mode %d", noise->mode);
+        return AUXSSM_ERR_ARG;
+    }
+    // host-side model parameters (doubles): m0 | chol_P0 | F | b | chol_Q
+    std::vector<double> hm((size_t)2 * D + 3 * D * D);
+    {
+        double* p = hm.data();
+        memcpy(p, fk->m0, D * sizeof(double)); p += D;
+        memcpy(p, fk->chol_P0, D * D * sizeof(double)); p += D * D;
+        memcpy(p, fk->F, D * D * sizeof(double)); p += D * D;
+        memcpy(p, fk->b, D * sizeof(double)); p += D;
+        memcpy(p, fk->chol_Q, D * D * sizeof(double));
+    }
+    const size_t sR = dtype == AUXSSM_F32 ? 4 : 8;
+    const size_t CT = (size_t)C * T;
+    size_t need = 4096;
+    if (!xs_out) need += CT * N * D * sR + 256;
+    if (!log_ws_out) need += CT * N * sR + 256;
+    if (!backward && !As_out) need += (size_t)C * (T > 1 ? T - 1 : 1) * N * 4 + 256;
+    need += (size_t)C * N * sR + 256;
+    need += CT * D * sR + 256;
+    int rc = ws_reserve(h, need);
+    if (rc) return rc;
+    CsmcArgs a;
+    a.C = C; a.T = T; a.N = N; a.backward = backward ? 1 : 0;
+    a.y = fk->y;
+    a.shd = sqrt_half_delta;
+    a.x = x;
+    a.u = ws_take(h, CT * D * sR);
+    a.xs = xs_out ? xs_out : ws_take(h, CT * N * D * sR);
+    a.lws = log_ws_out ? log_ws_out : ws_take(h, CT * N * sR);
+    a.As = As_out ? As_out : (!backward ? (int32_t*)ws_take(h, (size_t)C * (T > 1 ? T - 1 : 1) * N * 4) : nullptr);
+    a.wT = ws_take(h, (size_t)C * N * sR);
+    a.anc = ancestors;
+    a.noise_mode = noise->mode;
+    a.key0 = noise->key0; a.key1 = noise->key1;
+    a.eps_aux = noise->eps_aux; a.eps_prop = noise->eps_prop; a.u_res = noise->u_res; a.u_bwd = noise->u_bwd;
+    if (!a.u || !a.xs || !a.lws || !a.wT || (!backward && !a.As)) return AUXSSM_ERR_NOMEM;
+#define AX_CSMC_D(R)                                                        \
+    switch (D) {                                                            \
+        case 1: return run_csmc<R, 1>(h, fk, hm.data(), a);                 \
+        case 2: return run_csmc<R, 2>(h, fk, hm.data(), a);                 \
+        case 3: return run_csmc<R, 3>(h, fk, hm.data(), a);                 \
+        default: return run_csmc<R, 4>(h, fk, hm.data(), a);                \
+    }
+    if (dtype == AUXSSM_F32) { AX_CSMC_D(float) } else { AX_CSMC_D(double) }
+#undef AX_CSMC_D
+}

@@ -143,6 +143,57 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
                         int nan_policy, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
                         int32_t* accepted, void* logs);
 
+/* ---- conditional SMC (particle Gibbs) sweep ------------------------------------------------------------
+ * == kernel(key, state) of aux_samplers._primitives.csmc.get_kernel (csmc.py:16-66: forward pass _csmc :69-107 with
+ * conditional multinomial resampling resamplings.py:14-37, then _backward_scanning_pass :110-124 or
+ * _backward_sampling_pass :127-149), and -- with proposal = AUX_INDEPENDENT -- kernel(key, state, delta) of
+ * aux_samplers.csmc.get_independent_kernel's classical branch (csmc/generic.py:56-72 + csmc/independent.py:57-75,
+ * 143-169, 192-198, 238-248), for C chains at once.
+ *
+ * A Python Mt/Gt object cannot run inside a kernel; the Feynman-Kac model is a closed family instead:
+ *   transition  x_t | x_{t-1} ~ N(F x_{t-1} + b, Q)   (time-invariant), initial N(m0, P0)
+ *   potential   FLAT: 0 | GAUSS_OBS: log N(y_t; x_t, sig_y^2 I) | SV: sum_k log N(y_{t,k}; 0, exp(x_{t,k}))
+ *   proposal    BOOTSTRAP_LG:    M0 = initial, Mt = transition, G0/Gt = potential          (test_csmc/common.py fixtures)
+ *               AUX_INDEPENDENT: u = x + sqrt(delta_t/2) eps_aux; M0/Mt = N(u_t, delta_t/2 I);
+ *                                G0 = log initial + potential, Gt = log transition + potential, Pt = transition
+ * m0, chol_P0 (lower), F, b, chol_Q (lower) are small HOST arrays of doubles; y (T, dx) is a DEVICE array of `dtype`
+ * shared by all chains; sqrt_half_delta (T) is a DEVICE array of `dtype` (AUX_INDEPENDENT only).
+ *
+ * Noise: EXPLICIT device arrays (the parity contract): eps_aux (C,T,dx) [AUX only], eps_prop (C,T,N,dx) ~ N(0,1) (row t
+ * feeds M0 / Mt.sample at time t), u_res (C,T-1,N) ~ U[0,1) (row t-1 resamples into time t), u_bwd (C,T) (entry t draws
+ * B_t; only entry T-1 is used when backward == 0); or THREEFRY: the same quantities generated in-kernel from
+ * (key0, key1), bit-identical to auxssm_rng_normal/uniform fills with streams 1..4 over the same flat indices.
+ *
+ * x (C,T,dx): reference trajectories in, new trajectories out.  ancestors (C,T) int32 out (updated = ancestors != 0,
+ * csmc.py:59).  xs_out (C,T,N,dx), log_ws_out (C,T,N), As_out (C,T-1,N) int32: optional full particle history
+ * (NULL -> kept in the handle's workspace).  N <= 1024.  Arithmetic uses the fixed reduction orders and the
+ * bit-reproducible exp/log documented in csrc/csmc.hip, so ancestors are bit-exact against oracle/csmc_ref.c. */
+typedef enum { AUXSSM_PROP_BOOTSTRAP_LG = 0, AUXSSM_PROP_AUX_INDEPENDENT = 1 } auxssm_fk_proposal;
+typedef enum { AUXSSM_POT_FLAT = 0, AUXSSM_POT_GAUSS_OBS = 1, AUXSSM_POT_SV = 2 } auxssm_fk_potential;
+typedef enum { AUXSSM_NOISE_EXPLICIT = 0, AUXSSM_NOISE_THREEFRY = 1 } auxssm_noise_mode;
+typedef struct {
+    int32_t proposal, potential, dx, reserved;
+    const double* m0;      /* host (dx) */
+    const double* chol_P0; /* host (dx,dx) lower */
+    const double* F;       /* host (dx,dx) */
+    const double* b;       /* host (dx) */
+    const double* chol_Q;  /* host (dx,dx) lower */
+    const void* y;         /* device (T,dx), may be NULL for FLAT */
+    double sig_y;
+} auxssm_fk_model;
+typedef struct {
+    int32_t mode;
+    uint32_t key0, key1;
+    int32_t reserved;
+    const void* eps_aux;
+    const void* eps_prop;
+    const void* u_res;
+    const void* u_bwd;
+} auxssm_csmc_noise;
+int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* model, int32_t C, int32_t T, int32_t N,
+                      int32_t backward, const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise,
+                      int32_t* ancestors, void* xs_out, void* log_ws_out, int32_t* As_out);
+
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i): see oracle/rng_np.py for the restatement. */
 int auxssm_rng_normal(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);

@@ -1,0 +1,395 @@
+/*
+ * ORACLE -- TEST INFRASTRUCTURE ONLY (never linked or loaded by the product).
+ *
+ * Plain-C, single-threaded restatement of the reference's conditional SMC sweep:
+ *   aux_samplers/_primitives/csmc/csmc.py      _csmc :69-107, _backward_scanning_pass :110-124,
+ *                                              _backward_sampling_pass :127-149, kernel :52-59
+ *   aux_samplers/_primitives/csmc/resamplings.py  multinomial :14-37   (-> jax.random.choice(p=w): cumsum, r = c[-1](1-u),
+ *                                              searchsorted -- third-party JAX, restated from its published algorithm)
+ *   aux_samplers/_primitives/math/utils.py     normalize :23-39 (exp(lw - logsumexp(lw)))
+ *   aux_samplers/csmc/generic.py               kernel :56-72  (u = x + sqrt(delta/2) eps)
+ *   aux_samplers/csmc/independent.py           AuxiliaryM0 :143-158, AuxiliaryG0 :163-169, AuxiliaryMtDynamics :192-198,
+ *                                              AuxiliaryGt :238-248 (classical, non-gradient branch)
+ * for the closed Feynman-Kac family of include/auxssm.h (linear-Gaussian transition; flat / Gaussian / SV potential).
+ *
+ * "Parity unpinned" against JAX bits: JAX is not installed, and XLA's summation order / exp / log are unknowable here,
+ * so the float-level contract is fixed HERE and the HIP kernels must reproduce it bit for bit:
+ *   - exp/log: the fdlibm-derived fixed operation sequences below (IEEE +,-,*,/,fma,rint only);
+ *   - cumsum : Kogge-Stone scan inside each group of 64 consecutive particles, group totals added left to right,
+ *              c_i = (t_0 + ... + t_{g-1}) + local_i;
+ *   - sum    : balanced binary tree inside each group of 64, then left to right over groups;  max: exact;
+ *   - every multiply-add that is fused is written as fma(); compile with -ffp-contract=off.
+ * What IS pinned: the statistical known answers of the reference's tests (test_csmc.py::test_flat_potential :18-69,
+ * test_resamplings.py::test_multinomial_resampling :11-24) -- see tests/test_oracle_csmc.py.
+ *
+ * Build: gcc -O2 -ffp-contract=off -shared -fPIC csmc_ref.c -o _build/libcsmc_ref.so -lm   (oracle/Makefile)
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define MAXD 4
+
+/* ------------------------------------------------------------------------------------------------ */
+/* real-type generic code via the preprocessor: this file includes itself twice                          */
+/* ------------------------------------------------------------------------------------------------ */
+#ifndef CSMC_REF_BODY
+
+static float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static double u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
+static uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
+
+static float exp_f32(float x) {
+    if (x != x) return x;
+    if (x > 88.72f) return INFINITY;
+    if (x < -87.3f) return 0.0f;
+    const float kf = rintf(x * 1.44269504088896341f);
+    float r = fmaf(-kf, 6.93145751953125e-1f, x);
+    r = fmaf(-kf, 1.42860682030941723212e-6f, r);
+    float p = 1.9841270114e-4f;
+    p = fmaf(p, r, 1.3888889225e-3f);
+    p = fmaf(p, r, 8.3333337670e-3f);
+    p = fmaf(p, r, 4.1666667908e-2f);
+    p = fmaf(p, r, 1.6666667163e-1f);
+    p = fmaf(p, r, 0.5f);
+    p = fmaf(p, r, 1.0f);
+    p = fmaf(p, r, 1.0f);
+    const int k = (int)kf;
+    const int k1 = k / 2, k2 = k - k1;
+    return p * u2f((uint32_t)(k1 + 127) << 23) * u2f((uint32_t)(k2 + 127) << 23);
+}
+static float log_f32(float x) {
+    if (x != x) return x;
+    if (x < 0.0f) return NAN;
+    if (x == 0.0f) return -INFINITY;
+    if (x == INFINITY) return x;
+    uint32_t ix = f2u(x);
+    int e = 0;
+    if (ix < 0x00800000u) { x = x * 33554432.0f; ix = f2u(x); e = -25; }
+    e += (int)(ix >> 23) - 127;
+    ix &= 0x007fffffu;
+    const uint32_t i = (ix + (0x95f64u << 3)) & 0x800000u;
+    const float m = u2f(ix | (i ^ 0x3f800000u));
+    e += (int)(i >> 23);
+    const float f = m - 1.0f;
+    const float s = f / (2.0f + f);
+    const float z = s * s;
+    const float w = z * z;
+    const float t1 = w * fmaf(w, 0.24279078841f, 0.40000972152f);
+    const float t2 = z * fmaf(w, 0.28498786688f, 0.66666662693f);
+    const float R = t2 + t1;
+    const float hfsq = 0.5f * f * f;
+    const float dk = (float)e;
+    return fmaf(dk, 6.9313812256e-01f, -((hfsq - fmaf(s, hfsq + R, dk * 9.0580006145e-06f)) - f));
+}
+static double exp_f64(double x) {
+    if (x != x) return x;
+    if (x > 709.78) return INFINITY;
+    if (x < -708.0) return 0.0;
+    const double kf = rint(x * 1.44269504088896338700e+00);
+    const double hi = fma(-kf, 6.93147180369123816490e-01, x);
+    const double lo = kf * 1.90821492927058770002e-10;
+    const double r = hi - lo;
+    const double t = r * r;
+    double c = 4.13813679705723846039e-08;
+    c = fma(c, t, -1.65339022054652515390e-06);
+    c = fma(c, t, 6.61375632143793436117e-05);
+    c = fma(c, t, -2.77777777770155933842e-03);
+    c = fma(c, t, 1.66666666666666019037e-01);
+    c = r - t * c;
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    const int k = (int)kf;
+    const int k1 = k / 2, k2 = k - k1;
+    return y * u2d((uint64_t)(k1 + 1023) << 52) * u2d((uint64_t)(k2 + 1023) << 52);
+}
+static double log_f64(double x) {
+    if (x != x) return x;
+    if (x < 0.0) return NAN;
+    if (x == 0.0) return -INFINITY;
+    if (x == INFINITY) return x;
+    uint64_t ix = d2u(x);
+    int e = 0;
+    if (ix < 0x0010000000000000ull) { x = x * 18014398509481984.0; ix = d2u(x); e = -54; }
+    uint32_t hx = (uint32_t)(ix >> 32);
+    e += (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    const uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    ix = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (ix & 0xffffffffull);
+    e += (int)(i >> 20);
+    const double m = u2d(ix);
+    const double f = m - 1.0;
+    const double s = f / (2.0 + f);
+    const double z = s * s;
+    const double w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1;
+    const double hfsq = 0.5 * f * f;
+    const double dk = (double)e;
+    return fma(dk, 6.93147180369123816490e-01, -((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f));
+}
+
+float csmc_ref_expf(float x) { return exp_f32(x); }
+float csmc_ref_logf(float x) { return log_f32(x); }
+double csmc_ref_exp(double x) { return exp_f64(x); }
+double csmc_ref_log(double x) { return log_f64(x); }
+
+typedef struct {
+    int proposal, potential, D, backward;
+    const double *m0, *LP0, *F, *b, *LQ; /* (D), (D,D) lower, (D,D), (D), (D,D) lower */
+    double sig_y;
+} fk_model;
+
+#define CSMC_REF_BODY
+#define REAL float
+#define SUF(n) n##_f32
+#define EXP exp_f32
+#define LOG log_f32
+#define FMA fmaf
+#include "csmc_ref.c"
+#undef REAL
+#undef SUF
+#undef EXP
+#undef LOG
+#undef FMA
+#define REAL double
+#define SUF(n) n##_f64
+#define EXP exp_f64
+#define LOG log_f64
+#define FMA fma
+#include "csmc_ref.c"
+
+#else /* CSMC_REF_BODY: the generic part, compiled once per real type */
+
+typedef struct {
+    int proposal, potential, D;
+    REAL m0[MAXD], LP0[MAXD * MAXD], F[MAXD * MAXD], b[MAXD], LQ[MAXD * MAXD];
+    REAL c_init, c_trans, c_obs, inv_sig_y;
+} SUF(fk);
+
+static void SUF(fk_fill)(SUF(fk) * m, const fk_model* g) {
+    const int D = g->D;
+    memset(m, 0, sizeof(*m));
+    m->proposal = g->proposal; m->potential = g->potential; m->D = D;
+    for (int k = 0; k < D; ++k) { m->m0[k] = (REAL)g->m0[k]; m->b[k] = (REAL)g->b[k]; }
+    for (int i = 0; i < D; ++i)
+        for (int j = 0; j < D; ++j) {
+            m->LP0[i * MAXD + j] = (REAL)g->LP0[i * D + j];
+            m->F[i * MAXD + j] = (REAL)g->F[i * D + j];
+            m->LQ[i * MAXD + j] = (REAL)g->LQ[i * D + j];
+        }
+    REAL ci = 0, ct = 0;
+    for (int k = 0; k < D; ++k) { ci -= LOG(m->LP0[k * MAXD + k]); ct -= LOG(m->LQ[k * MAXD + k]); }
+    const REAL hl2pi = (REAL)0.91893853320467274178;
+    m->c_init = ci - (REAL)D * hl2pi;
+    m->c_trans = ct - (REAL)D * hl2pi;
+    if (g->potential == 1) {
+        m->inv_sig_y = (REAL)1 / (REAL)g->sig_y;
+        m->c_obs = -(REAL)D * LOG((REAL)g->sig_y) - (REAL)D * hl2pi;
+    } else {
+        m->inv_sig_y = 0;
+        m->c_obs = -hl2pi;
+    }
+}
+
+/* log N(x; mean, L L^T) with the additive constant precomputed */
+static REAL SUF(gauss)(int D, const REAL* x, const REAL* mean, const REAL* L, REAL cst) {
+    REAL z[MAXD], q = 0;
+    for (int k = 0; k < D; ++k) {
+        REAL acc = x[k] - mean[k];
+        for (int j = 0; j < k; ++j) acc = FMA(-L[k * MAXD + j], z[j], acc);
+        z[k] = acc / L[k * MAXD + k];
+        q = FMA(z[k], z[k], q);
+    }
+    return FMA((REAL)-0.5, q, cst);
+}
+static void SUF(tmean)(const SUF(fk) * m, const REAL* xp, REAL* mu) {
+    for (int k = 0; k < m->D; ++k) {
+        REAL acc = m->b[k];
+        for (int j = 0; j < m->D; ++j) acc = FMA(m->F[k * MAXD + j], xp[j], acc);
+        mu[k] = acc;
+    }
+}
+static REAL SUF(pot)(const SUF(fk) * m, const REAL* x, const REAL* y) {
+    const int D = m->D;
+    if (m->potential == 0) return (REAL)0;
+    if (m->potential == 1) {
+        REAL q = 0;
+        for (int k = 0; k < D; ++k) { const REAL z = (y[k] - x[k]) * m->inv_sig_y; q = FMA(z, z, q); }
+        return FMA((REAL)-0.5, q, m->c_obs);
+    }
+    REAL acc = 0;
+    for (int k = 0; k < D; ++k) {
+        const REAL e = EXP(-x[k]);
+        const REAL s = FMA(y[k] * y[k], e, x[k]);
+        const REAL v = FMA((REAL)-0.5, s, m->c_obs);
+        acc += (v == v) ? v : (REAL)0;
+    }
+    return acc;
+}
+
+/* ---- the fixed reduction orders ---- */
+static REAL SUF(tree64)(const REAL* v, int n) { /* balanced binary tree over 64 slots, missing slots are +0 */
+    REAL t[64];
+    for (int i = 0; i < 64; ++i) t[i] = i < n ? v[i] : (REAL)0;
+    for (int off = 1; off < 64; off <<= 1)
+        for (int i = 0; i < 64; i += 2 * off) t[i] = t[i] + t[i + off];
+    return t[0];
+}
+static REAL SUF(sum)(const REAL* v, int N) {
+    REAL s = 0;
+    for (int g = 0; g * 64 < N; ++g) {
+        const int n = N - g * 64 < 64 ? N - g * 64 : 64;
+        const REAL t = SUF(tree64)(v + g * 64, n);
+        s = g == 0 ? t : s + t;
+    }
+    return s;
+}
+static void SUF(cumsum)(const REAL* w, int N, REAL* c) {
+    REAL pre = 0;
+    for (int g = 0; g * 64 < N; ++g) {
+        REAL t[64], o[64];
+        const int n = N - g * 64 < 64 ? N - g * 64 : 64;
+        for (int i = 0; i < 64; ++i) t[i] = i < n ? w[g * 64 + i] : (REAL)0;
+        for (int off = 1; off < 64; off <<= 1) { /* Kogge-Stone */
+            for (int i = 0; i < 64; ++i) o[i] = i >= off ? t[i] + t[i - off] : t[i];
+            memcpy(t, o, sizeof t);
+        }
+        for (int i = 0; i < n; ++i) c[g * 64 + i] = g == 0 ? t[i] : pre + t[i];
+        pre = g == 0 ? t[63] : pre + t[63];
+    }
+}
+/* normalize (math/utils.py:23-39) */
+static void SUF(normalize)(const REAL* lw, int N, REAL* w, REAL* tmp) {
+    REAL m = lw[0];
+    for (int i = 1; i < N; ++i) m = m > lw[i] ? m : lw[i];
+    if (!(m - m == 0)) m = 0;
+    for (int i = 0; i < N; ++i) tmp[i] = EXP(lw[i] - m);
+    const REAL lse = LOG(SUF(sum)(tmp, N)) + m;
+    for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - lse);
+}
+static int SUF(lower_bound)(const REAL* c, int n, REAL r) {
+    int lo = 0, hi = n;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] < r) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+/* jax.random.choice(key, N, p=w, shape=()) given the uniform draw */
+static int SUF(choice)(const REAL* c, int N, REAL un) {
+    const REAL r = c[N - 1] * ((REAL)1 - un);
+    const int i = SUF(lower_bound)(c, N, r);
+    return i < N - 1 ? i : N - 1;
+}
+
+/* One sweep of one chain.  x (T,D) in/out; y (T,D) or NULL; shd (T) or NULL; eps_aux (T,D) or NULL;
+ * eps_prop (T,N,D); u_res (T-1,N); u_bwd (T); outputs anc (T), xs (T,N,D), lws (T,N), As (T-1,N) [all required]. */
+int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y, const REAL* shd, const REAL* eps_aux,
+                        const REAL* eps_prop, const REAL* u_res, const REAL* u_bwd, int32_t* anc, REAL* xs, REAL* lws,
+                        int32_t* As) {
+    SUF(fk) m;
+    SUF(fk_fill)(&m, g);
+    const int D = m.D;
+    REAL* u = (REAL*)malloc(sizeof(REAL) * (size_t)T * D);
+    REAL* w = (REAL*)malloc(sizeof(REAL) * N);
+    REAL* c = (REAL*)malloc(sizeof(REAL) * N);
+    REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
+    REAL* lw = (REAL*)malloc(sizeof(REAL) * N);
+    REAL zero[MAXD] = {0, 0, 0, 0};
+    if (m.proposal == 1) /* csmc/generic.py:67 */
+        for (int t = 0; t < T; ++t)
+            for (int k = 0; k < D; ++k) u[t * D + k] = FMA(shd[t], eps_aux[t * D + k], x[t * D + k]);
+    /* t = 0 (csmc.py:74-80) */
+    for (int i = 0; i < N; ++i) {
+        REAL* xi = xs + (size_t)i * D;
+        const REAL* e = eps_prop + (size_t)i * D;
+        if (m.proposal == 0) {
+            for (int k = 0; k < D; ++k) {
+                REAL acc = m.m0[k];
+                for (int j = 0; j <= k; ++j) acc = FMA(m.LP0[k * MAXD + j], e[j], acc);
+                xi[k] = acc;
+            }
+        } else {
+            for (int k = 0; k < D; ++k) xi[k] = FMA(shd[0], e[k], u[k]);
+        }
+        if (i == 0) for (int k = 0; k < D; ++k) xi[k] = x[k];
+        REAL gq = SUF(pot)(&m, xi, y ? y : zero);
+        if (m.proposal == 1) gq = gq + SUF(gauss)(D, xi, m.m0, m.LP0, m.c_init);
+        lws[i] = gq;
+    }
+    SUF(normalize)(lws, N, w, tmp);
+    for (int t = 1; t < T; ++t) {
+        const REAL* xprev = xs + (size_t)(t - 1) * N * D;
+        REAL* xcur = xs + (size_t)t * N * D;
+        const REAL* yt = y ? y + (size_t)t * D : zero;
+        SUF(cumsum)(w, N, c);
+        for (int i = 0; i < N; ++i) {
+            int idx = 0;
+            if (i > 0) idx = SUF(choice)(c, N, u_res[(size_t)(t - 1) * N + i]); /* resamplings.py:35-36 */
+            As[(size_t)(t - 1) * N + i] = idx;
+            const REAL* xp = xprev + (size_t)idx * D;
+            const REAL* e = eps_prop + ((size_t)t * N + i) * D;
+            REAL* xi = xcur + (size_t)i * D;
+            if (m.proposal == 0) {
+                for (int k = 0; k < D; ++k) {
+                    REAL acc = m.b[k];
+                    for (int j = 0; j < D; ++j) acc = FMA(m.F[k * MAXD + j], xp[j], acc);
+                    for (int j = 0; j <= k; ++j) acc = FMA(m.LQ[k * MAXD + j], e[j], acc);
+                    xi[k] = acc;
+                }
+            } else {
+                for (int k = 0; k < D; ++k) xi[k] = FMA(shd[t], e[k], u[t * D + k]);
+            }
+            if (i == 0) for (int k = 0; k < D; ++k) xi[k] = x[t * D + k];
+            REAL gq = SUF(pot)(&m, xi, yt);
+            if (m.proposal == 1) {
+                REAL mu[MAXD];
+                SUF(tmean)(&m, xp, mu);
+                gq = SUF(gauss)(D, xi, mu, m.LQ, m.c_trans) + gq;
+            }
+            lw[i] = gq;
+        }
+        memcpy(lws + (size_t)t * N, lw, sizeof(REAL) * N);
+        SUF(normalize)(lw, N, w, tmp);
+    }
+    /* backward (csmc.py:110-149) */
+    SUF(cumsum)(w, N, c);
+    int B = SUF(choice)(c, N, u_bwd[T - 1]);
+    anc[T - 1] = B;
+    REAL xn[MAXD];
+    for (int k = 0; k < D; ++k) xn[k] = x[(T - 1) * D + k] = xs[((size_t)(T - 1) * N + B) * D + k];
+    for (int t = T - 2; t >= 0; --t) {
+        if (!g->backward) {
+            B = As[(size_t)t * N + B];
+        } else {
+            for (int i = 0; i < N; ++i) {
+                REAL mu[MAXD];
+                SUF(tmean)(&m, xs + ((size_t)t * N + i) * D, mu);
+                lw[i] = SUF(gauss)(D, xn, mu, m.LQ, m.c_trans) + lws[(size_t)t * N + i];
+            }
+            SUF(normalize)(lw, N, w, tmp);
+            SUF(cumsum)(w, N, c);
+            B = SUF(choice)(c, N, u_bwd[t]);
+        }
+        anc[t] = B;
+        for (int k = 0; k < D; ++k) xn[k] = x[t * D + k] = xs[((size_t)t * N + B) * D + k];
+    }
+    free(u); free(w); free(c); free(tmp); free(lw);
+    return 0;
+}
+
+/* conditional multinomial resampling alone (resamplings.py:14-37), for the reference's statistical test */
+void SUF(csmc_ref_multinomial)(const REAL* w, int N, const REAL* un, int32_t* idx) {
+    REAL* c = (REAL*)malloc(sizeof(REAL) * N);
+    SUF(cumsum)(w, N, c);
+    for (int i = 0; i < N; ++i) idx[i] = i == 0 ? 0 : SUF(choice)(c, N, un[i]);
+    free(c);
+}
+void SUF(csmc_ref_normalize)(const REAL* lw, int N, REAL* w) {
+    REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
+    SUF(normalize)(lw, N, w, tmp);
+    free(tmp);
+}
+
+#endif /* CSMC_REF_BODY */

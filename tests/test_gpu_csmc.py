@@ -1,0 +1,174 @@
+"""GPU parity tests of the conditional-SMC path: HIP kernels through the C ABI vs the plain-C oracle
+(oracle/csmc_ref.c) on identical explicit noise.  The contract (BASELINE north_star): ancestor indices BIT-EXACT;
+here particles, log-weights and trajectories are bit-exact too, because both sides use the same fixed reduction
+orders and the same bit-reproducible exp/log.  Plus the reference's own statistical tests on the HIP path."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import csmc as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _models(d, rng):
+    from aux_ssm_samplers_amd.csmc import GaussianInit, LinearGaussianDynamics
+    A = rng.standard_normal((d, d))
+    Q = A @ A.T / d + 0.5 * np.eye(d)
+    F = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d))
+    b = 0.1 * rng.standard_normal(d)
+    P0 = 2.0 * np.eye(d)
+    m0 = 0.1 * rng.standard_normal(d)
+    return GaussianInit(m0=m0, P0=P0), LinearGaussianDynamics(F=F, b=b, Q=Q)
+
+
+def _odesc(proposal, potential, M0, Mt, sig_y=1.0):
+    return dict(proposal=proposal, potential=potential, m0=M0.m0, chol_P0=M0.chol(), F=Mt.F, b=Mt.b, chol_Q=Mt.chol(), sig_y=sig_y)
+
+
+def _pot(kind, y, sig=0.7):
+    from aux_ssm_samplers_amd.csmc import FlatPotential, GaussianObsPotential, SVPotential
+    if kind == O.POT_FLAT:
+        return FlatPotential(), FlatPotential()
+    if kind == O.POT_GAUSS_OBS:
+        return GaussianObsPotential(sig=sig, y=y[0]), GaussianObsPotential(sig=sig, params=y[1:])
+    return SVPotential(y=y[0]), SVPotential(params=y[1:])
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d,N,T", [(1, 32, 5), (1, 1024, 300), (2, 100, 64), (3, 512, 40), (4, 65, 33)])
+@pytest.mark.parametrize("proposal", [O.BOOTSTRAP_LG, O.AUX_INDEPENDENT])
+@pytest.mark.parametrize("potential", [O.POT_FLAT, O.POT_GAUSS_OBS, O.POT_SV])
+@pytest.mark.parametrize("backward", [True, False])
+def test_sweep_bit_exact_vs_oracle(dtype, d, N, T, proposal, potential, backward):
+    from aux_ssm_samplers_amd.csmc import _device
+    rng = np.random.default_rng(1000 * d + N + T)
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(potential, y)
+    sig = 0.7
+    x0 = rng.standard_normal((T, d)).astype(dtype)
+    noise = dict(eps_prop=rng.standard_normal((T, N, d)), u_res=rng.random((T - 1, N)), u_bwd=rng.random(T))
+    delta = None
+    okw = {}
+    if proposal == O.AUX_INDEPENDENT:
+        delta = 0.5 + rng.random(T)  # time-varying delta (csmc/generic.py:61-63 accepts a vector)
+        noise["eps_aux"] = rng.standard_normal((T, d))
+        fk = _device.describe_independent(M0, G0, Mt, Gt, Mt)
+        okw = dict(sqrt_half_delta=np.sqrt(0.5 * delta), eps_aux=noise["eps_aux"])
+    else:
+        fk = _device.describe_bootstrap(M0, G0, Mt, Gt, Mt)
+    noise32 = {k: np.asarray(v, dtype) for k, v in noise.items()}
+    x, anc, hist = _device.sweep(fk, x0, N, backward, noise={k: v[None] for k, v in noise32.items()}, delta=delta, want_history=True)
+    ref = O.sweep(_odesc(proposal, potential, M0, Mt, sig), x0, N, backward, y=y if potential else None, eps_prop=noise["eps_prop"],
+                  u_res=noise["u_res"], u_bwd=noise["u_bwd"], dtype=dtype, **okw)
+    npt.assert_array_equal(hist["xs"], ref["xs"])
+    npt.assert_array_equal(hist["log_ws"], ref["log_ws"])
+    npt.assert_array_equal(hist["As"], ref["As"])          # resampling ancestors: bit-exact
+    npt.assert_array_equal(anc, ref["ancestors"])          # backward indices: bit-exact
+    npt.assert_array_equal(x, ref["x"])
+    assert np.all(hist["As"][:, 0] == 0) and np.all(hist["xs"][:, 0] == x0)
+
+
+def test_multichain_equals_single_chain_and_threefry_equals_explicit():
+    """C chains in one launch == C single launches; in-kernel Threefry noise == the same draws materialised by the fill
+    kernels (streams 1..4 over the same flat indices) and fed back as explicit arrays."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.csmc import _device
+    rng = np.random.default_rng(7)
+    d, N, T, C = 2, 128, 50, 5
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(O.POT_SV, y)
+    fk = _device.describe_independent(M0, G0, Mt, Gt, Mt)
+    x0 = rng.standard_normal((C, T, d)).astype(np.float32)
+    key = R.PRNGKey(99)
+    h = _lib.default_handle()
+    xa, anca, _ = _device.sweep(fk, x0, N, True, key=key, delta=0.5)
+    noise = dict(eps_aux=h.rng_normal(key, 1, (C, T, d), np.float32).to_host(),
+                 eps_prop=h.rng_normal(key, 2, (C, T, N, d), np.float32).to_host(),
+                 u_res=h.rng_uniform(key, 3, (C, T - 1, N), np.float32).to_host(),
+                 u_bwd=h.rng_uniform(key, 4, (C, T), np.float32).to_host())
+    xb, ancb, _ = _device.sweep(fk, x0, N, True, noise=noise, delta=0.5)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    for c in range(C):
+        xc, ancc, _ = _device.sweep(fk, x0[c], N, True, noise={k: v[c:c + 1] for k, v in noise.items()}, delta=0.5)
+        npt.assert_array_equal(xc, xb[c])
+        npt.assert_array_equal(ancc, ancb[c])
+
+
+@pytest.mark.parametrize("backward", [True, False])
+def test_flat_potential_reference_statistical_test(backward):
+    """aux_samplers/_primitives/test_csmc/test_csmc.py::test_flat_potential (:18-69) on the HIP path: AR(1) prior is
+    invariant: mean 0, var 1, lag-1 cov rho, atol 0.05.  2048 chains x 40 sweeps instead of 1 chain x 50_000."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd._primitives.csmc import get_kernel
+    from aux_ssm_samplers_amd.csmc import GaussianInit, LinearGaussianDynamics, FlatPotential
+    T, N, rho, C, M = 5, 32, 0.9, 2048, 40
+    M0 = GaussianInit(m0=[0.0], P0=[[1.0]])
+    Mt = LinearGaussianDynamics(F=[[rho]], b=[0.0], Q=[[1 - rho ** 2]])
+    init, kernel = get_kernel(M0, FlatPotential(), Mt, FlatPotential(), N=N, backward=backward, Pt=Mt)
+    rng = np.random.default_rng(0)
+    state = init(rng.standard_normal((C, T, 1)).astype(np.float32))
+    keys = R.split(R.PRNGKey(0), M)
+    out = []
+    for it in range(M):
+        state = kernel(keys[it], state)
+        if it >= M // 4:
+            out.append(state.x[:, :, 0])
+    xs = np.concatenate(out)
+    cov = np.cov(xs, rowvar=False)
+    npt.assert_allclose(xs.mean(0), 0.0, atol=0.05)
+    npt.assert_allclose(np.diag(cov), 1.0, atol=0.05)
+    npt.assert_allclose(np.diag(cov, 1), rho, atol=0.05)
+
+
+def test_independent_kernel_api_and_C3_shape_smoke():
+    """csmc.get_independent_kernel on the SV model of BASELINE config C3 (d=1, N=1024, backward sampling), reduced T.
+    Checks the API surface (init/kernel/CSMCState) and bit-exactness against the oracle given the same noise."""
+    from aux_ssm_samplers_amd.csmc import get_independent_kernel, GaussianInit, LinearGaussianDynamics, SVPotential
+    T, N = 2048, 1024
+    phi, tau = 0.9, 2.0
+    q = tau / (1 - phi ** 2)  # examples/stochastic_volatility/model.py:34-53
+    rng = np.random.default_rng(5)
+    xtrue = np.zeros(T)
+    xtrue[0] = np.sqrt(q) * rng.standard_normal()
+    for t in range(1, T):
+        xtrue[t] = phi * xtrue[t - 1] + np.sqrt(q) * rng.standard_normal()
+    y = (np.exp(0.5 * xtrue) * rng.standard_normal(T))[:, None]
+    M0 = GaussianInit(m0=[0.0], P0=[[q]])
+    Mt = LinearGaussianDynamics(F=[[phi]], b=[0.0], Q=[[q]])
+    init, kernel = get_independent_kernel(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), N, backward=True, Pt=Mt)
+    x0 = xtrue[:, None].astype(np.float32)
+    noise = dict(eps_aux=rng.standard_normal((1, T, 1)), eps_prop=rng.standard_normal((1, T, N, 1)),
+                 u_res=rng.random((1, T - 1, N)), u_bwd=rng.random((1, T)))
+    noise = {k: v.astype(np.float32) for k, v in noise.items()}
+    st = kernel(None, init(x0), 0.5, noise=noise)
+    assert st.x.shape == (T, 1) and st.updated.shape == (T,) and st.updated.dtype == bool
+    ref = O.sweep(dict(proposal=O.AUX_INDEPENDENT, potential=O.POT_SV, m0=[0.0], chol_P0=[[np.sqrt(q)]], F=[[phi]], b=[0.0],
+                       chol_Q=[[np.sqrt(q)]]), x0, N, True, y=y, sqrt_half_delta=np.full(T, np.sqrt(0.25)),
+                  eps_aux=noise["eps_aux"][0], eps_prop=noise["eps_prop"][0], u_res=noise["u_res"][0], u_bwd=noise["u_bwd"][0])
+    npt.assert_array_equal(st.ancestors, ref["ancestors"])
+    npt.assert_array_equal(st.x, ref["x"])
+    assert st.updated.mean() > 0.5  # backward sampling moves most time steps
+
+
+def test_unsupported_python_models_fail_loudly():
+    from aux_ssm_samplers_amd._primitives.csmc import get_kernel
+    from aux_ssm_samplers_amd.csmc import get_independent_kernel, get_generic_kernel, GaussianInit, LinearGaussianDynamics, FlatPotential
+
+    class MyDyn:
+        def sample(self, key, x, p):
+            return x
+
+    M0 = GaussianInit(m0=[0.0], P0=[[1.0]])
+    Mt = LinearGaussianDynamics(F=[[0.5]], b=[0.0], Q=[[1.0]])
+    with pytest.raises(NotImplementedError):
+        get_kernel(M0, FlatPotential(), MyDyn(), FlatPotential(), N=8)
+    with pytest.raises(NotImplementedError):
+        get_independent_kernel(M0, FlatPotential(), Mt, FlatPotential(), 8, gradient=True)
+    with pytest.raises(NotImplementedError):
+        get_generic_kernel(lambda u, s: None, 8)
+    with pytest.raises(ValueError):
+        get_generic_kernel(lambda u, s: None, 8, backward=True)  # csmc/generic.py:44-45

