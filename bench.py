@@ -133,14 +133,14 @@ def main():
         handle.prof_disable()
 
     # the trivial chain-gather (RCCL): acceptance flags + last log-alphas of every chain to rank 0
+    from aux_ssm_samplers_amd.parallel import gather_chains
     acc = chains.accepted.to_host()
     logs = chains.logs.to_host()
     if dist is not None:
-        ta = torch.from_numpy(acc.astype(np.int32)).cuda()
-        gathered = [torch.empty_like(ta) for _ in range(world)] if rank == 0 else None
-        dist.gather(ta, gathered, dst=0)
+        per_chain = np.concatenate([acc[:, None].astype(np.float64), logs.astype(np.float64)], axis=1)  # (C, 6)
+        g = gather_chains(per_chain, C * world, dist, dst=0, device=torch.device("cuda", local_rank))
         if rank == 0:
-            acc = torch.cat(gathered).cpu().numpy()
+            acc, logs = g[:, 0], g[:, 1:]
 
     if rank == 0:
         s = np.dtype(dtype).itemsize
