@@ -181,6 +181,12 @@ class Handle:
         check(self.lib.auxssm_rng_normal(self.h, dtype_code(dtype), key[0], key[1], stream, out.size, out.ptr))
         return out
 
+    def rng_normal_into(self, key, stream, out):
+        check(self.lib.auxssm_rng_normal(self.h, dtype_code(out.dtype), int(key[0]), int(key[1]), stream, out.size, out.ptr))
+
+    def rng_uniform_into(self, key, stream, out):
+        check(self.lib.auxssm_rng_uniform(self.h, dtype_code(out.dtype), int(key[0]), int(key[1]), stream, out.size, out.ptr))
+
     def rng_uniform(self, key, stream, shape, dtype):
         out = self.empty(shape, dtype)
         check(self.lib.auxssm_rng_uniform(self.h, dtype_code(dtype), key[0], key[1], stream, out.size, out.ptr))

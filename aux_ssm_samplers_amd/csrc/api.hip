@@ -68,7 +68,8 @@ ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
 // instantiation units
 #define AX_DECL_UNIT(NAME) \
     const KalmanEntry* kalman_unit_##NAME(int P); \
-    const SampleEntry* sample_unit_##NAME();
+    const SampleEntry* sample_unit_##NAME(); \
+    const SweepLogpdfEntry* sweep_logpdf_unit_##NAME(int PO);
 AX_DECL_UNIT(f32_d1) AX_DECL_UNIT(f32_d2) AX_DECL_UNIT(f32_d3) AX_DECL_UNIT(f32_d4)
 AX_DECL_UNIT(f64_d1) AX_DECL_UNIT(f64_d2) AX_DECL_UNIT(f64_d3) AX_DECL_UNIT(f64_d4)
 
@@ -104,6 +105,25 @@ const SampleEntry* sample_entry(int dtype, int D) {
             case 2: return sample_unit_f64_d2();
             case 3: return sample_unit_f64_d3();
             case 4: return sample_unit_f64_d4();
+        }
+    }
+    return nullptr;
+}
+
+const SweepLogpdfEntry* sweep_logpdf_entry(int dtype, int D, int PO) {
+    if (dtype == AUXSSM_F32) {
+        switch (D) {
+            case 1: return sweep_logpdf_unit_f32_d1(PO);
+            case 2: return sweep_logpdf_unit_f32_d2(PO);
+            case 3: return sweep_logpdf_unit_f32_d3(PO);
+            case 4: return sweep_logpdf_unit_f32_d4(PO);
+        }
+    } else if (dtype == AUXSSM_F64) {
+        switch (D) {
+            case 1: return sweep_logpdf_unit_f64_d1(PO);
+            case 2: return sweep_logpdf_unit_f64_d2(PO);
+            case 3: return sweep_logpdf_unit_f64_d3(PO);
+            case 4: return sweep_logpdf_unit_f64_d4(PO);
         }
     }
     return nullptr;
@@ -265,7 +285,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     const KalmanEntry* ke = need_kalman(dtype, D, P);
     const KalmanEntry* ko = need_kalman(dtype, D, PO);
     const SampleEntry* se = sample_entry(dtype, D);
-    if (!ke || !ko || !se) return AUXSSM_ERR_UNSUPPORTED;
+    const SweepLogpdfEntry* sl = sweep_logpdf_entry(dtype, D, PO);
+    if (!sl) set_error("(dx=%d, p_obs=%d) sweep not instantiated (p_obs <= 4)", D, PO);
+    if (!ke || !ko || !se || !sl) return AUXSSM_ERR_UNSUPPORTED;
     const KDims kd{C, T, 1};
     const size_t sR = sizeof(R);
     const size_t CT = (size_t)C * T;
@@ -281,7 +303,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     add((size_t)C * 8 * sR + 2048);                    // scalars
     add(ke->filter_ws(h, kd, parallel));
     add(se->sample_ws(h, kd, parallel));
-    add(ke->logpdf_ws(h, kd));
+    add(sl->ws(h, kd));
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     R* ysc = (R*)ws_take(h, CT * P * sR);
@@ -293,11 +315,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     R* Ps = (R*)ws_take(h, CT * D * D * sR);
     R* xp = (R*)ws_take(h, CT * D * sR);
     R* ell = (R*)ws_take(h, C * sR);
-    R* jp_prop = (R*)ws_take(h, C * sR);
-    R* jp_rev = (R*)ws_take(h, C * sR);
-    R* lt_prop = (R*)ws_take(h, C * sR);
-    R* lt_rev = (R*)ws_take(h, C * sR);
-    R* corr = (R*)ws_take(h, C * sR);
+    R* sums = (R*)ws_take(h, (size_t)5 * C * sR);
     const size_t mark = h->ws_off;
 
     // observations_factory / dynamics_factory of the LG_CONCAT device model
@@ -333,30 +351,18 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     if (rc) return rc;
     h->ws_off = mark;
 
-    // proposal log-densities (generic.py:88) and targets (generic.py:89)
-    const Arr x_arr = dense(x, kd, D), xp_arr = dense(xp, kd, D);
-    LogpdfArgs la;
-    fill_logpdf_args(la, &dc, &gc, cv(ysc_arr), xp_arr, nan_policy);
-    rc = ke->logpdf(h, la, jp_prop);
-    if (rc) return rc;
-    h->ws_off = mark;
-    la.xs = x_arr;
-    rc = ke->logpdf(h, la, jp_rev);
-    if (rc) return rc;
-    h->ws_off = mark;
-    auxssm_dims dobs = *dims;
-    dobs.B = 1;
-    fill_logpdf_args(la, &dobs, model, cv(*yobs), xp_arr, nan_policy);
-    rc = ko->logpdf(h, la, lt_prop);
-    if (rc) return rc;
-    h->ws_off = mark;
-    la.xs = x_arr;
-    rc = ko->logpdf(h, la, lt_rev);
-    if (rc) return rc;
-    h->ws_off = mark;
-
-    hipLaunchKernelGGL((k_correction<R>), dim3(C), dim3(256), 0, h->stream, (long long)T * D, (const R*)x, (const R*)xp,
-                       (const R*)u, (R)(1.0 / delta), corr);
+    // all proposal / target log-densities and the MH correction in one pass (generic.py:88-89, :103-105)
+    {
+        SweepLogpdfArgs la;
+        la.d = kd;
+        la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
+        la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
+        la.x = x; la.xp = xp; la.u = u; la.delta = delta; la.nan_policy = nan_policy;
+        rc = sl->run(h, la, sums);
+        if (rc) return rc;
+        h->ws_off = mark;
+    }
+    R* jp_prop = sums; R* jp_rev = sums + C; R* lt_prop = sums + 2 * C; R* lt_rev = sums + 3 * C; R* corr = sums + 4 * C;
     hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)jp_prop, (const R*)jp_rev,
                        (const R*)ell, (const R*)ell, (const R*)lt_prop, (const R*)lt_rev, (const R*)corr, (const R*)u_acc,
                        accepted, (R*)logs);

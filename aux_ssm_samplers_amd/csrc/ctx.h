@@ -82,6 +82,12 @@ struct KalmanEntry {
     logpdf_fn logpdf;
     logpdf_ws_fn logpdf_ws;
 };
+typedef int (*sweep_logpdf_fn)(auxssm_ctx*, const SweepLogpdfArgs&, void* out /*[5][C]*/);
+typedef size_t (*sweep_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);
+struct SweepLogpdfEntry {
+    sweep_logpdf_fn run;
+    sweep_logpdf_ws_fn ws;
+};
 struct SampleEntry {
     sample_fn sample;
     sample_ws_fn sample_ws;
@@ -93,5 +99,6 @@ constexpr int MAX_P = 8;
 // defined by the instantiation units (inst_*.hip); nullptr entries = not built
 const KalmanEntry* kalman_entry(int dtype, int D, int P);
 const SampleEntry* sample_entry(int dtype, int D);
+const SweepLogpdfEntry* sweep_logpdf_entry(int dtype, int D, int PO);
 
 }  // namespace ax

@@ -270,4 +270,114 @@ template <typename R, int D, int P> AX_HD R body_joint_logpdf(const LogpdfArgs& 
     return out;
 }
 
+
+// ---- all log-densities of one auxiliary-Kalman sweep of the LG_CONCAT device model in one pass ---------------------
+// For the current state x and the proposal xp (kalman/generic.py:64-70):
+//   out[0] += loglik_concat(xp) + prior(xp)   (posterior_logpdf + ell of the proposal, base.py:72-96)
+//   out[1] += loglik_concat(x)  + prior(x)
+//   out[2] += loglik_obs(xp)    + prior(xp)   (log_likelihood_fn(x_prop), generic.py:89)
+//   out[3] += loglik_obs(x)     + prior(x)
+//   out[4] += ((xp-u)^2 - (x-u)^2) / delta    (generic.py:103-105)
+// loglik_concat uses R = blkdiag(delta/2 I, Robs): its Cholesky is block diagonal, so the term is the auxiliary block
+// (diagonal) plus the observation block -- the same arithmetic as the dense 2d x 2d factorisation without the zeros.
+struct SweepLogpdfArgs {
+    KDims d;
+    Arr m0, P0, Fs, Qs, bs, Hs, Rs, cs, ys;  // dynamics + REAL observation model, ys = yobs
+    const void* x;                           // dense (C,T,D)
+    const void* xp;
+    const void* u;
+    double delta;
+    int nan_policy;
+};
+
+template <typename R, int D, int PO> AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, int c, int t, R* out5) {
+    const long long r = (long long)c * a.d.T + t;
+    R x[D], xp[D], u[D];
+    ld<R, D>((const R*)a.x + r * D, x);
+    ld<R, D>((const R*)a.xp + r * D, xp);
+    ld<R, D>((const R*)a.u + r * D, u);
+    // observation block
+    R ob_x, ob_p;
+    bool badobs_x = false, badobs_p = false;
+    {
+        R H[PO * D], cv[PO], y[PO], r1[PO], r2[PO];
+        bool skip[PO];
+        ld<R, PO * D>(at<R>(a.Hs, c, t, 0), H);
+        ld<R, PO>(at<R>(a.cs, c, t, 0), cv);
+        ld<R, PO>(at<R>(a.ys, c, t, 0), y);
+#pragma unroll
+        for (int k = 0; k < PO; ++k) {
+            R p1 = cv[k], p2 = cv[k];
+#pragma unroll
+            for (int j = 0; j < D; ++j) p1 += H[k * D + j] * xp[j], p2 += H[k * D + j] * x[j];
+            r1[k] = y[k] - p1;
+            r2[k] = y[k] - p2;
+            skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
+            badobs_p = badobs_p || (!skip[k] && !finite_(r1[k]));
+            badobs_x = badobs_x || (!skip[k] && !finite_(r2[k]));
+        }
+        gauss_logpdf2<R, PO>(r1, r2, at<R>(a.Rs, c, t, 0), a.nan_policy == 1 ? skip : nullptr, ob_p, ob_x);
+    }
+    // auxiliary block: log N(u; x, delta/2 I), and the MH correction
+    R ax_x, ax_p, corr = 0;
+    bool bad_aux_p, bad_aux_x;
+    {
+        const R hd = (R)(0.5 * a.delta);
+        const R sd = sqrt_(hd);
+        R q1 = 0, q2 = 0;
+        bool b1 = false, b2 = false;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const R d1 = u[k] - xp[k], d2 = u[k] - x[k];
+            b1 = b1 || !finite_(d1);
+            b2 = b2 || !finite_(d2);
+            const R z1 = d1 / sd, z2 = d2 / sd;
+            q1 += z1 * z1;
+            q2 += z2 * z2;
+            const R e1 = xp[k] - u[k], e2 = x[k] - u[k];
+            corr += (e1 * e1 - e2 * e2) / (R)a.delta;
+        }
+        const R cst = -(R)D * log_(sd) - (R)(0.5 * LOG_2PI) * (R)D;
+        ax_p = (R)-0.5 * q1 + cst;
+        ax_x = (R)-0.5 * q2 + cst;
+        if (b1) ax_p = 0;
+        if (b2) ax_x = 0;
+        bad_aux_p = b1;
+        bad_aux_x = b2;
+    }
+    // transition / initial term
+    R pr_x, pr_p;
+    {
+        R r1[D], r2[D];
+        if (t == 0) {
+            R m0[D];
+            ld<R, D>(at<R>(a.m0, c, 0, 0), m0);
+#pragma unroll
+            for (int k = 0; k < D; ++k) r1[k] = xp[k] - m0[k], r2[k] = x[k] - m0[k];
+            gauss_logpdf2<R, D>(r1, r2, at<R>(a.P0, c, 0, 0), nullptr, pr_p, pr_x);
+        } else {
+            R xq[D], xpq[D], F[D * D], bd[D], m1[D], m2[D];
+            ld<R, D>((const R*)a.x + (r - 1) * D, xq);
+            ld<R, D>((const R*)a.xp + (r - 1) * D, xpq);
+            ld<R, D * D>(at<R>(a.Fs, c, t - 1, 0), F);
+            ld<R, D>(at<R>(a.bs, c, t - 1, 0), bd);
+            mv<R, D, D>(F, xpq, m1);
+            mv<R, D, D>(F, xq, m2);
+#pragma unroll
+            for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
+            gauss_logpdf2<R, D>(r1, r2, at<R>(a.Qs, c, t - 1, 0), nullptr, pr_p, pr_x);
+        }
+    }
+    // reference policy (jnp.nansum over per-step logpdfs): a non-finite component anywhere in the stacked residual
+    // [u - x ; y - H x - c] drops the whole step of the concatenated model; the target only sees the observation block.
+    const bool ref = a.nan_policy == 0;
+    const R cc_p = (ref && (bad_aux_p || badobs_p)) ? (R)0 : ax_p + ob_p;
+    const R cc_x = (ref && (bad_aux_x || badobs_x)) ? (R)0 : ax_x + ob_x;
+    out5[0] = cc_p + pr_p;
+    out5[1] = cc_x + pr_x;
+    out5[2] = ob_p + pr_p;
+    out5[3] = ob_x + pr_x;
+    out5[4] = corr;
+}
+
 }  // namespace ax

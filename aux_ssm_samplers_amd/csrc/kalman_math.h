@@ -590,4 +590,50 @@ AX_HD R gauss_logpdf(const R* r, const R* __restrict__ cov, const bool* skip) {
     return out;
 }
 
+
+// Same as gauss_logpdf for two residuals sharing one covariance (one Cholesky, two triangular solves).
+template <typename R, int N>
+AX_HD void gauss_logpdf2(const R* r1, const R* r2, const R* __restrict__ cov, const bool* skip, R& o1, R& o2) {
+    R a[N], b[N];
+    int dim = 0;
+    bool bad1 = false, bad2 = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool sk = skip ? skip[k] : false;
+        a[k] = sk ? (R)0 : r1[k];
+        b[k] = sk ? (R)0 : r2[k];
+        bad1 = bad1 || !finite_(a[k]);
+        bad2 = bad2 || !finite_(b[k]);
+        dim += sk ? 0 : 1;
+    }
+    if constexpr (N == 1) {
+        const R sd = sqrt_(cov[0]);
+        const R z1 = a[0] / sd, z2 = b[0] / sd;
+        const R cst = -log_(sd) - (R)(0.5 * LOG_2PI);
+        o1 = (R)-0.5 * z1 * z1 + cst;
+        o2 = (R)-0.5 * z2 * z2 + cst;
+        if (skip && skip[0]) o1 = o2 = 0;
+    } else {
+        R S[symsize(N)], L[symsize(N)];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = i; j < N; ++j) S[sidx_u(N, i, j)] = cov[i * N + j];
+        const bool ok = chol_packed<R, N>(S, L, skip);
+        R logdet = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) logdet += (skip && skip[k]) ? (R)0 : log_(L[lidx(k, k)]);
+        lsolve<R, N>(L, a);
+        lsolve<R, N>(L, b);
+        R q1 = 0, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) q1 += a[k] * a[k], q2 += b[k] * b[k];
+        const R cst = -logdet - (R)(0.5 * LOG_2PI) * (R)dim;
+        o1 = ok ? (R)-0.5 * q1 + cst : r_nan<R>();
+        o2 = ok ? (R)-0.5 * q2 + cst : r_nan<R>();
+    }
+    if (bad1 || isnan_(o1)) o1 = 0;
+    if (bad2 || isnan_(o2)) o2 = 0;
+}
+
 }  // namespace ax

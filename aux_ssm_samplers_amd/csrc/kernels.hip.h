@@ -75,6 +75,23 @@ __global__ void __launch_bounds__(TB_ELEM) k_joint_logpdf(LogpdfArgs a, R* __res
     if (threadIdx.x == 0) part[(long long)s * ntile + tile] = tot;
 }
 
+// five per-chain sums of the fused sweep log-density pass; part layout [5][C][ntile]
+template <typename R, int D, int PO>
+__global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, R* __restrict__ part, int ntile) {
+    __shared__ R sh[TB_ELEM];
+    const int C = a.d.C;
+    const int c = blockIdx.x % C;
+    const int tile = blockIdx.x / C;
+    const int t = tile * TB_ELEM + threadIdx.x;
+    R v[5] = {0, 0, 0, 0, 0};
+    if (t < a.d.T) body_sweep_logpdf<R, D, PO>(a, c, t, v);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const R tot = block_sum<R, TB_ELEM>(v[k], sh);
+        if (threadIdx.x == 0) part[((long long)k * C + c) * ntile + tile] = tot;
+    }
+}
+
 // out[c] = sum_b ( add0[c*B+b] + sum_tile part[(c*B+b)*ntile + tile] ), fixed order.  One workgroup per chain.
 template <typename R>
 __global__ void __launch_bounds__(TB_ELEM) k_reduce_rows(const R* __restrict__ part, const R* __restrict__ add0,
@@ -308,6 +325,20 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
     return AUXSSM_OK;
 }
 
+template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
+    return (size_t)5 * d.C * ntiles(d.T) * sizeof(R) + 256;
+}
+// out: [5][C]
+template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
+    const int C = a.d.C, nt = ntiles(a.d.T);
+    R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
+    ProfScope ps(h, AUXSSM_K_LOGPDF);
+    hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3((unsigned)nt * C), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
 // one instantiation unit = one (dtype, D): all P for the filter / logpdf, plus the sampler
 #define AX_KALMAN_ENTRY(R, D, P) \
     { &run_filter<R, D, P>, &filter_ws<R, D, P>, &run_logpdf<R, D, P>, &logpdf_ws<R, D, P> }
@@ -320,6 +351,13 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
                                                AX_KALMAN_ENTRY(R, D, 5), AX_KALMAN_ENTRY(R, D, 6),  \
                                                AX_KALMAN_ENTRY(R, D, 7), AX_KALMAN_ENTRY(R, D, 8)}; \
         return (P >= 1 && P <= MAX_P) ? &tab[P - 1] : nullptr;                                       \
+    }                                                                                                \
+    const SweepLogpdfEntry* sweep_logpdf_unit_##NAME(int PO) {                                       \
+        static const SweepLogpdfEntry tab[4] = {{&run_sweep_logpdf<R, D, 1>, &sweep_logpdf_ws<R, D, 1>}, \
+                                                {&run_sweep_logpdf<R, D, 2>, &sweep_logpdf_ws<R, D, 2>}, \
+                                                {&run_sweep_logpdf<R, D, 3>, &sweep_logpdf_ws<R, D, 3>}, \
+                                                {&run_sweep_logpdf<R, D, 4>, &sweep_logpdf_ws<R, D, 4>}}; \
+        return (PO >= 1 && PO <= 4) ? &tab[PO - 1] : nullptr;                                        \
     }                                                                                                \
     const SampleEntry* sample_unit_##NAME() {                                                        \
         static const SampleEntry e = {&run_sample<R, D>, &sample_ws<R, D>};                          \

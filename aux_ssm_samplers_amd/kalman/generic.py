@@ -112,6 +112,10 @@ class DeviceChains:
         self.dtype = self.x.dtype
         self.accepted = handle.zeros((self.C,), np.int32)
         self.logs = handle.zeros((self.C, 5), self.dtype)
+        # per-sweep noise, allocated once: no hipMalloc / hipFree (and no stream sync) inside the sweep loop
+        self.eps_aux = handle.empty(self.x.shape, self.dtype)
+        self.eps_samp = handle.empty(self.x.shape, self.dtype)
+        self.u_acc = handle.empty((self.C,), self.dtype)
 
     def to_host(self):
         return self.x.to_host()
@@ -131,9 +135,10 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
 
     def draw(handle, key, chains):
         k_aux, k_samp, k_acc = _random.split(key, 3)
-        shape = (chains.C, chains.T, chains.dx)
-        return (handle.rng_normal(k_aux, 0, shape, chains.dtype), handle.rng_normal(k_samp, 0, shape, chains.dtype),
-                handle.rng_uniform(k_acc, 0, (chains.C,), chains.dtype))
+        handle.rng_normal_into(k_aux, 0, chains.eps_aux)
+        handle.rng_normal_into(k_samp, 0, chains.eps_samp)
+        handle.rng_uniform_into(k_acc, 0, chains.u_acc)
+        return chains.eps_aux, chains.eps_samp, chains.u_acc
 
     def kernel(key, state, delta, noise=None):
         """state.x: ndarray (T, dx) [one chain], ndarray (C, T, dx) or DeviceChains (resident, updated in place)."""
@@ -144,9 +149,10 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
             eps_aux, eps_samp, u_acc = draw(handle, key, chains)
         else:
             shape = (chains.C, chains.T, chains.dx)
-            eps_aux = handle.to_device(np.asarray(noise["eps_aux"], chains.dtype).reshape(shape))
-            eps_samp = handle.to_device(np.asarray(noise["eps_samp"], chains.dtype).reshape(shape))
-            u_acc = handle.to_device(np.asarray(noise["u_accept"], chains.dtype).reshape(chains.C))
+            eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc
+            eps_aux.copy_from_host(np.asarray(noise["eps_aux"], chains.dtype).reshape(shape))
+            eps_samp.copy_from_host(np.asarray(noise["eps_samp"], chains.dtype).reshape(shape))
+            u_acc.copy_from_host(np.asarray(noise["u_accept"], chains.dtype).reshape(chains.C))
         sweep(handle, chains, delta, eps_aux, eps_samp, u_acc)
         if resident:
             return KalmanSampler(x=chains, updated=chains.accepted)

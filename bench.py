@@ -109,8 +109,10 @@ def main():
         handle.sync()
         torch.cuda.synchronize()
 
+    keys = R.split(key, args.steps + args.warmup + 1)
+
     def step(k):
-        kernel(R.split(key, args.steps + args.warmup + 1)[k], state, delta)
+        kernel(keys[k], state, delta)
 
     for k in range(args.warmup):
         step(k)
