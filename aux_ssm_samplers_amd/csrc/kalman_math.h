@@ -31,21 +31,30 @@ template <typename R, int D> struct FiltPre {
     R C[DS];
 };
 
+// records are 16-byte aligned (NPAD, workspace carve): whole-record 16-byte vector loads/stores
 template <typename R, int D> AX_HD void fe_store(R* __restrict__ p, const FiltElem<R, D>& e) {
     constexpr int DS = symsize(D);
-    st<R, D * D>(p, e.A);
-    st<R, D>(p + D * D, e.b);
-    st<R, DS>(p + D * D + D, e.C);
-    st<R, D>(p + D * D + D + DS, e.eta);
-    st<R, DS>(p + D * D + 2 * D + DS, e.J);
+    constexpr int N = FiltElem<R, D>::N;
+    R t[N];
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) t[i] = e.A[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) t[D * D + i] = e.b[i], t[D * D + D + DS + i] = e.eta[i];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) t[D * D + D + i] = e.C[i], t[D * D + 2 * D + DS + i] = e.J[i];
+    stv<R, N>(p, t);
 }
 template <typename R, int D> AX_HD void fe_load(const R* __restrict__ p, FiltElem<R, D>& e) {
     constexpr int DS = symsize(D);
-    ld<R, D * D>(p, e.A);
-    ld<R, D>(p + D * D, e.b);
-    ld<R, DS>(p + D * D + D, e.C);
-    ld<R, D>(p + D * D + D + DS, e.eta);
-    ld<R, DS>(p + D * D + 2 * D + DS, e.J);
+    constexpr int N = FiltElem<R, D>::N;
+    R t[N];
+    ldv<R, N>(p, t);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) e.A[i] = t[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) e.b[i] = t[D * D + i], e.eta[i] = t[D * D + D + DS + i];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) e.C[i] = t[D * D + D + i], e.J[i] = t[D * D + 2 * D + DS + i];
 }
 template <typename R, int D> AX_HD void fe_identity(FiltElem<R, D>& e) {
 #pragma unroll
@@ -74,7 +83,7 @@ AX_HD bool obs_mask(const R* y, const R* H, const R* c, bool* nan, R* H_, R* c_)
     return any;
 }
 
-// S = H_ P H_^T + R_ (packed), PHt = P H_^T.  Rm is read from memory entry by entry (keeps R out of VGPRs).
+// S = H_ P H_^T + R_ (LOWER-packed, lidx), PHt = P H_^T.  Rm is read from memory entry by entry (keeps R out of VGPRs).
 template <typename R, int D, int P>
 AX_HD void innovation_cov(const R* Pd, const R* H_, const R* __restrict__ Rm, const bool* nan, R* PHt, R* S) {
     mmt<R, D, D, P>(Pd, H_, PHt);  // PHt[i][k] = sum_j P[i][j] H_[k][j]
@@ -86,7 +95,7 @@ AX_HD void innovation_cov(const R* Pd, const R* H_, const R* __restrict__ Rm, co
 #pragma unroll
             for (int j = 0; j < D; ++j) s += H_[k * D + j] * PHt[j * P + l];
             const R r = (nan[k] || nan[l]) ? (R)0 : Rm[k * P + l];
-            S[sidx_u(P, k, l)] = s + r;
+            S[lidx(l, k)] = s + r;
         }
 }
 
@@ -107,19 +116,19 @@ AX_HD R kalman_update(R* m, R* Pd, const R* H, const R* c, const R* __restrict__
         yd[k] = nan[k] ? (R)0 : y[k] - yh;
         dim += nan[k] ? 0 : 1;
     }
-    R PHt[D * P], S[symsize(P)], L[symsize(P)];
-    innovation_cov<R, D, P>(Pd, H_, Rm, nan, PHt, S);
+    R PHt[D * P], L[symsize(P)], invd[P];
+    innovation_cov<R, D, P>(Pd, H_, Rm, nan, PHt, L);
     R G[D * P];
     R ell;
     if constexpr (P == 1) {  // scalar branch :108-111
-        const R s = S[0];
+        const R s = L[0];
         const R sd = sqrt_(s);
         const R z = yd[0] / sd;
         ell = (R)-0.5 * z * z - log_(sd) - (R)(0.5 * LOG_2PI);
 #pragma unroll
         for (int i = 0; i < D; ++i) G[i] = PHt[i] / s;
     } else {
-        const bool ok = chol_packed<R, P>(S, L, nan);
+        const bool ok = chol_inplace<R, P>(L, invd, nan);
         R z[P];
         R logdet = 0;
 #pragma unroll
@@ -127,7 +136,7 @@ AX_HD R kalman_update(R* m, R* Pd, const R* H, const R* c, const R* __restrict__
             z[k] = yd[k];
             logdet += nan[k] ? (R)0 : log_(L[lidx(k, k)]);
         }
-        lsolve<R, P>(L, z);
+        lsolve<R, P>(L, invd, z);
         R q = 0;
 #pragma unroll
         for (int k = 0; k < P; ++k) q += z[k] * z[k];
@@ -138,7 +147,7 @@ AX_HD R kalman_update(R* m, R* Pd, const R* H, const R* c, const R* __restrict__
             R g[P];
 #pragma unroll
             for (int k = 0; k < P; ++k) g[k] = PHt[i * P + k];
-            cho_solve<R, P>(L, g);
+            cho_solve<R, P>(L, invd, g);
 #pragma unroll
             for (int k = 0; k < P; ++k) G[i * P + k] = ok ? g[k] : r_nan<R>();
         }
@@ -165,6 +174,49 @@ AX_HD R kalman_update(R* m, R* Pd, const R* H, const R* c, const R* __restrict__
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j < D; ++j) Pd[i * D + j] = (i == j) ? Pn[i * D + i] : (R)0.5 * (Pn[i * D + j] + Pn[j * D + i]);
+    return isnan_(ell) ? (R)0 : ell;
+}
+
+// Log-likelihood increment only (the ell_inc output of sequential_update, filtering.py:106-114,125): the parallel
+// filter's second pass (filtering.py:60-62) discards the updated moments, so the gain is never formed here.
+template <typename R, int D, int P>
+AX_HD R kalman_ell_inc(const R* m, const R* Pd, const R* H, const R* c, const R* __restrict__ Rm, const R* y) {
+    bool nan[P];
+    R H_[P * D], c_[P];
+    const bool any = obs_mask<R, D, P>(y, H, c, nan, H_, c_);
+    if (!any) return (R)0;
+    R yd[P];
+    int dim = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        R yh = c_[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) yh += H_[k * D + j] * m[j];
+        yd[k] = nan[k] ? (R)0 : y[k] - yh;
+        dim += nan[k] ? 0 : 1;
+    }
+    R L[symsize(P)], invd[P];
+    {
+        R PHt[D * P];
+        innovation_cov<R, D, P>(Pd, H_, Rm, nan, PHt, L);
+    }
+    R ell;
+    if constexpr (P == 1) {
+        const R sd = sqrt_(L[0]);
+        const R z = yd[0] / sd;
+        ell = (R)-0.5 * z * z - log_(sd) - (R)(0.5 * LOG_2PI);
+    } else {
+        const bool ok = chol_inplace<R, P>(L, invd, nan);
+        R logdet = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) logdet += nan[k] ? (R)0 : log_(L[lidx(k, k)]);
+        lsolve<R, P>(L, invd, yd);
+        R q = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) q += yd[k] * yd[k];
+        ell = (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim;
+        if (!ok) ell = r_nan<R>();
+    }
     return isnan_(ell) ? (R)0 : ell;
 }
 
@@ -202,71 +254,81 @@ AX_HD void filter_elem(const R* F, const R* bdyn, const R* m_, const R* P_, cons
         for (int i = 0; i < symsize(D); ++i) e.J[i] = 0;
         return;
     }
-    R PHt[D * P], S[symsize(P)];
-    innovation_cov<R, D, P>(P_, H_, Rm, nan, PHt, S);
-    R Z[P * D];  // S^{-1} H_
-    if constexpr (P == 1) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) Z[j] = H_[j] / S[0];
-    } else {
-        R L[symsize(P)];
-        const bool ok = chol_packed<R, P>(S, L, nan);
-#pragma unroll
-        for (int i = 0; i < P * D; ++i) Z[i] = H_[i];
-#pragma unroll
-        for (int j = 0; j < D; ++j) cho_solve_col<R, P, D>(L, Z, j);
-        if (!ok) {
-#pragma unroll
-            for (int i = 0; i < P * D; ++i) Z[i] = r_nan<R>();
-        }
+    // Information form of the same element.  With L L^T = S and W = L^-1 H_ (p x d):
+    //   M = H_^T S^-1 H_ = W^T W,  v(r) = H_^T S^-1 r = W^T (L^-1 r)
+    //   K H_ = P_ M,  K r = P_ v(r),  K S0 K^T = P_ M P_      (S0 = S on the observed block)
+    //   A = F - P_ M F;  b = m_ + P_ v(y - H_ m_ - c_);  C = P_ - P_ M P_;  eta = F^T v(y - H_ b - c_);  J = F^T M F
+    // i.e. filtering.py:224-236 with the p x d intermediates (S_invH_T, K, temp) contracted away: only d x d products
+    // remain after one Cholesky and d + 2 forward substitutions.
+    R L[symsize(P)], invd[P];
+    {
+        R PHt[D * P];
+        innovation_cov<R, D, P>(P_, H_, Rm, nan, PHt, L);
     }
-    R ydm[P], ydb[P];
+    const bool ok = chol_inplace<R, P>(L, invd, nan);
+    R rm[P], rb[P];
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         R hm = c_[k], hb = c_[k];
 #pragma unroll
         for (int j = 0; j < D; ++j) hm += H_[k * D + j] * m_[j], hb += H_[k * D + j] * bdyn[j];
-        ydm[k] = nan[k] ? (R)0 : y[k] - hm;
-        ydb[k] = nan[k] ? (R)0 : y[k] - hb;
+        rm[k] = nan[k] ? (R)0 : y[k] - hm;
+        rb[k] = nan[k] ? (R)0 : y[k] - hb;
     }
-    R K[D * P];
-    mmt<R, D, D, P>(P_, Z, K);  // K = P_ Z^T
-    R HF[P * D];
-    mm<R, P, D, D>(H_, F, HF);
-    // A = F - K H_ F
 #pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            R s = 0;
-#pragma unroll
-            for (int k = 0; k < P; ++k) s += K[i * P + k] * HF[k * D + j];
-            e.A[i * D + j] = F[i * D + j] - s;
-        }
+    for (int j = 0; j < D; ++j) lsolve_col<R, P, D>(L, invd, H_, j);  // H_ <- W = L^-1 H_
+    lsolve<R, P>(L, invd, rm);
+    lsolve<R, P>(L, invd, rb);
+    R M[symsize(D)], vm[D], vb[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        R s = 0;
+        R s1 = 0, s2 = 0;
 #pragma unroll
-        for (int k = 0; k < P; ++k) s += K[i * P + k] * ydm[k];
-        e.b[i] = m_[i] + s;
+        for (int k = 0; k < P; ++k) s1 += H_[k * D + i] * rm[k], s2 += H_[k * D + i] * rb[k];
+        vm[i] = ok ? s1 : r_nan<R>();
+        vb[i] = ok ? s2 : r_nan<R>();
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            R s = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) s += H_[k * D + i] * H_[k * D + j];
+            M[sidx_u(D, i, j)] = ok ? s : r_nan<R>();
+        }
     }
-    // C = P_ - K S0 K^T, with S0 K^T = H_ P_ on the observed block (= PHt^T)
-    R Cd[D * D];
+    R PM[D * D], MF[D * D];
 #pragma unroll
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            R s = 0;
+            R s1 = 0, s2 = 0;
 #pragma unroll
-            for (int k = 0; k < P; ++k) s += K[i * P + k] * PHt[j * P + k];
-            Cd[i * D + j] = P_[i * D + j] - s;
+            for (int k = 0; k < D; ++k) s1 += P_[i * D + k] * M[sidx(D, k, j)], s2 += M[sidx(D, i, k)] * F[k * D + j];
+            PM[i * D + j] = s1;
+            MF[i * D + j] = s2;
         }
+    R Cd[D * D], Jd[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R sb = m_[i], se = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R sa = F[i * D + j], sc = P_[i * D + j], sj = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                sa -= PM[i * D + k] * F[k * D + j];
+                sc -= PM[i * D + k] * P_[k * D + j];
+                sj += F[k * D + i] * MF[k * D + j];
+            }
+            e.A[i * D + j] = sa;
+            Cd[i * D + j] = sc;
+            Jd[i * D + j] = sj;
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) sb += P_[i * D + k] * vm[k], se += F[k * D + i] * vb[k];
+        e.b[i] = sb;
+        e.eta[i] = se;
+    }
     sympack<R, D>(Cd, e.C);
-    R ZF[P * D];
-    mm<R, P, D, D>(Z, F, ZF);  // temp^T = Z F
-    tmv<R, D, P>(ZF, ydb, e.eta);
-    R Jd[D * D];
-    tmm<R, D, P, D>(ZF, HF, Jd);
     sympack<R, D>(Jd, e.J);
 }
 
@@ -450,8 +512,8 @@ template <typename R, int D> AX_HD void chol_nan_to_num(const R* Spacked, R* Ld)
     if constexpr (D == 1) {
         Ld[0] = nan_to_num(sqrt_(Spacked[0]));
     } else {
-        R L[symsize(D)];
-        const bool ok = chol_packed<R, D>(Spacked, L, nullptr);
+        R L[symsize(D)], invd[D];
+        const bool ok = chol_packed<R, D>(Spacked, L, invd, nullptr);
 #pragma unroll
         for (int i = 0; i < D; ++i)
 #pragma unroll
@@ -471,13 +533,13 @@ AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* 
     if constexpr (D == 1) {
         e.G[0] = Pd[0] * F[0] / S[0];
     } else {
-        R L[symsize(D)];
-        const bool ok = chol_packed<R, D>(S, L, nullptr);
+        R L[symsize(D)], invd[D];
+        const bool ok = chol_packed<R, D>(S, L, invd, nullptr);
         R X[D * D];  // S^-1 F
 #pragma unroll
         for (int i = 0; i < D * D; ++i) X[i] = F[i];
 #pragma unroll
-        for (int j = 0; j < D; ++j) cho_solve_col<R, D, D>(L, X, j);
+        for (int j = 0; j < D; ++j) cho_solve_col<R, D, D>(L, invd, X, j);
         mmt<R, D, D, D>(Pd, X, e.G);  // gain = P X^T
         if (!ok) {
 #pragma unroll
@@ -570,16 +632,16 @@ AX_HD R gauss_logpdf(const R* r, const R* __restrict__ cov, const bool* skip) {
         out = (R)-0.5 * z * z - log_(sd) - (R)(0.5 * LOG_2PI);
         if (skip && skip[0]) out = 0;
     } else {
-        R S[symsize(N)], L[symsize(N)];
+        R L[symsize(N)], invd[N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int j = i; j < N; ++j) S[sidx_u(N, i, j)] = cov[i * N + j];
-        const bool ok = chol_packed<R, N>(S, L, skip);
+            for (int j = i; j < N; ++j) L[lidx(j, i)] = cov[i * N + j];
+        const bool ok = chol_inplace<R, N>(L, invd, skip);
         R logdet = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) logdet += (skip && skip[k]) ? (R)0 : log_(L[lidx(k, k)]);
-        lsolve<R, N>(L, res);
+        lsolve<R, N>(L, invd, res);
         R q = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) q += res[k] * res[k];
@@ -614,17 +676,17 @@ AX_HD void gauss_logpdf2(const R* r1, const R* r2, const R* __restrict__ cov, co
         o2 = (R)-0.5 * z2 * z2 + cst;
         if (skip && skip[0]) o1 = o2 = 0;
     } else {
-        R S[symsize(N)], L[symsize(N)];
+        R L[symsize(N)], invd[N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
-            for (int j = i; j < N; ++j) S[sidx_u(N, i, j)] = cov[i * N + j];
-        const bool ok = chol_packed<R, N>(S, L, skip);
+            for (int j = i; j < N; ++j) L[lidx(j, i)] = cov[i * N + j];
+        const bool ok = chol_inplace<R, N>(L, invd, skip);
         R logdet = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) logdet += (skip && skip[k]) ? (R)0 : log_(L[lidx(k, k)]);
-        lsolve<R, N>(L, a);
-        lsolve<R, N>(L, b);
+        lsolve<R, N>(L, invd, a);
+        lsolve<R, N>(L, invd, b);
         R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) q1 += a[k] * a[k], q2 += b[k] * b[k];

@@ -34,6 +34,71 @@ template <typename R, int TB> __device__ __forceinline__ R block_sum(R v, R* sh)
     return r;
 }
 
+// ---- wave-cooperative record loads staged through LDS --------------------------------------------------------------------
+// The wave needs record r(l) of N reals for each lane l, and those 64 records are contiguous in memory (ascending or
+// descending with the lane).  Copy them as one contiguous stream (lane l reads element j*64 + l: 512 B / 1 KiB per
+// instruction, 4-8 cache lines instead of 64), scatter into an LDS image with an ODD record stride (conflict-free per-lane
+// reads), then every lane reads its own record.  Anything else (broadcast stride 0, batch-strided) falls back to a direct read.
+// Workgroups using this are exactly one wave, so __syncthreads() is only a compiler/LDS fence.
+template <typename R> struct WaveIO {
+    R* lds;
+    int lane;
+    int nvalid;  // valid lanes are 0 .. nvalid-1
+    // phase 1: buf[j] = element j*64 + lane of the wave's contiguous 64-record stream (fully coalesced), or the lane's own
+    // record for strides that are not record-dense.  No barrier: every array's fetch is issued before any finish.
+    template <typename R2, int N> __device__ __forceinline__ void fetch(const R2* lane_ptr, long long stride, bool valid, R2* buf) const {
+        static_assert(sizeof(R2) == sizeof(R), "one real type per kernel");
+        if (stride == N || stride == -N) {
+            const R2* p0 = stride < 0 ? lane_ptr + (long long)(lane - (nvalid - 1)) * N : lane_ptr - (long long)lane * N;
+            const int total = nvalid * N;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int q = j * 64 + lane;
+                buf[j] = q < total ? p0[q] : (R2)0;
+            }
+        } else if (valid) {
+            ld<R2, N>(lane_ptr, buf);
+        } else {
+#pragma unroll
+            for (int e = 0; e < N; ++e) buf[e] = 0;
+        }
+    }
+    // phase 2: scatter the stream into an LDS image with an odd record stride, then read this lane's record back.
+    template <typename R2, int N> __device__ __forceinline__ void finish(long long stride, bool valid, R2* buf) const {
+        if (stride == N || stride == -N) {
+            constexpr int RS = N | 1;
+            R2* L = (R2*)lds;
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const int q = j * 64 + lane;
+                const int r = q / N;
+                if (r < 64) L[r * RS + (q - r * N)] = buf[j];
+            }
+            __syncthreads();
+            const int myr = stride < 0 ? nvalid - 1 - lane : lane;
+#pragma unroll
+            for (int e = 0; e < N; ++e) buf[e] = valid ? L[myr * RS + e] : (R2)0;
+            __syncthreads();
+        }
+    }
+};
+template <typename R> constexpr size_t stage_bytes(int maxrec) { return (size_t)64 * (maxrec | 1) * sizeof(R) + 16; }
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// ---- XCD-aware (tile, sequence) decode for the elementwise kernels ------------------------------------------------------------
+// Workgroups are dealt round-robin over the 8 XCDs (block b and b+8 share one; MI355X_MICROARCH.md), each XCD with a private L2.
+// Chain-shared model parameters of a time tile should therefore be touched by ONE XCD: put tile % 8 in the low 3 bits of the
+// block id, so that every sequence's block for that tile lands on the same XCD, and consecutive block ids sweep
+// 8 tiles x all sequences (co-resident in time).  Purely a speed choice: any placement gives the same results.
+// grid = ntile8 * 8 * S blocks with ntile8 = ceil(ntile / 8); out-of-range tiles exit.
+__device__ __forceinline__ void decode_tile_seq(int S, int& tile, int& s) {
+    const unsigned b = blockIdx.x;
+    const unsigned lo = b & 7u, rest = b >> 3;
+    s = (int)(rest % (unsigned)S);
+    tile = (int)((rest / (unsigned)S) * 8u + lo);
+}
+inline unsigned grid_tile_seq(int ntile, int S) { return (unsigned)(((ntile + 7) / 8) * 8) * (unsigned)S; }
+
 // ---- Kalman elementwise kernels -----------------------------------------------------------------------------
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_t0(FilterArgs a) {
     const int s = blockIdx.x * TB_ELEM + threadIdx.x;
@@ -43,34 +108,39 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
 // grid = ntile * S, sequence index fastest so that workgroups of different chains touching the same time
 // tile (hence the same chain-shared model parameters) are co-scheduled and share them through L2.
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_init(FilterArgs a) {
-    const int S = a.d.S();
-    const int s = blockIdx.x % S;
-    const int i = (blockIdx.x / S) * TB_ELEM + threadIdx.x;
-    if (i < a.d.n()) body_filter_init<R, D, P>(a, s, i);
+    int tile, s;
+    decode_tile_seq(a.d.S(), tile, s);
+    const int i = tile * TB_ELEM + threadIdx.x;
+    if (i >= a.d.n()) return;
+    DirectIO io;
+    body_filter_init<R, D, P>(a, io, s, i, true);
 }
 
 template <typename R, int D, int P>
 __global__ void __launch_bounds__(TB_ELEM) k_filter_ell(FilterArgs a, R* __restrict__ part, int ntile) {
     __shared__ R sh[TB_ELEM];
-    const int S = a.d.S();
-    const int s = blockIdx.x % S;
-    const int tile = blockIdx.x / S;
+    int tile, s;
+    decode_tile_seq(a.d.S(), tile, s);
+    if (tile >= ntile) return;
     const int i = tile * TB_ELEM + threadIdx.x;
-    R v = 0;
-    if (i < a.d.n()) v = body_filter_ell<R, D, P>(a, s, i);
+    DirectIO io;
+    const R v = body_filter_ell<R, D, P>(a, io, s, i, i < a.d.n());
     const R tot = block_sum<R, TB_ELEM>(v, sh);
     if (threadIdx.x == 0) part[(long long)s * ntile + tile] = tot;
 }
 
+// lanes over i = t - 1; the t = 0 terms are added by lane 0 of tile 0
 template <typename R, int D, int P>
 __global__ void __launch_bounds__(TB_ELEM) k_joint_logpdf(LogpdfArgs a, R* __restrict__ part, int ntile) {
     __shared__ R sh[TB_ELEM];
-    const int S = a.d.S();
-    const int s = blockIdx.x % S;
-    const int tile = blockIdx.x / S;
-    const int t = tile * TB_ELEM + threadIdx.x;
-    R v = 0;
-    if (t < a.d.T) v = body_joint_logpdf<R, D, P>(a, s, t);
+    int tile, s;
+    decode_tile_seq(a.d.S(), tile, s);
+    if (tile >= ntile) return;
+    const int n = a.d.T - 1;
+    const int i = tile * TB_ELEM + threadIdx.x;
+    DirectIO io;
+    R v = body_joint_logpdf<R, D, P>(a, io, s, i, i < n);
+    if (tile == 0 && threadIdx.x == 0) v += body_joint_logpdf_head<R, D, P>(a, s);
     const R tot = block_sum<R, TB_ELEM>(v, sh);
     if (threadIdx.x == 0) part[(long long)s * ntile + tile] = tot;
 }
@@ -80,11 +150,20 @@ template <typename R, int D, int PO>
 __global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, R* __restrict__ part, int ntile) {
     __shared__ R sh[TB_ELEM];
     const int C = a.d.C;
-    const int c = blockIdx.x % C;
-    const int tile = blockIdx.x / C;
-    const int t = tile * TB_ELEM + threadIdx.x;
+    int tile, c;
+    decode_tile_seq(C, tile, c);
+    if (tile >= ntile) return;
+    const int n = a.d.T - 1;
+    const int i = tile * TB_ELEM + threadIdx.x;
     R v[5] = {0, 0, 0, 0, 0};
-    if (t < a.d.T) body_sweep_logpdf<R, D, PO>(a, c, t, v);
+    DirectIO io;
+    body_sweep_logpdf<R, D, PO>(a, io, c, i, i < n, v);
+    if (tile == 0 && threadIdx.x == 0) {
+        R h[5];
+        body_sweep_logpdf_head<R, D, PO>(a, c, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += h[k];
+    }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
         const R tot = block_sum<R, TB_ELEM>(v[k], sh);
@@ -109,33 +188,51 @@ __global__ void __launch_bounds__(TB_ELEM) k_reduce_rows(const R* __restrict__ p
 }
 
 template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample_init(SampleArgs a) {
-    const int S = a.d.S();
-    const int s = blockIdx.x % S;
-    const int j = (blockIdx.x / S) * TB_ELEM + threadIdx.x;
-    if (j < a.d.T) body_sample_init<R, D>(a, s, j);
+    int tile, s;
+    decode_tile_seq(a.d.S(), tile, s);
+    const int n = a.d.T - 1;
+    if (tile == 0 && threadIdx.x == 0) body_sample_last<R, D>(a, s);
+    const int jp = tile * TB_ELEM + threadIdx.x;
+    if (jp >= n) return;
+    DirectIO io;
+    body_sample_init<R, D>(a, io, s, jp, true);
 }
 
 // ---- generic chunked scan ---------------------------------------------------------------------------------------
+// one wave = one group of 64 chunks of one sequence; row k of the group is 64 contiguous records (ScanLayout)
 template <class Op>
-__global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, ScanBufs sb, int S, int n, int E, int nchunk) {
+__global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, ScanBufs sb, int n) {
     using R = typename Op::R;
     using Full = typename Op::Full;
-    const long long g = (long long)blockIdx.x * TB_SCAN + threadIdx.x;
-    if (g >= (long long)S * nchunk) return;
-    const int s = (int)(g / nchunk), ch = (int)(g % nchunk);
-    const int i0 = ch * E;
-    const int i1 = min(n, i0 + E);
-    Full acc, cur, nxt;
-    Op::load(a, s, i0, acc);
-    if (i0 + 1 < i1) Op::load(a, s, i0 + 1, nxt);
-    for (int i = i0 + 1; i < i1; ++i) {
-        cur = nxt;
-        if (i + 1 < i1) Op::load(a, s, i + 1, nxt);  // software prefetch of the next element
-        Full o;
-        Op::combine(acc, cur, o);
-        acc = o;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ScanLayout lay = Op::layout(a);
+    const int s = blockIdx.x / lay.ngrp, grp = blockIdx.x % lay.ngrp;
+    const int lane = threadIdx.x;
+    const int ch = grp * lay.W + lane;
+    const bool inrow = lane < lay.W;
+    const bool live = inrow && ch < lay.nchunk;
+    const int len = live ? min(lay.E, n - ch * lay.E) : 0;
+    WaveIO<R> io{(R*)smem, lane, lay.W};
+    R rec[Full::NPAD], nxt[Full::NPAD];
+    Full acc;
+    io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 0) + (long long)lane * Full::NPAD, Full::NPAD, inrow, rec);
+    io.template finish<R, Full::NPAD>(Full::NPAD, inrow, rec);
+    Op::unpack(rec, acc);
+    if (lay.E > 1) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 1) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+    for (int k = 1; k < lay.E; ++k) {
+#pragma unroll
+        for (int e = 0; e < Full::NPAD; ++e) rec[e] = nxt[e];
+        io.template finish<R, Full::NPAD>(Full::NPAD, inrow, rec);
+        // the next row's global reads fly while this row is combined
+        if (k + 1 < lay.E) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, k + 1) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+        if (k < len) {
+            Full cur, o;
+            Op::unpack(rec, cur);
+            Op::combine(acc, cur, o);
+            acc = o;
+        }
     }
-    Op::store_rec((R*)sb.agg + g * Full::NPAD, acc);
+    if (live) Op::store_rec((R*)sb.agg + ((long long)s * lay.nchunk + ch) * Full::NPAD, acc);
 }
 
 template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanBufs sb, int nchunk) {
@@ -191,32 +288,42 @@ template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanB
 }
 
 template <class Op>
-__global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, ScanBufs sb, int S, int n, int E, int nchunk) {
+__global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, ScanBufs sb, int n) {
     using R = typename Op::R;
     using Full = typename Op::Full;
     using Pre = typename Op::Pre;
-    const long long g = (long long)blockIdx.x * TB_SCAN + threadIdx.x;
-    if (g >= (long long)S * nchunk) return;
-    const int s = (int)(g / nchunk), ch = (int)(g % nchunk);
-    const int i0 = ch * E;
-    const int i1 = min(n, i0 + E);
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ScanLayout lay = Op::layout(a);
+    const int s = blockIdx.x / lay.ngrp, grp = blockIdx.x % lay.ngrp;
+    const int lane = threadIdx.x;
+    const int ch = grp * lay.W + lane;
+    const bool inrow = lane < lay.W;
+    const bool live = inrow && ch < lay.nchunk;
+    const int len = live ? min(lay.E, n - ch * lay.E) : 0;
     Pre p;
-    if (nchunk > 1) {
-        Op::load_pre((const R*)sb.pre + g * Pre::NPAD, p);
+    if (lay.nchunk > 1 && live) {
+        Op::load_pre((const R*)sb.pre + ((long long)s * lay.nchunk + ch) * Pre::NPAD, p);
     } else {
         Full id;
         Op::identity(id);
         Op::to_pre(id, p);
     }
-    Full cur, nxt;
-    if (i0 < i1) Op::load(a, s, i0, nxt);
-    for (int i = i0; i < i1; ++i) {
-        cur = nxt;
-        if (i + 1 < i1) Op::load(a, s, i + 1, nxt);
-        Pre o;
-        Op::apply(p, cur, o);
-        p = o;
-        Op::write_out(a, s, i, p);
+    WaveIO<R> io{(R*)smem, lane, lay.W};
+    R rec[Full::NPAD], nxt[Full::NPAD];
+    io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 0) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+    for (int k = 0; k < lay.E; ++k) {
+#pragma unroll
+        for (int e = 0; e < Full::NPAD; ++e) rec[e] = nxt[e];
+        io.template finish<R, Full::NPAD>(Full::NPAD, inrow, rec);
+        if (k + 1 < lay.E) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, k + 1) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+        if (k < len) {
+            Full cur;
+            Pre o;
+            Op::unpack(rec, cur);
+            Op::apply(p, cur, o);
+            p = o;
+            Op::write_out(a, s, ch * lay.E + k, p);
+        }
     }
 }
 
@@ -225,22 +332,27 @@ template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int 
     if (pl.nchunk <= 1) return 0;
     return (size_t)S * pl.nchunk * (Op::Full::NPAD + Op::Pre::NPAD) * sizeof(typename Op::R) + 512;
 }
+inline ScanLayout make_layout(const ScanPlan& pl) {
+    const int W = pl.nchunk < 64 ? pl.nchunk : 64;
+    return ScanLayout{pl.E, pl.nchunk, (pl.nchunk + W - 1) / W, W};
+}
 
-template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n, int parallel) {
+// `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
+template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
-    const ScanPlan pl = plan_scan(h, S, n, parallel);
+    const ScanLayout lay = Op::layout(a);
     ScanBufs sb{nullptr, nullptr};
-    const long long nthreads = (long long)S * pl.nchunk;
-    const unsigned grid = (unsigned)((nthreads + TB_SCAN - 1) / TB_SCAN);
-    if (pl.nchunk > 1) {
-        sb.agg = ws_take(h, (size_t)S * pl.nchunk * Op::Full::NPAD * sizeof(R));
-        sb.pre = ws_take(h, (size_t)S * pl.nchunk * Op::Pre::NPAD * sizeof(R));
-        hipLaunchKernelGGL((k_scan_reduce<Op>), dim3(grid), dim3(TB_SCAN), 0, h->stream, a, sb, S, n, pl.E, pl.nchunk);
+    const unsigned grid = (unsigned)S * lay.ngrp;
+    const size_t stage = stage_bytes<R>(Op::Full::NPAD);
+    if (lay.nchunk > 1) {
+        sb.agg = ws_take(h, (size_t)S * lay.nchunk * Op::Full::NPAD * sizeof(R));
+        sb.pre = ws_take(h, (size_t)S * lay.nchunk * Op::Pre::NPAD * sizeof(R));
+        hipLaunchKernelGGL((k_scan_reduce<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
         const size_t lds = (size_t)TB_AGGS * Op::Full::NPAD * sizeof(R);
-        hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, pl.nchunk);
+        hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, lay.nchunk);
     }
-    hipLaunchKernelGGL((k_scan_down<Op>), dim3(grid), dim3(TB_SCAN), 0, h->stream, a, sb, S, n, pl.E, pl.nchunk);
+    hipLaunchKernelGGL((k_scan_down<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -250,8 +362,9 @@ inline int ntiles(int n) { return (n + TB_ELEM - 1) / TB_ELEM; }
 
 template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
     const int S = d.S(), n = d.n();
+    const ScanLayout lay = make_layout(plan_scan(h, S, n, parallel));
     size_t b = 0;
-    b += (size_t)S * (n > 0 ? n : 1) * FiltElem<R, D>::NPAD * sizeof(R) + 256;
+    b += (size_t)S * lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + 256;
     b += (size_t)S * sizeof(R) + 256;                           // ell0
     b += (size_t)S * (ntiles(n) + 1) * sizeof(R) + 256;         // ell partials
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
@@ -261,7 +374,8 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
 template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterArgs& a_in, int parallel, void* ell_out) {
     FilterArgs a = a_in;
     const int S = a.d.S(), n = a.d.n();
-    a.elem = ws_take(h, (size_t)S * (n > 0 ? n : 1) * FiltElem<R, D>::NPAD * sizeof(R));
+    a.lay = make_layout(plan_scan(h, S, n, parallel));
+    a.elem = ws_take(h, (size_t)S * a.lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R));
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
     const int nt = ntiles(n);
     R* part = (R*)ws_take(h, (size_t)S * (nt + 1) * sizeof(R));
@@ -269,16 +383,16 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     if (n > 0) {
         {
             ProfScope ps(h, AUXSSM_K_FILTER_INIT);
-            hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3((unsigned)nt * S), dim3(TB_ELEM), 0, h->stream, a);
+            hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n, parallel);
+            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_ELL);
-            hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3((unsigned)nt * S), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+            hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
         }
     }
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0,
@@ -289,20 +403,23 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
 
 template <typename R, int D> size_t sample_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
     const int S = d.S();
-    return (size_t)S * d.T * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel);
+    const ScanLayout lay = make_layout(plan_scan(h, S, d.T, parallel));
+    return (size_t)S * lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel);
 }
 
 template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_in, int parallel) {
     SampleArgs a = a_in;
     const int S = a.d.S(), T = a.d.T;
-    a.elem = ws_take(h, (size_t)S * T * SampElem<R, D>::NPAD * sizeof(R));
+    a.lay = make_layout(plan_scan(h, S, T, parallel));
+    a.elem = ws_take(h, (size_t)S * a.lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R));
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
-        hipLaunchKernelGGL((k_sample_init<R, D>), dim3((unsigned)ntiles(T) * S), dim3(TB_ELEM), 0, h->stream, a);
+        const int nt = ntiles(T - 1) > 0 ? ntiles(T - 1) : 1;
+        hipLaunchKernelGGL((k_sample_init<R, D>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
     }
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
-        const int rc = run_scan<SampleOp<R, D>>(h, a, S, T, parallel);
+        const int rc = run_scan<SampleOp<R, D>>(h, a, S, T);
         if (rc) return rc;
     }
     AX_HIP(hipGetLastError());
@@ -310,15 +427,15 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
 }
 
 template <typename R, int D, int P> size_t logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)d.S() * ntiles(d.T) * sizeof(R) + 256;
+    return (size_t)d.S() * (ntiles(d.T) + 1) * sizeof(R) + 256;
 }
 
 template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfArgs& a, void* out) {
     const int S = a.d.S(), T = a.d.T;
-    const int nt = ntiles(T);
+    const int nt = ntiles(T - 1) > 0 ? ntiles(T - 1) : 1;
     R* part = (R*)ws_take(h, (size_t)S * nt * sizeof(R));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    hipLaunchKernelGGL((k_joint_logpdf<R, D, P>), dim3((unsigned)nt * S), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+    hipLaunchKernelGGL((k_joint_logpdf<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr,
                        a.d.B, nt, (R*)out);
     AX_HIP(hipGetLastError());
@@ -326,14 +443,14 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
 }
 
 template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * ntiles(d.T) * sizeof(R) + 256;
+    return (size_t)5 * d.C * (ntiles(d.T) + 1) * sizeof(R) + 256;
 }
 // out: [5][C]
 template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
-    const int C = a.d.C, nt = ntiles(a.d.T);
+    const int C = a.d.C, nt = ntiles(a.d.T - 1) > 0 ? ntiles(a.d.T - 1) : 1;
     R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3((unsigned)nt * C), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+    hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;

@@ -51,6 +51,43 @@ template <typename R, int N> AX_HD void st(R* __restrict__ p, const R* v) {
     for (int i = 0; i < N; ++i) p[i] = v[i];
 }
 
+// ---- 16-byte vector loads/stores of an internal record (pointer 16-byte aligned, N reals, any tail scalar) -------------------
+#if defined(__HIPCC__)
+template <typename R> struct Vec16;
+template <> struct Vec16<float> { typedef float __attribute__((ext_vector_type(4))) type; static constexpr int W = 4; };
+template <> struct Vec16<double> { typedef double __attribute__((ext_vector_type(2))) type; static constexpr int W = 2; };
+template <typename R, int N> AX_HD void ldv(const R* __restrict__ p, R* out) {
+    using V = typename Vec16<R>::type;
+    constexpr int W = Vec16<R>::W;
+    const V* q = reinterpret_cast<const V*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int i = 0; i < N / W; ++i) {
+        const V v = q[i];
+#pragma unroll
+        for (int k = 0; k < W; ++k) out[i * W + k] = v[k];
+    }
+#pragma unroll
+    for (int i = N / W * W; i < N; ++i) out[i] = p[i];
+}
+template <typename R, int N> AX_HD void stv(R* __restrict__ p, const R* v) {
+    using V = typename Vec16<R>::type;
+    constexpr int W = Vec16<R>::W;
+    V* q = reinterpret_cast<V*>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int i = 0; i < N / W; ++i) {
+        V t;
+#pragma unroll
+        for (int k = 0; k < W; ++k) t[k] = v[i * W + k];
+        q[i] = t;
+    }
+#pragma unroll
+    for (int i = N / W * W; i < N; ++i) p[i] = v[i];
+}
+#else  // host build (tests/hostsim): plain scalar copies
+template <typename R, int N> AX_HD void ldv(const R* p, R* out) { ld<R, N>(p, out); }
+template <typename R, int N> AX_HD void stv(R* p, const R* v) { st<R, N>(p, v); }
+#endif
+
 // ---- dense products (row-major) -----------------------------------------------------------------
 // C[M][N] = A[M][K] * B[K][N]
 template <typename R, int M, int K, int N> AX_HD void mm(const R* A, const R* B, R* C) {
@@ -144,10 +181,11 @@ template <typename R, int D> AX_HD void symunpack(const R* S, R* M) {
 }
 
 // ---- Cholesky, packed lower, LAPACK/JAX semantics ------------------------------------------------
-// In: packed-symmetric A (upper storage, size symsize(N)).  Out: packed-lower L.  `skip[k]` marks an index
-// that is treated as deleted (L_kk = 1, off-diagonals 0).  Returns false on failure (pivot <= 0 or NaN);
-// the caller decides what a failed factor means (the reference gets an all-NaN factor from JAX).
-template <typename R, int N> AX_HD bool chol_packed(const R* A, R* L, const bool* skip) {
+// In: packed-symmetric A (upper storage, size symsize(N)).  Out: packed-lower L and the reciprocal diagonal invd
+// (one division per column; the triangular solves below multiply by it -- fp64 division is ~10x an fma on gfx950).
+// `skip[k]` marks an index that is treated as deleted (L_kk = 1, off-diagonals 0).  Returns false on failure
+// (pivot <= 0 or NaN); the caller decides what a failed factor means (the reference gets an all-NaN factor from JAX).
+template <typename R, int N> AX_HD bool chol_packed(const R* A, R* L, R* invd, const bool* skip) {
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
@@ -159,6 +197,7 @@ template <typename R, int N> AX_HD bool chol_packed(const R* A, R* L, const bool
         const R ljj = sk ? (R)1 : sqrt_(s);
         L[lidx(j, j)] = ljj;
         const R inv = (R)1 / ljj;
+        invd[j] = inv;
 #pragma unroll
         for (int i = j + 1; i < N; ++i) {
             R t = A[sidx_u(N, j, i)];
@@ -170,51 +209,79 @@ template <typename R, int N> AX_HD bool chol_packed(const R* A, R* L, const bool
     }
     return ok;
 }
-// dense symmetric input (full D x D row-major) convenience
-template <typename R, int N> AX_HD bool chol_dense(const R* A, R* L) {
-    R S[symsize(N)];
+// In-place variant: A holds the symmetric matrix in LOWER-packed storage (lidx) on entry and L on exit.
+template <typename R, int N> AX_HD bool chol_inplace(R* A, R* invd, const bool* skip) {
+    bool ok = true;
 #pragma unroll
-    for (int i = 0; i < N; ++i)
+    for (int j = 0; j < N; ++j) {
+        R s = A[lidx(j, j)];
 #pragma unroll
-        for (int j = i; j < N; ++j) S[sidx_u(N, i, j)] = A[i * N + j];
-    return chol_packed<R, N>(S, L, nullptr);
+        for (int k = 0; k < j; ++k) s -= A[lidx(j, k)] * A[lidx(j, k)];
+        const bool sk = skip ? skip[j] : false;
+        ok = ok && (sk || (s > (R)0));
+        const R ljj = sk ? (R)1 : sqrt_(s);
+        A[lidx(j, j)] = ljj;
+        const R inv = (R)1 / ljj;
+        invd[j] = inv;
+#pragma unroll
+        for (int i = j + 1; i < N; ++i) {
+            R t = A[lidx(i, j)];
+#pragma unroll
+            for (int k = 0; k < j; ++k) t -= A[lidx(i, k)] * A[lidx(j, k)];
+            const bool ski = skip ? (skip[i] || sk) : false;
+            A[lidx(i, j)] = ski ? (R)0 : t * inv;
+        }
+    }
+    return ok;
 }
 // solve L z = b in place
-template <typename R, int N> AX_HD void lsolve(const R* L, R* b) {
+template <typename R, int N> AX_HD void lsolve(const R* L, const R* invd, R* b) {
 #pragma unroll
     for (int i = 0; i < N; ++i) {
         R s = b[i];
 #pragma unroll
         for (int k = 0; k < i; ++k) s -= L[lidx(i, k)] * b[k];
-        b[i] = s / L[lidx(i, i)];
+        b[i] = s * invd[i];
     }
 }
 // solve L^T z = b in place
-template <typename R, int N> AX_HD void ltsolve(const R* L, R* b) {
+template <typename R, int N> AX_HD void ltsolve(const R* L, const R* invd, R* b) {
 #pragma unroll
     for (int i = N - 1; i >= 0; --i) {
         R s = b[i];
 #pragma unroll
         for (int k = i + 1; k < N; ++k) s -= L[lidx(k, i)] * b[k];
-        b[i] = s / L[lidx(i, i)];
+        b[i] = s * invd[i];
     }
 }
-template <typename R, int N> AX_HD void cho_solve(const R* L, R* b) {
-    lsolve<R, N>(L, b);
-    ltsolve<R, N>(L, b);
+template <typename R, int N> AX_HD void cho_solve(const R* L, const R* invd, R* b) {
+    lsolve<R, N>(L, invd, b);
+    ltsolve<R, N>(L, invd, b);
 }
-// solve with a strided right-hand side: column `col` of a row-major [N][NC] matrix, in place
-template <typename R, int N, int NC> AX_HD void cho_solve_col(const R* L, R* Bm, int col) {
-    R t[N];
+// column `col` of a row-major [N][NC] matrix, in place
+template <typename R, int N, int NC> AX_HD void lsolve_col(const R* L, const R* invd, R* Bm, int col) {
 #pragma unroll
-    for (int i = 0; i < N; ++i) t[i] = Bm[i * NC + col];
-    cho_solve<R, N>(L, t);
+    for (int i = 0; i < N; ++i) {
+        R s = Bm[i * NC + col];
 #pragma unroll
-    for (int i = 0; i < N; ++i) Bm[i * NC + col] = t[i];
+        for (int k = 0; k < i; ++k) s -= L[lidx(i, k)] * Bm[k * NC + col];
+        Bm[i * NC + col] = s * invd[i];
+    }
+}
+template <typename R, int N, int NC> AX_HD void cho_solve_col(const R* L, const R* invd, R* Bm, int col) {
+    lsolve_col<R, N, NC>(L, invd, Bm, col);
+#pragma unroll
+    for (int i = N - 1; i >= 0; --i) {
+        R s = Bm[i * NC + col];
+#pragma unroll
+        for (int k = i + 1; k < N; ++k) s -= L[lidx(k, i)] * Bm[k * NC + col];
+        Bm[i * NC + col] = s * invd[i];
+    }
 }
 
 // ---- LU with partial pivoting, W [D][D] destroyed, RHS [D][NR] overwritten by W^{-1} RHS -----------------
 template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) {
+    R ipiv[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         // bring the largest |W[r][k]|, r >= k, to row k by compare-and-swap (branch-free selects)
@@ -235,6 +302,7 @@ template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) {
             }
         }
         const R inv = (R)1 / W[k * D + k];
+        ipiv[k] = inv;
 #pragma unroll
         for (int r = k + 1; r < D; ++r) {
             const R f = W[r * D + k] * inv;
@@ -246,7 +314,7 @@ template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) {
     }
 #pragma unroll
     for (int k = D - 1; k >= 0; --k) {
-        const R inv = (R)1 / W[k * D + k];
+        const R inv = ipiv[k];
 #pragma unroll
         for (int j = 0; j < NR; ++j) {
             R s = B[k * NR + j];

@@ -15,22 +15,34 @@ using namespace ax;
 struct HsArr { const void* ptr; long long sc, st, sb; };
 static Arr cv(const HsArr& a) { return Arr{a.ptr, a.sc, a.st, a.sb}; }
 
-template <class Op> static void scan_host(typename Op::Args& a, int S, int n, int E) {
+static ScanLayout make_layout_host(int n, int E) {
+    if (E <= 0 || E > n) E = n > 0 ? n : 1;
+    const int nchunk = n > 0 ? (n + E - 1) / E : 1;
+    const int W = nchunk < 64 ? nchunk : 64;
+    return ScanLayout{E, nchunk, (nchunk + W - 1) / W, W};
+}
+
+template <class Op> static void scan_host(typename Op::Args& a, int S, int n) {
+    using R = typename Op::R;
     using Full = typename Op::Full;
     using Pre = typename Op::Pre;
     if (n <= 0) return;
-    if (E <= 0 || E > n) E = n;
-    const int nchunk = (n + E - 1) / E;
+    const ScanLayout lay = Op::layout(a);
+    const int E = lay.E, nchunk = lay.nchunk;
+    auto load = [&](int s, int i, Full& e) {
+        const int ch = i / E, k = i % E, g = ch / lay.W, l = ch % lay.W;
+        Op::load_rec(Op::row_ptr(a, s, g, k) + (long long)l * Full::NPAD, e);
+    };
     std::vector<Full> agg((size_t)S * nchunk);
     std::vector<Pre> pre((size_t)S * nchunk);
     for (int s = 0; s < S; ++s)
         for (int ch = 0; ch < nchunk; ++ch) {
             const int i0 = ch * E, i1 = std::min(n, i0 + E);
             Full acc;
-            Op::load(a, s, i0, acc);
+            load(s, i0, acc);
             for (int i = i0 + 1; i < i1; ++i) {
                 Full e, o;
-                Op::load(a, s, i, e);
+                load(s, i, e);
                 Op::combine(acc, e, o);
                 acc = o;
             }
@@ -53,7 +65,7 @@ template <class Op> static void scan_host(typename Op::Args& a, int S, int n, in
             for (int i = i0; i < i1; ++i) {
                 Full e;
                 Pre o;
-                Op::load(a, s, i, e);
+                load(s, i, e);
                 Op::apply(p, e, o);
                 p = o;
                 Op::write_out(a, s, i, p);
@@ -69,19 +81,21 @@ static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E,
     a.Hs = cv(g[5]); a.Rs = cv(g[6]); a.cs = cv(g[7]); a.ys = cv(*ys);
     a.ms = ms; a.Ps = Ps;
     const int S = C * B, n = T - 1;
-    std::vector<R> elem((size_t)S * std::max(n, 1) * FiltElem<R, D>::NPAD), ell0(S);
+    a.lay = make_layout_host(n, E);
+    std::vector<R> elem((size_t)S * a.lay.seq_records() * FiltElem<R, D>::NPAD + 16), ell0(S);
     a.elem = elem.data();
     a.ell0 = ell0.data();
+    DirectIO io;
     for (int s = 0; s < S; ++s) body_filter_t0<R, D, P>(a, s);
     for (int s = 0; s < S; ++s)
-        for (int i = 0; i < n; ++i) body_filter_init<R, D, P>(a, s, i);
-    scan_host<FilterOp<R, D>>(a, S, n, E);
+        for (int i = 0; i < n; ++i) body_filter_init<R, D, P>(a, io, s, i, true);
+    scan_host<FilterOp<R, D>>(a, S, n);
     for (int c = 0; c < C; ++c) {
         R tot = 0;
         for (int b = 0; b < B; ++b) {
             const int s = c * B + b;
             R e = ell0[s];
-            for (int i = 0; i < n; ++i) e += body_filter_ell<R, D, P>(a, s, i);
+            for (int i = 0; i < n; ++i) e += body_filter_ell<R, D, P>(a, io, s, i, true);
             tot += e;
         }
         ((R*)ell)[c] = tot;
@@ -96,11 +110,15 @@ static int sample_T(int C, int T, int B, const HsArr* g, const void* ms, const v
     a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
     a.ms = ms; a.Ps = Ps; a.eps = eps; a.xs = xs;
     const int S = C * B;
-    std::vector<R> elem((size_t)S * T * SampElem<R, D>::NPAD);
+    a.lay = make_layout_host(T, E);
+    std::vector<R> elem((size_t)S * a.lay.seq_records() * SampElem<R, D>::NPAD + 16);
     a.elem = elem.data();
-    for (int s = 0; s < S; ++s)
-        for (int j = 0; j < T; ++j) body_sample_init<R, D>(a, s, j);
-    scan_host<SampleOp<R, D>>(a, S, T, E);
+    DirectIO io;
+    for (int s = 0; s < S; ++s) {
+        body_sample_last<R, D>(a, s);
+        for (int jp = 0; jp < T - 1; ++jp) body_sample_init<R, D>(a, io, s, jp, true);
+    }
+    scan_host<SampleOp<R, D>>(a, S, T);
     return 0;
 }
 
@@ -111,10 +129,13 @@ static int logpdf_T(int C, int T, int B, const HsArr* g, const HsArr* ys, const 
     a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
     a.Hs = cv(g[5]); a.Rs = cv(g[6]); a.cs = cv(g[7]); a.ys = cv(*ys); a.xs = cv(*xs);
     a.nan_policy = pol;
+    DirectIO io;
     for (int c = 0; c < C; ++c) {
         R tot = 0;
-        for (int b = 0; b < B; ++b)
-            for (int t = 0; t < T; ++t) tot += body_joint_logpdf<R, D, P>(a, c * B + b, t);
+        for (int b = 0; b < B; ++b) {
+            tot += body_joint_logpdf_head<R, D, P>(a, c * B + b);
+            for (int i = 0; i < T - 1; ++i) tot += body_joint_logpdf<R, D, P>(a, io, c * B + b, i, true);
+        }
         ((R*)out)[c] = tot;
     }
     return 0;
