@@ -142,6 +142,7 @@ struct Smem {
 };
 
 // normalize (math/utils.py:23-39): w = exp(lw - logsumexp(lw)); logsumexp = log(sum(exp(lw - max))) + max
+// red: 32 slots (max in [0,16), sum in [16,32)); the caller guarantees a barrier between two calls (the cumsum's).
 template <typename R> __device__ __forceinline__ R block_normalize(R lw, R* red, int tid, int nw) {
     const int lane = tid & 63, wv = tid >> 6;
     R m = wave_max(lw);
@@ -149,29 +150,27 @@ template <typename R> __device__ __forceinline__ R block_normalize(R lw, R* red,
     __syncthreads();
     m = red[0];
     for (int k = 1; k < nw; ++k) m = m > red[k] ? m : red[k];
-    __syncthreads();
     if (!(m - m == 0)) m = 0;  // non-finite max -> 0 (jax logsumexp)
     const R e = det_exp(lw - m);
     R s = wave_sum_tree(e);
-    if (lane == 0) red[wv] = s;
+    if (lane == 0) red[16 + wv] = s;
     __syncthreads();
-    s = red[0];
-    for (int k = 1; k < nw; ++k) s += red[k];
-    __syncthreads();
+    s = red[16];
+    for (int k = 1; k < nw; ++k) s += red[16 + k];
     const R lse = det_log(s) + m;
     return det_exp(lw - lse);
 }
 
-// inclusive cumsum of w into c[]; returns nothing, c[] valid after the trailing barrier
+// inclusive cumsum of w into c[] (slots [32,48) of red hold the wave totals); c[] valid after the trailing barrier
 template <typename R> __device__ __forceinline__ void block_cumsum(R w, R* c, R* red, int tid, int nw) {
     const int lane = tid & 63, wv = tid >> 6;
     const R v = wave_scan_ks(w, lane);
-    if (lane == 63) red[wv] = v;
+    if (lane == 63) red[32 + wv] = v;
     __syncthreads();
     R pre = 0;
     if (wv > 0) {
-        pre = red[0];
-        for (int k = 1; k < wv; ++k) pre += red[k];
+        pre = red[32];
+        for (int k = 1; k < wv; ++k) pre += red[32 + k];
     }
     c[tid] = wv > 0 ? pre + v : v;
     __syncthreads();
@@ -202,9 +201,11 @@ template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
 template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
-    R* c = (R*)smem;              // [TB]
-    R* xprev = c + TB;            // [TB][D]
-    R* red = xprev + TB * D;      // [16]
+    // two images of (c, xprev), alternated by time-step parity: readers of step t never race writers of step t+1,
+    // which removes the end-of-step barrier (4 barriers per step: max, sum, wave totals, publish)
+    R* cbuf = (R*)smem;                 // [2][TB]
+    R* xbuf = cbuf + 2 * TB;            // [2][TB][D]
+    R* red = xbuf + 2 * TB * D;         // [48]
     const int ch = blockIdx.x;
     const bool live = tid < N;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
@@ -264,6 +265,8 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         }
         if (live) un = noise_uniform<R>(a, a.u_res, STREAM_U_RES, ures_base + (long long)(t - 1) * N + tid);
         // conditional multinomial resampling (resamplings.py:14-37 -> jax.random.choice: cumsum, r = c[-1] (1-u), searchsorted)
+        R* c = cbuf + (t & 1) * TB;
+        R* xprev = xbuf + (t & 1) * TB * D;
 #pragma unroll
         for (int k = 0; k < D; ++k) xprev[tid * D + k] = x[k];
         block_cumsum<R>(w, c, red, tid, nw);  // trailing barrier also publishes xprev
@@ -314,7 +317,6 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
             lws[o] = lw;
             if (As) As[(long long)(t - 1) * N + tid] = idx;
         }
-        __syncthreads();  // everyone is done reading c / xprev
         w = block_normalize<R>(lw, red, tid, nw);
     }
     if (live) ((R*)a.wT)[(long long)ch * N + tid] = w;
@@ -326,7 +328,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     R* c = (R*)smem;
     R* red = c + TB;
-    int& sB = *(int*)(red + 16);
+    int& sB = *(int*)(red + 48);
     const int ch = blockIdx.x;
     const bool live = tid < N;
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
@@ -448,12 +450,12 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
-        const size_t lds = (size_t)TB * (1 + D) * sizeof(R) + 16 * sizeof(R) + 64;
+        const size_t lds = (size_t)2 * TB * (1 + D) * sizeof(R) + 48 * sizeof(R) + 64;
         hipLaunchKernelGGL((k_csmc_fwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_BWD);
-        const size_t lds = (size_t)TB * sizeof(R) + 16 * sizeof(R) + 64;
+        const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + 64;
         hipLaunchKernelGGL((k_csmc_bwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
     }
     AX_HIP(hipGetLastError());

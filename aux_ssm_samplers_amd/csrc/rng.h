@@ -31,12 +31,20 @@ template <typename R> AX_HD R bits_to_uniform(uint32_t b);
 template <> AX_HD float bits_to_uniform<float>(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }
 template <> AX_HD double bits_to_uniform<double>(uint32_t b) { return (double)b * 2.3283064365386963e-10; }
 
-// Box-Muller on two 32-bit words: u1 = (b0 + 0.5) 2^-32 in (0,1), u2 = (b1 + 0.5) 2^-32
-template <typename R> AX_HD R bits_to_normal(uint32_t b0, uint32_t b1) {
+// Box-Muller on two 32-bit words.  fp64: u = (b + 0.5) 2^-32 in (0,1), double math.  fp32: u = ((b >> 8) + 0.5) 2^-24,
+// float math throughout (the cSMC kernels draw N of these per time step; fp64 log/cos there cost more than the step).
+template <typename R> AX_HD R bits_to_normal(uint32_t b0, uint32_t b1);
+template <> AX_HD double bits_to_normal<double>(uint32_t b0, uint32_t b1) {
     const double u1 = ((double)b0 + 0.5) * 2.3283064365386963e-10;
     const double u2 = ((double)b1 + 0.5) * 2.3283064365386963e-10;
     const double r = sqrt(-2.0 * log(u1));
-    return (R)(r * cos(6.283185307179586476925286766559 * u2));
+    return r * cos(6.283185307179586476925286766559 * u2);
+}
+template <> AX_HD float bits_to_normal<float>(uint32_t b0, uint32_t b1) {
+    const float u1 = ((float)(b0 >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float u2 = ((float)(b1 >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    const float r = sqrtf(-2.0f * logf(u1));
+    return r * cosf(6.283185307179586f * u2);
 }
 
 }  // namespace ax

@@ -60,6 +60,111 @@ def cpu_baseline(T, d, budget_s=20.0):
                 sample=f"{n} sweep(s) of 1 chain, same T={T} d={d} fp64 workload, NumPy oracle parallel path, {el:.1f} s")
 
 
+def sv_data(T, seed=0):
+    """Stochastic-volatility data of config C3 (examples/stochastic_volatility/model.py:11-53; nu=0, phi=.9, tau=2, d=1)."""
+    phi, tau = 0.9, 2.0
+    q = tau / (1 - phi ** 2)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    e = rng.standard_normal(T)
+    x = np.empty(T)
+    x[0] = np.sqrt(q) * e[0]
+    for t in range(1, T):
+        x[t] = phi * x[t - 1] + np.sqrt(q) * e[t]
+    y = np.exp(0.5 * x) * rng.standard_normal(T)
+    return phi, q, x[:, None], y[:, None]
+
+
+def run_csmc(args, rank, world, local_rank, dist, torch):
+    """Secondary workload: BASELINE configs[2] = C3, SV d=1 T=65536, auxiliary cSMC with independent proposals, N=1024,
+    backward sampling, fp32, in-kernel Threefry noise.  One step = one sweep of every chain on this GPU."""
+    import ctypes as C
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics, SVPotential
+    from aux_ssm_samplers_amd.parallel import gather_chains
+    T, N, Cn = args.T, args.N, args.chains
+    dtype = np.float32 if args.dtype == "f32" else np.float64
+    phi, q, xtrue, y = sv_data(T)
+    M0 = GaussianInit(m0=[0.0], P0=[[q]])
+    Mt = LinearGaussianDynamics(F=[[phi]], b=[0.0], Q=[[q]])
+    fk = _device.describe_independent(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), Mt)
+    handle = _lib.default_handle(local_rank)
+    rng = np.random.Generator(np.random.PCG64(1000 + rank))
+    x0 = (xtrue[None] + 0.1 * rng.standard_normal((Cn, T, 1))).astype(dtype)
+    xd = handle.to_device(x0)
+    anc = handle.zeros((Cn, T), np.int32)
+    yd = fk.ydev(handle, dtype)
+    shd = handle.to_device(np.full(T, np.sqrt(0.25)), dtype)
+    m = _lib.FkModel(fk.proposal, fk.potential, 1, 0, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
+                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, yd.ptr.value, 1.0)
+    keys = R.split(R.PRNGKey(77 + rank), args.steps + args.warmup + 1)
+
+    def step(k):
+        nz = _lib.CsmcNoise()
+        nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(keys[k][0]), int(keys[k][1])
+        _lib.check(handle.lib.auxssm_csmc_sweep(handle.h, _lib.dtype_code(dtype), C.byref(m), Cn, T, N, 1, shd.ptr, xd.ptr,
+                                                C.byref(nz), anc.ptr, None, None, None))
+
+    def barrier():
+        handle.sync()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        handle.sync()
+
+    for k in range(args.warmup):
+        step(k)
+    barrier()
+    handle.prof_enable(_lib.K_CSMC_FWD, args.steps + 1)
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(args.warmup + k)
+    barrier()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    fn, fms = handle.prof_read()
+    handle.prof_disable()
+    moved = (anc.to_host() != 0).mean(axis=1)  # per-chain fraction of updated time steps
+    if dist is not None:
+        g = gather_chains(moved[:, None], Cn * world, dist, dst=0, device=torch.device("cuda", local_rank))
+        moved = g[:, 0] if rank == 0 else moved
+    if rank == 0:
+        s = np.dtype(dtype).itemsize
+        alg = Cn * T * N * (1 * s + s)  # forward pass writes xs + log_ws (SURVEY 8d; As is not stored with backward sampling)
+        roof = None
+        if fn:
+            ach = alg / (fms / fn * 1e-3) / 1e9
+            roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=None,
+                        kernel="k_csmc_fwd<float,1> (persistent forward pass)", avg_launch_ms=round(fms / fn, 3), launches=fn,
+                        algorithmic_bytes_per_launch=alg)
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            from oracle import csmc as O
+            Tb = min(T, 4096)
+            r2 = np.random.default_rng(0)
+            od = dict(proposal=O.AUX_INDEPENDENT, potential=O.POT_SV, m0=[0.0], chol_P0=[[np.sqrt(q)]], F=[[phi]], b=[0.0], chol_Q=[[np.sqrt(q)]])
+            kw = dict(y=y[:Tb], sqrt_half_delta=np.full(Tb, 0.5), eps_aux=r2.standard_normal((Tb, 1)), eps_prop=r2.standard_normal((Tb, N, 1)),
+                      u_res=r2.random((Tb - 1, N)), u_bwd=r2.random(Tb))
+            t1 = time.perf_counter()
+            O.sweep(od, xtrue[:Tb], N, True, dtype=np.float32, **kw)
+            dt = time.perf_counter() - t1
+            cpu = dict(value=1.0 / (dt * T / Tb), unit="sweeps/s", cores=1, kind="port",
+                       sample=f"1 sweep of 1 chain at T={Tb} (scaled linearly to T={T}), N={N}, C oracle csmc_ref.c, {dt:.1f} s")
+        print(json.dumps({
+            "metric": "Gibbs sweeps/sec (auxiliary cSMC, backward sampling)", "value": round(Cn * world * args.steps / el, 2),
+            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"C3: stochastic volatility d=1 T={T}, auxiliary cSMC N={N}, independent proposals, backward sampling",
+                       "chains_per_gpu": Cn, "delta": 0.5, "parallelism": f"chains x{world} (independent, no collective)"},
+            "updated_fraction": float(np.mean(moved)), "roofline": roof, "cpu_baseline": cpu}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -71,7 +176,12 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the scan with HIP events")
+    ap.add_argument("--workload", default="kalman", choices=["kalman", "csmc"],
+                    help="kalman = BASELINE configs[1] (C2, the headline); csmc = configs[2] (C3), secondary")
+    ap.add_argument("--N", type=int, default=1024, help="particles (csmc workload)")
     args = ap.parse_args()
+    if args.workload == "csmc" and args.dtype == "f64" and "--dtype" not in " ".join(sys.argv):
+        args.dtype = "f32"
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -84,6 +194,9 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(local_rank)
+
+    if args.workload == "csmc":
+        return run_csmc(args, rank, world, local_rank, dist, torch)
 
     from aux_ssm_samplers_amd import _lib, random as R
     from aux_ssm_samplers_amd.kalman import get_kernel
