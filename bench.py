@@ -262,11 +262,17 @@ def main():
         n = T - 1
         alg_bytes = C * (n * (3 * d * d + 2 * d) * s + n * (d * d + d) * s)
         roof = None
+        traffic = None  # HBM bytes per launch group from the PMC passes committed under profiles/ (same config only)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            traffic = tj.get(f"kalman_C2_{args.dtype}_T{T}_d{d}_chains{C}", {}).get("filter_scan_group_hbm_bytes")
+        except Exception:
+            pass
         if scan_n:
             avg_s = scan_ms / scan_n * 1e-3
             ach = alg_bytes / avg_s / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4),
-                        traffic=None, kernel="filter associative scan (k_scan_reduce+k_scan_aggs+k_scan_down<FilterOp>)",
+                        traffic=traffic, kernel="filter associative scan (k_scan_reduce+k_scan_aggs+k_scan_down<FilterOp>)",
                         avg_launch_ms=round(scan_ms / scan_n, 4), launches=scan_n, algorithmic_bytes_per_launch=alg_bytes)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
