@@ -87,6 +87,7 @@ def load():
         "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
+        "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
     }

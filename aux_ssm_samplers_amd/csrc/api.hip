@@ -1,6 +1,7 @@
 // api.hip -- the C ABI of libauxssm.so (include/auxssm.h): handle, workspace, dispatch, the fused
 // auxiliary-Kalman sweep and the Threefry fill kernels.
 #include <cstdarg>
+#include <cstdlib>
 #include <cstring>
 
 #include "ctx.h"
@@ -53,13 +54,19 @@ ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
         p.nchunk = 1;
         return p;
     }
-    const long long target = (long long)h->num_cu * 4 * 64 * 2;  // two waves per SIMD
+    // one wave per SIMD: the fp64 d=4 combine needs ~400 unified registers, so that is the residency anyway, and fewer,
+    // longer chunks halve the aggregate-scan work (measured on C2 x 64 chains: E = 64 beats 16/32/48/96)
+    const long long target = (long long)h->num_cu * 4 * 64;
     long long E = ((long long)S * n + target - 1) / target;
     long long emin = (long long)(sqrt((double)n / 43.0) + 0.5);
     if (emin < 2) emin = 2;
     if (emin > 32) emin = 32;
     if (E < emin) E = emin;
     if (E > 512) E = 512;
+    if (const char* ev = getenv("AUXSSM_SCAN_E")) {  // tuning/debug override
+        const long long v = atoll(ev);
+        if (v >= 1 && v <= 4096) E = v;
+    }
     p.E = (int)E;
     p.nchunk = (int)((n + E - 1) / E);
     return p;

@@ -401,6 +401,35 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(
     }
 }
 
+// ---- standalone primitives: normalize (math/utils.py:23-39) and conditional multinomial resampling (resamplings.py:14-37),
+// one workgroup per row, exactly the block primitives of the forward pass
+template <typename R> __global__ void __launch_bounds__(1024) k_normalize_resample(int N, const R* lw, const R* w_in, const R* un, R* w_out, int32_t* idx) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x;
+    R* c = (R*)smem;
+    R* red = c + TB;
+    const long long row = (long long)blockIdx.x * N;
+    const bool live = tid < N;
+    R w;
+    if (lw) {
+        w = block_normalize<R>(live ? lw[row + tid] : (R)-INFINITY, red, tid, nw);
+        if (live && w_out) w_out[row + tid] = w;
+    } else {
+        w = live ? w_in[row + tid] : (R)0;
+    }
+    if (!idx) return;
+    block_cumsum<R>(w, c, red, tid, nw);
+    if (live) {
+        int i = 0;
+        if (tid > 0) {
+            const R r = c[N - 1] * ((R)1 - un[row + tid]);
+            i = lower_bound<R>(c, N, r);
+            i = i < N - 1 ? i : N - 1;
+        }
+        idx[row + tid] = i;
+    }
+}
+
 template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model* fk, const double* host) {
     // host = [m0 (D) | chol_P0 (D*D) | F (D*D) | b (D) | chol_Q (D*D)] as doubles
     const int D = fk->dx;
@@ -465,6 +494,40 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
 }  // namespace ax
 
 using namespace ax;
+
+extern "C" int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t N, const void* log_weights,
+                                         const void* weights, const void* uniforms, void* weights_out, int32_t* indices) {
+    if (!h) {
+        set_error("handle is NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    AX_HIP(hipSetDevice(h->device));
+    if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
+        set_error("dtype must be 0 (f32) or 1 (f64)");
+        return AUXSSM_ERR_ARG;
+    }
+    if (rows < 1 || N < 1 || N > 1024) {
+        set_error("need rows >= 1 and 1 <= N <= 1024");
+        return AUXSSM_ERR_ARG;
+    }
+    if ((!log_weights) == (!weights)) {
+        set_error("give exactly one of log_weights / weights");
+        return AUXSSM_ERR_ARG;
+    }
+    if (indices && !uniforms) {
+        set_error("indices need uniforms");
+        return AUXSSM_ERR_ARG;
+    }
+    const int TB = (N + 63) / 64 * 64;
+    if (dtype == AUXSSM_F32)
+        hipLaunchKernelGGL((k_normalize_resample<float>), dim3(rows), dim3(TB), (size_t)TB * 4 + 48 * 4 + 64, h->stream, N,
+                           (const float*)log_weights, (const float*)weights, (const float*)uniforms, (float*)weights_out, indices);
+    else
+        hipLaunchKernelGGL((k_normalize_resample<double>), dim3(rows), dim3(TB), (size_t)TB * 8 + 48 * 8 + 64, h->stream, N,
+                           (const double*)log_weights, (const double*)weights, (const double*)uniforms, (double*)weights_out, indices);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
 
 extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* fk, int32_t C, int32_t T, int32_t N,
                                  int32_t backward, const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise,

@@ -17,7 +17,7 @@ namespace ax {
 
 constexpr int TB_ELEM = 128;  // elementwise kernels: threads per workgroup
 constexpr int TB_SCAN = 64;   // chunk kernels: one wave per workgroup
-constexpr int TB_AGGS = 128;  // aggregate scan: threads per sequence
+constexpr int TB_AGGS = 256;  // aggregate scan: threads per sequence
 
 // ---- block-wide deterministic sum (fixed tree) ------------------------------------------------------------
 template <typename R, int TB> __device__ __forceinline__ R block_sum(R v, R* sh) {

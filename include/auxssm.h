@@ -194,6 +194,14 @@ int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* model, 
                       int32_t backward, const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise,
                       int32_t* ancestors, void* xs_out, void* log_ws_out, int32_t* As_out);
 
+/* auxssm_normalize_resample == normalize(log_weights) (_primitives/math/utils.py:23-39) and/or
+ * multinomial(key, weights) (_primitives/csmc/resamplings.py:14-37) with the U[0,1) draws given explicitly, for `rows`
+ * independent weight vectors of length N <= 1024 (row-major).  Give log_weights (-> normalised weights in weights_out, may be
+ * NULL) or already normalised weights; if `indices` is non-NULL the conditional multinomial ancestors (index 0 pinned to 0)
+ * are written from `uniforms` (rows, N).  Same reduction orders and exp/log as the cSMC kernels (bit-exact vs oracle). */
+int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t N, const void* log_weights, const void* weights,
+                              const void* uniforms, void* weights_out, int32_t* indices);
+
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i): see oracle/rng_np.py for the restatement. */
 int auxssm_rng_normal(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);

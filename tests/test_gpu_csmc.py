@@ -172,3 +172,34 @@ def test_unsupported_python_models_fail_loudly():
         get_generic_kernel(lambda u, s: None, 8)
     with pytest.raises(ValueError):
         get_generic_kernel(lambda u, s: None, 8, backward=True)  # csmc/generic.py:44-45
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [2, 10, 64, 100, 1024])
+def test_normalize_and_multinomial_primitives_bit_exact(dtype, N):
+    """math/utils.py::normalize and resamplings.py::multinomial as standalone device primitives vs the C oracle."""
+    from aux_ssm_samplers_amd._primitives.math import normalize
+    from aux_ssm_samplers_amd._primitives.csmc.resamplings import multinomial
+    rng = np.random.default_rng(N)
+    lw = (5 * rng.standard_normal((7, N))).astype(dtype)
+    w = normalize(lw)
+    u = rng.random((7, N)).astype(dtype)
+    idx = multinomial(None, w, u=u)
+    for r in range(7):
+        wr = O.normalize(lw[r], dtype)
+        npt.assert_array_equal(w[r], wr)
+        npt.assert_array_equal(idx[r], O.multinomial(wr, u[r], dtype))
+    assert np.all(idx[:, 0] == 0)
+
+
+def test_multinomial_resampling_reference_statistical_test():
+    # test_csmc/test_resamplings.py:11-24 on the HIP path: index 0 always 0, the others ~ weights (atol 1e-3)
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd._primitives.csmc.resamplings import multinomial
+    rng = np.random.default_rng(42)
+    w = rng.random(10)
+    w /= w.sum()
+    idx = multinomial(R.PRNGKey(42), np.broadcast_to(w, (100_000, 10)).copy())
+    assert np.all(idx[:, 0] == 0)
+    cnt = np.bincount(idx[:, 1:].ravel(), minlength=10)
+    npt.assert_allclose(cnt / cnt.sum(), w, atol=2e-3)
