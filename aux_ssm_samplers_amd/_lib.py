@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libauxssm.so")
 F32, F64 = 0, 1
 NAN_REFERENCE, NAN_MASKED = 0, 1
 KMODEL_LG_CONCAT = 1
+LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
  K_CSMC_BWD) = range(9)
 
@@ -85,7 +86,7 @@ def load():
         "auxssm_kalman_filter": ([vp, i32, P(Dims), P(Lgssm), P(Arr), i32, vp, vp, vp], C.c_int),
         "auxssm_kalman_sample": ([vp, i32, P(Dims), P(Lgssm), vp, vp, vp, i32, vp], C.c_int),
         "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
-        "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),

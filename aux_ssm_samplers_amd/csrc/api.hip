@@ -136,10 +136,7 @@ const SweepLogpdfEntry* sweep_logpdf_entry(int dtype, int D, int PO) {
     return nullptr;
 }
 
-static inline Arr cv(const auxssm_arr& a) { return Arr{a.ptr, (long long)a.sc, (long long)a.st, (long long)a.sb}; }
-static inline Arr dense(const void* p, const KDims& d, long long rec) {
-    return Arr{p, (long long)d.T * d.B * rec, (long long)d.B * rec, rec};
-}
+static inline Arr cv(const auxssm_arr& a) { return Arr{a.ptr, (long long)a.sc, (long long)a.st, (long long)a.sb, 1}; }
 
 static int check_dims(const auxssm_dims* d, bool need_dy) {
     if (!d) {
@@ -188,7 +185,9 @@ static void fill_filter_args(FilterArgs& a, const auxssm_dims* d, const auxssm_l
     a.d = KDims{d->C, d->T, d->B};
     a.m0 = cv(g->m0); a.P0 = cv(g->P0); a.Fs = cv(g->Fs); a.Qs = cv(g->Qs); a.bs = cv(g->bs);
     a.Hs = cv(g->Hs); a.Rs = cv(g->Rs); a.cs = cv(g->cs); a.ys = cv(*ys);
-    a.ms = ms; a.Ps = Ps; a.elem = nullptr; a.ell0 = nullptr;
+    a.ms = dense_arr(ms, a.d, d->dx); a.Ps = dense_arr(Ps, a.d, (long long)d->dx * d->dx);
+    a.elem = nullptr; a.ell0 = nullptr;
+    a.lay = ScanLayout{1, 1, 1, 1, 0, d->C * d->B};
 }
 static void fill_logpdf_args(LogpdfArgs& a, const auxssm_dims* d, const auxssm_lgssm* g, const Arr& ys, const Arr& xs, int pol) {
     a.d = KDims{d->C, d->T, d->B};
@@ -221,41 +220,36 @@ __global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cob
         cc[t * P + r] = r < D ? (R)0 : at<R>(cobs, 0, t, 0)[r - D];
     }
 }
-// u = x + sqrt(d/2) eps ; ys_c[c,t,:] = [u ; yobs_t]
+// u = x + sqrt(d/2) eps ; ys_c[c,t,:] = [u ; yobs_t].  x, eps dense (C,T,D); u, ysc through strided views (dense or chain-minor).
+// cfast != 0: consecutive lanes = consecutive chains (coalesced writes of the chain-minor buffers).
+// x, eps, u, ysc through strided views.  cfast != 0 (chain-minor layout everywhere): consecutive lanes = consecutive chains;
+// otherwise lanes run over (t, k) of one chain (dense layout everywhere).  Either way every access of a wave is contiguous.
 template <typename R>
-__global__ void k_concat_obs(int C, int T, int D, int PO, const R* x, const R* eps, R shd, Arr yobs, R* u, R* ysc) {
+__global__ void k_concat_obs(int C, int T, int D, int PO, Arr x, Arr eps, R shd, Arr yobs, Arr u, Arr ysc, int cfast) {
     const int P = D + PO;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)C * T * P) return;
-    const int k = (int)(g % P);
-    const long long ct = g / P;
-    const int c = (int)(ct / T);
-    const long long t = ct % T;
-    if (k < D) {
-        const R v = x[ct * D + k] + shd * eps[ct * D + k];
-        u[ct * D + k] = v;
-        ysc[g] = v;
+    int c, k;
+    long long t;
+    if (cfast) {
+        c = (int)(g % C);
+        const long long r = g / C;
+        k = (int)(r % P);
+        t = r / P;
     } else {
-        ysc[g] = at<R>(yobs, c, t, 0)[k - D];
+        k = (int)(g % P);
+        const long long ct = g / P;
+        c = (int)(ct / T);
+        t = ct % T;
     }
-}
-// corr[c] = sum_{t,k} ((xp-u)^2 - (x-u)^2) / delta     (generic.py:103-105), one workgroup per chain
-template <typename R> __global__ void __launch_bounds__(256) k_correction(long long TD, const R* x, const R* xp, const R* u, R inv_delta, R* out) {
-    __shared__ R sh[256];
-    const int c = blockIdx.x;
-    const long long base = (long long)c * TD;
-    R v = 0;
-    for (long long k = threadIdx.x; k < TD; k += 256) {
-        const R a = xp[base + k] - u[base + k], b = x[base + k] - u[base + k];
-        v += (a * a - b * b) * inv_delta;
+    R* yo = const_cast<R*>(at<R>(ysc, c, t, 0)) + (long long)k * ysc.se;
+    if (k < D) {
+        const R v = at<R>(x, c, t, 0)[(long long)k * x.se] + shd * at<R>(eps, c, t, 0)[(long long)k * eps.se];
+        const_cast<R*>(at<R>(u, c, t, 0))[(long long)k * u.se] = v;
+        *yo = v;
+    } else {
+        *yo = at<R>(yobs, c, t, 0)[k - D];
     }
-    sh[threadIdx.x] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) out[c] = sh[0];
 }
 // _get_alpha + bernoulli (generic.py:70-73, 98-106)
 template <typename R>
@@ -278,15 +272,29 @@ __global__ void k_accept(int C, const R* jp_prop, const R* jp_rev, const R* ell_
         logs[c * 5 + 4] = lt_rev[c];
     }
 }
-template <typename R> __global__ void k_select(long long TD, long long total, const int32_t* accepted, const R* xp, R* x) {
+// x <- xp for accepted chains, both through strided views; cfast as in k_concat_obs
+template <typename R> __global__ void k_select(int C, int T, int D, const int32_t* accepted, Arr xp, Arr x, int cfast) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= total) return;
-    if (accepted[g / TD]) x[g] = xp[g];
+    if (g >= (long long)C * T * D) return;
+    int c, k;
+    long long t;
+    if (cfast) {
+        c = (int)(g % C);
+        const long long r = g / C;
+        k = (int)(r % D);
+        t = r / D;
+    } else {
+        k = (int)(g % D);
+        const long long ct = g / D;
+        c = (int)(ct / T);
+        t = ct % T;
+    }
+    if (accepted[c]) const_cast<R*>(at<R>(x, c, t, 0))[(long long)k * x.se] = at<R>(xp, c, t, 0)[(long long)k * xp.se];
 }
 
 template <typename R>
 static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
-                           double delta, int parallel, int nan_policy, void* x, const void* eps_aux, const void* eps_samp,
+                           double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
                            const void* u_acc, int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy, P = D + PO;
     const KalmanEntry* ke = need_kalman(dtype, D, P);
@@ -296,6 +304,8 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     if (!sl) set_error("(dx=%d, p_obs=%d) sweep not instantiated (p_obs <= 4)", D, PO);
     if (!ke || !ko || !se || !sl) return AUXSSM_ERR_UNSUPPORTED;
     const KDims kd{C, T, 1};
+    // layout 1: x and the noise are chain-minor (T, dx, C) and so is every internal per-chain buffer: lanes <-> chains
+    const int cm = layout == AUXSSM_LAYOUT_CHAIN_MINOR ? 1 : 0;
     const size_t sR = sizeof(R);
     const size_t CT = (size_t)C * T;
     size_t need = 0;
@@ -324,6 +334,14 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     R* ell = (R*)ws_take(h, C * sR);
     R* sums = (R*)ws_take(h, (size_t)5 * C * sR);
     const size_t mark = h->ws_off;
+    const Arr yscA = cm ? cm_arr(ysc, kd, P) : dense_arr(ysc, kd, P);
+    const Arr uA = cm ? cm_arr(u, kd, D) : dense_arr(u, kd, D);
+    const Arr msA = cm ? cm_arr(ms, kd, D) : dense_arr(ms, kd, D);
+    const Arr PsA = cm ? cm_arr(Ps, kd, (long long)D * D) : dense_arr(Ps, kd, (long long)D * D);
+    const Arr xpA = cm ? cm_arr(xp, kd, D) : dense_arr(xp, kd, D);
+    const Arr xA = cm ? cm_arr(x, kd, D) : dense_arr(x, kd, D);
+    const Arr epsauxA = cm ? cm_arr(eps_aux, kd, D) : dense_arr(eps_aux, kd, D);
+    const Arr epsA = cm ? cm_arr(eps_samp, kd, D) : dense_arr(eps_samp, kd, D);
 
     // observations_factory / dynamics_factory of the LG_CONCAT device model
     {
@@ -332,13 +350,13 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
                            cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
         const long long n2 = (long long)CT * P;
         hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, T, D, PO,
-                           (const R*)x, (const R*)eps_aux, (R)sqrt(0.5 * delta), cv(*yobs), u, ysc);
+                           xA, epsauxA, (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, cm);
     }
     auxssm_lgssm gc = *model;
     gc.Hs = auxssm_arr{Hc, 0, (int64_t)P * D, 0};
     gc.Rs = auxssm_arr{Rc, 0, (int64_t)P * P, 0};
     gc.cs = auxssm_arr{cc, 0, (int64_t)P, 0};
-    const auxssm_arr ysc_arr{ysc, (int64_t)T * P, (int64_t)P, 0};
+    const auxssm_arr ysc_dummy{ysc, (int64_t)T * P, (int64_t)P, 0};
     auxssm_dims dc = *dims;
     dc.dy = P;
     dc.B = 1;
@@ -346,14 +364,19 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     // proposal LGSSM: filter + pathwise sample (generic.py:80-86).  The factories of this model do not depend on the
     // linearisation point, so the reverse LGSSM (generic.py:67) is the same one and its filter pass is not repeated.
     FilterArgs fa;
-    fill_filter_args(fa, &dc, &gc, &ysc_arr, ms, Ps);
+    fill_filter_args(fa, &dc, &gc, &ysc_dummy, ms, Ps);
+    fa.ys = yscA;
+    fa.ms = msA;
+    fa.Ps = PsA;
+    fa.lay.cm = cm;
     rc = ke->filter(h, fa, parallel, ell);
     if (rc) return rc;
     h->ws_off = mark;
     SampleArgs sa;
     sa.d = kd;
     sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
-    sa.ms = ms; sa.Ps = Ps; sa.eps = eps_samp; sa.xs = xp; sa.elem = nullptr;
+    sa.ms = msA; sa.Ps = PsA; sa.eps = epsA; sa.xs = xpA; sa.elem = nullptr;
+    sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;
     h->ws_off = mark;
@@ -364,7 +387,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         la.d = kd;
         la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
         la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
-        la.x = x; la.xp = xp; la.u = u; la.delta = delta; la.nan_policy = nan_policy;
+        la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
         rc = sl->run(h, la, sums);
         if (rc) return rc;
         h->ws_off = mark;
@@ -374,8 +397,8 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
                        (const R*)ell, (const R*)ell, (const R*)lt_prop, (const R*)lt_rev, (const R*)corr, (const R*)u_acc,
                        accepted, (R*)logs);
     const long long total = (long long)CT * D;
-    hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, (long long)T * D, total,
-                       (const int32_t*)accepted, (const R*)xp, (R*)x);
+    hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, C, T, D,
+                       (const int32_t*)accepted, xpA, xA, cm);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -583,7 +606,9 @@ int auxssm_kalman_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, co
     SampleArgs a;
     a.d = kd;
     a.Fs = cv(lgssm->Fs); a.Qs = cv(lgssm->Qs); a.bs = cv(lgssm->bs);
-    a.ms = ms; a.Ps = Ps; a.eps = eps; a.xs = xs; a.elem = nullptr;
+    a.ms = dense_arr(ms, kd, dims->dx); a.Ps = dense_arr(Ps, kd, (long long)dims->dx * dims->dx);
+    a.eps = dense_arr(eps, kd, dims->dx); a.xs = dense_arr(xs, kd, dims->dx); a.elem = nullptr;
+    a.lay = ScanLayout{1, 1, 1, 1, 0, kd.C * kd.B};
     return e->sample(h, a, parallel);
 }
 
@@ -610,7 +635,7 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
 }
 
 int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
-                        const auxssm_arr* yobs, double delta, int parallel, int nan_policy, void* x, const void* eps_aux,
+                        const auxssm_arr* yobs, double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux,
                         const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
     AX_NEED_H(h);
     int rc;
@@ -627,13 +652,17 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
         set_error("delta must be > 0");
         return AUXSSM_ERR_ARG;
     }
+    if (layout != AUXSSM_LAYOUT_DENSE && layout != AUXSSM_LAYOUT_CHAIN_MINOR) {
+        set_error("layout must be AUXSSM_LAYOUT_DENSE (0) or AUXSSM_LAYOUT_CHAIN_MINOR (1)");
+        return AUXSSM_ERR_ARG;
+    }
     if (!yobs || !yobs->ptr || !x || !eps_aux || !eps_samp || !u_acc || !accepted) {
         set_error("yobs/x/eps_aux/eps_samp/u_acc/accepted must be non-NULL");
         return AUXSSM_ERR_ARG;
     }
     if (dtype == AUXSSM_F32)
-        return sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
-    return sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        return sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+    return sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
 }
 
 static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32_t k1, uint32_t stream, int64_t n, void* out) {

@@ -15,12 +15,27 @@
 
 namespace ax {
 
+// Strided array view: element e of the record at (chain c, time t, batch b) lives at ptr + c sc + t st + b sb + e se.
+// se = 1: the record is contiguous (user-facing dense / broadcast arrays).  se = S: "chain-minor" internal buffers
+// [t][e][s] -- consecutive lanes = consecutive sequences read consecutive addresses for every component.
 struct Arr {
     const void* ptr;
-    long long sc, st, sb;
+    long long sc, st, sb, se;
 };
 template <typename R> AX_HD const R* at(const Arr& a, int c, long long t, int b) {
     return (const R*)a.ptr + (long long)c * a.sc + t * a.st + (long long)b * a.sb;
+}
+template <typename R, int N> AX_HD void lds_(const R* __restrict__ p, long long se, R* out) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[i] = p[i * se];
+}
+template <typename R, int N> AX_HD void sts_(R* __restrict__ p, long long se, const R* v) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) p[i * se] = v[i];
+}
+template <typename R, int N> AX_HD void rd(const Arr& a, int c, long long t, int b, R* out) { lds_<R, N>(at<R>(a, c, t, b), a.se, out); }
+template <typename R, int N> AX_HD void wr(const Arr& a, int c, long long t, int b, const R* v) {
+    sts_<R, N>(const_cast<R*>(at<R>(a, c, t, b)), a.se, v);
 }
 
 struct KDims {
@@ -37,6 +52,7 @@ struct KDims {
 // record (g E + k) W + l of its sequence (W = 64, or the chunk count if smaller), so those W records are one contiguous run.
 struct ScanLayout {
     int E, nchunk, ngrp, W;  // W = chunks interleaved per row = min(64, nchunk); ngrp = ceil(nchunk / W)
+    int cm, S;               // cm != 0: chain-minor element buffer [i][e][s] (S sequences), used when lanes map to sequences
     AX_HD long long seq_records() const { return (long long)ngrp * E * W; }
     AX_HD long long pos(int i) const {
         const int ch = i / E, k = i - ch * E;
@@ -44,77 +60,93 @@ struct ScanLayout {
         return ((long long)g * E + k) * W + l;
     }
     AX_HD long long row(int grp, int k) const { return ((long long)grp * E + k) * W; }
+    // offset (in reals) of component 0 of element i of sequence s, and the component stride
+    AX_HD long long eoff(int s, int i, int npad) const {
+        return cm ? (long long)i * npad * S + s : ((long long)s * seq_records() + pos(i)) * npad;
+    }
+    AX_HD long long es() const { return cm ? S : 1; }
+    AX_HD long long total_reals(int n, int Sq, int npad) const {
+        return cm ? (long long)(n > 0 ? n : 1) * npad * Sq : (long long)Sq * seq_records() * npad;
+    }
 };
 
 // Two-phase protocol so that the global-memory latency of all the arrays a body needs overlaps:
-//   fetch<N>(lane_ptr, lane_stride, valid, buf)  -- issue the global reads into buf (no barrier);
-//   finish<N>(lane_stride, valid, buf)           -- turn buf into this lane's record (WaveIO: transposition through LDS).
+//   fetch<N>(lane_ptr, lane_stride, se, valid, buf)  -- issue the global reads into buf (no barrier); se = element stride
+//   finish<N>(lane_stride, se, valid, buf)           -- turn buf into this lane's record (WaveIO: transposition through LDS).
 // lane_ptr = this lane's record; lane_stride = distance in reals between consecutive lanes' records.
 struct DirectIO {
-    template <typename R, int N> AX_HD void fetch(const R* lane_ptr, long long /*lane_stride*/, bool valid, R* buf) const {
+    template <typename R, int N> AX_HD void fetch(const R* lane_ptr, long long /*lane_stride*/, long long se, bool valid, R* buf) const {
         if (valid) {
-            ld<R, N>(lane_ptr, buf);
+            lds_<R, N>(lane_ptr, se, buf);
         } else {
 #pragma unroll
             for (int i = 0; i < N; ++i) buf[i] = 0;
         }
     }
-    template <typename R, int N> AX_HD void finish(long long /*lane_stride*/, bool /*valid*/, R* /*buf*/) const {}
+    template <typename R, int N> AX_HD void finish(long long /*lane_stride*/, long long /*se*/, bool /*valid*/, R* /*buf*/) const {}
 };
 
 struct FilterArgs {
     KDims d;
     Arr m0, P0, Fs, Qs, bs, Hs, Rs, cs, ys;
-    void* ms;       // dense (C,T,B,D)
-    void* Ps;       // dense (C,T,B,D,D)
-    void* elem;     // [S][lay.seq_records()][FiltElem::NPAD]
+    Arr ms;         // (C,T,B,D): dense, or chain-minor inside the fused sweep
+    Arr Ps;         // (C,T,B,D,D)
+    void* elem;     // scan elements, layout `lay`
     void* ell0;     // [S]
     ScanLayout lay;
 };
+AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
+    return Arr{p, (long long)d.T * d.B * rec, (long long)d.B * rec, rec, 1};
+}
+// chain-minor view of an internal (S = C*B sequences, T, rec) buffer: [t][e][s]
+AX_HD Arr cm_arr(const void* p, const KDims& d, long long rec) {
+    const long long S = (long long)d.C * d.B;
+    return Arr{p, (long long)d.B, rec * S, 1, S};
+}
 
 // ---- t = 0 measurement update (filtering.py:52) -------------------------------------------------
 template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& a, int s) {
     const int c = s / a.d.B, b = s % a.d.B;
-    R m[D], Pd[D * D], H[P * D], cv[P], y[P];
-    ld<R, D>(at<R>(a.m0, c, 0, b), m);
-    ld<R, D * D>(at<R>(a.P0, c, 0, b), Pd);
-    ld<R, P * D>(at<R>(a.Hs, c, 0, b), H);
-    ld<R, P>(at<R>(a.cs, c, 0, b), cv);
-    ld<R, P>(at<R>(a.ys, c, 0, b), y);
-    const R ell = kalman_update<R, D, P>(m, Pd, H, cv, at<R>(a.Rs, c, 0, b), y);
-    const long long r = a.d.rec(s, 0);
-    st<R, D>((R*)a.ms + r * D, m);
-    st<R, D * D>((R*)a.Ps + r * D * D, Pd);
+    R m[D], Pd[D * D], H[P * D], cv[P], y[P], Rm[P * P];
+    rd<R, D>(a.m0, c, 0, b, m);
+    rd<R, D * D>(a.P0, c, 0, b, Pd);
+    rd<R, P * D>(a.Hs, c, 0, b, H);
+    rd<R, P>(a.cs, c, 0, b, cv);
+    rd<R, P>(a.ys, c, 0, b, y);
+    rd<R, P * P>(a.Rs, c, 0, b, Rm);
+    const R ell = kalman_update<R, D, P>(m, Pd, H, cv, Rm, y);
+    wr<R, D>(a.ms, c, 0, b, m);
+    wr<R, D * D>(a.Ps, c, 0, b, Pd);
     ((R*)a.ell0)[s] = ell;
 }
 
+template <typename R_, int D> struct FilterOp;
 // ---- scan element for transition i -> i+1 (filtering.py:188-250) ---------------------------------
 template <typename R, int D, int P, class IO>
 AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
     R F[D * D], bd[D], m_[D], P_[D * D], H[P * D], cv[P], y[P], Rm[P * P];
-    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, valid, F);
-    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, valid, bd);
-    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, valid, P_);
-    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, valid, H);
-    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, valid, cv);
-    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, valid, y);
-    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, valid, Rm);
-    io.template finish<R, D * D>(a.Fs.st, valid, F);
-    io.template finish<R, D>(a.bs.st, valid, bd);
-    io.template finish<R, D * D>(a.Qs.st, valid, P_);
-    io.template finish<R, P * D>(a.Hs.st, valid, H);
-    io.template finish<R, P>(a.cs.st, valid, cv);
-    io.template finish<R, P>(a.ys.st, valid, y);
-    io.template finish<R, P * P>(a.Rs.st, valid, Rm);
+    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, a.Fs.se, valid, F);
+    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, a.bs.se, valid, bd);
+    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, a.Qs.se, valid, P_);
+    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
+    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
+    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
+    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
+    io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
+    io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, P_);
+    io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
+    io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
+    io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
+    io.template finish<R, P * P>(a.Rs.st, a.Rs.se, valid, Rm);
     if (!valid) return;
     if (i == 0) {
         // first transition: built around predict(m0+, P0+)  (m_ = F m + b, P_ = F P F^T + Q, not symmetrised: filtering.py:200-201)
-        const long long r = a.d.rec(s, 0);
         R m0p[D], P0p[D * D], tm[D], FP[D * D], Pn[D * D];
-        ld<R, D>((const R*)a.ms + r * D, m0p);
-        ld<R, D * D>((const R*)a.Ps + r * D * D, P0p);
+        rd<R, D>(a.ms, c, 0, b, m0p);
+        rd<R, D * D>(a.Ps, c, 0, b, P0p);
         mv<R, D, D>(F, m0p, tm);
         mm<R, D, D, D>(F, P0p, FP);
         mmt<R, D, D, D>(FP, F, Pn);
@@ -129,7 +161,7 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
     }
     FiltElem<R, D> e;
     filter_elem<R, D, P>(F, bd, m_, P_, H, cv, Rm, y, e);
-    fe_store<R, D>((R*)a.elem + ((long long)s * a.lay.seq_records() + a.lay.pos(i)) * FiltElem<R, D>::NPAD, e);
+    FilterOp<R, D>::store_elem(a, s, i, e);
 }
 
 // ---- log-likelihood increment of step i+1 from the filtered moments at i (filtering.py:60) ---------
@@ -137,27 +169,25 @@ template <typename R, int D, int P, class IO>
 AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
-    const long long r = a.d.rec(s, i);
-    const long long dstride = a.d.B;  // dense arrays: consecutive time steps are B records apart
     R m[D], Pd[D * D], F[D * D], bd[D], Q[D * D], H[P * D], cv[P], y[P], Rm[P * P];
-    io.template fetch<R, D>((const R*)a.ms + r * D, dstride * D, valid, m);
-    io.template fetch<R, D * D>((const R*)a.Ps + r * D * D, dstride * D * D, valid, Pd);
-    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, valid, F);
-    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, valid, bd);
-    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, valid, Q);
-    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, valid, H);
-    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, valid, cv);
-    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, valid, y);
-    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, valid, Rm);
-    io.template finish<R, D>(dstride * D, valid, m);
-    io.template finish<R, D * D>(dstride * D * D, valid, Pd);
-    io.template finish<R, D * D>(a.Fs.st, valid, F);
-    io.template finish<R, D>(a.bs.st, valid, bd);
-    io.template finish<R, D * D>(a.Qs.st, valid, Q);
-    io.template finish<R, P * D>(a.Hs.st, valid, H);
-    io.template finish<R, P>(a.cs.st, valid, cv);
-    io.template finish<R, P>(a.ys.st, valid, y);
-    io.template finish<R, P * P>(a.Rs.st, valid, Rm);
+    io.template fetch<R, D>(at<R>(a.ms, c, i, b), a.ms.st, a.ms.se, valid, m);
+    io.template fetch<R, D * D>(at<R>(a.Ps, c, i, b), a.Ps.st, a.Ps.se, valid, Pd);
+    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, a.Fs.se, valid, F);
+    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, a.bs.se, valid, bd);
+    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, a.Qs.se, valid, Q);
+    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
+    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
+    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
+    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template finish<R, D>(a.ms.st, a.ms.se, valid, m);
+    io.template finish<R, D * D>(a.Ps.st, a.Ps.se, valid, Pd);
+    io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
+    io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
+    io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, Q);
+    io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
+    io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
+    io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
+    io.template finish<R, P * P>(a.Rs.st, a.Rs.se, valid, Rm);
     if (!valid) return (R)0;
     kalman_predict<R, D>(m, Pd, F, bd, Q);
     return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
@@ -218,11 +248,40 @@ template <typename R_, int D> struct FilterOp {
     static AX_HD void apply(const Pre& p, const Full& e, Pre& o) { filter_apply<R, D>(p, e, o); }
     // inclusive prefix i  ->  filtered moments at time i + 1
     static AX_HD void write_out(const Args& a, int s, int i, const Pre& p) {
-        const long long r = a.d.rec(s, (long long)i + 1);
-        st<R, D>((R*)a.ms + r * D, p.b);
+        const int c = s / a.d.B, b = s % a.d.B;
+        wr<R, D>(a.ms, c, (long long)i + 1, b, p.b);
         R Pd[D * D];
         symunpack<R, D>(p.C, Pd);
-        st<R, D * D>((R*)a.Ps + r * D * D, Pd);
+        wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
+    }
+    // element i of sequence s in either element layout
+    static AX_HD void store_elem(const Args& a, int s, int i, const Full& e) {
+        R* p = (R*)a.elem + a.lay.eoff(s, i, Full::NPAD);
+        if (a.lay.cm) {
+            R t[Full::N];
+            pack(e, t);
+            sts_<R, Full::N>(p, a.lay.es(), t);
+        } else {
+            fe_store<R, D>(p, e);
+        }
+    }
+    static AX_HD void load_elem(const Args& a, int s, int i, Full& e) {
+        const R* p = (const R*)a.elem + a.lay.eoff(s, i, Full::NPAD);
+        if (a.lay.cm) {
+            R t[Full::N];
+            lds_<R, Full::N>(p, a.lay.es(), t);
+            unpack(t, e);
+        } else {
+            fe_load<R, D>(p, e);
+        }
+    }
+    static AX_HD void pack(const Full& e, R* t) {
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) t[i] = e.A[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) t[D * D + i] = e.b[i], t[D * D + D + DS + i] = e.eta[i];
+#pragma unroll
+        for (int i = 0; i < DS; ++i) t[D * D + D + i] = e.C[i], t[D * D + 2 * D + DS + i] = e.J[i];
     }
 };
 
@@ -230,11 +289,11 @@ template <typename R_, int D> struct FilterOp {
 struct SampleArgs {
     KDims d;
     Arr Fs, Qs, bs;
-    const void* ms;   // dense
-    const void* Ps;   // dense
-    const void* eps;  // dense (C,T,B,D)
-    void* xs;         // dense (C,T,B,D)
-    void* elem;       // [S][lay.seq_records()][SampElem::NPAD], scan position j = T-1-t
+    Arr ms;           // (C,T,B,D) dense or chain-minor
+    Arr Ps;
+    Arr eps;          // (C,T,B,D)
+    Arr xs;           // (C,T,B,D) output
+    void* elem;       // scan elements (layout `lay`), scan position j = T-1-t
     ScanLayout lay;
 };
 
@@ -246,36 +305,35 @@ template <typename R, int D, class IO> AX_HD void body_sample_init(const SampleA
     const int c = s / a.d.B, b = s % a.d.B;
     const int T = a.d.T;
     const long long t = (long long)T - 2 - jp;
-    const long long r = a.d.rec(s, t);
-    const long long ds = a.d.B;
     R m[D], Pd[D * D], eps[D], F[D * D], Q[D * D], bd[D];
-    io.template fetch<R, D>((const R*)a.ms + r * D, -ds * D, valid, m);
-    io.template fetch<R, D * D>((const R*)a.Ps + r * D * D, -ds * D * D, valid, Pd);
-    io.template fetch<R, D>((const R*)a.eps + r * D, -ds * D, valid, eps);
-    io.template fetch<R, D * D>(at<R>(a.Fs, c, t, b), -a.Fs.st, valid, F);
-    io.template fetch<R, D * D>(at<R>(a.Qs, c, t, b), -a.Qs.st, valid, Q);
-    io.template fetch<R, D>(at<R>(a.bs, c, t, b), -a.bs.st, valid, bd);
-    io.template finish<R, D>(-ds * D, valid, m);
-    io.template finish<R, D * D>(-ds * D * D, valid, Pd);
-    io.template finish<R, D>(-ds * D, valid, eps);
-    io.template finish<R, D * D>(-a.Fs.st, valid, F);
-    io.template finish<R, D * D>(-a.Qs.st, valid, Q);
-    io.template finish<R, D>(-a.bs.st, valid, bd);
+    io.template fetch<R, D>(at<R>(a.ms, c, t, b), -a.ms.st, a.ms.se, valid, m);
+    io.template fetch<R, D * D>(at<R>(a.Ps, c, t, b), -a.Ps.st, a.Ps.se, valid, Pd);
+    io.template fetch<R, D>(at<R>(a.eps, c, t, b), -a.eps.st, a.eps.se, valid, eps);
+    io.template fetch<R, D * D>(at<R>(a.Fs, c, t, b), -a.Fs.st, a.Fs.se, valid, F);
+    io.template fetch<R, D * D>(at<R>(a.Qs, c, t, b), -a.Qs.st, a.Qs.se, valid, Q);
+    io.template fetch<R, D>(at<R>(a.bs, c, t, b), -a.bs.st, a.bs.se, valid, bd);
+    io.template finish<R, D>(-a.ms.st, a.ms.se, valid, m);
+    io.template finish<R, D * D>(-a.Ps.st, a.Ps.se, valid, Pd);
+    io.template finish<R, D>(-a.eps.st, a.eps.se, valid, eps);
+    io.template finish<R, D * D>(-a.Fs.st, a.Fs.se, valid, F);
+    io.template finish<R, D * D>(-a.Qs.st, a.Qs.se, valid, Q);
+    io.template finish<R, D>(-a.bs.st, a.bs.se, valid, bd);
     if (!valid) return;
     SampElem<R, D> e;
     sample_elem<R, D>(F, Q, bd, m, Pd, eps, e);
-    SampleOp<R, D>::store_rec((R*)a.elem + ((long long)s * a.lay.seq_records() + a.lay.pos(jp + 1)) * SampElem<R, D>::NPAD, e);
+    SampleOp<R, D>::store_elem(a, s, jp + 1, e);
 }
 // scan element 0 <-> t = T-1   (_sample_last_step, sampling.py:115-124)
 template <typename R, int D> AX_HD void body_sample_last(const SampleArgs& a, int s) {
-    const long long r = a.d.rec(s, (long long)a.d.T - 1);
+    const int c = s / a.d.B, b = s % a.d.B;
+    const long long tl = (long long)a.d.T - 1;
     R m[D], Pd[D * D], eps[D];
-    ld<R, D>((const R*)a.ms + r * D, m);
-    ld<R, D * D>((const R*)a.Ps + r * D * D, Pd);
-    ld<R, D>((const R*)a.eps + r * D, eps);
+    rd<R, D>(a.ms, c, tl, b, m);
+    rd<R, D * D>(a.Ps, c, tl, b, Pd);
+    rd<R, D>(a.eps, c, tl, b, eps);
     SampElem<R, D> e;
     sample_last<R, D>(m, Pd, eps, e);
-    SampleOp<R, D>::store_rec((R*)a.elem + ((long long)s * a.lay.seq_records() + a.lay.pos(0)) * SampElem<R, D>::NPAD, e);
+    SampleOp<R, D>::store_elem(a, s, 0, e);
 }
 
 template <typename R_, int D> struct SampleOp {
@@ -322,8 +380,33 @@ template <typename R_, int D> struct SampleOp {
     static AX_HD void load_pre(const R* q, Pre& p) { ldv<R, D>(q, p.e); }
     static AX_HD void apply(const Pre& p, const Full& e, Pre& o) { sample_apply<R, D>(p, e, o); }
     static AX_HD void write_out(const Args& a, int s, int j, const Pre& p) {
-        const long long r = a.d.rec(s, (long long)a.d.T - 1 - j);
-        st<R, D>((R*)a.xs + r * D, p.e);
+        wr<R, D>(a.xs, s / a.d.B, (long long)a.d.T - 1 - j, s % a.d.B, p.e);
+    }
+    static AX_HD void pack(const Full& e, R* t) {
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) t[i] = e.G[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) t[D * D + i] = e.e[i];
+    }
+    static AX_HD void store_elem(const Args& a, int s, int j, const Full& e) {
+        R* p = (R*)a.elem + a.lay.eoff(s, j, Full::NPAD);
+        if (a.lay.cm) {
+            R t[Full::N];
+            pack(e, t);
+            sts_<R, Full::N>(p, a.lay.es(), t);
+        } else {
+            store_rec(p, e);
+        }
+    }
+    static AX_HD void load_elem(const Args& a, int s, int j, Full& e) {
+        const R* p = (const R*)a.elem + a.lay.eoff(s, j, Full::NPAD);
+        if (a.lay.cm) {
+            R t[Full::N];
+            lds_<R, Full::N>(p, a.lay.es(), t);
+            unpack(t, e);
+        } else {
+            load_rec(p, e);
+        }
     }
 };
 
@@ -339,24 +422,24 @@ template <typename R, int D, int P, class IO> AX_HD R body_joint_logpdf(const Lo
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
     R x[D], xp[D], H[P * D], cv[P], y[P], Rm[P * P], F[D * D], bd[D], Q[D * D];
-    io.template fetch<R, D>(at<R>(a.xs, c, t, b), a.xs.st, valid, x);
-    io.template fetch<R, D>(at<R>(a.xs, c, i, b), a.xs.st, valid, xp);
-    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, valid, H);
-    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, valid, cv);
-    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, valid, y);
-    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, valid, Rm);
-    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, valid, F);
-    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, valid, bd);
-    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, valid, Q);
-    io.template finish<R, D>(a.xs.st, valid, x);
-    io.template finish<R, D>(a.xs.st, valid, xp);
-    io.template finish<R, P * D>(a.Hs.st, valid, H);
-    io.template finish<R, P>(a.cs.st, valid, cv);
-    io.template finish<R, P>(a.ys.st, valid, y);
-    io.template finish<R, P * P>(a.Rs.st, valid, Rm);
-    io.template finish<R, D * D>(a.Fs.st, valid, F);
-    io.template finish<R, D>(a.bs.st, valid, bd);
-    io.template finish<R, D * D>(a.Qs.st, valid, Q);
+    io.template fetch<R, D>(at<R>(a.xs, c, t, b), a.xs.st, a.xs.se, valid, x);
+    io.template fetch<R, D>(at<R>(a.xs, c, i, b), a.xs.st, a.xs.se, valid, xp);
+    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
+    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
+    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
+    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, a.Fs.se, valid, F);
+    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, a.bs.se, valid, bd);
+    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, a.Qs.se, valid, Q);
+    io.template finish<R, D>(a.xs.st, a.xs.se, valid, x);
+    io.template finish<R, D>(a.xs.st, a.xs.se, valid, xp);
+    io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
+    io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
+    io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
+    io.template finish<R, P * P>(a.Rs.st, a.Rs.se, valid, Rm);
+    io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
+    io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
+    io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, Q);
     if (!valid) return (R)0;
     R out = 0;
     {
@@ -385,11 +468,11 @@ template <typename R, int D, int P, class IO> AX_HD R body_joint_logpdf(const Lo
 template <typename R, int D, int P> AX_HD R body_joint_logpdf_head(const LogpdfArgs& a, int s) {
     const int c = s / a.d.B, b = s % a.d.B;
     R x[D], H[P * D], cv[P], y[P], m0[D];
-    ld<R, D>(at<R>(a.xs, c, 0, b), x);
-    ld<R, P * D>(at<R>(a.Hs, c, 0, b), H);
-    ld<R, P>(at<R>(a.cs, c, 0, b), cv);
-    ld<R, P>(at<R>(a.ys, c, 0, b), y);
-    ld<R, D>(at<R>(a.m0, c, 0, b), m0);
+    rd<R, D>(a.xs, c, 0, b, x);
+    rd<R, P * D>(a.Hs, c, 0, b, H);
+    rd<R, P>(a.cs, c, 0, b, cv);
+    rd<R, P>(a.ys, c, 0, b, y);
+    rd<R, D>(a.m0, c, 0, b, m0);
     R out = 0;
     R res[P];
     bool skip[P];
@@ -401,11 +484,16 @@ template <typename R, int D, int P> AX_HD R body_joint_logpdf_head(const LogpdfA
         res[k] = y[k] - pr;
         skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
     }
-    out += gauss_logpdf<R, P>(res, at<R>(a.Rs, c, 0, b), a.nan_policy == 1 ? skip : nullptr);
-    R r0[D];
+    {
+        R Rm[P * P];
+        rd<R, P * P>(a.Rs, c, 0, b, Rm);
+        out += gauss_logpdf<R, P>(res, Rm, a.nan_policy == 1 ? skip : nullptr);
+    }
+    R r0[D], P0m[D * D];
+    rd<R, D * D>(a.P0, c, 0, b, P0m);
 #pragma unroll
     for (int k = 0; k < D; ++k) r0[k] = x[k] - m0[k];
-    out += gauss_logpdf<R, D>(r0, at<R>(a.P0, c, 0, b), nullptr);
+    out += gauss_logpdf<R, D>(r0, P0m, nullptr);
     return out;
 }
 
@@ -421,9 +509,9 @@ template <typename R, int D, int P> AX_HD R body_joint_logpdf_head(const LogpdfA
 struct SweepLogpdfArgs {
     KDims d;
     Arr m0, P0, Fs, Qs, bs, Hs, Rs, cs, ys;  // dynamics + REAL observation model, ys = yobs
-    const void* x;                           // dense (C,T,D)
-    const void* xp;
-    const void* u;
+    Arr x;                                   // (C,T,D)
+    Arr xp;
+    Arr u;
     double delta;
     int nan_policy;
 };
@@ -482,32 +570,31 @@ AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, co
 template <typename R, int D, int PO, class IO>
 AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, bool valid, R* out5) {
     const long long t = (long long)i + 1;
-    const long long r = (long long)c * a.d.T + t;
     R x[D], xp[D], u[D], xq[D], xpq[D], H[PO * D], cv[PO], y[PO], Rm[PO * PO], F[D * D], bd[D], Q[D * D];
-    io.template fetch<R, D>((const R*)a.x + r * D, D, valid, x);
-    io.template fetch<R, D>((const R*)a.xp + r * D, D, valid, xp);
-    io.template fetch<R, D>((const R*)a.u + r * D, D, valid, u);
-    io.template fetch<R, D>((const R*)a.x + (r - 1) * D, D, valid, xq);
-    io.template fetch<R, D>((const R*)a.xp + (r - 1) * D, D, valid, xpq);
-    io.template fetch<R, PO * D>(at<R>(a.Hs, c, t, 0), a.Hs.st, valid, H);
-    io.template fetch<R, PO>(at<R>(a.cs, c, t, 0), a.cs.st, valid, cv);
-    io.template fetch<R, PO>(at<R>(a.ys, c, t, 0), a.ys.st, valid, y);
-    io.template fetch<R, PO * PO>(at<R>(a.Rs, c, t, 0), a.Rs.st, valid, Rm);
-    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, 0), a.Fs.st, valid, F);
-    io.template fetch<R, D>(at<R>(a.bs, c, i, 0), a.bs.st, valid, bd);
-    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, 0), a.Qs.st, valid, Q);
-    io.template finish<R, D>(D, valid, x);
-    io.template finish<R, D>(D, valid, xp);
-    io.template finish<R, D>(D, valid, u);
-    io.template finish<R, D>(D, valid, xq);
-    io.template finish<R, D>(D, valid, xpq);
-    io.template finish<R, PO * D>(a.Hs.st, valid, H);
-    io.template finish<R, PO>(a.cs.st, valid, cv);
-    io.template finish<R, PO>(a.ys.st, valid, y);
-    io.template finish<R, PO * PO>(a.Rs.st, valid, Rm);
-    io.template finish<R, D * D>(a.Fs.st, valid, F);
-    io.template finish<R, D>(a.bs.st, valid, bd);
-    io.template finish<R, D * D>(a.Qs.st, valid, Q);
+    io.template fetch<R, D>(at<R>(a.x, c, t, 0), a.x.st, a.x.se, valid, x);
+    io.template fetch<R, D>(at<R>(a.xp, c, t, 0), a.xp.st, a.xp.se, valid, xp);
+    io.template fetch<R, D>(at<R>(a.u, c, t, 0), a.u.st, a.u.se, valid, u);
+    io.template fetch<R, D>(at<R>(a.x, c, i, 0), a.x.st, a.x.se, valid, xq);
+    io.template fetch<R, D>(at<R>(a.xp, c, i, 0), a.xp.st, a.xp.se, valid, xpq);
+    io.template fetch<R, PO * D>(at<R>(a.Hs, c, t, 0), a.Hs.st, a.Hs.se, valid, H);
+    io.template fetch<R, PO>(at<R>(a.cs, c, t, 0), a.cs.st, a.cs.se, valid, cv);
+    io.template fetch<R, PO>(at<R>(a.ys, c, t, 0), a.ys.st, a.ys.se, valid, y);
+    io.template fetch<R, PO * PO>(at<R>(a.Rs, c, t, 0), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, 0), a.Fs.st, a.Fs.se, valid, F);
+    io.template fetch<R, D>(at<R>(a.bs, c, i, 0), a.bs.st, a.bs.se, valid, bd);
+    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, 0), a.Qs.st, a.Qs.se, valid, Q);
+    io.template finish<R, D>(a.x.st, a.x.se, valid, x);
+    io.template finish<R, D>(a.xp.st, a.xp.se, valid, xp);
+    io.template finish<R, D>(a.u.st, a.u.se, valid, u);
+    io.template finish<R, D>(a.x.st, a.x.se, valid, xq);
+    io.template finish<R, D>(a.xp.st, a.xp.se, valid, xpq);
+    io.template finish<R, PO * D>(a.Hs.st, a.Hs.se, valid, H);
+    io.template finish<R, PO>(a.cs.st, a.cs.se, valid, cv);
+    io.template finish<R, PO>(a.ys.st, a.ys.se, valid, y);
+    io.template finish<R, PO * PO>(a.Rs.st, a.Rs.se, valid, Rm);
+    io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
+    io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
+    io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, Q);
 #pragma unroll
     for (int k = 0; k < 5; ++k) out5[k] = 0;
     if (!valid) return;
@@ -530,21 +617,22 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
 }
 // t = 0 terms (one lane per chain)
 template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_head(const SweepLogpdfArgs& a, int c, R* out5) {
-    const long long r = (long long)c * a.d.T;
-    R x[D], xp[D], u[D], H[PO * D], cv[PO], y[PO], m0[D];
-    ld<R, D>((const R*)a.x + r * D, x);
-    ld<R, D>((const R*)a.xp + r * D, xp);
-    ld<R, D>((const R*)a.u + r * D, u);
-    ld<R, PO * D>(at<R>(a.Hs, c, 0, 0), H);
-    ld<R, PO>(at<R>(a.cs, c, 0, 0), cv);
-    ld<R, PO>(at<R>(a.ys, c, 0, 0), y);
-    ld<R, D>(at<R>(a.m0, c, 0, 0), m0);
+    R x[D], xp[D], u[D], H[PO * D], cv[PO], y[PO], m0[D], Rm[PO * PO], P0m[D * D];
+    rd<R, D>(a.x, c, 0, 0, x);
+    rd<R, D>(a.xp, c, 0, 0, xp);
+    rd<R, D>(a.u, c, 0, 0, u);
+    rd<R, PO * PO>(a.Rs, c, 0, 0, Rm);
+    rd<R, D * D>(a.P0, c, 0, 0, P0m);
+    rd<R, PO * D>(a.Hs, c, 0, 0, H);
+    rd<R, PO>(a.cs, c, 0, 0, cv);
+    rd<R, PO>(a.ys, c, 0, 0, y);
+    rd<R, D>(a.m0, c, 0, 0, m0);
     R cc_p, cc_x, ob_p, ob_x, corr;
-    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, at<R>(a.Rs, c, 0, 0), cc_p, cc_x, ob_p, ob_x, corr);
+    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
     R r1[D], r2[D], pr_p, pr_x;
 #pragma unroll
     for (int k = 0; k < D; ++k) r1[k] = xp[k] - m0[k], r2[k] = x[k] - m0[k];
-    gauss_logpdf2<R, D>(r1, r2, at<R>(a.P0, c, 0, 0), nullptr, pr_p, pr_x);
+    gauss_logpdf2<R, D>(r1, r2, P0m, nullptr, pr_p, pr_x);
     out5[0] = cc_p + pr_p;
     out5[1] = cc_x + pr_x;
     out5[2] = ob_p + pr_p;

@@ -46,9 +46,9 @@ template <typename R> struct WaveIO {
     int nvalid;  // valid lanes are 0 .. nvalid-1
     // phase 1: buf[j] = element j*64 + lane of the wave's contiguous 64-record stream (fully coalesced), or the lane's own
     // record for strides that are not record-dense.  No barrier: every array's fetch is issued before any finish.
-    template <typename R2, int N> __device__ __forceinline__ void fetch(const R2* lane_ptr, long long stride, bool valid, R2* buf) const {
+    template <typename R2, int N> __device__ __forceinline__ void fetch(const R2* lane_ptr, long long stride, long long se, bool valid, R2* buf) const {
         static_assert(sizeof(R2) == sizeof(R), "one real type per kernel");
-        if (stride == N || stride == -N) {
+        if (se == 1 && (stride == N || stride == -N)) {
             const R2* p0 = stride < 0 ? lane_ptr + (long long)(lane - (nvalid - 1)) * N : lane_ptr - (long long)lane * N;
             const int total = nvalid * N;
 #pragma unroll
@@ -57,15 +57,15 @@ template <typename R> struct WaveIO {
                 buf[j] = q < total ? p0[q] : (R2)0;
             }
         } else if (valid) {
-            ld<R2, N>(lane_ptr, buf);
+            lds_<R2, N>(lane_ptr, se, buf);
         } else {
 #pragma unroll
             for (int e = 0; e < N; ++e) buf[e] = 0;
         }
     }
     // phase 2: scatter the stream into an LDS image with an odd record stride, then read this lane's record back.
-    template <typename R2, int N> __device__ __forceinline__ void finish(long long stride, bool valid, R2* buf) const {
-        if (stride == N || stride == -N) {
+    template <typename R2, int N> __device__ __forceinline__ void finish(long long stride, long long se, bool valid, R2* buf) const {
+        if (se == 1 && (stride == N || stride == -N)) {
             constexpr int RS = N | 1;
             R2* L = (R2*)lds;
 #pragma unroll
@@ -198,6 +198,138 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample
     body_sample_init<R, D>(a, io, s, jp, true);
 }
 
+// ---- chain-minor mode: lanes <-> sequences -----------------------------------------------------------------------------
+// Used by the fused sweep when many chains run side by side.  Per-chain buffers are [t][e][s] (cm_arr), so every component
+// load/store of a wave is one contiguous 64-real run, and chain-shared model parameters are the same address in every lane
+// (one cache line per instruction).  No transposition between the elementwise and the scan kernels, no LDS staging.
+// A workgroup = one wave = 64 sequences x a tile of TI consecutive time steps; reductions over time are per-lane sums.
+constexpr int TB_CM = 64;
+// Wave-uniform loop index made opaque to loop-strength-reduction: with runtime strides LSR otherwise keeps one 64-bit
+// induction pointer PER LOAD of the body in VGPRs (k_filter_ell_cm<double,4,8>: 512 registers + scratch vs 316 with this).
+__device__ __forceinline__ int opaque_uniform(int i) {
+    int ii = __builtin_amdgcn_readfirstlane(i);
+    asm volatile("" : "+s"(ii));
+    return ii;
+}
+struct CmTile {
+    int s, i0, i1, tt;
+    bool live;
+};
+__device__ __forceinline__ CmTile decode_cm(int S, int n, int TI) {
+    const int stiles = (S + TB_CM - 1) / TB_CM;
+    CmTile c;
+    c.tt = blockIdx.x / stiles;
+    c.s = (blockIdx.x % stiles) * TB_CM + threadIdx.x;
+    c.i0 = c.tt * TI;
+    c.i1 = min(n, c.i0 + TI);
+    c.live = c.s < S;
+    return c;
+}
+inline unsigned grid_cm(int S, int n, int TI) { return (unsigned)((S + TB_CM - 1) / TB_CM) * (unsigned)((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1); }
+
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_filter_init_cm(FilterArgs a, int TI) {
+    const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
+    if (!c.live) return;
+    DirectIO io;
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) {
+        body_filter_init<R, D, P>(a, io, c.s, opaque_uniform(i), true);
+    }
+}
+template <typename R, int D, int P>
+__global__ void __launch_bounds__(TB_CM) k_filter_ell_cm(FilterArgs a, R* __restrict__ part, int ntile, int TI) {
+    const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
+    if (!c.live) return;
+    DirectIO io;
+    R acc = 0;
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) {
+        acc += body_filter_ell<R, D, P>(a, io, c.s, opaque_uniform(i), true);
+    }
+    part[(long long)c.s * ntile + c.tt] = acc;
+}
+template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_init_cm(SampleArgs a, int TI) {
+    const CmTile c = decode_cm(a.d.S(), a.d.T - 1, TI);
+    if (!c.live) return;
+    DirectIO io;
+    if (c.tt == 0) body_sample_last<R, D>(a, c.s);
+#pragma unroll 1
+    for (int jp = c.i0; jp < c.i1; ++jp) {
+        body_sample_init<R, D>(a, io, c.s, opaque_uniform(jp), true);
+    }
+}
+template <typename R, int D, int PO>
+__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+    const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
+    if (!c.live) return;
+    DirectIO io;
+    R v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) body_sweep_logpdf_head<R, D, PO>(a, c.s, v);
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) {
+        R w[5];
+        body_sweep_logpdf<R, D, PO>(a, io, c.s, opaque_uniform(i), true, w);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
+}
+
+// scan passes: lane <-> sequence, workgroup <-> (chunk, 64 sequences)
+template <class Op>
+__global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    const ScanLayout lay = Op::layout(a);
+    const int stiles = (S + TB_CM - 1) / TB_CM;
+    const int ch = blockIdx.x / stiles;
+    const int s = (blockIdx.x % stiles) * TB_CM + threadIdx.x;
+    if (s >= S) return;
+    const int i0 = ch * lay.E, i1 = min(n, i0 + lay.E);
+    Full acc, nxt;
+    Op::load_elem(a, s, i0, acc);
+    if (i0 + 1 < i1) Op::load_elem(a, s, i0 + 1, nxt);
+    for (int i = i0 + 1; i < i1; ++i) {
+        const Full cur = nxt;
+        if (i + 1 < i1) Op::load_elem(a, s, opaque_uniform(i + 1), nxt);  // next element's reads fly during the combine
+        Full o;
+        Op::combine(acc, cur, o);
+        acc = o;
+    }
+    Op::store_rec((R*)sb.agg + ((long long)s * lay.nchunk + ch) * Full::NPAD, acc);
+}
+template <class Op>
+__global__ void __launch_bounds__(TB_CM) k_scan_down_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    using Pre = typename Op::Pre;
+    const ScanLayout lay = Op::layout(a);
+    const int stiles = (S + TB_CM - 1) / TB_CM;
+    const int ch = blockIdx.x / stiles;
+    const int s = (blockIdx.x % stiles) * TB_CM + threadIdx.x;
+    if (s >= S) return;
+    const int i0 = ch * lay.E, i1 = min(n, i0 + lay.E);
+    Pre p;
+    if (lay.nchunk > 1) {
+        Op::load_pre((const R*)sb.pre + ((long long)s * lay.nchunk + ch) * Pre::NPAD, p);
+    } else {
+        Full id;
+        Op::identity(id);
+        Op::to_pre(id, p);
+    }
+    Full nxt;
+    if (i0 < i1) Op::load_elem(a, s, i0, nxt);
+    for (int i = i0; i < i1; ++i) {
+        const Full cur = nxt;
+        if (i + 1 < i1) Op::load_elem(a, s, opaque_uniform(i + 1), nxt);
+        Pre o;
+        Op::apply(p, cur, o);
+        p = o;
+        Op::write_out(a, s, opaque_uniform(i), p);
+    }
+}
+
 // ---- generic chunked scan ---------------------------------------------------------------------------------------
 // one wave = one group of 64 chunks of one sequence; row k of the group is 64 contiguous records (ScanLayout)
 template <class Op>
@@ -215,16 +347,16 @@ __global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, Sc
     WaveIO<R> io{(R*)smem, lane, lay.W};
     R rec[Full::NPAD], nxt[Full::NPAD];
     Full acc;
-    io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 0) + (long long)lane * Full::NPAD, Full::NPAD, inrow, rec);
-    io.template finish<R, Full::NPAD>(Full::NPAD, inrow, rec);
+    io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 0) + (long long)lane * Full::NPAD, Full::NPAD, 1, inrow, rec);
+    io.template finish<R, Full::NPAD>(Full::NPAD, 1, inrow, rec);
     Op::unpack(rec, acc);
-    if (lay.E > 1) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 1) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+    if (lay.E > 1) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 1) + (long long)lane * Full::NPAD, Full::NPAD, 1, inrow, nxt);
     for (int k = 1; k < lay.E; ++k) {
 #pragma unroll
         for (int e = 0; e < Full::NPAD; ++e) rec[e] = nxt[e];
-        io.template finish<R, Full::NPAD>(Full::NPAD, inrow, rec);
+        io.template finish<R, Full::NPAD>(Full::NPAD, 1, inrow, rec);
         // the next row's global reads fly while this row is combined
-        if (k + 1 < lay.E) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, k + 1) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+        if (k + 1 < lay.E) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, k + 1) + (long long)lane * Full::NPAD, Full::NPAD, 1, inrow, nxt);
         if (k < len) {
             Full cur, o;
             Op::unpack(rec, cur);
@@ -310,12 +442,12 @@ __global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, Scan
     }
     WaveIO<R> io{(R*)smem, lane, lay.W};
     R rec[Full::NPAD], nxt[Full::NPAD];
-    io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 0) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+    io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, 0) + (long long)lane * Full::NPAD, Full::NPAD, 1, inrow, nxt);
     for (int k = 0; k < lay.E; ++k) {
 #pragma unroll
         for (int e = 0; e < Full::NPAD; ++e) rec[e] = nxt[e];
-        io.template finish<R, Full::NPAD>(Full::NPAD, inrow, rec);
-        if (k + 1 < lay.E) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, k + 1) + (long long)lane * Full::NPAD, Full::NPAD, inrow, nxt);
+        io.template finish<R, Full::NPAD>(Full::NPAD, 1, inrow, rec);
+        if (k + 1 < lay.E) io.template fetch<R, Full::NPAD>(Op::row_ptr(a, s, grp, k + 1) + (long long)lane * Full::NPAD, Full::NPAD, 1, inrow, nxt);
         if (k < len) {
             Full cur;
             Pre o;
@@ -332,10 +464,11 @@ template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int 
     if (pl.nchunk <= 1) return 0;
     return (size_t)S * pl.nchunk * (Op::Full::NPAD + Op::Pre::NPAD) * sizeof(typename Op::R) + 512;
 }
-inline ScanLayout make_layout(const ScanPlan& pl) {
+inline ScanLayout make_layout(const ScanPlan& pl, int cm, int S) {
     const int W = pl.nchunk < 64 ? pl.nchunk : 64;
-    return ScanLayout{pl.E, pl.nchunk, (pl.nchunk + W - 1) / W, W};
+    return ScanLayout{pl.E, pl.nchunk, (pl.nchunk + W - 1) / W, W, cm, S};
 }
+constexpr int TI_CM = 8;  // time steps per wave in the chain-minor elementwise kernels
 
 // `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
 template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
@@ -343,16 +476,18 @@ template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int 
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
     ScanBufs sb{nullptr, nullptr};
-    const unsigned grid = (unsigned)S * lay.ngrp;
+    const unsigned grid = lay.cm ? (unsigned)((S + TB_CM - 1) / TB_CM) * lay.nchunk : (unsigned)S * lay.ngrp;
     const size_t stage = stage_bytes<R>(Op::Full::NPAD);
     if (lay.nchunk > 1) {
         sb.agg = ws_take(h, (size_t)S * lay.nchunk * Op::Full::NPAD * sizeof(R));
         sb.pre = ws_take(h, (size_t)S * lay.nchunk * Op::Pre::NPAD * sizeof(R));
-        hipLaunchKernelGGL((k_scan_reduce<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
+        if (lay.cm) hipLaunchKernelGGL((k_scan_reduce_cm<Op>), dim3(grid), dim3(TB_CM), 0, h->stream, a, sb, S, n);
+        else hipLaunchKernelGGL((k_scan_reduce<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
         const size_t lds = (size_t)TB_AGGS * Op::Full::NPAD * sizeof(R);
         hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, lay.nchunk);
     }
-    hipLaunchKernelGGL((k_scan_down<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
+    if (lay.cm) hipLaunchKernelGGL((k_scan_down_cm<Op>), dim3(grid), dim3(TB_CM), 0, h->stream, a, sb, S, n);
+    else hipLaunchKernelGGL((k_scan_down<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -362,11 +497,12 @@ inline int ntiles(int n) { return (n + TB_ELEM - 1) / TB_ELEM; }
 
 template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
     const int S = d.S(), n = d.n();
-    const ScanLayout lay = make_layout(plan_scan(h, S, n, parallel));
+    const ScanLayout lay = make_layout(plan_scan(h, S, n, parallel), 0, S);
     size_t b = 0;
+    // (the time-minor layout is never smaller than the chain-minor one)
     b += (size_t)S * lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + 256;
     b += (size_t)S * sizeof(R) + 256;                           // ell0
-    b += (size_t)S * (ntiles(n) + 1) * sizeof(R) + 256;         // ell partials
+    b += (size_t)S * (cmax(ntiles(n), (n + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;  // ell partials
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
     return b;
 }
@@ -374,16 +510,18 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
 template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterArgs& a_in, int parallel, void* ell_out) {
     FilterArgs a = a_in;
     const int S = a.d.S(), n = a.d.n();
-    a.lay = make_layout(plan_scan(h, S, n, parallel));
-    a.elem = ws_take(h, (size_t)S * a.lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R));
+    const int cm = a_in.lay.cm;  // the caller chose the layout of ms / Ps; the element buffer follows it
+    a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
+    a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
-    const int nt = ntiles(n);
+    const int nt = cm ? (n + TI_CM - 1) / TI_CM : ntiles(n);
     R* part = (R*)ws_take(h, (size_t)S * (nt + 1) * sizeof(R));
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     if (n > 0) {
         {
             ProfScope ps(h, AUXSSM_K_FILTER_INIT);
-            hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
+            if (cm) hipLaunchKernelGGL((k_filter_init_cm<R, D, P>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+            else hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
@@ -392,7 +530,8 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_ELL);
-            hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+            if (cm) hipLaunchKernelGGL((k_filter_ell_cm<R, D, P>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+            else hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
         }
     }
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0,
@@ -403,19 +542,21 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
 
 template <typename R, int D> size_t sample_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
     const int S = d.S();
-    const ScanLayout lay = make_layout(plan_scan(h, S, d.T, parallel));
+    const ScanLayout lay = make_layout(plan_scan(h, S, d.T, parallel), 0, S);
     return (size_t)S * lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel);
 }
 
 template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_in, int parallel) {
     SampleArgs a = a_in;
     const int S = a.d.S(), T = a.d.T;
-    a.lay = make_layout(plan_scan(h, S, T, parallel));
-    a.elem = ws_take(h, (size_t)S * a.lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R));
+    const int cm = a_in.lay.cm;
+    a.lay = make_layout(plan_scan(h, S, T, parallel), cm, S);
+    a.elem = ws_take(h, (size_t)a.lay.total_reals(T, S, SampElem<R, D>::NPAD) * sizeof(R));
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
         const int nt = ntiles(T - 1) > 0 ? ntiles(T - 1) : 1;
-        hipLaunchKernelGGL((k_sample_init<R, D>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
+        if (cm) hipLaunchKernelGGL((k_sample_init_cm<R, D>), dim3(grid_cm(S, T - 1, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+        else hipLaunchKernelGGL((k_sample_init<R, D>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
     }
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
@@ -443,14 +584,17 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
 }
 
 template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * (ntiles(d.T) + 1) * sizeof(R) + 256;
+    return (size_t)5 * d.C * (cmax(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;
 }
 // out: [5][C]
 template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
-    const int C = a.d.C, nt = ntiles(a.d.T - 1) > 0 ? ntiles(a.d.T - 1) : 1;
+    const bool cm = a.xp.se != 1;  // chain-minor proposal buffer -> lanes over chains
+    const int n = a.d.T - 1;
+    const int C = a.d.C, nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+    if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+    else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;

@@ -12,6 +12,7 @@ Two execution paths, same semantics:
 """
 import ctypes as C
 import math
+import os
 from dataclasses import dataclass
 from typing import Any
 
@@ -100,15 +101,19 @@ def _log_alpha(lp_prop, lp_rev, lt_prop, lt_rev, sqrt_delta, u, x, x_prop):
 # device sweep
 # ------------------------------------------------------------------------------------------------
 class DeviceChains:
-    """C chains' trajectories resident in HBM: x (C, T, dx)."""
+    """C chains' trajectories resident in HBM.  With >= 32 chains (or chain_minor=True) the state and the per-sweep noise
+    are stored chain-minor, (T, dx, C): the sweep's lanes then run over chains (AUXSSM_LAYOUT_CHAIN_MINOR, include/auxssm.h)."""
 
-    def __init__(self, handle, x, dtype=None):
+    def __init__(self, handle, x, dtype=None, chain_minor=None):
         x = np.asarray(x)
         if x.ndim == 2:
             x = x[None]
         self.handle = handle
-        self.x = handle.to_device(x, dtype or x.dtype)
-        self.C, self.T, self.dx = self.x.shape
+        self.C, self.T, self.dx = x.shape
+        env = os.environ.get("AUXSSM_CM")
+        self.chain_minor = bool(int(env)) if env is not None and chain_minor is None else (self.C >= 32 if chain_minor is None else bool(chain_minor))
+        self.layout = _lib.LAYOUT_CHAIN_MINOR if self.chain_minor else _lib.LAYOUT_DENSE
+        self.x = handle.to_device(self._to_layout(x), dtype or x.dtype)
         self.dtype = self.x.dtype
         self.accepted = handle.zeros((self.C,), np.int32)
         self.logs = handle.zeros((self.C, 5), self.dtype)
@@ -117,8 +122,15 @@ class DeviceChains:
         self.eps_samp = handle.empty(self.x.shape, self.dtype)
         self.u_acc = handle.empty((self.C,), self.dtype)
 
+    def _to_layout(self, a):
+        """(C, T, dx) -> the resident layout"""
+        a = np.asarray(a).reshape(self.C, self.T, self.dx)
+        return np.ascontiguousarray(a.transpose(1, 2, 0)) if self.chain_minor else a
+
     def to_host(self):
-        return self.x.to_host()
+        """trajectories as (C, T, dx)"""
+        a = self.x.to_host()
+        return np.ascontiguousarray(a.transpose(2, 0, 1)) if self.chain_minor else a
 
 
 def _get_device_kernel(model, parallel, nan_policy="reference"):
@@ -130,7 +142,7 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         dims = _lib.Dims(chains.C, chains.T, 1, chains.dx, model.p_obs)
         _lib.check(handle.lib.auxssm_kalman_sweep(
             handle.h, _lib.dtype_code(chains.dtype), _lib.KMODEL_LG_CONCAT, C.byref(dims), C.byref(dl.c), C.byref(yarr),
-            float(delta), int(bool(parallel)), pol, chains.x.ptr, eps_aux.ptr, eps_samp.ptr, u_acc.ptr,
+            float(delta), int(bool(parallel)), pol, chains.layout, chains.x.ptr, eps_aux.ptr, eps_samp.ptr, u_acc.ptr,
             chains.accepted.ptr, chains.logs.ptr))
 
     def draw(handle, key, chains):
@@ -150,8 +162,8 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         else:
             shape = (chains.C, chains.T, chains.dx)
             eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc
-            eps_aux.copy_from_host(np.asarray(noise["eps_aux"], chains.dtype).reshape(shape))
-            eps_samp.copy_from_host(np.asarray(noise["eps_samp"], chains.dtype).reshape(shape))
+            eps_aux.copy_from_host(chains._to_layout(np.asarray(noise["eps_aux"], chains.dtype)).reshape(eps_aux.shape))
+            eps_samp.copy_from_host(chains._to_layout(np.asarray(noise["eps_samp"], chains.dtype)).reshape(eps_samp.shape))
             u_acc.copy_from_host(np.asarray(noise["u_accept"], chains.dtype).reshape(chains.C))
         sweep(handle, chains, delta, eps_aux, eps_samp, u_acc)
         if resident:

@@ -136,11 +136,18 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
  * Noise is explicit (the parity contract): eps_aux, eps_samp (C,T,dx) ~ N(0,I), u_acc (C) ~ U[0,1).
  * x (C,T,dx) is updated in place; accepted (C) int32; logs (C,5) = log_alpha, lp_prop, lp_rev, lt_prop, lt_rev
  * (may be NULL).  B must be 1.
+ *
+ * layout: AUXSSM_LAYOUT_DENSE -- x, eps_aux, eps_samp are (C,T,dx) row-major and lanes run over time;
+ *         AUXSSM_LAYOUT_CHAIN_MINOR -- they are (T,dx,C) row-major (chain index fastest).  Then lanes run over CHAINS: every
+ *         per-chain buffer inside the sweep is [t][component][chain], so each wave access is one contiguous run and the
+ *         chain-shared model parameters are wave-uniform loads; there is no transposition anywhere in the sweep.  This is the
+ *         layout to use with >= 32 chains (bench.py); results are identical up to the combination tree of the scan.
  */
 typedef enum { AUXSSM_KMODEL_LG_CONCAT = 1 } auxssm_kalman_model;
+typedef enum { AUXSSM_LAYOUT_DENSE = 0, AUXSSM_LAYOUT_CHAIN_MINOR = 1 } auxssm_layout;
 int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims,
                         const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, int parallel,
-                        int nan_policy, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
+                        int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
                         int32_t* accepted, void* logs);
 
 /* ---- conditional SMC (particle Gibbs) sweep ------------------------------------------------------------

@@ -13,13 +13,28 @@
 using namespace ax;
 
 struct HsArr { const void* ptr; long long sc, st, sb; };
-static Arr cv(const HsArr& a) { return Arr{a.ptr, a.sc, a.st, a.sb}; }
+static Arr cv(const HsArr& a) { return Arr{a.ptr, a.sc, a.st, a.sb, 1}; }
 
-static ScanLayout make_layout_host(int n, int E) {
+static ScanLayout make_layout_host(int n, int E, int cm, int S) {
     if (E <= 0 || E > n) E = n > 0 ? n : 1;
     const int nchunk = n > 0 ? (n + E - 1) / E : 1;
     const int W = nchunk < 64 ? nchunk : 64;
-    return ScanLayout{E, nchunk, (nchunk + W - 1) / W, W};
+    return ScanLayout{E, nchunk, (nchunk + W - 1) / W, W, cm, S};
+}
+// chain-minor <-> dense copies of a (C,T,B,rec) buffer (host test helper)
+template <typename R> static void cm_to_dense(const std::vector<R>& cmb, const KDims& d, int rec, R* dense) {
+    const Arr a = cm_arr(cmb.data(), d, rec), o = dense_arr(dense, d, rec);
+    for (int c = 0; c < d.C; ++c)
+        for (int t = 0; t < d.T; ++t)
+            for (int b = 0; b < d.B; ++b)
+                for (int e = 0; e < rec; ++e) const_cast<R*>(at<R>(o, c, t, b))[e * o.se] = at<R>(a, c, t, b)[e * a.se];
+}
+template <typename R> static void dense_to_cm(const R* dense, const KDims& d, int rec, std::vector<R>& cmb) {
+    const Arr a = cm_arr(cmb.data(), d, rec), o = dense_arr(dense, d, rec);
+    for (int c = 0; c < d.C; ++c)
+        for (int t = 0; t < d.T; ++t)
+            for (int b = 0; b < d.B; ++b)
+                for (int e = 0; e < rec; ++e) const_cast<R*>(at<R>(a, c, t, b))[e * a.se] = at<R>(o, c, t, b)[e * o.se];
 }
 
 template <class Op> static void scan_host(typename Op::Args& a, int S, int n) {
@@ -29,10 +44,7 @@ template <class Op> static void scan_host(typename Op::Args& a, int S, int n) {
     if (n <= 0) return;
     const ScanLayout lay = Op::layout(a);
     const int E = lay.E, nchunk = lay.nchunk;
-    auto load = [&](int s, int i, Full& e) {
-        const int ch = i / E, k = i % E, g = ch / lay.W, l = ch % lay.W;
-        Op::load_rec(Op::row_ptr(a, s, g, k) + (long long)l * Full::NPAD, e);
-    };
+    auto load = [&](int s, int i, Full& e) { Op::load_elem(a, s, i, e); };
     std::vector<Full> agg((size_t)S * nchunk);
     std::vector<Pre> pre((size_t)S * nchunk);
     for (int s = 0; s < S; ++s)
@@ -79,10 +91,21 @@ static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E,
     a.d = KDims{C, T, B};
     a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
     a.Hs = cv(g[5]); a.Rs = cv(g[6]); a.cs = cv(g[7]); a.ys = cv(*ys);
-    a.ms = ms; a.Ps = Ps;
     const int S = C * B, n = T - 1;
-    a.lay = make_layout_host(n, E);
-    std::vector<R> elem((size_t)S * a.lay.seq_records() * FiltElem<R, D>::NPAD + 16), ell0(S);
+    const int cm = E < 0 ? 1 : 0;  // E < 0: chain-minor internal buffers with chunk |E|
+    if (cm) E = -E;
+    a.lay = make_layout_host(n, E, cm, S);
+    std::vector<R> msc, Psc;
+    if (cm) {
+        msc.resize((size_t)S * T * D);
+        Psc.resize((size_t)S * T * D * D);
+        a.ms = cm_arr(msc.data(), a.d, D);
+        a.Ps = cm_arr(Psc.data(), a.d, D * D);
+    } else {
+        a.ms = dense_arr(ms, a.d, D);
+        a.Ps = dense_arr(Ps, a.d, D * D);
+    }
+    std::vector<R> elem((size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) + 16), ell0(S);
     a.elem = elem.data();
     a.ell0 = ell0.data();
     DirectIO io;
@@ -100,6 +123,10 @@ static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E,
         }
         ((R*)ell)[c] = tot;
     }
+    if (cm) {
+        cm_to_dense<R>(msc, a.d, D, (R*)ms);
+        cm_to_dense<R>(Psc, a.d, D * D, (R*)Ps);
+    }
     return 0;
 }
 
@@ -108,10 +135,27 @@ static int sample_T(int C, int T, int B, const HsArr* g, const void* ms, const v
     SampleArgs a;
     a.d = KDims{C, T, B};
     a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
-    a.ms = ms; a.Ps = Ps; a.eps = eps; a.xs = xs;
     const int S = C * B;
-    a.lay = make_layout_host(T, E);
-    std::vector<R> elem((size_t)S * a.lay.seq_records() * SampElem<R, D>::NPAD + 16);
+    const int cm = E < 0 ? 1 : 0;
+    if (cm) E = -E;
+    a.lay = make_layout_host(T, E, cm, S);
+    std::vector<R> msc, Psc, xsc;
+    if (cm) {
+        msc.resize((size_t)S * T * D);
+        Psc.resize((size_t)S * T * D * D);
+        xsc.resize((size_t)S * T * D);
+        dense_to_cm<R>((const R*)ms, a.d, D, msc);
+        dense_to_cm<R>((const R*)Ps, a.d, D * D, Psc);
+        a.ms = cm_arr(msc.data(), a.d, D);
+        a.Ps = cm_arr(Psc.data(), a.d, D * D);
+        a.xs = cm_arr(xsc.data(), a.d, D);
+    } else {
+        a.ms = dense_arr(ms, a.d, D);
+        a.Ps = dense_arr(Ps, a.d, D * D);
+        a.xs = dense_arr(xs, a.d, D);
+    }
+    a.eps = dense_arr(eps, a.d, D);
+    std::vector<R> elem((size_t)a.lay.total_reals(T, S, SampElem<R, D>::NPAD) + 16);
     a.elem = elem.data();
     DirectIO io;
     for (int s = 0; s < S; ++s) {
@@ -119,6 +163,7 @@ static int sample_T(int C, int T, int B, const HsArr* g, const void* ms, const v
         for (int jp = 0; jp < T - 1; ++jp) body_sample_init<R, D>(a, io, s, jp, true);
     }
     scan_host<SampleOp<R, D>>(a, S, T);
+    if (cm) cm_to_dense<R>(xsc, a.d, D, (R*)xs);
     return 0;
 }
 

@@ -73,8 +73,9 @@ def test_joint_logpdf(nan_index, dx, dy):
 
 
 @pytest.mark.parametrize("d", [1, 2, 4])
+@pytest.mark.parametrize("E", [4, -4])  # negative: chain-minor internal buffers (the fused sweep's layout)
 @pytest.mark.parametrize("dtype,tol", [(np.float64, TOL64), (np.float32, dict(rtol=2e-3, atol=2e-3))])
-def test_chain_batched_broadcast_layout(d, dtype, tol):
+def test_chain_batched_broadcast_layout(d, E, dtype, tol):
     """C chains share time-invariant (stride-0) model parameters; only ys varies per chain."""
     T, C = 40, 3
     m = lg_model(T, d)
@@ -90,9 +91,9 @@ def test_chain_batched_broadcast_layout(d, dtype, tol):
     bt = np.broadcast_to
     lg = (m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
           bt(H_, (T, P, d)), bt(R_, (T, P, P)), bt(np.zeros(P), (T, P)))
-    ms, Ps, ell = H.filtering(ys, lg, 4, dtype=dtype, chains=True, chain_axis=False)
+    ms, Ps, ell = H.filtering(ys, lg, E, dtype=dtype, chains=True, chain_axis=False)
     eps = rng.standard_normal((C, T, d))
-    xs = H.sampling(eps, ms, Ps, lg, 4, dtype=dtype, chains=True)
+    xs = H.sampling(eps, ms, Ps, lg, E, dtype=dtype, chains=True)
     for c in range(C):
         oms, oPs, oell = K.filtering(ys[c], lg, True)
         npt.assert_allclose(ms[c], oms, **tol)
