@@ -11,6 +11,9 @@
 //                      and writes the outputs in the caller's dense layout.
 // No inter-workgroup communication inside a launch, so no spin-waits and a deterministic combination tree.
 #pragma once
+#include <algorithm>
+#include <cstdlib>
+
 #include "ctx.h"
 
 namespace ax {
@@ -468,7 +471,12 @@ inline ScanLayout make_layout(const ScanPlan& pl, int cm, int S) {
     const int W = pl.nchunk < 64 ? pl.nchunk : 64;
     return ScanLayout{pl.E, pl.nchunk, (pl.nchunk + W - 1) / W, W, cm, S};
 }
-constexpr int TI_CM = 8;  // time steps per wave in the chain-minor elementwise kernels
+// time steps per wave in the chain-minor elementwise kernels (AUXSSM_TI overrides, for tuning)
+inline int ti_cm() {
+    static int v = [] { const char* e = getenv("AUXSSM_TI"); const int t = e ? atoi(e) : 16; return t >= 1 && t <= 1024 ? t : 16; }();
+    return v;
+}
+#define TI_CM ti_cm()
 
 // `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
 template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
@@ -502,7 +510,7 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     // (the time-minor layout is never smaller than the chain-minor one)
     b += (size_t)S * lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + 256;
     b += (size_t)S * sizeof(R) + 256;                           // ell0
-    b += (size_t)S * (cmax(ntiles(n), (n + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;  // ell partials
+    b += (size_t)S * (std::max(ntiles(n), (n + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;  // ell partials
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
     return b;
 }
@@ -584,7 +592,7 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
 }
 
 template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * (cmax(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;
+    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;
 }
 // out: [5][C]
 template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {

@@ -168,9 +168,9 @@ def run_csmc(args, rank, world, local_rank, dist, torch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=64, help="chains per GPU")
+    ap.add_argument("--chains", type=int, default=256, help="chains per GPU (SURVEY 8d lists 1, 8, 64, 256 for C2)")
     ap.add_argument("--T", type=int, default=65536)
     ap.add_argument("--d", type=int, default=4)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
