@@ -404,13 +404,21 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
 }
 
 // ---- RNG fill -----------------------------------------------------------------------------------------------------
-template <typename R, bool NORMAL>
-__global__ void k_rng_fill(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
+template <typename R> __global__ void k_rng_uniform(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t x0 = (uint32_t)(i & 0xffffffffu), x1 = stream ^ (uint32_t)((unsigned long long)i >> 32 << 16);
+    if (i < n) out[i] = stream_uniform<R>(k0, k1, stream, (unsigned long long)i);
+}
+// one Threefry block -> out[2 i], out[2 i + 1]
+template <typename R> __global__ void k_rng_normal(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i >= n) return;
+    uint32_t x0, x1;
+    stream_counter(stream, (unsigned long long)i, x0, x1);
     threefry2x32(k0, k1, x0, x1);
-    out[i] = NORMAL ? bits_to_normal<R>(x0, x1) : bits_to_uniform<R>(x0);
+    R z0, z1;
+    bits_to_normal2<R>(x0, x1, z0, z1);
+    out[2 * i] = z0;
+    if (2 * i + 1 < n) out[2 * i + 1] = z1;
 }
 
 }  // namespace ax
@@ -674,13 +682,14 @@ static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32
         return AUXSSM_ERR_ARG;
     }
     if (n == 0) return AUXSSM_OK;
-    const unsigned grid = (unsigned)((n + 255) / 256);
+    const long long work = normal ? (n + 1) / 2 : n;
+    const unsigned grid = (unsigned)((work + 255) / 256);
     if (dtype == AUXSSM_F32) {
-        if (normal) hipLaunchKernelGGL((k_rng_fill<float, true>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
-        else hipLaunchKernelGGL((k_rng_fill<float, false>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
+        if (normal) hipLaunchKernelGGL((k_rng_normal<float>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
+        else hipLaunchKernelGGL((k_rng_uniform<float>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
     } else {
-        if (normal) hipLaunchKernelGGL((k_rng_fill<double, true>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
-        else hipLaunchKernelGGL((k_rng_fill<double, false>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
+        if (normal) hipLaunchKernelGGL((k_rng_normal<double>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
+        else hipLaunchKernelGGL((k_rng_uniform<double>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
     }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;

@@ -52,15 +52,11 @@ enum { STREAM_EPS_AUX = 1, STREAM_EPS_PROP = 2, STREAM_U_RES = 3, STREAM_U_BWD =
 
 template <typename R> __device__ __forceinline__ R noise_normal(const CsmcArgs& a, const void* arr, uint32_t stream, long long idx) {
     if (a.noise_mode == 0) return ((const R*)arr)[idx];
-    uint32_t x0 = (uint32_t)(idx & 0xffffffffll), x1 = stream ^ (uint32_t)((unsigned long long)idx >> 32 << 16);
-    threefry2x32(a.key0, a.key1, x0, x1);
-    return bits_to_normal<R>(x0, x1);
+    return stream_normal<R>(a.key0, a.key1, stream, (unsigned long long)idx);
 }
 template <typename R> __device__ __forceinline__ R noise_uniform(const CsmcArgs& a, const void* arr, uint32_t stream, long long idx) {
     if (a.noise_mode == 0) return ((const R*)arr)[idx];
-    uint32_t x0 = (uint32_t)(idx & 0xffffffffll), x1 = stream ^ (uint32_t)((unsigned long long)idx >> 32 << 16);
-    threefry2x32(a.key0, a.key1, x0, x1);
-    return bits_to_uniform<R>(x0);
+    return stream_uniform<R>(a.key0, a.key1, stream, (unsigned long long)idx);
 }
 
 AXD_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }

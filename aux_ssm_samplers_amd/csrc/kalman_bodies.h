@@ -34,6 +34,15 @@ template <typename R, int N> AX_HD void sts_(R* __restrict__ p, long long se, co
     for (int i = 0; i < N; ++i) p[i * se] = v[i];
 }
 template <typename R, int N> AX_HD void rd(const Arr& a, int c, long long t, int b, R* out) { lds_<R, N>(at<R>(a, c, t, b), a.se, out); }
+// only the upper triangle (row <= col) of a symmetric P x P record: the covariance consumers never touch the rest, and the
+// 28 doubles (P = 8) it saves per lane are the difference between spilling and not in the p = 8 kernels
+template <typename R, int P> AX_HD void lds_upper_(const R* __restrict__ p, long long se, R* out) {
+#pragma unroll
+    for (int k = 0; k < P; ++k)
+#pragma unroll
+        for (int l = k; l < P; ++l) out[k * P + l] = p[(long long)(k * P + l) * se];
+}
+template <typename R, int P> AX_HD void rd_upper(const Arr& a, int c, long long t, int b, R* out) { lds_upper_<R, P>(at<R>(a, c, t, b), a.se, out); }
 template <typename R, int N> AX_HD void wr(const Arr& a, int c, long long t, int b, const R* v) {
     sts_<R, N>(const_cast<R*>(at<R>(a, c, t, b)), a.se, v);
 }
@@ -84,6 +93,10 @@ struct DirectIO {
         }
     }
     template <typename R, int N> AX_HD void finish(long long /*lane_stride*/, long long /*se*/, bool /*valid*/, R* /*buf*/) const {}
+    // symmetric P x P record: upper triangle only, always a direct read
+    template <typename R, int P> AX_HD void fetch_upper(const R* lane_ptr, long long se, bool valid, R* buf) const {
+        if (valid) lds_upper_<R, P>(lane_ptr, se, buf);
+    }
 };
 
 struct FilterArgs {
@@ -113,7 +126,7 @@ template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& 
     rd<R, P * D>(a.Hs, c, 0, b, H);
     rd<R, P>(a.cs, c, 0, b, cv);
     rd<R, P>(a.ys, c, 0, b, y);
-    rd<R, P * P>(a.Rs, c, 0, b, Rm);
+    rd_upper<R, P>(a.Rs, c, 0, b, Rm);
     const R ell = kalman_update<R, D, P>(m, Pd, H, cv, Rm, y);
     wr<R, D>(a.ms, c, 0, b, m);
     wr<R, D * D>(a.Ps, c, 0, b, Pd);
@@ -133,14 +146,13 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
     io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
     io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
     io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
-    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template fetch_upper<R, P>(at<R>(a.Rs, c, t, b), a.Rs.se, valid, Rm);
     io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
     io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
     io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, P_);
     io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
     io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
     io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
-    io.template finish<R, P * P>(a.Rs.st, a.Rs.se, valid, Rm);
     if (!valid) return;
     if (i == 0) {
         // first transition: built around predict(m0+, P0+)  (m_ = F m + b, P_ = F P F^T + Q, not symmetrised: filtering.py:200-201)
@@ -178,7 +190,7 @@ AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
     io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
     io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
-    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template fetch_upper<R, P>(at<R>(a.Rs, c, t, b), a.Rs.se, valid, Rm);
     io.template finish<R, D>(a.ms.st, a.ms.se, valid, m);
     io.template finish<R, D * D>(a.Ps.st, a.Ps.se, valid, Pd);
     io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
@@ -187,7 +199,6 @@ AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
     io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
     io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
-    io.template finish<R, P * P>(a.Rs.st, a.Rs.se, valid, Rm);
     if (!valid) return (R)0;
     kalman_predict<R, D>(m, Pd, F, bd, Q);
     return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
@@ -195,11 +206,13 @@ AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
 
 // ---- scan operator: parallel filter ----------------------------------------------------------------
 struct ScanBufs {
-    void* agg;  // [S][nchunk][Full::NPAD]
-    void* pre;  // [S][nchunk][Pre::NPAD]
+    void* agg;   // [S][nchunk][Full::NPAD]
+    void* pre;   // [S][nchunk][Pre::NPAD]
+    void* hook;  // [S][nchunk] per-chunk sums of Op::hook (ops with HAS_HOOK), else unused
 };
 
 template <typename R_, int D> struct FilterOp {
+    static constexpr bool HAS_HOOK = false;
     using R = R_;
     using Full = FiltElem<R, D>;
     using Pre = FiltPre<R, D>;
@@ -285,6 +298,39 @@ template <typename R_, int D> struct FilterOp {
     }
 };
 
+// FilterOp whose final pass also accumulates the marginal log-likelihood (filtering.py:60-62): while the final pass holds the
+// filtered moments of time i in registers (the prefix BEFORE element i is applied), the increment of step i+1 is
+// log N(y_{i+1}; H m^- + c, S) with (m^-, P^-) = predict(m_i, P_i) -- the same kalman_ell_inc as the separate pass, on the same
+// values, so ell is unchanged; only the extra pass over ms / Ps disappears.
+template <typename R_, int D, int P> struct FilterOpEll : FilterOp<R_, D> {
+    static constexpr bool HAS_HOOK = true;
+    using R = R_;
+    using Base = FilterOp<R_, D>;
+    using Pre = typename Base::Pre;
+    static AX_HD R hook(const FilterArgs& a, int s, int i, const Pre& p) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)i + 1;
+        R m[D], Pd[D * D], F[D * D], bd[D], Q[D * D], H[P * D], cv[P], y[P], Rm[P * P];
+        if (i == 0) {  // the prefix of the first element is the identity; the moments at t = 0 come from the t = 0 update
+            rd<R, D>(a.ms, c, 0, b, m);
+            rd<R, D * D>(a.Ps, c, 0, b, Pd);
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) m[k] = p.b[k];
+            symunpack<R, D>(p.C, Pd);
+        }
+        rd<R, D * D>(a.Fs, c, i, b, F);
+        rd<R, D>(a.bs, c, i, b, bd);
+        rd<R, D * D>(a.Qs, c, i, b, Q);
+        rd<R, P * D>(a.Hs, c, t, b, H);
+        rd<R, P>(a.cs, c, t, b, cv);
+        rd<R, P>(a.ys, c, t, b, y);
+        rd_upper<R, P>(a.Rs, c, t, b, Rm);
+        kalman_predict<R, D>(m, Pd, F, bd, Q);
+        return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
+    }
+};
+
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SampleArgs {
     KDims d;
@@ -337,6 +383,7 @@ template <typename R, int D> AX_HD void body_sample_last(const SampleArgs& a, in
 }
 
 template <typename R_, int D> struct SampleOp {
+    static constexpr bool HAS_HOOK = false;
     using R = R_;
     using Full = SampElem<R, D>;
     using Pre = SampPre<R, D>;
@@ -427,7 +474,7 @@ template <typename R, int D, int P, class IO> AX_HD R body_joint_logpdf(const Lo
     io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
     io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
     io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
-    io.template fetch<R, P * P>(at<R>(a.Rs, c, t, b), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template fetch_upper<R, P>(at<R>(a.Rs, c, t, b), a.Rs.se, valid, Rm);
     io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, a.Fs.se, valid, F);
     io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, a.bs.se, valid, bd);
     io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, a.Qs.se, valid, Q);
@@ -436,7 +483,6 @@ template <typename R, int D, int P, class IO> AX_HD R body_joint_logpdf(const Lo
     io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
     io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
     io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
-    io.template finish<R, P * P>(a.Rs.st, a.Rs.se, valid, Rm);
     io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
     io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
     io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, Q);
@@ -486,7 +532,7 @@ template <typename R, int D, int P> AX_HD R body_joint_logpdf_head(const LogpdfA
     }
     {
         R Rm[P * P];
-        rd<R, P * P>(a.Rs, c, 0, b, Rm);
+        rd_upper<R, P>(a.Rs, c, 0, b, Rm);
         out += gauss_logpdf<R, P>(res, Rm, a.nan_policy == 1 ? skip : nullptr);
     }
     R r0[D], P0m[D * D];
@@ -579,7 +625,7 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
     io.template fetch<R, PO * D>(at<R>(a.Hs, c, t, 0), a.Hs.st, a.Hs.se, valid, H);
     io.template fetch<R, PO>(at<R>(a.cs, c, t, 0), a.cs.st, a.cs.se, valid, cv);
     io.template fetch<R, PO>(at<R>(a.ys, c, t, 0), a.ys.st, a.ys.se, valid, y);
-    io.template fetch<R, PO * PO>(at<R>(a.Rs, c, t, 0), a.Rs.st, a.Rs.se, valid, Rm);
+    io.template fetch_upper<R, PO>(at<R>(a.Rs, c, t, 0), a.Rs.se, valid, Rm);
     io.template fetch<R, D * D>(at<R>(a.Fs, c, i, 0), a.Fs.st, a.Fs.se, valid, F);
     io.template fetch<R, D>(at<R>(a.bs, c, i, 0), a.bs.st, a.bs.se, valid, bd);
     io.template fetch<R, D * D>(at<R>(a.Qs, c, i, 0), a.Qs.st, a.Qs.se, valid, Q);
@@ -591,7 +637,6 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
     io.template finish<R, PO * D>(a.Hs.st, a.Hs.se, valid, H);
     io.template finish<R, PO>(a.cs.st, a.cs.se, valid, cv);
     io.template finish<R, PO>(a.ys.st, a.ys.se, valid, y);
-    io.template finish<R, PO * PO>(a.Rs.st, a.Rs.se, valid, Rm);
     io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
     io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
     io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, Q);
@@ -621,7 +666,7 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_head(const Swe
     rd<R, D>(a.x, c, 0, 0, x);
     rd<R, D>(a.xp, c, 0, 0, xp);
     rd<R, D>(a.u, c, 0, 0, u);
-    rd<R, PO * PO>(a.Rs, c, 0, 0, Rm);
+    rd_upper<R, PO>(a.Rs, c, 0, 0, Rm);
     rd<R, D * D>(a.P0, c, 0, 0, P0m);
     rd<R, PO * D>(a.Hs, c, 0, 0, H);
     rd<R, PO>(a.cs, c, 0, 0, cv);

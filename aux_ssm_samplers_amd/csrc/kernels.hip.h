@@ -66,6 +66,9 @@ template <typename R> struct WaveIO {
             for (int e = 0; e < N; ++e) buf[e] = 0;
         }
     }
+    template <typename R2, int P> __device__ __forceinline__ void fetch_upper(const R2* lane_ptr, long long se, bool valid, R2* buf) const {
+        if (valid) lds_upper_<R2, P>(lane_ptr, se, buf);
+    }
     // phase 2: scatter the stream into an LDS image with an odd record stride, then read this lane's record back.
     template <typename R2, int N> __device__ __forceinline__ void finish(long long stride, long long se, bool valid, R2* buf) const {
         if (se == 1 && (stride == N || stride == -N)) {
@@ -321,15 +324,32 @@ __global__ void __launch_bounds__(TB_CM) k_scan_down_cm(typename Op::Args a, Sca
         Op::identity(id);
         Op::to_pre(id, p);
     }
-    Full nxt;
-    if (i0 < i1) Op::load_elem(a, s, i0, nxt);
-    for (int i = i0; i < i1; ++i) {
-        const Full cur = nxt;
-        if (i + 1 < i1) Op::load_elem(a, s, opaque_uniform(i + 1), nxt);
-        Pre o;
-        Op::apply(p, cur, o);
-        p = o;
-        Op::write_out(a, s, opaque_uniform(i), p);
+    if constexpr (Op::HAS_HOOK) {
+        // the element's reads are issued first and fly during the (compute-heavy) hook; no second element buffer, which
+        // would not fit next to the hook's working set (fp64 d=4 p=8: 512 registers + scratch with one)
+        R hacc = 0;
+        for (int i = i0; i < i1; ++i) {
+            const int iu = opaque_uniform(i);
+            Full cur;
+            Op::load_elem(a, s, iu, cur);
+            hacc += Op::hook(a, s, iu, p);
+            Pre o;
+            Op::apply(p, cur, o);
+            p = o;
+            Op::write_out(a, s, iu, p);
+        }
+        ((R*)sb.hook)[(long long)s * lay.nchunk + ch] = hacc;
+    } else {
+        Full nxt;
+        if (i0 < i1) Op::load_elem(a, s, i0, nxt);
+        for (int i = i0; i < i1; ++i) {
+            const Full cur = nxt;
+            if (i + 1 < i1) Op::load_elem(a, s, opaque_uniform(i + 1), nxt);
+            Pre o;
+            Op::apply(p, cur, o);
+            p = o;
+            Op::write_out(a, s, opaque_uniform(i), p);
+        }
     }
 }
 
@@ -479,11 +499,12 @@ inline int ti_cm() {
 #define TI_CM ti_cm()
 
 // `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
-template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
+// DownOp: the operator of the final pass (same element/prefix types as Op; may carry a per-step hook, chain-minor mode only)
+template <class Op, class DownOp = Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n, void* hook_part = nullptr) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
-    ScanBufs sb{nullptr, nullptr};
+    ScanBufs sb{nullptr, nullptr, hook_part};
     const unsigned grid = lay.cm ? (unsigned)((S + TB_CM - 1) / TB_CM) * lay.nchunk : (unsigned)S * lay.ngrp;
     const size_t stage = stage_bytes<R>(Op::Full::NPAD);
     if (lay.nchunk > 1) {
@@ -494,7 +515,7 @@ template <class Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int 
         const size_t lds = (size_t)TB_AGGS * Op::Full::NPAD * sizeof(R);
         hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, lay.nchunk);
     }
-    if (lay.cm) hipLaunchKernelGGL((k_scan_down_cm<Op>), dim3(grid), dim3(TB_CM), 0, h->stream, a, sb, S, n);
+    if (lay.cm) hipLaunchKernelGGL((k_scan_down_cm<DownOp>), dim3(grid), dim3(TB_CM), 0, h->stream, a, sb, S, n);
     else hipLaunchKernelGGL((k_scan_down<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
@@ -510,7 +531,7 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     // (the time-minor layout is never smaller than the chain-minor one)
     b += (size_t)S * lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + 256;
     b += (size_t)S * sizeof(R) + 256;                           // ell0
-    b += (size_t)S * (std::max(ntiles(n), (n + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;  // ell partials
+    b += (size_t)S * (std::max(ntiles(n), lay.nchunk) + 1) * sizeof(R) + 256;  // ell partials (per tile, or per chunk)
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
     return b;
 }
@@ -522,7 +543,8 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
     a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
-    const int nt = cm ? (n + TI_CM - 1) / TI_CM : ntiles(n);
+    // chain-minor: the log-likelihood increments are accumulated by the scan's final pass (FilterOpEll), one partial per chunk
+    const int nt = cm ? a.lay.nchunk : ntiles(n);
     R* part = (R*)ws_take(h, (size_t)S * (nt + 1) * sizeof(R));
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     if (n > 0) {
@@ -533,13 +555,12 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n);
+            const int rc = cm ? run_scan<FilterOp<R, D>, FilterOpEll<R, D, P>>(h, a, S, n, part) : run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
-        {
+        if (!cm) {
             ProfScope ps(h, AUXSSM_K_FILTER_ELL);
-            if (cm) hipLaunchKernelGGL((k_filter_ell_cm<R, D, P>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
-            else hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+            hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
         }
     }
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0,

@@ -1,5 +1,6 @@
 """ORACLE -- TEST INFRASTRUCTURE ONLY.  NumPy restatement of the device RNG fills (csrc/rng.h, api.hip::k_rng_fill):
-out[i] = f(threefry2x32(key, counter = (lo32(i), stream ^ (hi32(i) << 16)))).
+uniform[i] = f(block i), normal[i] = Box-Muller branch (i & 1) of block i >> 1, block b = threefry2x32(key,
+counter = (lo32(b), stream ^ (hi32(b) << 16))).
 Threefry-2x32-20 itself is pinned by the Random123 known-answer vectors (tests/test_rng.py).  The normal transform uses
 libm log/cos on both sides, so device-vs-oracle agreement for normals is to rounding (a few ulp), not bitwise; uniforms are
 bit-exact.  jax.random bit-compatibility is NOT claimed (unverifiable offline)."""
@@ -43,12 +44,18 @@ def uniform(key, stream, n, dtype):
 
 
 def normal(key, stream, n, dtype):
-    b0, b1 = _bits(key, stream, n)
+    nb = (n + 1) // 2
+    b0, b1 = _bits(key, stream, nb)
     if np.dtype(dtype) == np.float32:
         u1 = ((b0 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(5.9604644775390625e-8)
         u2 = ((b1 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(5.9604644775390625e-8)
         r = np.sqrt(np.float32(-2.0) * np.log(u1))
-        return (r * np.cos(np.float32(6.283185307179586) * u2)).astype(np.float32)
-    u1 = (b0.astype(np.float64) + 0.5) * 2.3283064365386963e-10
-    u2 = (b1.astype(np.float64) + 0.5) * 2.3283064365386963e-10
-    return np.sqrt(-2.0 * np.log(u1)) * np.cos(6.283185307179586476925286766559 * u2)
+        a = np.float32(6.283185307179586) * u2
+        z = np.stack([r * np.cos(a), r * np.sin(a)], axis=1).astype(np.float32)
+    else:
+        u1 = (b0.astype(np.float64) + 0.5) * 2.3283064365386963e-10
+        u2 = (b1.astype(np.float64) + 0.5) * 2.3283064365386963e-10
+        r = np.sqrt(-2.0 * np.log(u1))
+        a = 6.283185307179586476925286766559 * u2
+        z = np.stack([r * np.cos(a), r * np.sin(a)], axis=1)
+    return z.reshape(-1)[:n]
