@@ -154,8 +154,8 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
 
     def kernel(key, state, delta, noise=None):
         """state.x: ndarray (T, dx) [one chain], ndarray (C, T, dx) or DeviceChains (resident, updated in place)."""
-        handle = _lib.default_handle()
         resident = isinstance(state.x, DeviceChains)
+        handle = state.x.handle if resident else _lib.default_handle()  # resident chains carry their device
         chains = state.x if resident else DeviceChains(handle, state.x)
         if noise is None:
             eps_aux, eps_samp, u_acc = draw(handle, key, chains)

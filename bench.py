@@ -75,7 +75,7 @@ def sv_data(T, seed=0):
     return phi, q, x[:, None], y[:, None]
 
 
-def run_csmc(args, rank, world, local_rank, dist, torch):
+def run_csmc(args, rank, world, local_rank, dist, torch, coll_dev):
     """Secondary workload: BASELINE configs[2] = C3, SV d=1 T=65536, auxiliary cSMC with independent proposals, N=1024,
     backward sampling, fp32, in-kernel Threefry noise.  One step = one sweep of every chain on this GPU."""
     import ctypes as C
@@ -123,14 +123,14 @@ def run_csmc(args, rank, world, local_rank, dist, torch):
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     fn, fms = handle.prof_read()
     handle.prof_disable()
     moved = (anc.to_host() != 0).mean(axis=1)  # per-chain fraction of updated time steps
     if dist is not None:
-        g = gather_chains(moved[:, None], Cn * world, dist, dst=0, device=torch.device("cuda", local_rank))
+        g = gather_chains(moved[:, None], Cn * world, dist, dst=0, device=coll_dev)
         moved = g[:, 0] if rank == 0 else moved
     if rank == 0:
         s = np.dtype(dtype).itemsize
@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--workload", default="kalman", choices=["kalman", "csmc"],
                     help="kalman = BASELINE configs[1] (C2, the headline); csmc = configs[2] (C3), secondary")
     ap.add_argument("--N", type=int, default=1024, help="particles (csmc workload)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one rank per GPU) is what the driver runs; gloo + ranks sharing a GPU is a rehearsal mode")
     args = ap.parse_args()
     if args.workload == "csmc" and args.dtype == "f64" and "--dtype" not in " ".join(sys.argv):
         args.dtype = "f32"
@@ -189,15 +191,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     import torch
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "gloo":
+        local_rank = local_rank % max(ndev, 1)  # rehearsal: ranks may share a GPU
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo")
     else:
         torch.cuda.set_device(local_rank)
+    coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
 
     if args.workload == "csmc":
-        return run_csmc(args, rank, world, local_rank, dist, torch)
+        return run_csmc(args, rank, world, local_rank, dist, torch, coll_dev)
 
     from aux_ssm_samplers_amd import _lib, random as R
     from aux_ssm_samplers_amd.kalman import get_kernel
@@ -240,7 +249,7 @@ def main():
     barrier()
     el = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device="cuda")
+        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         el = float(t.item())
     scan_n, scan_ms = (0, 0.0)
@@ -254,7 +263,7 @@ def main():
     logs = chains.logs.to_host()
     if dist is not None:
         per_chain = np.concatenate([acc[:, None].astype(np.float64), logs.astype(np.float64)], axis=1)  # (C, 6)
-        g = gather_chains(per_chain, C * world, dist, dst=0, device=torch.device("cuda", local_rank))
+        g = gather_chains(per_chain, C * world, dist, dst=0, device=coll_dev)
         if rank == 0:
             acc, logs = g[:, 0], g[:, 1:]
 
