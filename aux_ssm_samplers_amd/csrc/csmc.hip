@@ -132,11 +132,6 @@ template <typename R> __device__ __forceinline__ R wave_scan_ks(R v, int lane) {
     return v;
 }
 
-struct Smem {
-    // carved from dynamic LDS
-    char* base;
-};
-
 // normalize (math/utils.py:23-39): w = exp(lw - logsumexp(lw)); logsumexp = log(sum(exp(lw - max))) + max
 // red: 32 slots (max in [0,16), sum in [16,32)); the caller guarantees a barrier between two calls (the cumsum's).
 template <typename R> __device__ __forceinline__ R block_normalize(R lw, R* red, int tid, int nw) {

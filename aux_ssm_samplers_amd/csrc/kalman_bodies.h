@@ -457,6 +457,32 @@ template <typename R_, int D> struct SampleOp {
     }
 };
 
+// SampleOp that never materialises its elements: load_elem builds (G_t, inc_t) from the filtered moments, the dynamics and the
+// noise (sampling.py:60-124) each time a pass needs it.  Both scan passes then stream ms / Ps / eps (d^2 + 2d reals per step)
+// instead of writing and re-reading the (d^2 + d)-real element buffer, and the sample-init launch disappears; the extra
+// arithmetic (one d x d Cholesky + SPD solve per step and pass) is small next to the saved HBM traffic.  Chain-minor mode only.
+template <typename R_, int D> struct SampleOpFly : SampleOp<R_, D> {
+    using R = R_;
+    using Full = typename SampleOp<R_, D>::Full;
+    static AX_HD void load_elem(const SampleArgs& a, int s, int j, Full& e) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)a.d.T - 1 - j;
+        R m[D], Pd[D * D], eps[D];
+        rd<R, D>(a.ms, c, t, b, m);
+        rd<R, D * D>(a.Ps, c, t, b, Pd);
+        rd<R, D>(a.eps, c, t, b, eps);
+        if (j == 0) {
+            sample_last<R, D>(m, Pd, eps, e);
+        } else {
+            R F[D * D], Q[D * D], bd[D];
+            rd<R, D * D>(a.Fs, c, t, b, F);
+            rd<R, D * D>(a.Qs, c, t, b, Q);
+            rd<R, D>(a.bs, c, t, b, bd);
+            sample_elem<R, D>(F, Q, bd, m, Pd, eps, e);
+        }
+    }
+};
+
 // ---- joint log-density of a trajectory: log_likelihood + prior_logpdf (base.py:99-166) ----------------
 struct LogpdfArgs {
     KDims d;

@@ -211,7 +211,7 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample
 // A workgroup = one wave = 64 sequences x a tile of TI consecutive time steps; reductions over time are per-lane sums.
 constexpr int TB_CM = 64;
 // Wave-uniform loop index made opaque to loop-strength-reduction: with runtime strides LSR otherwise keeps one 64-bit
-// induction pointer PER LOAD of the body in VGPRs (k_filter_ell_cm<double,4,8>: 512 registers + scratch vs 316 with this).
+// induction pointer PER LOAD of the body in VGPRs (a log-likelihood tile loop at fp64 d=4 p=8: 512 registers + scratch vs 316 with this).
 __device__ __forceinline__ int opaque_uniform(int i) {
     int ii = __builtin_amdgcn_readfirstlane(i);
     asm volatile("" : "+s"(ii));
@@ -241,18 +241,6 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_f
     for (int i = c.i0; i < c.i1; ++i) {
         body_filter_init<R, D, P>(a, io, c.s, opaque_uniform(i), true);
     }
-}
-template <typename R, int D, int P>
-__global__ void __launch_bounds__(TB_CM) k_filter_ell_cm(FilterArgs a, R* __restrict__ part, int ntile, int TI) {
-    const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
-    if (!c.live) return;
-    DirectIO io;
-    R acc = 0;
-#pragma unroll 1
-    for (int i = c.i0; i < c.i1; ++i) {
-        acc += body_filter_ell<R, D, P>(a, io, c.s, opaque_uniform(i), true);
-    }
-    part[(long long)c.s * ntile + c.tt] = acc;
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_init_cm(SampleArgs a, int TI) {
     const CmTile c = decode_cm(a.d.S(), a.d.T - 1, TI);
@@ -500,7 +488,8 @@ inline int ti_cm() {
 
 // `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
 // DownOp: the operator of the final pass (same element/prefix types as Op; may carry a per-step hook, chain-minor mode only)
-template <class Op, class DownOp = Op> int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n, void* hook_part = nullptr) {
+template <class Op, class DownOp = Op, class ReduceOp = Op>
+int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n, void* hook_part = nullptr) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
@@ -510,7 +499,7 @@ template <class Op, class DownOp = Op> int run_scan(auxssm_ctx* h, const typenam
     if (lay.nchunk > 1) {
         sb.agg = ws_take(h, (size_t)S * lay.nchunk * Op::Full::NPAD * sizeof(R));
         sb.pre = ws_take(h, (size_t)S * lay.nchunk * Op::Pre::NPAD * sizeof(R));
-        if (lay.cm) hipLaunchKernelGGL((k_scan_reduce_cm<Op>), dim3(grid), dim3(TB_CM), 0, h->stream, a, sb, S, n);
+        if (lay.cm) hipLaunchKernelGGL((k_scan_reduce_cm<ReduceOp>), dim3(grid), dim3(TB_CM), 0, h->stream, a, sb, S, n);
         else hipLaunchKernelGGL((k_scan_reduce<Op>), dim3(grid), dim3(TB_SCAN), stage, h->stream, a, sb, n);
         const size_t lds = (size_t)TB_AGGS * Op::Full::NPAD * sizeof(R);
         hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, lay.nchunk);
@@ -580,6 +569,16 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
     const int S = a.d.S(), T = a.d.T;
     const int cm = a_in.lay.cm;
     a.lay = make_layout(plan_scan(h, S, T, parallel), cm, S);
+    static const bool fly = [] { const char* e = getenv("AUXSSM_SAMPLE_FLY"); return e ? atoi(e) != 0 : true; }();
+    if (cm && fly) {
+        // chain-minor: elements are recomputed on the fly by both scan passes (SampleOpFly), nothing to initialise
+        a.elem = nullptr;
+        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
+        const int rc = run_scan<SampleOp<R, D>, SampleOpFly<R, D>, SampleOpFly<R, D>>(h, a, S, T);
+        if (rc) return rc;
+        AX_HIP(hipGetLastError());
+        return AUXSSM_OK;
+    }
     a.elem = ws_take(h, (size_t)a.lay.total_reals(T, S, SampElem<R, D>::NPAD) * sizeof(R));
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
