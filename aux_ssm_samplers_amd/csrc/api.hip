@@ -188,6 +188,7 @@ static void fill_filter_args(FilterArgs& a, const auxssm_dims* d, const auxssm_l
     a.ms = dense_arr(ms, a.d, d->dx); a.Ps = dense_arr(Ps, a.d, (long long)d->dx * d->dx);
     a.elem = nullptr; a.ell0 = nullptr;
     a.lay = ScanLayout{1, 1, 1, 1, 0, d->C * d->B};
+    a.pblk = 0;
 }
 static void fill_logpdf_args(LogpdfArgs& a, const auxssm_dims* d, const auxssm_lgssm* g, const Arr& ys, const Arr& xs, int pol) {
     a.d = KDims{d->C, d->T, d->B};
@@ -369,6 +370,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     fa.ms = msA;
     fa.Ps = PsA;
     fa.lay.cm = cm;
+    fa.pblk = D;  // R = blkdiag(delta/2 I_d, Robs) by construction
     rc = ke->filter(h, fa, parallel, ell);
     if (rc) return rc;
     h->ws_off = mark;

@@ -107,6 +107,7 @@ struct FilterArgs {
     void* elem;     // scan elements, layout `lay`
     void* ell0;     // [S]
     ScanLayout lay;
+    int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
 };
 AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
     return Arr{p, (long long)d.T * d.B * rec, (long long)d.B * rec, rec, 1};
@@ -135,7 +136,7 @@ template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& 
 
 template <typename R_, int D> struct FilterOp;
 // ---- scan element for transition i -> i+1 (filtering.py:188-250) ---------------------------------
-template <typename R, int D, int P, class IO>
+template <typename R, int D, int P, class IO, int P1 = 0>
 AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
@@ -172,12 +173,13 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
         for (int k = 0; k < D; ++k) m_[k] = bd[k];
     }
     FiltElem<R, D> e;
-    filter_elem<R, D, P>(F, bd, m_, P_, H, cv, Rm, y, e);
+    if constexpr (P1 > 0 && P1 < P) filter_elem_blk<R, D, P, P1>(F, bd, m_, P_, H, cv, Rm, y, e);
+    else filter_elem<R, D, P>(F, bd, m_, P_, H, cv, Rm, y, e);
     FilterOp<R, D>::store_elem(a, s, i, e);
 }
 
 // ---- log-likelihood increment of step i+1 from the filtered moments at i (filtering.py:60) ---------
-template <typename R, int D, int P, class IO>
+template <typename R, int D, int P, class IO, int P1 = 0>
 AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
@@ -201,7 +203,8 @@ AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
     io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
     if (!valid) return (R)0;
     kalman_predict<R, D>(m, Pd, F, bd, Q);
-    return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
+    if constexpr (P1 > 0 && P1 < P) return kalman_ell_inc_blk<R, D, P, P1>(m, Pd, H, cv, Rm, y);
+    else return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
 }
 
 // ---- scan operator: parallel filter ----------------------------------------------------------------
@@ -302,7 +305,7 @@ template <typename R_, int D> struct FilterOp {
 // filtered moments of time i in registers (the prefix BEFORE element i is applied), the increment of step i+1 is
 // log N(y_{i+1}; H m^- + c, S) with (m^-, P^-) = predict(m_i, P_i) -- the same kalman_ell_inc as the separate pass, on the same
 // values, so ell is unchanged; only the extra pass over ms / Ps disappears.
-template <typename R_, int D, int P> struct FilterOpEll : FilterOp<R_, D> {
+template <typename R_, int D, int P, int P1 = 0> struct FilterOpEll : FilterOp<R_, D> {
     static constexpr bool HAS_HOOK = true;
     using R = R_;
     using Base = FilterOp<R_, D>;
@@ -327,7 +330,8 @@ template <typename R_, int D, int P> struct FilterOpEll : FilterOp<R_, D> {
         rd<R, P>(a.ys, c, t, b, y);
         rd_upper<R, P>(a.Rs, c, t, b, Rm);
         kalman_predict<R, D>(m, Pd, F, bd, Q);
-        return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
+        if constexpr (P1 > 0 && P1 < P) return kalman_ell_inc_blk<R, D, P, P1>(m, Pd, H, cv, Rm, y);
+        else return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
     }
 };
 

@@ -236,6 +236,47 @@ template <typename R, int D> AX_HD void kalman_predict(R* m, R* Pd, const R* F, 
         for (int j = 0; j < D; ++j) Pd[i * D + j] = (i == j) ? Pn[i * D + i] : (R)0.5 * (Pn[i * D + j] + Pn[j * D + i]);
 }
 
+// element from the information quantities M = H^T S^-1 H (packed sym), vm = H^T S^-1 (y - H m_ - c), vb = H^T S^-1 (y - H b - c):
+//   A = F - P_ M F;  b = m_ + P_ vm;  C = P_ - P_ M P_;  eta = F^T vb;  J = F^T M F
+template <typename R, int D>
+AX_HD void filter_elem_from_info(const R* F, const R* m_, const R* P_, const R* M, const R* vm, const R* vb, FiltElem<R, D>& e) {
+    R PM[D * D], MF[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s1 += P_[i * D + k] * M[sidx(D, k, j)], s2 += M[sidx(D, i, k)] * F[k * D + j];
+            PM[i * D + j] = s1;
+            MF[i * D + j] = s2;
+        }
+    R Cd[D * D], Jd[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R sb = m_[i], se = 0;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R sa = F[i * D + j], sc = P_[i * D + j], sj = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                sa -= PM[i * D + k] * F[k * D + j];
+                sc -= PM[i * D + k] * P_[k * D + j];
+                sj += F[k * D + i] * MF[k * D + j];
+            }
+            e.A[i * D + j] = sa;
+            Cd[i * D + j] = sc;
+            Jd[i * D + j] = sj;
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) sb += P_[i * D + k] * vm[k], se += F[k * D + i] * vb[k];
+        e.b[i] = sb;
+        e.eta[i] = se;
+    }
+    sympack<R, D>(Cd, e.C);
+    sympack<R, D>(Jd, e.J);
+}
+
 // _filtering_init_one (filtering.py:196-250).  (m_, P_) are the *predicted* moments the element is built
 // around: predict(m0+, P0+) for the first transition, (b, Q) for every other one (:188-192).
 template <typename R, int D, int P>
@@ -295,41 +336,175 @@ AX_HD void filter_elem(const R* F, const R* bdyn, const R* m_, const R* P_, cons
             M[sidx_u(D, i, j)] = ok ? s : r_nan<R>();
         }
     }
-    R PM[D * D], MF[D * D];
+    filter_elem_from_info<R, D>(F, m_, P_, M, vm, vb, e);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Information form for a BLOCK-DIAGONAL observation covariance R = blkdiag(R_1 (P1 x P1), R_2 (P-P1 x P-P1)), e.g. the
+// auxiliary observations concatenated with the real ones (R = blkdiag(delta/2 I, Robs)).  With
+//     Lam = H^T R^-1 H = sum_b H_b^T R_b^-1 H_b,   g(r) = H^T R^-1 r = sum_b H_b^T R_b^-1 r_b,
+// the push-through / Woodbury / determinant identities give, for S = H P H^T + R,
+//     H^T S^-1 H = (I + Lam P)^-1 Lam,   H^T S^-1 r = (I + Lam P)^-1 g(r),
+//     r^T S^-1 r = r^T R^-1 r - g^T P (I + Lam P)^-1 g,   log|S| = log|R| + log|I + Lam P|,
+// i.e. the same M, v and log-likelihood as the dense p x p Cholesky of S (filtering.py:106-117, :214-236) from two small
+// Cholesky factors and one d x d LU.  Missing components are deleted inside their block (skip), as in the dense path.
+// Needs R_b positive definite; the dense path stays the default and the only one for general R.
+// ------------------------------------------------------------------------------------------------
+// One block: rows [O, O+PB) of H (P x D), c, y and the diagonal block of R (upper entries of the P x P record).
+// Accumulates Lam (packed sym D), g1 = H_b^T R_b^-1 r1, g2 (second residual, may alias the first), q1 = r1^T R_b^-1 r1,
+// logdet += sum log L_kk, dim += #observed.
+template <typename R, int D, int P, int O, int PB>
+AX_HD bool info_block(const R* H, const R* Rm, const bool* nan, const R* r1, const R* r2, R* Lam, R* g1, R* g2, R& q1, R& logdet, int& dim) {
+    R L[symsize(PB)], invd[PB], W[PB * D], z1[PB], z2[PB];
+    bool sk[PB];
 #pragma unroll
-    for (int i = 0; i < D; ++i)
+    for (int k = 0; k < PB; ++k) {
+        sk[k] = nan[O + k];
+        z1[k] = sk[k] ? (R)0 : r1[O + k];
+        z2[k] = sk[k] ? (R)0 : r2[O + k];
+        dim += sk[k] ? 0 : 1;
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
-            R s1 = 0, s2 = 0;
+        for (int l = 0; l <= k; ++l) L[lidx(k, l)] = (sk[k] || sk[l]) ? (R)0 : Rm[(O + l) * P + (O + k)];
 #pragma unroll
-            for (int k = 0; k < D; ++k) s1 += P_[i * D + k] * M[sidx(D, k, j)], s2 += M[sidx(D, i, k)] * F[k * D + j];
-            PM[i * D + j] = s1;
-            MF[i * D + j] = s2;
-        }
-    R Cd[D * D], Jd[D * D];
+        for (int j = 0; j < D; ++j) W[k * D + j] = sk[k] ? (R)0 : H[(O + k) * D + j];
+    }
+    const bool ok = chol_inplace<R, PB>(L, invd, sk);
+#pragma unroll
+    for (int k = 0; k < PB; ++k) logdet += sk[k] ? (R)0 : log_(L[lidx(k, k)]);
+#pragma unroll
+    for (int j = 0; j < D; ++j) lsolve_col<R, PB, D>(L, invd, W, j);
+    lsolve<R, PB>(L, invd, z1);
+    lsolve<R, PB>(L, invd, z2);
+#pragma unroll
+    for (int k = 0; k < PB; ++k) q1 += z1[k] * z1[k];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
-        R sb = m_[i], se = 0;
+        R s1 = 0, s2 = 0;
+#pragma unroll
+        for (int k = 0; k < PB; ++k) s1 += W[k * D + i] * z1[k], s2 += W[k * D + i] * z2[k];
+        g1[i] += s1;
+        g2[i] += s2;
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            R s = 0;
+#pragma unroll
+            for (int k = 0; k < PB; ++k) s += W[k * D + i] * W[k * D + j];
+            Lam[sidx_u(D, i, j)] += s;
+        }
+    }
+    return ok;
+}
+
+// scan element, block-diagonal R (same outputs as filter_elem)
+template <typename R, int D, int P, int P1>
+AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, const R* H, const R* c, const R* Rm, const R* y,
+                           FiltElem<R, D>& e) {
+    bool nan[P];
+    bool any = false;
+    R rm[P], rb[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        nan[k] = !finite_(y[k]);
+        any = any || !nan[k];
+        R hm = c[k], hb = c[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) hm += H[k * D + j] * m_[j], hb += H[k * D + j] * bdyn[j];
+        rm[k] = y[k] - hm;
+        rb[k] = y[k] - hb;
+    }
+    if (!any) {  // _passthrough :239-248
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) e.A[i] = F[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) e.b[i] = m_[i], e.eta[i] = 0;
+        sympack<R, D>(P_, e.C);
+#pragma unroll
+        for (int i = 0; i < symsize(D); ++i) e.J[i] = 0;
+        return;
+    }
+    R Lam[symsize(D)], gm[D], gb[D];
+#pragma unroll
+    for (int i = 0; i < symsize(D); ++i) Lam[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) gm[i] = 0, gb[i] = 0;
+    R q = 0, logdet = 0;
+    int dim = 0;
+    bool ok = info_block<R, D, P, 0, P1>(H, Rm, nan, rm, rb, Lam, gm, gb, q, logdet, dim);
+    ok = info_block<R, D, P, P1, P - P1>(H, Rm, nan, rm, rb, Lam, gm, gb, q, logdet, dim) && ok;
+    // W2 = I + Lam P_ ;  [M | vm | vb] = W2^-1 [Lam | gm | gb]
+    constexpr int NR = D + 2;
+    R W2[D * D], B[D * NR];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            R sa = F[i * D + j], sc = P_[i * D + j], sj = 0;
+            R s = (i == j) ? (R)1 : (R)0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                sa -= PM[i * D + k] * F[k * D + j];
-                sc -= PM[i * D + k] * P_[k * D + j];
-                sj += F[k * D + i] * MF[k * D + j];
-            }
-            e.A[i * D + j] = sa;
-            Cd[i * D + j] = sc;
-            Jd[i * D + j] = sj;
+            for (int k = 0; k < D; ++k) s += Lam[sidx(D, i, k)] * P_[k * D + j];
+            W2[i * D + j] = s;
+            B[i * NR + j] = Lam[sidx(D, i, j)];
         }
-#pragma unroll
-        for (int k = 0; k < D; ++k) sb += P_[i * D + k] * vm[k], se += F[k * D + i] * vb[k];
-        e.b[i] = sb;
-        e.eta[i] = se;
+        B[i * NR + D] = gm[i];
+        B[i * NR + D + 1] = gb[i];
     }
-    sympack<R, D>(Cd, e.C);
-    sympack<R, D>(Jd, e.J);
+    lu_solve<R, D, NR>(W2, B);
+    R M[symsize(D)], vm[D], vb[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        vm[i] = ok ? B[i * NR + D] : r_nan<R>();
+        vb[i] = ok ? B[i * NR + D + 1] : r_nan<R>();
+#pragma unroll
+        for (int j = i; j < D; ++j) M[sidx_u(D, i, j)] = ok ? ((i == j) ? B[i * NR + i] : (R)0.5 * (B[i * NR + j] + B[j * NR + i])) : r_nan<R>();
+    }
+    filter_elem_from_info<R, D>(F, m_, P_, M, vm, vb, e);
+}
+
+// log-likelihood increment, block-diagonal R (same value as kalman_ell_inc)
+template <typename R, int D, int P, int P1>
+AX_HD R kalman_ell_inc_blk(const R* m, const R* Pd, const R* H, const R* c, const R* Rm, const R* y) {
+    bool nan[P];
+    bool any = false;
+    R r[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        nan[k] = !finite_(y[k]);
+        any = any || !nan[k];
+        R hm = c[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) hm += H[k * D + j] * m[j];
+        r[k] = y[k] - hm;
+    }
+    if (!any) return (R)0;
+    R Lam[symsize(D)], g[D], g2[D];
+#pragma unroll
+    for (int i = 0; i < symsize(D); ++i) Lam[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) g[i] = 0, g2[i] = 0;
+    R q = 0, logdet = 0;
+    int dim = 0;
+    bool ok = info_block<R, D, P, 0, P1>(H, Rm, nan, r, r, Lam, g, g2, q, logdet, dim);
+    ok = info_block<R, D, P, P1, P - P1>(H, Rm, nan, r, r, Lam, g, g2, q, logdet, dim) && ok;
+    R W2[D * D], z[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        z[i] = g[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = (i == j) ? (R)1 : (R)0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += Lam[sidx(D, i, k)] * Pd[k * D + j];
+            W2[i * D + j] = s;
+        }
+    }
+    const R ldw = lu_solve_logdet<R, D, 1>(W2, z);  // z = (I + Lam P)^-1 g
+    R Pg[D];
+    mv<R, D, D>(Pd, g, Pg);
+    R corr = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) corr += Pg[i] * z[i];
+    R ell = (R)-0.5 * (q - corr) - logdet - (R)0.5 * ldw - (R)(0.5 * LOG_2PI) * (R)dim;
+    if (!ok) ell = r_nan<R>();
+    return isnan_(ell) ? (R)0 : ell;
 }
 
 // ------------------------------------------------------------------------------------------------

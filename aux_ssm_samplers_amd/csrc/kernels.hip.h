@@ -233,13 +233,13 @@ __device__ __forceinline__ CmTile decode_cm(int S, int n, int TI) {
 }
 inline unsigned grid_cm(int S, int n, int TI) { return (unsigned)((S + TB_CM - 1) / TB_CM) * (unsigned)((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1); }
 
-template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_filter_init_cm(FilterArgs a, int TI) {
+template <typename R, int D, int P, int P1> __global__ void __launch_bounds__(TB_CM) k_filter_init_cm(FilterArgs a, int TI) {
     const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
     if (!c.live) return;
     DirectIO io;
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
-        body_filter_init<R, D, P>(a, io, c.s, opaque_uniform(i), true);
+        body_filter_init<R, D, P, DirectIO, P1>(a, io, c.s, opaque_uniform(i), true);
     }
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_init_cm(SampleArgs a, int TI) {
@@ -529,6 +529,9 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     FilterArgs a = a_in;
     const int S = a.d.S(), n = a.d.n();
     const int cm = a_in.lay.cm;  // the caller chose the layout of ms / Ps; the element buffer follows it
+    // block-diagonal R with a leading dx x dx block (the concatenated auxiliary observations): information form
+    static const bool blk_on = [] { const char* e = getenv("AUXSSM_INFO_BLOCKS"); return e ? atoi(e) != 0 : true; }();
+    const bool blk = blk_on && P > D && a_in.pblk == D;
     a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
     a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
@@ -539,12 +542,15 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     if (n > 0) {
         {
             ProfScope ps(h, AUXSSM_K_FILTER_INIT);
-            if (cm) hipLaunchKernelGGL((k_filter_init_cm<R, D, P>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+            if (cm && blk) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, (P > D ? D : 0)>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+            else if (cm) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, 0>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
             else hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-            const int rc = cm ? run_scan<FilterOp<R, D>, FilterOpEll<R, D, P>>(h, a, S, n, part) : run_scan<FilterOp<R, D>>(h, a, S, n);
+            const int rc = (cm && blk) ? run_scan<FilterOp<R, D>, FilterOpEll<R, D, P, (P > D ? D : 0)>>(h, a, S, n, part)
+                           : cm      ? run_scan<FilterOp<R, D>, FilterOpEll<R, D, P, 0>>(h, a, S, n, part)
+                                     : run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
         if (!cm) {

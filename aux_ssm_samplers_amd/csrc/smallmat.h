@@ -280,8 +280,12 @@ template <typename R, int N, int NC> AX_HD void cho_solve_col(const R* L, const 
 }
 
 // ---- LU with partial pivoting, W [D][D] destroyed, RHS [D][NR] overwritten by W^{-1} RHS -----------------
-template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) {
+template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B);
+template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) { (void)lu_solve_logdet<R, D, NR>(W, B); }
+// returns log |det W|
+template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B) {
     R ipiv[D];
+    R ld_ = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         // bring the largest |W[r][k]|, r >= k, to row k by compare-and-swap (branch-free selects)
@@ -303,6 +307,7 @@ template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) {
         }
         const R inv = (R)1 / W[k * D + k];
         ipiv[k] = inv;
+        ld_ -= log_(abs_(inv));
 #pragma unroll
         for (int r = k + 1; r < D; ++r) {
             const R f = W[r * D + k] * inv;
@@ -323,6 +328,7 @@ template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) {
             B[k * NR + j] = s * inv;
         }
     }
+    return ld_;
 }
 
 }  // namespace ax

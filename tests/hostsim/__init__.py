@@ -51,7 +51,7 @@ def _garr(desc):
     return g, keep
 
 
-def filtering(ys, lgssm, E=0, dtype=np.float64, chains=False, chain_axis=False):
+def filtering(ys, lgssm, E=0, dtype=np.float64, chains=False, chain_axis=False, pblk=0):
     C_, T, B, dx, dy, batched = _layout.infer_dims(ys, lgssm, chains)
     desc = _layout.describe_lgssm(lgssm, C_, T, B, dx, dy, batched, dtype, chain_axis)
     yd = _layout.describe(ys, (dy,), chains=C_ if chains else None, time_len=T, batch=B if batched else None, dtype=dtype, name="ys")
@@ -61,7 +61,7 @@ def filtering(ys, lgssm, E=0, dtype=np.float64, chains=False, chain_axis=False):
     ell = np.empty((C_,), dtype)
     ya = _arr(yd)
     rc = lib().hs_filter(_dt(dtype), dx, dy, C_, T, B, g, C.byref(ya), int(E), ms.ctypes.data_as(C.c_void_p),
-                         Ps.ctypes.data_as(C.c_void_p), ell.ctypes.data_as(C.c_void_p))
+                         Ps.ctypes.data_as(C.c_void_p), ell.ctypes.data_as(C.c_void_p), int(pblk))
     assert rc == 0, rc
     return _squeeze(ms, chains, batched), _squeeze(Ps, chains, batched), (ell if chains else ell[0])
 

@@ -86,7 +86,7 @@ template <class Op> static void scan_host(typename Op::Args& a, int S, int n) {
 }
 
 template <typename R, int D, int P>
-static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell) {
+static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell, int pblk) {
     FilterArgs a;
     a.d = KDims{C, T, B};
     a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
@@ -110,15 +110,20 @@ static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E,
     a.ell0 = ell0.data();
     DirectIO io;
     for (int s = 0; s < S; ++s) body_filter_t0<R, D, P>(a, s);
+    a.pblk = pblk;
+    constexpr int P1 = (P > D) ? D : 0;
     for (int s = 0; s < S; ++s)
-        for (int i = 0; i < n; ++i) body_filter_init<R, D, P>(a, io, s, i, true);
+        for (int i = 0; i < n; ++i) {
+            if (pblk == D && P1 > 0) body_filter_init<R, D, P, DirectIO, P1>(a, io, s, i, true);
+            else body_filter_init<R, D, P>(a, io, s, i, true);
+        }
     scan_host<FilterOp<R, D>>(a, S, n);
     for (int c = 0; c < C; ++c) {
         R tot = 0;
         for (int b = 0; b < B; ++b) {
             const int s = c * B + b;
             R e = ell0[s];
-            for (int i = 0; i < n; ++i) e += body_filter_ell<R, D, P>(a, io, s, i, true);
+            for (int i = 0; i < n; ++i) e += (pblk == D && P1 > 0) ? body_filter_ell<R, D, P, DirectIO, P1>(a, io, s, i, true) : body_filter_ell<R, D, P>(a, io, s, i, true);
             tot += e;
         }
         ((R*)ell)[c] = tot;
@@ -203,8 +208,8 @@ static int logpdf_T(int C, int T, int B, const HsArr* g, const HsArr* ys, const 
 
 extern "C" {
 
-int hs_filter(int dtype, int D, int P, int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell) {
-#define CALL(R, D, P) filter_T<R, D, P>(C, T, B, g, ys, E, ms, Ps, ell)
+int hs_filter(int dtype, int D, int P, int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell, int pblk) {
+#define CALL(R, D, P) filter_T<R, D, P>(C, T, B, g, ys, E, ms, Ps, ell, pblk)
     if (dtype == 0) { HS_D_SWITCH(CALL, float) } else { HS_D_SWITCH(CALL, double) }
 #undef CALL
 }

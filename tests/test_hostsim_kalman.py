@@ -100,3 +100,34 @@ def test_chain_batched_broadcast_layout(d, E, dtype, tol):
         npt.assert_allclose(Ps[c], oPs, **tol)
         npt.assert_allclose(ell[c], oell, rtol=tol["rtol"] * 10, atol=tol["atol"] * 10)
         npt.assert_allclose(xs[c], K.sampling(eps[c], oms, oPs, lg, True), rtol=tol["rtol"] * 5, atol=tol["atol"] * 5)
+
+
+@pytest.mark.parametrize("d,po", [(1, 1), (2, 2), (2, 3), (4, 4), (3, 2)])
+@pytest.mark.parametrize("E", [0, 3, -3])
+def test_block_diagonal_R_information_form(d, po, E):
+    """R = blkdiag(R1 (d x d), R2 (po x po)) with the pblk hint: the information form (Lam = sum_b H_b^T R_b^-1 H_b,
+    M = (I + Lam P)^-1 Lam, log|S| = log|R| + log|I + Lam P|) must reproduce the dense-Cholesky path / the oracle,
+    including missing components inside either block and fully missing steps."""
+    T, p = 60, d + po
+    rng = np.random.default_rng(10 * d + po)
+    Fs = 0.6 * rng.standard_normal((T - 1, d, d)) / np.sqrt(d)
+    A = rng.standard_normal((T - 1, d, 2 * d))
+    Qs = A @ A.transpose(0, 2, 1) / (2 * d) + 0.2 * np.eye(d)
+    bs = rng.standard_normal((T - 1, d))
+    Hs = rng.standard_normal((T, p, d))
+    Rs = np.zeros((T, p, p))
+    B1 = rng.standard_normal((T, d, 2 * d))
+    B2 = rng.standard_normal((T, po, 2 * po))
+    Rs[:, :d, :d] = B1 @ B1.transpose(0, 2, 1) / (2 * d) + 0.2 * np.eye(d)
+    Rs[:, d:, d:] = B2 @ B2.transpose(0, 2, 1) / (2 * po) + 0.2 * np.eye(po)
+    cs = rng.standard_normal((T, p))
+    ys = rng.standard_normal((T, p))
+    ys[rng.random((T, p)) < 0.15] = np.nan
+    ys[5] = np.nan
+    ys[0] = rng.standard_normal(p)
+    lg = (rng.standard_normal(d), np.eye(d), Fs, Qs, bs, Hs, Rs, cs)
+    ms, Ps, ell = H.filtering(ys, lg, E, pblk=d)
+    oms, oPs, oell = K.filtering(ys, lg, True)
+    npt.assert_allclose(ms, oms, rtol=1e-8, atol=1e-10)
+    npt.assert_allclose(Ps, oPs, rtol=1e-8, atol=1e-10)
+    npt.assert_allclose(ell, oell, rtol=1e-9)
