@@ -1,0 +1,53 @@
+"""The reference's import surface (aux_samplers/__init__.py:1-4, kalman/__init__.py:1, csmc/__init__.py:1-5,
+_primitives/kalman/__init__.py:1-3, _primitives/csmc/__init__.py:1) resolves through the compatibility shim; argument
+errors raised at construction time are the reference's ValueErrors (csmc/generic.py:44-47, csmc.py:47-50).  CPU only."""
+import inspect
+
+import pytest
+
+
+def test_reference_import_paths_resolve():
+    from aux_samplers import SamplerState  # noqa: F401
+    from aux_samplers.kalman import get_kernel as kk
+    from aux_samplers.csmc import (get_kernel, get_generic_kernel, get_independent_kernel, Distribution, UnivariatePotential,
+                                   Dynamics, Potential)
+    from aux_samplers._primitives.kalman import LGSSM, filtering, sampling, posterior_logpdf
+    from aux_samplers._primitives.csmc import get_kernel as pk
+    from aux_samplers._primitives.csmc.resamplings import multinomial
+    from aux_samplers._primitives.math.utils import normalize
+    assert list(inspect.signature(kk).parameters) == ["dynamics_factory", "observations_factory", "log_likelihood_fn", "parallel"]
+    assert list(inspect.signature(get_generic_kernel).parameters) == ["factory", "N", "backward", "Pt"]
+    assert list(inspect.signature(get_independent_kernel).parameters)[:9] == ["M0", "G0", "Mt", "Gt", "N", "backward", "Pt", "gradient", "parallel"]
+    assert list(inspect.signature(pk).parameters) == ["M0", "G0", "Mt", "Gt", "N", "backward", "Pt"]
+    assert list(inspect.signature(filtering).parameters)[:3] == ["ys", "lgssm", "parallel"]
+    assert list(inspect.signature(sampling).parameters)[:5] == ["key", "ms", "Ps", "lgssm", "parallel"]
+    assert list(inspect.signature(posterior_logpdf).parameters)[:4] == ["ys", "xs", "ell", "lgssm"]
+    assert LGSSM._fields == ("m0", "P0", "Fs", "Qs", "bs", "Hs", "Rs", "cs")
+    assert get_kernel is get_generic_kernel and callable(multinomial) and callable(normalize)
+    for cls in (Distribution, UnivariatePotential, Dynamics, Potential):
+        assert inspect.isclass(cls)
+
+
+def test_construction_time_value_errors():
+    from aux_samplers.csmc import get_generic_kernel, GaussianInit, LinearGaussianDynamics, FlatPotential
+    from aux_samplers._primitives.csmc import get_kernel
+    with pytest.raises(ValueError):
+        get_generic_kernel(lambda u, s: None, 8, backward=True)          # Pt missing (csmc/generic.py:44-45)
+    with pytest.raises(ValueError):
+        get_generic_kernel(lambda u, s: None, 8, backward=True, Pt=object())  # no logpdf (csmc/generic.py:46-47)
+    M0 = GaussianInit(m0=[0.0], P0=[[1.0]])
+    Mt = LinearGaussianDynamics(F=[[0.5]], b=[0.0], Q=[[1.0]])
+    with pytest.raises(ValueError):
+        get_kernel(M0, FlatPotential(), Mt, FlatPotential(), N=8, backward=True, Pt=object())  # csmc.py:49-50
+
+
+def test_init_kernel_return_order_and_state():
+    import numpy as np
+    from aux_samplers.kalman import get_kernel, LGConcatModel
+    T, d = 6, 2
+    bt = np.broadcast_to
+    model = LGConcatModel(np.zeros(d), np.eye(d), bt(np.eye(d), (T - 1, d, d)), bt(np.eye(d), (T - 1, d, d)), bt(np.zeros(d), (T - 1, d)),
+                          bt(np.eye(d), (T, d, d)), bt(np.eye(d), (T, d, d)), bt(np.zeros(d), (T, d)), np.zeros((T, d)))
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    st = init(np.zeros((T, d)))
+    assert st.updated is True and st.x.shape == (T, d) and callable(kernel)  # kalman/generic.py:92-95: returns (init, kernel)
