@@ -217,3 +217,31 @@ def test_full_size_C2_properties(dtype, tol):
         assert np.all(np.abs(a.log_alpha) < 5.0), a.log_alpha
         npt.assert_allclose(kpar(None, init(x), 0.5, noise=dict(noise, u_accept=np.zeros(C))).x,
                             kseq(None, init(x), 0.5, noise=dict(noise, u_accept=np.zeros(C))).x, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("seed", [42, 666])
+@pytest.mark.parametrize("T,dx,dy", [(3, 1, 1), (5, 2, 3)])
+@pytest.mark.parametrize("parallel", [True, False])
+def test_sampler_moments_reference_statistical_test(seed, T, dx, dy, parallel):
+    """aux_samplers/_primitives/test_kalman/test_sampling.py::test_parallel_vs_sequential (:23-68) on the HIP path: the
+    empirical mean / covariance of 500 000 pathwise samples (device Threefry noise, one launch over 500 000 chains) match
+    the RTS smoother at atol = rtol = 1e-2."""
+    import ctypes as C
+    from aux_ssm_samplers_amd import _lib, _layout, random as R
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    ys, lg = ref_lgssm_inputs(seed, T, dx, dy)
+    ms, Ps, _ = K.filtering(ys, lg, False)
+    esm, esP = K.explicit_smoother(ms, Ps, lg[2], lg[3], lg[4])
+    h = _lib.default_handle()
+    NS = 500_000
+    dl = DeviceLGSSM(h, list(lg[:5]) + [None, None, None], 1, T, 1, dx, 1, False, np.float64)  # chain-shared (stride 0)
+    msd = h.to_device(np.broadcast_to(ms, (NS, T, dx)).copy())
+    Psd = h.to_device(np.broadcast_to(Ps, (NS, T, dx, dx)).copy())
+    eps = h.rng_normal(R.PRNGKey(seed), 0, (NS, T, 1, dx), np.float64)
+    xs = h.empty((NS, T, 1, dx), np.float64)
+    dims = _lib.Dims(NS, T, 1, dx, 1)
+    _lib.check(h.lib.auxssm_kalman_sample(h.h, _lib.F64, C.byref(dims), C.byref(dl.c), msd.ptr, Psd.ptr, eps.ptr, int(parallel), xs.ptr))
+    s = xs.to_host()[:, :, 0, :]
+    npt.assert_allclose(s.mean(0), esm, atol=1e-2, rtol=1e-2)
+    cov = np.einsum("nti,ntj->tij", s - s.mean(0), s - s.mean(0)) / (NS - 1)
+    npt.assert_allclose(cov, esP, atol=1e-2, rtol=1e-2)
