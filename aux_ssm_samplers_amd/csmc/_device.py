@@ -83,6 +83,18 @@ def describe_independent(M0, G0, Mt, Gt, Pt):
     return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), Mt.F, Mt.b, Mt.chol(), y, sig)
 
 
+def key_noise(handle, key, Cn, T, N, d, dtype):
+    """The explicit noise arrays a THREEFRY sweep with `key` draws in-kernel (index map: csrc/csmc.hip::k_csmc_fwd): an
+    EXPLICIT sweep on these arrays is bit-identical to the keyed one.  Debug / test utility."""
+    T2 = (T + 1) // 2
+    ep = handle.rng_normal(key, 2, (Cn, T2, N, d, 2), dtype).to_host()
+    ur = handle.rng_uniform(key, 3, (Cn, T2, N, 2), dtype).to_host()
+    return dict(eps_aux=handle.rng_normal(key, 1, (Cn, T, d), dtype).to_host(),
+                eps_prop=np.ascontiguousarray(np.moveaxis(ep, 4, 2).reshape(Cn, 2 * T2, N, d)[:, :T]),
+                u_res=np.ascontiguousarray(np.moveaxis(ur, 3, 2).reshape(Cn, 2 * T2, N)[:, :max(T - 1, 0)]),
+                u_bwd=handle.rng_uniform(key, 4, (Cn, T), dtype).to_host())
+
+
 def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, want_history=False):
     """x: (T, d) one chain or (C, T, d).  noise: dict of explicit arrays (eps_prop, u_res, u_bwd[, eps_aux]) or None -> Threefry(key).
     Returns (x_new, ancestors, history dict or None)."""

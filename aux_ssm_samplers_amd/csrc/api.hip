@@ -406,11 +406,15 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
 }
 
 // ---- RNG fill -----------------------------------------------------------------------------------------------------
+// one Threefry block -> out[2 i], out[2 i + 1] (both fills)
 template <typename R> __global__ void k_rng_uniform(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = stream_uniform<R>(k0, k1, stream, (unsigned long long)i);
+    if (2 * i >= n) return;
+    R u0, u1;
+    stream_uniform2<R>(k0, k1, stream, (unsigned long long)i, u0, u1);
+    out[2 * i] = u0;
+    if (2 * i + 1 < n) out[2 * i + 1] = u1;
 }
-// one Threefry block -> out[2 i], out[2 i + 1]
 template <typename R> __global__ void k_rng_normal(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (2 * i >= n) return;
@@ -684,7 +688,7 @@ static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32
         return AUXSSM_ERR_ARG;
     }
     if (n == 0) return AUXSSM_OK;
-    const long long work = normal ? (n + 1) / 2 : n;
+    const long long work = (n + 1) / 2;
     const unsigned grid = (unsigned)((work + 255) / 256);
     if (dtype == AUXSSM_F32) {
         if (normal) hipLaunchKernelGGL((k_rng_normal<float>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);

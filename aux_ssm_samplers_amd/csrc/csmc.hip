@@ -132,22 +132,44 @@ template <typename R> __device__ __forceinline__ R wave_scan_ks(R v, int lane) {
     return v;
 }
 
+// the up-to-16 per-wave partials of a block reduction, fetched with wide LDS reads into registers (same values, same
+// left-to-right combination order as a scalar loop over red[]; only the dependent LDS round trips disappear)
+template <typename R> __device__ __forceinline__ void load16(const R* red, R* t) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = red[k];
+}
+
 // normalize (math/utils.py:23-39): w = exp(lw - logsumexp(lw)); logsumexp = log(sum(exp(lw - max))) + max
-// red: 32 slots (max in [0,16), sum in [16,32)); the caller guarantees a barrier between two calls (the cumsum's).
+// red: 48 slots (max in [0,16), sum in [16,32), scan totals in [32,48)); slots of unused waves are never read.
 template <typename R> __device__ __forceinline__ R block_normalize(R lw, R* red, int tid, int nw) {
     const int lane = tid & 63, wv = tid >> 6;
     R m = wave_max(lw);
     if (lane == 0) red[wv] = m;
     __syncthreads();
-    m = red[0];
-    for (int k = 1; k < nw; ++k) m = m > red[k] ? m : red[k];
+    R t[16];
+    load16<R>(red, t);
+    m = t[0];
+    if (nw == 16) {  // full workgroup: no per-slot masks
+#pragma unroll
+        for (int k = 1; k < 16; ++k) m = t[k] > m ? t[k] : m;
+    } else {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) m = (k < nw && t[k] > m) ? t[k] : m;
+    }
     if (!(m - m == 0)) m = 0;  // non-finite max -> 0 (jax logsumexp)
     const R e = det_exp(lw - m);
     R s = wave_sum_tree(e);
     if (lane == 0) red[16 + wv] = s;
     __syncthreads();
-    s = red[16];
-    for (int k = 1; k < nw; ++k) s += red[16 + k];
+    load16<R>(red + 16, t);
+    s = t[0];
+    if (nw == 16) {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s = s + t[k];
+    } else {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) s = k < nw ? s + t[k] : s;
+    }
     const R lse = det_log(s) + m;
     return det_exp(lw - lse);
 }
@@ -158,11 +180,11 @@ template <typename R> __device__ __forceinline__ void block_cumsum(R w, R* c, R*
     const R v = wave_scan_ks(w, lane);
     if (lane == 63) red[32 + wv] = v;
     __syncthreads();
-    R pre = 0;
-    if (wv > 0) {
-        pre = red[32];
-        for (int k = 1; k < wv; ++k) pre += red[32 + k];
-    }
+    R t[16];
+    load16<R>(red + 32, t);
+    R pre = t[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) pre = k < wv ? pre + t[k] : pre;
     c[tid] = wv > 0 ? pre + v : v;
     __syncthreads();
 }
@@ -210,10 +232,25 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
     const R ninf = -INFINITY;
 
     // t = 0  (csmc.py:74-80)
-    R x[D], eps[D], ycur[D];
+    // In-kernel draws (THREEFRY): one Threefry block serves TWO consecutive time steps of a particle, so each step pays for
+    // one block (normals on even t, uniforms on odd t) instead of two.  With T2 = ceil(T/2):
+    //   eps_prop[ch][t][n][k] = normal  2 * (((ch T2 + (t >> 1)) N + n) D + k) + (t & 1)  of stream 2
+    //   u_res[ch][s][n]       = uniform 2 * ((ch T2 + (s >> 1)) N + n) + (s & 1)          of stream 3
+    // (flat auxssm_rng_* indices; csmc/_device.py::key_noise builds the equivalent explicit arrays).
+    const bool gen = a.noise_mode != 0;
+    const long long T2 = (T + 1) >> 1;
+    R x[D], eps[D], eps_nx[D], ycur[D], un_nx = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        eps[k] = live ? noise_normal<R>(a, a.eps_prop, STREAM_EPS_PROP, eps_base + (long long)tid * D + k) : (R)0;
+        eps_nx[k] = 0;
+        if (gen) {
+            R z0, z1;
+            stream_normal2<R>(a.key0, a.key1, STREAM_EPS_PROP, (unsigned long long)(((long long)ch * T2 * N + tid) * D + k), z0, z1);
+            eps[k] = live ? z0 : (R)0;
+            eps_nx[k] = live ? z1 : (R)0;
+        } else {
+            eps[k] = live ? ((const R*)a.eps_prop)[eps_base + (long long)tid * D + k] : (R)0;
+        }
         ycur[k] = yv ? yv[k] : (R)0;
     }
     if (m.proposal == 0) {  // M0 = N(m0, P0)
@@ -250,11 +287,25 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         // issue this step's independent loads first
         R un = 0;
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            eps[k] = live ? noise_normal<R>(a, a.eps_prop, STREAM_EPS_PROP, eps_base + ((long long)t * N + tid) * D + k) : (R)0;
-            ycur[k] = yv ? yv[(long long)t * D + k] : (R)0;
+        for (int k = 0; k < D; ++k) ycur[k] = yv ? yv[(long long)t * D + k] : (R)0;
+        if (!gen) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) eps[k] = live ? ((const R*)a.eps_prop)[eps_base + ((long long)t * N + tid) * D + k] : (R)0;
+            if (live) un = ((const R*)a.u_res)[ures_base + (long long)(t - 1) * N + tid];
+        } else if (t & 1) {  // normals cached by step t - 1; uniforms of steps t and t + 1
+#pragma unroll
+            for (int k = 0; k < D; ++k) eps[k] = eps_nx[k];
+            stream_uniform2<R>(a.key0, a.key1, STREAM_U_RES, (unsigned long long)(((long long)ch * T2 + ((t - 1) >> 1)) * N + tid), un, un_nx);
+        } else {  // uniform cached by step t - 1; normals of steps t and t + 1
+            un = un_nx;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                R z0, z1;
+                stream_normal2<R>(a.key0, a.key1, STREAM_EPS_PROP, (unsigned long long)((((long long)ch * T2 + (t >> 1)) * N + tid) * D + k), z0, z1);
+                eps[k] = live ? z0 : (R)0;
+                eps_nx[k] = live ? z1 : (R)0;
+            }
         }
-        if (live) un = noise_uniform<R>(a, a.u_res, STREAM_U_RES, ures_base + (long long)(t - 1) * N + tid);
         // conditional multinomial resampling (resamplings.py:14-37 -> jax.random.choice: cumsum, r = c[-1] (1-u), searchsorted)
         R* c = cbuf + (t & 1) * TB;
         R* xprev = xbuf + (t & 1) * TB * D;

@@ -31,6 +31,44 @@ template <typename R> AX_HD R bits_to_uniform(uint32_t b);
 template <> AX_HD float bits_to_uniform<float>(uint32_t b) { return (float)(b >> 8) * 5.9604644775390625e-8f; }
 template <> AX_HD double bits_to_uniform<double>(uint32_t b) { return (double)b * 2.3283064365386963e-10; }
 
+// cos(2 pi u), sin(2 pi u) for u in [0, 1): q = rint(4u), f = u - q/4 (exact, |f| <= 1/8), theta = 2 pi f in
+// [-pi/4, pi/4], the fdlibm k_sin/k_cos polynomials on theta, then the quadrant rotation.  Explicit fma everywhere so that
+// the result does not depend on the contraction setting of the translation unit.  (The libm sin/cos carry their
+// large-argument reduction inline on the GPU -- ~100 instructions that an angle in [0, 2 pi) never needs.)
+AX_HD float rng_fma(float a, float b, float c) { return fmaf(a, b, c); }
+AX_HD double rng_fma(double a, double b, double c) { return fma(a, b, c); }
+template <typename R> struct SinCosPoly;
+template <> struct SinCosPoly<float> {
+    static constexpr int NS = 4, NC = 4;
+    static constexpr float S[4] = {-1.6666667163e-01f, 8.3333337680e-03f, -1.9841270114e-04f, 2.7557314297e-06f};
+    static constexpr float Cc[4] = {4.1666667908e-02f, -1.3888889225e-03f, 2.4801587642e-05f, -2.7557314297e-07f};
+};
+template <> struct SinCosPoly<double> {
+    static constexpr int NS = 6, NC = 6;
+    static constexpr double S[6] = {-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                                    2.75573137070700676789e-06,  -2.50507602534068634195e-08, 1.58969099521155010221e-10};
+    static constexpr double Cc[6] = {4.16666666666666019037e-02,  -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                                     -2.75573143513906633035e-07, 2.08757232129817482790e-09,  -1.13596475577881948265e-11};
+};
+template <typename R> AX_HD void sincos_2pi(R u, R& c, R& s) {
+    using P = SinCosPoly<R>;
+    const R q = rint((R)4 * u);  // 0..4
+    const R f = rng_fma((R)-0.25, q, u);
+    const R th = (R)6.283185307179586476925286766559 * f;
+    const R z = th * th;
+    R ps = P::S[P::NS - 1], pc = P::Cc[P::NC - 1];
+#pragma unroll
+    for (int k = P::NS - 2; k >= 0; --k) ps = rng_fma(ps, z, P::S[k]);
+#pragma unroll
+    for (int k = P::NC - 2; k >= 0; --k) pc = rng_fma(pc, z, P::Cc[k]);
+    const R sn = rng_fma(th * z, ps, th);
+    const R cs = rng_fma(z * z, pc, rng_fma((R)-0.5, z, (R)1));
+    const int qi = (int)q & 3;
+    const R a = (qi & 1) ? sn : cs, b = (qi & 1) ? cs : sn;  // cos = +-a, sin = +-b
+    c = (qi == 1 || qi == 2) ? -a : a;
+    s = (qi >= 2) ? -b : b;
+}
+
 // Box-Muller on one Threefry block (two 32-bit words) -> TWO normals (cos and sin branch).  Normal number `idx` of a stream
 // is branch (idx & 1) of the block with counter idx >> 1.  fp64: u = (b + 0.5) 2^-32 in (0,1), double math.  fp32:
 // u = ((b >> 8) + 0.5) 2^-24, float math throughout (the cSMC kernels draw N of these per time step).
@@ -39,17 +77,19 @@ template <> AX_HD void bits_to_normal2<double>(uint32_t b0, uint32_t b1, double&
     const double u1 = ((double)b0 + 0.5) * 2.3283064365386963e-10;
     const double u2 = ((double)b1 + 0.5) * 2.3283064365386963e-10;
     const double r = sqrt(-2.0 * log(u1));
-    const double a = 6.283185307179586476925286766559 * u2;
-    z0 = r * cos(a);
-    z1 = r * sin(a);
+    double c, s;
+    sincos_2pi<double>(u2, c, s);
+    z0 = r * c;
+    z1 = r * s;
 }
 template <> AX_HD void bits_to_normal2<float>(uint32_t b0, uint32_t b1, float& z0, float& z1) {
     const float u1 = ((float)(b0 >> 8) + 0.5f) * 5.9604644775390625e-8f;
     const float u2 = ((float)(b1 >> 8) + 0.5f) * 5.9604644775390625e-8f;
     const float r = sqrtf(-2.0f * logf(u1));
-    const float a = 6.283185307179586f * u2;
-    z0 = r * cosf(a);
-    z1 = r * sinf(a);
+    float c, s;
+    sincos_2pi<float>(u2, c, s);
+    z0 = r * c;
+    z1 = r * s;
 }
 // counter words of block `blk` of a stream
 AX_HD void stream_counter(uint32_t stream, unsigned long long blk, uint32_t& x0, uint32_t& x1) {
@@ -65,11 +105,26 @@ template <typename R> AX_HD R stream_normal(uint32_t k0, uint32_t k1, uint32_t s
     bits_to_normal2<R>(x0, x1, z0, z1);
     return (idx & 1) ? z1 : z0;
 }
+// uniform number idx of (key, stream): word (idx & 1) of block idx >> 1
 template <typename R> AX_HD R stream_uniform(uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long idx) {
     uint32_t x0, x1;
-    stream_counter(stream, idx, x0, x1);
+    stream_counter(stream, idx >> 1, x0, x1);
     threefry2x32(k0, k1, x0, x1);
-    return bits_to_uniform<R>(x0);
+    return bits_to_uniform<R>((idx & 1) ? x1 : x0);
+}
+// both numbers of block blk
+template <typename R> AX_HD void stream_normal2(uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long blk, R& z0, R& z1) {
+    uint32_t x0, x1;
+    stream_counter(stream, blk, x0, x1);
+    threefry2x32(k0, k1, x0, x1);
+    bits_to_normal2<R>(x0, x1, z0, z1);
+}
+template <typename R> AX_HD void stream_uniform2(uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long blk, R& u0, R& u1) {
+    uint32_t x0, x1;
+    stream_counter(stream, blk, x0, x1);
+    threefry2x32(k0, k1, x0, x1);
+    u0 = bits_to_uniform<R>(x0);
+    u1 = bits_to_uniform<R>(x1);
 }
 
 }  // namespace ax

@@ -169,7 +169,9 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
  * Noise: EXPLICIT device arrays (the parity contract): eps_aux (C,T,dx) [AUX only], eps_prop (C,T,N,dx) ~ N(0,1) (row t
  * feeds M0 / Mt.sample at time t), u_res (C,T-1,N) ~ U[0,1) (row t-1 resamples into time t), u_bwd (C,T) (entry t draws
  * B_t; only entry T-1 is used when backward == 0); or THREEFRY: the same quantities generated in-kernel from
- * (key0, key1), bit-identical to auxssm_rng_normal/uniform fills with streams 1..4 over the same flat indices.
+ * (key0, key1) with streams 1..4 of the auxssm_rng_normal/uniform counter space: eps_aux and u_bwd over the same flat
+ * indices; eps_prop and u_res with two consecutive time steps sharing one Threefry block (index map in csrc/csmc.hip,
+ * k_csmc_fwd), so a THREEFRY run equals an EXPLICIT run on the correspondingly permuted fills.
  *
  * x (C,T,dx): reference trajectories in, new trajectories out.  ancestors (C,T) int32 out (updated = ancestors != 0,
  * csmc.py:59).  xs_out (C,T,N,dx), log_ws_out (C,T,N), As_out (C,T-1,N) int32: optional full particle history
@@ -210,7 +212,8 @@ int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t 
                               const void* uniforms, void* weights_out, int32_t* indices);
 
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
- * out[i], i < n, is a pure function of (key0, key1, stream, i): see oracle/rng_np.py for the restatement. */
+ * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see
+ * oracle/rng_np.py for the restatement. */
 int auxssm_rng_normal(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);
 int auxssm_rng_uniform(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);
 

@@ -1,8 +1,8 @@
 """ORACLE -- TEST INFRASTRUCTURE ONLY.  NumPy restatement of the device RNG fills (csrc/rng.h, api.hip::k_rng_fill):
-uniform[i] = f(block i), normal[i] = Box-Muller branch (i & 1) of block i >> 1, block b = threefry2x32(key,
+uniform[i] = word (i & 1) of block i >> 1, normal[i] = Box-Muller branch (i & 1) of block i >> 1, block b = threefry2x32(key,
 counter = (lo32(b), stream ^ (hi32(b) << 16))).
-Threefry-2x32-20 itself is pinned by the Random123 known-answer vectors (tests/test_rng.py).  The normal transform uses
-libm log/cos on both sides, so device-vs-oracle agreement for normals is to rounding (a few ulp), not bitwise; uniforms are
+Threefry-2x32-20 itself is pinned by the Random123 known-answer vectors (tests/test_rng.py).  The normal transform (libm log,
+own sincos_2pi) is restated without fma, so device-vs-oracle agreement for normals is to rounding (a few ulp), not bitwise; uniforms are
 bit-exact.  jax.random bit-compatibility is NOT claimed (unverifiable offline)."""
 import numpy as np
 
@@ -37,10 +37,43 @@ def _bits(key, stream, n):
 
 
 def uniform(key, stream, n, dtype):
-    b0, _ = _bits(key, stream, n)
+    b0, b1 = _bits(key, stream, (n + 1) // 2)
+    b = np.stack([b0, b1], axis=1).reshape(-1)[:n]
     if np.dtype(dtype) == np.float32:
-        return ((b0 >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)).astype(np.float32)
-    return b0.astype(np.float64) * 2.3283064365386963e-10
+        return ((b >> np.uint32(8)).astype(np.float32) * np.float32(5.9604644775390625e-8)).astype(np.float32)
+    return b.astype(np.float64) * 2.3283064365386963e-10
+
+
+_S = {np.float32: [-1.6666667163e-01, 8.3333337680e-03, -1.9841270114e-04, 2.7557314297e-06],
+      np.float64: [-1.66666666666666324348e-01, 8.33333333332248946124e-03, -1.98412698298579493134e-04,
+                   2.75573137070700676789e-06, -2.50507602534068634195e-08, 1.58969099521155010221e-10]}
+_C = {np.float32: [4.1666667908e-02, -1.3888889225e-03, 2.4801587642e-05, -2.7557314297e-07],
+      np.float64: [4.16666666666666019037e-02, -1.38888888888741095749e-03, 2.48015872894767294178e-05,
+                   -2.75573143513906633035e-07, 2.08757232129817482790e-09, -1.13596475577881948265e-11]}
+
+
+def sincos_2pi(u):
+    """cos(2 pi u), sin(2 pi u) the way csrc/rng.h::sincos_2pi computes them (quadrant split of u, fdlibm kernels on
+    theta = 2 pi f).  NumPy has no fma, so the last bit can differ from the device; tests compare with a tolerance."""
+    R = u.dtype.type
+    q = np.rint(R(4) * u)
+    f = u - R(0.25) * q  # exact
+    th = R(6.283185307179586476925286766559) * f
+    z = th * th
+    ps = np.full_like(u, R(_S[R][-1]))
+    pc = np.full_like(u, R(_C[R][-1]))
+    for k in _S[R][-2::-1]:
+        ps = ps * z + R(k)
+    for k in _C[R][-2::-1]:
+        pc = pc * z + R(k)
+    sn = th * z * ps + th
+    cs = z * z * pc + (R(1) - R(0.5) * z)
+    qi = q.astype(np.int64) & 3
+    a = np.where(qi & 1, sn, cs)
+    b = np.where(qi & 1, cs, sn)
+    c = np.where((qi == 1) | (qi == 2), -a, a)
+    s = np.where(qi >= 2, -b, b)
+    return c.astype(R), s.astype(R)
 
 
 def normal(key, stream, n, dtype):
@@ -50,12 +83,10 @@ def normal(key, stream, n, dtype):
         u1 = ((b0 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(5.9604644775390625e-8)
         u2 = ((b1 >> np.uint32(8)).astype(np.float32) + np.float32(0.5)) * np.float32(5.9604644775390625e-8)
         r = np.sqrt(np.float32(-2.0) * np.log(u1))
-        a = np.float32(6.283185307179586) * u2
-        z = np.stack([r * np.cos(a), r * np.sin(a)], axis=1).astype(np.float32)
     else:
         u1 = (b0.astype(np.float64) + 0.5) * 2.3283064365386963e-10
         u2 = (b1.astype(np.float64) + 0.5) * 2.3283064365386963e-10
         r = np.sqrt(-2.0 * np.log(u1))
-        a = 6.283185307179586476925286766559 * u2
-        z = np.stack([r * np.cos(a), r * np.sin(a)], axis=1)
+    c, s = sincos_2pi(u2)
+    z = np.stack([r * c, r * s], axis=1).astype(dtype)
     return z.reshape(-1)[:n]

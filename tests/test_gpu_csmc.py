@@ -70,13 +70,15 @@ def test_sweep_bit_exact_vs_oracle(dtype, d, N, T, proposal, potential, backward
     assert np.all(hist["As"][:, 0] == 0) and np.all(hist["xs"][:, 0] == x0)
 
 
-def test_multichain_equals_single_chain_and_threefry_equals_explicit():
+@pytest.mark.parametrize("T", [50, 51, 1, 2])
+def test_multichain_equals_single_chain_and_threefry_equals_explicit(T):
     """C chains in one launch == C single launches; in-kernel Threefry noise == the same draws materialised by the fill
-    kernels (streams 1..4 over the same flat indices) and fed back as explicit arrays."""
+    kernels (_device.key_noise: streams 1..4, two time steps per Threefry block for the forward pass) fed back as
+    explicit arrays."""
     from aux_ssm_samplers_amd import _lib, random as R
     from aux_ssm_samplers_amd.csmc import _device
     rng = np.random.default_rng(7)
-    d, N, T, C = 2, 128, 50, 5
+    d, N, C = 2, 128, 5
     M0, Mt = _models(d, rng)
     y = rng.standard_normal((T, d))
     G0, Gt = _pot(O.POT_SV, y)
@@ -85,10 +87,7 @@ def test_multichain_equals_single_chain_and_threefry_equals_explicit():
     key = R.PRNGKey(99)
     h = _lib.default_handle()
     xa, anca, _ = _device.sweep(fk, x0, N, True, key=key, delta=0.5)
-    noise = dict(eps_aux=h.rng_normal(key, 1, (C, T, d), np.float32).to_host(),
-                 eps_prop=h.rng_normal(key, 2, (C, T, N, d), np.float32).to_host(),
-                 u_res=h.rng_uniform(key, 3, (C, T - 1, N), np.float32).to_host(),
-                 u_bwd=h.rng_uniform(key, 4, (C, T), np.float32).to_host())
+    noise = _device.key_noise(h, key, C, T, N, d, np.float32)
     xb, ancb, _ = _device.sweep(fk, x0, N, True, noise=noise, delta=0.5)
     npt.assert_array_equal(xa, xb)
     npt.assert_array_equal(anca, ancb)
