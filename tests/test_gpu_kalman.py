@@ -186,8 +186,8 @@ def test_rng_device_matches_host_threefry():
     key = R.PRNGKey(123456789012345)
     n = 4096
     u = h.rng_uniform(key, 7, (n,), np.float64).to_host()
-    a, _ = R.threefry2x32(key[0], key[1], np.arange(n, dtype=np.uint32), np.full(n, 7, np.uint32))
-    npt.assert_array_equal(u, a.astype(np.float64) * 2.3283064365386963e-10)
+    a, b = R.threefry2x32(key[0], key[1], np.arange(n // 2, dtype=np.uint32), np.full(n // 2, 7, np.uint32))
+    npt.assert_array_equal(u, np.stack([a, b], axis=1).reshape(-1).astype(np.float64) * 2.3283064365386963e-10)  # block i>>1, word i&1
     z = h.rng_normal(key, 3, (200000,), np.float32).to_host()
     assert abs(z.mean()) < 0.01 and abs(z.std() - 1) < 0.01
 
