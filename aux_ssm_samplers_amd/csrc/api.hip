@@ -175,9 +175,17 @@ static int check_lgssm(const auxssm_lgssm* g, int T) {
     }
     return AUXSSM_OK;
 }
+// sizes the register-resident per-lane kernels are instantiated for; everything else runs the wide-state path (wide.hip)
+static bool is_wide(int D, int P) { return D > MAX_D || P > MAX_P; }
 static const KalmanEntry* need_kalman(int dtype, int D, int P) {
-    const KalmanEntry* e = (D >= 1 && D <= MAX_D) ? kalman_entry(dtype, D, P) : nullptr;
-    if (!e) set_error("(dx=%d, dy=%d) is not instantiated in this build (dx <= %d, dy <= %d)", D, P, MAX_D, MAX_P);
+    if (is_wide(D, P)) {
+        std::string why;
+        if (wide_fits(dtype, D, P, &why)) return wide_kalman_entry(dtype);
+        set_error("%s", why.c_str());
+        return nullptr;
+    }
+    const KalmanEntry* e = kalman_entry(dtype, D, P);
+    if (!e) set_error("(dx=%d, dy=%d) is not instantiated in this build", D, P);
     return e;
 }
 
@@ -189,11 +197,13 @@ static void fill_filter_args(FilterArgs& a, const auxssm_dims* d, const auxssm_l
     a.elem = nullptr; a.ell0 = nullptr;
     a.lay = ScanLayout{1, 1, 1, 1, 0, d->C * d->B};
     a.pblk = 0;
+    a.dx = d->dx; a.dy = d->dy;
 }
 static void fill_logpdf_args(LogpdfArgs& a, const auxssm_dims* d, const auxssm_lgssm* g, const Arr& ys, const Arr& xs, int pol) {
     a.d = KDims{d->C, d->T, d->B};
     a.m0 = cv(g->m0); a.P0 = cv(g->P0); a.Fs = cv(g->Fs); a.Qs = cv(g->Qs); a.bs = cv(g->bs);
     a.Hs = cv(g->Hs); a.Rs = cv(g->Rs); a.cs = cv(g->cs); a.ys = ys; a.xs = xs; a.nan_policy = pol;
+    a.dx = d->dx; a.dy = d->dy;
 }
 
 // ---- sweep helper kernels (pure data movement / reductions; runtime sizes) --------------------------------
@@ -298,12 +308,24 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
                            double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
                            const void* u_acc, int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy, P = D + PO;
-    const KalmanEntry* ke = need_kalman(dtype, D, P);
-    const KalmanEntry* ko = need_kalman(dtype, D, PO);
-    const SampleEntry* se = sample_entry(dtype, D);
-    const SweepLogpdfEntry* sl = sweep_logpdf_entry(dtype, D, PO);
-    if (!sl) set_error("(dx=%d, p_obs=%d) sweep not instantiated (p_obs <= 4)", D, PO);
-    if (!ke || !ko || !se || !sl) return AUXSSM_ERR_UNSUPPORTED;
+    // one path for the whole sweep: the register kernels when every piece is instantiated, else the wide-state path
+    const bool wide = is_wide(D, P) || PO > 4;
+    const KalmanEntry* ke = wide ? nullptr : need_kalman(dtype, D, P);
+    const SampleEntry* se = wide ? wide_sample_entry(dtype) : sample_entry(dtype, D);
+    const SweepLogpdfEntry* sl = wide ? wide_sweep_logpdf_entry(dtype) : sweep_logpdf_entry(dtype, D, PO);
+    if (wide) {
+        std::string why;
+        if (!wide_fits(dtype, D, P, &why)) {
+            set_error("%s", why.c_str());
+            return AUXSSM_ERR_UNSUPPORTED;
+        }
+        if (layout != AUXSSM_LAYOUT_DENSE) {
+            set_error("(dx=%d, dy=%d) runs the wide-state path, which takes the dense (C, T, dx) layout only", D, P);
+            return AUXSSM_ERR_UNSUPPORTED;
+        }
+        ke = wide_kalman_entry(dtype);
+    }
+    if (!ke || !se || !sl) return AUXSSM_ERR_UNSUPPORTED;
     const KDims kd{C, T, 1};
     // layout 1: x and the noise are chain-minor (T, dx, C) and so is every internal per-chain buffer: lanes <-> chains
     const int cm = layout == AUXSSM_LAYOUT_CHAIN_MINOR ? 1 : 0;
@@ -319,9 +341,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     add(CT * D * D * sR);                              // Ps
     add(CT * D * sR);                                  // x_prop
     add((size_t)C * 8 * sR + 2048);                    // scalars
-    add(ke->filter_ws(h, kd, parallel));
-    add(se->sample_ws(h, kd, parallel));
-    add(sl->ws(h, kd));
+    add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
+    add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
+    add(wide ? wide_logpdf_ws(dtype, kd) : sl->ws(h, kd));
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     R* ysc = (R*)ws_take(h, CT * P * sR);
@@ -376,6 +398,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     h->ws_off = mark;
     SampleArgs sa;
     sa.d = kd;
+    sa.dx = D;
     sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
     sa.ms = msA; sa.Ps = PsA; sa.eps = epsA; sa.xs = xpA; sa.elem = nullptr;
     sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
@@ -387,6 +410,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     {
         SweepLogpdfArgs la;
         la.d = kd;
+        la.dx = D; la.po = PO;
         la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
         la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
         la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
@@ -595,7 +619,8 @@ int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, co
     const KalmanEntry* e = need_kalman(dtype, dims->dx, dims->dy);
     if (!e) return AUXSSM_ERR_UNSUPPORTED;
     const KDims kd{dims->C, dims->T, dims->B};
-    if ((rc = ws_reserve(h, e->filter_ws(h, kd, parallel) + 4096))) return rc;
+    const size_t wsb = is_wide(dims->dx, dims->dy) ? wide_filter_ws(h, dtype, kd, parallel, dims->dx) : e->filter_ws(h, kd, parallel);
+    if ((rc = ws_reserve(h, wsb + 4096))) return rc;
     FilterArgs a;
     fill_filter_args(a, dims, lgssm, ys, ms, Ps);
     return e->filter(h, a, parallel, ell);
@@ -610,15 +635,23 @@ int auxssm_kalman_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, co
         set_error("lgssm(Fs,Qs,bs)/ms/Ps/eps/xs must be non-NULL");
         return AUXSSM_ERR_ARG;
     }
-    const SampleEntry* e = (dims->dx <= MAX_D) ? sample_entry(dtype, dims->dx) : nullptr;
+    const bool wide = dims->dx > MAX_D;
+    std::string why;
+    if (wide && !wide_fits(dtype, dims->dx, 0, &why)) {
+        set_error("%s", why.c_str());
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    const SampleEntry* e = wide ? wide_sample_entry(dtype) : sample_entry(dtype, dims->dx);
     if (!e) {
-        set_error("dx=%d is not instantiated in this build (dx <= %d)", dims->dx, MAX_D);
+        set_error("dx=%d is not instantiated in this build", dims->dx);
         return AUXSSM_ERR_UNSUPPORTED;
     }
     const KDims kd{dims->C, dims->T, dims->B};
-    if ((rc = ws_reserve(h, e->sample_ws(h, kd, parallel) + 4096))) return rc;
+    const size_t wsb = wide ? wide_sample_ws(h, dtype, kd, parallel, dims->dx) : e->sample_ws(h, kd, parallel);
+    if ((rc = ws_reserve(h, wsb + 4096))) return rc;
     SampleArgs a;
     a.d = kd;
+    a.dx = dims->dx;
     a.Fs = cv(lgssm->Fs); a.Qs = cv(lgssm->Qs); a.bs = cv(lgssm->bs);
     a.ms = dense_arr(ms, kd, dims->dx); a.Ps = dense_arr(Ps, kd, (long long)dims->dx * dims->dx);
     a.eps = dense_arr(eps, kd, dims->dx); a.xs = dense_arr(xs, kd, dims->dx); a.elem = nullptr;
@@ -642,7 +675,8 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
     const KalmanEntry* e = need_kalman(dtype, dims->dx, dims->dy);
     if (!e) return AUXSSM_ERR_UNSUPPORTED;
     const KDims kd{dims->C, dims->T, dims->B};
-    if ((rc = ws_reserve(h, e->logpdf_ws(h, kd) + 4096))) return rc;
+    const size_t wsb = is_wide(dims->dx, dims->dy) ? wide_logpdf_ws(dtype, kd) : e->logpdf_ws(h, kd);
+    if ((rc = ws_reserve(h, wsb + 4096))) return rc;
     LogpdfArgs a;
     fill_logpdf_args(a, dims, lgssm, cv(*ys), cv(*xs), nan_policy);
     return e->logpdf(h, a, out);

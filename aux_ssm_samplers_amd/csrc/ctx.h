@@ -101,4 +101,15 @@ const KalmanEntry* kalman_entry(int dtype, int D, int P);
 const SampleEntry* sample_entry(int dtype, int D);
 const SweepLogpdfEntry* sweep_logpdf_entry(int dtype, int D, int PO);
 
+// wide.hip: one workgroup per time step / scan element, matrices in LDS -- every (dx, dy) the register kernels do not cover.
+// wide_fits() says whether the LDS plan of the largest kernel fits this device for (dtype, dx, dy); why = message if not.
+const KalmanEntry* wide_kalman_entry(int dtype);
+const SampleEntry* wide_sample_entry(int dtype);
+const SweepLogpdfEntry* wide_sweep_logpdf_entry(int dtype);
+bool wide_fits(int dtype, int dx, int dy, std::string* why);
+// the wide entries' *_ws members return 0 (the table signatures carry no sizes): api.hip asks through these instead
+size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d);
+size_t wide_sample_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d);
+size_t wide_logpdf_ws(int dtype, const KDims& kd);
+
 }  // namespace ax

@@ -108,6 +108,7 @@ struct FilterArgs {
     void* ell0;     // [S]
     ScanLayout lay;
     int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
+    int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
 AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
     return Arr{p, (long long)d.T * d.B * rec, (long long)d.B * rec, rec, 1};
@@ -345,6 +346,7 @@ struct SampleArgs {
     Arr xs;           // (C,T,B,D) output
     void* elem;       // scan elements (layout `lay`), scan position j = T-1-t
     ScanLayout lay;
+    int dx = 0;       // runtime size (wide.hip only)
 };
 
 template <typename R_, int D> struct SampleOp;
@@ -492,6 +494,7 @@ struct LogpdfArgs {
     KDims d;
     Arr m0, P0, Fs, Qs, bs, Hs, Rs, cs, ys, xs;
     int nan_policy;  // 0 reference, 1 masked
+    int dx = 0, dy = 0;  // runtime sizes (wide.hip only)
 };
 
 // observation term at time t + transition term into t (t >= 1); lanes are indexed by i = t - 1
@@ -590,6 +593,7 @@ struct SweepLogpdfArgs {
     Arr u;
     double delta;
     int nan_policy;
+    int dx = 0, po = 0;  // runtime sizes (wide.hip only)
 };
 
 // the observation + auxiliary blocks at one time step for (xp, x); returns via references

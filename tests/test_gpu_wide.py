@@ -1,0 +1,147 @@
+"""GPU parity tests of the wide-state Kalman path (csrc/wide.hip: one workgroup per time step / scan element, matrices in
+LDS) -- every (dx, dy) beyond the register-resident per-lane kernels (dx > 4 or dy > 8), up to SURVEY config C5
+(dx = dy = 64, fp32).  Oracle: oracle/kalman_np.py on the same seeded inputs, plus the reference's independent
+explicit Kalman filter.  Tolerances: fp64 rtol 1e-8 / atol 1e-10 on well-conditioned models (1e-6 on the reference's
+random ill-conditioned test models, whose own test uses 1e-7 at dx <= 2); fp32 stated per test.
+"""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import kalman_np as K
+from tests.helpers import ref_lgssm_inputs, ref_batched_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def P():
+    import aux_ssm_samplers_amd._primitives.kalman as prim
+    return prim
+
+
+def stable_model(rng, T, d, p, nan=True):
+    Fs = 0.5 * rng.standard_normal((T - 1, d, d)) / np.sqrt(d)
+    A = rng.standard_normal((T - 1, d, 2 * d))
+    Qs = A @ A.transpose(0, 2, 1) / (2 * d) + 0.1 * np.eye(d)
+    bs = rng.standard_normal((T - 1, d))
+    Hs = rng.standard_normal((T, p, d)) / np.sqrt(d)
+    Bm = rng.standard_normal((T, p, 2 * p))
+    Rs = Bm @ Bm.transpose(0, 2, 1) / (2 * p) + 0.1 * np.eye(p)
+    cs = rng.standard_normal((T, p))
+    ys = rng.standard_normal((T, p))
+    if nan:
+        ys[rng.random(T) < 0.1] = np.nan
+        ys[rng.random((T, p)) < 0.05] = np.nan
+        ys[0] = rng.standard_normal(p)
+    m0 = rng.standard_normal(d)
+    A0 = rng.standard_normal((d, 2 * d))
+    P0 = A0 @ A0.T / (2 * d) + 0.5 * np.eye(d)
+    return ys, (m0, P0, Fs, Qs, bs, Hs, Rs, cs)
+
+
+@pytest.mark.parametrize("seed", [0, 1234])
+@pytest.mark.parametrize("T", [1, 5, 7])
+@pytest.mark.parametrize("dx,dy", [(5, 3), (2, 9), (6, 11), (8, 8), (16, 5)])
+@pytest.mark.parametrize("parallel", [False, True])
+@pytest.mark.parametrize("nan_index", [True, False])
+def test_filter_reference_style_cases(P, seed, T, dx, dy, parallel, nan_index):
+    """The reference's test_filtering.py recipe (random F, Q, H, R; NaN rows as at :43-47) at sizes it never reaches."""
+    ys, lg = ref_lgssm_inputs(seed, max(T, 5), dx, dy, nan_index)
+    if T < 5:
+        m0, P0, Fs, Qs, bs, Hs, Rs, cs = lg
+        ys, lg = ys[:T], (m0, P0, Fs[:T - 1], Qs[:T - 1], bs[:T - 1], Hs[:T], Rs[:T], cs[:T])
+    ms, Ps, ell = P.filtering(ys, P.LGSSM(*lg), parallel)
+    oms, oPs, oell = K.filtering(ys, lg, parallel)
+    npt.assert_allclose(ms, oms, rtol=1e-6, atol=1e-8)
+    npt.assert_allclose(Ps, oPs, rtol=1e-6, atol=1e-8)
+    npt.assert_allclose(ell, oell, rtol=1e-8, atol=1e-8)
+    m0, P0, Fs, Qs, bs, Hs, Rs, cs = lg
+    ems, ePs, eell = K.explicit_filter(ys, m0, P0, Hs, Rs, cs, Fs, Qs, bs)
+    npt.assert_allclose(ms, ems, rtol=1e-5, atol=1e-7)
+    npt.assert_allclose(ell, eell, rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("d,p,T", [(5, 5, 700), (8, 16, 300), (12, 7, 257), (16, 16, 130), (32, 32, 40)])
+def test_all_scan_levels_fp64(P, d, p, T):
+    """Time-varying stable model with NaN rows, T long enough for several chunks per sequence: parallel scan vs oracle,
+    sequential == parallel, sampler and joint log-density."""
+    rng = np.random.default_rng(d * 1000 + T)
+    ys, lg64 = stable_model(rng, T, d, p)
+    lg = P.LGSSM(*lg64)
+    oms, oPs, oell = K.filtering(ys, lg64, True)
+    ms, Ps, ell = P.filtering(ys, lg, True)
+    npt.assert_allclose(ms, oms, rtol=1e-8, atol=1e-10)
+    npt.assert_allclose(Ps, oPs, rtol=1e-8, atol=1e-10)
+    npt.assert_allclose(ell, oell, rtol=1e-9)
+    seq = P.filtering(ys, lg, False)
+    npt.assert_allclose(seq[0], ms, rtol=1e-8, atol=1e-10)
+    npt.assert_allclose(seq[2], ell, rtol=1e-9)
+    eps = rng.standard_normal((T, d))
+    for par in (True, False):
+        xs = P.sampling(None, oms, oPs, lg, par, eps=eps)
+        npt.assert_allclose(xs, K.sampling(eps, oms, oPs, lg64, True), rtol=1e-8, atol=1e-9)
+    xr = rng.standard_normal((T, d))
+    npt.assert_allclose(P.posterior_logpdf(ys, xr, oell, lg), K.posterior_logpdf(ys, xr, oell, lg64), rtol=1e-9)
+    npt.assert_allclose(P.prior_logpdf(xr, lg), K.prior_logpdf(xr, lg64), rtol=1e-9)
+    npt.assert_allclose(P.log_likelihood(ys, xr, lg), K.log_likelihood(ys, xr, lg64), rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed", [0, 7])
+@pytest.mark.parametrize("parallel", [True, False])
+def test_batched_model(P, seed, parallel):
+    """B-axis semantics (base.py:40-49) on the wide path: batched == oracle batched (== block-diagonal dense)."""
+    T, dx, dy, B = 5, 6, 3, 3
+    (bys, blg), (ys, lg) = ref_batched_inputs(seed, T, dx, dy, B)
+    bms, bPs, bell = P.filtering(bys, P.LGSSM(*blg), parallel)
+    oms, oPs, oell = K.filtering(bys, blg, parallel)
+    npt.assert_allclose(bms, oms, rtol=1e-6, atol=1e-8)
+    npt.assert_allclose(bPs, oPs, rtol=1e-6, atol=1e-8)
+    npt.assert_allclose(bell, oell, rtol=1e-8)
+    eps = np.random.default_rng(seed).standard_normal((T, B, dx))
+    bx = P.sampling(None, oms, oPs, P.LGSSM(*blg), parallel, eps=eps)
+    dms, dPs, _ = K.filtering(ys, lg, False)
+    npt.assert_allclose(bx.reshape(T, B * dx), K.sampling(eps.reshape(T, B * dx), dms, dPs, lg, parallel), rtol=1e-6, atol=1e-8)
+
+
+def c5_model(T, d=64, delta=0.1, seed=0):
+    """F = 0.9 I + 0.04 tridiag(1, 0, 1) on the 8 x 8 grid's flattened index, Q = I, first-order
+    auxiliary observations H = I, R = delta/2 I (p = d)."""
+    F = 0.9 * np.eye(d) + 0.04 * (np.eye(d, k=1) + np.eye(d, k=-1))
+    rng = np.random.default_rng(seed)
+    x = np.zeros((T, d))
+    x[0] = rng.standard_normal(d)
+    for t in range(1, T):
+        x[t] = F @ x[t - 1] + rng.standard_normal(d)
+    u = x + np.sqrt(delta / 2) * rng.standard_normal((T, d))
+    bt = np.broadcast_to
+    lg = (np.zeros(d), np.eye(d), bt(F, (T - 1, d, d)), bt(np.eye(d), (T - 1, d, d)), bt(np.zeros(d), (T - 1, d)),
+          bt(np.eye(d), (T, d, d)), bt(delta / 2 * np.eye(d), (T, d, d)), bt(np.zeros(d), (T, d)))
+    return u, lg, x
+
+
+@pytest.mark.parametrize("dtype,T", [(np.float32, 96), (np.float64, 40)])
+def test_C5_dense_d64(P, dtype, T):
+    """Config C5's model (d = p = 64; fp64 at d = 40, the largest the fp64 LDS plan holds) on a short horizon the fp64 oracle
+    finishes in seconds: filter, sampler and log-density vs oracle.  fp32 tolerance 5e-4 (stated, achieved ~1e-5)."""
+    d = 64 if dtype == np.float32 else 40
+    u, lg64, x = c5_model(T, d)
+    lg = P.LGSSM(*[np.ascontiguousarray(a, dtype) for a in lg64])
+    oms, oPs, oell = K.filtering(u, lg64, True)
+    ms, Ps, ell = P.filtering(u.astype(dtype), lg, True)
+    tol = dict(rtol=1e-8, atol=1e-10) if dtype == np.float64 else dict(rtol=5e-4, atol=5e-4)
+    npt.assert_allclose(ms, oms, **tol)
+    npt.assert_allclose(Ps, oPs, **tol)
+    npt.assert_allclose(ell, oell, rtol=tol["rtol"])
+    eps = np.random.default_rng(1).standard_normal((T, d))
+    xs = P.sampling(None, oms.astype(dtype), oPs.astype(dtype), lg, True, eps=eps.astype(dtype))
+    npt.assert_allclose(xs, K.sampling(eps, oms, oPs, lg64, True), **tol)
+    npt.assert_allclose(P.posterior_logpdf(u.astype(dtype), x.astype(dtype), oell, lg), K.posterior_logpdf(u, x, oell, lg64), rtol=tol["rtol"])
+
+
+def test_too_large_for_lds_fails_loudly(P):
+    """fp64 d = 64 exceeds the 160 KB LDS plan: a clear ValueError, never a silent fallback."""
+    T, d = 4, 64
+    u, lg64, _ = c5_model(T, d)
+    with pytest.raises((ValueError, RuntimeError), match="LDS"):
+        P.filtering(u, P.LGSSM(*lg64), True)
