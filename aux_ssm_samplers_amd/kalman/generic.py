@@ -112,6 +112,8 @@ class DeviceChains:
         self.C, self.T, self.dx = x.shape
         env = os.environ.get("AUXSSM_CM")
         self.chain_minor = bool(int(env)) if env is not None and chain_minor is None else (self.C >= 32 if chain_minor is None else bool(chain_minor))
+        if self.dx > 4 and chain_minor is None:
+            self.chain_minor = False  # dx > 4 runs the wide-state kernels (csrc/wide.hip): a workgroup per time step, dense layout
         self.layout = _lib.LAYOUT_CHAIN_MINOR if self.chain_minor else _lib.LAYOUT_DENSE
         self.x = handle.to_device(self._to_layout(x), dtype or x.dtype)
         self.dtype = self.x.dtype

@@ -145,3 +145,65 @@ def test_too_large_for_lds_fails_loudly(P):
     u, lg64, _ = c5_model(T, d)
     with pytest.raises((ValueError, RuntimeError), match="LDS"):
         P.filtering(u, P.LGSSM(*lg64), True)
+
+
+def lg_concat_wide(T, d, po, seed=0):
+    """Stable LG model of state size d with po real observations, as an LGConcatModel (the sweep's device model)."""
+    from aux_ssm_samplers_amd.kalman import LGConcatModel
+    rng = np.random.default_rng(seed)
+    F = 0.9 * np.eye(d) + 0.04 * (np.eye(d, k=1) + np.eye(d, k=-1))
+    Q = 0.2 * np.eye(d)
+    Hobs = rng.standard_normal((po, d)) / np.sqrt(d)
+    Robs = 0.5 * np.eye(po)
+    x = np.zeros((T, d))
+    x[0] = rng.standard_normal(d)
+    for t in range(1, T):
+        x[t] = F @ x[t - 1] + np.sqrt(0.2) * rng.standard_normal(d)
+    y = x @ Hobs.T + np.sqrt(0.5) * rng.standard_normal((T, po))
+    bt = np.broadcast_to
+    m0, P0 = np.zeros(d), np.eye(d)
+    model = LGConcatModel(m0, P0, bt(F, (T - 1, d, d)), bt(Q, (T - 1, d, d)), bt(np.zeros(d), (T - 1, d)),
+                          bt(Hobs, (T, po, d)), bt(Robs, (T, po, po)), bt(np.zeros(po), (T, po)), y)
+    return model, x, y, (m0, P0)
+
+
+@pytest.mark.parametrize("d,po,T", [(6, 6, 300), (8, 3, 130), (16, 16, 60), (3, 7, 100)])
+@pytest.mark.parametrize("parallel", [True, False])
+def test_device_sweep_wide_vs_oracle_sweep(d, po, T, parallel):
+    """kalman/generic.py:53-106 through auxssm_kalman_sweep on the wide-state path (p = d + po up to 32) vs the oracle's
+    sweep on identical explicit noise; the exact LG proposal makes log alpha == 0 (SURVEY 8c known answer)."""
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    model, xt, y, (m0, P0) = lg_concat_wide(T, d, po)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, parallel)
+    rng = np.random.Generator(np.random.PCG64(1000))
+    x = xt + 0.3 * rng.standard_normal((T, d))
+    noise = dict(eps_aux=rng.standard_normal((T, d)), eps_samp=rng.standard_normal((T, d)), u_accept=rng.random())
+    lgo = (m0, P0, model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs)
+    ref = K.kalman_sweep(x, 0.5, model.dynamics_factory, model.observations_factory,
+                         lambda z: K.log_likelihood(y, z, lgo) + K.prior_logpdf(z, lgo), parallel, **noise)
+    out = kernel(None, init(x), 0.5, noise=noise)
+    npt.assert_allclose(out.x, ref["x"], rtol=1e-8, atol=1e-9)
+    assert out.updated == ref["accepted"]
+    npt.assert_allclose(out.logs[0, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
+    assert abs(out.log_alpha) < 1e-6 and out.updated
+
+
+def test_device_sweep_wide_multichain_resident():
+    """Several chains resident on the device (dense layout for dx > 4), device Threefry noise: every chain accepts with
+    log alpha == 0 (exact LG proposal) and moves."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains
+    T, d, po, C = 80, 8, 8, 5
+    model, xt, y, _ = lg_concat_wide(T, d, po)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    rng = np.random.default_rng(3)
+    x0 = xt[None] + 0.3 * rng.standard_normal((C, T, d))
+    h = _lib.default_handle()
+    chains = DeviceChains(h, x0)
+    assert not chains.chain_minor
+    st = kernel(7, init(chains), 0.5)
+    xa = st.x.to_host()
+    assert np.all(st.x.accepted.to_host() == 1)
+    assert np.all(np.abs(st.x.logs.to_host()[:, 0]) < 1e-6)
+    assert np.abs(xa - x0).max() > 1e-3 and np.all(np.isfinite(xa))
