@@ -19,7 +19,10 @@
 namespace ax {
 namespace wide {
 
-constexpr int NT = 256;          // lanes per workgroup
+#ifndef AUXSSM_WIDE_NT
+#define AUXSSM_WIDE_NT 1024
+#endif
+constexpr int NT = AUXSSM_WIDE_NT;         // lanes per workgroup: 4 waves per SIMD hide the LDS latency of the dependent sweeps
 constexpr int NWV = NT / 64;     // waves per workgroup
 constexpr size_t LDS_BUDGET = 160 * 1024 - 512;
 
@@ -53,52 +56,123 @@ template <typename R> __device__ void load_vec(R* dst, const R* __restrict__ src
 }
 
 // C (M x N, ldc) = alpha op(A) op(B) + beta C;  op(A) is M x K (TA: stored K x M), op(B) is K x N (TB: stored N x K).
-// C must not alias A or B.  4 x 4 register tile per lane.
-template <typename R, bool TA, bool TB>
-__device__ void gemm(int M, int N, int K, const R* A, int lda, const R* B, int ldb, R* C, int ldc, R alpha, R beta, int tid) {
-    const int tn = (N + 3) >> 2, ntile = ((M + 3) >> 2) * tn;
-    for (int tile = tid; tile < ntile; tile += NT) {
-        const int ti = tile / tn;
-        const int i0 = ti << 2, j0 = (tile - ti * tn) << 2;
-        int ia[4], jb[4];
+// C must not alias A or B.  Matrix cores: each wave owns whole output tiles and walks K with f32 / f64 MFMAs whose A / B
+// fragments are single LDS reads per lane (out-of-range rows / columns / k read as zero).
+typedef double f64x4 __attribute__((ext_vector_type(4)));
+
+// fp32: v_mfma_f32_16x16x4_f32 -- A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D[row 4 (l >> 4) + r][col l & 15], r < 4.
+// (16 x 16 tiles: a 64 x 64 product is 16 tiles = one per wave of the 1024-lane workgroup; four k-steps of fragments are
+// fetched before their four MFMAs so the LDS latency is paid once per 16 k.)
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+template <bool TA, bool TB>
+__device__ void gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha, float beta, int tid) {
+    const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
+    for (int tile = wv; tile < ntile; tile += NWV) {
+        const int ti = tile / tn, i0 = ti << 4, j0 = (tile - ti * tn) << 4;
+        const int i = i0 + lo, j = j0 + lo;
+        const bool iv = i < M, jv = j < N;
+        const float* pa = TA ? A + i : A + i * lda;
+        const float* pb = TB ? B + j * ldb : B + j;
+        f32x4 acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            float a[4], b[4];
 #pragma unroll
-        for (int x = 0; x < 4; ++x) {
-            const int i = i0 + x < M ? i0 + x : M - 1, j = j0 + x < N ? j0 + x : N - 1;
-            ia[x] = TA ? i : i * lda;
-            jb[x] = TB ? j * ldb : j;
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + hi;
+                const bool kv = k < K;
+                a[u] = (iv && kv) ? (TA ? pa[k * lda] : pa[k]) : 0.f;
+                b[u] = (jv && kv) ? (TB ? pb[k] : pb[k * ldb]) : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
         }
-        R acc[16];
+        if (jv) {
 #pragma unroll
-        for (int x = 0; x < 16; ++x) acc[x] = 0;
-        for (int k = 0; k < K; ++k) {
-            const int ka = TA ? k * lda : k, kb = TB ? k : k * ldb;
-            R a[4], b[4];
-#pragma unroll
-            for (int x = 0; x < 4; ++x) a[x] = A[ia[x] + ka], b[x] = B[jb[x] + kb];
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-#pragma unroll
-                for (int y = 0; y < 4; ++y) acc[x * 4 + y] += a[x] * b[y];
-        }
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y)
-                if (i0 + x < M && j0 + y < N) {
-                    R* q = &C[(i0 + x) * ldc + j0 + y];
-                    *q = beta != (R)0 ? alpha * acc[x * 4 + y] + beta * *q : alpha * acc[x * 4 + y];
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + 4 * hi + r;
+                if (row < M) {
+                    float* q = &C[row * ldc + j];
+                    *q = beta != 0.f ? alpha * acc[r] + beta * *q : alpha * acc[r];
                 }
+            }
+        }
     }
     __syncthreads();
 }
-// y (M) = alpha op(A) x + beta y
-template <typename R, bool TA> __device__ void gemv(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid) {
-    for (int i = tid; i < M; i += NT) {
-        R s = 0;
-        for (int k = 0; k < K; ++k) s += (TA ? A[k * lda + i] : A[i * lda + k]) * x[k];
-        y[i] = beta != (R)0 ? alpha * s + beta * y[i] : alpha * s;
+// fp64: v_mfma_f64_16x16x4_f64 -- A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D[row (l >> 4) + 4 r][col l & 15]
+template <bool TA, bool TB>
+__device__ void gemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, double alpha, double beta, int tid) {
+    const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
+    const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
+    for (int tile = wv; tile < ntile; tile += NWV) {
+        const int ti = tile / tn, i0 = ti << 4, j0 = (tile - ti * tn) << 4;
+        const int i = i0 + lo, j = j0 + lo;
+        const bool iv = i < M, jv = j < N;
+        const double* pa = TA ? A + i : A + i * lda;
+        const double* pb = TB ? B + j * ldb : B + j;
+        f64x4 acc = {0, 0, 0, 0};
+        for (int k0 = 0; k0 < K; k0 += 16) {
+            double a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int k = k0 + 4 * u + hi;
+                const bool kv = k < K;
+                a[u] = (iv && kv) ? (TA ? pa[k * lda] : pa[k]) : 0.0;
+                b[u] = (jv && kv) ? (TB ? pb[k] : pb[k * ldb]) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u], b[u], acc, 0, 0, 0);
+        }
+        if (jv) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = i0 + hi + 4 * r;
+                if (row < M) {
+                    double* q = &C[row * ldc + j];
+                    *q = beta != 0.0 ? alpha * acc[r] + beta * *q : alpha * acc[r];
+                }
+            }
+        }
     }
     __syncthreads();
+}
+// y (M) = alpha op(A) x + beta y;  four lanes per row, each a quarter of the k range, combined by two shuffles
+template <typename R, bool TA> __device__ void gemv(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid) {
+    const int q = tid & 3;
+    for (int i0 = 0; i0 < M; i0 += NT / 4) {
+        const int i = i0 + (tid >> 2);
+        R s = 0;
+        if (i < M)
+            for (int k = q; k < K; k += 4) s += (TA ? A[k * lda + i] : A[i * lda + k]) * x[k];
+        s += __shfl_xor(s, 1, 64);
+        s += __shfl_xor(s, 2, 64);
+        if (i < M && q == 0) y[i] = beta != (R)0 ? alpha * s + beta * y[i] : alpha * s;
+    }
+    __syncthreads();
+}
+// y[i] = sum_j A[i lda + j] x[j], one wave per row, lanes over j: coalesced when A is a row-major record in global memory
+template <typename R> __device__ void gemv_rows(int M, int K, const R* __restrict__ A, long long lda, const R* x, R* y, int tid) {
+    const int lane = tid & 63;
+    for (int i = tid >> 6; i < M; i += NWV) {
+        R s = 0;
+        for (int j = lane; j < K; j += 64) s += A[i * lda + j] * x[j];
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) y[i] = s;
+    }
+    __syncthreads();
+}
+// sum of one value per lane over the workgroup (every lane gets it); red = NWV reals of LDS scratch
+template <typename R> __device__ R block_sum(R v, R* red, int tid) {
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    R s = 0;
+    for (int w = 0; w < NWV; ++w) s += red[w];
+    __syncthreads();
+    return s;
 }
 // M <- 0.5 (M + M^T)
 template <typename R> __device__ void symmetrise(R* M, int ld, int n, int tid) {
@@ -111,10 +185,31 @@ template <typename R> __device__ void symmetrise(R* M, int ld, int n, int tid) {
     __syncthreads();
 }
 
+// The triangular sweeps below give wave ti = tid >> 6 the rows ti + NWV a and lane tj = tid & 63 the columns tj + 64 b, so a
+// wave always touches 64 consecutive columns of one row.  Scalings are DEFERRED (a finished row / column is read unscaled and multiplied by its reciprocal pivot on the
+// fly, then scaled once at the end), which leaves one barrier per elimination step.
+
+// y[c] -= f x[c] for c = c0, c0 + 64, ... < c1 (a wave covers 64 consecutive columns of one row: conflict-free for any ld)
+template <typename R> __device__ __forceinline__ void axpy64(R* __restrict__ y, const R* __restrict__ x, R f, int c0, int c1) {
+    for (int c = c0; c < c1; c += 64) y[c] -= f * x[c];
+}
+// X[r][c] -= Lc[r * ldl] * xi for r = r0, r0 + NWV, ... < r1 (column c of X, leading dimension ld)
+template <typename R> __device__ __forceinline__ void colupd(R* Xc, int ld, const R* Lc, int ldl, R xi, int r0, int r1) {
+    int r = r0;
+    for (; r + NWV < r1; r += 2 * NWV) {
+        const R l0 = Lc[r * ldl], l1 = Lc[(r + NWV) * ldl];
+        const R b0 = Xc[r * ld], b1 = Xc[(r + NWV) * ld];
+        Xc[r * ld] = b0 - l0 * xi;
+        Xc[(r + NWV) * ld] = b1 - l1 * xi;
+    }
+    for (; r < r1; r += NWV) Xc[r * ld] -= Lc[r * ldl] * xi;
+}
+
 // In-place lower Cholesky of the LOWER triangle of S (n x n).  skip[k] (may be null): index k is deleted (L_kk = 1,
-// off-diagonals 0) -- the NaN-observation masking of filtering.py:89-100.  invd = 1 / diag.  Returns false (uniformly)
-// on a non-positive / NaN pivot; the factor then holds NaNs, as JAX's does.  Same subtraction order as smallmat.h.
-template <typename R> __device__ bool chol(R* S, int ld, int n, const unsigned char* skip, R* invd, int* flag, int tid) {
+// off-diagonals 0) -- the NaN-observation masking of filtering.py:89-100.  invd = 1 / diag; dg = scratch (n).  Returns false
+// (uniformly) on a non-positive / NaN pivot; the factor then holds NaNs, as JAX's does.  Same operation order as smallmat.h.
+template <typename R> __device__ bool chol(R* S, int ld, int n, const unsigned char* skip, R* invd, R* dg, int* flag, int tid) {
+    const int ti = tid >> 6, tj = tid & 63;
     if (tid == 0) *flag = 1;
     __syncthreads();
     for (int j = 0; j < n; ++j) {
@@ -122,143 +217,184 @@ template <typename R> __device__ bool chol(R* S, int ld, int n, const unsigned c
         const R s = S[j * ld + j];
         const R ljj = skj ? (R)1 : sqrt_(s);
         const R inv = (R)1 / ljj;
-        __syncthreads();
         if (tid == 0) {
-            S[j * ld + j] = ljj;
+            dg[j] = ljj;
             invd[j] = inv;
             if (!skj && !(s > (R)0)) *flag = 0;
         }
-        for (int i = j + 1 + tid; i < n; i += NT) S[i * ld + j] = (skj || (skip && skip[i])) ? (R)0 : S[i * ld + j] * inv;
-        __syncthreads();
-        for (int i = j + 1 + tid / 64; i < n; i += NWV) {
-            const R lij = S[i * ld + j];
-            for (int k = j + 1 + (tid & 63); k <= i; k += 64) S[i * ld + k] -= lij * S[k * ld + j];
-        }
+        if (!skj)
+            for (int r = j + 1 + ti; r < n; r += NWV) {
+                if (skip && skip[r]) continue;
+                const R lrj = S[r * ld + j] * inv;
+                for (int c = j + 1 + tj; c <= r; c += 64)
+                    if (!(skip && skip[c])) S[r * ld + c] -= lrj * (S[c * ld + j] * inv);
+            }
         __syncthreads();
     }
+    for (int r = ti; r < n; r += NWV)
+        for (int c = tj; c <= r; c += 64)
+            S[r * ld + c] = r == c ? dg[r] : ((skip && (skip[r] || skip[c])) ? (R)0 : S[r * ld + c] * invd[c]);
+    __syncthreads();
     return *flag != 0;
 }
 
-// right-hand sides of a cooperative solve: a matrix block (nc columns) plus up to two vectors riding along as extra columns
-template <typename R> struct Rhs {
-    R* B;
-    int ldb, nc;
-    R* v1;
-    R* v2;
-    __device__ int ncol() const { return nc + (v1 ? 1 : 0) + (v2 ? 1 : 0); }
-    __device__ R& at(int i, int c) const { return c < nc ? B[i * ldb + c] : (c == nc ? v1[i] : v2[i]); }
-};
-
-// X <- L^-1 X
-template <typename R> __device__ void trsm_l(const R* L, int ld, int n, const R* invd, const Rhs<R>& X, int tid) {
-    const int ncol = X.ncol();
-    for (int i = 0; i < n; ++i) {
-        for (int c = tid; c < ncol; c += NT) X.at(i, c) *= invd[i];
-        __syncthreads();
-        for (int r = i + 1 + tid / 64; r < n; r += NWV) {
-            const R l = L[r * ld + i];
-            for (int c = tid & 63; c < ncol; c += 64) X.at(r, c) -= l * X.at(i, c);
-        }
+// X (n x nc, ld) <- L^-1 X
+template <typename R> __device__ void trsm_l(const R* L, int ldl, int n, const R* invd, R* X, int ld, int nc, int tid) {
+    const int ti = tid >> 6, tj = tid & 63;
+    for (int i = 0; i + 1 < n; ++i) {
+        const R inv = invd[i];
+        for (int c = tj; c < nc; c += 64) colupd<R>(X + c, ld, L + i, ldl, X[i * ld + c] * inv, i + 1 + ti, n);
         __syncthreads();
     }
+    for (int r = ti; r < n; r += NWV)
+        for (int c = tj; c < nc; c += 64) X[r * ld + c] *= invd[r];
+    __syncthreads();
 }
 // X <- L^-T X
-template <typename R> __device__ void trsm_lt(const R* L, int ld, int n, const R* invd, const Rhs<R>& X, int tid) {
-    const int ncol = X.ncol();
-    for (int i = n - 1; i >= 0; --i) {
-        for (int c = tid; c < ncol; c += NT) X.at(i, c) *= invd[i];
-        __syncthreads();
-        for (int r = tid / 64; r < i; r += NWV) {
-            const R l = L[i * ld + r];
-            for (int c = tid & 63; c < ncol; c += 64) X.at(r, c) -= l * X.at(i, c);
-        }
+template <typename R> __device__ void trsm_lt(const R* L, int ldl, int n, const R* invd, R* X, int ld, int nc, int tid) {
+    const int ti = tid >> 6, tj = tid & 63;
+    for (int i = n - 1; i > 0; --i) {
+        const R inv = invd[i];
+        for (int c = tj; c < nc; c += 64) colupd<R>(X + c, ld, L + i * ldl, 1, X[i * ld + c] * inv, ti, i);
         __syncthreads();
     }
+    for (int r = ti; r < n; r += NWV)
+        for (int c = tj; c < nc; c += 64) X[r * ld + c] *= invd[r];
+    __syncthreads();
 }
 
-// LU with partial pivoting of W (n x n, destroyed); two RHS groups overwritten by W^-1 RHS (X1 may have nc = 0 and no
-// vectors).  scratch: fcol[n], ipiv[n] reals, *piv int.  Returns log|det W| (thread-uniform).
-template <typename R>
-__device__ R lu_solve(R* W, int ld, int n, const Rhs<R>& X0, const Rhs<R>& X1, R* fcol, R* ipiv, int* piv, int tid) {
-    const int n0 = X0.ncol(), n1 = X1.ncol();
-    R logdet = 0;
-    for (int k = 0; k < n; ++k) {
-        if (tid < 64) {  // first row r >= k with the largest |W[r][k]| (NaNs never win), wave 0
-            R best = abs_(W[k * ld + k]);
-            int idx = k;
-            for (int r = k + 1 + tid; r < n; r += 64) {
-                const R v = abs_(W[r * ld + k]);
-                if (v > best) best = v, idx = r;
-            }
+// 32-bit order-preserving pivot key: the leading bits of |v| with the low 7 bits replaced by (127 - row): the largest
+// magnitude wins up to a relative 2^-16 (fp32) / 2^-13 (fp64), ties and near-ties go to the smaller row, NaN never wins.
+__device__ __forceinline__ unsigned int piv_key(float v, int r) {
+    const float a = fabsf(v);
+    const unsigned int bits = (a == a) ? __float_as_uint(a) : 0u;
+    return (bits & ~0x7fu) | (unsigned int)(127 - r);
+}
+__device__ __forceinline__ unsigned int piv_key(double v, int r) {
+    const double a = fabs(v);
+    const unsigned int bits = (a == a) ? (unsigned int)((unsigned long long)__double_as_longlong(a) >> 32) : 0u;
+    return (bits & ~0x7fu) | (unsigned int)(127 - r);
+}
+
+// value of lane `src` (wave-uniform index) broadcast to the wave through v_readlane (no LDS traffic)
+__device__ __forceinline__ float bcast(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+__device__ __forceinline__ double bcast(double v, int src) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffll), src), hi = __builtin_amdgcn_readlane((int)(b >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// Z = [W (n x n) | RHS (n x (nct - n))] in LDS: RHS <- W^-1 RHS by Gauss-Jordan elimination with (implicit) partial
+// pivoting, Z held in REGISTERS for the whole elimination: wave ti owns rows ti + NWV a (a < NRR), lane tj owns columns
+// tj + 64 b (b < 4).  Column k of a wave's rows sits in that wave's lane k & 63, so multipliers are v_readlane broadcasts;
+// only the pivot bid (one 32-bit LDS atomic max per wave) and the pivot row (nct values) cross waves, with two barriers
+// per pivot:
+//   [bids for pivot k were placed at the end of step k - 1] | barrier | the wave owning the pivot row publishes it and
+//   1 / pivot | barrier | every lane updates its NRR x 4 registers and its wave bids for pivot k + 1.
+// Rows are never swapped: pivot k stays in row perm[k]; the solution row k is written back from row perm[k] at the end.
+// Needs n <= NWV * NRR and nct <= 256.  LDS scratch: rowbuf[nct + 1], pinv[n] reals; iperm[n] ints; key[2].
+// (The reference's jnp.linalg.solve is LU + two triangular solves; same solution, rounding-level differences.)
+template <typename R, int NRR>
+__device__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
+    const int ti = tid >> 6, tj = tid & 63;
+    R z[NRR][4];
+    bool used[NRR];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const R ob = __shfl_xor(best, off, 64);
-                const int oi = __shfl_xor(idx, off, 64);
-                if (ob > best || (ob == best && oi < idx)) best = ob, idx = oi;
-            }
-            if (tid == 0) *piv = idx;
+    for (int a = 0; a < NRR; ++a) {
+        used[a] = false;
+        const int r = ti + NWV * a;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = tj + 64 * b;
+            z[a][b] = (r < n && c < nct) ? Z[r * ld + c] : (R)0;
         }
-        __syncthreads();
-        const int pr = *piv;
-        if (pr != k) {
-            const int wc = n - k;
-            for (int c = tid; c < wc + n0 + n1; c += NT) {
-                R* a;
-                R* b;
-                if (c < wc) a = &W[k * ld + k + c], b = &W[pr * ld + k + c];
-                else if (c < wc + n0) a = &X0.at(k, c - wc), b = &X0.at(pr, c - wc);
-                else a = &X1.at(k, c - wc - n0), b = &X1.at(pr, c - wc - n0);
-                const R t = *a;
-                *a = *b;
-                *b = t;
-            }
-        }
-        __syncthreads();
-        const R inv = (R)1 / W[k * ld + k];
-        logdet -= log_(abs_(inv));
-        for (int r = k + 1 + tid; r < n; r += NT) fcol[r] = W[r * ld + k] * inv;
-        if (tid == 0) ipiv[k] = inv;
-        __syncthreads();
-        const int wc = n - k - 1;
-        for (int r = k + 1 + tid / 64; r < n; r += NWV) {
-            const R f = fcol[r];
-            for (int c = tid & 63; c < wc + n0 + n1; c += 64) {
-                if (c < wc) W[r * ld + k + 1 + c] -= f * W[k * ld + k + 1 + c];
-                else if (c < wc + n0) X0.at(r, c - wc) -= f * X0.at(k, c - wc);
-                else X1.at(r, c - wc - n0) -= f * X1.at(k, c - wc - n0);
-            }
-        }
-        __syncthreads();
     }
-    for (int k = n - 1; k >= 0; --k) {  // back substitution, right-looking
-        const R inv = ipiv[k];
-        for (int c = tid; c < n0 + n1; c += NT) {
-            if (c < n0) X0.at(k, c) *= inv;
-            else X1.at(k, c - n0) *= inv;
-        }
-        __syncthreads();
-        for (int r = tid / 64; r < k; r += NWV) {
-            const R u = W[r * ld + k];
-            for (int c = tid & 63; c < n0 + n1; c += 64) {
-                if (c < n0) X0.at(r, c) -= u * X0.at(k, c);
-                else X1.at(r, c - n0) -= u * X1.at(k, c - n0);
+    if (tid < 2) key[tid] = 0;
+    __syncthreads();
+    R colk[NRR];  // column k of this wave's rows (wave-uniform)
+    auto column = [&](int k) {
+        const int kb = k >> 6, src = k & 63;
+        unsigned int best = 0;
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            const R v = kb == 0 ? z[a][0] : (kb == 1 ? z[a][1] : (kb == 2 ? z[a][2] : z[a][3]));
+            colk[a] = bcast(v, src);
+            const int r = ti + NWV * a;
+            if (r < n && !used[a]) {
+                const unsigned int ky = piv_key(colk[a], r);
+                best = ky > best ? ky : best;
             }
         }
+        if (tj == 0 && best) (void)__hip_atomic_fetch_max(key + (k & 1), best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    };
+    column(0);
+    for (int k = 0; k < n; ++k) {
         __syncthreads();
+        const int pr = 127 - (int)(key[k & 1] & 0x7fu);
+        const int pa = pr / NWV;
+        if (ti == pr - pa * NWV) {  // this wave owns the pivot row
+#pragma unroll
+            for (int a = 0; a < NRR; ++a)
+                if (a == pa) {
+                    used[a] = true;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (tj + 64 * b < nct) rowbuf[tj + 64 * b] = z[a][b];
+                    if (tj == 0) {
+                        const R inv = (R)1 / colk[a];
+                        rowbuf[nct] = inv;
+                        pinv[pr] = inv;
+                        iperm[pr] = k;
+                        key[(k + 1) & 1] = 0;  // last read before this step's first barrier; bids for pivot k + 1 come after the second
+                    }
+                }
+        }
+        __syncthreads();
+        const R inv = rowbuf[nct];
+        R zk[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) zk[b] = (tj + 64 * b < nct) ? rowbuf[tj + 64 * b] : (R)0;
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            const R f = (ti + NWV * a != pr) ? colk[a] * inv : (R)0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) z[a][b] -= f * zk[b];
+        }
+        // rowbuf is rewritten only after the next step's first barrier, which every lane passes after the reads above
+        if (k + 1 < n) column(k + 1);
     }
-    return logdet;
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        const int r = ti + NWV * a;
+        if (r < n) {
+            const R inv = pinv[r];
+            const int kr = iperm[r];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = tj + 64 * b;
+                if (c >= n && c < nct) Z[kr * ld + c] = z[a][b] * inv;
+            }
+        }
+    }
+    __syncthreads();
+}
+template <typename R> __device__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
+    if (n <= NWV * 4) gj_solve<R, 4>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
+    else if (n <= NWV * 8) gj_solve<R, 8>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
+    else gj_solve<R, 128 / NWV>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
 }
 
 // ---- observation model of one time step, masked (filtering.py:89-100, :204-213) ------------------------------------------
 template <typename R> struct Obs {
-    R* H_;   // p x d, ld = ldp_(d); missing rows zeroed
+    R* H_;   // p x d (leading dimension chosen by the kernel); missing rows zeroed
     R* c_;   // p
     R* y;    // p (raw)
     unsigned char* nan;
     int* cnt;  // #observed components
 };
-template <typename R> __device__ bool load_obs(const Obs<R>& o, const R* Hg, const R* cg, const R* yg, int p, int d, int tid) {
-    const int ldd = ldp_(d);
+template <typename R> __device__ bool load_obs(const Obs<R>& o, const R* Hg, const R* cg, const R* yg, int p, int d, int ldh, int tid) {
+    const int ldd = ldh;
     if (tid == 0) *o.cnt = 0;
     __syncthreads();
     for (int k = tid; k < p; k += NT) {
@@ -278,10 +414,10 @@ template <typename R> __device__ bool load_obs(const Obs<R>& o, const R* Hg, con
 // S (lower triangle valid, ld ldp_(p)) = H_ P_ H_^T + R_;  PHt (d x p, ld ldp_(p)) = P_ H_^T.  Rg: the p x p record in
 // global memory, upper entries read (as the per-lane path does).
 template <typename R>
-__device__ void innovation(const Obs<R>& o, const R* P_, const R* Rg, int p, int d, R* PHt, R* S, int tid) {
+__device__ void innovation(const Obs<R>& o, int ldh, const R* P_, const R* Rg, int p, int d, R* PHt, R* S, int tid) {
     const int ldd = ldp_(d), ldp = ldp_(p);
-    gemm<R, false, true>(d, p, d, P_, ldd, o.H_, ldd, PHt, ldp, (R)1, (R)0, tid);
-    gemm<R, false, false>(p, p, d, o.H_, ldd, PHt, ldp, S, ldp, (R)1, (R)0, tid);
+    gemm<false, true>(d, p, d, P_, ldd, o.H_, ldh, PHt, ldp, (R)1, (R)0, tid);
+    gemm<false, false>(p, p, d, o.H_, ldh, PHt, ldp, S, ldp, (R)1, (R)0, tid);
     for (int i = tid / 64; i < p; i += NWV)
         for (int j = tid & 63; j <= i; j += 64) {
             // lower (i, j) <- the value the reference computes for the upper (j, i) entry
@@ -290,13 +426,15 @@ __device__ void innovation(const Obs<R>& o, const R* P_, const R* Rg, int p, int
         }
     __syncthreads();
 }
-// -0.5 |z|^2 - sum log L_kk - dim/2 log 2 pi over the observed components; NaN / failed factor -> 0 (nansum).  Lane 0's value.
-template <typename R> __device__ R ell_from(const R* L, int ldp, const R* z, const unsigned char* nan, int p, int dim, bool ok) {
-    R q = 0, logdet = 0;
-    for (int k = 0; k < p; ++k) {
+// -0.5 |z|^2 - sum log L_kk - dim/2 log 2 pi over the observed components; NaN / failed factor -> 0 (nansum).  Cooperative.
+template <typename R> __device__ R ell_from(const R* L, int ldp, const R* z, const unsigned char* nan, int p, int dim, bool ok, R* red, int tid) {
+    R q = 0, ld_ = 0;
+    for (int k = tid; k < p; k += NT) {
         q += z[k] * z[k];
-        logdet += (nan && nan[k]) ? (R)0 : log_(L[k * ldp + k]);
+        ld_ += (nan && nan[k]) ? (R)0 : log_(L[k * ldp + k]);
     }
+    q = block_sum<R>(q, red, tid);
+    const R logdet = block_sum<R>(ld_, red, tid);
     R ell = (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim;
     if (!ok) ell = r_nan<R>();
     return isnan_(ell) ? (R)0 : ell;
@@ -304,19 +442,19 @@ template <typename R> __device__ R ell_from(const R* L, int ldp, const R* z, con
 
 // ---- t = 0 measurement update (sequential_update, filtering.py:83-130); one workgroup per sequence ------------------------
 static size_t lds_filter_t0(size_t s, int d, int p) {
-    const size_t ldd = ldp_(d), ldp = ldp_(p);
-    return al16(d * ldd * s) + 3 * al16(p * ldd * s) + al16(p * ldp * s) + al16(d * s) * 2 + 5 * al16(p * s) + al16(p) + 64;
+    const size_t ldd = ldp_(d), ldp = ldp_(p), ldx = ldp_(d + 1);
+    return al16(d * ldd * s) + 2 * al16(p * ldd * s) + al16(p * ldx * s) + al16(p * ldp * s) + al16(d * s) * 2 + 6 * al16(p * s) + al16(p) + 256;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, s = blockIdx.x, c = s / a.d.B, b = s % a.d.B, d = a.dx, p = a.dy;
-    const int ldd = ldp_(d), ldp = ldp_(p);
+    const int ldd = ldp_(d), ldp = ldp_(p), ldx = ldp_(d + 1);
     Bump L{smem};
     R* P = L.take<R>(d * ldd);
     Obs<R> o;
     o.H_ = L.take<R>(p * ldd);
     R* HP = L.take<R>(p * ldd);
-    R* X = L.take<R>(p * ldd);
+    R* X = L.take<R>(p * ldx);  // [H_ P | yd] -> [S^-1 H_ P | L^-1 yd]
     R* S = L.take<R>(p * ldp);
     R* m = L.take<R>(d);
     R* dm = L.take<R>(d);
@@ -325,12 +463,14 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterA
     R* yd = L.take<R>(p);
     R* z = L.take<R>(p);
     R* invd = L.take<R>(p);
+    R* dg = L.take<R>(p);
+    R* red = L.take<R>(NWV);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
     int* flag = L.take<int>(1);
     load_mat<R>(P, ldd, at<R>(a.P0, c, 0, b), d, d, tid);
     load_vec<R>(m, at<R>(a.m0, c, 0, b), d, tid);
-    const bool any = load_obs<R>(o, at<R>(a.Hs, c, 0, b), at<R>(a.cs, c, 0, b), at<R>(a.ys, c, 0, b), p, d, tid);
+    const bool any = load_obs<R>(o, at<R>(a.Hs, c, 0, b), at<R>(a.cs, c, 0, b), at<R>(a.ys, c, 0, b), p, d, ldd, tid);
     R* mo = const_cast<R*>(at<R>(a.ms, c, 0, b));
     R* Po = const_cast<R*>(at<R>(a.Ps, c, 0, b));
     if (!any) {  // _passthrough :127-130
@@ -339,29 +479,30 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterA
         if (tid == 0) ((R*)a.ell0)[s] = 0;
         return;
     }
+    gemv<R, false>(p, d, o.H_, ldd, m, yd, (R)1, (R)0, tid);
     for (int k = tid; k < p; k += NT) {
-        R yh = o.c_[k];
-        for (int j = 0; j < d; ++j) yh += o.H_[k * ldd + j] * m[j];
-        yd[k] = o.nan[k] ? (R)0 : o.y[k] - yh;
-        z[k] = yd[k];
+        yd[k] = o.nan[k] ? (R)0 : o.y[k] - (yd[k] + o.c_[k]);
+        X[k * ldx + d] = yd[k];
     }
     // HP = H_ P (p x d);  S = HP H_^T + R_
-    gemm<R, false, false>(p, d, d, o.H_, ldd, P, ldd, HP, ldd, (R)1, (R)0, tid);
-    gemm<R, false, true>(p, p, d, HP, ldd, o.H_, ldd, S, ldp, (R)1, (R)0, tid);
+    gemm<false, false>(p, d, d, o.H_, ldd, P, ldd, HP, ldd, (R)1, (R)0, tid);
+    gemm<false, true>(p, p, d, HP, ldd, o.H_, ldd, S, ldp, (R)1, (R)0, tid);
     const R* Rg = at<R>(a.Rs, c, 0, b);
     for (int i = tid / 64; i < p; i += NWV)
         for (int j = tid & 63; j <= i; j += 64) S[i * ldp + j] += (o.nan[i] || o.nan[j]) ? (R)0 : Rg[(long long)j * p + i];
     for (int i = tid / 64; i < p; i += NWV)
-        for (int j = tid & 63; j < d; j += 64) X[i * ldd + j] = HP[i * ldd + j];
+        for (int j = tid & 63; j < d; j += 64) X[i * ldx + j] = HP[i * ldd + j];
     __syncthreads();
-    const bool ok = chol<R>(S, ldp, p, o.nan, invd, flag, tid);
+    const bool ok = chol<R>(S, ldp, p, o.nan, invd, dg, flag, tid);
     // z = L^-1 yd;  X = S^-1 HP  (gain^T, :117)
-    trsm_l<R>(S, ldp, p, invd, Rhs<R>{X, ldd, d, z, nullptr}, tid);
-    const R ell = ell_from<R>(S, ldp, z, o.nan, p, *o.cnt, ok);
-    trsm_lt<R>(S, ldp, p, invd, Rhs<R>{X, ldd, d, nullptr, nullptr}, tid);
+    trsm_l<R>(S, ldp, p, invd, X, ldx, d + 1, tid);
+    for (int k = tid; k < p; k += NT) z[k] = X[k * ldx + d];
+    __syncthreads();
+    const R ell = ell_from<R>(S, ldp, z, o.nan, p, *o.cnt, ok, red, tid);
+    trsm_lt<R>(S, ldp, p, invd, X, ldx, d, tid);
     // m += X^T yd;  P <- sym(P - X^T HP)
-    gemv<R, true>(d, p, X, ldd, yd, dm, (R)1, (R)0, tid);
-    gemm<R, true, false>(d, d, p, X, ldd, HP, ldd, P, ldd, (R)-1, (R)1, tid);
+    gemv<R, true>(d, p, X, ldx, yd, dm, (R)1, (R)0, tid);
+    gemm<true, false>(d, d, p, X, ldx, HP, ldd, P, ldd, (R)-1, (R)1, tid);
     symmetrise<R>(P, ldd, d, tid);
     const R bad = r_nan<R>();
     for (int i = tid; i < d; i += NT) mo[i] = ok ? m[i] + dm[i] : bad;
@@ -373,7 +514,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterA
 // ---- scan element of transition i -> i + 1 (_filtering_init_one, filtering.py:196-250), information form of kalman_math.h ---
 static size_t lds_filter_init(size_t s, int d, int p) {
     const size_t ldd = ldp_(d), ldp = ldp_(p);
-    return 5 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * std::max(ldp, ldd) * s) + al16(p * ldp * s) + 6 * al16(d * s) +
+    return 5 * al16(d * ldd * s) + al16(p * (size_t)ldp_(d + 2) * s) + al16(d * std::max(ldp, ldd) * s) + al16(p * ldp * s) + 6 * al16(d * s) +
            6 * al16(p * s) + al16(p) + 64;
 }
 __host__ __device__ inline long long fe_size(int d) { return 3ll * d * d + 2 * d; }
@@ -383,7 +524,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1;
     const int s = blockIdx.x / n, i = blockIdx.x - s * n, c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
-    const int ldd = ldp_(d), ldp = ldp_(p), ldt = ldp > ldd ? ldp : ldd;
+    const int ldd = ldp_(d), ldp = ldp_(p), ldt = ldp > ldd ? ldp : ldd, ldh = ldp_(d + 2);
     Bump L{smem};
     R* F = L.take<R>(d * ldd);
     R* P_ = L.take<R>(d * ldd);
@@ -391,7 +532,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     R* MF = L.take<R>(d * ldd);
     R* O = L.take<R>(d * ldd);
     Obs<R> o;
-    o.H_ = L.take<R>(p * ldd);
+    o.H_ = L.take<R>(p * ldh);  // [H_ | rm | rb] -> [W | L^-1 rm | L^-1 rb]
     R* Tm = L.take<R>(d * ldt);
     R* S = L.take<R>(p * ldp);
     R* bd = L.take<R>(d);
@@ -405,7 +546,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     R* rm = L.take<R>(p);
     R* rb = L.take<R>(p);
     R* invd = L.take<R>(p);
-    (void)L.take<R>(p);
+    R* dg = L.take<R>(p);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
     int* flag = L.take<int>(1);
@@ -419,12 +560,12 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     load_mat<R>(F, ldd, at<R>(a.Fs, c, i, b), d, d, tid);
     load_mat<R>(P_, ldd, at<R>(a.Qs, c, i, b), d, d, tid);
     load_vec<R>(bd, at<R>(a.bs, c, i, b), d, tid);
-    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, tid);
+    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldh, tid);
     if (i == 0) {  // built around predict(m0+, P0+), not symmetrised (filtering.py:200-201)
         load_mat<R>(M, ldd, at<R>(a.Ps, c, 0, b), d, d, tid);
         load_vec<R>(m0p, at<R>(a.ms, c, 0, b), d, tid);
-        gemm<R, false, false>(d, d, d, F, ldd, M, ldd, Tm, ldt, (R)1, (R)0, tid);
-        gemm<R, false, true>(d, d, d, Tm, ldt, F, ldd, P_, ldd, (R)1, (R)1, tid);
+        gemm<false, false>(d, d, d, F, ldd, M, ldd, Tm, ldt, (R)1, (R)0, tid);
+        gemm<false, true>(d, d, d, Tm, ldt, F, ldd, P_, ldd, (R)1, (R)1, tid);
         gemv<R, false>(d, d, F, ldd, m0p, m_, (R)1, (R)0, tid);
         for (int k = tid; k < d; k += NT) m_[k] += bd[k];
     } else {
@@ -441,20 +582,22 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
         for (int k = tid; k < d; k += NT) eb[k] = m_[k], eeta[k] = 0;
         return;
     }
-    innovation<R>(o, P_, at<R>(a.Rs, c, t, b), p, d, Tm, S, tid);
+    innovation<R>(o, ldh, P_, at<R>(a.Rs, c, t, b), p, d, Tm, S, tid);
+    gemv<R, false>(p, d, o.H_, ldh, m_, rm, (R)1, (R)0, tid);
+    gemv<R, false>(p, d, o.H_, ldh, bd, rb, (R)1, (R)0, tid);
     for (int k = tid; k < p; k += NT) {
-        R hm = o.c_[k], hb = o.c_[k];
-        for (int j = 0; j < d; ++j) hm += o.H_[k * ldd + j] * m_[j], hb += o.H_[k * ldd + j] * bd[j];
-        rm[k] = o.nan[k] ? (R)0 : o.y[k] - hm;
-        rb[k] = o.nan[k] ? (R)0 : o.y[k] - hb;
+        o.H_[k * ldh + d] = o.nan[k] ? (R)0 : o.y[k] - (rm[k] + o.c_[k]);
+        o.H_[k * ldh + d + 1] = o.nan[k] ? (R)0 : o.y[k] - (rb[k] + o.c_[k]);
     }
     __syncthreads();
-    const bool ok = chol<R>(S, ldp, p, o.nan, invd, flag, tid);
-    trsm_l<R>(S, ldp, p, invd, Rhs<R>{o.H_, ldd, d, rm, rb}, tid);  // H_ <- W = L^-1 H_
+    const bool ok = chol<R>(S, ldp, p, o.nan, invd, dg, flag, tid);
+    trsm_l<R>(S, ldp, p, invd, o.H_, ldh, d + 2, tid);  // [H_ | rm | rb] <- L^-1 [.]
+    for (int k = tid; k < p; k += NT) rm[k] = o.H_[k * ldh + d], rb[k] = o.H_[k * ldh + d + 1];
+    __syncthreads();
     // M = W^T W, vm = W^T rm, vb = W^T rb
-    gemm<R, true, false>(d, d, p, o.H_, ldd, o.H_, ldd, M, ldd, (R)1, (R)0, tid);
-    gemv<R, true>(d, p, o.H_, ldd, rm, vm, (R)1, (R)0, tid);
-    gemv<R, true>(d, p, o.H_, ldd, rb, vb, (R)1, (R)0, tid);
+    gemm<true, false>(d, d, p, o.H_, ldh, o.H_, ldh, M, ldd, (R)1, (R)0, tid);
+    gemv<R, true>(d, p, o.H_, ldh, rm, vm, (R)1, (R)0, tid);
+    gemv<R, true>(d, p, o.H_, ldh, rb, vb, (R)1, (R)0, tid);
     if (!ok) {
         const R bad = r_nan<R>();
         for (int r = tid / 64; r < d; r += NWV)
@@ -463,20 +606,20 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
         __syncthreads();
     }
     // A = F - P_ M F;  b = m_ + P_ vm;  C = sym(P_ - P_ M P_);  eta = F^T vb;  J = sym(F^T M F)
-    gemm<R, false, false>(d, d, d, P_, ldd, M, ldd, Tm, ldt, (R)1, (R)0, tid);   // PM
-    gemm<R, false, false>(d, d, d, M, ldd, F, ldd, MF, ldd, (R)1, (R)0, tid);
-    gemm<R, false, false>(d, d, d, Tm, ldt, F, ldd, O, ldd, (R)1, (R)0, tid);
+    gemm<false, false>(d, d, d, P_, ldd, M, ldd, Tm, ldt, (R)1, (R)0, tid);   // PM
+    gemm<false, false>(d, d, d, M, ldd, F, ldd, MF, ldd, (R)1, (R)0, tid);
+    gemm<false, false>(d, d, d, Tm, ldt, F, ldd, O, ldd, (R)1, (R)0, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) eA[r * d + q] = F[r * ldd + q] - O[r * ldd + q];
     __syncthreads();
-    gemm<R, false, false>(d, d, d, Tm, ldt, P_, ldd, O, ldd, (R)1, (R)0, tid);
+    gemm<false, false>(d, d, d, Tm, ldt, P_, ldd, O, ldd, (R)1, (R)0, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
             const R v1 = P_[r * ldd + q] - O[r * ldd + q], v2 = P_[q * ldd + r] - O[q * ldd + r];
             eC[r * d + q] = r == q ? v1 : (R)0.5 * (v1 + v2);
         }
     __syncthreads();
-    gemm<R, true, false>(d, d, d, F, ldd, MF, ldd, O, ldd, (R)1, (R)0, tid);
+    gemm<true, false>(d, d, d, F, ldd, MF, ldd, O, ldd, (R)1, (R)0, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) eJ[r * d + q] = r == q ? O[r * ldd + r] : (R)0.5 * (O[r * ldd + q] + O[q * ldd + r]);
     gemv<R, false>(d, d, P_, ldd, vm, tv, (R)1, (R)0, tid);
@@ -487,22 +630,47 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
 }
 
 // ---- the associative operator of the parallel filter (_filtering_op_impl, filtering.py:163-183; one LU as in kalman_math.h) -
-template <typename R> struct Agg {  // running prefix in LDS
-    R *A, *C, *J, *b, *eta;
+// The running prefix lives in LDS inside ONE augmented matrix Z = [W | A | C | v] (d x (3d + 1)) so that the pivoted LU of
+// W = I + C1 J2 sweeps its right-hand sides [A1 | C1 | b1 + C1 eta2] in the same pass; the down-sweep, which carries only
+// (b, C), uses Z = [W | C | v].
+template <typename R> struct Agg {
+    R *Z, *A, *C, *J, *b, *eta;  // A, C: views into Z (leading dimension ldz); J: d x d, ld ldp_(d)
+    int ldz, nct;                // columns of Z
+    R *T1, *T2, *Eb;             // d x d scratch
+    R *v, *w, *e2;               // d
+    R *rowbuf, *pinv;            // elimination scratch: 3d + 2, d
+    int* iperm;
+    unsigned int* key;
 };
-template <typename R> struct CombTmp {
-    R *W, *T1, *T2, *Eb;           // d x d
-    R *v, *w, *e2, *fcol, *ipiv;   // d
-    int* piv;
-};
-static size_t lds_combine(size_t s, int d) { return 7 * al16(d * (size_t)ldp_(d) * s) + 7 * al16(d * s) + 64; }
+static size_t lds_combine(size_t s, int d) { return al16(d * (size_t)ldp_(3 * d + 1) * s) + 4 * al16(d * (size_t)ldp_(d) * s) + 6 * al16(d * s) + al16((3 * d + 2) * s) + al16(d * 4) + 64; }
 
+template <typename R> __device__ void carve_combine(Bump& L, Agg<R>& g, int d, bool full) {
+    const int ldd = ldp_(d);
+    g.nct = full ? 3 * d + 1 : 2 * d + 1;
+    g.ldz = ldp_(g.nct);
+    g.Z = L.take<R>(d * g.ldz);
+    g.A = full ? g.Z + d : nullptr;
+    g.C = g.Z + (full ? 2 * d : d);
+    g.J = L.take<R>(d * ldd);
+    g.T1 = L.take<R>(d * ldd);
+    g.T2 = L.take<R>(d * ldd);
+    g.Eb = L.take<R>(d * ldd);
+    g.b = L.take<R>(d);
+    g.eta = L.take<R>(d);
+    g.v = L.take<R>(d);
+    g.w = L.take<R>(d);
+    g.e2 = L.take<R>(d);
+    g.rowbuf = L.take<R>(3 * d + 2);
+    g.pinv = L.take<R>(d);
+    g.iperm = L.take<int>(d);
+    g.key = L.take<unsigned int>(2);
+}
 template <typename R> __device__ void agg_load(const Agg<R>& g, const R* __restrict__ e, int d, int tid) {
     const int ldd = ldp_(d);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
-            g.A[r * ldd + q] = e[r * d + q];
-            g.C[r * ldd + q] = e[d * d + d + r * d + q];
+            if (g.A) g.A[r * g.ldz + q] = e[r * d + q];
+            g.C[r * g.ldz + q] = e[d * d + d + r * d + q];
             g.J[r * ldd + q] = e[2 * d * d + 2 * d + r * d + q];
         }
     for (int k = tid; k < d; k += NT) g.b[k] = e[d * d + k], g.eta[k] = e[2 * d * d + d + k];
@@ -512,8 +680,8 @@ template <typename R> __device__ void agg_store(R* __restrict__ e, const Agg<R>&
     const int ldd = ldp_(d);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
-            e[r * d + q] = g.A[r * ldd + q];
-            e[d * d + d + r * d + q] = g.C[r * ldd + q];
+            e[r * d + q] = g.A[r * g.ldz + q];
+            e[d * d + d + r * d + q] = g.C[r * g.ldz + q];
             e[2 * d * d + 2 * d + r * d + q] = g.J[r * ldd + q];
         }
     for (int k = tid; k < d; k += NT) e[d * d + k] = g.b[k], e[2 * d * d + d + k] = g.eta[k];
@@ -522,65 +690,50 @@ template <typename R> __device__ void agg_store(R* __restrict__ e, const Agg<R>&
 //   W = I + C1 J2;  [X | Y | z] = W^-1 [A1 | C1 | b1 + C1 eta2]
 //   A = A2 X;  b = A2 z + b2;  C = sym(A2 Y A2^T + C2);  eta = X^T (eta2 - J2 b1) + eta1;  J = sym(X^T (J2 A1) + J1)
 // full = false: only (b, C) are updated (the down-sweep; they depend on a1 only through (b1, C1)).
-template <typename R> __device__ void combine(const Agg<R>& g, const CombTmp<R>& t, const R* __restrict__ e2, int d, bool full, int tid) {
-    const int ldd = ldp_(d);
+template <typename R> __device__ void combine(const Agg<R>& g, const R* __restrict__ e2, int d, bool full, int tid) {
+    const int ldd = ldp_(d), ldz = g.ldz;
     const R* A2 = e2;
     const R* b2 = e2 + d * d;
     const R* C2 = b2 + d;
     const R* eta2 = C2 + d * d;
     const R* J2 = eta2 + d;
-    load_mat<R>(t.Eb, ldd, J2, d, d, tid);
-    load_vec<R>(t.e2, eta2, d, tid);
-    gemm<R, false, false>(d, d, d, g.C, ldd, t.Eb, ldd, t.W, ldd, (R)1, (R)0, tid);
-    for (int k = tid; k < d; k += NT) t.W[k * ldd + k] += (R)1;
-    gemv<R, false>(d, d, g.C, ldd, t.e2, t.v, (R)1, (R)0, tid);
-    for (int k = tid; k < d; k += NT) t.v[k] += g.b[k];
+    load_mat<R>(g.Eb, ldd, J2, d, d, tid);
+    load_vec<R>(g.e2, eta2, d, tid);
+    gemm<false, false>(d, d, d, g.C, ldz, g.Eb, ldd, g.Z, ldz, (R)1, (R)0, tid);  // W = C1 J2 (+ I below)
+    gemv<R, false>(d, d, g.C, ldz, g.e2, g.v, (R)1, (R)0, tid);
+    for (int k = tid; k < d; k += NT) {
+        g.Z[k * ldz + k] += (R)1;
+        g.Z[k * ldz + g.nct - 1] = g.v[k] + g.b[k];
+    }
     if (full) {
-        gemm<R, false, false>(d, d, d, t.Eb, ldd, g.A, ldd, t.T1, ldd, (R)1, (R)0, tid);  // J2 A1
-        gemv<R, false>(d, d, t.Eb, ldd, g.b, t.w, (R)1, (R)0, tid);
-        for (int k = tid; k < d; k += NT) t.w[k] = t.e2[k] - t.w[k];
+        gemm<false, false>(d, d, d, g.Eb, ldd, g.A, ldz, g.T1, ldd, (R)1, (R)0, tid);  // J2 A1
+        gemv<R, false>(d, d, g.Eb, ldd, g.b, g.w, (R)1, (R)0, tid);
+        for (int k = tid; k < d; k += NT) g.w[k] = g.e2[k] - g.w[k];
     }
     __syncthreads();
-    if (full) lu_solve<R>(t.W, ldd, d, Rhs<R>{g.A, ldd, d, nullptr, nullptr}, Rhs<R>{g.C, ldd, d, t.v, nullptr}, t.fcol, t.ipiv, t.piv, tid);
-    else lu_solve<R>(t.W, ldd, d, Rhs<R>{g.C, ldd, d, t.v, nullptr}, Rhs<R>{nullptr, 0, 0, nullptr, nullptr}, t.fcol, t.ipiv, t.piv, tid);
+    lu_solve<R>(g.Z, ldz, d, g.nct, g.rowbuf, g.pinv, g.iperm, g.key, tid);
+    for (int k = tid; k < d; k += NT) g.v[k] = g.Z[k * ldz + g.nct - 1];  // z
+    __syncthreads();
     if (full) {
-        gemm<R, true, false>(d, d, d, g.A, ldd, t.T1, ldd, g.J, ldd, (R)1, (R)1, tid);  // J1 + X^T (J2 A1)
+        gemm<true, false>(d, d, d, g.A, ldz, g.T1, ldd, g.J, ldd, (R)1, (R)1, tid);  // J1 + X^T (J2 A1)
         symmetrise<R>(g.J, ldd, d, tid);
-        gemv<R, true>(d, d, g.A, ldd, t.w, g.eta, (R)1, (R)1, tid);
+        gemv<R, true>(d, d, g.A, ldz, g.w, g.eta, (R)1, (R)1, tid);
     }
-    load_mat<R>(t.Eb, ldd, A2, d, d, tid);
-    gemm<R, false, false>(d, d, d, t.Eb, ldd, g.C, ldd, t.T2, ldd, (R)1, (R)0, tid);  // A2 Y
+    load_mat<R>(g.Eb, ldd, A2, d, d, tid);
+    gemm<false, false>(d, d, d, g.Eb, ldd, g.C, ldz, g.T2, ldd, (R)1, (R)0, tid);  // A2 Y
     for (int r = tid / 64; r < d; r += NWV)
-        for (int q = tid & 63; q < d; q += 64) g.C[r * ldd + q] = C2[r * d + q];
+        for (int q = tid & 63; q < d; q += 64) g.C[r * ldz + q] = C2[r * d + q];
     __syncthreads();
-    gemm<R, false, true>(d, d, d, t.T2, ldd, t.Eb, ldd, g.C, ldd, (R)1, (R)1, tid);
-    symmetrise<R>(g.C, ldd, d, tid);
-    gemv<R, false>(d, d, t.Eb, ldd, t.v, g.b, (R)1, (R)0, tid);
+    gemm<false, true>(d, d, d, g.T2, ldd, g.Eb, ldd, g.C, ldz, (R)1, (R)1, tid);
+    symmetrise<R>(g.C, ldz, d, tid);
+    gemv<R, false>(d, d, g.Eb, ldd, g.v, g.b, (R)1, (R)0, tid);
     for (int k = tid; k < d; k += NT) g.b[k] += b2[k];
     if (full) {
-        gemm<R, false, false>(d, d, d, t.Eb, ldd, g.A, ldd, t.T1, ldd, (R)1, (R)0, tid);  // A2 X
+        gemm<false, false>(d, d, d, g.Eb, ldd, g.A, ldz, g.T1, ldd, (R)1, (R)0, tid);  // A2 X
         for (int r = tid / 64; r < d; r += NWV)
-            for (int q = tid & 63; q < d; q += 64) g.A[r * ldd + q] = t.T1[r * ldd + q];
+            for (int q = tid & 63; q < d; q += 64) g.A[r * ldz + q] = g.T1[r * ldd + q];
     }
     __syncthreads();
-}
-template <typename R> __device__ void carve_combine(Bump& L, Agg<R>& g, CombTmp<R>& t, int d) {
-    const int ldd = ldp_(d);
-    g.A = L.take<R>(d * ldd);
-    g.C = L.take<R>(d * ldd);
-    g.J = L.take<R>(d * ldd);
-    t.W = L.take<R>(d * ldd);
-    t.T1 = L.take<R>(d * ldd);
-    t.T2 = L.take<R>(d * ldd);
-    t.Eb = L.take<R>(d * ldd);
-    g.b = L.take<R>(d);
-    g.eta = L.take<R>(d);
-    t.v = L.take<R>(d);
-    t.w = L.take<R>(d);
-    t.e2 = L.take<R>(d);
-    t.fcol = L.take<R>(d);
-    t.ipiv = L.take<R>(d);
-    t.piv = L.take<int>(1);
 }
 
 // chunk aggregate: elements [ch E, min(n, (ch+1) E))
@@ -589,12 +742,11 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_reduce(const
     const int tid = threadIdx.x, s = blockIdx.x / nchunk, ch = blockIdx.x - s * nchunk;
     Bump L{smem};
     Agg<R> g;
-    CombTmp<R> t;
-    carve_combine<R>(L, g, t, d);
+    carve_combine<R>(L, g, d, true);
     const long long ne = fe_size(d);
     const int i0 = ch * E, i1 = min(n, i0 + E);
     agg_load<R>(g, elem + ((long long)s * n + i0) * ne, d, tid);
-    for (int i = i0 + 1; i < i1; ++i) combine<R>(g, t, elem + ((long long)s * n + i) * ne, d, true, tid);
+    for (int i = i0 + 1; i < i1; ++i) combine<R>(g, elem + ((long long)s * n + i) * ne, d, true, tid);
     agg_store<R>(aggs + ((long long)s * nchunk + ch) * ne, g, d, tid);
 }
 // exclusive scan of the chunk aggregates of one sequence; pre[ch] = (b, C) of the prefix before chunk ch (ch >= 1)
@@ -603,16 +755,14 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_aggs(const R
     const int tid = threadIdx.x, s = blockIdx.x;
     Bump L{smem};
     Agg<R> g;
-    CombTmp<R> t;
-    carve_combine<R>(L, g, t, d);
+    carve_combine<R>(L, g, d, true);
     const long long ne = fe_size(d), np = (long long)d * d + d;
-    const int ldd = ldp_(d);
     agg_load<R>(g, aggs + (long long)s * nchunk * ne, d, tid);
     for (int ch = 1; ch < nchunk; ++ch) {
         R* q = pre + ((long long)s * nchunk + ch) * np;
         for (int k = tid; k < d; k += NT) q[k] = g.b[k];
-        store_mat<R>(q + d, g.C, ldd, d, d, tid);
-        if (ch + 1 < nchunk) combine<R>(g, t, aggs + ((long long)s * nchunk + ch) * ne, d, true, tid);
+        store_mat<R>(q + d, g.C, g.ldz, d, d, tid);
+        if (ch + 1 < nchunk) combine<R>(g, aggs + ((long long)s * nchunk + ch) * ne, d, true, tid);
     }
 }
 // down-sweep: filtered moments ms[i + 1], Ps[i + 1] = (b, C) of the inclusive prefix i
@@ -622,25 +772,22 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
     const int s = blockIdx.x / nchunk, ch = blockIdx.x - s * nchunk, c = s / a.d.B, b = s % a.d.B;
     Bump L{smem};
     Agg<R> g;
-    CombTmp<R> t;
-    carve_combine<R>(L, g, t, d);
+    carve_combine<R>(L, g, d, false);
     const long long ne = fe_size(d), np = (long long)d * d + d;
-    const int ldd = ldp_(d);
     const int i0 = ch * E, i1 = min(n, i0 + E);
-    int i = i0;
     if (ch == 0) {
         agg_load<R>(g, elem + (long long)s * n * ne, d, tid);  // prefix 0 = element 0 itself
     } else {
         const R* q = pre + ((long long)s * nchunk + ch) * np;
         load_vec<R>(g.b, q, d, tid);
-        load_mat<R>(g.C, ldd, q + d, d, d, tid);
+        load_mat<R>(g.C, g.ldz, q + d, d, d, tid);
     }
-    for (; i < i1; ++i) {
-        if (!(ch == 0 && i == 0)) combine<R>(g, t, elem + ((long long)s * n + i) * ne, d, false, tid);
+    for (int i = i0; i < i1; ++i) {
+        if (!(ch == 0 && i == 0)) combine<R>(g, elem + ((long long)s * n + i) * ne, d, false, tid);
         R* mo = const_cast<R*>(at<R>(a.ms, c, (long long)i + 1, b));
         R* Po = const_cast<R*>(at<R>(a.Ps, c, (long long)i + 1, b));
         for (int k = tid; k < d; k += NT) mo[k] = g.b[k];
-        store_mat<R>(Po, g.C, ldd, d, d, tid);
+        store_mat<R>(Po, g.C, g.ldz, d, d, tid);
         __syncthreads();
     }
 }
@@ -648,7 +795,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
 // ---- log-likelihood increments (filtering.py:60-62): predict from the filtered moments at i, ell_inc of step i + 1 ---------
 static size_t lds_filter_ell(size_t s, int d, int p) {
     const size_t ldd = ldp_(d), ldp = ldp_(p);
-    return 4 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * ldp * s) + al16(p * ldp * s) + 3 * al16(d * s) + 5 * al16(p * s) + al16(p) + 64;
+    return 4 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * ldp * s) + al16(p * ldp * s) + 3 * al16(d * s) + 5 * al16(p * s) + al16(p) + 256;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(FilterArgs a, R* __restrict__ ellinc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -672,11 +819,12 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(Filter
     o.y = L.take<R>(p);
     R* yd = L.take<R>(p);
     R* invd = L.take<R>(p);
-    (void)L.take<R>(p);
+    R* dg = L.take<R>(p);
+    R* red = L.take<R>(NWV);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
     int* flag = L.take<int>(1);
-    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, tid);
+    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
     if (!any) {
         if (tid == 0) ellinc[(long long)s * n + i] = 0;
         return;
@@ -689,19 +837,17 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(Filter
     // sequential_predict :134-139
     gemv<R, false>(d, d, F, ldd, m, m_, (R)1, (R)0, tid);
     for (int k = tid; k < d; k += NT) m_[k] += bd[k];
-    gemm<R, false, false>(d, d, d, F, ldd, P, ldd, Tm, ldd, (R)1, (R)0, tid);
-    gemm<R, false, true>(d, d, d, Tm, ldd, F, ldd, P_, ldd, (R)1, (R)1, tid);
+    gemm<false, false>(d, d, d, F, ldd, P, ldd, Tm, ldd, (R)1, (R)0, tid);
+    gemm<false, true>(d, d, d, Tm, ldd, F, ldd, P_, ldd, (R)1, (R)1, tid);
     symmetrise<R>(P_, ldd, d, tid);
-    innovation<R>(o, P_, at<R>(a.Rs, c, t, b), p, d, PHt, S, tid);
-    for (int k = tid; k < p; k += NT) {
-        R yh = o.c_[k];
-        for (int j = 0; j < d; ++j) yh += o.H_[k * ldd + j] * m_[j];
-        yd[k] = o.nan[k] ? (R)0 : o.y[k] - yh;
-    }
+    innovation<R>(o, ldd, P_, at<R>(a.Rs, c, t, b), p, d, PHt, S, tid);
+    gemv<R, false>(p, d, o.H_, ldd, m_, yd, (R)1, (R)0, tid);
+    for (int k = tid; k < p; k += NT) yd[k] = o.nan[k] ? (R)0 : o.y[k] - (yd[k] + o.c_[k]);
     __syncthreads();
-    const bool ok = chol<R>(S, ldp, p, o.nan, invd, flag, tid);
-    trsm_l<R>(S, ldp, p, invd, Rhs<R>{nullptr, 0, 0, yd, nullptr}, tid);
-    if (tid == 0) ellinc[(long long)s * n + i] = ell_from<R>(S, ldp, yd, o.nan, p, *o.cnt, ok);
+    const bool ok = chol<R>(S, ldp, p, o.nan, invd, dg, flag, tid);
+    trsm_l<R>(S, ldp, p, invd, yd, 1, 1, tid);
+    const R ell = ell_from<R>(S, ldp, yd, o.nan, p, *o.cnt, ok, red, tid);
+    if (tid == 0) ellinc[(long long)s * n + i] = ell;
 }
 
 // out[r] = sum_{b < B} ( add0[r B + b] + sum_{i < n} part[(r B + b) n + i] ), fixed order; one workgroup per output
@@ -732,8 +878,8 @@ static size_t lds_sample_init(size_t s, int d) { return 7 * al16(d * (size_t)ldp
 template <typename R> __device__ R nan_to_num_(R x) { return nan_to_num<R>(x); }
 
 // Lc <- lower Cholesky factor of the symmetric matrix in Lc (full storage), nan_to_num'ed; a failed factorisation is all zero
-template <typename R> __device__ void chol_n2n(R* Lc, int ld, int n, R* invd, int* flag, int tid) {
-    const bool ok = chol<R>(Lc, ld, n, nullptr, invd, flag, tid);
+template <typename R> __device__ void chol_n2n(R* Lc, int ld, int n, R* invd, R* dg, int* flag, int tid) {
+    const bool ok = chol<R>(Lc, ld, n, nullptr, invd, dg, flag, tid);
     for (int r = tid / 64; r < n; r += NWV)
         for (int q = tid & 63; q < n; q += 64) Lc[r * ld + q] = (q <= r && ok) ? nan_to_num<R>(Lc[r * ld + q]) : (R)0;
     __syncthreads();
@@ -758,7 +904,8 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     R* pm = L.take<R>(d);
     R* tv = L.take<R>(d);
     R* invd = L.take<R>(d);
-    (void)L.take<R>(2 * d);
+    R* dg = L.take<R>(d);
+    (void)L.take<R>(d);
     int* flag = L.take<int>(1);
     R* e = elem + ((long long)s * T + j) * ((long long)d * d + d);
     load_mat<R>(P, ldd, at<R>(a.Ps, c, t, b), d, d, tid);
@@ -768,7 +915,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = r == q ? P[r * ldd + r] : (R)0.5 * (P[r * ldd + q] + P[q * ldd + r]);
         __syncthreads();
-        chol_n2n<R>(X, ldd, d, invd, flag, tid);
+        chol_n2n<R>(X, ldd, d, invd, dg, flag, tid);
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) e[r * d + q] = 0;
         for (int k = tid; k < d; k += NT) {
@@ -782,29 +929,29 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     load_mat<R>(S, ldd, at<R>(a.Qs, c, t, b), d, d, tid);
     load_vec<R>(bd, at<R>(a.bs, c, t, b), d, tid);
     // S = sym(F P F^T + Q);  gain = P (S^-1 F)^T  (mean_and_chol :84-97)
-    gemm<R, false, false>(d, d, d, F, ldd, P, ldd, T1, ldd, (R)1, (R)0, tid);
-    gemm<R, false, true>(d, d, d, T1, ldd, F, ldd, S, ldd, (R)1, (R)1, tid);
+    gemm<false, false>(d, d, d, F, ldd, P, ldd, T1, ldd, (R)1, (R)0, tid);
+    gemm<false, true>(d, d, d, T1, ldd, F, ldd, S, ldd, (R)1, (R)1, tid);
     symmetrise<R>(S, ldd, d, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) S0[r * ldd + q] = S[r * ldd + q], X[r * ldd + q] = F[r * ldd + q];
     __syncthreads();
-    const bool ok = chol<R>(S, ldd, d, nullptr, invd, flag, tid);
-    trsm_l<R>(S, ldd, d, invd, Rhs<R>{X, ldd, d, nullptr, nullptr}, tid);
-    trsm_lt<R>(S, ldd, d, invd, Rhs<R>{X, ldd, d, nullptr, nullptr}, tid);
-    gemm<R, false, true>(d, d, d, P, ldd, X, ldd, G, ldd, (R)1, (R)0, tid);
+    const bool ok = chol<R>(S, ldd, d, nullptr, invd, dg, flag, tid);
+    trsm_l<R>(S, ldd, d, invd, X, ldd, d, tid);
+    trsm_lt<R>(S, ldd, d, invd, X, ldd, d, tid);
+    gemm<false, true>(d, d, d, P, ldd, X, ldd, G, ldd, (R)1, (R)0, tid);
     if (!ok) {
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) G[r * ldd + q] = r_nan<R>();
         __syncthreads();
     }
     // Sig = sym(P - G S G^T);  Lc = nan_to_num(chol(Sig))  (:98-104)
-    gemm<R, false, false>(d, d, d, G, ldd, S0, ldd, T1, ldd, (R)1, (R)0, tid);
+    gemm<false, false>(d, d, d, G, ldd, S0, ldd, T1, ldd, (R)1, (R)0, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = P[r * ldd + q];
     __syncthreads();
-    gemm<R, false, true>(d, d, d, T1, ldd, G, ldd, X, ldd, (R)-1, (R)1, tid);
+    gemm<false, true>(d, d, d, T1, ldd, G, ldd, X, ldd, (R)-1, (R)1, tid);
     symmetrise<R>(X, ldd, d, tid);
-    chol_n2n<R>(X, ldd, d, invd, flag, tid);
+    chol_n2n<R>(X, ldd, d, invd, dg, flag, tid);
     // inc = m - G (F m + b) + Lc eps  (:108-112)
     gemv<R, false>(d, d, F, ldd, m, pm, (R)1, (R)0, tid);
     for (int k = tid; k < d; k += NT) pm[k] += bd[k];
@@ -839,7 +986,7 @@ template <typename R> __device__ void sample_combine_w(SAgg<R>& g, const R* __re
     gemv<R, false>(d, d, g.Gc, ldd, g.e, g.tv, (R)1, (R)0, tid);
     for (int k = tid; k < d; k += NT) g.e[k] = g.tv[k] + g.ec[k];
     if (full) {
-        gemm<R, false, false>(d, d, d, g.Gc, ldd, g.G, ldd, g.Go, ldd, (R)1, (R)0, tid);
+        gemm<false, false>(d, d, d, g.Gc, ldd, g.G, ldd, g.Go, ldd, (R)1, (R)0, tid);
         R* sw = g.G;
         g.G = g.Go;
         g.Go = sw;
@@ -902,36 +1049,38 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_down(Sample
 // Cholesky of the covariance record `cov` (n x n in global memory, upper entries read) with deleted components `skip`, then
 // up to two residuals solved in place.  Returns through o1 / o2 (lane-0 values; 0 where the reference's nansum drops the term).
 template <typename R>
-__device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* skip, R* r1, R* r2, R* Lb, R* invd, int* flag, int tid, R& o1, R& o2) {
+__device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* skip, R* r1, R* r2, R* Lb, R* invd, R* dg, R* rr, int* flag, int tid, R& o1, R& o2) {
     const int ld = ldp_(n);
+    // the covariance record is symmetric: its lower triangle is read (row-contiguous, coalesced)
     for (int i = tid / 64; i < n; i += NWV)
-        for (int j = tid & 63; j <= i; j += 64) Lb[i * ld + j] = cov[(long long)j * n + i];
-    __syncthreads();
-    int dim = 0;
-    bool bad1 = false, bad2 = false;
-    for (int k = 0; k < n; ++k) {  // every lane computes these (cheap, uniform)
+        for (int j = tid & 63; j <= i; j += 64) Lb[i * ld + j] = cov[(long long)i * n + j];
+    int dimc = 0, b1 = 0, b2 = 0;
+    for (int k = tid; k < n; k += NT) {  // rr = [r1 | r2] (n x 2), deleted components zeroed
         const bool sk = skip && skip[k];
-        dim += sk ? 0 : 1;
-        bad1 = bad1 || (!sk && !finite_(r1[k]));
-        if (r2) bad2 = bad2 || (!sk && !finite_(r2[k]));
+        dimc += sk ? 0 : 1;
+        b1 |= (!sk && !finite_(r1[k])) ? 1 : 0;
+        b2 |= (!sk && r2 && !finite_(r2[k])) ? 1 : 0;
+        rr[2 * k] = sk ? (R)0 : r1[k];
+        rr[2 * k + 1] = (sk || !r2) ? (R)0 : r2[k];
     }
-    __syncthreads();
-    if (skip)
-        for (int k = tid; k < n; k += NT)
-            if (skip[k]) {
-                r1[k] = 0;
-                if (r2) r2[k] = 0;
-            }
-    __syncthreads();
-    const bool ok = chol<R>(Lb, ld, n, skip, invd, flag, tid);
-    trsm_l<R>(Lb, ld, n, invd, Rhs<R>{nullptr, 0, 0, r1, r2}, tid);
-    R q1 = 0, q2 = 0, logdet = 0;
-    for (int k = 0; k < n; ++k) {
-        q1 += r1[k] * r1[k];
-        if (r2) q2 += r2[k] * r2[k];
-        logdet += (skip && skip[k]) ? (R)0 : log_(Lb[k * ld + k]);
+    const bool bad1 = __syncthreads_or(b1), bad2 = __syncthreads_or(b2);
+    (void)dimc;
+    const bool ok = chol<R>(Lb, ld, n, skip, invd, dg, flag, tid);
+    trsm_l<R>(Lb, ld, n, invd, rr, 2, 2, tid);
+    R q1 = 0, q2 = 0, ldt = 0, dm = 0;
+    for (int k = tid; k < n; k += NT) {
+        q1 += rr[2 * k] * rr[2 * k];
+        q2 += rr[2 * k + 1] * rr[2 * k + 1];
+        const bool sk = skip && skip[k];
+        ldt += sk ? (R)0 : log_(Lb[k * ld + k]);
+        dm += sk ? (R)0 : (R)1;
     }
-    const R cst = -logdet - (R)(0.5 * LOG_2PI) * (R)dim;
+    R* red = dg;  // dg is free once the factor is final (n >= 1 reals... NWV needed: callers size dg with >= NWV)
+    q1 = block_sum<R>(q1, red, tid);
+    q2 = block_sum<R>(q2, red, tid);
+    const R logdet = block_sum<R>(ldt, red, tid);
+    const R dimr = block_sum<R>(dm, red, tid);
+    const R cst = -logdet - (R)(0.5 * LOG_2PI) * dimr;
     o1 = ok ? (R)-0.5 * q1 + cst : r_nan<R>();
     o2 = ok ? (R)-0.5 * q2 + cst : r_nan<R>();
     if (bad1 || isnan_(o1)) o1 = 0;
@@ -942,7 +1091,7 @@ __device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* sk
 // joint log-density (base.py:99-166): item (s, t): observation term at t + transition into t (t >= 1) or initial term (t = 0)
 static size_t lds_logpdf(size_t s, int d, int p) {
     const int n = std::max(d, p);
-    return al16(n * (size_t)ldp_(n) * s) + 4 * al16(d * s) + 4 * al16(n * s) + al16(n) + 64;
+    return al16(n * (size_t)ldp_(n) * s) + 4 * al16(d * s) + 5 * al16(n * s) + al16(n) + 512;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs a, R* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -956,38 +1105,35 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs
     (void)L.take<R>(d);
     R* ro = L.take<R>(nmax);
     R* invd = L.take<R>(nmax);
-    (void)L.take<R>(2 * nmax);
+    R* dg = L.take<R>(nmax > NWV ? nmax : NWV);
+    R* rr = L.take<R>(2 * nmax);
     unsigned char* skip = L.take<unsigned char>(nmax);
     int* flag = L.take<int>(1);
     load_vec<R>(x, at<R>(a.xs, c, t, b), d, tid);
     const R* Hg = at<R>(a.Hs, c, t, b);
     const R* cg = at<R>(a.cs, c, t, b);
     const R* yg = at<R>(a.ys, c, t, b);
+    gemv_rows<R>(p, d, Hg, d, x, ro, tid);
     for (int k = tid; k < p; k += NT) {
-        R pr = cg[k];
-        for (int j = 0; j < d; ++j) pr += Hg[(long long)k * d + j] * x[j];
-        ro[k] = yg[k] - pr;
+        ro[k] = yg[k] - (cg[k] + ro[k]);
         skip[k] = (a.nan_policy == 1) && !finite_(yg[k]);
     }
     __syncthreads();
     R o_obs, o_dyn, dummy;
-    gauss2<R>(at<R>(a.Rs, c, t, b), p, a.nan_policy == 1 ? skip : nullptr, ro, nullptr, Lb, invd, flag, tid, o_obs, dummy);
+    gauss2<R>(at<R>(a.Rs, c, t, b), p, a.nan_policy == 1 ? skip : nullptr, ro, nullptr, Lb, invd, dg, rr, flag, tid, o_obs, dummy);
     if (t == 0) {
         const R* m0 = at<R>(a.m0, c, 0, b);
         for (int k = tid; k < d; k += NT) rd_[k] = x[k] - m0[k];
         __syncthreads();
-        gauss2<R>(at<R>(a.P0, c, 0, b), d, nullptr, rd_, nullptr, Lb, invd, flag, tid, o_dyn, dummy);
+        gauss2<R>(at<R>(a.P0, c, 0, b), d, nullptr, rd_, nullptr, Lb, invd, dg, rr, flag, tid, o_dyn, dummy);
     } else {
         load_vec<R>(xq, at<R>(a.xs, c, t - 1, b), d, tid);
         const R* Fg = at<R>(a.Fs, c, t - 1, b);
         const R* bg = at<R>(a.bs, c, t - 1, b);
-        for (int k = tid; k < d; k += NT) {
-            R pr = 0;
-            for (int j = 0; j < d; ++j) pr += Fg[(long long)k * d + j] * xq[j];
-            rd_[k] = x[k] - (pr + bg[k]);
-        }
+        gemv_rows<R>(d, d, Fg, d, xq, rd_, tid);
+        for (int k = tid; k < d; k += NT) rd_[k] = x[k] - (rd_[k] + bg[k]);
         __syncthreads();
-        gauss2<R>(at<R>(a.Qs, c, t - 1, b), d, nullptr, rd_, nullptr, Lb, invd, flag, tid, o_dyn, dummy);
+        gauss2<R>(at<R>(a.Qs, c, t - 1, b), d, nullptr, rd_, nullptr, Lb, invd, dg, rr, flag, tid, o_dyn, dummy);
     }
     if (tid == 0) part[(long long)s * T + t] = o_obs + o_dyn;
 }
@@ -995,7 +1141,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs
 // the five sums of one sweep of the LG_CONCAT device model (body_sweep_logpdf of kalman_bodies.h); part [5][C][T]
 static size_t lds_sweep_logpdf(size_t s, int d, int po) {
     const int n = std::max(d, po);
-    return al16(n * (size_t)ldp_(n) * s) + 7 * al16(d * s) + 4 * al16(n * s) + al16(n) + 64;
+    return al16(n * (size_t)ldp_(n) * s) + 7 * al16(d * s) + 6 * al16(n * s) + al16(n) + 512;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(SweepLogpdfArgs a, R* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1013,7 +1159,8 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
     R* r1 = L.take<R>(nmax);
     R* r2 = L.take<R>(nmax);
     R* invd = L.take<R>(nmax);
-    (void)L.take<R>(nmax);
+    R* dg = L.take<R>(nmax > NWV ? nmax : NWV);
+    R* rr = L.take<R>(2 * nmax);
     unsigned char* skip = L.take<unsigned char>(nmax);
     int* flag = L.take<int>(1);
     load_vec<R>(x, at<R>(a.x, c, t, 0), d, tid);
@@ -1022,35 +1169,37 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
     const R* Hg = at<R>(a.Hs, c, t, 0);
     const R* cg = at<R>(a.cs, c, t, 0);
     const R* yg = at<R>(a.ys, c, t, 0);
+    gemv_rows<R>(po, d, Hg, d, xp, r1, tid);
+    gemv_rows<R>(po, d, Hg, d, x, r2, tid);
+    int bp = 0, bx = 0;
     for (int k = tid; k < po; k += NT) {
-        R p1 = cg[k], p2 = cg[k];
-        for (int j = 0; j < d; ++j) p1 += Hg[(long long)k * d + j] * xp[j], p2 += Hg[(long long)k * d + j] * x[j];
-        r1[k] = yg[k] - p1;
-        r2[k] = yg[k] - p2;
+        r1[k] = yg[k] - (cg[k] + r1[k]);
+        r2[k] = yg[k] - (cg[k] + r2[k]);
         skip[k] = (a.nan_policy == 1) && !finite_(yg[k]);
+        bp |= (!skip[k] && !finite_(r1[k])) ? 1 : 0;
+        bx |= (!skip[k] && !finite_(r2[k])) ? 1 : 0;
     }
-    __syncthreads();
-    bool badobs_p = false, badobs_x = false;
-    for (int k = 0; k < po; ++k) {
-        badobs_p = badobs_p || (!skip[k] && !finite_(r1[k]));
-        badobs_x = badobs_x || (!skip[k] && !finite_(r2[k]));
-    }
+    const bool badobs_p = __syncthreads_or(bp), badobs_x = __syncthreads_or(bx);
     R ob_p, ob_x, pr_p, pr_x;
-    gauss2<R>(at<R>(a.Rs, c, t, 0), po, a.nan_policy == 1 ? skip : nullptr, r1, r2, Lb, invd, flag, tid, ob_p, ob_x);
+    gauss2<R>(at<R>(a.Rs, c, t, 0), po, a.nan_policy == 1 ? skip : nullptr, r1, r2, Lb, invd, dg, rr, flag, tid, ob_p, ob_x);
     // auxiliary block N(u; x, delta/2 I) and the MH correction (generic.py:103-105)
     const R hd = (R)(0.5 * a.delta), sd = sqrt_(hd);
     R q1 = 0, q2 = 0, corr = 0;
-    bool b1 = false, b2 = false;
-    for (int k = 0; k < d; ++k) {
+    int ib1 = 0, ib2 = 0;
+    for (int k = tid; k < d; k += NT) {
         const R e1 = u[k] - xp[k], e2 = u[k] - x[k];
-        b1 = b1 || !finite_(e1);
-        b2 = b2 || !finite_(e2);
+        ib1 |= finite_(e1) ? 0 : 1;
+        ib2 |= finite_(e2) ? 0 : 1;
         const R z1 = e1 / sd, z2 = e2 / sd;
         q1 += z1 * z1;
         q2 += z2 * z2;
         const R f1 = xp[k] - u[k], f2 = x[k] - u[k];
         corr += (f1 * f1 - f2 * f2) / (R)a.delta;
     }
+    const bool b1 = __syncthreads_or(ib1), b2 = __syncthreads_or(ib2);
+    q1 = block_sum<R>(q1, dg, tid);
+    q2 = block_sum<R>(q2, dg, tid);
+    corr = block_sum<R>(corr, dg, tid);
     const R cst = -(R)d * log_(sd) - (R)(0.5 * LOG_2PI) * (R)d;
     const R ax_p = b1 ? (R)0 : (R)-0.5 * q1 + cst, ax_x = b2 ? (R)0 : (R)-0.5 * q2 + cst;
     const bool ref = a.nan_policy == 0;
@@ -1060,20 +1209,20 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
         const R* m0 = at<R>(a.m0, c, 0, 0);
         for (int k = tid; k < d; k += NT) d1[k] = xp[k] - m0[k], d2[k] = x[k] - m0[k];
         __syncthreads();
-        gauss2<R>(at<R>(a.P0, c, 0, 0), d, nullptr, d1, d2, Lb, invd, flag, tid, pr_p, pr_x);
+        gauss2<R>(at<R>(a.P0, c, 0, 0), d, nullptr, d1, d2, Lb, invd, dg, rr, flag, tid, pr_p, pr_x);
     } else {
         load_vec<R>(xq, at<R>(a.x, c, t - 1, 0), d, tid);
         load_vec<R>(xpq, at<R>(a.xp, c, t - 1, 0), d, tid);
         const R* Fg = at<R>(a.Fs, c, t - 1, 0);
         const R* bg = at<R>(a.bs, c, t - 1, 0);
+        gemv_rows<R>(d, d, Fg, d, xpq, d1, tid);
+        gemv_rows<R>(d, d, Fg, d, xq, d2, tid);
         for (int k = tid; k < d; k += NT) {
-            R m1 = 0, m2 = 0;
-            for (int j = 0; j < d; ++j) m1 += Fg[(long long)k * d + j] * xpq[j], m2 += Fg[(long long)k * d + j] * xq[j];
-            d1[k] = xp[k] - (m1 + bg[k]);
-            d2[k] = x[k] - (m2 + bg[k]);
+            d1[k] = xp[k] - (d1[k] + bg[k]);
+            d2[k] = x[k] - (d2[k] + bg[k]);
         }
         __syncthreads();
-        gauss2<R>(at<R>(a.Qs, c, t - 1, 0), d, nullptr, d1, d2, Lb, invd, flag, tid, pr_p, pr_x);
+        gauss2<R>(at<R>(a.Qs, c, t - 1, 0), d, nullptr, d1, d2, Lb, invd, dg, rr, flag, tid, pr_p, pr_x);
     }
     if (tid == 0) {
         const long long CT = (long long)C * T, o = (long long)c * T + t;

@@ -1,0 +1,50 @@
+// micro-benchmark of wide.hip's cooperative solves on one workgroup (d = 64): cycles per call
+#include "../../aux_ssm_samplers_amd/csrc/wide.hip"
+namespace ax { void set_error(const char*, ...) {} void* ws_take(auxssm_ctx*, size_t) { return nullptr; } }
+using namespace ax::wide;
+template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long* cyc, int d, int iters, int mode) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    Bump L{smem};
+    const int nct = 3 * d + 1, ldz = ldp_(nct);
+    R* Z = L.take<R>(d * ldz);
+    R* rowbuf = L.take<R>(nct + 1);
+    R* pinv = L.take<R>(d);
+    int* iperm = L.take<int>(d);
+    unsigned int* key = L.take<unsigned int>(2);
+    R* invd = L.take<R>(d);
+    R* dg = L.take<R>(d);
+    int* flag = L.take<int>(1);
+    long long tot = 0;
+    for (int it = 0; it < iters; ++it) {
+        for (int r = tid / 64; r < d; r += NWV)
+            for (int c = tid & 63; c < nct; c += 64) Z[r * ldz + c] = (r == c ? (R)(d + 1) : (R)0) + (R)(((r * 131 + c * 71 + it) % 17) - 8) * (R)0.05;
+        if (mode == 1)  // SPD for the Cholesky: make the leading block symmetric
+            for (int r = tid / 64; r < d; r += NWV)
+                for (int c = tid & 63; c < r; c += 64) Z[r * ldz + c] = Z[c * ldz + r];
+        __syncthreads();
+        const long long t0 = clock64();
+        if (mode == 0) lu_solve<R>(Z, ldz, d, nct, rowbuf, pinv, iperm, key, tid);
+        if (mode == 1) (void)chol<R>(Z, ldz, d, nullptr, invd, dg, flag, tid);
+        if (mode == 2) trsm_l<R>(Z, ldz, d, pinv, Z + d, ldz, d + 2, tid);
+        if (mode == 3) gemm<false, false>(d, d, d, Z, ldz, Z + d, ldz, Z + 2 * d, ldz, (R)1, (R)0, tid);
+        tot += clock64() - t0;
+    }
+    if (tid == 0) cyc[0] = tot;
+    out[tid] = Z[(tid % d) * ldz + d + (tid % d)];
+}
+int main() {
+    float* out; long long* cyc;
+    hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 64);
+    const int d = 64, iters = 50;
+    const size_t lds = 120 * 1024;
+    hipFuncSetAttribute((const void*)kb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const char* names[] = {"gj_solve [W|A|C|v]", "chol", "trsm_l (d+2 cols)", "gemm 64^3"};
+    for (int mode = 0; mode < 4; ++mode) {
+        hipLaunchKernelGGL(kb<float>, dim3(1), dim3(NT), lds, 0, out, cyc, d, iters, mode);
+        hipDeviceSynchronize();
+        long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+        printf("%-22s d=%d NT=%d: %.0f cycles/call (%.1f per step)\n", names[mode], d, NT, (double)c / iters, (double)c / iters / d);
+    }
+    return 0;
+}
