@@ -429,6 +429,217 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     return AUXSSM_OK;
 }
 
+// ---- stochastic-volatility device factories (examples/stochastic_volatility/auxiliary_kalman.py:22-48, model.py:56-82) ----------
+// potential log g_t(x) = sum_k log N(y_k; 0, exp(x_k)); grad_k = (y_k^2 e^{-x_k} - 1) / 2, hess_kk = -y_k^2 e^{-x_k} / 2.
+//   first order  (:28-35): ys = u + delta/2 grad(x_lin),                      H = I, R = delta/2 I,  c = 0
+//   second order (:37-46): Om = (-hess + 2/delta I)^-1 (diagonal), ys = Om (2u/delta + grad - hess x_lin), H = I, R = Om, c = 0
+template <typename R> AX_HD R sv_nan_to_num(R v) { return nan_to_num<R>(v); }
+// pass 1 (eps != null): u = x + sqrt(delta/2) eps and the observations linearised at x; pass 2: linearised at xlin, u given
+template <typename R>
+__global__ void k_sv_obs(long long total, int T, int D, int order, const R* __restrict__ xlin, const R* __restrict__ eps, R shd, R delta,
+                         Arr yobs, R* __restrict__ u, R* __restrict__ ys, R* __restrict__ Rs) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= total) return;
+    const int k = (int)(g % D);
+    const long long ct = g / D, t = ct % T;
+    const R x = xlin[g];
+    R uu;
+    if (eps) {
+        uu = x + shd * eps[g];
+        u[g] = uu;
+    } else {
+        uu = u[g];
+    }
+    const R y = at<R>(yobs, 0, t, 0)[k];
+    const R w = y * y * exp_(-x);
+    const R grad = nan_to_num<R>((R)0.5 * (w - (R)1));
+    if (order == 1) {
+        ys[g] = uu + (R)0.5 * delta * grad;
+    } else {
+        const R hess = (R)-0.5 * w;
+        const R om = (R)1 / (-hess + (R)2 / delta);
+        ys[g] = om * ((R)2 * uu / delta + grad - hess * x);
+        R* Rr = Rs + ct * D * D + (long long)k * D;
+        for (int j = 0; j < D; ++j) Rr[j] = j == k ? om : (R)0;
+    }
+}
+template <typename R> __global__ void k_scaled_eye(int D, R v, R* eye) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < D * D) eye[i] = (i / D == i % D) ? v : (R)0;
+}
+template <typename R> __global__ void k_fill(long long n, R v, R* out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = v;
+}
+// per chain (one workgroup): pot(xp), pot(x), la1 = sum_t log N(ys1_t; xp_t, R1_t), la2 = sum_t log N(ys2_t; x_t, R2_t) (R diagonal;
+// a step whose term is NaN is dropped, as the reference's nansum over time steps does), corr (generic.py:103-105).  out [5][C].
+template <typename R>
+__global__ void __launch_bounds__(256) k_sv_terms(int C, int T, int D, R delta, const R* __restrict__ x, const R* __restrict__ xp, const R* __restrict__ u,
+                                                  Arr yobs, const R* __restrict__ ys1, const R* __restrict__ ys2, const R* __restrict__ R1,
+                                                  const R* __restrict__ R2, R* __restrict__ out) {
+    __shared__ R sh[256];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    R acc[5] = {0, 0, 0, 0, 0};
+    for (long long t = tid; t < T; t += 256) {
+        R pp = 0, px = 0, l1 = 0, l2 = 0, cr = 0;
+        for (int k = 0; k < D; ++k) {
+            const long long g = ((long long)c * T + t) * D + k;
+            const R y = at<R>(yobs, 0, t, 0)[k];
+            const R a = xp[g], b = x[g], uu = u[g];
+            pp += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * a - (R)0.5 * y * y * exp_(-a));
+            px += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * b - (R)0.5 * y * y * exp_(-b));
+            const R r1 = R1 ? R1[g * D + k] : (R)0.5 * delta, r2 = R2 ? R2[g * D + k] : (R)0.5 * delta;
+            const R s1 = sqrt_(r1), s2 = sqrt_(r2);
+            const R z1 = (ys1[g] - a) / s1, z2 = (ys2[g] - b) / s2;
+            l1 += (R)-0.5 * z1 * z1 - log_(s1) - (R)(0.5 * LOG_2PI);
+            l2 += (R)-0.5 * z2 * z2 - log_(s2) - (R)(0.5 * LOG_2PI);
+            const R e1 = a - uu, e2 = b - uu;
+            cr += (e1 * e1 - e2 * e2) / delta;
+        }
+        acc[0] += pp;
+        acc[1] += px;
+        acc[2] += isnan_(l1) ? (R)0 : l1;
+        acc[3] += isnan_(l2) ? (R)0 : l2;
+        acc[4] += cr;
+    }
+    for (int q = 0; q < 5; ++q) {
+        sh[tid] = acc[q];
+        __syncthreads();
+        for (int off = 128; off > 0; off >>= 1) {
+            if (tid < off) sh[tid] += sh[tid + off];
+            __syncthreads();
+        }
+        if (tid == 0) out[(long long)q * C + c] = sh[0];
+        __syncthreads();
+    }
+}
+// lt = joint - la + pot (target = prior + potential; joint = auxiliary log-likelihood + prior), then _get_alpha + bernoulli
+template <typename R>
+__global__ void k_sv_accept(int C, const R* j1, const R* j2, const R* ell1, const R* ell2, const R* terms, const R* u_acc, int32_t* accepted, R* logs) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const R pot_p = terms[c], pot_x = terms[C + c], la1 = terms[2 * C + c], la2 = terms[3 * C + c], corr = terms[4 * C + c];
+    const R lp_prop = j1[c] - ell1[c], lp_rev = j2[c] - ell2[c];
+    const R lt_prop = (j1[c] - la1) + pot_p, lt_rev = (j2[c] - la2) + pot_x;
+    R la = lt_prop - lt_rev;
+    la += lp_rev - lp_prop;
+    la -= corr;
+    const R alpha = exp_(min_(la, (R)0));
+    accepted[c] = (u_acc[c] < alpha) ? 1 : 0;
+    if (logs) {
+        logs[c * 5 + 0] = la;
+        logs[c * 5 + 1] = lp_prop;
+        logs[c * 5 + 2] = lp_rev;
+        logs[c * 5 + 3] = lt_prop;
+        logs[c * 5 + 4] = lt_rev;
+    }
+}
+
+// kernel(key, state, delta) of kalman/generic.py:53-76 with the SV factories: both linearisation points (x for the proposal,
+// x_prop for the reverse move) get their own observation set and filter pass, as in the reference.
+template <typename R>
+static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
+                    double delta, int parallel, int nan_policy, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
+                    int32_t* accepted, void* logs) {
+    const int C = dims->C, T = dims->T, D = dims->dx;
+    const bool wide = is_wide(D, D);
+    const KalmanEntry* ke = need_kalman(dtype, D, D);
+    const SampleEntry* se = wide ? wide_sample_entry(dtype) : sample_entry(dtype, D);
+    if (!ke || !se) return AUXSSM_ERR_UNSUPPORTED;
+    const KDims kd{C, T, 1};
+    const size_t sR = sizeof(R), CT = (size_t)C * T;
+    const bool second = order == 2;
+    size_t need = 0;
+    auto add = [&](size_t b) { need += b + 256; };
+    for (int q = 0; q < 4; ++q) add(CT * D * sR);            // u, ys1, ys2, x_prop
+    if (second) add(2 * CT * D * D * sR);                    // Rs1, Rs2
+    add(CT * D * sR);                                        // ms
+    add(CT * D * D * sR);                                    // Ps
+    add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + 4096);
+    add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
+    add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
+    add(wide ? wide_logpdf_ws(dtype, kd) : ke->logpdf_ws(h, kd));
+    int rc = ws_reserve(h, need);
+    if (rc) return rc;
+    R* u = (R*)ws_take(h, CT * D * sR);
+    R* ys1 = (R*)ws_take(h, CT * D * sR);
+    R* ys2 = (R*)ws_take(h, CT * D * sR);
+    R* xp = (R*)ws_take(h, CT * D * sR);
+    R* Rs1 = second ? (R*)ws_take(h, CT * D * D * sR) : nullptr;
+    R* Rs2 = second ? (R*)ws_take(h, CT * D * D * sR) : nullptr;
+    R* ms = (R*)ws_take(h, CT * D * sR);
+    R* Ps = (R*)ws_take(h, CT * D * D * sR);
+    R* eye = (R*)ws_take(h, (size_t)D * D * sR);
+    R* Rc = (R*)ws_take(h, (size_t)D * D * sR);
+    R* zero = (R*)ws_take(h, (size_t)D * sR);
+    R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
+    if (!u || !ys1 || !ys2 || !xp || !ms || !Ps || !eye || !Rc || !zero || !sc) return AUXSSM_ERR_NOMEM;
+    R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
+    const size_t mark = h->ws_off;
+    const long long tot = (long long)CT * D;
+    const unsigned gb = (unsigned)((tot + 255) / 256);
+
+    hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)1, eye);
+    hipLaunchKernelGGL((k_fill<R>), dim3(1), dim3(256), 0, h->stream, (long long)D, (R)0, zero);
+    AX_HIP(hipGetLastError());
+    // observation LGSSMs of the two linearisation points (H = I, c = 0; R = delta/2 I or the per-step diagonal Omega)
+    auxssm_lgssm g1 = *model;
+    g1.Hs = auxssm_arr{eye, 0, 0, 0};
+    g1.cs = auxssm_arr{zero, 0, 0, 0};
+    g1.Rs = second ? auxssm_arr{Rs1, (int64_t)T * D * D, (int64_t)D * D, 0} : auxssm_arr{Rc, 0, 0, 0};
+    auxssm_lgssm g2 = g1;
+    if (second) g2.Rs = auxssm_arr{Rs2, (int64_t)T * D * D, (int64_t)D * D, 0};
+    if (!second) hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)(0.5 * delta), Rc);
+    auxssm_dims dc = *dims;
+    dc.dy = D;
+    dc.B = 1;
+    const auxssm_arr y1d{ys1, (int64_t)T * D, (int64_t)D, 0}, y2d{ys2, (int64_t)T * D, (int64_t)D, 0};
+
+    // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
+    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, T, D, order, (const R*)x, (const R*)eps_aux, (R)sqrt(0.5 * delta),
+                       (R)delta, cv(*yobs), u, ys1, Rs1);
+    FilterArgs fa;
+    fill_filter_args(fa, &dc, &g1, &y1d, ms, Ps);
+    rc = ke->filter(h, fa, parallel, ell1);
+    if (rc) return rc;
+    h->ws_off = mark;
+    SampleArgs sa;
+    sa.d = kd;
+    sa.dx = D;
+    sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
+    sa.ms = dense_arr(ms, kd, D); sa.Ps = dense_arr(Ps, kd, (long long)D * D);
+    sa.eps = dense_arr(eps_samp, kd, D); sa.xs = dense_arr(xp, kd, D); sa.elem = nullptr;
+    sa.lay = ScanLayout{1, 1, 1, 1, 0, C};
+    rc = se->sample(h, sa, parallel);
+    if (rc) return rc;
+    h->ws_off = mark;
+    // reverse move: observations linearised at x_prop, filter for its marginal likelihood (generic.py:67)
+    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, T, D, order, (const R*)xp, (const R*)nullptr, (R)0, (R)delta,
+                       cv(*yobs), u, ys2, Rs2);
+    fill_filter_args(fa, &dc, &g2, &y2d, ms, Ps);
+    rc = ke->filter(h, fa, parallel, ell2);
+    if (rc) return rc;
+    h->ws_off = mark;
+    // joint log-densities of both auxiliary models (posterior_logpdf + ell, base.py:72-96)
+    LogpdfArgs la;
+    fill_logpdf_args(la, &dc, &g1, cv(y1d), dense_arr(xp, kd, D), nan_policy);
+    rc = ke->logpdf(h, la, j1);
+    if (rc) return rc;
+    h->ws_off = mark;
+    fill_logpdf_args(la, &dc, &g2, cv(y2d), dense_arr(x, kd, D), nan_policy);
+    rc = ke->logpdf(h, la, j2);
+    if (rc) return rc;
+    h->ws_off = mark;
+    hipLaunchKernelGGL((k_sv_terms<R>), dim3(C), dim3(256), 0, h->stream, C, T, D, (R)delta, (const R*)x, (const R*)xp, (const R*)u, cv(*yobs),
+                       (const R*)ys1, (const R*)ys2, (const R*)Rs1, (const R*)Rs2, terms);
+    hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
+                       (const R*)ell2, (const R*)terms, (const R*)u_acc, accepted, (R*)logs);
+    hipLaunchKernelGGL((k_select<R>), dim3(gb), dim3(256), 0, h->stream, C, T, D, (const int32_t*)accepted, dense_arr(xp, kd, D),
+                       dense_arr(x, kd, D), 0);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
 // ---- RNG fill -----------------------------------------------------------------------------------------------------
 // one Threefry block -> out[2 i], out[2 i + 1] (both fills)
 template <typename R> __global__ void k_rng_uniform(uint32_t k0, uint32_t k1, uint32_t stream, long long n, R* out) {
@@ -687,10 +898,23 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
                         const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
     AX_NEED_H(h);
     int rc;
-    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true)) || (rc = check_lgssm(model, dims->T))) return rc;
-    if (model_kind != AUXSSM_KMODEL_LG_CONCAT) {
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true))) return rc;
+    const bool sv = model_kind == AUXSSM_KMODEL_SV_FIRST || model_kind == AUXSSM_KMODEL_SV_SECOND;
+    if (model_kind != AUXSSM_KMODEL_LG_CONCAT && !sv) {
         set_error("unknown model_kind %d", model_kind);
         return AUXSSM_ERR_ARG;
+    }
+    if (sv) {
+        if (!model || !model->m0.ptr || !model->P0.ptr || (dims->T > 1 && (!model->Fs.ptr || !model->Qs.ptr || !model->bs.ptr))) {
+            set_error("model needs m0, P0 (and Fs, Qs, bs with T > 1)");
+            return AUXSSM_ERR_ARG;
+        }
+        if (dims->dy != dims->dx) {
+            set_error("stochastic-volatility models observe every state component: dy (%d) must equal dx (%d)", dims->dy, dims->dx);
+            return AUXSSM_ERR_ARG;
+        }
+    } else if ((rc = check_lgssm(model, dims->T))) {
+        return rc;
     }
     if (dims->B != 1) {
         set_error("auxssm_kalman_sweep needs B == 1");
@@ -707,6 +931,16 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
     if (!yobs || !yobs->ptr || !x || !eps_aux || !eps_samp || !u_acc || !accepted) {
         set_error("yobs/x/eps_aux/eps_samp/u_acc/accepted must be non-NULL");
         return AUXSSM_ERR_ARG;
+    }
+    if (sv) {
+        if (layout != AUXSSM_LAYOUT_DENSE) {
+            set_error("the stochastic-volatility sweeps take the dense (C, T, dx) layout");
+            return AUXSSM_ERR_UNSUPPORTED;
+        }
+        const int order = model_kind == AUXSSM_KMODEL_SV_FIRST ? 1 : 2;
+        if (dtype == AUXSSM_F32)
+            return sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        return sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
     if (dtype == AUXSSM_F32)
         return sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);

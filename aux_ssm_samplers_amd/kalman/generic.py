@@ -40,8 +40,8 @@ def get_kernel(dynamics_factory, observations_factory, log_likelihood_fn, parall
 def _same_device_model(*fns):
     owners = [getattr(f, "__self__", None) for f in fns]
     names = [getattr(f, "__name__", "") for f in fns]
-    from .models import LGConcatModel
-    if (isinstance(owners[0], LGConcatModel) and all(o is owners[0] for o in owners)
+    from .models import LGConcatModel, SVModel
+    if (isinstance(owners[0], (LGConcatModel, SVModel)) and all(o is owners[0] for o in owners)
             and names == ["dynamics_factory", "observations_factory", "log_likelihood_fn"]):
         return owners[0]
     return None
@@ -143,7 +143,7 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         dl, ybuf, yarr = model.device(handle, chains.dtype)
         dims = _lib.Dims(chains.C, chains.T, 1, chains.dx, model.p_obs)
         _lib.check(handle.lib.auxssm_kalman_sweep(
-            handle.h, _lib.dtype_code(chains.dtype), _lib.KMODEL_LG_CONCAT, C.byref(dims), C.byref(dl.c), C.byref(yarr),
+            handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
             float(delta), int(bool(parallel)), pol, chains.layout, chains.x.ptr, eps_aux.ptr, eps_samp.ptr, u_acc.ptr,
             chains.accepted.ptr, chains.logs.ptr))
 
@@ -158,7 +158,7 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         """state.x: ndarray (T, dx) [one chain], ndarray (C, T, dx) or DeviceChains (resident, updated in place)."""
         resident = isinstance(state.x, DeviceChains)
         handle = state.x.handle if resident else _lib.default_handle()  # resident chains carry their device
-        chains = state.x if resident else DeviceChains(handle, state.x)
+        chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None)
         if noise is None:
             eps_aux, eps_samp, u_acc = draw(handle, key, chains)
         else:

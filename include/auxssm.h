@@ -143,7 +143,16 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
  *         chain-shared model parameters are wave-uniform loads; there is no transposition anywhere in the sweep.  This is the
  *         layout to use with >= 32 chains (bench.py); results are identical up to the combination tree of the scan.
  */
-typedef enum { AUXSSM_KMODEL_LG_CONCAT = 1 } auxssm_kalman_model;
+typedef enum {
+    AUXSSM_KMODEL_LG_CONCAT = 1,
+    /* Stochastic volatility y_{t,k} ~ N(0, exp(x_{t,k})) on linear-Gaussian dynamics (`model`: m0, P0, Fs, Qs, bs; Hs/Rs/cs unused),
+     * examples/stochastic_volatility/auxiliary_kalman.py:22-48: observations_factory(x, u, d) is the first-order
+     * (ys = u + d/2 grad log g(x), R = d/2 I) or second-order (R = (-hess + 2/d I)^-1, ys = R (2u/d + grad - hess x)) auxiliary
+     * observation set with H = I, c = 0, rebuilt at both linearisation points (x and x_prop) each sweep;
+     * log_likelihood_fn(x) = prior_logpdf(x) + sum log g.  yobs (T, dx), dims->dy = dx, dense layout. */
+    AUXSSM_KMODEL_SV_FIRST = 2,
+    AUXSSM_KMODEL_SV_SECOND = 3
+} auxssm_kalman_model;
 typedef enum { AUXSSM_LAYOUT_DENSE = 0, AUXSSM_LAYOUT_CHAIN_MINOR = 1 } auxssm_layout;
 int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims,
                         const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, int parallel,
