@@ -2,8 +2,9 @@ from .generic import get_kernel as get_generic_kernel
 from .independent import get_kernel as get_independent_kernel
 from .generic import get_kernel
 from .._primitives.csmc.base import Distribution, UnivariatePotential, Dynamics, Potential, CSMCState
-from .models import GaussianInit, LinearGaussianDynamics, FlatPotential, GaussianObsPotential, SVPotential
+from .models import (GaussianInit, LinearGaussianDynamics, FlatPotential, GaussianObsPotential, SVPotential, Lorenz63Dynamics,
+                     MaskedGaussianObsPotential)
 
 __all__ = ["get_kernel", "get_generic_kernel", "get_independent_kernel", "Distribution", "UnivariatePotential", "Dynamics",
            "Potential", "CSMCState", "GaussianInit", "LinearGaussianDynamics", "FlatPotential", "GaussianObsPotential",
-           "SVPotential"]
+           "SVPotential", "Lorenz63Dynamics", "MaskedGaussianObsPotential"]

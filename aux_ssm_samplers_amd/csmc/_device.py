@@ -4,16 +4,17 @@ import ctypes as C
 import numpy as np
 
 from .. import _lib, random as _random
-from .models import GaussianInit, LinearGaussianDynamics, FlatPotential, GaussianObsPotential, SVPotential
+from .models import (GaussianInit, LinearGaussianDynamics, FlatPotential, GaussianObsPotential, SVPotential, Lorenz63Dynamics,
+                     MaskedGaussianObsPotential)
 
 _UNSUPPORTED = ("{what} is a Python object the HIP kernels cannot evaluate. The cSMC kernels run the closed model family "
-                "of aux_ssm_samplers_amd.csmc.models (GaussianInit, LinearGaussianDynamics, FlatPotential, "
-                "GaussianObsPotential, SVPotential) in-kernel; there is no CPU fallback.")
+                "of aux_ssm_samplers_amd.csmc.models (GaussianInit, LinearGaussianDynamics, Lorenz63Dynamics, FlatPotential, "
+                "GaussianObsPotential, MaskedGaussianObsPotential, SVPotential) in-kernel; there is no CPU fallback.")
 
 
 class FkDesc:
-    def __init__(self, proposal, potential, m0, chol_P0, F, b, chol_Q, y, sig_y):
-        self.proposal, self.potential, self.sig_y = proposal, potential, float(sig_y)
+    def __init__(self, proposal, potential, m0, chol_P0, F, b, chol_Q, y, sig_y, transition=_lib.TRANS_LINEAR):
+        self.proposal, self.potential, self.sig_y, self.transition = proposal, potential, float(sig_y), int(transition)
         self.m0 = np.ascontiguousarray(m0, np.float64).reshape(-1)
         self.dx = self.m0.shape[0]
         d = self.dx
@@ -38,6 +39,13 @@ def _potential(G0, Gt, d):
         raise NotImplementedError(_UNSUPPORTED.format(what=f"G0={type(G0).__name__} with Gt={type(Gt).__name__}"))
     if isinstance(Gt, FlatPotential):
         return _lib.POT_FLAT, None, 1.0
+    if isinstance(Gt, MaskedGaussianObsPotential):
+        if G0.y is None or Gt.params is None:
+            raise ValueError("the potential needs y (G0.y = ys[0]) and params (Gt.params = ys[1:])")
+        y = np.concatenate([np.reshape(G0.y, (1, d)), np.reshape(Gt.params, (-1, d))], axis=0)
+        if abs(G0.sig - Gt.sig) > 1e-12 * Gt.sig:
+            raise NotImplementedError("G0 and Gt must share the observation noise scale")
+        return _lib.POT_GAUSS_OBS_MASKED, y, Gt.sig
     if isinstance(Gt, (GaussianObsPotential, SVPotential)):
         y0 = G0.m0 if isinstance(G0, GaussianInit) else G0.y
         if y0 is None or Gt.params is None:
@@ -57,20 +65,30 @@ def _potential(G0, Gt, d):
 def _dyn(M0, Mt):
     if not isinstance(M0, GaussianInit):
         raise NotImplementedError(_UNSUPPORTED.format(what=f"M0={type(M0).__name__}"))
-    if not isinstance(Mt, LinearGaussianDynamics):
+    if not isinstance(Mt, (LinearGaussianDynamics, Lorenz63Dynamics)):
         raise NotImplementedError(_UNSUPPORTED.format(what=f"Mt={type(Mt).__name__}"))
     return M0, Mt
+
+
+def _trans(Mt):
+    """(transition kind, F, b) as the C ABI wants them (include/auxssm.h, auxssm_fk_transition)"""
+    if isinstance(Mt, Lorenz63Dynamics):
+        F = np.zeros((3, 3))
+        F[0] = np.asarray(Mt.theta, np.float64).reshape(3)
+        return _lib.TRANS_LORENZ63_EM, F, np.array([float(Mt.dt), 0.0, 0.0])
+    return _lib.TRANS_LINEAR, Mt.F, Mt.b
 
 
 def describe_bootstrap(M0, G0, Mt, Gt, Pt):
     """_primitives.csmc.get_kernel: M0/Mt are the proposals, G0/Gt the potentials."""
     M0, Mt = _dyn(M0, Mt)
-    if Pt is not None and Pt is not Mt and not (isinstance(Pt, LinearGaussianDynamics) and np.array_equal(Pt.F, Mt.F)
-                                                   and np.array_equal(Pt.Q, Mt.Q) and np.array_equal(Pt.b, Mt.b)):
+    if Pt is not None and Pt is not Mt and not (isinstance(Pt, LinearGaussianDynamics) and isinstance(Mt, LinearGaussianDynamics)
+                                                   and np.array_equal(Pt.F, Mt.F) and np.array_equal(Pt.Q, Mt.Q) and np.array_equal(Pt.b, Mt.b)):
         raise NotImplementedError("backward sampling with Pt != Mt is not supported by the bootstrap device kernel")
     d = np.size(M0.m0)
     pot, y, sig = _potential(G0, Gt, d)
-    return FkDesc(_lib.PROP_BOOTSTRAP_LG, pot, M0.m0, M0.chol(), Mt.F, Mt.b, Mt.chol(), y, sig)
+    tk, F, b = _trans(Mt)
+    return FkDesc(_lib.PROP_BOOTSTRAP_LG, pot, M0.m0, M0.chol(), F, b, Mt.chol(), y, sig, tk)
 
 
 def describe_independent(M0, G0, Mt, Gt, Pt):
@@ -80,7 +98,8 @@ def describe_independent(M0, G0, Mt, Gt, Pt):
         raise NotImplementedError("Pt must be the model dynamics Mt")
     d = np.size(M0.m0)
     pot, y, sig = _potential(G0, Gt, d)
-    return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), Mt.F, Mt.b, Mt.chol(), y, sig)
+    tk, F, b = _trans(Mt)
+    return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), F, b, Mt.chol(), y, sig, tk)
 
 
 def key_noise(handle, key, Cn, T, N, d, dtype):
@@ -108,7 +127,7 @@ def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, 
     dtype = np.dtype(np.float32) if xc.dtype == np.float32 else np.dtype(np.float64)
     xd = handle.to_device(xc, dtype)
     anc = handle.zeros((Cn, T), np.int32)
-    m = _lib.FkModel(fk.proposal, fk.potential, d, 0, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
+    m = _lib.FkModel(fk.proposal, fk.potential, d, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
                      fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
     yd = fk.ydev(handle, dtype)
     if yd is not None:

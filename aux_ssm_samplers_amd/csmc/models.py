@@ -54,3 +54,34 @@ class SVPotential(UnivariatePotential, Potential):
     As G0 give y = ys[0]; as Gt give params = ys[1:]."""
     y: Optional[Any] = None
     params: Optional[Any] = None
+
+
+@dataclass
+class Lorenz63Dynamics(Dynamics, Potential):
+    """Euler-Maruyama step of the stochastic Lorenz-63 system, examples/lorenz/model.py:10-25:
+    x_{t+1} | x_t ~ N(x_t + dt (phi_0(x_t) + theta * phi(x_t)), dt sigma_x^2 I),
+    phi_0 = (0, -x2 - x1 x3, x1 x2), phi = (x2 - x1, x1, -x3), theta = (sigma, rho, beta)."""
+    theta: Any
+    sigma_x: float
+    dt: float
+    params: Optional[Any] = None
+
+    def chol(self):
+        return float(self.sigma_x) * np.sqrt(float(self.dt)) * np.eye(3)
+
+    def mean(self, x):
+        x = np.asarray(x)
+        th = np.asarray(self.theta, np.float64)
+        x1, x2, x3 = x[..., 0], x[..., 1], x[..., 2]
+        f = np.stack([th[0] * (x2 - x1), th[1] * x1 - x2 - x1 * x3, x1 * x2 - th[2] * x3], axis=-1)
+        return x + self.dt * f
+
+
+@dataclass
+class MaskedGaussianObsPotential(UnivariatePotential, Potential):
+    """sum over the FINITE components of y_t of log N(y_{t,k}; x_{t,k}, sig^2): state components observed directly, missing
+    components / whole missing steps carry NaN (examples/lorenz/model.py:43-56 observes x2, x3 every 80th step).
+    As G0 give y = ys[0]; as Gt give params = ys[1:]."""
+    sig: float = 1.0
+    y: Optional[Any] = None
+    params: Optional[Any] = None

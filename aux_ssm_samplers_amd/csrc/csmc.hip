@@ -24,7 +24,7 @@ namespace ax {
 constexpr int CS_MAXD = 4;
 
 template <typename R> struct FkDev {
-    int proposal, potential, D, pad;
+    int proposal, potential, D, transition;  // transition: 0 = linear-Gaussian (F, b); 1 = Lorenz-63 Euler-Maruyama (theta = F[0][0..2], dt = b[0])
     R m0[CS_MAXD], LP0[CS_MAXD * CS_MAXD], F[CS_MAXD * CS_MAXD], b[CS_MAXD], LQ[CS_MAXD * CS_MAXD];
     R c_init, c_trans, c_obs, inv_sig_y;  // additive constants: -sum log L_kk - D/2 log 2pi, etc.
 };
@@ -77,6 +77,18 @@ template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mea
     return fma_((R)-0.5, q, cst);
 }
 template <typename R, int D> AXD_HD void trans_mean(const FkDev<R>& m, const R* xp, R* mu) {
+    if constexpr (D == 3) {
+        if (m.transition == 1) {  // x + dt (phi_0(x) + theta * phi(x)), examples/lorenz/model.py:10-25; fixed operation order
+            const R th1 = m.F[0], th2 = m.F[1], th3 = m.F[2], dt = m.b[0];
+            const R f1 = th1 * (xp[1] - xp[0]);
+            const R f2 = fma_(-xp[0], xp[2], fma_(th2, xp[0], -xp[1]));
+            const R f3 = fma_(xp[0], xp[1], -(th3 * xp[2]));
+            mu[0] = fma_(dt, f1, xp[0]);
+            mu[1] = fma_(dt, f2, xp[1]);
+            mu[2] = fma_(dt, f3, xp[2]);
+            return;
+        }
+    }
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         R acc = m.b[k];
@@ -96,6 +108,19 @@ template <typename R, int D> AXD_HD R potential(const FkDev<R>& m, const R* x, c
             q = fma_(z, z, q);
         }
         return fma_((R)-0.5, q, m.c_obs);
+    }
+    if (m.potential == 3) {  // y_k ~ N(x_k, sig_y^2) for the finite y_k only (missing components / whole missing steps are skipped)
+        R q = 0;
+        int nobs = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            if (y[k] - y[k] == 0) {
+                const R z = (y[k] - x[k]) * m.inv_sig_y;
+                q = fma_(z, z, q);
+                ++nobs;
+            }
+        }
+        return fma_((R)-0.5, q, (R)nobs * m.c_obs);
     }
     // stochastic volatility: y_k ~ N(0, exp(x_k)):  -0.5 (y^2 e^{-x} + x) - 0.5 log 2pi, NaN terms -> 0
     R acc = 0;
@@ -324,11 +349,11 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
         // propagate (csmc.py:91-92)
         if (m.proposal == 0) {
+            R mu[D];
+            trans_mean<R, D>(m, xp, mu);
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                R acc = m.b[k];
-#pragma unroll
-                for (int j = 0; j < D; ++j) acc = fma_(m.F[k * CS_MAXD + j], xp[j], acc);
+                R acc = mu[k];
 #pragma unroll
                 for (int j = 0; j <= k; ++j) acc = fma_(m.LQ[k * CS_MAXD + j], eps[j], acc);
                 x[k] = acc;
@@ -479,6 +504,7 @@ template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model*
     m.proposal = fk->proposal;
     m.potential = fk->potential;
     m.D = D;
+    m.transition = fk->transition;
     const double* p = host;
     for (int k = 0; k < D; ++k) m.m0[k] = (R)p[k];
     p += D;
@@ -504,6 +530,9 @@ template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model*
     if (fk->potential == 1) {
         m.inv_sig_y = (R)1 / (R)fk->sig_y;
         m.c_obs = -(R)D * det_log((R)fk->sig_y) - (R)D * half_log_2pi;
+    } else if (fk->potential == 3) {  // per observed component
+        m.inv_sig_y = (R)1 / (R)fk->sig_y;
+        m.c_obs = -det_log((R)fk->sig_y) - half_log_2pi;
     } else {
         m.inv_sig_y = 0;
         m.c_obs = -half_log_2pi;
@@ -600,7 +629,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         set_error("unknown proposal kind %d", fk->proposal);
         return AUXSSM_ERR_ARG;
     }
-    if (fk->potential < AUXSSM_POT_FLAT || fk->potential > AUXSSM_POT_SV) {
+    if (fk->potential < AUXSSM_POT_FLAT || fk->potential > AUXSSM_POT_GAUSS_OBS_MASKED) {
         set_error("unknown potential kind %d", fk->potential);
         return AUXSSM_ERR_ARG;
     }

@@ -95,7 +95,7 @@ def run_csmc(args, rank, world, local_rank, dist, torch, coll_dev):
     anc = handle.zeros((Cn, T), np.int32)
     yd = fk.ydev(handle, dtype)
     shd = handle.to_device(np.full(T, np.sqrt(0.25)), dtype)
-    m = _lib.FkModel(fk.proposal, fk.potential, 1, 0, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
+    m = _lib.FkModel(fk.proposal, fk.potential, 1, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
                      fk.b.ctypes.data, fk.chol_Q.ctypes.data, yd.ptr.value, 1.0)
     keys = R.split(R.PRNGKey(77 + rank), args.steps + args.warmup + 1)
 

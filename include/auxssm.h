@@ -187,10 +187,19 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
  * (NULL -> kept in the handle's workspace).  N <= 1024.  Arithmetic uses the fixed reduction orders and the
  * bit-reproducible exp/log documented in csrc/csmc.hip, so ancestors are bit-exact against oracle/csmc_ref.c. */
 typedef enum { AUXSSM_PROP_BOOTSTRAP_LG = 0, AUXSSM_PROP_AUX_INDEPENDENT = 1 } auxssm_fk_proposal;
-typedef enum { AUXSSM_POT_FLAT = 0, AUXSSM_POT_GAUSS_OBS = 1, AUXSSM_POT_SV = 2 } auxssm_fk_potential;
+typedef enum {
+    AUXSSM_POT_FLAT = 0,
+    AUXSSM_POT_GAUSS_OBS = 1,        /* y_t ~ N(x_t, sig_y^2 I) */
+    AUXSSM_POT_SV = 2,               /* y_{t,k} ~ N(0, exp(x_{t,k})) */
+    AUXSSM_POT_GAUSS_OBS_MASKED = 3  /* y_{t,k} ~ N(x_{t,k}, sig_y^2) for the finite y_{t,k} only: missing components / steps skipped
+                                        (examples/lorenz/model.py:43-56: x2, x3 observed every 80th step) */
+} auxssm_fk_potential;
+/* transition x_{t+1} | x_t ~ N(mean(x_t), Q): LINEAR mean = F x + b; LORENZ63_EM mean = x + dt (phi_0(x) + theta * phi(x)), the
+ * Euler-Maruyama step of examples/lorenz/model.py:10-25 (dx = 3; theta = F[0..2], dt = b[0], Q = chol_Q chol_Q^T = dt sigma_x^2 I) */
+typedef enum { AUXSSM_TRANS_LINEAR = 0, AUXSSM_TRANS_LORENZ63_EM = 1 } auxssm_fk_transition;
 typedef enum { AUXSSM_NOISE_EXPLICIT = 0, AUXSSM_NOISE_THREEFRY = 1 } auxssm_noise_mode;
 typedef struct {
-    int32_t proposal, potential, dx, reserved;
+    int32_t proposal, potential, dx, transition;
     const double* m0;      /* host (dx) */
     const double* chol_P0; /* host (dx,dx) lower */
     const double* F;       /* host (dx,dx) */

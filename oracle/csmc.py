@@ -11,13 +11,14 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _SO = os.path.join(_HERE, "_build", "libcsmc_ref.so")
 
 BOOTSTRAP_LG, AUX_INDEPENDENT = 0, 1
-POT_FLAT, POT_GAUSS_OBS, POT_SV = 0, 1, 2
+POT_FLAT, POT_GAUSS_OBS, POT_SV, POT_GAUSS_OBS_MASKED = 0, 1, 2, 3
+TRANS_LINEAR, TRANS_LORENZ63_EM = 0, 1
 
 
 class _Model(C.Structure):
     _fields_ = [("proposal", C.c_int), ("potential", C.c_int), ("D", C.c_int), ("backward", C.c_int),
                 ("m0", C.c_void_p), ("LP0", C.c_void_p), ("F", C.c_void_p), ("b", C.c_void_p), ("LQ", C.c_void_p),
-                ("sig_y", C.c_double)]
+                ("sig_y", C.c_double), ("transition", C.c_int)]
 
 
 _lib = None
@@ -46,14 +47,14 @@ def _p(a):
 
 
 def sweep(model, x, N, backward, *, y=None, sqrt_half_delta=None, eps_aux=None, eps_prop, u_res, u_bwd, dtype=np.float32):
-    """One cSMC sweep of one chain.  model: dict(proposal, potential, m0, chol_P0, F, b, chol_Q, sig_y).
+    """One cSMC sweep of one chain.  model: dict(proposal, potential, m0, chol_P0, F, b, chol_Q, sig_y[, transition]).
     Returns dict(x, ancestors, xs, log_ws, As)."""
     dtype = np.dtype(dtype)
     x = np.array(x, dtype, order="C")
     T, D = x.shape
     keep = [np.ascontiguousarray(np.asarray(model[k], np.float64)) for k in ("m0", "chol_P0", "F", "b", "chol_Q")]
     m = _Model(int(model["proposal"]), int(model["potential"]), D, int(bool(backward)), _p(keep[0]), _p(keep[1]), _p(keep[2]),
-               _p(keep[3]), _p(keep[4]), float(model.get("sig_y", 1.0)))
+               _p(keep[3]), _p(keep[4]), float(model.get("sig_y", 1.0)), int(model.get("transition", 0)))
     cv = lambda a: None if a is None else np.ascontiguousarray(a, dtype)
     y, shd, eps_aux, eps_prop, u_res, u_bwd = map(cv, (y, sqrt_half_delta, eps_aux, eps_prop, u_res, u_bwd))
     assert eps_prop.shape == (T, N, D) and u_bwd.shape == (T,) and (T == 1 or u_res.shape == (T - 1, N))

@@ -141,6 +141,7 @@ typedef struct {
     int proposal, potential, D, backward;
     const double *m0, *LP0, *F, *b, *LQ; /* (D), (D,D) lower, (D,D), (D), (D,D) lower */
     double sig_y;
+    int transition; /* 0 linear (F, b); 1 Lorenz-63 Euler-Maruyama: theta = F[0..2], dt = b[0] (examples/lorenz/model.py:10-25) */
 } fk_model;
 
 #define CSMC_REF_BODY
@@ -165,7 +166,7 @@ typedef struct {
 #else /* CSMC_REF_BODY: the generic part, compiled once per real type */
 
 typedef struct {
-    int proposal, potential, D;
+    int proposal, potential, D, transition;
     REAL m0[MAXD], LP0[MAXD * MAXD], F[MAXD * MAXD], b[MAXD], LQ[MAXD * MAXD];
     REAL c_init, c_trans, c_obs, inv_sig_y;
 } SUF(fk);
@@ -173,7 +174,7 @@ typedef struct {
 static void SUF(fk_fill)(SUF(fk) * m, const fk_model* g) {
     const int D = g->D;
     memset(m, 0, sizeof(*m));
-    m->proposal = g->proposal; m->potential = g->potential; m->D = D;
+    m->proposal = g->proposal; m->potential = g->potential; m->D = D; m->transition = g->transition;
     for (int k = 0; k < D; ++k) { m->m0[k] = (REAL)g->m0[k]; m->b[k] = (REAL)g->b[k]; }
     for (int i = 0; i < D; ++i)
         for (int j = 0; j < D; ++j) {
@@ -189,6 +190,9 @@ static void SUF(fk_fill)(SUF(fk) * m, const fk_model* g) {
     if (g->potential == 1) {
         m->inv_sig_y = (REAL)1 / (REAL)g->sig_y;
         m->c_obs = -(REAL)D * LOG((REAL)g->sig_y) - (REAL)D * hl2pi;
+    } else if (g->potential == 3) { /* masked Gaussian observations: constant per observed component */
+        m->inv_sig_y = (REAL)1 / (REAL)g->sig_y;
+        m->c_obs = -LOG((REAL)g->sig_y) - hl2pi;
     } else {
         m->inv_sig_y = 0;
         m->c_obs = -hl2pi;
@@ -207,6 +211,16 @@ static REAL SUF(gauss)(int D, const REAL* x, const REAL* mean, const REAL* L, RE
     return FMA((REAL)-0.5, q, cst);
 }
 static void SUF(tmean)(const SUF(fk) * m, const REAL* xp, REAL* mu) {
+    if (m->transition == 1) { /* x + dt (phi_0(x) + theta * phi(x)), examples/lorenz/model.py:10-25; fixed operation order */
+        const REAL th1 = m->F[0], th2 = m->F[1], th3 = m->F[2], dt = m->b[0];
+        const REAL f1 = th1 * (xp[1] - xp[0]);
+        const REAL f2 = FMA(-xp[0], xp[2], FMA(th2, xp[0], -xp[1]));
+        const REAL f3 = FMA(xp[0], xp[1], -(th3 * xp[2]));
+        mu[0] = FMA(dt, f1, xp[0]);
+        mu[1] = FMA(dt, f2, xp[1]);
+        mu[2] = FMA(dt, f3, xp[2]);
+        return;
+    }
     for (int k = 0; k < m->D; ++k) {
         REAL acc = m->b[k];
         for (int j = 0; j < m->D; ++j) acc = FMA(m->F[k * MAXD + j], xp[j], acc);
@@ -220,6 +234,13 @@ static REAL SUF(pot)(const SUF(fk) * m, const REAL* x, const REAL* y) {
         REAL q = 0;
         for (int k = 0; k < D; ++k) { const REAL z = (y[k] - x[k]) * m->inv_sig_y; q = FMA(z, z, q); }
         return FMA((REAL)-0.5, q, m->c_obs);
+    }
+    if (m->potential == 3) { /* y_k ~ N(x_k, sig_y^2) for the finite y_k only */
+        REAL q = 0;
+        int nobs = 0;
+        for (int k = 0; k < D; ++k)
+            if (y[k] - y[k] == 0) { const REAL z = (y[k] - x[k]) * m->inv_sig_y; q = FMA(z, z, q); ++nobs; }
+        return FMA((REAL)-0.5, q, (REAL)nobs * m->c_obs);
     }
     REAL acc = 0;
     for (int k = 0; k < D; ++k) {
@@ -332,9 +353,10 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             const REAL* e = eps_prop + ((size_t)t * N + i) * D;
             REAL* xi = xcur + (size_t)i * D;
             if (m.proposal == 0) {
+                REAL mu0[MAXD];
+                SUF(tmean)(&m, xp, mu0);
                 for (int k = 0; k < D; ++k) {
-                    REAL acc = m.b[k];
-                    for (int j = 0; j < D; ++j) acc = FMA(m.F[k * MAXD + j], xp[j], acc);
+                    REAL acc = mu0[k];
                     for (int j = 0; j <= k; ++j) acc = FMA(m.LQ[k * MAXD + j], e[j], acc);
                     xi[k] = acc;
                 }

@@ -92,9 +92,9 @@ def test_argument_errors_are_value_errors():
     import aux_ssm_samplers_amd._primitives.kalman as P
     from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics, FlatPotential
     rng = np.random.default_rng(0)
-    lg5 = _rand_lgssm(rng, 4, 5, 2)  # dx = 5 is not instantiated
-    with pytest.raises(ValueError):
-        P.filtering(rng.standard_normal((4, 2)), P.LGSSM(*lg5), True)
+    lg80 = _rand_lgssm(rng, 3, 80, 2)  # fp64 dx = 80 exceeds the LDS plan of the wide-state path: loud error, no fallback
+    with pytest.raises(ValueError, match="LDS"):
+        P.filtering(rng.standard_normal((3, 2)), P.LGSSM(*lg80), True)
     lg = _rand_lgssm(rng, 4, 2, 2)
     with pytest.raises(ValueError):
         P.filtering(rng.standard_normal((5, 2)), P.LGSSM(*lg), True)  # T mismatch

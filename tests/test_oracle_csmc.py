@@ -96,3 +96,38 @@ def test_sweep_invariants(proposal, backward):
     if not backward:  # ancestor tracing: B_{t-1} = A_t[B_t]
         for t in range(T - 1, 0, -1):
             assert r["ancestors"][t - 1] == r["As"][t - 1, r["ancestors"][t]]
+
+
+def test_lorenz63_transition_and_masked_potential_in_the_oracle():
+    """The Lorenz-63 Euler-Maruyama mean (examples/lorenz/model.py:10-25) and the masked Gaussian potential of the C oracle against
+    direct NumPy formulas: one bootstrap step with N = 1 degenerate noise reproduces mean(x) + chol_Q eps; log-weights equal the
+    sum over finite y components of log N(y; x, sig^2)."""
+    from oracle import csmc as O
+    theta, dt, sx, sig = np.array([10.0, 28.0, 8.0 / 3.0]), 0.01, 3.0, 1.3
+    rng = np.random.default_rng(0)
+    T, N = 6, 16
+    F = np.zeros((3, 3))
+    F[0] = theta
+    od = dict(proposal=O.BOOTSTRAP_LG, potential=O.POT_GAUSS_OBS_MASKED, m0=[1.5, -1.5, 25.0], chol_P0=np.diag([20.0, 4.0, 4.0]), F=F,
+              b=[dt, 0, 0], chol_Q=sx * np.sqrt(dt) * np.eye(3), sig_y=sig, transition=O.TRANS_LORENZ63_EM)
+    y = np.full((T, 3), np.nan)
+    y[::2, 1:] = rng.standard_normal((3, 2)) + [[-1.5, 25.0]]
+    y[4, 1] = np.nan  # partially missing step
+    eps = rng.standard_normal((T, N, 3))
+    x0 = np.repeat(np.array([[1.5, -1.5, 25.0]]), T, axis=0)
+    out = O.sweep(od, x0, N, False, y=y, eps_prop=eps, u_res=rng.random((T - 1, N)), u_bwd=rng.random(T), dtype=np.float64)
+    xs, As, lws = out["xs"], out["As"], out["log_ws"]
+
+    def mean(x):
+        x1, x2, x3 = x[..., 0], x[..., 1], x[..., 2]
+        return x + dt * np.stack([theta[0] * (x2 - x1), theta[1] * x1 - x2 - x1 * x3, x1 * x2 - theta[2] * x3], axis=-1)
+
+    for t in range(1, T):
+        par = xs[t - 1][As[t - 1]]
+        want = mean(par) + sx * np.sqrt(dt) * eps[t]
+        want[0] = x0[t]
+        npt.assert_allclose(xs[t], want, rtol=1e-13, atol=1e-13)
+    for t in range(T):
+        obs = np.isfinite(y[t])
+        want = np.sum(-0.5 * ((y[t][obs] - xs[t][:, obs]) / sig) ** 2 - np.log(sig) - 0.5 * np.log(2 * np.pi), axis=1)
+        npt.assert_allclose(lws[t], want, rtol=1e-12, atol=1e-12)
