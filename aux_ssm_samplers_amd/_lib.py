@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libauxssm.so")
 
 F32, F64 = 0, 1
 NAN_REFERENCE, NAN_MASKED = 0, 1
-KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND = 1, 2, 3
+KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND, KMODEL_LORENZ63_EXT = 1, 2, 3, 4
 LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
  K_CSMC_BWD) = range(9)

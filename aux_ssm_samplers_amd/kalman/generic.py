@@ -40,8 +40,8 @@ def get_kernel(dynamics_factory, observations_factory, log_likelihood_fn, parall
 def _same_device_model(*fns):
     owners = [getattr(f, "__self__", None) for f in fns]
     names = [getattr(f, "__name__", "") for f in fns]
-    from .models import LGConcatModel, SVModel
-    if (isinstance(owners[0], (LGConcatModel, SVModel)) and all(o is owners[0] for o in owners)
+    from .models import LGConcatModel, SVModel, LorenzModel
+    if (isinstance(owners[0], (LGConcatModel, SVModel, LorenzModel)) and all(o is owners[0] for o in owners)
             and names == ["dynamics_factory", "observations_factory", "log_likelihood_fn"]):
         return owners[0]
     return None

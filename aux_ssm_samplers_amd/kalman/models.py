@@ -144,3 +144,83 @@ class SVModel:
             ybuf, yarr = _upload_arr(handle, self.yobs, (d,), 1, T, 1, False, False, np.dtype(dtype), "ys")
             dev = self._dev[key] = (dl, ybuf, yarr)
         return dev
+
+
+class LorenzModel:
+    """Stochastic Lorenz-63 with Euler-Maruyama dynamics and sparse linear-Gaussian observations,
+    examples/lorenz/auxiliary_kalman.py:14-52 (model.py:10-25; linearisation.py:11-44 with the analytic Jacobian in place of jacfwd):
+
+        dynamics_factory(x)           -> m0, P0, F_t = I + dt J(x_t), tile(Q), b_t = mean(x_t) - F_t x_t       (:27-29)
+        observations_factory(x, u, d) -> ys = [u; y], Hs = [I; H], Rs = blkdiag(d/2 I, R), cs = [0; c]        (:31-36)
+        log_likelihood_fn(x)          -> log N(x_0; m0, P0) + sum log N(x_{t+1}; mean(x_t), Q) + nansum_t log N(y_t; H_t x_t + c_t, R_t)
+
+    ys (T, po) with NaN rows where nothing is observed; Hs (T, po, 3) may carry NaN rows there too (model.py:43-56).
+    Pass the three bound methods to kalman.get_kernel: it runs the device sweep (model kind LORENZ63_EXT)."""
+    kmodel = _lib.KMODEL_LORENZ63_EXT
+    dense_only = True
+
+    def __init__(self, ys, Hs, Rs, cs, m0, P0, theta, sigma_x, dt):
+        self.yobs, self.Hobs, self.Robs, self.cobs = np.asarray(ys), np.asarray(Hs), np.asarray(Rs), np.asarray(cs)
+        self.T, self.p_obs = self.yobs.shape
+        self.dx = 3
+        self.m0, self.P0 = np.asarray(m0, np.float64), np.asarray(P0, np.float64)
+        self.theta = np.asarray(theta, np.float64).reshape(3)
+        self.sigma_x, self.dt = float(sigma_x), float(dt)
+        self.Q = self.dt * self.sigma_x ** 2 * np.eye(3)
+        self.Qs = np.broadcast_to(self.Q, (self.T - 1, 3, 3))
+        self._dev = {}
+
+    def mean(self, x):
+        x = np.asarray(x)
+        th, dt = self.theta, self.dt
+        x1, x2, x3 = x[..., 0], x[..., 1], x[..., 2]
+        return x + dt * np.stack([th[0] * (x2 - x1), th[1] * x1 - x2 - x1 * x3, x1 * x2 - th[2] * x3], axis=-1)
+
+    def dynamics_factory(self, x):
+        x = np.asarray(x)
+        xl = x[:-1]
+        th, dt = self.theta, self.dt
+        n = xl.shape[0]
+        J = np.zeros((n, 3, 3), x.dtype)
+        J[:, 0, 0], J[:, 0, 1] = -th[0], th[0]
+        J[:, 1, 0], J[:, 1, 1], J[:, 1, 2] = th[1] - xl[:, 2], -1.0, -xl[:, 0]
+        J[:, 2, 0], J[:, 2, 1], J[:, 2, 2] = xl[:, 1], xl[:, 0], -th[2]
+        Fs = np.eye(3, dtype=x.dtype) + dt * J
+        bs = self.mean(xl) - np.einsum("tij,tj->ti", Fs, xl)
+        return self.m0.astype(x.dtype), self.P0.astype(x.dtype), Fs, self.Qs.astype(x.dtype), bs
+
+    def observations_factory(self, x, u, delta):
+        return LGConcatModel.observations_factory(self, x, u, delta)
+
+    def log_likelihood_fn(self, x):
+        """NumPy (host path / oracle): the same nansum-over-steps semantics as the reference (:38-46)."""
+        x = np.asarray(x, np.float64)
+
+        def mvn(r, cov):
+            L = np.linalg.cholesky(cov)
+            z = np.linalg.solve(L, r[..., None])[..., 0]
+            return -0.5 * np.sum(z * z, -1) - np.sum(np.log(np.diagonal(L, axis1=-2, axis2=-1)), -1) - 0.5 * r.shape[-1] * np.log(2 * np.pi)
+
+        out = mvn(x[0] - self.m0, self.P0)
+        out += np.sum(mvn(x[1:] - self.mean(x[:-1]), self.Q))
+        with np.errstate(all="ignore"):
+            pred = np.einsum("tij,tj->ti", self.Hobs, x) + self.cobs
+            ll = mvn(np.asarray(self.yobs, np.float64) - pred, np.asarray(self.Robs, np.float64))
+        return float(out + np.nansum(ll))
+
+    def device(self, handle, dtype):
+        key = (id(handle), np.dtype(dtype).str)
+        dev = self._dev.get(key)
+        if dev is None:
+            T, po = self.T, self.p_obs
+            par = np.concatenate([self.theta, [self.dt]])  # rides in the Fs slot of the C struct (include/auxssm.h, LORENZ63_EXT)
+            n = T - 1
+            lg = (self.m0, self.P0, np.broadcast_to(np.eye(3), (n, 3, 3)), self.Qs, np.broadcast_to(np.zeros(3), (n, 3)),
+                  self.Hobs, self.Robs, self.cobs)
+            dl = DeviceLGSSM(handle, lg, 1, T, 1, 3, po, False, dtype)
+            pbuf = handle.to_device(par, dtype)
+            dl.bufs["lorenz_par"] = pbuf
+            dl.c.Fs = pbuf.arr(0, 0, 0)
+            ybuf, yarr = _upload_arr(handle, self.yobs, (po,), 1, T, 1, False, False, np.dtype(dtype), "ys")
+            dev = self._dev[key] = (dl, ybuf, yarr)
+        return dev

@@ -151,7 +151,14 @@ typedef enum {
      * observation set with H = I, c = 0, rebuilt at both linearisation points (x and x_prop) each sweep;
      * log_likelihood_fn(x) = prior_logpdf(x) + sum log g.  yobs (T, dx), dims->dy = dx, dense layout. */
     AUXSSM_KMODEL_SV_FIRST = 2,
-    AUXSSM_KMODEL_SV_SECOND = 3
+    AUXSSM_KMODEL_SV_SECOND = 3,
+    /* Stochastic Lorenz-63 (examples/lorenz/auxiliary_kalman.py:14-52, model.py:10-25): dynamics_factory(x) is the first-order
+     * extended linearisation (linearisation.py:11-44, analytic Jacobian) of mean(x) = x + dt (phi_0(x) + theta * phi(x)) at every x_t,
+     * rebuilt at both linearisation points each sweep; observations_factory concatenates the auxiliary and the real observations as
+     * LG_CONCAT does; log_likelihood_fn(x) = log N(x_0; m0, P0) + sum log N(x_{t+1}; mean(x_t), Q) + nansum_t log N(y_t; H_t x_t + c_t, R_t).
+     * `model`: m0, P0, Qs as usual; Fs.ptr -> DEVICE array [theta1, theta2, theta3, dt] of `dtype` (bs unused); Hs, Rs, cs = the
+     * real observation model (rows of unobserved steps may be NaN); yobs (T, dy) with NaN = missing; dx = 3, dy <= 3; dense layout. */
+    AUXSSM_KMODEL_LORENZ63_EXT = 4
 } auxssm_kalman_model;
 typedef enum { AUXSSM_LAYOUT_DENSE = 0, AUXSSM_LAYOUT_CHAIN_MINOR = 1 } auxssm_layout;
 int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims,

@@ -1,4 +1,4 @@
-"""GPU parity tests of the stochastic-volatility auxiliary-Kalman sweep (device factories AUXSSM_KMODEL_SV_FIRST / SV_SECOND,
+"""GPU parity tests of the auxiliary-Kalman sweep on the nonlinear example models (stochastic volatility, Lorenz-63) (device factories AUXSSM_KMODEL_SV_FIRST / SV_SECOND,
 reference examples/stochastic_volatility/auxiliary_kalman.py:22-48): device sweep vs the oracle's restatement of
 kalman/generic.py:53-106 driven by the same closed-form NumPy factories, on identical explicit noise.  fp64 tolerances:
 x_prop rtol 1e-9 / atol 1e-10, log-densities rtol 1e-9."""
@@ -99,3 +99,66 @@ def test_sv_chain_moves_and_targets_posterior():
     lp = np.array([model.log_likelihood_fn(xs[c]) for c in range(C)])
     assert np.all(np.isfinite(lp)) and np.all(lp > model.log_likelihood_fn(xtrue) - 4 * T)
     assert np.abs(xs - xtrue[None]).max() > 1e-3
+
+
+def lorenz_kalman_setup(T, every=8, dt=0.01, seed=0):
+    """examples/lorenz: theta = (10, 28, 8/3), sigma_x = 3, m0 = (1.5, -1.5, 25), P0 = diag(400, 20, 20), (x2, x3) observed every `every`-th
+    step with variance 5, NaN rows (ys AND Hs, as model.py:43-56) elsewhere."""
+    from aux_ssm_samplers_amd.kalman import LorenzModel
+    rng = np.random.default_rng(seed)
+    theta, sx = np.array([10.0, 28.0, 8.0 / 3.0]), 3.0
+    m0, P0 = np.array([1.5, -1.5, 25.0]), np.diag([400.0, 20.0, 20.0])
+    H = np.array([[0, 1.0, 0], [0, 0, 1.0]])
+    ys = np.full((T, 2), np.nan)
+    Hs = np.full((T, 2, 3), np.nan)
+    Hs[::every] = H
+    Rs = np.broadcast_to(5.0 * np.eye(2), (T, 2, 2))
+    cs = np.zeros((T, 2))
+    model = LorenzModel(ys, Hs, Rs, cs, m0, P0, theta, sx, dt)
+    x = np.zeros((T, 3))
+    x[0] = m0
+    for t in range(1, T):
+        x[t] = model.mean(x[t - 1]) + sx * np.sqrt(dt) * rng.standard_normal(3)
+    ys[::every] = x[::every] @ H.T + np.sqrt(5.0) * rng.standard_normal((len(x[::every]), 2))
+    model.yobs = ys
+    return model, x
+
+
+@pytest.mark.parametrize("T", [120, 257])
+@pytest.mark.parametrize("parallel", [True, False])
+@pytest.mark.parametrize("nan_policy", ["reference"])
+def test_lorenz_device_sweep_vs_oracle(T, parallel, nan_policy):
+    """Config C4's Kalman half (Lorenz-63, extended linearisation rebuilt at x and at x_prop, sparse observations with NaN rows)
+    on the device vs the oracle's sweep driven by the same NumPy factories."""
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    model, xtrue = lorenz_kalman_setup(T)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, parallel)
+    rng = np.random.Generator(np.random.PCG64(5))
+    x = xtrue + 0.05 * rng.standard_normal((T, 3))
+    delta = 0.02
+    for rep in range(2):
+        noise = dict(eps_aux=rng.standard_normal((T, 3)), eps_samp=rng.standard_normal((T, 3)), u_accept=rng.random())
+        ref = K.kalman_sweep(x, delta, model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, parallel, **noise)
+        out = kernel(None, init(x), delta, noise=noise)
+        npt.assert_allclose(out.logs[0, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-8)
+        npt.assert_allclose(out.log_alpha, ref["log_alpha"], rtol=1e-5, atol=1e-6)
+        assert out.updated == ref["accepted"]
+        npt.assert_allclose(out.x, ref["x"], rtol=1e-8, atol=1e-9)
+        x = ref["x"]
+
+
+def test_lorenz_host_factory_path_equals_device_sweep():
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    T = 100
+    model, xtrue = lorenz_kalman_setup(T, seed=2)
+    init, kdev = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    init2, khost = get_kernel(lambda z: model.dynamics_factory(z), lambda z, u, dl: model.observations_factory(z, u, dl),
+                              lambda z: model.log_likelihood_fn(z), True)
+    rng = np.random.default_rng(9)
+    x = xtrue + 0.05 * rng.standard_normal((T, 3))
+    noise = dict(eps_aux=rng.standard_normal((T, 3)), eps_samp=rng.standard_normal((T, 3)), u_accept=0.4)
+    a = kdev(None, init(x), 0.02, noise=noise)
+    b = khost(None, init2(x), 0.02, noise=noise)
+    npt.assert_allclose(a.x, b.x, rtol=1e-8, atol=1e-9)
+    npt.assert_allclose(a.log_alpha, b.log_alpha, rtol=1e-5, atol=1e-6)
+    assert a.updated == b.updated
