@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Secondary measurements on the BASELINE configs that are not the headline (bench.py measures C2 and, with --workload csmc, C3):
+   C3k  stochastic volatility d=1 T=65536, auxiliary-Kalman sweep (first / second order), fp64
+   C4   Lorenz-63 T=16384 dt=1.25e-4 obs every 80 steps, fp32: Kalman sweep (extended linearisation) + cSMC sweep N=512 (bootstrap, backward sampling)
+   C5   dense d = p = 64 T=8192 fp32: filter + sampler + joint log-density of one chain (wide-state path)
+Prints one JSON line per measurement.  Inputs are resident in HBM (DeviceChains) where the API allows it; device Threefry noise."""
+import json
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, ".")
+from aux_ssm_samplers_amd import _lib, random as R  # noqa: E402
+from aux_ssm_samplers_amd.kalman import get_kernel, SVModel, LorenzModel  # noqa: E402
+from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler  # noqa: E402
+
+
+def timed_sweeps(kernel, chains, delta, steps=5, warmup=2, seed=1):
+    h = chains.handle
+    state = KalmanSampler(x=chains, updated=None)
+    keys = R.split(R.PRNGKey(seed), steps + warmup)
+    for k in range(warmup):
+        kernel(keys[k], state, delta)
+    h.sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        kernel(keys[warmup + k], state, delta)
+    h.sync()
+    el = time.perf_counter() - t0
+    return chains.C * steps / el, el / steps * 1e3, float(chains.accepted.to_host().mean())
+
+
+def c3_kalman(order, chains=64, T=65536):
+    sys.path.insert(0, "tests")
+    from test_gpu_nonlinear_kalman import sv_setup
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, rho=0.0)
+    model = SVModel(y, m0, P0, F, Q, b, order=order)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    h = _lib.default_handle()
+    ch = DeviceChains(h, np.repeat(xtrue[None], chains, axis=0), chain_minor=False)
+    v, ms, acc = timed_sweeps(kernel, ch, 0.5)
+    print(json.dumps(dict(config=f"C3 SV d=1 T={T}, aux-Kalman order {order}, fp64", chains=chains, sweeps_per_s=round(v, 1), ms_per_step=round(ms, 2), accept=acc)))
+
+
+def c4(chains=8, T=16384, N=512):
+    sys.path.insert(0, "tests")
+    from test_gpu_nonlinear_kalman import lorenz_kalman_setup
+    from test_gpu_csmc import lorenz_setup
+    from aux_ssm_samplers_amd.csmc import _device
+    model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    h = _lib.default_handle()
+    ch = DeviceChains(h, np.repeat(xtrue[None], chains, axis=0).astype(np.float32), chain_minor=False)
+    v, ms, acc = timed_sweeps(kernel, ch, 1e-4)
+    print(json.dumps(dict(config=f"C4 Lorenz-63 T={T} dt=1.25e-4 obs/80, aux-Kalman (extended linearisation), fp32", chains=chains,
+                          sweeps_per_s=round(v, 1), ms_per_step=round(ms, 2), accept=acc)))
+    M0, Mt, G0, Gt, xt, y, sig_y = lorenz_setup(T, every=80, dt=1.25e-4)
+    fk = _device.describe_bootstrap(M0, G0, Mt, Gt, Mt)
+    x = np.repeat(xt[None], chains, axis=0).astype(np.float32)
+    _device.sweep(fk, x, N, True, key=0)
+    h.sync()
+    t0 = time.perf_counter()
+    reps = 3
+    for k in range(reps):
+        x, anc, _ = _device.sweep(fk, x, N, True, key=1 + k)
+    h.sync()
+    el = time.perf_counter() - t0
+    print(json.dumps(dict(config=f"C4 Lorenz-63 T={T}, cSMC N={N} bootstrap + backward sampling, fp32 (host round trip of x included)", chains=chains,
+                          sweeps_per_s=round(chains * reps / el, 1), ms_per_step=round(el / reps * 1e3, 2), updated=float((anc != 0).mean()))))
+
+
+def c5(T=8192):
+    sys.path.insert(0, "tests")
+    from test_gpu_wide import c5_model
+    import aux_ssm_samplers_amd._primitives.kalman as P
+    u, lg64, x = c5_model(T, 64)
+    lg = P.LGSSM(*[np.ascontiguousarray(a, np.float32) for a in lg64])
+    u = u.astype(np.float32)
+    h = _lib.default_handle()
+    eps = np.random.default_rng(0).standard_normal((T, 64)).astype(np.float32)
+    for rep in range(2):
+        for kid, name in ((_lib.K_FILTER_INIT, "init"), (_lib.K_FILTER_SCAN, "scan"), (_lib.K_FILTER_ELL, "ell")):
+            h.prof_enable(kid, 4)
+            ms, Ps, ell = P.filtering(u, lg, True)
+            n, t = h.prof_read()
+            h.prof_disable()
+            if rep:
+                print(json.dumps(dict(config=f"C5 dense d=p=64 T={T} fp32, 1 chain, filter {name} kernels", ms=round(t, 2))))
+        for kid, name in ((_lib.K_SAMPLE_INIT, "sampler init"), (_lib.K_SAMPLE_SCAN, "sampler scan")):
+            h.prof_enable(kid, 4)
+            xs = P.sampling(None, ms, Ps, lg, True, eps=eps)
+            n, t = h.prof_read()
+            h.prof_disable()
+            if rep:
+                print(json.dumps(dict(config=f"C5 dense d=p=64 T={T} fp32, 1 chain, {name} kernels", ms=round(t, 2))))
+        h.prof_enable(_lib.K_LOGPDF, 4)
+        lp = P.posterior_logpdf(u, xs, ell, lg)
+        n, t = h.prof_read()
+        h.prof_disable()
+        if rep:
+            print(json.dumps(dict(config=f"C5 dense d=p=64 T={T} fp32, 1 chain, joint log-density kernel", ms=round(t, 2), lp=float(lp))))
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["c3k", "c4", "c5"]
+    if "c3k" in which:
+        c3_kalman(1)
+        c3_kalman(2)
+    if "c4" in which:
+        c4()
+    if "c5" in which:
+        c5()
