@@ -7,3 +7,5 @@ Python host code -> ctypes -> libauxssm.so (hand-written HIP).  No CPU fallback:
 library or a GPU is missing.
 """
 __version__ = "0.1.0"
+
+from .common import delta_adaptation  # noqa: E402,F401  (reference: aux_samplers/__init__.py:4)

@@ -51,3 +51,15 @@ def test_init_kernel_return_order_and_state():
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
     st = init(np.zeros((T, d)))
     assert st.updated is True and st.x.shape == (T, d) and callable(kernel)  # kalman/generic.py:92-95: returns (init, kernel)
+
+
+def test_delta_adaptation_matches_reference_formula():
+    """aux_samplers/common.py:4-32: delta * exp(rate * (acc - target)), clipped; scalars and per-time-step vectors."""
+    import numpy as np
+    from aux_samplers import delta_adaptation
+    from aux_ssm_samplers_amd.common import delta_adaptation as d2
+    assert delta_adaptation is d2
+    assert abs(delta_adaptation(0.5, 0.234, 0.5, 0.1) - 0.5 * np.exp(0.1 * (0.5 - 0.234))) < 1e-15
+    assert delta_adaptation(1e-19, 0.5, 0.0, 10.0) == 1e-20 and delta_adaptation(1e19, 0.5, 1.0, 10.0) == 1e20
+    d = delta_adaptation(np.array([0.1, 0.2]), 0.3, np.array([0.1, 0.9]), 0.5)
+    np.testing.assert_allclose(d, [0.1 * np.exp(-0.1), 0.2 * np.exp(0.3)], rtol=1e-15)
