@@ -379,6 +379,95 @@ __device__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* 
     }
     __syncthreads();
 }
+// Z = [S (n x n, symmetric positive definite, FULL storage) | RHS (n x (nct - n))] in LDS: RHS <- S^-1 RHS by Gauss-Jordan
+// elimination WITHOUT pivoting (the pivots are the squared Cholesky diagonal, so the failure test "pivot <= 0 or NaN" and
+// log|S| = sum log pivot are exactly what the Cholesky route gives), Z in registers as in gj_solve: one barrier per pivot.
+// skip[k] (may be null): index k is deleted (row / column k of S must be zero on entry; treated as a unit row).
+// Replaces chol + trsm_l (+ trsm_lt) wherever the factor itself is not needed.  Needs n <= NWV * NRR, nct <= 256.
+// LDS scratch: rowbuf[2 (nct + 1)], piv[n] reals.  Returns ok (uniform); *half_logdet = 0.5 log|S| over the kept indices.
+template <typename R, int NRR>
+__device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid) {
+    const int ti = tid >> 6, tj = tid & 63;
+    R z[NRR][4];
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        const int r = ti + NWV * a;
+        const bool sk = skip && r < n && skip[r];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = tj + 64 * b;
+            R v = (r < n && c < nct) ? Z[r * ld + c] : (R)0;
+            if (sk) v = c == r ? (R)1 : (R)0;
+            z[a][b] = v;
+        }
+    }
+    __syncthreads();
+    const int rb = nct + 1;
+    for (int k = 0; k < n; ++k) {
+        const int ka = k / NWV, kb = k >> 6, src = k & 63;
+        R* rbuf = rowbuf + (k & 1) * rb;
+        if (ti == k - ka * NWV) {  // the wave owning row k publishes it (current values) and the pivot
+#pragma unroll
+            for (int a = 0; a < NRR; ++a)
+                if (a == ka) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) {
+                        if (tj + 64 * b < nct) rbuf[tj + 64 * b] = z[a][b];
+                        if (b == kb && tj == src) {
+                            rbuf[nct] = (R)1 / z[a][b];
+                            piv[k] = z[a][b];
+                        }
+                    }
+                }
+        }
+        __syncthreads();
+        const R inv = rbuf[nct];
+        R zk[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) zk[b] = (tj + 64 * b < nct) ? rbuf[tj + 64 * b] : (R)0;
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            const R v = kb == 0 ? z[a][0] : (kb == 1 ? z[a][1] : (kb == 2 ? z[a][2] : z[a][3]));
+            const R f = (ti + NWV * a != k) ? bcast(v, src) * inv : (R)0;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) z[a][b] -= f * zk[b];
+        }
+        // rowbuf is double-buffered: the half read here is rewritten at step k + 2, after every lane has passed barrier k + 1
+    }
+    __syncthreads();
+    int bad = 0;
+    R hl = 0;
+    for (int k = tid; k < n; k += NT) {
+        const R d = piv[k];
+        if (!(skip && skip[k])) {
+            bad |= !(d > (R)0);
+            hl += (R)0.5 * log_(d);
+        }
+    }
+    const bool ok = !__syncthreads_or(bad);
+    if (half_logdet) *half_logdet = block_sum<R>(hl, rowbuf, tid);
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        const int r = ti + NWV * a;
+        if (r < n) {
+            const R inv = (R)1 / piv[r];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = tj + 64 * b;
+                if (c >= n && c < nct) Z[r * ld + c] = z[a][b] * inv;
+            }
+        }
+    }
+    __syncthreads();
+    return ok;
+}
+__host__ __device__ inline bool spd_fits(int n, int nct) { return n <= 8 * NWV && nct <= 256; }
+template <typename R>
+__device__ bool spd_solve(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid) {
+    if (n <= NWV * 4) return spd_solve_t<R, 4>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid);
+    return spd_solve_t<R, 8>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid);
+}
+
 template <typename R> __device__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
     if (n <= NWV * 4) gj_solve<R, 4>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
     else if (n <= NWV * 8) gj_solve<R, 8>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
@@ -411,63 +500,54 @@ template <typename R> __device__ bool load_obs(const Obs<R>& o, const R* Hg, con
     __syncthreads();
     return *o.cnt > 0;
 }
-// S (lower triangle valid, ld ldp_(p)) = H_ P_ H_^T + R_;  PHt (d x p, ld ldp_(p)) = P_ H_^T.  Rg: the p x p record in
-// global memory, upper entries read (as the per-lane path does).
+// S (p x p, FULL symmetric storage, leading dimension lds) = H_ P_ H_^T + R_;  PHt (d x p, ld ldp_(p)) = P_ H_^T.  Rg: the p x p
+// covariance record in global memory (its upper entries are read, as the per-lane path does); deleted indices get a zero row /
+// column (spd_solve treats them as unit rows).
 template <typename R>
-__device__ void innovation(const Obs<R>& o, int ldh, const R* P_, const R* Rg, int p, int d, R* PHt, R* S, int tid) {
+__device__ void innovation(const Obs<R>& o, int ldh, const R* P_, const R* Rg, int p, int d, R* PHt, R* S, int lds, int tid) {
     const int ldd = ldp_(d), ldp = ldp_(p);
     gemm<false, true>(d, p, d, P_, ldd, o.H_, ldh, PHt, ldp, (R)1, (R)0, tid);
-    gemm<false, false>(p, p, d, o.H_, ldh, PHt, ldp, S, ldp, (R)1, (R)0, tid);
+    gemm<false, false>(p, p, d, o.H_, ldh, PHt, ldp, S, lds, (R)1, (R)0, tid);
     for (int i = tid / 64; i < p; i += NWV)
         for (int j = tid & 63; j <= i; j += 64) {
-            // lower (i, j) <- the value the reference computes for the upper (j, i) entry
             const R r = (o.nan[i] || o.nan[j]) ? (R)0 : Rg[(long long)j * p + i];
-            S[i * ldp + j] = S[j * ldp + i] + r;
+            const R v = S[j * lds + i] + r;  // the value the reference computes for the upper (j, i) entry
+            S[i * lds + j] = v;
+            S[j * lds + i] = v;
         }
     __syncthreads();
 }
-// -0.5 |z|^2 - sum log L_kk - dim/2 log 2 pi over the observed components; NaN / failed factor -> 0 (nansum).  Cooperative.
-template <typename R> __device__ R ell_from(const R* L, int ldp, const R* z, const unsigned char* nan, int p, int dim, bool ok, R* red, int tid) {
-    R q = 0, ld_ = 0;
-    for (int k = tid; k < p; k += NT) {
-        q += z[k] * z[k];
-        ld_ += (nan && nan[k]) ? (R)0 : log_(L[k * ldp + k]);
-    }
-    q = block_sum<R>(q, red, tid);
-    const R logdet = block_sum<R>(ld_, red, tid);
-    R ell = (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim;
+// log N from the solved system: -0.5 r^T S^-1 r - 0.5 log|S| - dim/2 log 2 pi; NaN / failed factor -> 0 (the reference's nansum)
+template <typename R> __device__ R ell_value(R q, R half_logdet, int dim, bool ok) {
+    R ell = (R)-0.5 * q - half_logdet - (R)(0.5 * LOG_2PI) * (R)dim;
     if (!ok) ell = r_nan<R>();
     return isnan_(ell) ? (R)0 : ell;
 }
 
 // ---- t = 0 measurement update (sequential_update, filtering.py:83-130); one workgroup per sequence ------------------------
 static size_t lds_filter_t0(size_t s, int d, int p) {
-    const size_t ldd = ldp_(d), ldp = ldp_(p), ldx = ldp_(d + 1);
-    return al16(d * ldd * s) + 2 * al16(p * ldd * s) + al16(p * ldx * s) + al16(p * ldp * s) + al16(d * s) * 2 + 6 * al16(p * s) + al16(p) + 256;
+    const size_t ldd = ldp_(d), ldz = ldp_(p + d + 1);
+    return al16(d * ldd * s) + 2 * al16(p * ldd * s) + al16(p * ldz * s) + al16(d * s) * 2 + 4 * al16(p * s) + al16((2 * (p + d + 2) + NWV) * s) + al16(p) + 128;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, s = blockIdx.x, c = s / a.d.B, b = s % a.d.B, d = a.dx, p = a.dy;
-    const int ldd = ldp_(d), ldp = ldp_(p), ldx = ldp_(d + 1);
+    const int ldd = ldp_(d), nct = p + d + 1, ldz = ldp_(nct);
     Bump L{smem};
     R* P = L.take<R>(d * ldd);
     Obs<R> o;
     o.H_ = L.take<R>(p * ldd);
     R* HP = L.take<R>(p * ldd);
-    R* X = L.take<R>(p * ldx);  // [H_ P | yd] -> [S^-1 H_ P | L^-1 yd]
-    R* S = L.take<R>(p * ldp);
+    R* Z = L.take<R>(p * ldz);  // [S | H_ P | yd] -> [S | S^-1 H_ P | S^-1 yd]
     R* m = L.take<R>(d);
     R* dm = L.take<R>(d);
     o.c_ = L.take<R>(p);
     o.y = L.take<R>(p);
     R* yd = L.take<R>(p);
-    R* z = L.take<R>(p);
-    R* invd = L.take<R>(p);
-    R* dg = L.take<R>(p);
-    R* red = L.take<R>(NWV);
+    R* piv = L.take<R>(p);
+    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
-    int* flag = L.take<int>(1);
     load_mat<R>(P, ldd, at<R>(a.P0, c, 0, b), d, d, tid);
     load_vec<R>(m, at<R>(a.m0, c, 0, b), d, tid);
     const bool any = load_obs<R>(o, at<R>(a.Hs, c, 0, b), at<R>(a.cs, c, 0, b), at<R>(a.ys, c, 0, b), p, d, ldd, tid);
@@ -482,40 +562,43 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterA
     gemv<R, false>(p, d, o.H_, ldd, m, yd, (R)1, (R)0, tid);
     for (int k = tid; k < p; k += NT) {
         yd[k] = o.nan[k] ? (R)0 : o.y[k] - (yd[k] + o.c_[k]);
-        X[k * ldx + d] = yd[k];
+        Z[k * ldz + p + d] = yd[k];
     }
     // HP = H_ P (p x d);  S = HP H_^T + R_
     gemm<false, false>(p, d, d, o.H_, ldd, P, ldd, HP, ldd, (R)1, (R)0, tid);
-    gemm<false, true>(p, p, d, HP, ldd, o.H_, ldd, S, ldp, (R)1, (R)0, tid);
+    gemm<false, true>(p, p, d, HP, ldd, o.H_, ldd, Z, ldz, (R)1, (R)0, tid);
     const R* Rg = at<R>(a.Rs, c, 0, b);
     for (int i = tid / 64; i < p; i += NWV)
-        for (int j = tid & 63; j <= i; j += 64) S[i * ldp + j] += (o.nan[i] || o.nan[j]) ? (R)0 : Rg[(long long)j * p + i];
+        for (int j = tid & 63; j <= i; j += 64) {
+            const R v = Z[i * ldz + j] + ((o.nan[i] || o.nan[j]) ? (R)0 : Rg[(long long)j * p + i]);
+            Z[i * ldz + j] = v;
+            Z[j * ldz + i] = v;
+        }
     for (int i = tid / 64; i < p; i += NWV)
-        for (int j = tid & 63; j < d; j += 64) X[i * ldx + j] = HP[i * ldd + j];
+        for (int j = tid & 63; j < d; j += 64) Z[i * ldz + p + j] = HP[i * ldd + j];
     __syncthreads();
-    const bool ok = chol<R>(S, ldp, p, o.nan, invd, dg, flag, tid);
-    // z = L^-1 yd;  X = S^-1 HP  (gain^T, :117)
-    trsm_l<R>(S, ldp, p, invd, X, ldx, d + 1, tid);
-    for (int k = tid; k < p; k += NT) z[k] = X[k * ldx + d];
-    __syncthreads();
-    const R ell = ell_from<R>(S, ldp, z, o.nan, p, *o.cnt, ok, red, tid);
-    trsm_lt<R>(S, ldp, p, invd, X, ldx, d, tid);
+    R hl;
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid);  // X = S^-1 HP (gain^T, :117), S^-1 yd
+    R q = 0;
+    for (int k = tid; k < p; k += NT) q += yd[k] * Z[k * ldz + p + d];
+    q = block_sum<R>(q, rowbuf, tid);
+    const R ell = ell_value<R>(q, hl, *o.cnt, ok);
     // m += X^T yd;  P <- sym(P - X^T HP)
-    gemv<R, true>(d, p, X, ldx, yd, dm, (R)1, (R)0, tid);
-    gemm<true, false>(d, d, p, X, ldx, HP, ldd, P, ldd, (R)-1, (R)1, tid);
+    gemv<R, true>(d, p, Z + p, ldz, yd, dm, (R)1, (R)0, tid);
+    gemm<true, false>(d, d, p, Z + p, ldz, HP, ldd, P, ldd, (R)-1, (R)1, tid);
     symmetrise<R>(P, ldd, d, tid);
     const R bad = r_nan<R>();
     for (int i = tid; i < d; i += NT) mo[i] = ok ? m[i] + dm[i] : bad;
     for (int r = tid / 64; r < d; r += NWV)
-        for (int q = tid & 63; q < d; q += 64) Po[(long long)r * d + q] = ok ? P[r * ldd + q] : bad;
+        for (int q2 = tid & 63; q2 < d; q2 += 64) Po[(long long)r * d + q2] = ok ? P[r * ldd + q2] : bad;
     if (tid == 0) ((R*)a.ell0)[s] = ell;
 }
 
 // ---- scan element of transition i -> i + 1 (_filtering_init_one, filtering.py:196-250), information form of kalman_math.h ---
 static size_t lds_filter_init(size_t s, int d, int p) {
-    const size_t ldd = ldp_(d), ldp = ldp_(p);
-    return 5 * al16(d * ldd * s) + al16(p * (size_t)ldp_(d + 2) * s) + al16(d * std::max(ldp, ldd) * s) + al16(p * ldp * s) + 6 * al16(d * s) +
-           6 * al16(p * s) + al16(p) + 64;
+    const size_t ldd = ldp_(d), ldp = ldp_(p), ldz = ldp_(p + d + 2);
+    return 5 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * std::max(ldp, ldd) * s) + al16(p * ldz * s) + 6 * al16(d * s) +
+           5 * al16(p * s) + al16((2 * (p + d + 3) + NWV) * s) + al16(p) + 128;
 }
 __host__ __device__ inline long long fe_size(int d) { return 3ll * d * d + 2 * d; }
 
@@ -524,7 +607,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1;
     const int s = blockIdx.x / n, i = blockIdx.x - s * n, c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
-    const int ldd = ldp_(d), ldp = ldp_(p), ldt = ldp > ldd ? ldp : ldd, ldh = ldp_(d + 2);
+    const int ldd = ldp_(d), ldp = ldp_(p), ldt = ldp > ldd ? ldp : ldd, nct = p + d + 2, ldz = ldp_(nct);
     Bump L{smem};
     R* F = L.take<R>(d * ldd);
     R* P_ = L.take<R>(d * ldd);
@@ -532,9 +615,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     R* MF = L.take<R>(d * ldd);
     R* O = L.take<R>(d * ldd);
     Obs<R> o;
-    o.H_ = L.take<R>(p * ldh);  // [H_ | rm | rb] -> [W | L^-1 rm | L^-1 rb]
+    o.H_ = L.take<R>(p * ldd);
     R* Tm = L.take<R>(d * ldt);
-    R* S = L.take<R>(p * ldp);
+    R* Z = L.take<R>(p * ldz);  // [S | H_ | rm | rb] -> [S | S^-1 H_ | S^-1 rm | S^-1 rb]
     R* bd = L.take<R>(d);
     R* m_ = L.take<R>(d);
     R* vm = L.take<R>(d);
@@ -545,11 +628,10 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     o.y = L.take<R>(p);
     R* rm = L.take<R>(p);
     R* rb = L.take<R>(p);
-    R* invd = L.take<R>(p);
-    R* dg = L.take<R>(p);
+    R* piv = L.take<R>(p);
+    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
-    int* flag = L.take<int>(1);
     R* e = elem + ((long long)s * n + i) * fe_size(d);
     R* eA = e;
     R* eb = e + d * d;
@@ -560,7 +642,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     load_mat<R>(F, ldd, at<R>(a.Fs, c, i, b), d, d, tid);
     load_mat<R>(P_, ldd, at<R>(a.Qs, c, i, b), d, d, tid);
     load_vec<R>(bd, at<R>(a.bs, c, i, b), d, tid);
-    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldh, tid);
+    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
     if (i == 0) {  // built around predict(m0+, P0+), not symmetrised (filtering.py:200-201)
         load_mat<R>(M, ldd, at<R>(a.Ps, c, 0, b), d, d, tid);
         load_vec<R>(m0p, at<R>(a.ms, c, 0, b), d, tid);
@@ -582,22 +664,24 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
         for (int k = tid; k < d; k += NT) eb[k] = m_[k], eeta[k] = 0;
         return;
     }
-    innovation<R>(o, ldh, P_, at<R>(a.Rs, c, t, b), p, d, Tm, S, tid);
-    gemv<R, false>(p, d, o.H_, ldh, m_, rm, (R)1, (R)0, tid);
-    gemv<R, false>(p, d, o.H_, ldh, bd, rb, (R)1, (R)0, tid);
+    innovation<R>(o, ldd, P_, at<R>(a.Rs, c, t, b), p, d, Tm, Z, ldz, tid);
+    gemv<R, false>(p, d, o.H_, ldd, m_, rm, (R)1, (R)0, tid);
+    gemv<R, false>(p, d, o.H_, ldd, bd, rb, (R)1, (R)0, tid);
     for (int k = tid; k < p; k += NT) {
-        o.H_[k * ldh + d] = o.nan[k] ? (R)0 : o.y[k] - (rm[k] + o.c_[k]);
-        o.H_[k * ldh + d + 1] = o.nan[k] ? (R)0 : o.y[k] - (rb[k] + o.c_[k]);
+        Z[k * ldz + p + d] = o.nan[k] ? (R)0 : o.y[k] - (rm[k] + o.c_[k]);
+        Z[k * ldz + p + d + 1] = o.nan[k] ? (R)0 : o.y[k] - (rb[k] + o.c_[k]);
     }
+    for (int k = tid / 64; k < p; k += NWV)
+        for (int j = tid & 63; j < d; j += 64) Z[k * ldz + p + j] = o.H_[k * ldd + j];
     __syncthreads();
-    const bool ok = chol<R>(S, ldp, p, o.nan, invd, dg, flag, tid);
-    trsm_l<R>(S, ldp, p, invd, o.H_, ldh, d + 2, tid);  // [H_ | rm | rb] <- L^-1 [.]
-    for (int k = tid; k < p; k += NT) rm[k] = o.H_[k * ldh + d], rb[k] = o.H_[k * ldh + d + 1];
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, (R*)nullptr, tid);
+    for (int k = tid; k < p; k += NT) rm[k] = Z[k * ldz + p + d], rb[k] = Z[k * ldz + p + d + 1];
     __syncthreads();
-    // M = W^T W, vm = W^T rm, vb = W^T rb
-    gemm<true, false>(d, d, p, o.H_, ldh, o.H_, ldh, M, ldd, (R)1, (R)0, tid);
-    gemv<R, true>(d, p, o.H_, ldh, rm, vm, (R)1, (R)0, tid);
-    gemv<R, true>(d, p, o.H_, ldh, rb, vb, (R)1, (R)0, tid);
+    // M = H_^T S^-1 H_, vm = H_^T S^-1 rm, vb = H_^T S^-1 rb  (the information quantities of kalman_math.h::filter_elem)
+    gemm<true, false>(d, d, p, o.H_, ldd, Z + p, ldz, M, ldd, (R)1, (R)0, tid);
+    symmetrise<R>(M, ldd, d, tid);
+    gemv<R, true>(d, p, o.H_, ldd, rm, vm, (R)1, (R)0, tid);
+    gemv<R, true>(d, p, o.H_, ldd, rb, vb, (R)1, (R)0, tid);
     if (!ok) {
         const R bad = r_nan<R>();
         for (int r = tid / 64; r < d; r += NWV)
@@ -794,15 +878,16 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
 
 // ---- log-likelihood increments (filtering.py:60-62): predict from the filtered moments at i, ell_inc of step i + 1 ---------
 static size_t lds_filter_ell(size_t s, int d, int p) {
-    const size_t ldd = ldp_(d), ldp = ldp_(p);
-    return 4 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * ldp * s) + al16(p * ldp * s) + 3 * al16(d * s) + 5 * al16(p * s) + al16(p) + 256;
+    const size_t ldd = ldp_(d), ldp = ldp_(p), ldz = ldp_(p + 1);
+    return 4 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * ldp * s) + al16(p * ldz * s) + 3 * al16(d * s) + 4 * al16(p * s) +
+           al16((2 * (p + 2) + NWV) * s) + al16(p) + 128;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(FilterArgs a, R* __restrict__ ellinc) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1;
     const int s = blockIdx.x / n, i = blockIdx.x - s * n, c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
-    const int ldd = ldp_(d), ldp = ldp_(p);
+    const int ldd = ldp_(d), ldp = ldp_(p), nct = p + 1, ldz = ldp_(nct);
     Bump L{smem};
     R* F = L.take<R>(d * ldd);
     R* P = L.take<R>(d * ldd);
@@ -811,19 +896,17 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(Filter
     Obs<R> o;
     o.H_ = L.take<R>(p * ldd);
     R* PHt = L.take<R>(d * ldp);
-    R* S = L.take<R>(p * ldp);
+    R* Z = L.take<R>(p * ldz);  // [S | yd]
     R* m = L.take<R>(d);
     R* m_ = L.take<R>(d);
     R* bd = L.take<R>(d);
     o.c_ = L.take<R>(p);
     o.y = L.take<R>(p);
     R* yd = L.take<R>(p);
-    R* invd = L.take<R>(p);
-    R* dg = L.take<R>(p);
-    R* red = L.take<R>(NWV);
+    R* piv = L.take<R>(p);
+    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
-    int* flag = L.take<int>(1);
     const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
     if (!any) {
         if (tid == 0) ellinc[(long long)s * n + i] = 0;
@@ -840,14 +923,19 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(Filter
     gemm<false, false>(d, d, d, F, ldd, P, ldd, Tm, ldd, (R)1, (R)0, tid);
     gemm<false, true>(d, d, d, Tm, ldd, F, ldd, P_, ldd, (R)1, (R)1, tid);
     symmetrise<R>(P_, ldd, d, tid);
-    innovation<R>(o, ldd, P_, at<R>(a.Rs, c, t, b), p, d, PHt, S, tid);
+    innovation<R>(o, ldd, P_, at<R>(a.Rs, c, t, b), p, d, PHt, Z, ldz, tid);
     gemv<R, false>(p, d, o.H_, ldd, m_, yd, (R)1, (R)0, tid);
-    for (int k = tid; k < p; k += NT) yd[k] = o.nan[k] ? (R)0 : o.y[k] - (yd[k] + o.c_[k]);
+    for (int k = tid; k < p; k += NT) {
+        yd[k] = o.nan[k] ? (R)0 : o.y[k] - (yd[k] + o.c_[k]);
+        Z[k * ldz + p] = yd[k];
+    }
     __syncthreads();
-    const bool ok = chol<R>(S, ldp, p, o.nan, invd, dg, flag, tid);
-    trsm_l<R>(S, ldp, p, invd, yd, 1, 1, tid);
-    const R ell = ell_from<R>(S, ldp, yd, o.nan, p, *o.cnt, ok, red, tid);
-    if (tid == 0) ellinc[(long long)s * n + i] = ell;
+    R hl;
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid);
+    R q = 0;
+    for (int k = tid; k < p; k += NT) q += yd[k] * Z[k * ldz + p];
+    q = block_sum<R>(q, rowbuf, tid);
+    if (tid == 0) ellinc[(long long)s * n + i] = ell_value<R>(q, hl, *o.cnt, ok);
 }
 
 // out[r] = sum_{b < B} ( add0[r B + b] + sum_{i < n} part[(r B + b) n + i] ), fixed order; one workgroup per output
@@ -874,8 +962,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_reduce(const R* _
 }
 
 // ---- pathwise sampler (sampling.py:60-124): scan position j <-> time T - 1 - j; element [G d*d | e d] ------------------------
-static size_t lds_sample_init(size_t s, int d) { return 7 * al16(d * (size_t)ldp_(d) * s) + 8 * al16(d * s) + 64; }
-template <typename R> __device__ R nan_to_num_(R x) { return nan_to_num<R>(x); }
+static size_t lds_sample_init(size_t s, int d) {
+    return 5 * al16(d * (size_t)ldp_(d) * s) + al16(d * (size_t)ldp_(2 * d) * s) + 8 * al16(d * s) + al16((2 * (2 * d + 1) + NWV) * s) + 128;
+}
 
 // Lc <- lower Cholesky factor of the symmetric matrix in Lc (full storage), nan_to_num'ed; a failed factorisation is all zero
 template <typename R> __device__ void chol_n2n(R* Lc, int ld, int n, R* invd, R* dg, int* flag, int tid) {
@@ -889,15 +978,14 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     const int tid = threadIdx.x, d = a.dx, T = a.d.T;
     const int s = blockIdx.x / T, j = blockIdx.x - s * T, c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)T - 1 - j;
-    const int ldd = ldp_(d);
+    const int ldd = ldp_(d), ldz = ldp_(2 * d);
     Bump L{smem};
     R* F = L.take<R>(d * ldd);
     R* P = L.take<R>(d * ldd);
     R* T1 = L.take<R>(d * ldd);
-    R* S = L.take<R>(d * ldd);
-    R* S0 = L.take<R>(d * ldd);
     R* X = L.take<R>(d * ldd);
     R* G = L.take<R>(d * ldd);
+    R* Z = L.take<R>(d * ldz);  // [S | F] -> [S | S^-1 F]
     R* m = L.take<R>(d);
     R* eps = L.take<R>(d);
     R* bd = L.take<R>(d);
@@ -905,7 +993,8 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     R* tv = L.take<R>(d);
     R* invd = L.take<R>(d);
     R* dg = L.take<R>(d);
-    (void)L.take<R>(d);
+    R* piv = L.take<R>(d);
+    R* rowbuf = L.take<R>(2 * (2 * d + 1) + NWV);
     int* flag = L.take<int>(1);
     R* e = elem + ((long long)s * T + j) * ((long long)d * d + d);
     load_mat<R>(P, ldd, at<R>(a.Ps, c, t, b), d, d, tid);
@@ -926,26 +1015,24 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
         return;
     }
     load_mat<R>(F, ldd, at<R>(a.Fs, c, t, b), d, d, tid);
-    load_mat<R>(S, ldd, at<R>(a.Qs, c, t, b), d, d, tid);
+    load_mat<R>(Z, ldz, at<R>(a.Qs, c, t, b), d, d, tid);
     load_vec<R>(bd, at<R>(a.bs, c, t, b), d, tid);
     // S = sym(F P F^T + Q);  gain = P (S^-1 F)^T  (mean_and_chol :84-97)
     gemm<false, false>(d, d, d, F, ldd, P, ldd, T1, ldd, (R)1, (R)0, tid);
-    gemm<false, true>(d, d, d, T1, ldd, F, ldd, S, ldd, (R)1, (R)1, tid);
-    symmetrise<R>(S, ldd, d, tid);
+    gemm<false, true>(d, d, d, T1, ldd, F, ldd, Z, ldz, (R)1, (R)1, tid);
+    symmetrise<R>(Z, ldz, d, tid);
     for (int r = tid / 64; r < d; r += NWV)
-        for (int q = tid & 63; q < d; q += 64) S0[r * ldd + q] = S[r * ldd + q], X[r * ldd + q] = F[r * ldd + q];
+        for (int q = tid & 63; q < d; q += 64) Z[r * ldz + d + q] = F[r * ldd + q];
     __syncthreads();
-    const bool ok = chol<R>(S, ldd, d, nullptr, invd, dg, flag, tid);
-    trsm_l<R>(S, ldd, d, invd, X, ldd, d, tid);
-    trsm_lt<R>(S, ldd, d, invd, X, ldd, d, tid);
-    gemm<false, true>(d, d, d, P, ldd, X, ldd, G, ldd, (R)1, (R)0, tid);
+    const bool ok = spd_solve<R>(Z, ldz, d, 2 * d, nullptr, rowbuf, piv, (R*)nullptr, tid);  // S itself stays intact in Z[:, :d]
+    gemm<false, true>(d, d, d, P, ldd, Z + d, ldz, G, ldd, (R)1, (R)0, tid);
     if (!ok) {
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) G[r * ldd + q] = r_nan<R>();
         __syncthreads();
     }
     // Sig = sym(P - G S G^T);  Lc = nan_to_num(chol(Sig))  (:98-104)
-    gemm<false, false>(d, d, d, G, ldd, S0, ldd, T1, ldd, (R)1, (R)0, tid);
+    gemm<false, false>(d, d, d, G, ldd, Z, ldz, T1, ldd, (R)1, (R)0, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = P[r * ldd + q];
     __syncthreads();
@@ -1049,38 +1136,42 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_down(Sample
 // Cholesky of the covariance record `cov` (n x n in global memory, upper entries read) with deleted components `skip`, then
 // up to two residuals solved in place.  Returns through o1 / o2 (lane-0 values; 0 where the reference's nansum drops the term).
 template <typename R>
-__device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* skip, R* r1, R* r2, R* Lb, R* invd, R* dg, R* rr, int* flag, int tid, R& o1, R& o2) {
-    const int ld = ldp_(n);
-    // the covariance record is symmetric: its lower triangle is read (row-contiguous, coalesced)
+__device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* skip, R* r1, R* r2, R* Z, R* piv, R* rowbuf, int tid, R& o1, R& o2) {
+    const int nct = n + 2, ldz = ldp_(nct);
+    // Z = [cov | r1 | r2]; the covariance record is symmetric: its lower triangle is read (row-contiguous, coalesced)
     for (int i = tid / 64; i < n; i += NWV)
-        for (int j = tid & 63; j <= i; j += 64) Lb[i * ld + j] = cov[(long long)i * n + j];
-    int dimc = 0, b1 = 0, b2 = 0;
-    for (int k = tid; k < n; k += NT) {  // rr = [r1 | r2] (n x 2), deleted components zeroed
+        for (int j = tid & 63; j <= i; j += 64) {
+            const bool sk = skip && (skip[i] || skip[j]);
+            const R v = sk ? (R)0 : cov[(long long)i * n + j];
+            Z[i * ldz + j] = v;
+            Z[j * ldz + i] = v;
+        }
+    int b1 = 0, b2 = 0;
+    R dm = 0;
+    for (int k = tid; k < n; k += NT) {
         const bool sk = skip && skip[k];
-        dimc += sk ? 0 : 1;
+        dm += sk ? (R)0 : (R)1;
         b1 |= (!sk && !finite_(r1[k])) ? 1 : 0;
         b2 |= (!sk && r2 && !finite_(r2[k])) ? 1 : 0;
-        rr[2 * k] = sk ? (R)0 : r1[k];
-        rr[2 * k + 1] = (sk || !r2) ? (R)0 : r2[k];
+        if (sk) {
+            r1[k] = 0;
+            if (r2) r2[k] = 0;
+        }
+        Z[k * ldz + n] = sk ? (R)0 : r1[k];
+        Z[k * ldz + n + 1] = (sk || !r2) ? (R)0 : r2[k];
     }
     const bool bad1 = __syncthreads_or(b1), bad2 = __syncthreads_or(b2);
-    (void)dimc;
-    const bool ok = chol<R>(Lb, ld, n, skip, invd, dg, flag, tid);
-    trsm_l<R>(Lb, ld, n, invd, rr, 2, 2, tid);
-    R q1 = 0, q2 = 0, ldt = 0, dm = 0;
+    R hl;
+    const bool ok = spd_solve<R>(Z, ldz, n, nct, skip, rowbuf, piv, &hl, tid);
+    R q1 = 0, q2 = 0;
     for (int k = tid; k < n; k += NT) {
-        q1 += rr[2 * k] * rr[2 * k];
-        q2 += rr[2 * k + 1] * rr[2 * k + 1];
-        const bool sk = skip && skip[k];
-        ldt += sk ? (R)0 : log_(Lb[k * ld + k]);
-        dm += sk ? (R)0 : (R)1;
+        q1 += r1[k] * Z[k * ldz + n];
+        if (r2) q2 += r2[k] * Z[k * ldz + n + 1];
     }
-    R* red = dg;  // dg is free once the factor is final (n >= 1 reals... NWV needed: callers size dg with >= NWV)
-    q1 = block_sum<R>(q1, red, tid);
-    q2 = block_sum<R>(q2, red, tid);
-    const R logdet = block_sum<R>(ldt, red, tid);
-    const R dimr = block_sum<R>(dm, red, tid);
-    const R cst = -logdet - (R)(0.5 * LOG_2PI) * dimr;
+    q1 = block_sum<R>(q1, rowbuf, tid);
+    q2 = block_sum<R>(q2, rowbuf, tid);
+    const R dimr = block_sum<R>(dm, rowbuf, tid);
+    const R cst = -hl - (R)(0.5 * LOG_2PI) * dimr;
     o1 = ok ? (R)-0.5 * q1 + cst : r_nan<R>();
     o2 = ok ? (R)-0.5 * q2 + cst : r_nan<R>();
     if (bad1 || isnan_(o1)) o1 = 0;
@@ -1091,24 +1182,22 @@ __device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* sk
 // joint log-density (base.py:99-166): item (s, t): observation term at t + transition into t (t >= 1) or initial term (t = 0)
 static size_t lds_logpdf(size_t s, int d, int p) {
     const int n = std::max(d, p);
-    return al16(n * (size_t)ldp_(n) * s) + 4 * al16(d * s) + 5 * al16(n * s) + al16(n) + 512;
+    return al16(n * (size_t)ldp_(n + 2) * s) + 4 * al16(d * s) + 3 * al16(n * s) + al16((2 * (n + 3) + NWV) * s) + al16(n) + 512;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs a, R* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, p = a.dy, T = a.d.T, nmax = d > p ? d : p;
     const int s = blockIdx.x / T, t = blockIdx.x - s * T, c = s / a.d.B, b = s % a.d.B;
     Bump L{smem};
-    R* Lb = L.take<R>(nmax * ldp_(nmax));
+    R* Lb = L.take<R>(nmax * ldp_(nmax + 2));
     R* x = L.take<R>(d);
     R* xq = L.take<R>(d);
     R* rd_ = L.take<R>(d);
     (void)L.take<R>(d);
     R* ro = L.take<R>(nmax);
-    R* invd = L.take<R>(nmax);
-    R* dg = L.take<R>(nmax > NWV ? nmax : NWV);
-    R* rr = L.take<R>(2 * nmax);
+    R* piv = L.take<R>(nmax);
+    R* rowbuf = L.take<R>(2 * (nmax + 3) + NWV);
     unsigned char* skip = L.take<unsigned char>(nmax);
-    int* flag = L.take<int>(1);
     load_vec<R>(x, at<R>(a.xs, c, t, b), d, tid);
     const R* Hg = at<R>(a.Hs, c, t, b);
     const R* cg = at<R>(a.cs, c, t, b);
@@ -1120,12 +1209,12 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs
     }
     __syncthreads();
     R o_obs, o_dyn, dummy;
-    gauss2<R>(at<R>(a.Rs, c, t, b), p, a.nan_policy == 1 ? skip : nullptr, ro, nullptr, Lb, invd, dg, rr, flag, tid, o_obs, dummy);
+    gauss2<R>(at<R>(a.Rs, c, t, b), p, a.nan_policy == 1 ? skip : nullptr, ro, nullptr, Lb, piv, rowbuf, tid, o_obs, dummy);
     if (t == 0) {
         const R* m0 = at<R>(a.m0, c, 0, b);
         for (int k = tid; k < d; k += NT) rd_[k] = x[k] - m0[k];
         __syncthreads();
-        gauss2<R>(at<R>(a.P0, c, 0, b), d, nullptr, rd_, nullptr, Lb, invd, dg, rr, flag, tid, o_dyn, dummy);
+        gauss2<R>(at<R>(a.P0, c, 0, b), d, nullptr, rd_, nullptr, Lb, piv, rowbuf, tid, o_dyn, dummy);
     } else {
         load_vec<R>(xq, at<R>(a.xs, c, t - 1, b), d, tid);
         const R* Fg = at<R>(a.Fs, c, t - 1, b);
@@ -1133,7 +1222,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs
         gemv_rows<R>(d, d, Fg, d, xq, rd_, tid);
         for (int k = tid; k < d; k += NT) rd_[k] = x[k] - (rd_[k] + bg[k]);
         __syncthreads();
-        gauss2<R>(at<R>(a.Qs, c, t - 1, b), d, nullptr, rd_, nullptr, Lb, invd, dg, rr, flag, tid, o_dyn, dummy);
+        gauss2<R>(at<R>(a.Qs, c, t - 1, b), d, nullptr, rd_, nullptr, Lb, piv, rowbuf, tid, o_dyn, dummy);
     }
     if (tid == 0) part[(long long)s * T + t] = o_obs + o_dyn;
 }
@@ -1141,14 +1230,14 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_logpdf(LogpdfArgs
 // the five sums of one sweep of the LG_CONCAT device model (body_sweep_logpdf of kalman_bodies.h); part [5][C][T]
 static size_t lds_sweep_logpdf(size_t s, int d, int po) {
     const int n = std::max(d, po);
-    return al16(n * (size_t)ldp_(n) * s) + 7 * al16(d * s) + 6 * al16(n * s) + al16(n) + 512;
+    return al16(n * (size_t)ldp_(n + 2) * s) + 7 * al16(d * s) + 4 * al16(n * s) + al16((2 * (n + 3) + NWV) * s) + al16(n) + 512;
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(SweepLogpdfArgs a, R* __restrict__ part) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, po = a.po, T = a.d.T, C = a.d.C, nmax = d > po ? d : po;
     const int c = blockIdx.x / T, t = blockIdx.x - c * T;
     Bump L{smem};
-    R* Lb = L.take<R>(nmax * ldp_(nmax));
+    R* Lb = L.take<R>(nmax * ldp_(nmax + 2));
     R* x = L.take<R>(d);
     R* xp = L.take<R>(d);
     R* u = L.take<R>(d);
@@ -1158,11 +1247,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
     R* d2 = L.take<R>(d);
     R* r1 = L.take<R>(nmax);
     R* r2 = L.take<R>(nmax);
-    R* invd = L.take<R>(nmax);
-    R* dg = L.take<R>(nmax > NWV ? nmax : NWV);
-    R* rr = L.take<R>(2 * nmax);
+    R* piv = L.take<R>(nmax);
+    R* rowbuf = L.take<R>(2 * (nmax + 3) + NWV);
     unsigned char* skip = L.take<unsigned char>(nmax);
-    int* flag = L.take<int>(1);
     load_vec<R>(x, at<R>(a.x, c, t, 0), d, tid);
     load_vec<R>(xp, at<R>(a.xp, c, t, 0), d, tid);
     load_vec<R>(u, at<R>(a.u, c, t, 0), d, tid);
@@ -1181,7 +1268,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
     }
     const bool badobs_p = __syncthreads_or(bp), badobs_x = __syncthreads_or(bx);
     R ob_p, ob_x, pr_p, pr_x;
-    gauss2<R>(at<R>(a.Rs, c, t, 0), po, a.nan_policy == 1 ? skip : nullptr, r1, r2, Lb, invd, dg, rr, flag, tid, ob_p, ob_x);
+    gauss2<R>(at<R>(a.Rs, c, t, 0), po, a.nan_policy == 1 ? skip : nullptr, r1, r2, Lb, piv, rowbuf, tid, ob_p, ob_x);
     // auxiliary block N(u; x, delta/2 I) and the MH correction (generic.py:103-105)
     const R hd = (R)(0.5 * a.delta), sd = sqrt_(hd);
     R q1 = 0, q2 = 0, corr = 0;
@@ -1197,9 +1284,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
         corr += (f1 * f1 - f2 * f2) / (R)a.delta;
     }
     const bool b1 = __syncthreads_or(ib1), b2 = __syncthreads_or(ib2);
-    q1 = block_sum<R>(q1, dg, tid);
-    q2 = block_sum<R>(q2, dg, tid);
-    corr = block_sum<R>(corr, dg, tid);
+    q1 = block_sum<R>(q1, rowbuf, tid);
+    q2 = block_sum<R>(q2, rowbuf, tid);
+    corr = block_sum<R>(corr, rowbuf, tid);
     const R cst = -(R)d * log_(sd) - (R)(0.5 * LOG_2PI) * (R)d;
     const R ax_p = b1 ? (R)0 : (R)-0.5 * q1 + cst, ax_x = b2 ? (R)0 : (R)-0.5 * q2 + cst;
     const bool ref = a.nan_policy == 0;
@@ -1209,7 +1296,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
         const R* m0 = at<R>(a.m0, c, 0, 0);
         for (int k = tid; k < d; k += NT) d1[k] = xp[k] - m0[k], d2[k] = x[k] - m0[k];
         __syncthreads();
-        gauss2<R>(at<R>(a.P0, c, 0, 0), d, nullptr, d1, d2, Lb, invd, dg, rr, flag, tid, pr_p, pr_x);
+        gauss2<R>(at<R>(a.P0, c, 0, 0), d, nullptr, d1, d2, Lb, piv, rowbuf, tid, pr_p, pr_x);
     } else {
         load_vec<R>(xq, at<R>(a.x, c, t - 1, 0), d, tid);
         load_vec<R>(xpq, at<R>(a.xp, c, t - 1, 0), d, tid);
@@ -1222,7 +1309,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
             d2[k] = x[k] - (d2[k] + bg[k]);
         }
         __syncthreads();
-        gauss2<R>(at<R>(a.Qs, c, t - 1, 0), d, nullptr, d1, d2, Lb, invd, dg, rr, flag, tid, pr_p, pr_x);
+        gauss2<R>(at<R>(a.Qs, c, t - 1, 0), d, nullptr, d1, d2, Lb, piv, rowbuf, tid, pr_p, pr_x);
     }
     if (tid == 0) {
         const long long CT = (long long)C * T, o = (long long)c * T + t;
@@ -1390,6 +1477,15 @@ bool wide_fits(int dtype, int dx, int dy, std::string* why) {
     const size_t s = dtype == AUXSSM_F32 ? 4 : 8;
     size_t need = std::max(wide::lds_combine(s, dx), wide::lds_sample_init(s, dx));
     if (dy > 0) need = std::max({need, wide::lds_filter_init(s, dx, dy), wide::lds_filter_t0(s, dx, dy), wide::lds_filter_ell(s, dx, dy), wide::lds_logpdf(s, dx, dy)});
+    const bool regs_ok = dx <= 8 * wide::NWV && 3 * dx + 1 <= 256 && (dy == 0 || (dy <= 8 * wide::NWV && dy + dx + 2 <= 256));
+    if (!regs_ok) {
+        if (why) {
+            char buf[256];
+            snprintf(buf, sizeof buf, "(dx=%d, dy=%d) exceeds the register-resident solves of the wide-state path (LDS / register plan: dx <= 85, dy + dx <= 254)", dx, dy);
+            *why = buf;
+        }
+        return false;
+    }
     if (need <= wide::LDS_BUDGET) return true;
     if (why) {
         char buf[256];

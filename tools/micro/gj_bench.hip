@@ -8,7 +8,7 @@ template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long
     Bump L{smem};
     const int nct = 3 * d + 1, ldz = ldp_(nct);
     R* Z = L.take<R>(d * ldz);
-    R* rowbuf = L.take<R>(nct + 1);
+    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
     R* pinv = L.take<R>(d);
     int* iperm = L.take<int>(d);
     unsigned int* key = L.take<unsigned int>(2);
@@ -19,7 +19,7 @@ template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long
     for (int it = 0; it < iters; ++it) {
         for (int r = tid / 64; r < d; r += NWV)
             for (int c = tid & 63; c < nct; c += 64) Z[r * ldz + c] = (r == c ? (R)(d + 1) : (R)0) + (R)(((r * 131 + c * 71 + it) % 17) - 8) * (R)0.05;
-        if (mode == 1)  // SPD for the Cholesky: make the leading block symmetric
+        if (mode == 1 || mode == 4)  // SPD for the Cholesky: make the leading block symmetric
             for (int r = tid / 64; r < d; r += NWV)
                 for (int c = tid & 63; c < r; c += 64) Z[r * ldz + c] = Z[c * ldz + r];
         __syncthreads();
@@ -28,6 +28,7 @@ template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long
         if (mode == 1) (void)chol<R>(Z, ldz, d, nullptr, invd, dg, flag, tid);
         if (mode == 2) trsm_l<R>(Z, ldz, d, pinv, Z + d, ldz, d + 2, tid);
         if (mode == 3) gemm<false, false>(d, d, d, Z, ldz, Z + d, ldz, Z + 2 * d, ldz, (R)1, (R)0, tid);
+        if (mode == 4) (void)spd_solve<R>(Z, ldz, d, 2 * d + 2, nullptr, rowbuf, pinv, (R*)nullptr, tid);
         tot += clock64() - t0;
     }
     if (tid == 0) cyc[0] = tot;
@@ -39,8 +40,8 @@ int main() {
     const int d = 64, iters = 50;
     const size_t lds = 120 * 1024;
     hipFuncSetAttribute((const void*)kb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const char* names[] = {"gj_solve [W|A|C|v]", "chol", "trsm_l (d+2 cols)", "gemm 64^3"};
-    for (int mode = 0; mode < 4; ++mode) {
+    const char* names[] = {"gj_solve [W|A|C|v]", "chol", "trsm_l (d+2 cols)", "gemm 64^3", "spd_solve [S|H|r|r]"};
+    for (int mode = 0; mode < 5; ++mode) {
         hipLaunchKernelGGL(kb<float>, dim3(1), dim3(NT), lds, 0, out, cyc, d, iters, mode);
         hipDeviceSynchronize();
         long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
