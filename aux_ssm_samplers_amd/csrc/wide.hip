@@ -849,6 +849,44 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_aggs(const R
         if (ch + 1 < nchunk) combine<R>(g, aggs + ((long long)s * nchunk + ch) * ne, d, true, tid);
     }
 }
+// second level: exclusive (b, C) prefixes of a run of aggregates.  Workgroup (s, c1) walks aggregates [c1 E1, min(n0, (c1+1) E1)) of
+// sequence s; its own incoming prefix is pre1[s][c1] (exclusive prefix over the level-1 chunks, c1 >= 1).  pre0[s][i] = (b, C) of
+// aggs0[0] (+) ... (+) aggs0[i-1] for i >= 1.
+template <typename R>
+__global__ void __launch_bounds__(NT) wk_scan_down_pre(const R* __restrict__ aggs0, const R* __restrict__ pre1, R* __restrict__ pre0, int n0, int E1,
+                                                       int nchunk1, int d) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, s = blockIdx.x / nchunk1, c1 = blockIdx.x - s * nchunk1;
+    Bump L{smem};
+    Agg<R> g;
+    carve_combine<R>(L, g, d, false);
+    const long long ne = fe_size(d), np = (long long)d * d + d;
+    const int i0 = c1 * E1, i1 = min(n0, i0 + E1);
+    bool have = false;
+    if (c1 > 0) {
+        const R* q = pre1 + ((long long)s * nchunk1 + c1) * np;
+        load_vec<R>(g.b, q, d, tid);
+        load_mat<R>(g.C, g.ldz, q + d, d, d, tid);
+        have = true;
+    }
+    for (int i = i0; i < i1; ++i) {
+        if (i > 0) {
+            R* q = pre0 + ((long long)s * n0 + i) * np;
+            for (int k = tid; k < d; k += NT) q[k] = g.b[k];
+            store_mat<R>(q + d, g.C, g.ldz, d, d, tid);
+            __syncthreads();
+        }
+        if (i + 1 < i1) {  // the prefix after the chunk's last aggregate belongs to the next workgroup
+            const R* e = aggs0 + ((long long)s * n0 + i) * ne;
+            if (have) combine<R>(g, e, d, false, tid);
+            else {
+                agg_load<R>(g, e, d, tid);
+                have = true;
+            }
+        }
+    }
+}
+
 // down-sweep: filtered moments ms[i + 1], Ps[i + 1] = (b, C) of the inclusive prefix i
 template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterArgs a, const R* __restrict__ elem, const R* __restrict__ pre, int E, int nchunk) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1323,10 +1361,11 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 struct WPlan {
-    int E, nchunk;
+    int E, nchunk;    // level 0: chunks of E consecutive elements
+    int E1, nchunk1;  // level 1 (filter scan only): chunks of E1 consecutive level-0 aggregates; nchunk1 = 1: single level
 };
 static WPlan plan(const auxssm_ctx* h, int S, int n, int parallel) {
-    WPlan p{n > 0 ? n : 1, 1};
+    WPlan p{n > 0 ? n : 1, 1, 1, 1};
     if (!parallel || n <= 3) return p;
     long long nchunk = ((long long)2 * h->num_cu + S - 1) / S;
     const long long cap = (long long)std::sqrt(2.0 * n);
@@ -1337,6 +1376,11 @@ static WPlan plan(const auxssm_ctx* h, int S, int n, int parallel) {
     }
     p.E = (int)((n + nchunk - 1) / nchunk);
     p.nchunk = (n + p.E - 1) / p.E;
+    p.E1 = p.nchunk;
+    if (p.nchunk >= 16 && !getenv("AUXSSM_WIDE_ONE_LEVEL")) {  // the aggregate scan is sequential per sequence: split it once more
+        p.E1 = (int)std::ceil(std::sqrt(1.6 * p.nchunk));
+        p.nchunk1 = (p.nchunk + p.E1 - 1) / p.E1;
+    }
     return p;
 }
 
@@ -1359,7 +1403,7 @@ template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims
     const int S = kd.S(), n = kd.n();
     const WPlan p = plan(h, S, n, parallel);
     const size_t ne = (size_t)fe_size(d);
-    return ((size_t)S * std::max(n, 1) * ne + (size_t)S * p.nchunk * (ne + (size_t)d * d + d) + (size_t)S * (std::max(n, 1) + 1)) * sizeof(R) + 4096;
+    return ((size_t)S * std::max(n, 1) * ne + (size_t)S * (p.nchunk + p.nchunk1) * (ne + (size_t)d * d + d) + (size_t)S * (std::max(n, 1) + 1)) * sizeof(R) + 8192;
 }
 
 template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int parallel, void* ell_out) {
@@ -1369,9 +1413,11 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
     R* elem = (R*)ws_take(h, (size_t)S * std::max(n, 1) * ne * sizeof(R));
     R* aggs = (R*)ws_take(h, (size_t)S * pl.nchunk * ne * sizeof(R));
     R* pre = (R*)ws_take(h, (size_t)S * pl.nchunk * np * sizeof(R));
+    R* aggs1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * ne * sizeof(R));
+    R* pre1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * np * sizeof(R));
     R* ell0 = (R*)ws_take(h, (size_t)S * sizeof(R));
     R* ellinc = (R*)ws_take(h, (size_t)S * std::max(n, 1) * sizeof(R));
-    if (!elem || !aggs || !pre || !ell0 || !ellinc) return AUXSSM_ERR_NOMEM;
+    if (!elem || !aggs || !pre || !aggs1 || !pre1 || !ell0 || !ellinc) return AUXSSM_ERR_NOMEM;
     FilterArgs fa = a;
     fa.ell0 = ell0;
     {
@@ -1385,7 +1431,13 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
             if (pl.nchunk > 1) {
                 WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk, lc, (const R*)elem, aggs, n, pl.E, pl.nchunk, d);
-                WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs, pre, pl.nchunk, d);
+                if (pl.nchunk1 > 1) {  // second level over the chunk aggregates: the sequential aggregate scan shrinks from nchunk to nchunk1
+                    WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk1, lc, (const R*)aggs, aggs1, pl.nchunk, pl.E1, pl.nchunk1, d);
+                    WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs1, pre1, pl.nchunk1, d);
+                    WK_LAUNCH((wk_scan_down_pre<R>), (long long)S * pl.nchunk1, lc, (const R*)aggs, (const R*)pre1, pre, pl.nchunk, pl.E1, pl.nchunk1, d);
+                } else {
+                    WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs, pre, pl.nchunk, d);
+                }
             }
             WK_LAUNCH((wk_scan_down<R>), (long long)S * pl.nchunk, lc, fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
         }
