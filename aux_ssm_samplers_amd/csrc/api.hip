@@ -194,7 +194,7 @@ static void fill_filter_args(FilterArgs& a, const auxssm_dims* d, const auxssm_l
     a.m0 = cv(g->m0); a.P0 = cv(g->P0); a.Fs = cv(g->Fs); a.Qs = cv(g->Qs); a.bs = cv(g->bs);
     a.Hs = cv(g->Hs); a.Rs = cv(g->Rs); a.cs = cv(g->cs); a.ys = cv(*ys);
     a.ms = dense_arr(ms, a.d, d->dx); a.Ps = dense_arr(Ps, a.d, (long long)d->dx * d->dx);
-    a.elem = nullptr; a.ell0 = nullptr;
+    a.elem = nullptr; a.ell0 = nullptr; a.ellz = nullptr;
     a.lay = ScanLayout{1, 1, 1, 1, 0, d->C * d->B};
     a.pblk = 0;
     a.dx = d->dx; a.dy = d->dy;

@@ -105,7 +105,8 @@ struct FilterArgs {
     Arr ms;         // (C,T,B,D): dense, or chain-minor inside the fused sweep
     Arr Ps;         // (C,T,B,D,D)
     void* elem;     // scan elements, layout `lay`
-    void* ell0;     // [S]
+    void* ell0;     // [S] log-likelihood term of the t = 0 update
+    void* ellz;     // [S] log-scale of the whole scan = sum of the increments of t = 1..T-1 (written by the final pass)
     ScanLayout lay;
     int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
@@ -235,6 +236,7 @@ template <typename R_, int D> struct FilterOp {
         for (int i = 0; i < D; ++i) e.b[i] = t[D * D + i], e.eta[i] = t[D * D + D + DS + i];
 #pragma unroll
         for (int i = 0; i < DS; ++i) e.C[i] = t[D * D + D + i], e.J[i] = t[D * D + 2 * D + DS + i];
+        e.z = t[Full::N - 1];
     }
     static AX_HD void load_rec(const R* p, Full& e) { fe_load<R, D>(p, e); }
     static AX_HD void store_rec(R* p, const Full& e) { fe_store<R, D>(p, e); }
@@ -245,22 +247,25 @@ template <typename R_, int D> struct FilterOp {
         for (int i = 0; i < D; ++i) p.b[i] = f.b[i];
 #pragma unroll
         for (int i = 0; i < DS; ++i) p.C[i] = f.C[i];
+        p.z = f.z;
     }
     static AX_HD void store_pre(R* q, const Pre& p) {
-        R t[D + DS];
+        R t[D + DS + 1];
 #pragma unroll
         for (int i = 0; i < D; ++i) t[i] = p.b[i];
 #pragma unroll
         for (int i = 0; i < DS; ++i) t[D + i] = p.C[i];
-        stv<R, D + DS>(q, t);
+        t[D + DS] = p.z;
+        stv<R, D + DS + 1>(q, t);
     }
     static AX_HD void load_pre(const R* q, Pre& p) {
-        R t[D + DS];
-        ldv<R, D + DS>(q, t);
+        R t[D + DS + 1];
+        ldv<R, D + DS + 1>(q, t);
 #pragma unroll
         for (int i = 0; i < D; ++i) p.b[i] = t[i];
 #pragma unroll
         for (int i = 0; i < DS; ++i) p.C[i] = t[D + i];
+        p.z = t[D + DS];
     }
     static AX_HD void apply(const Pre& p, const Full& e, Pre& o) { filter_apply<R, D>(p, e, o); }
     // inclusive prefix i  ->  filtered moments at time i + 1
@@ -270,6 +275,7 @@ template <typename R_, int D> struct FilterOp {
         R Pd[D * D];
         symunpack<R, D>(p.C, Pd);
         wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
+        if (i == a.d.n() - 1 && a.ellz) ((R*)a.ellz)[s] = p.z;  // scale of the full product = log p(y_1..T-1 | y_0)
     }
     // element i of sequence s in either element layout
     static AX_HD void store_elem(const Args& a, int s, int i, const Full& e) {
@@ -299,6 +305,7 @@ template <typename R_, int D> struct FilterOp {
         for (int i = 0; i < D; ++i) t[D * D + i] = e.b[i], t[D * D + D + DS + i] = e.eta[i];
 #pragma unroll
         for (int i = 0; i < DS; ++i) t[D * D + D + i] = e.C[i], t[D * D + 2 * D + DS + i] = e.J[i];
+        t[Full::N - 1] = e.z;
     }
 };
 

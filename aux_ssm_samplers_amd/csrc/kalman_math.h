@@ -8,11 +8,15 @@ namespace ax {
 
 // ------------------------------------------------------------------------------------------------
 // Scan element of the parallel filter: (A, b, C, eta, J), C and J symmetric-packed.
-// Memory record: [A (D*D) | b (D) | C (DS) | eta (D) | J (DS)], padded to FE_PAD reals.
+// Memory record: [A (D*D) | b (D) | C (DS) | eta (D) | J (DS) | z], padded to NPAD reals.
 // ------------------------------------------------------------------------------------------------
+// z = log of the element's scale factor: the element is the function  exp(z) N(x_k; A x_{k-1} + b, C) exp(eta^T x_{k-1} - x_{k-1}^T J x_{k-1} / 2)
+// of (x_{k-1}, x_k) (Sarkka & Garcia-Fernandez 2021, eq. 12-13, with the normaliser the reference drops).  Carrying it through the
+// scan makes the marginal log-likelihood the z of the total product, so the reference's second pass over the filtered moments
+// (filtering.py:60-62) is not needed: same number, no extra memory pass.
 template <typename R, int D> struct FiltElem {
     static constexpr int DS = symsize(D);
-    static constexpr int N = D * D + 2 * D + 2 * DS;
+    static constexpr int N = D * D + 2 * D + 2 * DS + 1;
     static constexpr int VEC = 16 / sizeof(R);
     static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
     R A[D * D];
@@ -20,15 +24,17 @@ template <typename R, int D> struct FiltElem {
     R C[DS];
     R eta[D];
     R J[DS];
+    R z;
 };
 // Reduced prefix that the final pass carries: only (b, C) = filtered (mean, cov) (filtering.py:55 discards the rest)
 template <typename R, int D> struct FiltPre {
     static constexpr int DS = symsize(D);
-    static constexpr int N = D + DS;
+    static constexpr int N = D + DS + 1;
     static constexpr int VEC = 16 / sizeof(R);
     static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
     R b[D];
     R C[DS];
+    R z;  // log-scale of the prefix = log p(y_1..k) (plus the t = 0 term added by the caller)
 };
 
 // records are 16-byte aligned (NPAD, workspace carve): whole-record 16-byte vector loads/stores
@@ -42,6 +48,7 @@ template <typename R, int D> AX_HD void fe_store(R* __restrict__ p, const FiltEl
     for (int i = 0; i < D; ++i) t[D * D + i] = e.b[i], t[D * D + D + DS + i] = e.eta[i];
 #pragma unroll
     for (int i = 0; i < DS; ++i) t[D * D + D + i] = e.C[i], t[D * D + 2 * D + DS + i] = e.J[i];
+    t[N - 1] = e.z;
     stv<R, N>(p, t);
 }
 template <typename R, int D> AX_HD void fe_load(const R* __restrict__ p, FiltElem<R, D>& e) {
@@ -55,6 +62,7 @@ template <typename R, int D> AX_HD void fe_load(const R* __restrict__ p, FiltEle
     for (int i = 0; i < D; ++i) e.b[i] = t[D * D + i], e.eta[i] = t[D * D + D + DS + i];
 #pragma unroll
     for (int i = 0; i < DS; ++i) e.C[i] = t[D * D + D + i], e.J[i] = t[D * D + 2 * D + DS + i];
+    e.z = t[N - 1];
 }
 template <typename R, int D> AX_HD void fe_identity(FiltElem<R, D>& e) {
 #pragma unroll
@@ -63,6 +71,7 @@ template <typename R, int D> AX_HD void fe_identity(FiltElem<R, D>& e) {
     for (int i = 0; i < D; ++i) e.b[i] = 0, e.eta[i] = 0;
 #pragma unroll
     for (int i = 0; i < symsize(D); ++i) e.C[i] = 0, e.J[i] = 0;
+    e.z = 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -293,6 +302,7 @@ AX_HD void filter_elem(const R* F, const R* bdyn, const R* m_, const R* P_, cons
         sympack<R, D>(P_, e.C);
 #pragma unroll
         for (int i = 0; i < symsize(D); ++i) e.J[i] = 0;
+        e.z = 0;
         return;
     }
     // Information form of the same element.  With L L^T = S and W = L^-1 H_ (p x d):
@@ -320,6 +330,17 @@ AX_HD void filter_elem(const R* F, const R* bdyn, const R* m_, const R* P_, cons
     for (int j = 0; j < D; ++j) lsolve_col<R, P, D>(L, invd, H_, j);  // H_ <- W = L^-1 H_
     lsolve<R, P>(L, invd, rm);
     lsolve<R, P>(L, invd, rb);
+    {  // log N(y; H_ m_ + c_, S): the element's scale (== the ell increment of sequential_update, filtering.py:106-114)
+        R q = 0, logdet = 0;
+        int dim = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            q += rm[k] * rm[k];
+            logdet += nan[k] ? (R)0 : log_(L[lidx(k, k)]);
+            dim += nan[k] ? 0 : 1;
+        }
+        e.z = ok ? (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim : r_nan<R>();
+    }
     R M[symsize(D)], vm[D], vb[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -420,6 +441,7 @@ AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, 
         sympack<R, D>(P_, e.C);
 #pragma unroll
         for (int i = 0; i < symsize(D); ++i) e.J[i] = 0;
+        e.z = 0;
         return;
     }
     R Lam[symsize(D)], gm[D], gb[D];
@@ -447,7 +469,15 @@ AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, 
         B[i * NR + D] = gm[i];
         B[i * NR + D + 1] = gb[i];
     }
-    lu_solve<R, D, NR>(W2, B);
+    const R ldw = lu_solve_logdet<R, D, NR>(W2, B);
+    {  // scale = log N(rm; 0, S) by the determinant / Woodbury identities above (same value as kalman_ell_inc_blk)
+        R Pg[D];
+        mv<R, D, D>(P_, gm, Pg);
+        R corr = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) corr += Pg[i] * B[i * NR + D];
+        e.z = ok ? (R)-0.5 * (q - corr) - logdet - (R)0.5 * ldw - (R)(0.5 * LOG_2PI) * (R)dim : r_nan<R>();
+    }
     R M[symsize(D)], vm[D], vb[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -525,6 +555,8 @@ AX_HD void filter_combine(const FiltElem<R, D>& a1, const FiltElem<R, D>& a2, Fi
         o.C[0] = M * (a1.C[0] * a2.A[0]) + a2.C[0];
         o.eta[0] = Nn * (a2.eta[0] - a2.J[0] * a1.b[0]) + a1.eta[0];
         o.J[0] = Nn * (a2.J[0] * a1.A[0]) + a1.J[0];
+        const R u = a1.b[0] / w, v = a1.C[0] * a2.eta[0] / w;
+        o.z = a1.z + a2.z - (R)0.5 * log_(abs_(w)) + a2.eta[0] * u + (R)0.5 * a2.eta[0] * v - (R)0.5 * (a2.J[0] * a1.b[0]) * u;
     } else {
         constexpr int NR = 2 * D + 1;
         R W[D * D], B[D * NR];
@@ -548,11 +580,23 @@ AX_HD void filter_combine(const FiltElem<R, D>& a1, const FiltElem<R, D>& a2, Fi
             }
             B[i * NR + 2 * D] = a1.b[i] + v[i];
         }
-        lu_solve<R, D, NR>(W, B);  // B = [X | Y | z]
+        const R ldw = lu_solve_logdet<R, D, NR>(W, B);  // B = [X | Y | z]
         R JA[D * D];
         symm<R, D, D>(a2.J, a1.A, JA);
         R w[D];
         symv<R, D>(a2.J, a1.b, w);
+        {  // scale of the product: z1 + z2 - log|W|/2 + eta2.u + eta2.v/2 - (J2 b1).u/2,  u = W^-1 b1,  v = W^-1 C1 eta2 = Y eta2
+            R t = 0;
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                R vi = 0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) vi += B[i * NR + D + j] * a2.eta[j];
+                const R ui = B[i * NR + 2 * D] - vi;
+                t += a2.eta[i] * ui + (R)0.5 * a2.eta[i] * vi - (R)0.5 * w[i] * ui;
+            }
+            o.z = a1.z + a2.z - (R)0.5 * ldw + t;
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) w[i] = a2.eta[i] - w[i];
         R AY[D * D];
@@ -607,6 +651,8 @@ AX_HD void filter_apply(const FiltPre<R, D>& p, const FiltElem<R, D>& a2, FiltPr
         const R M = a2.A[0] / w;
         o.b[0] = M * (p.b[0] + p.C[0] * a2.eta[0]) + a2.b[0];
         o.C[0] = M * (p.C[0] * a2.A[0]) + a2.C[0];
+        const R u = p.b[0] / w, v = p.C[0] * a2.eta[0] / w;
+        o.z = p.z + a2.z - (R)0.5 * log_(abs_(w)) + a2.eta[0] * u + (R)0.5 * a2.eta[0] * v - (R)0.5 * (a2.J[0] * p.b[0]) * u;
     } else {
         constexpr int NR = D + 1;
         R W[D * D], B[D * NR];
@@ -627,7 +673,20 @@ AX_HD void filter_apply(const FiltPre<R, D>& p, const FiltElem<R, D>& a2, FiltPr
             for (int j = 0; j < D; ++j) B[i * NR + j] = p.C[sidx(D, i, j)];
             B[i * NR + D] = p.b[i] + v[i];
         }
-        lu_solve<R, D, NR>(W, B);  // [Y | z]
+        const R ldw = lu_solve_logdet<R, D, NR>(W, B);  // [Y | z]
+        {
+            R Jb[D], t = 0;
+            symv<R, D>(a2.J, p.b, Jb);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                R vi = 0;
+#pragma unroll
+                for (int j = 0; j < D; ++j) vi += B[i * NR + j] * a2.eta[j];
+                const R ui = B[i * NR + D] - vi;
+                t += a2.eta[i] * ui + (R)0.5 * a2.eta[i] * vi - (R)0.5 * Jb[i] * ui;
+            }
+            o.z = p.z + a2.z - (R)0.5 * ldw + t;
+        }
         R AY[D * D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {

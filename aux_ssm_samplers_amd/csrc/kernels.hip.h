@@ -535,9 +535,10 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
     a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
-    // chain-minor: the log-likelihood increments are accumulated by the scan's final pass (FilterOpEll), one partial per chunk
+    // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final
+    // pass writes it per sequence; the reference's second pass over the filtered moments (filtering.py:60-62) does not exist here
+    a.ellz = ws_take(h, (size_t)S * sizeof(R));
     const int nt = cm ? a.lay.nchunk : ntiles(n);
-    R* part = (R*)ws_take(h, (size_t)S * (nt + 1) * sizeof(R));
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     if (n > 0) {
         {
@@ -548,18 +549,12 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-            const int rc = (cm && blk) ? run_scan<FilterOp<R, D>, FilterOpEll<R, D, P, (P > D ? D : 0)>>(h, a, S, n, part)
-                           : cm      ? run_scan<FilterOp<R, D>, FilterOpEll<R, D, P, 0>>(h, a, S, n, part)
-                                     : run_scan<FilterOp<R, D>>(h, a, S, n);
+            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
-        if (!cm) {
-            ProfScope ps(h, AUXSSM_K_FILTER_ELL);
-            hipLaunchKernelGGL((k_filter_ell<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
-        }
     }
-    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0,
-                       a.d.B, n > 0 ? nt : 0, (R*)ell_out);
+    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, n > 0 ? 1 : 0,
+                       (R*)ell_out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

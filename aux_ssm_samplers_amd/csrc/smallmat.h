@@ -285,7 +285,7 @@ template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) { (void)lu_
 // returns log |det W|
 template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B) {
     R ipiv[D];
-    R ld_ = 0;
+    R ld_ = 0, pp = 1;  // log|det| from products of PAIRS of reciprocal pivots: half the logarithms, no under/overflow in practice
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         // bring the largest |W[r][k]|, r >= k, to row k by compare-and-swap (branch-free selects)
@@ -307,7 +307,11 @@ template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B) {
         }
         const R inv = (R)1 / W[k * D + k];
         ipiv[k] = inv;
-        ld_ -= log_(abs_(inv));
+        pp *= abs_(inv);
+        if ((k & 1) == 1 || k == D - 1) {
+            ld_ -= log_(pp);
+            pp = 1;
+        }
 #pragma unroll
         for (int r = k + 1; r < D; ++r) {
             const R f = W[r * D + k] * inv;

@@ -105,9 +105,10 @@ static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E,
         a.ms = dense_arr(ms, a.d, D);
         a.Ps = dense_arr(Ps, a.d, D * D);
     }
-    std::vector<R> elem((size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) + 16), ell0(S);
+    std::vector<R> elem((size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) + 16), ell0(S), ellz(S, (R)0);
     a.elem = elem.data();
     a.ell0 = ell0.data();
+    a.ellz = ellz.data();
     DirectIO io;
     for (int s = 0; s < S; ++s) body_filter_t0<R, D, P>(a, s);
     a.pblk = pblk;
@@ -122,9 +123,7 @@ static int filter_T(int C, int T, int B, const HsArr* g, const HsArr* ys, int E,
         R tot = 0;
         for (int b = 0; b < B; ++b) {
             const int s = c * B + b;
-            R e = ell0[s];
-            for (int i = 0; i < n; ++i) e += (pblk == D && P1 > 0) ? body_filter_ell<R, D, P, DirectIO, P1>(a, io, s, i, true) : body_filter_ell<R, D, P>(a, io, s, i, true);
-            tot += e;
+            tot += ell0[s] + (n > 0 ? ellz[s] : (R)0);  // the scan's log-scale is the marginal log-likelihood of t = 1..T-1
         }
         ((R*)ell)[c] = tot;
     }
