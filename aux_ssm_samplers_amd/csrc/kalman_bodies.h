@@ -180,44 +180,13 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
     FilterOp<R, D>::store_elem(a, s, i, e);
 }
 
-// ---- log-likelihood increment of step i+1 from the filtered moments at i (filtering.py:60) ---------
-template <typename R, int D, int P, class IO, int P1 = 0>
-AX_HD R body_filter_ell(const FilterArgs& a, IO& io, int s, int i, bool valid) {
-    const int c = s / a.d.B, b = s % a.d.B;
-    const long long t = (long long)i + 1;
-    R m[D], Pd[D * D], F[D * D], bd[D], Q[D * D], H[P * D], cv[P], y[P], Rm[P * P];
-    io.template fetch<R, D>(at<R>(a.ms, c, i, b), a.ms.st, a.ms.se, valid, m);
-    io.template fetch<R, D * D>(at<R>(a.Ps, c, i, b), a.Ps.st, a.Ps.se, valid, Pd);
-    io.template fetch<R, D * D>(at<R>(a.Fs, c, i, b), a.Fs.st, a.Fs.se, valid, F);
-    io.template fetch<R, D>(at<R>(a.bs, c, i, b), a.bs.st, a.bs.se, valid, bd);
-    io.template fetch<R, D * D>(at<R>(a.Qs, c, i, b), a.Qs.st, a.Qs.se, valid, Q);
-    io.template fetch<R, P * D>(at<R>(a.Hs, c, t, b), a.Hs.st, a.Hs.se, valid, H);
-    io.template fetch<R, P>(at<R>(a.cs, c, t, b), a.cs.st, a.cs.se, valid, cv);
-    io.template fetch<R, P>(at<R>(a.ys, c, t, b), a.ys.st, a.ys.se, valid, y);
-    io.template fetch_upper<R, P>(at<R>(a.Rs, c, t, b), a.Rs.se, valid, Rm);
-    io.template finish<R, D>(a.ms.st, a.ms.se, valid, m);
-    io.template finish<R, D * D>(a.Ps.st, a.Ps.se, valid, Pd);
-    io.template finish<R, D * D>(a.Fs.st, a.Fs.se, valid, F);
-    io.template finish<R, D>(a.bs.st, a.bs.se, valid, bd);
-    io.template finish<R, D * D>(a.Qs.st, a.Qs.se, valid, Q);
-    io.template finish<R, P * D>(a.Hs.st, a.Hs.se, valid, H);
-    io.template finish<R, P>(a.cs.st, a.cs.se, valid, cv);
-    io.template finish<R, P>(a.ys.st, a.ys.se, valid, y);
-    if (!valid) return (R)0;
-    kalman_predict<R, D>(m, Pd, F, bd, Q);
-    if constexpr (P1 > 0 && P1 < P) return kalman_ell_inc_blk<R, D, P, P1>(m, Pd, H, cv, Rm, y);
-    else return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
-}
-
 // ---- scan operator: parallel filter ----------------------------------------------------------------
 struct ScanBufs {
     void* agg;   // [S][nchunk][Full::NPAD]
     void* pre;   // [S][nchunk][Pre::NPAD]
-    void* hook;  // [S][nchunk] per-chunk sums of Op::hook (ops with HAS_HOOK), else unused
 };
 
 template <typename R_, int D> struct FilterOp {
-    static constexpr bool HAS_HOOK = false;
     using R = R_;
     using Full = FiltElem<R, D>;
     using Pre = FiltPre<R, D>;
@@ -309,40 +278,6 @@ template <typename R_, int D> struct FilterOp {
     }
 };
 
-// FilterOp whose final pass also accumulates the marginal log-likelihood (filtering.py:60-62): while the final pass holds the
-// filtered moments of time i in registers (the prefix BEFORE element i is applied), the increment of step i+1 is
-// log N(y_{i+1}; H m^- + c, S) with (m^-, P^-) = predict(m_i, P_i) -- the same kalman_ell_inc as the separate pass, on the same
-// values, so ell is unchanged; only the extra pass over ms / Ps disappears.
-template <typename R_, int D, int P, int P1 = 0> struct FilterOpEll : FilterOp<R_, D> {
-    static constexpr bool HAS_HOOK = true;
-    using R = R_;
-    using Base = FilterOp<R_, D>;
-    using Pre = typename Base::Pre;
-    static AX_HD R hook(const FilterArgs& a, int s, int i, const Pre& p) {
-        const int c = s / a.d.B, b = s % a.d.B;
-        const long long t = (long long)i + 1;
-        R m[D], Pd[D * D], F[D * D], bd[D], Q[D * D], H[P * D], cv[P], y[P], Rm[P * P];
-        if (i == 0) {  // the prefix of the first element is the identity; the moments at t = 0 come from the t = 0 update
-            rd<R, D>(a.ms, c, 0, b, m);
-            rd<R, D * D>(a.Ps, c, 0, b, Pd);
-        } else {
-#pragma unroll
-            for (int k = 0; k < D; ++k) m[k] = p.b[k];
-            symunpack<R, D>(p.C, Pd);
-        }
-        rd<R, D * D>(a.Fs, c, i, b, F);
-        rd<R, D>(a.bs, c, i, b, bd);
-        rd<R, D * D>(a.Qs, c, i, b, Q);
-        rd<R, P * D>(a.Hs, c, t, b, H);
-        rd<R, P>(a.cs, c, t, b, cv);
-        rd<R, P>(a.ys, c, t, b, y);
-        rd_upper<R, P>(a.Rs, c, t, b, Rm);
-        kalman_predict<R, D>(m, Pd, F, bd, Q);
-        if constexpr (P1 > 0 && P1 < P) return kalman_ell_inc_blk<R, D, P, P1>(m, Pd, H, cv, Rm, y);
-        else return kalman_ell_inc<R, D, P>(m, Pd, H, cv, Rm, y);
-    }
-};
-
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SampleArgs {
     KDims d;
@@ -396,7 +331,6 @@ template <typename R, int D> AX_HD void body_sample_last(const SampleArgs& a, in
 }
 
 template <typename R_, int D> struct SampleOp {
-    static constexpr bool HAS_HOOK = false;
     using R = R_;
     using Full = SampElem<R, D>;
     using Pre = SampPre<R, D>;

@@ -186,49 +186,6 @@ AX_HD R kalman_update(R* m, R* Pd, const R* H, const R* c, const R* __restrict__
     return isnan_(ell) ? (R)0 : ell;
 }
 
-// Log-likelihood increment only (the ell_inc output of sequential_update, filtering.py:106-114,125): the parallel
-// filter's second pass (filtering.py:60-62) discards the updated moments, so the gain is never formed here.
-template <typename R, int D, int P>
-AX_HD R kalman_ell_inc(const R* m, const R* Pd, const R* H, const R* c, const R* __restrict__ Rm, const R* y) {
-    bool nan[P];
-    R H_[P * D], c_[P];
-    const bool any = obs_mask<R, D, P>(y, H, c, nan, H_, c_);
-    if (!any) return (R)0;
-    R yd[P];
-    int dim = 0;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        R yh = c_[k];
-#pragma unroll
-        for (int j = 0; j < D; ++j) yh += H_[k * D + j] * m[j];
-        yd[k] = nan[k] ? (R)0 : y[k] - yh;
-        dim += nan[k] ? 0 : 1;
-    }
-    R L[symsize(P)], invd[P];
-    {
-        R PHt[D * P];
-        innovation_cov<R, D, P>(Pd, H_, Rm, nan, PHt, L);
-    }
-    R ell;
-    if constexpr (P == 1) {
-        const R sd = sqrt_(L[0]);
-        const R z = yd[0] / sd;
-        ell = (R)-0.5 * z * z - log_(sd) - (R)(0.5 * LOG_2PI);
-    } else {
-        const bool ok = chol_inplace<R, P>(L, invd, nan);
-        R logdet = 0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) logdet += nan[k] ? (R)0 : log_(L[lidx(k, k)]);
-        lsolve<R, P>(L, invd, yd);
-        R q = 0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) q += yd[k] * yd[k];
-        ell = (R)-0.5 * q - logdet - (R)(0.5 * LOG_2PI) * (R)dim;
-        if (!ok) ell = r_nan<R>();
-    }
-    return isnan_(ell) ? (R)0 : ell;
-}
-
 // sequential_predict (filtering.py:134-139)
 template <typename R, int D> AX_HD void kalman_predict(R* m, R* Pd, const R* F, const R* b, const R* Q) {
     R t[D], FP[D * D], Pn[D * D];
@@ -470,7 +427,7 @@ AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, 
         B[i * NR + D + 1] = gb[i];
     }
     const R ldw = lu_solve_logdet<R, D, NR>(W2, B);
-    {  // scale = log N(rm; 0, S) by the determinant / Woodbury identities above (same value as kalman_ell_inc_blk)
+    {  // scale = log N(rm; 0, S) by the determinant / Woodbury identities above (log|S| = log|R| + log|I + Lam P|, r^T S^-1 r = r^T R^-1 r - g^T P (I + Lam P)^-1 g)
         R Pg[D];
         mv<R, D, D>(P_, gm, Pg);
         R corr = 0;
@@ -487,54 +444,6 @@ AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, 
         for (int j = i; j < D; ++j) M[sidx_u(D, i, j)] = ok ? ((i == j) ? B[i * NR + i] : (R)0.5 * (B[i * NR + j] + B[j * NR + i])) : r_nan<R>();
     }
     filter_elem_from_info<R, D>(F, m_, P_, M, vm, vb, e);
-}
-
-// log-likelihood increment, block-diagonal R (same value as kalman_ell_inc)
-template <typename R, int D, int P, int P1>
-AX_HD R kalman_ell_inc_blk(const R* m, const R* Pd, const R* H, const R* c, const R* Rm, const R* y) {
-    bool nan[P];
-    bool any = false;
-    R r[P];
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        nan[k] = !finite_(y[k]);
-        any = any || !nan[k];
-        R hm = c[k];
-#pragma unroll
-        for (int j = 0; j < D; ++j) hm += H[k * D + j] * m[j];
-        r[k] = y[k] - hm;
-    }
-    if (!any) return (R)0;
-    R Lam[symsize(D)], g[D], g2[D];
-#pragma unroll
-    for (int i = 0; i < symsize(D); ++i) Lam[i] = 0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) g[i] = 0, g2[i] = 0;
-    R q = 0, logdet = 0;
-    int dim = 0;
-    bool ok = info_block<R, D, P, 0, P1>(H, Rm, nan, r, r, Lam, g, g2, q, logdet, dim);
-    ok = info_block<R, D, P, P1, P - P1>(H, Rm, nan, r, r, Lam, g, g2, q, logdet, dim) && ok;
-    R W2[D * D], z[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        z[i] = g[i];
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            R s = (i == j) ? (R)1 : (R)0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) s += Lam[sidx(D, i, k)] * Pd[k * D + j];
-            W2[i * D + j] = s;
-        }
-    }
-    const R ldw = lu_solve_logdet<R, D, 1>(W2, z);  // z = (I + Lam P)^-1 g
-    R Pg[D];
-    mv<R, D, D>(Pd, g, Pg);
-    R corr = 0;
-#pragma unroll
-    for (int i = 0; i < D; ++i) corr += Pg[i] * z[i];
-    R ell = (R)-0.5 * (q - corr) - logdet - (R)0.5 * ldw - (R)(0.5 * LOG_2PI) * (R)dim;
-    if (!ok) ell = r_nan<R>();
-    return isnan_(ell) ? (R)0 : ell;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -122,18 +122,6 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
     body_filter_init<R, D, P>(a, io, s, i, true);
 }
 
-template <typename R, int D, int P>
-__global__ void __launch_bounds__(TB_ELEM) k_filter_ell(FilterArgs a, R* __restrict__ part, int ntile) {
-    __shared__ R sh[TB_ELEM];
-    int tile, s;
-    decode_tile_seq(a.d.S(), tile, s);
-    if (tile >= ntile) return;
-    const int i = tile * TB_ELEM + threadIdx.x;
-    DirectIO io;
-    const R v = body_filter_ell<R, D, P>(a, io, s, i, i < a.d.n());
-    const R tot = block_sum<R, TB_ELEM>(v, sh);
-    if (threadIdx.x == 0) part[(long long)s * ntile + tile] = tot;
-}
 
 // lanes over i = t - 1; the t = 0 terms are added by lane 0 of tile 0
 template <typename R, int D, int P>
@@ -312,22 +300,7 @@ __global__ void __launch_bounds__(TB_CM) k_scan_down_cm(typename Op::Args a, Sca
         Op::identity(id);
         Op::to_pre(id, p);
     }
-    if constexpr (Op::HAS_HOOK) {
-        // the element's reads are issued first and fly during the (compute-heavy) hook; no second element buffer, which
-        // would not fit next to the hook's working set (fp64 d=4 p=8: 512 registers + scratch with one)
-        R hacc = 0;
-        for (int i = i0; i < i1; ++i) {
-            const int iu = opaque_uniform(i);
-            Full cur;
-            Op::load_elem(a, s, iu, cur);
-            hacc += Op::hook(a, s, iu, p);
-            Pre o;
-            Op::apply(p, cur, o);
-            p = o;
-            Op::write_out(a, s, iu, p);
-        }
-        ((R*)sb.hook)[(long long)s * lay.nchunk + ch] = hacc;
-    } else {
+    {
         Full nxt;
         if (i0 < i1) Op::load_elem(a, s, i0, nxt);
         for (int i = i0; i < i1; ++i) {
@@ -487,13 +460,13 @@ inline int ti_cm() {
 #define TI_CM ti_cm()
 
 // `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
-// DownOp: the operator of the final pass (same element/prefix types as Op; may carry a per-step hook, chain-minor mode only)
+// DownOp: the operator of the final pass (same element/prefix types as Op; e.g. SampleOpFly, which rebuilds its elements)
 template <class Op, class DownOp = Op, class ReduceOp = Op>
-int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n, void* hook_part = nullptr) {
+int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
-    ScanBufs sb{nullptr, nullptr, hook_part};
+    ScanBufs sb{nullptr, nullptr};
     const unsigned grid = lay.cm ? (unsigned)((S + TB_CM - 1) / TB_CM) * lay.nchunk : (unsigned)S * lay.ngrp;
     const size_t stage = stage_bytes<R>(Op::Full::NPAD);
     if (lay.nchunk > 1) {
