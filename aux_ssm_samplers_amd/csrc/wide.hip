@@ -9,7 +9,8 @@
 //   that carries only (b, C) resp. e), with a workgroup walking a chunk sequentially.
 //
 // Scan element records in the workspace (dense, row-major):
-//   filter : [A d*d | b d | C d*d | eta d | J d*d]          sampler : [G d*d | e d]
+//   filter : [A d*d | b d | C d*d | eta d | J d*d | z]      sampler : [G d*d | e d]
+//   (z = log-scale of the element, kalman_math.h::FiltElem: the scale of the total product is the marginal log-likelihood)
 #include <algorithm>
 #include <cmath>
 #include <string>
@@ -600,7 +601,8 @@ static size_t lds_filter_init(size_t s, int d, int p) {
     return 5 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * std::max(ldp, ldd) * s) + al16(p * ldz * s) + 6 * al16(d * s) +
            5 * al16(p * s) + al16((2 * (p + d + 3) + NWV) * s) + al16(p) + 128;
 }
-__host__ __device__ inline long long fe_size(int d) { return 3ll * d * d + 2 * d; }
+__host__ __device__ inline long long fe_size(int d) { return 3ll * d * d + 2 * d + 1; }  // [A | b | C | eta | J | z]
+__host__ __device__ inline long long pre_size(int d) { return (long long)d * d + d + 1; }    // [b | C | z]
 
 template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(FilterArgs a, R* __restrict__ elem) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -662,6 +664,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
                 eJ[r * d + q] = 0;
             }
         for (int k = tid; k < d; k += NT) eb[k] = m_[k], eeta[k] = 0;
+        if (tid == 0) eJ[d * d] = 0;  // z
         return;
     }
     innovation<R>(o, ldd, P_, at<R>(a.Rs, c, t, b), p, d, Tm, Z, ldz, tid);
@@ -674,7 +677,17 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     for (int k = tid / 64; k < p; k += NWV)
         for (int j = tid & 63; j < d; j += 64) Z[k * ldz + p + j] = o.H_[k * ldd + j];
     __syncthreads();
-    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, (R*)nullptr, tid);
+    for (int k = tid; k < p; k += NT) rm[k] = Z[k * ldz + p + d];  // the residual y - H_ m_ - c_ itself (rm held H_ m_ so far)
+    __syncthreads();
+    R hl;
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid);
+    {  // the element's log-scale: log N(y; H_ m_ + c_, S)
+        R q = 0;
+        for (int k = tid; k < p; k += NT) q += rm[k] * Z[k * ldz + p + d];
+        q = block_sum<R>(q, rowbuf, tid);
+        const R zs = ok ? (R)-0.5 * q - hl - (R)(0.5 * LOG_2PI) * (R)*o.cnt : r_nan<R>();
+        if (tid == 0) eJ[d * d] = zs;
+    }
     for (int k = tid; k < p; k += NT) rm[k] = Z[k * ldz + p + d], rb[k] = Z[k * ldz + p + d + 1];
     __syncthreads();
     // M = H_^T S^-1 H_, vm = H_^T S^-1 rm, vb = H_^T S^-1 rb  (the information quantities of kalman_math.h::filter_elem)
@@ -719,6 +732,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
 // (b, C), uses Z = [W | C | v].
 template <typename R> struct Agg {
     R *Z, *A, *C, *J, *b, *eta;  // A, C: views into Z (leading dimension ldz); J: d x d, ld ldp_(d)
+    R z;                         // log-scale of the prefix (every lane holds the same value)
     int ldz, nct;                // columns of Z
     R *T1, *T2, *Eb;             // d x d scratch
     R *v, *w, *e2;               // d
@@ -726,7 +740,7 @@ template <typename R> struct Agg {
     int* iperm;
     unsigned int* key;
 };
-static size_t lds_combine(size_t s, int d) { return al16(d * (size_t)ldp_(3 * d + 1) * s) + 4 * al16(d * (size_t)ldp_(d) * s) + 6 * al16(d * s) + al16((3 * d + 2) * s) + al16(d * 4) + 64; }
+static size_t lds_combine(size_t s, int d) { return al16(d * (size_t)ldp_(3 * d + 1) * s) + 4 * al16(d * (size_t)ldp_(d) * s) + 6 * al16(d * s) + al16((3 * d + 2 + NWV) * s) + al16(d * 4) + 64; }
 
 template <typename R> __device__ void carve_combine(Bump& L, Agg<R>& g, int d, bool full) {
     const int ldd = ldp_(d);
@@ -744,12 +758,12 @@ template <typename R> __device__ void carve_combine(Bump& L, Agg<R>& g, int d, b
     g.v = L.take<R>(d);
     g.w = L.take<R>(d);
     g.e2 = L.take<R>(d);
-    g.rowbuf = L.take<R>(3 * d + 2);
+    g.rowbuf = L.take<R>(3 * d + 2 > NWV ? 3 * d + 2 : NWV);
     g.pinv = L.take<R>(d);
     g.iperm = L.take<int>(d);
     g.key = L.take<unsigned int>(2);
 }
-template <typename R> __device__ void agg_load(const Agg<R>& g, const R* __restrict__ e, int d, int tid) {
+template <typename R> __device__ void agg_load(Agg<R>& g, const R* __restrict__ e, int d, int tid) {
     const int ldd = ldp_(d);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
@@ -758,6 +772,7 @@ template <typename R> __device__ void agg_load(const Agg<R>& g, const R* __restr
             g.J[r * ldd + q] = e[2 * d * d + 2 * d + r * d + q];
         }
     for (int k = tid; k < d; k += NT) g.b[k] = e[d * d + k], g.eta[k] = e[2 * d * d + d + k];
+    g.z = e[fe_size(d) - 1];
     __syncthreads();
 }
 template <typename R> __device__ void agg_store(R* __restrict__ e, const Agg<R>& g, int d, int tid) {
@@ -769,12 +784,13 @@ template <typename R> __device__ void agg_store(R* __restrict__ e, const Agg<R>&
             e[2 * d * d + 2 * d + r * d + q] = g.J[r * ldd + q];
         }
     for (int k = tid; k < d; k += NT) e[d * d + k] = g.b[k], e[2 * d * d + d + k] = g.eta[k];
+    if (tid == 0) e[fe_size(d) - 1] = g.z;
 }
 // g <- g (+) e2   (g = earlier prefix a1, e2 = later element a2 in global memory)
 //   W = I + C1 J2;  [X | Y | z] = W^-1 [A1 | C1 | b1 + C1 eta2]
 //   A = A2 X;  b = A2 z + b2;  C = sym(A2 Y A2^T + C2);  eta = X^T (eta2 - J2 b1) + eta1;  J = sym(X^T (J2 A1) + J1)
 // full = false: only (b, C) are updated (the down-sweep; they depend on a1 only through (b1, C1)).
-template <typename R> __device__ void combine(const Agg<R>& g, const R* __restrict__ e2, int d, bool full, int tid) {
+template <typename R> __device__ void combine(Agg<R>& g, const R* __restrict__ e2, int d, bool full, int tid) {
     const int ldd = ldp_(d), ldz = g.ldz;
     const R* A2 = e2;
     const R* b2 = e2 + d * d;
@@ -789,14 +805,23 @@ template <typename R> __device__ void combine(const Agg<R>& g, const R* __restri
         g.Z[k * ldz + k] += (R)1;
         g.Z[k * ldz + g.nct - 1] = g.v[k] + g.b[k];
     }
-    if (full) {
-        gemm<false, false>(d, d, d, g.Eb, ldd, g.A, ldz, g.T1, ldd, (R)1, (R)0, tid);  // J2 A1
-        gemv<R, false>(d, d, g.Eb, ldd, g.b, g.w, (R)1, (R)0, tid);
-        for (int k = tid; k < d; k += NT) g.w[k] = g.e2[k] - g.w[k];
-    }
+    if (full) gemm<false, false>(d, d, d, g.Eb, ldd, g.A, ldz, g.T1, ldd, (R)1, (R)0, tid);  // J2 A1
+    gemv<R, false>(d, d, g.Eb, ldd, g.b, g.w, (R)1, (R)0, tid);                                // J2 b1
     __syncthreads();
     lu_solve<R>(g.Z, ldz, d, g.nct, g.rowbuf, g.pinv, g.iperm, g.key, tid);
-    for (int k = tid; k < d; k += NT) g.v[k] = g.Z[k * ldz + g.nct - 1];  // z
+    for (int k = tid; k < d; k += NT) g.v[k] = g.Z[k * ldz + g.nct - 1];  // W^-1 (b1 + C1 eta2)
+    __syncthreads();
+    {  // log-scale of the product: z1 + z2 - log|W|/2 + eta2.u + eta2.v/2 - (J2 b1).u/2, u = W^-1 b1, v = W^-1 C1 eta2 = Y eta2
+        gemv<R, false>(d, d, g.C, ldz, g.e2, g.T2, (R)1, (R)0, tid);  // v (T2 is free here)
+        R t = 0;
+        for (int k = tid; k < d; k += NT) {
+            const R vi = g.T2[k], ui = g.v[k] - vi;
+            t += g.e2[k] * ui + (R)0.5 * g.e2[k] * vi - (R)0.5 * g.w[k] * ui - (R)0.5 * log_(abs_((R)1 / g.pinv[k]));
+        }
+        t = block_sum<R>(t, g.rowbuf, tid);
+        g.z = g.z + e2[fe_size(d) - 1] + t;
+    }
+    for (int k = tid; k < d; k += NT) g.w[k] = g.e2[k] - g.w[k];  // eta2 - J2 b1
     __syncthreads();
     if (full) {
         gemm<true, false>(d, d, d, g.A, ldz, g.T1, ldd, g.J, ldd, (R)1, (R)1, tid);  // J1 + X^T (J2 A1)
@@ -840,12 +865,13 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_aggs(const R
     Bump L{smem};
     Agg<R> g;
     carve_combine<R>(L, g, d, true);
-    const long long ne = fe_size(d), np = (long long)d * d + d;
+    const long long ne = fe_size(d), np = pre_size(d);
     agg_load<R>(g, aggs + (long long)s * nchunk * ne, d, tid);
     for (int ch = 1; ch < nchunk; ++ch) {
         R* q = pre + ((long long)s * nchunk + ch) * np;
         for (int k = tid; k < d; k += NT) q[k] = g.b[k];
         store_mat<R>(q + d, g.C, g.ldz, d, d, tid);
+        if (tid == 0) q[np - 1] = g.z;
         if (ch + 1 < nchunk) combine<R>(g, aggs + ((long long)s * nchunk + ch) * ne, d, true, tid);
     }
 }
@@ -860,13 +886,14 @@ __global__ void __launch_bounds__(NT) wk_scan_down_pre(const R* __restrict__ agg
     Bump L{smem};
     Agg<R> g;
     carve_combine<R>(L, g, d, false);
-    const long long ne = fe_size(d), np = (long long)d * d + d;
+    const long long ne = fe_size(d), np = pre_size(d);
     const int i0 = c1 * E1, i1 = min(n0, i0 + E1);
     bool have = false;
     if (c1 > 0) {
         const R* q = pre1 + ((long long)s * nchunk1 + c1) * np;
         load_vec<R>(g.b, q, d, tid);
         load_mat<R>(g.C, g.ldz, q + d, d, d, tid);
+        g.z = q[np - 1];
         have = true;
     }
     for (int i = i0; i < i1; ++i) {
@@ -874,6 +901,7 @@ __global__ void __launch_bounds__(NT) wk_scan_down_pre(const R* __restrict__ agg
             R* q = pre0 + ((long long)s * n0 + i) * np;
             for (int k = tid; k < d; k += NT) q[k] = g.b[k];
             store_mat<R>(q + d, g.C, g.ldz, d, d, tid);
+            if (tid == 0) q[np - 1] = g.z;
             __syncthreads();
         }
         if (i + 1 < i1) {  // the prefix after the chunk's last aggregate belongs to the next workgroup
@@ -895,7 +923,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
     Bump L{smem};
     Agg<R> g;
     carve_combine<R>(L, g, d, false);
-    const long long ne = fe_size(d), np = (long long)d * d + d;
+    const long long ne = fe_size(d), np = pre_size(d);
     const int i0 = ch * E, i1 = min(n, i0 + E);
     if (ch == 0) {
         agg_load<R>(g, elem + (long long)s * n * ne, d, tid);  // prefix 0 = element 0 itself
@@ -903,6 +931,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
         const R* q = pre + ((long long)s * nchunk + ch) * np;
         load_vec<R>(g.b, q, d, tid);
         load_mat<R>(g.C, g.ldz, q + d, d, d, tid);
+        g.z = q[np - 1];
     }
     for (int i = i0; i < i1; ++i) {
         if (!(ch == 0 && i == 0)) combine<R>(g, elem + ((long long)s * n + i) * ne, d, false, tid);
@@ -910,70 +939,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
         R* Po = const_cast<R*>(at<R>(a.Ps, c, (long long)i + 1, b));
         for (int k = tid; k < d; k += NT) mo[k] = g.b[k];
         store_mat<R>(Po, g.C, g.ldz, d, d, tid);
+        if (i == n - 1 && tid == 0) ((R*)a.ellz)[s] = g.z;  // log-scale of the full product = log p(y_1..T-1 | y_0)
         __syncthreads();
     }
-}
-
-// ---- log-likelihood increments (filtering.py:60-62): predict from the filtered moments at i, ell_inc of step i + 1 ---------
-static size_t lds_filter_ell(size_t s, int d, int p) {
-    const size_t ldd = ldp_(d), ldp = ldp_(p), ldz = ldp_(p + 1);
-    return 4 * al16(d * ldd * s) + al16(p * ldd * s) + al16(d * ldp * s) + al16(p * ldz * s) + 3 * al16(d * s) + 4 * al16(p * s) +
-           al16((2 * (p + 2) + NWV) * s) + al16(p) + 128;
-}
-template <typename R> __global__ void __launch_bounds__(NT) wk_filter_ell(FilterArgs a, R* __restrict__ ellinc) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1;
-    const int s = blockIdx.x / n, i = blockIdx.x - s * n, c = s / a.d.B, b = s % a.d.B;
-    const long long t = (long long)i + 1;
-    const int ldd = ldp_(d), ldp = ldp_(p), nct = p + 1, ldz = ldp_(nct);
-    Bump L{smem};
-    R* F = L.take<R>(d * ldd);
-    R* P = L.take<R>(d * ldd);
-    R* Tm = L.take<R>(d * ldd);
-    R* P_ = L.take<R>(d * ldd);
-    Obs<R> o;
-    o.H_ = L.take<R>(p * ldd);
-    R* PHt = L.take<R>(d * ldp);
-    R* Z = L.take<R>(p * ldz);  // [S | yd]
-    R* m = L.take<R>(d);
-    R* m_ = L.take<R>(d);
-    R* bd = L.take<R>(d);
-    o.c_ = L.take<R>(p);
-    o.y = L.take<R>(p);
-    R* yd = L.take<R>(p);
-    R* piv = L.take<R>(p);
-    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
-    o.nan = L.take<unsigned char>(p);
-    o.cnt = L.take<int>(1);
-    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
-    if (!any) {
-        if (tid == 0) ellinc[(long long)s * n + i] = 0;
-        return;
-    }
-    load_mat<R>(F, ldd, at<R>(a.Fs, c, i, b), d, d, tid);
-    load_mat<R>(P, ldd, at<R>(a.Ps, c, i, b), d, d, tid);
-    load_mat<R>(P_, ldd, at<R>(a.Qs, c, i, b), d, d, tid);
-    load_vec<R>(m, at<R>(a.ms, c, i, b), d, tid);
-    load_vec<R>(bd, at<R>(a.bs, c, i, b), d, tid);
-    // sequential_predict :134-139
-    gemv<R, false>(d, d, F, ldd, m, m_, (R)1, (R)0, tid);
-    for (int k = tid; k < d; k += NT) m_[k] += bd[k];
-    gemm<false, false>(d, d, d, F, ldd, P, ldd, Tm, ldd, (R)1, (R)0, tid);
-    gemm<false, true>(d, d, d, Tm, ldd, F, ldd, P_, ldd, (R)1, (R)1, tid);
-    symmetrise<R>(P_, ldd, d, tid);
-    innovation<R>(o, ldd, P_, at<R>(a.Rs, c, t, b), p, d, PHt, Z, ldz, tid);
-    gemv<R, false>(p, d, o.H_, ldd, m_, yd, (R)1, (R)0, tid);
-    for (int k = tid; k < p; k += NT) {
-        yd[k] = o.nan[k] ? (R)0 : o.y[k] - (yd[k] + o.c_[k]);
-        Z[k * ldz + p] = yd[k];
-    }
-    __syncthreads();
-    R hl;
-    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid);
-    R q = 0;
-    for (int k = tid; k < p; k += NT) q += yd[k] * Z[k * ldz + p];
-    q = block_sum<R>(q, rowbuf, tid);
-    if (tid == 0) ellinc[(long long)s * n + i] = ell_value<R>(q, hl, *o.cnt, ok);
 }
 
 // out[r] = sum_{b < B} ( add0[r B + b] + sum_{i < n} part[(r B + b) n + i] ), fixed order; one workgroup per output
@@ -1403,23 +1371,24 @@ template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims
     const int S = kd.S(), n = kd.n();
     const WPlan p = plan(h, S, n, parallel);
     const size_t ne = (size_t)fe_size(d);
-    return ((size_t)S * std::max(n, 1) * ne + (size_t)S * (p.nchunk + p.nchunk1) * (ne + (size_t)d * d + d) + (size_t)S * (std::max(n, 1) + 1)) * sizeof(R) + 8192;
+    return ((size_t)S * std::max(n, 1) * ne + (size_t)S * (p.nchunk + p.nchunk1) * (ne + (size_t)pre_size(d)) + (size_t)S * (std::max(n, 1) + 2)) * sizeof(R) + 8192;
 }
 
 template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int parallel, void* ell_out) {
     const int S = a.d.S(), n = a.d.n(), d = a.dx, p = a.dy;
     const WPlan pl = plan(h, S, n, parallel);
-    const size_t ne = (size_t)fe_size(d), np = (size_t)d * d + d;
+    const size_t ne = (size_t)fe_size(d), np = (size_t)pre_size(d);
     R* elem = (R*)ws_take(h, (size_t)S * std::max(n, 1) * ne * sizeof(R));
     R* aggs = (R*)ws_take(h, (size_t)S * pl.nchunk * ne * sizeof(R));
     R* pre = (R*)ws_take(h, (size_t)S * pl.nchunk * np * sizeof(R));
     R* aggs1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * ne * sizeof(R));
     R* pre1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * np * sizeof(R));
     R* ell0 = (R*)ws_take(h, (size_t)S * sizeof(R));
-    R* ellinc = (R*)ws_take(h, (size_t)S * std::max(n, 1) * sizeof(R));
-    if (!elem || !aggs || !pre || !aggs1 || !pre1 || !ell0 || !ellinc) return AUXSSM_ERR_NOMEM;
+    R* ellz = (R*)ws_take(h, (size_t)S * sizeof(R));
+    if (!elem || !aggs || !pre || !aggs1 || !pre1 || !ell0 || !ellz) return AUXSSM_ERR_NOMEM;
     FilterArgs fa = a;
     fa.ell0 = ell0;
+    fa.ellz = ellz;
     {
         ProfScope ps(h, AUXSSM_K_FILTER_INIT);
         WK_LAUNCH((wk_filter_t0<R>), S, lds_filter_t0(sizeof(R), d, p), fa);
@@ -1441,10 +1410,9 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
             }
             WK_LAUNCH((wk_scan_down<R>), (long long)S * pl.nchunk, lc, fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
         }
-        ProfScope ps(h, AUXSSM_K_FILTER_ELL);
-        WK_LAUNCH((wk_filter_ell<R>), (long long)S * n, lds_filter_ell(sizeof(R), d, p), fa, ellinc);
     }
-    hipLaunchKernelGGL((wk_reduce<R>), dim3(a.d.C), dim3(NT), 0, h->stream, (const R*)ellinc, (const R*)ell0, a.d.B, (long long)std::max(n, 0), (R*)ell_out);
+    // ell = t = 0 term + the scan's log-scale (the reference's second pass, filtering.py:60-62, is not needed)
+    hipLaunchKernelGGL((wk_reduce<R>), dim3(a.d.C), dim3(NT), 0, h->stream, (const R*)ellz, (const R*)ell0, a.d.B, (long long)(n > 0 ? 1 : 0), (R*)ell_out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -1528,7 +1496,7 @@ const SweepLogpdfEntry* wide_sweep_logpdf_entry(int dtype) {
 bool wide_fits(int dtype, int dx, int dy, std::string* why) {
     const size_t s = dtype == AUXSSM_F32 ? 4 : 8;
     size_t need = std::max(wide::lds_combine(s, dx), wide::lds_sample_init(s, dx));
-    if (dy > 0) need = std::max({need, wide::lds_filter_init(s, dx, dy), wide::lds_filter_t0(s, dx, dy), wide::lds_filter_ell(s, dx, dy), wide::lds_logpdf(s, dx, dy)});
+    if (dy > 0) need = std::max({need, wide::lds_filter_init(s, dx, dy), wide::lds_filter_t0(s, dx, dy), wide::lds_logpdf(s, dx, dy)});
     const bool regs_ok = dx <= 8 * wide::NWV && 3 * dx + 1 <= 256 && (dy == 0 || (dy <= 8 * wide::NWV && dy + dx + 2 <= 256));
     if (!regs_ok) {
         if (why) {

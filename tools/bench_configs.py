@@ -80,7 +80,7 @@ def c5(T=8192):
     h = _lib.default_handle()
     eps = np.random.default_rng(0).standard_normal((T, 64)).astype(np.float32)
     for rep in range(2):
-        for kid, name in ((_lib.K_FILTER_INIT, "init"), (_lib.K_FILTER_SCAN, "scan"), (_lib.K_FILTER_ELL, "ell")):
+        for kid, name in ((_lib.K_FILTER_INIT, "init"), (_lib.K_FILTER_SCAN, "scan (incl. log-likelihood)")):
             h.prof_enable(kid, 4)
             ms, Ps, ell = P.filtering(u, lg, True)
             n, t = h.prof_read()

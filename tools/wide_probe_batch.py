@@ -21,7 +21,7 @@ rng = np.random.default_rng(0)
 bu = (u[:, None, :] + 0.1 * rng.standard_normal((T, B, d))).astype(np.float32)
 h = _lib.default_handle()
 tot = 0.0
-for kid, name in ((_lib.K_FILTER_INIT, "filter init"), (_lib.K_FILTER_SCAN, "filter scan"), (_lib.K_FILTER_ELL, "filter ell")):
+for kid, name in ((_lib.K_FILTER_INIT, "filter init"), (_lib.K_FILTER_SCAN, "filter scan (incl. log-likelihood)")):
     for rep in range(2):
         h.prof_enable(kid, 4)
         ms, Ps, ell = P.filtering(bu, blg, True)
