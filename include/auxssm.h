@@ -90,7 +90,7 @@ typedef enum {
     AUXSSM_K_NONE = 0,
     AUXSSM_K_FILTER_INIT = 1,
     AUXSSM_K_FILTER_SCAN = 2, /* the three launches of the filter's associative scan, timed as one unit */
-    AUXSSM_K_FILTER_ELL = 3,
+    AUXSSM_K_FILTER_ELL = 3,  /* reserved: the log-likelihood is carried by the scan elements, no such pass exists */
     AUXSSM_K_SAMPLE_INIT = 4,
     AUXSSM_K_SAMPLE_SCAN = 5,
     AUXSSM_K_LOGPDF = 6,
