@@ -245,3 +245,44 @@ def test_sampler_moments_reference_statistical_test(seed, T, dx, dy, parallel):
     npt.assert_allclose(s.mean(0), esm, atol=1e-2, rtol=1e-2)
     cov = np.einsum("nti,ntj->tij", s - s.mean(0), s - s.mean(0)) / (NS - 1)
     npt.assert_allclose(cov, esP, atol=1e-2, rtol=1e-2)
+
+
+@pytest.mark.parametrize("d,T", [(4, 700), (2, 333), (1, 200)])
+@pytest.mark.parametrize("parallel", [True, False])
+def test_chain_minor_sweep_equals_dense_sweep_and_oracle(d, T, parallel):
+    """The layout bench.py runs (>= 32 chains: state, noise and every internal buffer chain-minor, lanes over chains) against the
+    dense layout chain by chain and against the oracle sweep, on identical explicit noise, missing observation rows included."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, LGConcatModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    C = 70  # more than one wave of chains, not a multiple of 64
+    m = lg_model(T, d)
+    y = m["y"].copy()
+    rng = np.random.default_rng(d * 100 + T)
+    y[rng.random(T) < 0.15] = np.nan      # whole steps missing
+    if d > 1:
+        y[rng.random((T, d)) < 0.05] = np.nan  # single components missing
+    bt = np.broadcast_to
+    model = LGConcatModel(m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
+                          bt(m["Hobs"], (T, d, d)), bt(m["Robs"], (T, d, d)), bt(m["cobs"], (T, d)), y)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, parallel)
+    x0 = m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    outs = {}
+    for cm in (True, False):
+        chains = DeviceChains(h, x0, chain_minor=cm)
+        assert chains.chain_minor == cm
+        st = kernel(None, KalmanSampler(x=chains, updated=None), 0.5, noise=noise)
+        outs[cm] = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    npt.assert_allclose(outs[True][0], outs[False][0], rtol=1e-9, atol=1e-10)
+    npt.assert_array_equal(outs[True][1], outs[False][1])
+    npt.assert_allclose(outs[True][2][:, 1:], outs[False][2][:, 1:], rtol=1e-9)
+    lgo = (m["m0"], m["P0"], model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs)
+    for c in (0, 33, C - 1):
+        ref = K.kalman_sweep(x0[c], 0.5, model.dynamics_factory, model.observations_factory,
+                             lambda z: K.log_likelihood(y, z, lgo) + K.prior_logpdf(z, lgo), parallel,
+                             eps_aux=noise["eps_aux"][c], eps_samp=noise["eps_samp"][c], u_accept=noise["u_accept"][c])
+        npt.assert_allclose(outs[True][0][c], ref["x"], rtol=1e-9, atol=1e-10)
+        npt.assert_allclose(outs[True][2][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
+        assert bool(outs[True][1][c]) == ref["accepted"]
