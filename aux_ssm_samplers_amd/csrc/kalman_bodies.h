@@ -109,6 +109,8 @@ struct FilterArgs {
     void* ellz;     // [S] log-scale of the whole scan = sum of the increments of t = 1..T-1 (written by the final pass)
     ScanLayout lay;
     int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
+    const void* tab = nullptr;  // chain-shared parameters: one FiltShared row per transition (else null)
+    void* pc = nullptr;         // ... and the per-chain element parts [i][b | eta | z][s]
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
 AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
@@ -275,6 +277,98 @@ template <typename R_, int D> struct FilterOp {
 #pragma unroll
         for (int i = 0; i < DS; ++i) t[D * D + D + i] = e.C[i], t[D * D + 2 * D + DS + i] = e.J[i];
         t[Full::N - 1] = e.z;
+    }
+};
+
+// ---- chain-shared model parameters (kalman_math.h::FiltShared) ---------------------------------------------------------------
+// table row of transition i -> i + 1, from chain 0's view of the shared parameters (the observation mask is the data's)
+template <typename R, int D, int P> AX_HD void body_filter_shared_tab(const FilterArgs& a, int i) {
+    using T = FiltShared<R, D, P>;
+    const long long t = (long long)i + 1;
+    R F[D * D], bd[D], P_[D * D], H[P * D], cv[P], y[P], Rm[P * P];
+    rd<R, D * D>(a.Fs, 0, i, 0, F);
+    rd<R, D>(a.bs, 0, i, 0, bd);
+    rd<R, D * D>(a.Qs, 0, i, 0, P_);
+    rd<R, P * D>(a.Hs, 0, t, 0, H);
+    rd<R, P>(a.cs, 0, t, 0, cv);
+    rd<R, P>(a.ys, 0, t, 0, y);
+    rd_upper<R, P>(a.Rs, 0, t, 0, Rm);
+    if (i == 0) {  // P_ = F P0+ F^T + Q, not symmetrised (filtering.py:200-201)
+        R P0p[D * D], FP[D * D], Pn[D * D];
+        rd<R, D * D>(a.Ps, 0, 0, 0, P0p);
+        mm<R, D, D, D>(F, P0p, FP);
+        mmt<R, D, D, D>(FP, F, Pn);
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) P_[k] = Pn[k] + P_[k];
+    }
+    R row[T::N];
+    filter_shared_row<R, D, P>(F, bd, P_, H, cv, Rm, y, row);
+    stv<R, T::N>((R*)a.tab + (long long)i * T::NPAD, row);
+}
+// per-chain part of element i: b = m_ + K r_m, eta = Ke r_b, z = -1/2 r_m^T S^-1 r_m + c0
+template <typename R, int D, int P> AX_HD void body_filter_init_shared(const FilterArgs& a, int s, int i) {
+    using T = FiltShared<R, D, P>;
+    const int c = s / a.d.B, b = s % a.d.B;
+    const long long t = (long long)i + 1;
+    const R* row = (const R*)a.tab + (long long)i * T::NPAD;
+    R y[P], rb[P], rm[P], m_[D];
+    rd<R, P>(a.ys, c, t, b, y);
+#pragma unroll
+    for (int k = 0; k < P; ++k) rb[k] = finite_(y[k]) ? y[k] - row[T::oYm + k] : (R)0, rm[k] = rb[k];
+#pragma unroll
+    for (int k = 0; k < D; ++k) m_[k] = row[T::oMd + k];
+    if (i == 0) {  // built around predict(m0+, P0+): m_ = b_dyn + F m0+, r_m = r_b - H F m0+
+        R m0p[D], F[D * D], Fm[D];
+        rd<R, D>(a.ms, c, 0, b, m0p);
+        rd<R, D * D>(a.Fs, 0, 0, 0, F);
+        mv<R, D, D>(F, m0p, Fm);
+#pragma unroll
+        for (int k = 0; k < D; ++k) m_[k] += Fm[k];
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            R hf = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) hf += row[T::oHF + k * D + j] * m0p[j];
+            rm[k] = finite_(y[k]) ? rb[k] - hf : (R)0;
+        }
+    }
+    R out[T::NPC];
+#pragma unroll
+    for (int j = 0; j < D; ++j) {
+        R sb_ = m_[j], se_ = 0;
+#pragma unroll
+        for (int k = 0; k < P; ++k) sb_ += row[T::oK + j * P + k] * rm[k], se_ += row[T::oKe + j * P + k] * rb[k];
+        out[j] = sb_;
+        out[D + j] = se_;
+    }
+    R q = 0;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        R sk = 0;
+#pragma unroll
+        for (int l = 0; l < P; ++l) sk += row[T::oSi + sidx(P, k, l)] * rm[l];
+        q += rm[k] * sk;
+    }
+    out[2 * D] = (R)-0.5 * q + row[T::oC0];
+    sts_<R, T::NPC>((R*)a.pc + (long long)i * T::NPC * a.lay.S + s, a.lay.S, out);
+}
+// FilterOp whose elements are split: matrices from the shared table (wave-uniform loads), (b, eta, z) per chain
+template <typename R_, int D, int P> struct FilterOpShared : FilterOp<R_, D> {
+    using R = R_;
+    using Full = typename FilterOp<R_, D>::Full;
+    static constexpr int DS = symsize(D);
+    static AX_HD void load_elem(const FilterArgs& a, int s, int i, Full& e) {
+        using T = FiltShared<R, D, P>;
+        const R* row = (const R*)a.tab + (long long)i * T::NPAD;
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) e.A[k] = row[T::oA + k];
+#pragma unroll
+        for (int k = 0; k < DS; ++k) e.C[k] = row[T::oC + k], e.J[k] = row[T::oJ + k];
+        R pc[T::NPC];
+        lds_<R, T::NPC>((const R*)a.pc + (long long)i * T::NPC * a.lay.S + s, a.lay.S, pc);
+#pragma unroll
+        for (int k = 0; k < D; ++k) e.b[k] = pc[k], e.eta[k] = pc[D + k];
+        e.z = pc[2 * D];
     }
 };
 

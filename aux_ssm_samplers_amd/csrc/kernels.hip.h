@@ -230,6 +230,17 @@ template <typename R, int D, int P, int P1> __global__ void __launch_bounds__(TB
         body_filter_init<R, D, P, DirectIO, P1>(a, io, c.s, opaque_uniform(i), true);
     }
 }
+// chain-shared parameters: the table (one lane per transition) and the per-chain element parts (lanes over chains)
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_shared_tab(FilterArgs a) {
+    const int i = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (i < a.d.n()) body_filter_shared_tab<R, D, P>(a, i);
+}
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_filter_init_cm_shared(FilterArgs a, int TI) {
+    const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
+    if (!c.live) return;
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) body_filter_init_shared<R, D, P>(a, c.s, opaque_uniform(i));
+}
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_init_cm(SampleArgs a, int TI) {
     const CmTile c = decode_cm(a.d.S(), a.d.T - 1, TI);
     if (!c.live) return;
@@ -506,7 +517,19 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     static const bool blk_on = [] { const char* e = getenv("AUXSSM_INFO_BLOCKS"); return e ? atoi(e) != 0 : true; }();
     const bool blk = blk_on && P > D && a_in.pblk == D;
     a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
-    a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
+    // chain-shared model parameters (the factories of a linear-Gaussian model): element matrices and gain-type operators once per
+    // time step, only (b, eta, z) per chain -- what jax.vmap leaves unbatched in the reference
+    static const bool shared_on = [] { const char* e = getenv("AUXSSM_SHARED"); return e ? atoi(e) != 0 : true; }();
+    const bool shared = shared_on && cm && n > 0 && a.d.B == 1 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 &&
+                        a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
+    using TS = FiltShared<R, D, P>;
+    if (shared) {
+        a.tab = ws_take(h, (size_t)n * TS::NPAD * sizeof(R));
+        a.pc = ws_take(h, (size_t)n * TS::NPC * S * sizeof(R));
+        a.elem = nullptr;
+    } else {
+        a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
+    }
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
     // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final
     // pass writes it per sequence; the reference's second pass over the filtered moments (filtering.py:60-62) does not exist here
@@ -516,13 +539,17 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     if (n > 0) {
         {
             ProfScope ps(h, AUXSSM_K_FILTER_INIT);
-            if (cm && blk) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, (P > D ? D : 0)>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+            if (shared) {
+                hipLaunchKernelGGL((k_filter_shared_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
+                hipLaunchKernelGGL((k_filter_init_cm_shared<R, D, P>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+            } else if (cm && blk) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, (P > D ? D : 0)>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
             else if (cm) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, 0>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
             else hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n);
+            const int rc = shared ? run_scan<FilterOp<R, D>, FilterOpShared<R, D, P>, FilterOpShared<R, D, P>>(h, a, S, n)
+                                  : run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
     }
