@@ -402,6 +402,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
     sa.ms = msA; sa.Ps = PsA; sa.eps = epsA; sa.xs = xpA; sa.elem = nullptr;
     sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
+    // the filtered covariances of this model do not depend on the chain when its parameters do not
+    sa.ps_shared = (model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->Hs.sc == 0 && model->Rs.sc == 0 &&
+                    model->cs.sc == 0 && model->P0.sc == 0 && C > 1) ? 1 : 0;
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;
     h->ws_off = mark;

@@ -383,6 +383,8 @@ struct SampleArgs {
     void* elem;       // scan elements (layout `lay`), scan position j = T-1-t
     ScanLayout lay;
     int dx = 0;       // runtime size (wide.hip only)
+    int ps_shared = 0;        // != 0: Ps (and Fs, Qs, bs) do not depend on the chain (filter ran on chain-shared parameters)
+    const void* tab = nullptr;  // then: one SampShared row per time step
 };
 
 template <typename R_, int D> struct SampleOp;
@@ -520,6 +522,45 @@ template <typename R_, int D> struct SampleOpFly : SampleOp<R_, D> {
             rd<R, D * D>(a.Qs, c, t, b, Q);
             rd<R, D>(a.bs, c, t, b, bd);
             sample_elem<R, D>(F, Q, bd, m, Pd, eps, e);
+        }
+    }
+};
+
+// chain-shared covariances: gain / Cholesky table row of time t (chain 0's copy of the shared Ps), and the op that reads it
+template <typename R, int D> AX_HD void body_sample_shared_tab(const SampleArgs& a, int t) {
+    using T = SampShared<R, D>;
+    R Pd[D * D], F[D * D], Q[D * D], bd[D], row[T::N];
+    rd<R, D * D>(a.Ps, 0, t, 0, Pd);
+    const bool last = t == a.d.T - 1;
+    if (!last) {
+        rd<R, D * D>(a.Fs, 0, t, 0, F);
+        rd<R, D * D>(a.Qs, 0, t, 0, Q);
+        rd<R, D>(a.bs, 0, t, 0, bd);
+    }
+    sample_shared_row<R, D>(F, Q, bd, Pd, last, row);
+    stv<R, T::N>((R*)a.tab + (long long)t * T::NPAD, row);
+}
+template <typename R_, int D> struct SampleOpShared : SampleOp<R_, D> {
+    using R = R_;
+    using Full = typename SampleOp<R_, D>::Full;
+    static AX_HD void load_elem(const SampleArgs& a, int s, int j, Full& e) {
+        using T = SampShared<R, D>;
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)a.d.T - 1 - j;
+        const R* row = (const R*)a.tab + t * T::NPAD;
+        R m[D], eps[D];
+        rd<R, D>(a.ms, c, t, b, m);
+        rd<R, D>(a.eps, c, t, b, eps);
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) e.G[i] = row[T::oG + i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R v = -row[T::oGb + i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += row[T::oM + i * D + k] * m[k];
+#pragma unroll
+            for (int k = 0; k <= i; ++k) v += row[T::oL + i * D + k] * eps[k];
+            e.e[i] = v;
         }
     }
 };

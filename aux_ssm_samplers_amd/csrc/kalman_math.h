@@ -765,9 +765,9 @@ template <typename R, int D> AX_HD void chol_nan_to_num(const R* Spacked, R* Ld)
     }
 }
 
-// mean_and_chol + _sampling_init_one (sampling.py:60-112) for t < T-1
+// mean_and_chol (sampling.py:60-105) for t < T-1: gain G = P (S^-1 F)^T, S = F P F^T + Q, and Lc = nan_to_num(chol(P - G S G^T))
 template <typename R, int D>
-AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* Pd, const R* eps, SampElem<R, D>& e) {
+AX_HD void sample_gain_chol(const R* F, const R* Q, const R* Pd, R* G, R* Lc) {
     R FP[D * D], Sd[D * D], S[symsize(D)];
     mm<R, D, D, D>(F, Pd, FP);
     mmt<R, D, D, D>(FP, F, Sd);
@@ -775,7 +775,7 @@ AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* 
     for (int i = 0; i < D * D; ++i) Sd[i] += Q[i];
     sympack<R, D>(Sd, S);
     if constexpr (D == 1) {
-        e.G[0] = Pd[0] * F[0] / S[0];
+        G[0] = Pd[0] * F[0] / S[0];
     } else {
         R L[symsize(D)], invd[D];
         const bool ok = chol_packed<R, D>(S, L, invd, nullptr);
@@ -784,10 +784,10 @@ AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* 
         for (int i = 0; i < D * D; ++i) X[i] = F[i];
 #pragma unroll
         for (int j = 0; j < D; ++j) cho_solve_col<R, D, D>(L, invd, X, j);
-        mmt<R, D, D, D>(Pd, X, e.G);  // gain = P X^T
+        mmt<R, D, D, D>(Pd, X, G);  // gain = P X^T
         if (!ok) {
 #pragma unroll
-            for (int i = 0; i < D * D; ++i) e.G[i] = r_nan<R>();
+            for (int i = 0; i < D * D; ++i) G[i] = r_nan<R>();
         }
     }
     // inc_Sig = sym(P - gain S gain^T)
@@ -798,15 +798,20 @@ AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* 
         for (int j = 0; j < D; ++j) {
             R s = 0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) s += e.G[i * D + k] * S[sidx(D, k, j)];
+            for (int k = 0; k < D; ++k) s += G[i * D + k] * S[sidx(D, k, j)];
             gS[i * D + j] = s;
         }
-    mmt<R, D, D, D>(gS, e.G, Sg);
+    mmt<R, D, D, D>(gS, G, Sg);
 #pragma unroll
     for (int i = 0; i < D * D; ++i) Sg[i] = Pd[i] - Sg[i];
     sympack<R, D>(Sg, Sig);
-    R Lc[D * D];
     chol_nan_to_num<R, D>(Sig, Lc);
+}
+// + _sampling_init_one (sampling.py:108-112): inc = m - G (F m + b) + Lc eps
+template <typename R, int D>
+AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* Pd, const R* eps, SampElem<R, D>& e) {
+    R Lc[D * D];
+    sample_gain_chol<R, D>(F, Q, Pd, e.G, Lc);
     R pm[D], t[D];
     mv<R, D, D>(F, m, pm);
 #pragma unroll
@@ -820,6 +825,39 @@ AX_HD void sample_elem(const R* F, const R* Q, const R* b, const R* m, const R* 
         e.e[i] = s;
     }
 }
+// Chain-shared parameters AND covariances (the filtered P_t of a linear-Gaussian model do not depend on the data): the gain G_t,
+// M1 = I - G F, gb = G b and the Cholesky factor Lc of the increment covariance are the same for every chain; a chain's increment is
+// e = M1 m - gb + Lc eps (sampling.py:108-112 rearranged).  Row layout: [G D*D | M1 D*D | gb D | Lc D*D (dense lower)].
+template <typename R, int D> struct SampShared {
+    static constexpr int oG = 0, oM = D * D, oGb = 2 * D * D, oL = 2 * D * D + D, N = 3 * D * D + D;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
+};
+template <typename R, int D>
+AX_HD void sample_shared_row(const R* F, const R* Q, const R* b, const R* Pd, bool last, R* row) {
+    using T = SampShared<R, D>;
+    R Lc[D * D];
+    if (last) {  // _sample_last_step: G = 0, e = m + chol(P) eps
+        R S[symsize(D)];
+        sympack<R, D>(Pd, S);
+        chol_nan_to_num<R, D>(S, Lc);
+#pragma unroll
+        for (int i = 0; i < D * D; ++i) row[T::oG + i] = 0, row[T::oM + i] = (i / D == i % D) ? (R)1 : (R)0, row[T::oL + i] = Lc[i];
+#pragma unroll
+        for (int i = 0; i < D; ++i) row[T::oGb + i] = 0;
+        return;
+    }
+    R G[D * D];
+    sample_gain_chol<R, D>(F, Q, Pd, G, Lc);
+    R GF[D * D], gb[D];
+    mm<R, D, D, D>(G, F, GF);
+    mv<R, D, D>(G, b, gb);
+#pragma unroll
+    for (int i = 0; i < D * D; ++i) row[T::oG + i] = G[i], row[T::oM + i] = ((i / D == i % D) ? (R)1 : (R)0) - GF[i], row[T::oL + i] = Lc[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) row[T::oGb + i] = gb[i];
+}
+
 // _sample_last_step (sampling.py:115-124)
 template <typename R, int D> AX_HD void sample_last(const R* m, const R* Pd, const R* eps, SampElem<R, D>& e) {
     R S[symsize(D)], Lc[D * D];

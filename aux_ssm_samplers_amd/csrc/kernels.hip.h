@@ -241,6 +241,10 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_f
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) body_filter_init_shared<R, D, P>(a, c.s, opaque_uniform(i));
 }
+template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample_shared_tab(SampleArgs a) {
+    const int t = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (t < a.d.T) body_sample_shared_tab<R, D>(a, t);
+}
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_init_cm(SampleArgs a, int TI) {
     const CmTile c = decode_cm(a.d.S(), a.d.T - 1, TI);
     if (!c.live) return;
@@ -562,7 +566,8 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
 template <typename R, int D> size_t sample_ws(const auxssm_ctx* h, const KDims& d, int parallel) {
     const int S = d.S();
     const ScanLayout lay = make_layout(plan_scan(h, S, d.T, parallel), 0, S);
-    return (size_t)S * lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel);
+    return (size_t)S * lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel) +
+           (size_t)d.T * SampShared<R, D>::NPAD * sizeof(R) + 256;
 }
 
 template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_in, int parallel) {
@@ -571,6 +576,21 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
     const int cm = a_in.lay.cm;
     a.lay = make_layout(plan_scan(h, S, T, parallel), cm, S);
     static const bool fly = [] { const char* e = getenv("AUXSSM_SAMPLE_FLY"); return e ? atoi(e) != 0 : true; }();
+    static const bool shared_on = [] { const char* e = getenv("AUXSSM_SHARED"); return e ? atoi(e) != 0 : true; }();
+    if (cm && shared_on && a.ps_shared && a.d.B == 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0) {
+        // chain-shared covariances: gains and Cholesky factors once per time step, a chain's element is two small mat-vecs
+        a.elem = nullptr;
+        a.tab = ws_take(h, (size_t)T * SampShared<R, D>::NPAD * sizeof(R));
+        {
+            ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
+            hipLaunchKernelGGL((k_sample_shared_tab<R, D>), dim3((T + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
+        }
+        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
+        const int rc = run_scan<SampleOp<R, D>, SampleOpShared<R, D>, SampleOpShared<R, D>>(h, a, S, T);
+        if (rc) return rc;
+        AX_HIP(hipGetLastError());
+        return AUXSSM_OK;
+    }
     if (cm && fly) {
         // chain-minor: elements are recomputed on the fly by both scan passes (SampleOpFly), nothing to initialise
         a.elem = nullptr;
