@@ -280,6 +280,16 @@ template <typename R_, int D> struct FilterOp {
     }
 };
 
+// A table row is read at a wave-uniform address and never written by the kernel that reads it: viewed through the constant
+// address space the loads become scalar (s_load into SGPRs) instead of 64 identical vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename R> using UniformRow = const __attribute__((address_space(4))) R*;
+template <typename R> __device__ __forceinline__ UniformRow<R> uniform_row(const R* p) { return (UniformRow<R>)(unsigned long long)p; }
+#else
+template <typename R> using UniformRow = const R*;
+template <typename R> inline UniformRow<R> uniform_row(const R* p) { return p; }
+#endif
+
 // ---- chain-shared model parameters (kalman_math.h::FiltShared) ---------------------------------------------------------------
 // table row of transition i -> i + 1, from chain 0's view of the shared parameters (the observation mask is the data's)
 template <typename R, int D, int P> AX_HD void body_filter_shared_tab(const FilterArgs& a, int i) {
@@ -310,7 +320,7 @@ template <typename R, int D, int P> AX_HD void body_filter_init_shared(const Fil
     using T = FiltShared<R, D, P>;
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
-    const R* row = (const R*)a.tab + (long long)i * T::NPAD;
+    const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
     R y[P], rb[P], rm[P], m_[D];
     rd<R, P>(a.ys, c, t, b, y);
 #pragma unroll
@@ -359,6 +369,8 @@ template <typename R_, int D, int P> struct FilterOpShared : FilterOp<R_, D> {
     static constexpr int DS = symsize(D);
     static AX_HD void load_elem(const FilterArgs& a, int s, int i, Full& e) {
         using T = FiltShared<R, D, P>;
+        // plain (vector) loads here: the scan kernels issue the next element's reads before the combine, which scalar loads into
+        // SGPRs cannot do for 36 doubles (measured: 0.85 -> 1.65 ms with scalar loads)
         const R* row = (const R*)a.tab + (long long)i * T::NPAD;
 #pragma unroll
         for (int k = 0; k < D * D; ++k) e.A[k] = row[T::oA + k];
@@ -369,6 +381,17 @@ template <typename R_, int D, int P> struct FilterOpShared : FilterOp<R_, D> {
 #pragma unroll
         for (int k = 0; k < D; ++k) e.b[k] = pc[k], e.eta[k] = pc[D + k];
         e.z = pc[2 * D];
+    }
+    // the filtered covariances are the same for every chain: only chain 0's copy is written (the sampler's table reads that one)
+    static AX_HD void write_out(const FilterArgs& a, int s, int i, const typename FilterOp<R_, D>::Pre& p) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        wr<R, D>(a.ms, c, (long long)i + 1, b, p.b);
+        if (s == 0) {
+            R Pd[D * D];
+            symunpack<R, D>(p.C, Pd);
+            wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
+        }
+        if (i == a.d.n() - 1 && a.ellz) ((R*)a.ellz)[s] = p.z;
     }
 };
 
@@ -547,7 +570,7 @@ template <typename R_, int D> struct SampleOpShared : SampleOp<R_, D> {
         using T = SampShared<R, D>;
         const int c = s / a.d.B, b = s % a.d.B;
         const long long t = (long long)a.d.T - 1 - j;
-        const R* row = (const R*)a.tab + t * T::NPAD;
+        const UniformRow<R> row = uniform_row<R>((const R*)a.tab + t * T::NPAD);
         R m[D], eps[D];
         rd<R, D>(a.ms, c, t, b, m);
         rd<R, D>(a.eps, c, t, b, eps);
