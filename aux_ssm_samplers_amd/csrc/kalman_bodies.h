@@ -693,6 +693,12 @@ struct SweepLogpdfArgs {
     double delta;
     int nan_policy;
     int dx = 0, po = 0;  // runtime sizes (wide.hip only)
+    const void* tab = nullptr;  // chain-shared parameters: per time step the Cholesky rows of Q_{t-1} and Robs_t (else null)
+};
+template <typename R, int D, int PO> struct LogShared {
+    static constexpr int oQ = 0, oR = CholRow<R, D>::SZ, N = CholRow<R, D>::SZ + CholRow<R, PO>::SZ;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
 };
 
 // the observation + auxiliary blocks at one time step for (xp, x); returns via references
@@ -811,6 +817,99 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_head(const Swe
 #pragma unroll
     for (int k = 0; k < D; ++k) r1[k] = xp[k] - m0[k], r2[k] = x[k] - m0[k];
     gauss_logpdf2<R, D>(r1, r2, P0m, nullptr, pr_p, pr_x);
+    out5[0] = cc_p + pr_p;
+    out5[1] = cc_x + pr_x;
+    out5[2] = ob_p + pr_p;
+    out5[3] = ob_x + pr_x;
+    out5[4] = corr;
+}
+
+// ---- the same pass with chain-shared parameters: Cholesky factors and log-determinants of Q_{t-1}, Robs_t once per time step ---
+template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_tab(const SweepLogpdfArgs& a, int i) {
+    using T = LogShared<R, D, PO>;
+    const long long t = (long long)i + 1;
+    R Q[D * D], Rm[PO * PO], y[PO], row[T::N];
+    rd<R, D * D>(a.Qs, 0, i, 0, Q);
+    rd_upper<R, PO>(a.Rs, 0, t, 0, Rm);
+    rd<R, PO>(a.ys, 0, t, 0, y);
+    bool skip[PO];
+#pragma unroll
+    for (int k = 0; k < PO; ++k) skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
+    chol_row<R, D>(Q, nullptr, row + T::oQ);
+    chol_row<R, PO>(Rm, a.nan_policy == 1 ? skip : nullptr, row + T::oR);
+    stv<R, T::N>((R*)a.tab + (long long)i * T::NPAD, row);
+}
+template <typename R, int D, int PO>
+AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int c, int i, R* out5) {
+    using T = LogShared<R, D, PO>;
+    using CQ = CholRow<R, D>;
+    using CR = CholRow<R, PO>;
+    const long long t = (long long)i + 1;
+    const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
+    R x[D], xp[D], u[D], xq[D], xpq[D], H[PO * D], cv[PO], y[PO], F[D * D], bd[D];
+    rd<R, D>(a.x, c, t, 0, x);
+    rd<R, D>(a.xp, c, t, 0, xp);
+    rd<R, D>(a.u, c, t, 0, u);
+    rd<R, D>(a.x, c, i, 0, xq);
+    rd<R, D>(a.xp, c, i, 0, xpq);
+    rd<R, PO * D>(a.Hs, 0, t, 0, H);
+    rd<R, PO>(a.cs, 0, t, 0, cv);
+    rd<R, PO>(a.ys, 0, t, 0, y);
+    rd<R, D * D>(a.Fs, 0, i, 0, F);
+    rd<R, D>(a.bs, 0, i, 0, bd);
+    // observation block (sweep_obs_terms with the factor from the table)
+    R ob_p, ob_x;
+    bool badobs_x = false, badobs_p = false;
+    {
+        R r1[PO], r2[PO];
+        bool skip[PO];
+#pragma unroll
+        for (int k = 0; k < PO; ++k) {
+            R p1 = cv[k], p2 = cv[k];
+#pragma unroll
+            for (int j = 0; j < D; ++j) p1 += H[k * D + j] * xp[j], p2 += H[k * D + j] * x[j];
+            r1[k] = y[k] - p1;
+            r2[k] = y[k] - p2;
+            skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
+            badobs_p = badobs_p || (!skip[k] && !finite_(r1[k]));
+            badobs_x = badobs_x || (!skip[k] && !finite_(r2[k]));
+        }
+        gauss_logpdf2_fact<R, PO>(r1, r2, row + T::oR + CR::oL, row + T::oR + CR::oI, row[T::oR + CR::oC], a.nan_policy == 1 ? skip : nullptr,
+                                  ob_p, ob_x);
+    }
+    R ax_x, ax_p, corr = 0;
+    bool b1 = false, b2 = false;
+    {
+        const R hd = (R)(0.5 * a.delta);
+        const R sd = sqrt_(hd);
+        R q1 = 0, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const R d1 = u[k] - xp[k], d2 = u[k] - x[k];
+            b1 = b1 || !finite_(d1);
+            b2 = b2 || !finite_(d2);
+            const R z1 = d1 / sd, z2 = d2 / sd;
+            q1 += z1 * z1;
+            q2 += z2 * z2;
+            const R e1 = xp[k] - u[k], e2 = x[k] - u[k];
+            corr += (e1 * e1 - e2 * e2) / (R)a.delta;
+        }
+        const R cst = -(R)D * log_(sd) - (R)(0.5 * LOG_2PI) * (R)D;
+        ax_p = b1 ? (R)0 : (R)-0.5 * q1 + cst;
+        ax_x = b2 ? (R)0 : (R)-0.5 * q2 + cst;
+    }
+    const bool ref = a.nan_policy == 0;
+    const R cc_p = (ref && (b1 || badobs_p)) ? (R)0 : ax_p + ob_p;
+    const R cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
+    R pr_p, pr_x;
+    {
+        R r1[D], r2[D], m1[D], m2[D];
+        mv<R, D, D>(F, xpq, m1);
+        mv<R, D, D>(F, xq, m2);
+#pragma unroll
+        for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
+        gauss_logpdf2_fact<R, D>(r1, r2, row + T::oQ + CQ::oL, row + T::oQ + CQ::oI, row[T::oQ + CQ::oC], nullptr, pr_p, pr_x);
+    }
     out5[0] = cc_p + pr_p;
     out5[1] = cc_x + pr_x;
     out5[2] = ob_p + pr_p;

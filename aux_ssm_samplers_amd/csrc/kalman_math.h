@@ -980,4 +980,69 @@ AX_HD void gauss_logpdf2(const R* r1, const R* r2, const R* __restrict__ cov, co
     if (bad2 || isnan_(o2)) o2 = 0;
 }
 
+// Two residuals against one covariance whose Cholesky factor (packed lower L, reciprocal diagonal invd) and additive constant
+// cst = -sum log L_kk - dim/2 log 2 pi come from a table (chain-shared parameters).  Same semantics as gauss_logpdf2: a failed
+// factorisation is cst = NaN; a non-finite kept residual or a NaN result is 0 (the reference's nansum).
+template <typename R, int N, typename LP>
+AX_HD void gauss_logpdf2_fact(const R* r1, const R* r2, LP L, LP invd, R cst, const bool* skip, R& o1, R& o2) {
+    R a[N], b[N];
+    bool bad1 = false, bad2 = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool sk = skip ? skip[k] : false;
+        a[k] = sk ? (R)0 : r1[k];
+        b[k] = sk ? (R)0 : r2[k];
+        bad1 = bad1 || !finite_(a[k]);
+        bad2 = bad2 || !finite_(b[k]);
+    }
+    R q1 = 0, q2 = 0;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        R s1 = a[i], s2 = b[i];
+#pragma unroll
+        for (int k = 0; k < i; ++k) s1 -= L[lidx(i, k)] * a[k], s2 -= L[lidx(i, k)] * b[k];
+        a[i] = s1 * invd[i];
+        b[i] = s2 * invd[i];
+        q1 += a[i] * a[i];
+        q2 += b[i] * b[i];
+    }
+    o1 = (R)-0.5 * q1 + cst;
+    o2 = (R)-0.5 * q2 + cst;
+    if (bad1 || isnan_(o1)) o1 = 0;
+    if (bad2 || isnan_(o2)) o2 = 0;
+}
+// table part for one covariance: [L packed (symsize N) | invd (N) | cst]; `skip` deletes components (L_kk = 1)
+template <typename R, int N> struct CholRow {
+    static constexpr int oL = 0, oI = symsize(N), oC = symsize(N) + N, SZ = symsize(N) + N + 1;
+};
+template <typename R, int N> AX_HD void chol_row(const R* __restrict__ cov, const bool* skip, R* out) {
+    using T = CholRow<R, N>;
+    R L[symsize(N)], invd[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i)
+#pragma unroll
+        for (int j = i; j < N; ++j) L[lidx(j, i)] = cov[i * N + j];
+    bool ok;
+    if constexpr (N == 1) {
+        ok = L[0] > (R)0;
+        L[0] = (skip && skip[0]) ? (R)1 : sqrt_(L[0]);
+        invd[0] = (R)1 / L[0];
+    } else {
+        ok = chol_inplace<R, N>(L, invd, skip);
+    }
+    R logdet = 0;
+    int dim = 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        const bool sk = skip ? skip[k] : false;
+        logdet += sk ? (R)0 : log_(L[lidx(k, k)]);
+        dim += sk ? 0 : 1;
+    }
+#pragma unroll
+    for (int i = 0; i < symsize(N); ++i) out[T::oL + i] = L[i];
+#pragma unroll
+    for (int i = 0; i < N; ++i) out[T::oI + i] = invd[i];
+    out[T::oC] = ok ? -logdet - (R)(0.5 * LOG_2PI) * (R)dim : r_nan<R>();
+}
+
 }  // namespace ax

@@ -273,6 +273,27 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, R*
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
 
+template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf_tab(SweepLogpdfArgs a) {
+    const int i = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (i < a.d.T - 1) body_sweep_logpdf_tab<R, D, PO>(a, i);
+}
+template <typename R, int D, int PO>
+__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+    const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
+    if (!c.live) return;
+    R v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) body_sweep_logpdf_head<R, D, PO>(a, c.s, v);
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) {
+        R w[5];
+        body_sweep_logpdf_shared<R, D, PO>(a, c.s, opaque_uniform(i), w);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
+}
+
 // scan passes: lane <-> sequence, workgroup <-> (chunk, 64 sequences)
 template <class Op>
 __global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
@@ -633,7 +654,8 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
 }
 
 template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;
+    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256 +
+           (size_t)d.T * LogShared<R, D, PO>::NPAD * sizeof(R) + 256;
 }
 // out: [5][C]
 template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
@@ -642,7 +664,15 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
     const int C = a.d.C, nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+    static const bool shared_on = [] { const char* e = getenv("AUXSSM_SHARED"); return e ? atoi(e) != 0 : true; }();
+    const bool shared = shared_on && cm && n > 0 && C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 &&
+                        a.cs.sc == 0 && a.ys.sc == 0;
+    if (shared) {  // chain-shared parameters: factor Q_{t-1} and Robs_t once per time step
+        SweepLogpdfArgs as = a;
+        as.tab = ws_take(h, (size_t)n * LogShared<R, D, PO>::NPAD * sizeof(R));
+        hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, as);
+        hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, as, part, nt, TI_CM);
+    } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
     else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
     AX_HIP(hipGetLastError());
