@@ -16,6 +16,7 @@ F32, F64 = 0, 1
 NAN_REFERENCE, NAN_MASKED = 0, 1
 KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND, KMODEL_LORENZ63_EXT = 1, 2, 3, 4
 LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
+OPT_SHARE_MODEL = 1
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
  K_CSMC_BWD) = range(9)
 
@@ -75,6 +76,7 @@ def load():
         "auxssm_destroy": ([vp], C.c_int),
         "auxssm_sync": ([vp], C.c_int),
         "auxssm_stream": ([vp, P(vp)], C.c_int),
+        "auxssm_set_option": ([vp, C.c_int, C.c_int], C.c_int),
         "auxssm_malloc": ([vp, C.c_size_t, P(vp)], C.c_int),
         "auxssm_free": ([vp, vp], C.c_int),
         "auxssm_memcpy_h2d": ([vp, vp, vp, C.c_size_t], C.c_int),
@@ -148,6 +150,10 @@ class Handle:
 
     def sync(self):
         check(self.lib.auxssm_sync(self.h))
+
+    def set_option(self, option, value):
+        """auxssm_set_option: e.g. (OPT_SHARE_MODEL, 0) forces the general per-chain path of the chain-minor sweep."""
+        check(self.lib.auxssm_set_option(self.h, int(option), int(value)))
 
     # ---- memory ----
     def empty(self, shape, dtype):

@@ -908,6 +908,7 @@ int auxssm_create(int device, auxssm_handle* out) {
     AX_HIP(hipGetDeviceProperties(&prop, device));
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     AX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
+    if (const char* e = getenv("AUXSSM_SHARED")) h->share_model = atoi(e) != 0;  // default of AUXSSM_OPT_SHARE_MODEL
     *out = h;
     return AUXSSM_OK;
 }
@@ -982,6 +983,16 @@ int auxssm_memset(auxssm_handle h, void* dst, int value, size_t bytes) {
     AX_NEED_H(h);
     AX_HIP(hipMemsetAsync(dst, value, bytes, h->stream));
     return AUXSSM_OK;
+}
+
+int auxssm_set_option(auxssm_handle h, int option, int value) {
+    AX_NEED_H(h);
+    if (option == AUXSSM_OPT_SHARE_MODEL) {
+        h->share_model = value != 0;
+        return AUXSSM_OK;
+    }
+    set_error("unknown option %d", option);
+    return AUXSSM_ERR_ARG;
 }
 
 int auxssm_prof_disable(auxssm_handle h) {

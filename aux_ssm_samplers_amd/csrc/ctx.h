@@ -39,6 +39,7 @@ struct auxssm_ctx {
     size_t ws_off = 0;
     ax::Prof prof;
     int num_cu = 256;
+    int share_model = 1;  // AUXSSM_OPT_SHARE_MODEL: hoist whatever depends only on chain-shared model parameters out of the chain loop
 };
 
 namespace ax {

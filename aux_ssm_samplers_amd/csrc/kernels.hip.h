@@ -544,7 +544,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
     // chain-shared model parameters (the factories of a linear-Gaussian model): element matrices and gain-type operators once per
     // time step, only (b, eta, z) per chain -- what jax.vmap leaves unbatched in the reference
-    static const bool shared_on = [] { const char* e = getenv("AUXSSM_SHARED"); return e ? atoi(e) != 0 : true; }();
+    const bool shared_on = h->share_model != 0;
     const bool shared = shared_on && cm && n > 0 && a.d.B == 1 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 &&
                         a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
     using TS = FiltShared<R, D, P>;
@@ -597,7 +597,7 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
     const int cm = a_in.lay.cm;
     a.lay = make_layout(plan_scan(h, S, T, parallel), cm, S);
     static const bool fly = [] { const char* e = getenv("AUXSSM_SAMPLE_FLY"); return e ? atoi(e) != 0 : true; }();
-    static const bool shared_on = [] { const char* e = getenv("AUXSSM_SHARED"); return e ? atoi(e) != 0 : true; }();
+    const bool shared_on = h->share_model != 0;
     if (cm && shared_on && a.ps_shared && a.d.B == 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0) {
         // chain-shared covariances: gains and Cholesky factors once per time step, a chain's element is two small mat-vecs
         a.elem = nullptr;
@@ -664,7 +664,7 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
     const int C = a.d.C, nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    static const bool shared_on = [] { const char* e = getenv("AUXSSM_SHARED"); return e ? atoi(e) != 0 : true; }();
+    const bool shared_on = h->share_model != 0;
     const bool shared = shared_on && cm && n > 0 && C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 &&
                         a.cs.sc == 0 && a.ys.sc == 0;
     if (shared) {  // chain-shared parameters: factor Q_{t-1} and Robs_t once per time step

@@ -13,6 +13,9 @@ Also reports, on the same JSON line:
                    algorithmic bytes = K3 n(3d^2+2d)s read + n(d^2+d)s written per chain, divided by its HIP-event
                    duration measured inside the timed region on the library's stream.  The marginal log-likelihood (K4, the
                    reference's second pass over the filtered moments) is the log-scale the scan elements carry: it costs no pass.
+  general_path  -- the same workload with nothing hoisted out of the chain loop (what chain-specific parameters cost); `value`
+                   is the default mode: the model's parameters are the same for every chain, so the element matrices, gains and
+                   Cholesky factors are computed once per time step and sweep (what jax.vmap leaves unbatched in the reference).
   cpu_baseline  -- the NumPy oracle (a port of the reference's parallel path) timed on this box's host, rank 0 only.
 """
 import argparse
@@ -177,6 +180,10 @@ def main():
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket the scan with HIP events")
+    ap.add_argument("--no-share-model", action="store_true",
+                    help="force the general per-chain path (AUXSSM_OPT_SHARE_MODEL = 0): nothing is hoisted out of the chain loop even though "
+                         "the parameters of this linear-Gaussian model are the same for every chain")
+    ap.add_argument("--no-general-leg", action="store_true", help="skip the extra (untimed-for-value) run of the general per-chain path")
     ap.add_argument("--workload", default="kalman", choices=["kalman", "csmc"],
                     help="kalman = BASELINE configs[1] (C2, the headline); csmc = configs[2] (C3), secondary")
     ap.add_argument("--N", type=int, default=1024, help="particles (csmc workload)")
@@ -221,6 +228,8 @@ def main():
     x0 = (m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
     chains = DeviceChains(handle, x0)
     state = KalmanSampler(x=chains, updated=None)
+    share = not args.no_share_model
+    handle.set_option(_lib.OPT_SHARE_MODEL, int(share))
     key = R.PRNGKey(2024 + rank)
     delta = 0.5
 
@@ -257,6 +266,30 @@ def main():
         scan_n, scan_ms = handle.prof_read()
         handle.prof_disable()
 
+    # second leg (reported beside the headline, never as `value`): the same workload on the general per-chain path, i.e. what a
+    # model with chain-specific parameters (any nonlinear model: a linearisation per chain) costs
+    general = None
+    if share and not args.no_general_leg and not args.no_prof:
+        handle.set_option(_lib.OPT_SHARE_MODEL, 0)
+        gsteps = max(3, args.steps // 2)
+        step(args.warmup + args.steps)  # warm the other code path (workspace, code objects)
+        barrier()
+        handle.prof_enable(_lib.K_FILTER_SCAN, gsteps + 1)
+        barrier()
+        g0 = time.perf_counter()
+        for k in range(gsteps):
+            step(k % (args.steps + args.warmup))
+        barrier()
+        gel = time.perf_counter() - g0
+        if dist is not None:
+            t = torch.tensor([gel], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            gel = float(t.item())
+        gn, gms = handle.prof_read()
+        handle.prof_disable()
+        handle.set_option(_lib.OPT_SHARE_MODEL, 1)
+        general = dict(steps=gsteps, value=C * world * gsteps / gel, ms_per_step=gel / gsteps * 1e3, scan_ms=gms / max(gn, 1))
+
     # the trivial chain-gather (RCCL): acceptance flags + last log-alphas of every chain to rank 0
     from aux_ssm_samplers_amd.parallel import gather_chains
     acc = chains.accepted.to_host()
@@ -277,14 +310,16 @@ def main():
         traffic = None  # HBM bytes per launch group from the PMC passes committed under profiles/ (same config only)
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            traffic = tj.get(f"kalman_C2_{args.dtype}_T{T}_d{d}_chains{C}", {}).get("filter_scan_group_hbm_bytes")
+            ent = tj.get(f"kalman_C2_{args.dtype}_T{T}_d{d}_chains{C}" + ("_shared_model" if share else ""), {})
+            traffic = ent.get("filter_scan_group_hbm_bytes")
         except Exception:
             pass
         if scan_n:
             avg_s = scan_ms / scan_n * 1e-3
             ach = alg_bytes / avg_s / 1e9
             roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4),
-                        traffic=traffic, kernel="filter associative scan incl. the marginal log-likelihood (k_scan_reduce_cm + k_scan_aggs + k_scan_down_cm<FilterOp>)",
+                        traffic=traffic, kernel="filter associative scan incl. the marginal log-likelihood (k_scan_reduce_cm + k_scan_aggs + k_scan_down_cm, " +
+                               ("FilterOpShared: element matrices read once per time step, (b, eta, z) per chain)" if share else "FilterOp: general per-chain elements)"),
                         avg_launch_ms=round(scan_ms / scan_n, 4), launches=scan_n, algorithmic_bytes_per_launch=alg_bytes)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
@@ -299,6 +334,15 @@ def main():
             "accept_rate": float(np.mean(acc)), "max_abs_log_alpha": float(np.max(np.abs(logs[:, 0]))),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        out["config"]["model_sharing"] = ("chain-shared model parameters hoisted out of the chain loop (jax.vmap semantics)" if share
+                                          else "off: general per-chain path")
+        if general is not None:
+            gach = alg_bytes / (general["scan_ms"] * 1e-3) / 1e9 if general["scan_ms"] else None
+            out["general_path"] = {"value": round(general["value"], 2), "unit": "sweeps/s", "steps": general["steps"],
+                                   "ms_per_step": round(general["ms_per_step"], 4), "scan_avg_launch_ms": round(general["scan_ms"], 4),
+                                   "scan_achieved_GBps": None if gach is None else round(gach, 1),
+                                   "scan_frac": None if gach is None else round(gach / 8000.0, 4),
+                                   "note": "same workload with AUXSSM_OPT_SHARE_MODEL = 0: every chain builds and combines its own d x d elements"}
         print(json.dumps(out))
     if dist is not None:
         dist.barrier()

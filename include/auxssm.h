@@ -72,6 +72,15 @@ int auxssm_device_count(int* count);
 int auxssm_create(int device, auxssm_handle* out);
 int auxssm_destroy(auxssm_handle h);
 int auxssm_sync(auxssm_handle h);
+/* Options of a handle.
+ * AUXSSM_OPT_SHARE_MODEL (default 1; environment AUXSSM_SHARED=0 changes the default): in the chain-minor sweep, when the
+ *   model's parameter arrays do not depend on the chain (chain stride 0: the factories of a linear-Gaussian model ignore the
+ *   linearisation point), everything that depends on the parameters only -- element matrices, gains, Cholesky factors of Q_t /
+ *   R_t, the filtered covariances -- is computed once per time step and sweep instead of once per chain (what jax.vmap leaves
+ *   unbatched in the reference).  0 forces the general per-chain path.  Results agree to rounding. */
+typedef enum { AUXSSM_OPT_SHARE_MODEL = 1 } auxssm_option;
+int auxssm_set_option(auxssm_handle h, int option, int value);
+
 /* the hipStream_t the handle launches on (as an opaque pointer) */
 int auxssm_stream(auxssm_handle h, void** stream);
 

@@ -278,6 +278,18 @@ def test_chain_minor_sweep_equals_dense_sweep_and_oracle(d, T, parallel):
     npt.assert_allclose(outs[True][0], outs[False][0], rtol=1e-9, atol=1e-10)
     npt.assert_array_equal(outs[True][1], outs[False][1])
     npt.assert_allclose(outs[True][2][:, 1:], outs[False][2][:, 1:], rtol=1e-9)
+    # the chain-minor run above hoisted the chain-shared model parameters (AUXSSM_OPT_SHARE_MODEL, default): the general per-chain
+    # path of the same layout must give the same sweep
+    h.set_option(_lib.OPT_SHARE_MODEL, 0)
+    try:
+        chains = DeviceChains(h, x0, chain_minor=True)
+        kernel(None, KalmanSampler(x=chains, updated=None), 0.5, noise=noise)
+        gen = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    finally:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    npt.assert_allclose(outs[True][0], gen[0], rtol=1e-9, atol=1e-10)
+    npt.assert_array_equal(outs[True][1], gen[1])
+    npt.assert_allclose(outs[True][2][:, 1:], gen[2][:, 1:], rtol=1e-9)
     lgo = (m["m0"], m["P0"], model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs)
     for c in (0, 33, C - 1):
         ref = K.kalman_sweep(x0[c], 0.5, model.dynamics_factory, model.observations_factory,
