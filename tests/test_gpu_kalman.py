@@ -298,3 +298,41 @@ def test_chain_minor_sweep_equals_dense_sweep_and_oracle(d, T, parallel):
         npt.assert_allclose(outs[True][0][c], ref["x"], rtol=1e-9, atol=1e-10)
         npt.assert_allclose(outs[True][2][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
         assert bool(outs[True][1][c]) == ref["accepted"]
+
+
+@pytest.mark.parametrize("dtype,nan_policy", [(np.float64, "masked"), (np.float32, "reference"), (np.float32, "masked")])
+def test_shared_model_mode_equals_general_path(dtype, nan_policy):
+    """AUXSSM_OPT_SHARE_MODEL on vs off (chain-minor layout), fp32 and the masked NaN policy included: same proposals, same
+    acceptances, same log terms up to rounding (fp64 1e-9; fp32: the two paths order 65k-term sums differently -> 2e-3 relative)."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import LGConcatModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler, _get_device_kernel
+    d, T, C = 4, 500, 96
+    m = lg_model(T, d)
+    y = m["y"].copy()
+    rng = np.random.default_rng(17)
+    y[rng.random(T) < 0.1] = np.nan
+    y[rng.random((T, d)) < 0.05] = np.nan
+    bt = np.broadcast_to
+    model = LGConcatModel(m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
+                          bt(m["Hobs"], (T, d, d)), bt(m["Robs"], (T, d, d)), bt(m["cobs"], (T, d)), y)
+    init, kernel = _get_device_kernel(model, True, nan_policy)
+    x0 = (m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    res = {}
+    try:
+        for share in (1, 0):
+            h.set_option(_lib.OPT_SHARE_MODEL, share)
+            chains = DeviceChains(h, x0, chain_minor=True)
+            kernel(None, KalmanSampler(x=chains, updated=None), 0.5, noise=noise)
+            res[share] = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    finally:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == np.float64 else dict(rtol=2e-3, atol=2e-3)
+    # compare the proposals through the accepted chains and the log terms; acceptance may flip only where log alpha ~ log u in fp32
+    npt.assert_allclose(res[1][2][:, 1:], res[0][2][:, 1:], rtol=tol["rtol"])
+    same = res[1][1] == res[0][1]
+    assert same.mean() > (0.999 if dtype == np.float64 else 0.9)
+    npt.assert_allclose(res[1][0][same], res[0][0][same], **tol)
+    assert np.all(np.isfinite(res[1][0]))
