@@ -366,13 +366,18 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     const Arr epsauxA = cm ? cm_arr(eps_aux, kd, D) : dense_arr(eps_aux, kd, D);
     const Arr epsA = cm ? cm_arr(eps_samp, kd, D) : dense_arr(eps_samp, kd, D);
 
-    // observations_factory / dynamics_factory of the LG_CONCAT device model
+    // observations_factory / dynamics_factory of the LG_CONCAT device model.  With chain-shared parameters in the chain-minor layout
+    // the filter builds u and the concatenated observation on the fly for t >= 1 (FilterArgs::aux_*): only row t = 0 is materialised.
+    const bool model_shared = model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->Hs.sc == 0 && model->Rs.sc == 0 &&
+                              model->cs.sc == 0 && model->P0.sc == 0 && yobs->sc == 0;
+    const bool aux_fly = cm && h->share_model && model_shared && C > 1 && T > 1 && !wide;
     {
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
                            cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
-        const long long n2 = (long long)CT * P;
-        hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, T, D, PO,
+        const int Tc = aux_fly ? 1 : T;
+        const long long n2 = (long long)C * Tc * P;
+        hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, Tc, D, PO,
                            xA, epsauxA, (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, cm);
     }
     auxssm_lgssm gc = *model;
@@ -393,6 +398,14 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     fa.Ps = PsA;
     fa.lay.cm = cm;
     fa.pblk = D;  // R = blkdiag(delta/2 I_d, Robs) by construction
+    if (aux_fly) {
+        fa.aux_on = 1;
+        fa.aux_x = xA;
+        fa.aux_eps = epsauxA;
+        fa.aux_u = uA;
+        fa.aux_yobs = cv(*yobs);
+        fa.aux_shd = sqrt(0.5 * delta);
+    }
     rc = ke->filter(h, fa, parallel, ell);
     if (rc) return rc;
     h->ws_off = mark;

@@ -111,6 +111,11 @@ struct FilterArgs {
     int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
     const void* tab = nullptr;  // chain-shared parameters: one FiltShared row per transition (else null)
     void* pc = nullptr;         // ... and the per-chain element parts [i][b | eta | z][s]
+    // Concatenated auxiliary observations built on the fly (sweep of the LG_CONCAT model, shared mode): for t >= 1 the observation
+    // is y_t = [u_t ; yobs_t] with u = x + aux_shd * eps (kalman/generic.py:59-63); u is written to aux_u, ys holds row t = 0 only.
+    int aux_on = 0;
+    Arr aux_x{}, aux_eps{}, aux_u{}, aux_yobs{};
+    double aux_shd = 0;
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
 AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
@@ -301,7 +306,12 @@ template <typename R, int D, int P> AX_HD void body_filter_shared_tab(const Filt
     rd<R, D * D>(a.Qs, 0, i, 0, P_);
     rd<R, P * D>(a.Hs, 0, t, 0, H);
     rd<R, P>(a.cs, 0, t, 0, cv);
-    rd<R, P>(a.ys, 0, t, 0, y);
+    if (a.aux_on) {  // only the observation mask matters here: the auxiliary part is always present, the rest is the data's
+#pragma unroll
+        for (int k = 0; k < P; ++k) y[k] = k < D ? (R)0 : at<R>(a.aux_yobs, 0, t, 0)[k - D];
+    } else {
+        rd<R, P>(a.ys, 0, t, 0, y);
+    }
     rd_upper<R, P>(a.Rs, 0, t, 0, Rm);
     if (i == 0) {  // P_ = F P0+ F^T + Q, not symmetrised (filtering.py:200-201)
         R P0p[D * D], FP[D * D], Pn[D * D];
@@ -322,7 +332,20 @@ template <typename R, int D, int P> AX_HD void body_filter_init_shared(const Fil
     const long long t = (long long)i + 1;
     const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
     R y[P], rb[P], rm[P], m_[D];
-    rd<R, P>(a.ys, c, t, b, y);
+    if (a.aux_on) {
+        if constexpr (P > D) {
+            R xv[D], ev[D], uv[D];
+            rd<R, D>(a.aux_x, c, t, b, xv);
+            rd<R, D>(a.aux_eps, c, t, b, ev);
+#pragma unroll
+            for (int k = 0; k < D; ++k) uv[k] = xv[k] + (R)a.aux_shd * ev[k], y[k] = uv[k];
+            wr<R, D>(a.aux_u, c, t, b, uv);
+#pragma unroll
+            for (int k = D; k < P; ++k) y[k] = at<R>(a.aux_yobs, 0, t, 0)[k - D];
+        }
+    } else {
+        rd<R, P>(a.ys, c, t, b, y);
+    }
 #pragma unroll
     for (int k = 0; k < P; ++k) rb[k] = finite_(y[k]) ? y[k] - row[T::oYm + k] : (R)0, rm[k] = rb[k];
 #pragma unroll

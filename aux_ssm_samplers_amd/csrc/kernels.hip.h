@@ -548,6 +548,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     const bool shared = shared_on && cm && n > 0 && a.d.B == 1 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 &&
                         a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
     using TS = FiltShared<R, D, P>;
+    if (!shared) a.aux_on = 0;  // (the caller materialised the concatenated observations in that case)
     if (shared) {
         a.tab = ws_take(h, (size_t)n * TS::NPAD * sizeof(R));
         a.pc = ws_take(h, (size_t)n * TS::NPC * S * sizeof(R));
