@@ -247,9 +247,9 @@ def test_sampler_moments_reference_statistical_test(seed, T, dx, dy, parallel):
     npt.assert_allclose(cov, esP, atol=1e-2, rtol=1e-2)
 
 
-@pytest.mark.parametrize("d,T", [(4, 700), (2, 333), (1, 200)])
+@pytest.mark.parametrize("d,T,time_varying", [(4, 700, False), (2, 333, False), (1, 200, False), (4, 260, True), (2, 150, True)])
 @pytest.mark.parametrize("parallel", [True, False])
-def test_chain_minor_sweep_equals_dense_sweep_and_oracle(d, T, parallel):
+def test_chain_minor_sweep_equals_dense_sweep_and_oracle(d, T, parallel, time_varying):
     """The layout bench.py runs (>= 32 chains: state, noise and every internal buffer chain-minor, lanes over chains) against the
     dense layout chain by chain and against the oracle sweep, on identical explicit noise, missing observation rows included."""
     from aux_ssm_samplers_amd import _lib
@@ -263,8 +263,19 @@ def test_chain_minor_sweep_equals_dense_sweep_and_oracle(d, T, parallel):
     if d > 1:
         y[rng.random((T, d)) < 0.05] = np.nan  # single components missing
     bt = np.broadcast_to
-    model = LGConcatModel(m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
-                          bt(m["Hobs"], (T, d, d)), bt(m["Robs"], (T, d, d)), bt(m["cobs"], (T, d)), y)
+    if time_varying:  # chain-shared but different at every time step (materialised arrays, time stride != 0)
+        Fs = m["F"][None] * (1 + 0.1 * rng.standard_normal((T - 1, 1, 1))) + 0.02 * rng.standard_normal((T - 1, d, d))
+        A = rng.standard_normal((T - 1, d, 2 * d))
+        Qs = 0.05 * A @ A.transpose(0, 2, 1) / d + 0.05 * np.eye(d)
+        bs = 0.1 * rng.standard_normal((T - 1, d))
+        Hs = np.eye(d)[None] + 0.2 * rng.standard_normal((T, d, d))
+        Bm = rng.standard_normal((T, d, 2 * d))
+        Rs = 0.2 * Bm @ Bm.transpose(0, 2, 1) / d + 0.2 * np.eye(d)
+        cs = 0.1 * rng.standard_normal((T, d))
+        model = LGConcatModel(m["m0"], m["P0"], Fs, Qs, bs, Hs, Rs, cs, y)
+    else:
+        model = LGConcatModel(m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
+                              bt(m["Hobs"], (T, d, d)), bt(m["Robs"], (T, d, d)), bt(m["cobs"], (T, d)), y)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, parallel)
     x0 = m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))
     noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
