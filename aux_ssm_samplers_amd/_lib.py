@@ -92,6 +92,11 @@ def load():
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_stats_attach": ([vp, vp, vp, vp, i64], C.c_int),
+        "auxssm_stats_update": ([vp, i32, i64, i64, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_accept_update": ([vp, i32, C.c_int32, C.c_int32, i64, dbl, vp, vp, vp], C.c_int),
+        "auxssm_delta_adapt": ([vp, i32, C.c_int32, C.c_int32, vp, dbl, dbl, dbl, dbl, vp, vp], C.c_int),
+        "auxssm_lorenz_theta_update": ([vp, i32, C.c_int32, C.c_int32, vp, dbl, dbl, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
     }
@@ -183,6 +188,34 @@ class Handle:
 
     def prof_disable(self):
         check(self.lib.auxssm_prof_disable(self.h))
+
+    # ---- the MCMC loop around the sweeps (include/auxssm.h: running statistics, adaptation, Lorenz theta step) ----
+    def stats_attach(self, stats, it):
+        """stats: (sq_jump, mean, sq_mean) DeviceArrays shaped like the resident state, or None to detach"""
+        p = [None, None, None] if stats is None else [a.ptr for a in stats]
+        check(self.lib.auxssm_stats_attach(self.h, p[0], p[1], p[2], int(it)))
+
+    def stats_update(self, it, x_prev, x_next, stats):
+        check(self.lib.auxssm_stats_update(self.h, dtype_code(x_next.dtype), x_next.size, int(it), x_prev.ptr, x_next.ptr, stats[0].ptr,
+                                           stats[1].ptr, stats[2].ptr))
+
+    def accept_update(self, it, beta, flags, avg, window):
+        """flags (C, m) int32 (nonzero = updated); avg, window (C, m)"""
+        Cn = flags.shape[0]
+        check(self.lib.auxssm_accept_update(self.h, dtype_code(avg.dtype), Cn, flags.size // max(Cn, 1), int(it), float(beta), flags.ptr,
+                                            avg.ptr, window.ptr))
+
+    def delta_adapt(self, window, target, rate, delta, sqrt_half_delta=None, min_delta=1e-20, max_delta=1e20):
+        Cn = window.shape[0]
+        check(self.lib.auxssm_delta_adapt(self.h, dtype_code(delta.dtype), Cn, delta.size, window.ptr, float(target), float(rate),
+                                          float(min_delta), float(max_delta), delta.ptr,
+                                          sqrt_half_delta.ptr if sqrt_half_delta is not None else None))
+
+    def lorenz_theta_update(self, x, sigma_theta, sigma_x, eps, par, mean_chol=None):
+        """x (C, T, 3), eps (C, 3), par (C, 4) DeviceArrays"""
+        Cn, T, _ = x.shape
+        check(self.lib.auxssm_lorenz_theta_update(self.h, dtype_code(x.dtype), Cn, T, x.ptr, float(sigma_theta), float(sigma_x), eps.ptr,
+                                                  par.ptr, mean_chol.ptr if mean_chol is not None else None))
 
     # ---- RNG fill ----
     def rng_normal(self, key, stream, shape, dtype):

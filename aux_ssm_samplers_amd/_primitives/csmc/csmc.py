@@ -19,6 +19,9 @@ def get_kernel(M0, G0, Mt, Gt, N, backward=False, Pt=None):
     fk = _device.describe_bootstrap(M0, G0, Mt, Gt, Pt if backward else None)
 
     def kernel(key, state, noise=None):
+        if isinstance(state.x, _device.CsmcChains):  # resident chains: in place, asynchronous
+            _device.sweep_resident(fk, state.x, N, backward, key)
+            return CSMCState(x=state.x, updated=state.x.ancestors)
         x, anc, extra = _device.sweep(fk, state.x, N, backward, key=key, noise=noise)
         out = CSMCState(x=x, updated=anc != 0)  # csmc.py:59
         out.ancestors = anc

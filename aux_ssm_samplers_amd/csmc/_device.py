@@ -114,6 +114,61 @@ def key_noise(handle, key, Cn, T, N, d, dtype):
                 u_bwd=handle.rng_uniform(key, 4, (Cn, T), dtype).to_host())
 
 
+class CsmcChains:
+    """C chains' reference trajectories resident in HBM, (C, T, d), with the sweep's other per-chain buffers: a run of sweeps on them
+    (kernel(key, state, delta) with state.x a CsmcChains) never returns to the host.  delta: per-time-step step sizes (T,) kept on the
+    device beside sqrt(delta / 2), the array the sweep reads (csmc/generic.py:61-63)."""
+
+    def __init__(self, handle, x, delta=None, dtype=None):
+        x = np.asarray(x)
+        if x.ndim == 2:
+            x = x[None]
+        self.handle = handle
+        self.C, self.T, self.dx = x.shape
+        self.dtype = np.dtype(dtype or (np.float32 if x.dtype == np.float32 else np.float64))
+        self.x = handle.to_device(x, self.dtype)
+        self.ancestors = handle.zeros((self.C, self.T), np.int32)
+        self.delta = self.sqrt_half_delta = None
+        if delta is not None:
+            self.set_delta(delta)
+
+    def set_delta(self, delta):
+        d = np.asarray(delta, np.float64) * np.ones(self.T)
+        self.delta = self.handle.to_device(d, self.dtype)
+        self.sqrt_half_delta = self.handle.to_device(np.sqrt(0.5 * d), self.dtype)
+
+    def to_host(self):
+        return self.x.to_host()
+
+    def stats_to_host(self, a):
+        return a.to_host()
+
+
+def sweep_resident(fk, chains, N, backward, key):
+    """One Threefry-keyed auxssm_csmc_sweep on resident chains.  Asynchronous."""
+    handle, d = chains.handle, chains.dx
+    if d != fk.dx:
+        raise ValueError(f"state dimension {d} != model dimension {fk.dx}")
+    m = _lib.FkModel(fk.proposal, fk.potential, d, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
+                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
+    yd = fk.ydev(handle, chains.dtype)
+    if yd is not None:
+        if yd.shape[0] != chains.T:
+            raise ValueError(f"observations have {yd.shape[0]} time steps, state has {chains.T}")
+        m.y = yd.ptr.value
+    shd = None
+    if fk.proposal == _lib.PROP_AUX_INDEPENDENT:
+        if chains.sqrt_half_delta is None:
+            raise ValueError("delta is required")
+        shd = chains.sqrt_half_delta
+    k = _random.as_key(key)
+    nz = _lib.CsmcNoise()
+    nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(k[0]), int(k[1])
+    _lib.check(handle.lib.auxssm_csmc_sweep(
+        handle.h, _lib.dtype_code(chains.dtype), C.byref(m), chains.C, chains.T, N, int(bool(backward)), shd.ptr if shd is not None else None,
+        chains.x.ptr, C.byref(nz), chains.ancestors.ptr, None, None, None))
+
+
 def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, want_history=False):
     """x: (T, d) one chain or (C, T, d).  noise: dict of explicit arrays (eps_prop, u_res, u_bwd[, eps_aux]) or None -> Threefry(key).
     Returns (x_new, ancestors, history dict or None)."""

@@ -31,6 +31,11 @@ def get_kernel(factory, N, backward=False, Pt=None):
 
     def kernel(key, state, delta, noise=None):
         # generic.py:56-72: u = x + sqrt(delta/2) eps; (m0, g0, mt, gt) = factory(u, sqrt(delta/2)); cSMC sweep
+        if isinstance(state.x, _device.CsmcChains):  # resident chains: in place, asynchronous; delta None = the chains' device delta
+            if delta is not None:
+                state.x.set_delta(delta)
+            _device.sweep_resident(fk, state.x, N, backward, key)
+            return CSMCState(x=state.x, updated=state.x.ancestors)
         x, anc, extra = _device.sweep(fk, state.x, N, backward, key=key, noise=noise, delta=delta)
         out = CSMCState(x=x, updated=anc != 0)
         out.ancestors = anc

@@ -283,8 +283,18 @@ __global__ void k_accept(int C, const R* jp_prop, const R* jp_rev, const R* ell_
         logs[c * 5 + 4] = lt_rev[c];
     }
 }
-// x <- xp for accepted chains, both through strided views; cfast as in k_concat_obs
-template <typename R> __global__ void k_select(int C, int T, int D, const int32_t* accepted, Arr xp, Arr x, int cfast) {
+// x <- xp for accepted chains, both through strided views; cfast as in k_concat_obs.  With running moments attached
+// (auxssm_stats_attach) the same pass folds the sweep into them, the `stats = tree_map(lambda u, v: (i * u + v) / (i + 1), ...)` line of
+// the reference's loop body (examples/stochastic_volatility/experiment.py:81-83, :113) -- no contraction, so the fold is the NumPy one
+// bit for bit.
+template <typename R> AX_HD R fold_mean(R i, R u, R v) {
+#pragma clang fp contract(off)
+    const R a = i * u;
+    const R b = a + v;
+    return b / (i + (R)1);
+}
+template <typename R>
+__global__ void k_select(int C, int T, int D, const int32_t* accepted, Arr xp, Arr x, int cfast, R* sq_jump, R* mean, R* sq_mean, long long iter) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)C * T * D) return;
     int c, k;
@@ -300,7 +310,27 @@ template <typename R> __global__ void k_select(int C, int T, int D, const int32_
         c = (int)(ct / T);
         t = ct % T;
     }
-    if (accepted[c]) const_cast<R*>(at<R>(x, c, t, 0))[(long long)k * x.se] = at<R>(xp, c, t, 0)[(long long)k * xp.se];
+    R* px = const_cast<R*>(at<R>(x, c, t, 0)) + (long long)k * x.se;
+    const int acc = accepted[c];
+    if (!mean) {
+        if (acc) *px = at<R>(xp, c, t, 0)[(long long)k * xp.se];
+        return;
+    }
+    const R xo = *px;
+    const R xn = acc ? at<R>(xp, c, t, 0)[(long long)k * xp.se] : xo;
+    if (acc) *px = xn;
+    const long long off = px - (const R*)x.ptr;
+    const R i = (R)iter, dj = xn - xo;
+    sq_jump[off] = fold_mean<R>(i, sq_jump[off], dj * dj);
+    mean[off] = fold_mean<R>(i, mean[off], xn);
+    sq_mean[off] = fold_mean<R>(i, sq_mean[off], xn * xn);
+}
+// the accept/select step of every Kalman sweep
+template <typename R> static void launch_select(auxssm_ctx* h, int C, int T, int D, const int32_t* accepted, Arr xp, Arr x, int cfast) {
+    const long long total = (long long)C * T * D;
+    hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, C, T, D, accepted, xp, x, cfast,
+                       (R*)h->st_sq_jump, (R*)h->st_mean, (R*)h->st_sq_mean, h->st_iter);
+    if (h->st_mean) ++h->st_iter;
 }
 
 template <typename R>
@@ -438,9 +468,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)jp_prop, (const R*)jp_rev,
                        (const R*)ell, (const R*)ell, (const R*)lt_prop, (const R*)lt_rev, (const R*)corr, (const R*)u_acc,
                        accepted, (R*)logs);
-    const long long total = (long long)CT * D;
-    hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, C, T, D,
-                       (const int32_t*)accepted, xpA, xA, cm);
+    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -650,8 +678,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
                        (const R*)ys1, (const R*)ys2, (const R*)Rs1, (const R*)Rs2, terms);
     hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
                        (const R*)ell2, (const R*)terms, (const R*)u_acc, accepted, (R*)logs);
-    hipLaunchKernelGGL((k_select<R>), dim3(gb), dim3(256), 0, h->stream, C, T, D, (const int32_t*)accepted, dense_arr(xp, kd, D),
-                       dense_arr(x, kd, D), 0);
+    launch_select<R>(h, C, T, D, (const int32_t*)accepted, dense_arr(xp, kd, D), dense_arr(x, kd, D), 0);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -667,11 +694,13 @@ template <typename R> AX_HD void lorenz_mean(const R* th, R dt, const R* x, R* m
     mu[2] = x[2] + dt * (x[0] * x[1] - th[2] * x[2]);
 }
 template <typename R>
-__global__ void k_lorenz_dyn(int C, int T, const R* __restrict__ par, const R* __restrict__ xlin, R* __restrict__ Fs, R* __restrict__ bs) {
+__global__ void k_lorenz_dyn(int C, int T, const R* __restrict__ par, long long psc, const R* __restrict__ xlin, R* __restrict__ Fs,
+                             R* __restrict__ bs) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = T - 1;
     if (g >= (long long)C * n) return;
     const long long c = g / n, i = g % n;
+    par += c * psc;  // per-chain theta (a Gibbs sampler over (x, theta) keeps one theta per chain)
     const R th[3] = {par[0], par[1], par[2]};
     const R dt = par[3];
     const R* x = xlin + (c * T + i) * 3;
@@ -686,11 +715,12 @@ __global__ void k_lorenz_dyn(int C, int T, const R* __restrict__ par, const R* _
 }
 // per chain: target(xp), target(x), corr.  out [3][C]
 template <typename R, int PO>
-__global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, R delta, const R* __restrict__ par, Arr m0, Arr P0, Arr Qs, Arr Hs, Arr Rs,
-                                                      Arr cs, Arr yobs, const R* __restrict__ x, const R* __restrict__ xp,
+__global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, R delta, const R* __restrict__ par, long long psc, Arr m0, Arr P0, Arr Qs,
+                                                      Arr Hs, Arr Rs, Arr cs, Arr yobs, const R* __restrict__ x, const R* __restrict__ xp,
                                                       const R* __restrict__ u, R* __restrict__ out) {
     __shared__ R sh[256];
     const int c = blockIdx.x, tid = threadIdx.x;
+    par += (long long)c * psc;
     const R th[3] = {par[0], par[1], par[2]};
     const R dt = par[3];
     R acc[3] = {0, 0, 0};
@@ -791,7 +821,8 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     if (!ysc || !Hc || !Rc || !cc || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc) return AUXSSM_ERR_NOMEM;
     R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
     const size_t mark = h->ws_off;
-    const R* par = (const R*)model->Fs.ptr;  // [theta1, theta2, theta3, dt]
+    const R* par = (const R*)model->Fs.ptr;  // [theta1, theta2, theta3, dt], chain stride model->Fs.sc (0 = one theta for all chains)
+    const long long psc = model->Fs.sc;
     const Arr xA = dense_arr(x, kd, D), xpA = dense_arr(xp, kd, D), uA = dense_arr(u, kd, D), yscA = dense_arr(ysc, kd, P);
     {
         const long long n1 = (long long)T * (P * D + P * P + P);
@@ -817,7 +848,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     const auxssm_arr yd{ysc, (int64_t)T * P, (int64_t)P, 0};
 
     // proposal: dynamics linearised at x (generic.py:80-86)
-    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, par, (const R*)x, Fs1, bs1);
+    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, par, psc, (const R*)x, Fs1, bs1);
     FilterArgs fa;
     fill_filter_args(fa, &dc, &g1, &yd, ms, Ps);
     fa.pblk = D;
@@ -835,7 +866,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     if (rc) return rc;
     h->ws_off = mark;
     // reverse move: dynamics linearised at x_prop (generic.py:67)
-    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, par, (const R*)xp, Fs2, bs2);
+    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, par, psc, (const R*)xp, Fs2, bs2);
     fill_filter_args(fa, &dc, &g2, &yd, ms, Ps);
     fa.pblk = D;
     rc = ke->filter(h, fa, parallel, ell2);
@@ -851,7 +882,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     if (rc) return rc;
     h->ws_off = mark;
 #define AX_LORENZ_TERMS(PO_)                                                                                                              \
-    hipLaunchKernelGGL((k_lorenz_terms<R, PO_>), dim3(C), dim3(256), 0, h->stream, C, T, (R)delta, par, cv(model->m0), cv(model->P0),    \
+    hipLaunchKernelGGL((k_lorenz_terms<R, PO_>), dim3(C), dim3(256), 0, h->stream, C, T, (R)delta, par, psc, cv(model->m0), cv(model->P0), \
                        cv(model->Qs), cv(model->Hs), cv(model->Rs), cv(model->cs), cv(*yobs), (const R*)x, (const R*)xp, (const R*)u, terms)
     if (PO == 1) AX_LORENZ_TERMS(1);
     else if (PO == 2) AX_LORENZ_TERMS(2);
@@ -859,9 +890,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
 #undef AX_LORENZ_TERMS
     hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
                        (const R*)ell2, (const R*)terms, (const R*)(terms + C), (const R*)(terms + 2 * C), (const R*)u_acc, accepted, (R*)logs);
-    const long long total = (long long)CT * D;
-    hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, C, T, D, (const int32_t*)accepted, xpA,
-                       xA, 0);
+    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, 0);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -40,6 +40,11 @@ struct auxssm_ctx {
     ax::Prof prof;
     int num_cu = 256;
     int share_model = 1;  // AUXSSM_OPT_SHARE_MODEL: hoist whatever depends only on chain-shared model parameters out of the chain loop
+    // auxssm_stats_attach: running moments folded in by the accept/select step of every Kalman sweep (layout of x); iter = sweeps folded so far
+    void* st_sq_jump = nullptr;
+    void* st_mean = nullptr;
+    void* st_sq_mean = nullptr;
+    long long st_iter = 0;
 };
 
 namespace ax {

@@ -131,7 +131,11 @@ class DeviceChains:
 
     def to_host(self):
         """trajectories as (C, T, dx)"""
-        a = self.x.to_host()
+        return self.stats_to_host(self.x)
+
+    def stats_to_host(self, a):
+        """any DeviceArray in the resident layout of x (e.g. the running moments of loop.loop) as (C, T, dx)"""
+        a = a.to_host()
         return np.ascontiguousarray(a.transpose(2, 0, 1)) if self.chain_minor else a
 
 
@@ -141,6 +145,8 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
     def sweep(handle, chains, delta, eps_aux, eps_samp, u_acc):
         """One auxssm_kalman_sweep on resident buffers (all DeviceArray). Asynchronous."""
         dl, ybuf, yarr = model.device(handle, chains.dtype)
+        if "lorenz_par" in dl.bufs and dl.bufs["lorenz_par"].shape[0] not in (1, chains.C):
+            raise ValueError(f"the model holds {dl.bufs['lorenz_par'].shape[0]} theta rows, the chains are {chains.C}")
         dims = _lib.Dims(chains.C, chains.T, 1, chains.dx, model.p_obs)
         _lib.check(handle.lib.auxssm_kalman_sweep(
             handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),

@@ -164,7 +164,10 @@ class LorenzModel:
         self.T, self.p_obs = self.yobs.shape
         self.dx = 3
         self.m0, self.P0 = np.asarray(m0, np.float64), np.asarray(P0, np.float64)
-        self.theta = np.asarray(theta, np.float64).reshape(3)
+        # theta (3,): one parameter vector for all chains; (C, 3): one per chain (the Gibbs sampler over (x, theta), loop.LorenzThetaStep).
+        # The NumPy methods below (host path / oracle) use chain 0's.
+        self.theta_rows = np.asarray(theta, np.float64).reshape(-1, 3)
+        self.theta = self.theta_rows[0].copy()
         self.sigma_x, self.dt = float(sigma_x), float(dt)
         self.Q = self.dt * self.sigma_x ** 2 * np.eye(3)
         self.Qs = np.broadcast_to(self.Q, (self.T - 1, 3, 3))
@@ -213,14 +216,27 @@ class LorenzModel:
         dev = self._dev.get(key)
         if dev is None:
             T, po = self.T, self.p_obs
-            par = np.concatenate([self.theta, [self.dt]])  # rides in the Fs slot of the C struct (include/auxssm.h, LORENZ63_EXT)
+            # rides in the Fs slot of the C struct (include/auxssm.h, LORENZ63_EXT): rows [theta1, theta2, theta3, dt]
+            par = np.concatenate([self.theta_rows, np.full((self.theta_rows.shape[0], 1), self.dt)], axis=1)
             n = T - 1
             lg = (self.m0, self.P0, np.broadcast_to(np.eye(3), (n, 3, 3)), self.Qs, np.broadcast_to(np.zeros(3), (n, 3)),
                   self.Hobs, self.Robs, self.cobs)
             dl = DeviceLGSSM(handle, lg, 1, T, 1, 3, po, False, dtype)
             pbuf = handle.to_device(par, dtype)
             dl.bufs["lorenz_par"] = pbuf
-            dl.c.Fs = pbuf.arr(0, 0, 0)
+            dl.c.Fs = pbuf.arr(4 if par.shape[0] > 1 else 0, 0, 0)
             ybuf, yarr = _upload_arr(handle, self.yobs, (po,), 1, T, 1, False, False, np.dtype(dtype), "ys")
             dev = self._dev[key] = (dl, ybuf, yarr)
         return dev
+
+    def par_device(self, handle, dtype, C):
+        """the device rows [theta, dt] the sweep reads, one per chain (C, 4): a single theta is replicated on first use, so that a theta
+        step can then write each chain's own"""
+        dl = self.device(handle, dtype)[0]
+        pbuf = dl.bufs["lorenz_par"]
+        if pbuf.shape[0] != C:
+            if pbuf.shape[0] != 1:
+                raise ValueError(f"the model holds {pbuf.shape[0]} theta rows, the chains are {C}")
+            pbuf = dl.bufs["lorenz_par"] = handle.to_device(np.repeat(pbuf.to_host(), C, axis=0), dtype)
+            dl.c.Fs = pbuf.arr(4 if C > 1 else 0, 0, 0)
+        return pbuf

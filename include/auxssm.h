@@ -165,7 +165,7 @@ typedef enum {
      * extended linearisation (linearisation.py:11-44, analytic Jacobian) of mean(x) = x + dt (phi_0(x) + theta * phi(x)) at every x_t,
      * rebuilt at both linearisation points each sweep; observations_factory concatenates the auxiliary and the real observations as
      * LG_CONCAT does; log_likelihood_fn(x) = log N(x_0; m0, P0) + sum log N(x_{t+1}; mean(x_t), Q) + nansum_t log N(y_t; H_t x_t + c_t, R_t).
-     * `model`: m0, P0, Qs as usual; Fs.ptr -> DEVICE array [theta1, theta2, theta3, dt] of `dtype` (bs unused); Hs, Rs, cs = the
+     * `model`: m0, P0, Qs as usual; Fs.ptr -> DEVICE array [theta1, theta2, theta3, dt] of `dtype`, chain stride Fs.sc (0: one theta for all chains; 4: one row per chain) (bs unused); Hs, Rs, cs = the
      * real observation model (rows of unobserved steps may be NaN); yobs (T, dy) with NaN = missing; dx = 3, dy <= 3; dense layout. */
     AUXSSM_KMODEL_LORENZ63_EXT = 4
 } auxssm_kalman_model;
@@ -244,6 +244,35 @@ int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* model, 
  * are written from `uniforms` (rows, N).  Same reduction orders and exp/log as the cSMC kernels (bit-exact vs oracle). */
 int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t N, const void* log_weights, const void* weights,
                               const void* uniforms, void* weights_out, int32_t* indices);
+
+/* ---- the MCMC loop around the sweeps: running statistics, step-size adaptation, Lorenz theta step --------------------
+ * == the body of `loop` in examples/stochastic_volatility/experiment.py:88-128 and examples/lorenz/experiment.py:120-169
+ * (stats_fn :81-83; moving averages :110-113; delta_adaptation aux_samplers/common.py:4-32), kept on the device so that a run of
+ * sweeps needs no host round trip.  `iter` is the reference's loop counter i (sweeps already folded in).
+ *
+ * auxssm_stats_attach: from now on the accept/select step of every auxssm_kalman_sweep on this handle also folds the sweep into the
+ *   running means  sq_jump <- (i sq_jump + (x' - x)^2) / (i + 1),  mean <- (i mean + x') / (i + 1),  sq_mean <- (i sq_mean + x'^2) / (i + 1)
+ *   (x the state before the sweep, x' after), arrays of x's shape, layout and dtype, and advances i by one; `iter` sets i for the next
+ *   sweep.  All three NULL detaches.  The fold costs no extra pass over x.
+ * auxssm_stats_update: the same fold as a standalone pass over n = C*T*dx elements (cSMC sweeps: keep a copy of x before the sweep).
+ * auxssm_accept_update: flags (C, m) int32, nonzero = updated (`accepted` of a Kalman sweep, m = 1; `ancestors` of a cSMC sweep,
+ *   m = T, csmc.py:59):  avg <- (i avg + f) / (i + 1),  window <- beta f + (1 - beta) window,  both (C, m) of `dtype`.
+ * auxssm_delta_adapt: delta_j <- clip(delta_j exp(rate (mean_c window[c, j] - target)), min_delta, max_delta), j < m: the reference's rule
+ *   on the chain-averaged windowed acceptance, because the chains of one sweep call share delta (C = 1: exactly the reference).  delta (m)
+ *   and, if non-NULL, sqrt_half_delta (m) = sqrt(delta / 2) (the cSMC sweep's input) are DEVICE arrays of `dtype`.
+ * auxssm_lorenz_theta_update: theta | x of the stochastic Lorenz-63 model (examples/lorenz/model.py:59-79: three independent conjugate
+ *   linear regressions of dx - dt phi_0(x) on dt phi(x), prior N(0, sigma_theta^2)), then theta = mean + chol * eps
+ *   (experiment.py:112-113).  x (C, T, 3) dense; eps (C, 3) ~ N(0, 1); par (C, 4) rows [theta1, theta2, theta3, dt]: dt is read, theta
+ *   overwritten -- the array model->Fs points at for AUXSSM_KMODEL_LORENZ63_EXT (chain stride 4).  mean_chol (C, 6) out, may be NULL. */
+int auxssm_stats_attach(auxssm_handle h, void* sq_jump, void* mean, void* sq_mean, int64_t iter);
+int auxssm_stats_update(auxssm_handle h, int dtype, int64_t n, int64_t iter, const void* x_prev, const void* x_next, void* sq_jump,
+                        void* mean, void* sq_mean);
+int auxssm_accept_update(auxssm_handle h, int dtype, int32_t C, int32_t m, int64_t iter, double beta, const int32_t* flags, void* avg,
+                         void* window);
+int auxssm_delta_adapt(auxssm_handle h, int dtype, int32_t C, int32_t m, const void* window, double target, double rate, double min_delta,
+                       double max_delta, void* delta, void* sqrt_half_delta);
+int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T, const void* x, double sigma_theta, double sigma_x,
+                               const void* eps, void* par, void* mean_chol);
 
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see

@@ -3,6 +3,7 @@
    C3k  stochastic volatility d=1 T=65536, auxiliary-Kalman sweep (first / second order), fp64
    C4   Lorenz-63 T=16384 dt=1.25e-4 obs every 80 steps, fp32: Kalman sweep (extended linearisation) + cSMC sweep N=512 (bootstrap, backward sampling)
    C5   dense d = p = 64 T=8192 fp32: filter + sampler + joint log-density of one chain (wide-state path)
+   loop the MCMC loop around the sweeps (aux_ssm_samplers_amd.loop: running moments, acceptance averages, adaptation, Lorenz theta step) on C2 / C3 / C4
 Prints one JSON line per measurement.  Inputs are resident in HBM (DeviceChains) where the API allows it; device Threefry noise."""
 import json
 import sys
@@ -102,8 +103,78 @@ def c5(T=8192):
             print(json.dumps(dict(config=f"C5 dense d=p=64 T={T} fp32, 1 chain, joint log-density kernel", ms=round(t, 2), lp=float(lp))))
 
 
+def timed_loop(label, kernel, state, delta, n_iter=40, **kw):
+    """loop() twice (first run warms code objects and the workspace); wall time of the second, host-synchronised at the end only"""
+    from aux_ssm_samplers_amd.loop import loop
+    chains = state.x
+    h = chains.handle
+    delta_fn = kw.pop("delta_fn", None)
+    for rep in range(2):
+        out = None  # frees the previous run's moment arrays outside the timed region
+        h.sync()
+        t0 = time.perf_counter()
+        out = loop(R.PRNGKey(5 + rep), delta, state, kernel, delta_fn, n_iter, **kw)
+        h.sync()
+        el = time.perf_counter() - t0
+    print(json.dumps(dict(config=label, chains=chains.C, sweeps_per_s=round(chains.C * n_iter / el, 1), ms_per_step=round(el / n_iter * 1e3, 3),
+                          avg_accept=round(float(out[5].to_host().mean()), 3))))
+    return out
+
+
+def loops():
+    sys.path.insert(0, "tests")
+    import bench
+    from aux_ssm_samplers_amd.common import delta_adaptation
+    from aux_ssm_samplers_amd.loop import LorenzThetaStep
+    h = _lib.default_handle()
+    # C2: 256 chains, chain-minor, chain-shared model
+    T, d, C = 65536, 4, 256
+    m, model = bench.build_model(T, d, np.float64)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    x0 = m["x_true"][None] + 0.3 * np.random.default_rng(0).standard_normal((C, T, d))
+    ch = DeviceChains(h, x0)
+    v, ms, acc = timed_sweeps(kernel, ch, 0.5, steps=20, warmup=3)
+    print(json.dumps(dict(config="C2 LG-SSM T=65536 d=4 fp64, bare sweeps (no statistics)", chains=C, sweeps_per_s=round(v, 1), ms_per_step=round(ms, 3))))
+    timed_loop("C2 LG-SSM T=65536 d=4 fp64, loop(): sweeps + running sq-jump/mean/sq-mean + acceptance averages, no host sync", kernel,
+               KalmanSampler(x=ch, updated=True), 0.5, beta=0.01)
+    timed_loop("C2 ..., loop() while adapting delta (one 2 KB read-back per sweep)", kernel, KalmanSampler(x=ch, updated=True), 0.5, beta=0.01,
+               delta_fn=delta_adaptation, target_alpha=0.5, lr=0.1)
+    del ch
+    # C4: the (x, theta) Gibbs sampler of the Lorenz example, 8 chains each with its own theta
+    from test_gpu_nonlinear_kalman import lorenz_kalman_setup
+    from test_gpu_csmc import lorenz_setup
+    T, C = 16384, 8
+    model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    ch = DeviceChains(h, np.repeat(xtrue[None], C, axis=0).astype(np.float32), chain_minor=False)
+    v, ms, acc = timed_sweeps(kernel, ch, 1e-4, steps=20, warmup=3)
+    print(json.dumps(dict(config="C4 Lorenz-63 T=16384 fp32, bare Kalman sweeps", chains=C, sweeps_per_s=round(v, 1), ms_per_step=round(ms, 3))))
+    step = LorenzThetaStep(model, 1e3 ** 0.5)  # sigma_theta of examples/lorenz/experiment.py:75
+    timed_loop("C4 Lorenz-63 T=16384 fp32, loop(): Kalman sweep + theta | x draw per chain + running statistics, no host sync", kernel,
+               KalmanSampler(x=ch, updated=True), 1e-4, beta=0.01, theta_step=step)
+    print(json.dumps(dict(theta_after=np.round(step.theta(ch), 3).tolist())))
+    # C3 / C4 cSMC on resident chains
+    from aux_ssm_samplers_amd.csmc import CsmcChains, CSMCState, get_independent_kernel, GaussianInit, LinearGaussianDynamics, SVPotential
+    from aux_ssm_samplers_amd._primitives.csmc import get_kernel as get_csmc_kernel
+    M0, Mt, G0, Gt, xt, y, sig_y = lorenz_setup(T, every=80, dt=1.25e-4)
+    init, ck = get_csmc_kernel(M0, G0, Mt, Gt, 512, backward=True, Pt=Mt)
+    cc = CsmcChains(h, np.repeat(xt[None], C, axis=0).astype(np.float32))
+    timed_loop("C4 Lorenz-63 T=16384 fp32, loop(): cSMC N=512 bootstrap + backward sampling + per-step statistics, resident chains", lambda k, s, dl: ck(k, s),
+               CSMCState(x=cc, updated=np.ones(T, bool)), None, n_iter=4, beta=0.01)
+    T3, C3 = 65536, 16
+    phi, q, xsv, ysv = bench.sv_data(T3, 0)
+    M0 = GaussianInit(m0=[0.0], P0=[[q]])
+    Mt = LinearGaussianDynamics(F=[[phi]], b=[0.0], Q=[[q]])
+    init, ik = get_independent_kernel(M0, SVPotential(y=ysv[0]), Mt, SVPotential(params=ysv[1:]), 1024, backward=True, Pt=Mt)
+    cc = CsmcChains(h, np.repeat(xsv.reshape(1, T3, 1), C3, axis=0).astype(np.float32))
+    timed_loop("C3 SV T=65536 fp32, loop(): aux-cSMC N=1024 backward sampling + per-step statistics + per-step delta adaptation on device", ik,
+               CSMCState(x=cc, updated=np.zeros(T3, bool)), 0.5, n_iter=4, beta=0.01, delta_fn=delta_adaptation, target_alpha=0.5, lr=0.1)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3k", "c4", "c5"]
+    if "loop" in which:
+        loops()
     if "c3k" in which:
         c3_kalman(1)
         c3_kalman(2)
