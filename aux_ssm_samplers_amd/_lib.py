@@ -18,7 +18,7 @@ KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND, KMODEL_LORENZ63_EXT = 1, 2,
 LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
 OPT_SHARE_MODEL = 1
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
- K_CSMC_BWD) = range(9)
+ K_CSMC_BWD, K_PIT_STITCH) = range(10)
 
 
 class AuxSSMError(RuntimeError):
@@ -91,6 +91,7 @@ def load():
         "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
+        "auxssm_csmc_pit_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_stats_attach": ([vp, vp, vp, vp, i64], C.c_int),
         "auxssm_stats_update": ([vp, i32, i64, i64, vp, vp, vp, vp, vp], C.c_int),

@@ -169,6 +169,65 @@ def sweep_resident(fk, chains, N, backward, key):
         chains.x.ptr, C.byref(nz), chains.ancestors.ptr, None, None, None))
 
 
+def _fk_struct(fk, handle, dtype, T):
+    m = _lib.FkModel(fk.proposal, fk.potential, fk.dx, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
+                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
+    yd = fk.ydev(handle, dtype)
+    if yd is not None:
+        if yd.shape[0] != T:
+            raise ValueError(f"observations have {yd.shape[0]} time steps, state has {T}")
+        m.y = yd.ptr.value
+    return m
+
+
+def pit_sweep_resident(fk, chains, N, key):
+    """One Threefry-keyed auxssm_csmc_pit_sweep (parallel-in-time cSMC) on resident chains.  Asynchronous."""
+    handle = chains.handle
+    if chains.dx != fk.dx:
+        raise ValueError(f"state dimension {chains.dx} != model dimension {fk.dx}")
+    if chains.sqrt_half_delta is None:
+        raise ValueError("delta is required")
+    m = _fk_struct(fk, handle, chains.dtype, chains.T)
+    k = _random.as_key(key)
+    nz = _lib.CsmcNoise()
+    nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(k[0]), int(k[1])
+    _lib.check(handle.lib.auxssm_csmc_pit_sweep(handle.h, _lib.dtype_code(chains.dtype), C.byref(m), chains.C, chains.T, N,
+                                                chains.sqrt_half_delta.ptr, chains.x.ptr, C.byref(nz), chains.ancestors.ptr))
+
+
+def pit_sweep(fk, x, N, *, key=None, noise=None, delta=None, handle=None):
+    """Parallel-in-time cSMC sweep.  x: (T, d) one chain or (C, T, d).  noise: dict(eps_aux (C,T,d), eps_prop (C,T,N,d), u_res (C,T,N)) of
+    explicit arrays or None -> Threefry(key).  Returns (x_new, ancestors)."""
+    handle = handle or _lib.default_handle()
+    x = np.asarray(x)
+    single = x.ndim == 2
+    xc = x[None] if single else x
+    Cn, T, d = xc.shape
+    if d != fk.dx:
+        raise ValueError(f"state dimension {d} != model dimension {fk.dx}")
+    if delta is None:
+        raise ValueError("delta is required")
+    dtype = np.dtype(np.float32) if xc.dtype == np.float32 else np.dtype(np.float64)
+    xd = handle.to_device(xc, dtype)
+    anc = handle.zeros((Cn, T), np.int32)
+    m = _fk_struct(fk, handle, dtype, T)
+    shd = handle.to_device(np.sqrt(0.5 * np.asarray(delta, np.float64)) * np.ones(T), dtype)
+    keep = []
+    nz = _lib.CsmcNoise()
+    if noise is None:
+        k = _random.as_key(key)
+        nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(k[0]), int(k[1])
+    else:
+        nz.mode = _lib.NOISE_EXPLICIT
+        for name, shp in dict(eps_prop=(Cn, T, N, d), u_res=(Cn, T, N), eps_aux=(Cn, T, d)).items():
+            buf = handle.to_device(np.asarray(noise[name], dtype).reshape(shp))
+            keep.append(buf)
+            setattr(nz, name, buf.ptr.value)
+    _lib.check(handle.lib.auxssm_csmc_pit_sweep(handle.h, _lib.dtype_code(dtype), C.byref(m), Cn, T, N, shd.ptr, xd.ptr, C.byref(nz), anc.ptr))
+    xo, ao = xd.to_host(), anc.to_host()
+    return (xo[0], ao[0]) if single else (xo, ao)
+
+
 def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, want_history=False):
     """x: (T, d) one chain or (C, T, d).  noise: dict of explicit arrays (eps_prop, u_res, u_bwd[, eps_aux]) or None -> Threefry(key).
     Returns (x_new, ancestors, history dict or None)."""

@@ -15,215 +15,9 @@
 //            added left to right; c_i = (t_0 + t_1 + ... + t_{g-1}) + local_i.
 //   sum    : balanced binary tree inside each group of 64 (== last element of that Kogge-Stone scan), then left to
 //            right over groups.   max : exact.
-#include "ctx.h"
-#include "det_math.h"
-#include "rng.h"
+#include "csmc_dev.h"
 
 namespace ax {
-
-constexpr int CS_MAXD = 4;
-
-template <typename R> struct FkDev {
-    int proposal, potential, D, transition;  // transition: 0 = linear-Gaussian (F, b); 1 = Lorenz-63 Euler-Maruyama (theta = F[0][0..2], dt = b[0])
-    R m0[CS_MAXD], LP0[CS_MAXD * CS_MAXD], F[CS_MAXD * CS_MAXD], b[CS_MAXD], LQ[CS_MAXD * CS_MAXD];
-    R c_init, c_trans, c_obs, inv_sig_y;  // additive constants: -sum log L_kk - D/2 log 2pi, etc.
-};
-
-struct CsmcArgs {
-    int C, T, N, backward;
-    const void* y;       // (T, D) shared by chains (may be null for the flat potential)
-    const void* shd;     // (T) sqrt(delta_t / 2), AUX proposal only
-    void* x;             // (C, T, D) reference trajectory in, new trajectory out
-    void* u;             // (C, T, D) auxiliary variables (workspace), AUX only
-    void* xs;            // (C, T, N, D)
-    void* lws;           // (C, T, N)
-    int32_t* As;         // (C, T-1, N) or null
-    void* wT;            // (C, N)
-    int32_t* anc;        // (C, T)
-    int noise_mode;      // 0 explicit arrays, 1 Threefry
-    uint32_t key0, key1;
-    const void* eps_aux;   // (C, T, D)
-    const void* eps_prop;  // (C, T, N, D)
-    const void* u_res;     // (C, T-1, N)
-    const void* u_bwd;     // (C, T)
-};
-
-enum { STREAM_EPS_AUX = 1, STREAM_EPS_PROP = 2, STREAM_U_RES = 3, STREAM_U_BWD = 4 };
-
-template <typename R> __device__ __forceinline__ R noise_normal(const CsmcArgs& a, const void* arr, uint32_t stream, long long idx) {
-    if (a.noise_mode == 0) return ((const R*)arr)[idx];
-    return stream_normal<R>(a.key0, a.key1, stream, (unsigned long long)idx);
-}
-template <typename R> __device__ __forceinline__ R noise_uniform(const CsmcArgs& a, const void* arr, uint32_t stream, long long idx) {
-    if (a.noise_mode == 0) return ((const R*)arr)[idx];
-    return stream_uniform<R>(a.key0, a.key1, stream, (unsigned long long)idx);
-}
-
-AXD_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }
-AXD_HD double fma_(double a, double b, double c) { return fma(a, b, c); }
-
-// log N(x; mean, L L^T) = cst - 0.5 |L^-1 (x - mean)|^2, forward substitution in a fixed order
-template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mean, const R* L, R cst) {
-    R z[D];
-    R q = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        R acc = x[k] - mean[k];
-#pragma unroll
-        for (int j = 0; j < k; ++j) acc = fma_(-L[k * CS_MAXD + j], z[j], acc);
-        z[k] = acc / L[k * CS_MAXD + k];
-        q = fma_(z[k], z[k], q);
-    }
-    return fma_((R)-0.5, q, cst);
-}
-template <typename R, int D> AXD_HD void trans_mean(const FkDev<R>& m, const R* xp, R* mu) {
-    if constexpr (D == 3) {
-        if (m.transition == 1) {  // x + dt (phi_0(x) + theta * phi(x)), examples/lorenz/model.py:10-25; fixed operation order
-            const R th1 = m.F[0], th2 = m.F[1], th3 = m.F[2], dt = m.b[0];
-            const R f1 = th1 * (xp[1] - xp[0]);
-            const R f2 = fma_(-xp[0], xp[2], fma_(th2, xp[0], -xp[1]));
-            const R f3 = fma_(xp[0], xp[1], -(th3 * xp[2]));
-            mu[0] = fma_(dt, f1, xp[0]);
-            mu[1] = fma_(dt, f2, xp[1]);
-            mu[2] = fma_(dt, f3, xp[2]);
-            return;
-        }
-    }
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        R acc = m.b[k];
-#pragma unroll
-        for (int j = 0; j < D; ++j) acc = fma_(m.F[k * CS_MAXD + j], xp[j], acc);
-        mu[k] = acc;
-    }
-}
-// potential g_t(x_t) (csmc test fixtures test_csmc/common.py:52-75; SV examples/stochastic_volatility/auxiliary_csmc.py:40-46)
-template <typename R, int D> AXD_HD R potential(const FkDev<R>& m, const R* x, const R* y) {
-    if (m.potential == 0) return (R)0;
-    if (m.potential == 1) {  // y ~ N(x, sig_y^2 I)
-        R q = 0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            const R z = (y[k] - x[k]) * m.inv_sig_y;
-            q = fma_(z, z, q);
-        }
-        return fma_((R)-0.5, q, m.c_obs);
-    }
-    if (m.potential == 3) {  // y_k ~ N(x_k, sig_y^2) for the finite y_k only (missing components / whole missing steps are skipped)
-        R q = 0;
-        int nobs = 0;
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            if (y[k] - y[k] == 0) {
-                const R z = (y[k] - x[k]) * m.inv_sig_y;
-                q = fma_(z, z, q);
-                ++nobs;
-            }
-        }
-        return fma_((R)-0.5, q, (R)nobs * m.c_obs);
-    }
-    // stochastic volatility: y_k ~ N(0, exp(x_k)):  -0.5 (y^2 e^{-x} + x) - 0.5 log 2pi, NaN terms -> 0
-    R acc = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const R e = det_exp(-x[k]);
-        const R s = fma_(y[k] * y[k], e, x[k]);
-        const R v = fma_((R)-0.5, s, m.c_obs);
-        acc += (v == v) ? v : (R)0;
-    }
-    return acc;
-}
-
-// ---- block primitives (TB threads = NW waves) ---------------------------------------------------------------------
-template <typename R> __device__ __forceinline__ R wave_max(R v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const R o = __shfl_xor(v, off, 64);
-        v = v > o ? v : o;  // NaN-agnostic: weights are never NaN for valid models
-    }
-    return v;
-}
-template <typename R> __device__ __forceinline__ R wave_sum_tree(R v) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
-    return v;
-}
-template <typename R> __device__ __forceinline__ R wave_scan_ks(R v, int lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const R o = __shfl_up(v, off, 64);
-        if (lane >= off) v += o;
-    }
-    return v;
-}
-
-// the up-to-16 per-wave partials of a block reduction, fetched with wide LDS reads into registers (same values, same
-// left-to-right combination order as a scalar loop over red[]; only the dependent LDS round trips disappear)
-template <typename R> __device__ __forceinline__ void load16(const R* red, R* t) {
-#pragma unroll
-    for (int k = 0; k < 16; ++k) t[k] = red[k];
-}
-
-// normalize (math/utils.py:23-39): w = exp(lw - logsumexp(lw)); logsumexp = log(sum(exp(lw - max))) + max
-// red: 48 slots (max in [0,16), sum in [16,32), scan totals in [32,48)); slots of unused waves are never read.
-template <typename R> __device__ __forceinline__ R block_normalize(R lw, R* red, int tid, int nw) {
-    const int lane = tid & 63, wv = tid >> 6;
-    R m = wave_max(lw);
-    if (lane == 0) red[wv] = m;
-    __syncthreads();
-    R t[16];
-    load16<R>(red, t);
-    m = t[0];
-    if (nw == 16) {  // full workgroup: no per-slot masks
-#pragma unroll
-        for (int k = 1; k < 16; ++k) m = t[k] > m ? t[k] : m;
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) m = (k < nw && t[k] > m) ? t[k] : m;
-    }
-    if (!(m - m == 0)) m = 0;  // non-finite max -> 0 (jax logsumexp)
-    const R e = det_exp(lw - m);
-    R s = wave_sum_tree(e);
-    if (lane == 0) red[16 + wv] = s;
-    __syncthreads();
-    load16<R>(red + 16, t);
-    s = t[0];
-    if (nw == 16) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) s = s + t[k];
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) s = k < nw ? s + t[k] : s;
-    }
-    const R lse = det_log(s) + m;
-    return det_exp(lw - lse);
-}
-
-// inclusive cumsum of w into c[] (slots [32,48) of red hold the wave totals); c[] valid after the trailing barrier
-template <typename R> __device__ __forceinline__ void block_cumsum(R w, R* c, R* red, int tid, int nw) {
-    const int lane = tid & 63, wv = tid >> 6;
-    const R v = wave_scan_ks(w, lane);
-    if (lane == 63) red[32 + wv] = v;
-    __syncthreads();
-    R t[16];
-    load16<R>(red + 32, t);
-    R pre = t[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) pre = k < wv ? pre + t[k] : pre;
-    c[tid] = wv > 0 ? pre + v : v;
-    __syncthreads();
-}
-
-// first index j in [0, n) with c[j] >= r  (jnp.searchsorted side='left'); n if none
-template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int n, R r) {
-    int lo = 0, hi = n;
-    while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (c[mid] < r) lo = mid + 1;
-        else hi = mid;
-    }
-    return lo;
-}
 
 // ---- prologue: u = x + sqrt(delta_t/2) eps   (csmc/generic.py:67) ------------------------------------------------------
 template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
@@ -494,48 +288,6 @@ template <typename R> __global__ void __launch_bounds__(1024) k_normalize_resamp
             i = i < N - 1 ? i : N - 1;
         }
         idx[row + tid] = i;
-    }
-}
-
-template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model* fk, const double* host) {
-    // host = [m0 (D) | chol_P0 (D*D) | F (D*D) | b (D) | chol_Q (D*D)] as doubles
-    const int D = fk->dx;
-    memset(&m, 0, sizeof(m));
-    m.proposal = fk->proposal;
-    m.potential = fk->potential;
-    m.D = D;
-    m.transition = fk->transition;
-    const double* p = host;
-    for (int k = 0; k < D; ++k) m.m0[k] = (R)p[k];
-    p += D;
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) m.LP0[i * CS_MAXD + j] = (R)p[i * D + j];
-    p += D * D;
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) m.F[i * CS_MAXD + j] = (R)p[i * D + j];
-    p += D * D;
-    for (int k = 0; k < D; ++k) m.b[k] = (R)p[k];
-    p += D;
-    for (int i = 0; i < D; ++i)
-        for (int j = 0; j < D; ++j) m.LQ[i * CS_MAXD + j] = (R)p[i * D + j];
-    // additive constants, computed once on the host in precision R (they enter both the GPU and the oracle as data)
-    R ci = 0, ct = 0;
-    for (int k = 0; k < D; ++k) {
-        ci -= det_log(m.LP0[k * CS_MAXD + k]);
-        ct -= det_log(m.LQ[k * CS_MAXD + k]);
-    }
-    const R half_log_2pi = (R)0.91893853320467274178;
-    m.c_init = ci - (R)D * half_log_2pi;
-    m.c_trans = ct - (R)D * half_log_2pi;
-    if (fk->potential == 1) {
-        m.inv_sig_y = (R)1 / (R)fk->sig_y;
-        m.c_obs = -(R)D * det_log((R)fk->sig_y) - (R)D * half_log_2pi;
-    } else if (fk->potential == 3) {  // per observed component
-        m.inv_sig_y = (R)1 / (R)fk->sig_y;
-        m.c_obs = -det_log((R)fk->sig_y) - half_log_2pi;
-    } else {
-        m.inv_sig_y = 0;
-        m.c_obs = -half_log_2pi;
     }
 }
 

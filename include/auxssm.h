@@ -104,7 +104,8 @@ typedef enum {
     AUXSSM_K_SAMPLE_SCAN = 5,
     AUXSSM_K_LOGPDF = 6,
     AUXSSM_K_CSMC_FWD = 7,
-    AUXSSM_K_CSMC_BWD = 8
+    AUXSSM_K_CSMC_BWD = 8,
+    AUXSSM_K_PIT_STITCH = 9 /* the log2(T) stitching launches of the parallel-in-time cSMC sweep, timed as one unit */
 } auxssm_kernel_id;
 int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches);
 int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms);
@@ -236,6 +237,21 @@ typedef struct {
 int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* model, int32_t C, int32_t T, int32_t N,
                       int32_t backward, const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise,
                       int32_t* ancestors, void* xs_out, void* log_ws_out, int32_t* As_out);
+
+/* ---- parallel-in-time conditional SMC (conditional dSMC) ------------------------------------------------------------
+ * == kernel(key, state, delta) of aux_samplers.csmc.get_independent_kernel(..., parallel=True), classical branch
+ * (csmc/independent.py:78-118 on _primitives/csmc/pit/csmc.py:69-114, operator.py, dc_map.py), for C chains at once: all T x N
+ * proposals x_t^n ~ N(u_t, delta_t/2 I) are drawn at once (slot 0 = the reference trajectory), then a binary tree over time stitches
+ * neighbouring blocks: N x N weights G_t(x_t^j, x_{t-1}^i) w_{t-1}^i w_t^j between the left block's last and the right block's first step,
+ * N conditional multinomial draws of (i, j) pairs (pair 0 pinned to (0, 0)); the root draws ONE pair and the selected trajectory is
+ * read off the tree.  log2(T) launches instead of T sequential steps; work (T - 1) N^2.
+ * model: proposal must be AUXSSM_PROP_AUX_INDEPENDENT (the tree needs proposals that are independent across time); any transition /
+ * potential of the family.  sqrt_half_delta (T) device.  Noise: EXPLICIT eps_aux (C,T,dx), eps_prop (C,T,N,dx), u_res (C,T,N) [row t
+ * feeds the stitch at the boundary (t-1 | t); entry (t, 0) is used by the root only; row 0 never] or THREEFRY (streams 1, 2, 3 at the
+ * same flat indices).  x (C,T,dx) in/out; ancestors (C,T) int32 = the leaf particle index selected at each step (updated =
+ * ancestors != 0).  T >= 2, 2 <= N <= 1024.  Reduction orders and exp/log are fixed (csrc/pit.hip): bit-exact vs oracle/csmc_ref.c. */
+int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* model, int32_t C, int32_t T, int32_t N,
+                          const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise, int32_t* ancestors);
 
 /* auxssm_normalize_resample == normalize(log_weights) (_primitives/math/utils.py:23-39) and/or
  * multinomial(key, weights) (_primitives/csmc/resamplings.py:14-37) with the U[0,1) draws given explicitly, for `rows`

@@ -68,6 +68,27 @@ def sweep(model, x, N, backward, *, y=None, sqrt_half_delta=None, eps_aux=None, 
     return dict(x=x, ancestors=anc, xs=xs, log_ws=lws, As=As[:T - 1])
 
 
+def pit_sweep(model, x, N, *, y=None, sqrt_half_delta, eps_aux, eps_prop, u_res, dtype=np.float32):
+    """One parallel-in-time cSMC sweep (conditional dSMC) of one chain, evaluated with full block gathers as the reference's operator
+    does (csmc_ref.c::csmc_ref_pit_sweep).  u_res (T, N): row t feeds the stitch at the boundary (t-1 | t).
+    Returns dict(x, ancestors, xs)."""
+    dtype = np.dtype(dtype)
+    x = np.array(x, dtype, order="C")
+    T, D = x.shape
+    keep = [np.ascontiguousarray(np.asarray(model[k], np.float64)) for k in ("m0", "chol_P0", "F", "b", "chol_Q")]
+    m = _Model(int(model["proposal"]), int(model["potential"]), D, 0, _p(keep[0]), _p(keep[1]), _p(keep[2]),
+               _p(keep[3]), _p(keep[4]), float(model.get("sig_y", 1.0)), int(model.get("transition", 0)))
+    cv = lambda a: None if a is None else np.ascontiguousarray(a, dtype)
+    y, shd, eps_aux, eps_prop, u_res = map(cv, (y, sqrt_half_delta, eps_aux, eps_prop, u_res))
+    assert T >= 2 and eps_prop.shape == (T, N, D) and u_res.shape == (T, N) and eps_aux.shape == (T, D) and shd.shape == (T,)
+    anc = np.zeros(T, np.int32)
+    xs = np.zeros((T, N, D), dtype)
+    fn = lib().csmc_ref_pit_sweep_f32 if dtype == np.float32 else lib().csmc_ref_pit_sweep_f64
+    rc = fn(C.byref(m), T, N, _p(x), _p(y), _p(shd), _p(eps_aux), _p(eps_prop), _p(u_res), _p(anc), _p(xs))
+    assert rc == 0
+    return dict(x=x, ancestors=anc, xs=xs)
+
+
 def multinomial(w, un, dtype=np.float32):
     w = np.ascontiguousarray(w, dtype)
     un = np.ascontiguousarray(un, dtype)

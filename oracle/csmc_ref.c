@@ -401,6 +401,149 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
     return 0;
 }
 
+/* ---- parallel-in-time conditional SMC (conditional dSMC): aux_samplers/_primitives/csmc/pit/csmc.py:69-114, operator.py:74-149,
+ * dc_map.py:70-121, driven as csmc/independent.py:78-118 does (classical branch: proposals N(u_t, delta_t/2 I)).  The tree is
+ * evaluated node by node with FULL block gathers, exactly as the reference's operator does (trajectories, origins and weights of a
+ * whole block are re-indexed at every stitch); the HIP kernels (csrc/pit.hip) keep only boundary indices and must give the same
+ * trajectory and origins.  Arithmetic contract: see the header of csrc/pit.hip. */
+static REAL SUF(gauss_r)(int D, const REAL* x, const REAL* mean, const REAL* L, const REAL* iL, REAL cst) {
+    REAL z[MAXD], q = 0;
+    for (int k = 0; k < D; ++k) {
+        REAL acc = x[k] - mean[k];
+        for (int j = 0; j < k; ++j) acc = FMA(-L[k * MAXD + j], z[j], acc);
+        z[k] = acc * iL[k];
+        q = FMA(z[k], z[k], q);
+    }
+    return FMA((REAL)-0.5, q, cst);
+}
+/* x (T,D) in/out; y (T,D) or NULL; shd (T); eps_aux (T,D); eps_prop (T,N,D); u_res (T,N); outputs anc (T) and, if non-NULL,
+ * xs (T,N,D) the leaf particles.  T >= 2. */
+int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y, const REAL* shd, const REAL* eps_aux,
+                            const REAL* eps_prop, const REAL* u_res, int32_t* anc, REAL* xs_out) {
+    SUF(fk) m;
+    SUF(fk_fill)(&m, g);
+    const int D = m.D;
+    const size_t TN = (size_t)T * N;
+    REAL* xs = (REAL*)malloc(sizeof(REAL) * TN * D);   /* current block trajectories, (T, N, D) */
+    REAL* xt = (REAL*)malloc(sizeof(REAL) * TN * D);
+    REAL* lw = (REAL*)malloc(sizeof(REAL) * TN);       /* per (t, slot) log-weights */
+    int32_t* org = (int32_t*)malloc(sizeof(int32_t) * TN);
+    int32_t* ot = (int32_t*)malloc(sizeof(int32_t) * TN);
+    REAL zero[MAXD] = {0, 0, 0, 0};
+    const REAL nln = -LOG((REAL)N);
+    REAL iL[MAXD];
+    for (int q = 0; q < D; ++q) iL[q] = (REAL)1 / m.LQ[q * MAXD + q];
+    /* leaves (pit/csmc.py:77-96) */
+    for (int t = 0; t < T; ++t)
+        for (int n = 0; n < N; ++n) {
+            for (int k = 0; k < D; ++k) {
+                const REAL uu = FMA(shd[t], eps_aux[t * D + k], x[t * D + k]);
+                xs[((size_t)t * N + n) * D + k] = n == 0 ? x[t * D + k] : FMA(shd[t], eps_prop[((size_t)t * N + n) * D + k], uu);
+            }
+            org[(size_t)t * N + n] = n;
+            lw[(size_t)t * N + n] = nln;
+        }
+    if (xs_out) memcpy(xs_out, xs, sizeof(REAL) * TN * D);
+    {
+        REAL* g0 = (REAL*)malloc(sizeof(REAL) * N);
+        REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
+        REAL mx;
+        for (int n = 0; n < N; ++n) {
+            REAL gq = SUF(pot)(&m, xs + (size_t)n * D, y ? y : zero);
+            g0[n] = gq + SUF(gauss)(D, xs + (size_t)n * D, m.m0, m.LP0, m.c_init);
+        }
+        mx = g0[0];
+        for (int n = 1; n < N; ++n) mx = mx > g0[n] ? mx : g0[n];
+        if (!(mx - mx == 0)) mx = 0;
+        for (int n = 0; n < N; ++n) tmp[n] = EXP(g0[n] - mx);
+        const REAL lse = LOG(SUF(sum)(tmp, N)) + mx;
+        for (int n = 0; n < N; ++n) lw[n] = g0[n] - lse;
+        free(g0); free(tmp);
+    }
+    int K = 0;
+    while ((1 << K) < T) ++K;
+    const long long NN = (long long)N * N;
+    const int NCH = N <= 32 ? 64 : (N <= 128 ? 256 : 1024);
+    const int Lc = (int)((NN + NCH - 1) / NCH);
+    REAL* mu = (REAL*)malloc(sizeof(REAL) * N * D);
+    REAL* pg = (REAL*)malloc(sizeof(REAL) * N);
+    REAL* cs = (REAL*)malloc(sizeof(REAL) * 1024);
+    REAL* ss = (REAL*)malloc(sizeof(REAL) * 1024);
+    int* li = (int*)malloc(sizeof(int) * N);
+    int* ri = (int*)malloc(sizeof(int) * N);
+    for (int k = 0; k < K; ++k) {
+        const long long bs = 1ll << k;
+        for (long long s0 = 0; s0 < T; s0 += 2 * bs) {
+            const long long mid = s0 + bs;
+            if (mid >= T) continue; /* passthrough (dc_map.py:93-105) */
+            const long long e1 = s0 + 2 * bs < T ? s0 + 2 * bs : T;
+            const int root = k == K - 1;
+            const REAL* xa = xs + (size_t)(mid - 1) * N * D;
+            const REAL* xb = xs + (size_t)mid * N * D;
+            const REAL* yv = y ? y + (size_t)mid * D : zero;
+            for (int n = 0; n < N; ++n) {
+                SUF(tmean)(&m, xa + (size_t)n * D, mu + (size_t)n * D);
+                pg[n] = SUF(pot)(&m, xb + (size_t)n * D, yv) + lw[(size_t)mid * N + n];
+            }
+            const REAL* ha = lw + (size_t)(mid - 1) * N;
+#define PIT_V(i, j) ((SUF(gauss_r)(D, xb + (size_t)(j) * D, mu + (size_t)(i) * D, m.LQ, iL, m.c_trans) + pg[j]) + ha[i])
+            REAL vmax = -INFINITY;
+            for (long long p = 0; p < NN; ++p) { const REAL v = PIT_V(p / N, p % N); vmax = v > vmax ? v : vmax; }
+            if (!(vmax - vmax == 0)) vmax = 0;
+            for (int c = 0; c < NCH; ++c) {
+                const long long p0 = (long long)c * Lc, p1 = p0 + Lc < NN ? p0 + Lc : NN;
+                REAL s = 0;
+                for (long long p = p0; p < p1; ++p) s = s + EXP(PIT_V(p / N, p % N) - vmax);
+                ss[c] = s;
+            }
+            SUF(cumsum)(ss, NCH, cs);
+            const int last_chunk = (int)((NN - 1) / Lc);
+            const int ndraw = root ? 1 : N;
+            for (int n = 0; n < ndraw; ++n) {
+                int il = 0, jr = 0;
+                if (root || n > 0) {
+                    const REAL r = cs[NCH - 1] * ((REAL)1 - u_res[(size_t)mid * N + n]);
+                    int ts = SUF(lower_bound)(cs, NCH, r);
+                    ts = ts < last_chunk ? ts : last_chunk;
+                    const REAL pre = ts > 0 ? cs[ts - 1] : (REAL)0;
+                    const long long q0 = (long long)ts * Lc, q1 = q0 + Lc < NN ? q0 + Lc : NN;
+                    long long psel = q1 - 1;
+                    REAL acc = 0;
+                    for (long long p = q0; p < q1; ++p) {
+                        acc = acc + EXP(PIT_V(p / N, p % N) - vmax);
+                        const REAL cv = ts > 0 ? pre + acc : acc;
+                        if (cv >= r) { psel = p; break; }
+                    }
+                    il = (int)(psel / N);
+                    jr = (int)(psel % N);
+                }
+                li[n] = il; ri[n] = jr;
+            }
+#undef PIT_V
+            /* _gather_results (operator.py:87-110): re-index both blocks, reset their weights to -log N; the root keeps ONE trajectory,
+             * stored in slot 0 */
+            for (long long t = s0; t < e1; ++t)
+                for (int n = 0; n < ndraw; ++n) {
+                    const int src = t < mid ? li[n] : ri[n];
+                    for (int q = 0; q < D; ++q) xt[((size_t)t * N + n) * D + q] = xs[((size_t)t * N + src) * D + q];
+                    ot[(size_t)t * N + n] = org[(size_t)t * N + src];
+                }
+            for (long long t = s0; t < e1; ++t)
+                for (int n = 0; n < ndraw; ++n) {
+                    for (int q = 0; q < D; ++q) xs[((size_t)t * N + n) * D + q] = xt[((size_t)t * N + n) * D + q];
+                    org[(size_t)t * N + n] = ot[(size_t)t * N + n];
+                    lw[(size_t)t * N + n] = nln;
+                }
+        }
+    }
+    for (int t = 0; t < T; ++t) {
+        anc[t] = org[(size_t)t * N];
+        for (int q = 0; q < D; ++q) x[t * D + q] = xs[((size_t)t * N) * D + q];
+    }
+    free(xs); free(xt); free(lw); free(org); free(ot); free(mu); free(pg); free(cs); free(ss); free(li); free(ri);
+    return 0;
+}
+
 /* conditional multinomial resampling alone (resamplings.py:14-37), for the reference's statistical test */
 void SUF(csmc_ref_multinomial)(const REAL* w, int N, const REAL* un, int32_t* idx) {
     REAL* c = (REAL*)malloc(sizeof(REAL) * N);

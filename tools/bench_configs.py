@@ -171,8 +171,41 @@ def loops():
                CSMCState(x=cc, updated=np.zeros(T3, bool)), 0.5, n_iter=4, beta=0.01, delta_fn=delta_adaptation, target_alpha=0.5, lr=0.1)
 
 
+def pit(T=65536):
+    """C3's model (SV, d = 1, T = 65536, fp32): parallel-in-time cSMC (auxssm_csmc_pit_sweep) vs the sequential sweep at the same N,
+    few chains (where the sequential sweep is latency-bound: T dependent steps)"""
+    import bench
+    from aux_ssm_samplers_amd.csmc import CsmcChains, CSMCState, get_independent_kernel, GaussianInit, LinearGaussianDynamics, SVPotential
+    h = _lib.default_handle()
+    phi, q, xsv, ysv = bench.sv_data(T, 0)
+    M0 = GaussianInit(m0=[0.0], P0=[[q]])
+    Mt = LinearGaussianDynamics(F=[[phi]], b=[0.0], Q=[[q]])
+    for N, chains in ((32, 1), (32, 16), (64, 1), (64, 16), (256, 1), (256, 8), (1024, 1), (1024, 4)):
+        row = dict(config=f"C3 SV T={T} fp32, N={N}", chains=chains)
+        for par in (True, False):
+            init, k = get_independent_kernel(M0, SVPotential(y=ysv[0]), Mt, SVPotential(params=ysv[1:]), N, backward=not par, Pt=Mt, parallel=par)
+            cc = CsmcChains(h, np.repeat(xsv.reshape(1, T, 1), chains, axis=0).astype(np.float32), delta=0.5)
+            st = CSMCState(x=cc, updated=None)
+            keys = R.split(R.PRNGKey(3), 8)
+            k(keys[0], st, None)
+            h.sync()
+            reps = 5 if par else 2
+            t0 = time.perf_counter()
+            for i in range(reps):
+                k(keys[1 + i], st, None)
+            h.sync()
+            el = (time.perf_counter() - t0) / reps
+            name = "pit" if par else "sequential_backward_sampling"
+            row[name + "_ms_per_sweep"] = round(el * 1e3, 2)
+            row[name + "_updated"] = round(float((cc.ancestors.to_host() != 0).mean()), 3)
+        row["speedup"] = round(row["sequential_backward_sampling_ms_per_sweep"] / row["pit_ms_per_sweep"], 1)
+        print(json.dumps(row), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3k", "c4", "c5"]
+    if "pit" in which:
+        pit()
     if "loop" in which:
         loops()
     if "c3k" in which:
