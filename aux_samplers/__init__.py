@@ -6,9 +6,9 @@ import sys
 
 import aux_ssm_samplers_amd as _impl
 
-_ALIASES = ["kalman", "csmc", "common", "random", "parallel", "_primitives", "_primitives.base", "_primitives.kalman",
+_ALIASES = ["kalman", "csmc", "common", "loop", "random", "parallel", "_primitives", "_primitives.base", "_primitives.kalman",
             "_primitives.kalman.base", "_primitives.kalman.filtering", "_primitives.kalman.sampling", "_primitives.csmc",
-            "_primitives.csmc.base", "_primitives.csmc.csmc", "_primitives.csmc.resamplings", "_primitives.math",
+            "_primitives.csmc.base", "_primitives.csmc.csmc", "_primitives.csmc.pit", "_primitives.csmc.resamplings", "_primitives.math",
             "_primitives.math.utils", "csmc.generic", "csmc.independent", "kalman.generic"]
 for _name in _ALIASES:
     sys.modules[f"{__name__}.{_name}"] = importlib.import_module(f"aux_ssm_samplers_amd.{_name}")
