@@ -8,6 +8,8 @@ import pytest
 
 from oracle import csmc as O
 
+from tests.helpers import lorenz_setup  # noqa: E402,F401
+
 pytestmark = pytest.mark.gpu
 
 
@@ -202,24 +204,6 @@ def test_multinomial_resampling_reference_statistical_test():
     assert np.all(idx[:, 0] == 0)
     cnt = np.bincount(idx[:, 1:].ravel(), minlength=10)
     npt.assert_allclose(cnt / cnt.sum(), w, atol=2e-3)
-
-
-def lorenz_setup(T, seed=0, every=8, dt=0.01, sig_y=np.sqrt(5.0)):
-    """examples/lorenz (experiment.py:75-83, model.py:10-56) on a short horizon: theta = (10, 28, 8/3), sigma_x = 3,
-    m0 = (1.5, -1.5, 25), P0 = diag(400, 20, 20), x2 and x3 observed every `every`-th step with sd sig_y, NaN elsewhere."""
-    from aux_ssm_samplers_amd.csmc import GaussianInit, Lorenz63Dynamics, MaskedGaussianObsPotential
-    rng = np.random.default_rng(seed)
-    Mt = Lorenz63Dynamics(theta=(10.0, 28.0, 8.0 / 3.0), sigma_x=3.0, dt=dt)
-    M0 = GaussianInit(m0=np.array([1.5, -1.5, 25.0]), P0=np.diag([400.0, 20.0, 20.0]))
-    x = np.zeros((T, 3))
-    x[0] = [1.5, -1.5, 25.0]
-    for t in range(1, T):
-        x[t] = Mt.mean(x[t - 1]) + 3.0 * np.sqrt(dt) * rng.standard_normal(3)
-    y = np.full((T, 3), np.nan)
-    y[::every, 1:] = x[::every, 1:] + sig_y * rng.standard_normal((len(x[::every]), 2))
-    G0 = MaskedGaussianObsPotential(sig=sig_y, y=y[0])
-    Gt = MaskedGaussianObsPotential(sig=sig_y, params=y[1:])
-    return M0, Mt, G0, Gt, x, y, sig_y
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])

@@ -256,3 +256,28 @@ def test_csmc_loop_statistics_and_per_step_adaptation(handle, backward):
     npt.assert_array_equal(window.to_host(), win_h)
     npt.assert_allclose(chains.sqrt_half_delta.to_host(), np.sqrt(0.5 * dl), rtol=1e-6)
     assert np.any(np.abs(snaps[-1] - snaps[0]) > 0) and np.ptp(dl) > 0
+
+
+def test_full_size_running_moments_T65536(handle):
+    """BASELINE config C2's horizon (T = 65536, d = 4, fp64), 8 chains: the moments the sweeps fold in equal the plain means of the
+    states the sweeps leave (the linear-Gaussian sweep always accepts: log alpha = 0), and the acceptance averages are 1."""
+    import bench
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    from aux_ssm_samplers_amd.loop import loop
+    T, d, C, n_iter = 65536, 4, 8, 4
+    m, model = bench.build_model(T, d, np.float64)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    x0 = m["x_true"][None] + 0.3 * np.random.default_rng(0).standard_normal((C, T, d))
+    chains = DeviceChains(handle, x0, chain_minor=True)
+    snaps = [x0]
+    n, stats, state, delta, window, avg = loop(R.PRNGKey(4), 0.5, KalmanSampler(x=chains, updated=True), kernel, None, n_iter,
+                                               callback=lambda i, s: snaps.append(chains.to_host()))
+    snaps = np.stack(snaps)
+    npt.assert_allclose(chains.stats_to_host(stats[1]), snaps[1:].mean(0), rtol=1e-12, atol=1e-12)
+    npt.assert_allclose(chains.stats_to_host(stats[2]), (snaps[1:] ** 2).mean(0), rtol=1e-12, atol=1e-12)
+    npt.assert_allclose(chains.stats_to_host(stats[0]), ((snaps[1:] - snaps[:-1]) ** 2).mean(0), rtol=1e-12, atol=1e-12)
+    npt.assert_array_equal(avg.to_host(), 1.0)
+    npt.assert_array_equal(window.to_host(), 1.0)
+    assert np.abs(snaps[-1] - snaps[0]).max() > 0.1

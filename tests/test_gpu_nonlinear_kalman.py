@@ -8,23 +8,9 @@ import pytest
 
 from oracle import kalman_np as K
 
+from tests.helpers import sv_setup, lorenz_kalman_setup  # noqa: E402,F401
+
 pytestmark = pytest.mark.gpu
-
-
-def sv_setup(T, d, seed=0, phi=0.9, tau=2.0, rho=0.25):
-    """model.py:34-53 (nu = 0): F = phi I, Q = P0 = U / (1 - phi^2), U = tau (rho + (1 - rho) I); data as model.py:11-31."""
-    rng = np.random.Generator(np.random.PCG64(seed))
-    U = tau * rho * np.ones((d, d))
-    U[np.diag_indices(d)] = tau
-    Q = U / (1 - phi ** 2)
-    F, b, m0 = phi * np.eye(d), np.zeros(d), np.zeros(d)
-    L = np.linalg.cholesky(Q)
-    x = np.zeros((T, d))
-    x[0] = L @ rng.standard_normal(d)
-    for t in range(1, T):
-        x[t] = F @ x[t - 1] + L @ rng.standard_normal(d)
-    y = np.exp(0.5 * x) * rng.standard_normal((T, d))
-    return y, x, (m0, Q, F, Q, b)
 
 
 def oracle_target(model):
@@ -99,29 +85,6 @@ def test_sv_chain_moves_and_targets_posterior():
     lp = np.array([model.log_likelihood_fn(xs[c]) for c in range(C)])
     assert np.all(np.isfinite(lp)) and np.all(lp > model.log_likelihood_fn(xtrue) - 4 * T)
     assert np.abs(xs - xtrue[None]).max() > 1e-3
-
-
-def lorenz_kalman_setup(T, every=8, dt=0.01, seed=0):
-    """examples/lorenz: theta = (10, 28, 8/3), sigma_x = 3, m0 = (1.5, -1.5, 25), P0 = diag(400, 20, 20), (x2, x3) observed every `every`-th
-    step with variance 5, NaN rows (ys AND Hs, as model.py:43-56) elsewhere."""
-    from aux_ssm_samplers_amd.kalman import LorenzModel
-    rng = np.random.default_rng(seed)
-    theta, sx = np.array([10.0, 28.0, 8.0 / 3.0]), 3.0
-    m0, P0 = np.array([1.5, -1.5, 25.0]), np.diag([400.0, 20.0, 20.0])
-    H = np.array([[0, 1.0, 0], [0, 0, 1.0]])
-    ys = np.full((T, 2), np.nan)
-    Hs = np.full((T, 2, 3), np.nan)
-    Hs[::every] = H
-    Rs = np.broadcast_to(5.0 * np.eye(2), (T, 2, 2))
-    cs = np.zeros((T, 2))
-    model = LorenzModel(ys, Hs, Rs, cs, m0, P0, theta, sx, dt)
-    x = np.zeros((T, 3))
-    x[0] = m0
-    for t in range(1, T):
-        x[t] = model.mean(x[t - 1]) + sx * np.sqrt(dt) * rng.standard_normal(3)
-    ys[::every] = x[::every] @ H.T + np.sqrt(5.0) * rng.standard_normal((len(x[::every]), 2))
-    model.yobs = ys
-    return model, x
 
 
 @pytest.mark.parametrize("T", [120, 257])

@@ -127,3 +127,35 @@ def test_argument_errors():
         _device.pit_sweep(fk, np.zeros((1, 1)), 8, key=0, delta=0.5)   # T >= 2
     with pytest.raises(ValueError):
         _device.pit_sweep(fk, np.zeros((4, 1)), 2048, key=0, delta=0.5)
+
+
+def test_full_size_properties_T65536():
+    """BASELINE config C3's horizon (T = 65536, SV model, fp32), N = 64: size-independent properties of the tree -- draws forced onto the
+    first pair return the reference trajectory untouched; a keyed sweep is deterministic, its ancestors are valid leaf indices, every
+    output value is one of that step's proposals around u_t, and a fresh key moves most of the trajectory."""
+    import bench
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics, SVPotential
+    T, N = 65536, 64
+    phi, q, xsv, ysv = bench.sv_data(T, 0)
+    M0 = GaussianInit(m0=[0.0], P0=[[q]])
+    Mt = LinearGaussianDynamics(F=[[phi]], b=[0.0], Q=[[q]])
+    fk = _device.describe_independent(M0, SVPotential(y=ysv[0]), Mt, SVPotential(params=ysv[1:]), Mt)
+    x0 = xsv.astype(np.float32)
+    h = _lib.default_handle()
+    key = R.PRNGKey(123)
+    noise = dict(eps_aux=h.rng_normal(key, 1, (1, T, 1), np.float32).to_host(), eps_prop=h.rng_normal(key, 2, (1, T, N, 1), np.float32).to_host(),
+                 u_res=np.full((1, T, N), np.float32(1.0) - np.float32(2.0 ** -24)))
+    x, anc = _device.pit_sweep(fk, x0, N, noise=noise, delta=0.5)
+    npt.assert_array_equal(anc, 0)
+    npt.assert_array_equal(x, x0)
+    xa, anca = _device.pit_sweep(fk, x0, N, key=key, delta=0.5)
+    xb, ancb = _device.pit_sweep(fk, x0, N, key=key, delta=0.5)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    assert anca.min() >= 0 and anca.max() < N and np.isfinite(xa).all()
+    shd = np.float32(np.sqrt(0.25))
+    leaves = np.float32(x0 + shd * noise["eps_aux"][0])[:, None, :] + shd * noise["eps_prop"][0]
+    leaves[:, 0] = x0
+    npt.assert_allclose(xa, leaves[np.arange(T), anca], rtol=1e-6, atol=1e-6)
+    assert (anca != 0).mean() > 0.5

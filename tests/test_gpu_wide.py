@@ -11,6 +11,8 @@ import pytest
 from oracle import kalman_np as K
 from tests.helpers import ref_lgssm_inputs, ref_batched_inputs
 
+from tests.helpers import c5_model  # noqa: E402,F401
+
 pytestmark = pytest.mark.gpu
 
 
@@ -102,22 +104,6 @@ def test_batched_model(P, seed, parallel):
     bx = P.sampling(None, oms, oPs, P.LGSSM(*blg), parallel, eps=eps)
     dms, dPs, _ = K.filtering(ys, lg, False)
     npt.assert_allclose(bx.reshape(T, B * dx), K.sampling(eps.reshape(T, B * dx), dms, dPs, lg, parallel), rtol=1e-6, atol=1e-8)
-
-
-def c5_model(T, d=64, delta=0.1, seed=0):
-    """F = 0.9 I + 0.04 tridiag(1, 0, 1) on the 8 x 8 grid's flattened index, Q = I, first-order
-    auxiliary observations H = I, R = delta/2 I (p = d)."""
-    F = 0.9 * np.eye(d) + 0.04 * (np.eye(d, k=1) + np.eye(d, k=-1))
-    rng = np.random.default_rng(seed)
-    x = np.zeros((T, d))
-    x[0] = rng.standard_normal(d)
-    for t in range(1, T):
-        x[t] = F @ x[t - 1] + rng.standard_normal(d)
-    u = x + np.sqrt(delta / 2) * rng.standard_normal((T, d))
-    bt = np.broadcast_to
-    lg = (np.zeros(d), np.eye(d), bt(F, (T - 1, d, d)), bt(np.eye(d), (T - 1, d, d)), bt(np.zeros(d), (T - 1, d)),
-          bt(np.eye(d), (T, d, d)), bt(delta / 2 * np.eye(d), (T, d, d)), bt(np.zeros(d), (T, d)))
-    return u, lg, x
 
 
 @pytest.mark.parametrize("dtype,T", [(np.float32, 96), (np.float64, 40)])

@@ -33,8 +33,7 @@ def timed_sweeps(kernel, chains, delta, steps=5, warmup=2, seed=1):
 
 
 def c3_kalman(order, chains=64, T=65536):
-    sys.path.insert(0, "tests")
-    from test_gpu_nonlinear_kalman import sv_setup
+    from tests.helpers import sv_setup
     y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, rho=0.0)
     model = SVModel(y, m0, P0, F, Q, b, order=order)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
@@ -45,9 +44,8 @@ def c3_kalman(order, chains=64, T=65536):
 
 
 def c4(chains=8, T=16384, N=512):
-    sys.path.insert(0, "tests")
-    from test_gpu_nonlinear_kalman import lorenz_kalman_setup
-    from test_gpu_csmc import lorenz_setup
+    from tests.helpers import lorenz_kalman_setup
+    from tests.helpers import lorenz_setup
     from aux_ssm_samplers_amd.csmc import _device
     model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
@@ -72,8 +70,7 @@ def c4(chains=8, T=16384, N=512):
 
 
 def c5(T=8192):
-    sys.path.insert(0, "tests")
-    from test_gpu_wide import c5_model
+    from tests.helpers import c5_model
     import aux_ssm_samplers_amd._primitives.kalman as P
     u, lg64, x = c5_model(T, 64)
     lg = P.LGSSM(*[np.ascontiguousarray(a, np.float32) for a in lg64])
@@ -122,7 +119,6 @@ def timed_loop(label, kernel, state, delta, n_iter=40, **kw):
 
 
 def loops():
-    sys.path.insert(0, "tests")
     import bench
     from aux_ssm_samplers_amd.common import delta_adaptation
     from aux_ssm_samplers_amd.loop import LorenzThetaStep
@@ -141,8 +137,8 @@ def loops():
                delta_fn=delta_adaptation, target_alpha=0.5, lr=0.1)
     del ch
     # C4: the (x, theta) Gibbs sampler of the Lorenz example, 8 chains each with its own theta
-    from test_gpu_nonlinear_kalman import lorenz_kalman_setup
-    from test_gpu_csmc import lorenz_setup
+    from tests.helpers import lorenz_kalman_setup
+    from tests.helpers import lorenz_setup
     T, C = 16384, 8
     model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
