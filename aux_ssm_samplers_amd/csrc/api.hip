@@ -480,12 +480,24 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
 template <typename R> AX_HD R sv_nan_to_num(R v) { return nan_to_num<R>(v); }
 // pass 1 (eps != null): u = x + sqrt(delta/2) eps and the observations linearised at x; pass 2: linearised at xlin, u given
 template <typename R>
-__global__ void k_sv_obs(long long total, int T, int D, int order, const R* __restrict__ xlin, const R* __restrict__ eps, R shd, R delta,
-                         Arr yobs, R* __restrict__ u, R* __restrict__ ys, R* __restrict__ Rs) {
+__global__ void k_sv_obs(long long total, int C, int T, int D, int order, int cfast, const R* __restrict__ xlin, const R* __restrict__ eps, R shd,
+                         R delta, Arr yobs, R* __restrict__ u, R* __restrict__ ys, R* __restrict__ Rs) {
+    // flat index g walks the (C, T, D) arrays in storage order, dense (c, t, k) or chain-minor (t, k, c)
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
-    const int k = (int)(g % D);
-    const long long ct = g / D, t = ct % T;
+    int k, c;
+    long long t;
+    if (cfast) {
+        c = (int)(g % C);
+        const long long r = g / C;
+        k = (int)(r % D);
+        t = r / D;
+    } else {
+        k = (int)(g % D);
+        const long long ct = g / D;
+        t = ct % T;
+        c = (int)(ct / T);
+    }
     const R x = xlin[g];
     R uu;
     if (eps) {
@@ -503,8 +515,10 @@ __global__ void k_sv_obs(long long total, int T, int D, int order, const R* __re
         const R hess = (R)-0.5 * w;
         const R om = (R)1 / (-hess + (R)2 / delta);
         ys[g] = om * ((R)2 * uu / delta + grad - hess * x);
-        R* Rr = Rs + ct * D * D + (long long)k * D;
-        for (int j = 0; j < D; ++j) Rr[j] = j == k ? om : (R)0;
+        // row k of the diagonal D x D record of (c, t): dense [c][t][k][j], chain-minor [t][k][j][c]
+        const long long base = cfast ? ((t * D + k) * D) * (long long)C + c : (((long long)c * T + t) * D + k) * D;
+        const long long js = cfast ? C : 1;
+        for (int j = 0; j < D; ++j) Rs[base + j * js] = j == k ? om : (R)0;
     }
 }
 template <typename R> __global__ void k_scaled_eye(int D, R v, R* eye) {
@@ -583,13 +597,19 @@ __global__ void k_sv_accept(int C, const R* j1, const R* j2, const R* ell1, cons
 // x_prop for the reverse move) get their own observation set and filter pass, as in the reference.
 template <typename R>
 static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
-                    double delta, int parallel, int nan_policy, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
-                    int32_t* accepted, void* logs) {
+                    double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
+                    const void* u_acc, int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = dims->dx;
     const bool wide = is_wide(D, D);
     const KalmanEntry* ke = need_kalman(dtype, D, D);
     const SampleEntry* se = wide ? wide_sample_entry(dtype) : sample_entry(dtype, D);
     if (!ke || !se) return AUXSSM_ERR_UNSUPPORTED;
+    // layout 1 (register kernels only): state, noise and every internal per-chain buffer chain-minor, lanes <-> chains
+    const int cm = layout == AUXSSM_LAYOUT_CHAIN_MINOR ? 1 : 0;
+    if (cm && wide) {
+        set_error("dx=%d runs the wide-state path, which takes the dense (C, T, dx) layout only", D);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
     const KDims kd{C, T, 1};
     const size_t sR = sizeof(R), CT = (size_t)C * T;
     const bool second = order == 2;
@@ -602,7 +622,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + 4096);
     add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
-    add(wide ? wide_logpdf_ws(dtype, kd) : ke->logpdf_ws(h, kd));
+    add(wide ? wide_logpdf_ws(dtype, kd) : std::max(ke->logpdf_ws(h, kd), se->sv_logpdf_ws(h, kd)));
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     R* u = (R*)ws_take(h, CT * D * sR);
@@ -622,6 +642,10 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     const size_t mark = h->ws_off;
     const long long tot = (long long)CT * D;
     const unsigned gb = (unsigned)((tot + 255) / 256);
+    auto arr = [&](const void* p, long long rec) { return cm ? cm_arr(p, kd, rec) : dense_arr(p, kd, rec); };
+    const Arr xA = arr(x, D), xpA = arr(xp, D), uA = arr(u, D), y1A = arr(ys1, D), y2A = arr(ys2, D);
+    const Arr R1A = second ? arr(Rs1, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
+    const Arr R2A = second ? arr(Rs2, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
 
     hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)1, eye);
     hipLaunchKernelGGL((k_fill<R>), dim3(1), dim3(256), 0, h->stream, (long long)D, (R)0, zero);
@@ -638,12 +662,19 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     dc.dy = D;
     dc.B = 1;
     const auxssm_arr y1d{ys1, (int64_t)T * D, (int64_t)D, 0}, y2d{ys2, (int64_t)T * D, (int64_t)D, 0};
+    // the filtered covariances do not depend on the chain when neither the dynamics nor R do (first order)
+    const int ps_shared = (!second && C > 1 && model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0) ? 1 : 0;
 
     // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
-    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, T, D, order, (const R*)x, (const R*)eps_aux, (R)sqrt(0.5 * delta),
-                       (R)delta, cv(*yobs), u, ys1, Rs1);
+    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)x, (const R*)eps_aux,
+                       (R)sqrt(0.5 * delta), (R)delta, cv(*yobs), u, ys1, Rs1);
     FilterArgs fa;
     fill_filter_args(fa, &dc, &g1, &y1d, ms, Ps);
+    fa.ys = y1A;
+    fa.ms = arr(ms, D);
+    fa.Ps = arr(Ps, (long long)D * D);
+    fa.lay.cm = cm;
+    if (second) fa.Rs = R1A;
     rc = ke->filter(h, fa, parallel, ell1);
     if (rc) return rc;
     h->ws_off = mark;
@@ -651,34 +682,56 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     sa.d = kd;
     sa.dx = D;
     sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
-    sa.ms = dense_arr(ms, kd, D); sa.Ps = dense_arr(Ps, kd, (long long)D * D);
-    sa.eps = dense_arr(eps_samp, kd, D); sa.xs = dense_arr(xp, kd, D); sa.elem = nullptr;
-    sa.lay = ScanLayout{1, 1, 1, 1, 0, C};
+    sa.ms = arr(ms, D); sa.Ps = arr(Ps, (long long)D * D);
+    sa.eps = arr(eps_samp, D); sa.xs = xpA; sa.elem = nullptr;
+    sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
+    sa.ps_shared = cm ? ps_shared : 0;
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;
     h->ws_off = mark;
     // reverse move: observations linearised at x_prop, filter for its marginal likelihood (generic.py:67)
-    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, T, D, order, (const R*)xp, (const R*)nullptr, (R)0, (R)delta,
-                       cv(*yobs), u, ys2, Rs2);
+    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)xp, (const R*)nullptr, (R)0,
+                       (R)delta, cv(*yobs), u, ys2, Rs2);
     fill_filter_args(fa, &dc, &g2, &y2d, ms, Ps);
+    fa.ys = y2A;
+    fa.ms = arr(ms, D);
+    fa.Ps = arr(Ps, (long long)D * D);
+    fa.lay.cm = cm;
+    if (second) fa.Rs = R2A;
     rc = ke->filter(h, fa, parallel, ell2);
     if (rc) return rc;
     h->ws_off = mark;
-    // joint log-densities of both auxiliary models (posterior_logpdf + ell, base.py:72-96)
-    LogpdfArgs la;
-    fill_logpdf_args(la, &dc, &g1, cv(y1d), dense_arr(xp, kd, D), nan_policy);
-    rc = ke->logpdf(h, la, j1);
-    if (rc) return rc;
-    h->ws_off = mark;
-    fill_logpdf_args(la, &dc, &g2, cv(y2d), dense_arr(x, kd, D), nan_policy);
-    rc = ke->logpdf(h, la, j2);
-    if (rc) return rc;
-    h->ws_off = mark;
-    hipLaunchKernelGGL((k_sv_terms<R>), dim3(C), dim3(256), 0, h->stream, C, T, D, (R)delta, (const R*)x, (const R*)xp, (const R*)u, cv(*yobs),
-                       (const R*)ys1, (const R*)ys2, (const R*)Rs1, (const R*)Rs2, terms);
-    hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
-                       (const R*)ell2, (const R*)terms, (const R*)u_acc, accepted, (R*)logs);
-    launch_select<R>(h, C, T, D, (const int32_t*)accepted, dense_arr(xp, kd, D), dense_arr(x, kd, D), 0);
+    if (!wide) {
+        // every log-density of the MH ratio in one pass over the chains (generic.py:88-89, :98-106)
+        SvLogpdfArgs la;
+        la.d = kd;
+        la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
+        la.yobs = cv(*yobs);
+        la.x = xA; la.xp = xpA; la.u = uA; la.ys1 = y1A; la.ys2 = y2A; la.R1 = R1A; la.R2 = R2A;
+        la.delta = delta;
+        rc = se->sv_logpdf(h, la, j1);  // j1 .. : [5][C] = jp_prop, jp_rev, lt_prop, lt_rev, corr
+        if (rc) return rc;
+        h->ws_off = mark;
+        hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)(j1 + C), (const R*)ell1,
+                           (const R*)ell2, (const R*)(j1 + 2 * C), (const R*)(j1 + 3 * C), (const R*)(j1 + 4 * C), (const R*)u_acc, accepted,
+                           (R*)logs);
+    } else {
+        // wide-state path: joint log-densities of both auxiliary models (posterior_logpdf + ell, base.py:72-96), then the SV terms
+        LogpdfArgs la;
+        fill_logpdf_args(la, &dc, &g1, cv(y1d), dense_arr(xp, kd, D), nan_policy);
+        rc = ke->logpdf(h, la, j1);
+        if (rc) return rc;
+        h->ws_off = mark;
+        fill_logpdf_args(la, &dc, &g2, cv(y2d), dense_arr(x, kd, D), nan_policy);
+        rc = ke->logpdf(h, la, j2);
+        if (rc) return rc;
+        h->ws_off = mark;
+        hipLaunchKernelGGL((k_sv_terms<R>), dim3(C), dim3(256), 0, h->stream, C, T, D, (R)delta, (const R*)x, (const R*)xp, (const R*)u,
+                           cv(*yobs), (const R*)ys1, (const R*)ys2, (const R*)Rs1, (const R*)Rs2, terms);
+        hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
+                           (const R*)ell2, (const R*)terms, (const R*)u_acc, accepted, (R*)logs);
+    }
+    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -1218,14 +1271,10 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
         return sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
     if (sv) {
-        if (layout != AUXSSM_LAYOUT_DENSE) {
-            set_error("the stochastic-volatility sweeps take the dense (C, T, dx) layout");
-            return AUXSSM_ERR_UNSUPPORTED;
-        }
         const int order = model_kind == AUXSSM_KMODEL_SV_FIRST ? 1 : 2;
         if (dtype == AUXSSM_F32)
-            return sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
-        return sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
+            return sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        return sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
     if (dtype == AUXSSM_F32)
         return sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);

@@ -94,9 +94,13 @@ struct SweepLogpdfEntry {
     sweep_logpdf_fn run;
     sweep_logpdf_ws_fn ws;
 };
+typedef int (*sv_logpdf_fn)(auxssm_ctx*, const SvLogpdfArgs&, void* out /*[5][C]*/);
+typedef size_t (*sv_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);
 struct SampleEntry {
     sample_fn sample;
     sample_ws_fn sample_ws;
+    sv_logpdf_fn sv_logpdf = nullptr;  // the SV sweep's fused log-density pass (register kernels only; null in the wide-state entry)
+    sv_logpdf_ws_fn sv_logpdf_ws = nullptr;
 };
 
 constexpr int MAX_D = 4;

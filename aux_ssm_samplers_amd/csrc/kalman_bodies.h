@@ -847,6 +847,92 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_head(const Swe
     out5[4] = corr;
 }
 
+// ---- the stochastic-volatility sweep's log-densities in one pass (examples/stochastic_volatility/auxiliary_kalman.py:22-48 +
+// kalman/generic.py:88-89, :98-106): per chain the five sums
+//   [0] log N(ys1; x', R1) + prior(x')   (joint of the proposal's auxiliary model at x')       [1] log N(ys2; x, R2) + prior(x)
+//   [2] log g(x') + prior(x')            (target at x')                                        [3] log g(x) + prior(x)
+//   [4] sum ((x' - u)^2 - (x - u)^2) / delta
+// with g the SV potential, R1 / R2 the (diagonal) auxiliary observation covariances of the two linearisation points (null: delta/2 I)
+// and a NaN auxiliary term dropped per time step (the reference's nansum).  Any layout: every array is read through its strides.
+struct SvLogpdfArgs {
+    KDims d;
+    Arr m0, P0, Fs, Qs, bs;  // linear-Gaussian dynamics
+    Arr yobs;                // (T, D), chain-shared
+    Arr x, xp, u, ys1, ys2;  // (C, T, D)
+    Arr R1, R2;              // (C, T, D, D), ptr null for the first-order factory
+    double delta;
+};
+template <typename R, int D>
+AX_HD void sv_step_terms(const SvLogpdfArgs& a, int c, long long t, const R* x, const R* xp, R* o5) {
+    R u[D], y[D], y1[D], y2[D];
+    rd<R, D>(a.u, c, t, 0, u);
+    rd<R, D>(a.yobs, 0, t, 0, y);
+    rd<R, D>(a.ys1, c, t, 0, y1);
+    rd<R, D>(a.ys2, c, t, 0, y2);
+    R pp = 0, px = 0, l1 = 0, l2 = 0, cr = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R av = xp[k], bv = x[k];
+        pp += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * av - (R)0.5 * y[k] * y[k] * exp_(-av));
+        px += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * bv - (R)0.5 * y[k] * y[k] * exp_(-bv));
+        const R r1 = a.R1.ptr ? at<R>(a.R1, c, t, 0)[(long long)(k * D + k) * a.R1.se] : (R)(0.5 * a.delta);
+        const R r2 = a.R2.ptr ? at<R>(a.R2, c, t, 0)[(long long)(k * D + k) * a.R2.se] : (R)(0.5 * a.delta);
+        const R s1 = sqrt_(r1), s2 = sqrt_(r2);
+        const R z1 = (y1[k] - av) / s1, z2 = (y2[k] - bv) / s2;
+        l1 += (R)-0.5 * z1 * z1 - log_(s1) - (R)(0.5 * LOG_2PI);
+        l2 += (R)-0.5 * z2 * z2 - log_(s2) - (R)(0.5 * LOG_2PI);
+        const R e1 = av - u[k], e2 = bv - u[k];
+        cr += (e1 * e1 - e2 * e2) / (R)a.delta;
+    }
+    o5[0] = isnan_(l1) ? (R)0 : l1;
+    o5[1] = isnan_(l2) ? (R)0 : l2;
+    o5[2] = pp;
+    o5[3] = px;
+    o5[4] = cr;
+}
+// lanes indexed by i = t - 1 (t >= 1)
+template <typename R, int D> AX_HD void body_sv_logpdf(const SvLogpdfArgs& a, int c, int i, bool valid, R* out5) {
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out5[k] = 0;
+    if (!valid) return;
+    const long long t = (long long)i + 1;
+    R x[D], xp[D], xq[D], xpq[D], F[D * D], bd[D], Q[D * D];
+    rd<R, D>(a.x, c, t, 0, x);
+    rd<R, D>(a.xp, c, t, 0, xp);
+    rd<R, D>(a.x, c, i, 0, xq);
+    rd<R, D>(a.xp, c, i, 0, xpq);
+    rd<R, D * D>(a.Fs, c, i, 0, F);
+    rd<R, D>(a.bs, c, i, 0, bd);
+    rd<R, D * D>(a.Qs, c, i, 0, Q);
+    sv_step_terms<R, D>(a, c, t, x, xp, out5);
+    R r1[D], r2[D], m1[D], m2[D], pr_p, pr_x;
+    mv<R, D, D>(F, xpq, m1);
+    mv<R, D, D>(F, xq, m2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
+    gauss_logpdf2<R, D>(r1, r2, Q, nullptr, pr_p, pr_x);
+    out5[0] += pr_p;
+    out5[1] += pr_x;
+    out5[2] += pr_p;
+    out5[3] += pr_x;
+}
+template <typename R, int D> AX_HD void body_sv_logpdf_head(const SvLogpdfArgs& a, int c, R* out5) {
+    R x[D], xp[D], m0[D], P0m[D * D];
+    rd<R, D>(a.x, c, 0, 0, x);
+    rd<R, D>(a.xp, c, 0, 0, xp);
+    rd<R, D>(a.m0, c, 0, 0, m0);
+    rd<R, D * D>(a.P0, c, 0, 0, P0m);
+    sv_step_terms<R, D>(a, c, 0, x, xp, out5);
+    R r1[D], r2[D], pr_p, pr_x;
+#pragma unroll
+    for (int k = 0; k < D; ++k) r1[k] = xp[k] - m0[k], r2[k] = x[k] - m0[k];
+    gauss_logpdf2<R, D>(r1, r2, P0m, nullptr, pr_p, pr_x);
+    out5[0] += pr_p;
+    out5[1] += pr_x;
+    out5[2] += pr_p;
+    out5[3] += pr_x;
+}
+
 // ---- the same pass with chain-shared parameters: Cholesky factors and log-determinants of Q_{t-1}, Robs_t once per time step ---
 template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_tab(const SweepLogpdfArgs& a, int i) {
     using T = LogShared<R, D, PO>;

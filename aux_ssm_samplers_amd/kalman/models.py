@@ -79,7 +79,7 @@ class SVModel:
 
     Pass the three bound methods to kalman.get_kernel: it runs the device sweep (auxssm_kalman_sweep, model kind SV_FIRST /
     SV_SECOND).  The same methods are NumPy factories for the host path and the oracle."""
-    dense_only = True
+    dense_only = False  # >= 32 chains run chain-minor (lanes over chains), as the LG_CONCAT sweep does
 
     def __init__(self, ys, m0, P0, F, Q, b, order=1):
         if order not in (1, 2):

@@ -151,7 +151,8 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
  *         AUXSSM_LAYOUT_CHAIN_MINOR -- they are (T,dx,C) row-major (chain index fastest).  Then lanes run over CHAINS: every
  *         per-chain buffer inside the sweep is [t][component][chain], so each wave access is one contiguous run and the
  *         chain-shared model parameters are wave-uniform loads; there is no transposition anywhere in the sweep.  This is the
- *         layout to use with >= 32 chains (bench.py); results are identical up to the combination tree of the scan.
+ *         layout to use with >= 32 chains (bench.py); results are identical up to the combination tree of the scan.  LG_CONCAT and the
+ *         SV factories (dx <= 4) take it; LORENZ63_EXT and the wide-state sizes (dx > 4) are dense only.
  */
 typedef enum {
     AUXSSM_KMODEL_LG_CONCAT = 1,
@@ -159,7 +160,7 @@ typedef enum {
      * examples/stochastic_volatility/auxiliary_kalman.py:22-48: observations_factory(x, u, d) is the first-order
      * (ys = u + d/2 grad log g(x), R = d/2 I) or second-order (R = (-hess + 2/d I)^-1, ys = R (2u/d + grad - hess x)) auxiliary
      * observation set with H = I, c = 0, rebuilt at both linearisation points (x and x_prop) each sweep;
-     * log_likelihood_fn(x) = prior_logpdf(x) + sum log g.  yobs (T, dx), dims->dy = dx, dense layout. */
+     * log_likelihood_fn(x) = prior_logpdf(x) + sum log g.  yobs (T, dx), dims->dy = dx; dense or (dx <= 4) chain-minor layout. */
     AUXSSM_KMODEL_SV_FIRST = 2,
     AUXSSM_KMODEL_SV_SECOND = 3,
     /* Stochastic Lorenz-63 (examples/lorenz/auxiliary_kalman.py:14-52, model.py:10-25): dynamics_factory(x) is the first-order

@@ -62,6 +62,44 @@ def test_sv_host_factory_path_equals_device_sweep(order):
     assert a.updated == bb.updated
 
 
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("d,T,C", [(1, 300, 40), (2, 129, 33), (4, 70, 64)])
+@pytest.mark.parametrize("share", [1, 0])
+def test_sv_chain_minor_sweep_vs_oracle(order, d, T, C, share):
+    """>= 32 chains run the SV sweep chain-minor (state (T, dx, C), lanes over chains; first order additionally with the chain-shared
+    tables): every chain vs the oracle's sweep on its own noise, and vs the dense-layout sweep of the same chains."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, SVModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, d, seed=7)
+    model = SVModel(y, m0, P0, F, Q, b, order=order)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    rng = np.random.Generator(np.random.PCG64(50 + d))
+    x0 = xtrue[None] + 0.2 * rng.standard_normal((C, T, d))
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    h.set_option(_lib.OPT_SHARE_MODEL, share)
+    try:
+        outs = {}
+        for cmin in (True, False):
+            chains = DeviceChains(h, x0, chain_minor=cmin)
+            assert chains.chain_minor == cmin
+            kernel(None, KalmanSampler(x=chains, updated=None), 0.3, noise=noise)
+            outs[cmin] = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    finally:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    npt.assert_allclose(outs[True][0], outs[False][0], rtol=1e-9, atol=1e-10)
+    npt.assert_array_equal(outs[True][1], outs[False][1])
+    npt.assert_allclose(outs[True][2][:, 1:], outs[False][2][:, 1:], rtol=1e-9)
+    for c in range(0, C, 7):
+        ref = K.kalman_sweep(x0[c], 0.3, model.dynamics_factory, model.observations_factory, oracle_target(model), True,
+                             eps_aux=noise["eps_aux"][c], eps_samp=noise["eps_samp"][c], u_accept=noise["u_accept"][c])
+        npt.assert_allclose(outs[True][2][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
+        assert bool(outs[True][1][c]) == ref["accepted"]
+        npt.assert_allclose(outs[True][0][c], ref["x"], rtol=1e-9, atol=1e-10)
+    assert 0 < outs[True][1].sum() < C or d == 4  # both branches of the accept step
+
+
 def test_sv_chain_moves_and_targets_posterior():
     """Many sweeps of many chains, device Threefry noise: acceptance is healthy and the chain stays in the high-probability region
     (a crude but reference-free sanity check of the MH ratio: a wrong ratio drives log pi(x) away or freezes the chain)."""

@@ -32,15 +32,21 @@ def timed_sweeps(kernel, chains, delta, steps=5, warmup=2, seed=1):
     return chains.C * steps / el, el / steps * 1e3, float(chains.accepted.to_host().mean())
 
 
-def c3_kalman(order, chains=64, T=65536):
+def c3_kalman(order, chains=64, T=65536, chain_minor=None):
     from tests.helpers import sv_setup
+    from aux_ssm_samplers_amd.common import delta_adaptation
+    from aux_ssm_samplers_amd.loop import loop
     y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, rho=0.0)
     model = SVModel(y, m0, P0, F, Q, b, order=order)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
     h = _lib.default_handle()
-    ch = DeviceChains(h, np.repeat(xtrue[None], chains, axis=0), chain_minor=False)
-    v, ms, acc = timed_sweeps(kernel, ch, 0.5)
-    print(json.dumps(dict(config=f"C3 SV d=1 T={T}, aux-Kalman order {order}, fp64", chains=chains, sweeps_per_s=round(v, 1), ms_per_step=round(ms, 2), accept=acc)))
+    ch = DeviceChains(h, np.repeat(xtrue[None], chains, axis=0), chain_minor=chain_minor)
+    # burn-in with the reference's adaptation rule so that the timed sweeps run at a step size that moves (target 0.234)
+    out = loop(R.PRNGKey(0), 0.05, KalmanSampler(x=ch, updated=True), kernel, delta_adaptation, 400, target_alpha=0.234, lr=0.3, beta=0.2)
+    delta = out[3]
+    v, ms, acc = timed_sweeps(kernel, ch, delta, steps=10)
+    print(json.dumps(dict(config=f"C3 SV d=1 T={T}, aux-Kalman order {order}, fp64, {'chain-minor' if ch.chain_minor else 'dense'} layout", chains=chains,
+                          delta=float(f"{delta:.3g}"), sweeps_per_s=round(v, 1), ms_per_step=round(ms, 2), accept=acc)), flush=True)
 
 
 def c4(chains=8, T=16384, N=512):
@@ -205,8 +211,9 @@ if __name__ == "__main__":
     if "loop" in which:
         loops()
     if "c3k" in which:
-        c3_kalman(1)
-        c3_kalman(2)
+        for chains, cmin in ((64, False), (64, None), (256, None), (1024, None)):
+            c3_kalman(1, chains, chain_minor=cmin)
+            c3_kalman(2, chains, chain_minor=cmin)
     if "c4" in which:
         c4()
     if "c5" in which:
