@@ -766,18 +766,19 @@ __global__ void k_lorenz_dyn(int C, int T, const R* __restrict__ par, long long 
     for (int k = 0; k < 9; ++k) Fo[k] = F[k];
     for (int r = 0; r < 3; ++r) bo[r] = mu[r] - (F[r * 3] * x[0] + F[r * 3 + 1] * x[1] + F[r * 3 + 2] * x[2]);
 }
-// per chain: target(xp), target(x), corr.  out [3][C]
+// per (chain, tile of 256 time steps): partial sums of target(xp), target(x), corr.  part [3][C][ntile]; k_sum_tiles finishes
 template <typename R, int PO>
-__global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, R delta, const R* __restrict__ par, long long psc, Arr m0, Arr P0, Arr Qs,
-                                                      Arr Hs, Arr Rs, Arr cs, Arr yobs, const R* __restrict__ x, const R* __restrict__ xp,
-                                                      const R* __restrict__ u, R* __restrict__ out) {
+__global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, int ntile, R delta, const R* __restrict__ par, long long psc, Arr m0, Arr P0,
+                                                      Arr Qs, Arr Hs, Arr Rs, Arr cs, Arr yobs, const R* __restrict__ x,
+                                                      const R* __restrict__ xp, const R* __restrict__ u, R* __restrict__ part) {
     __shared__ R sh[256];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    const int tile = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
     par += (long long)c * psc;
     const R th[3] = {par[0], par[1], par[2]};
     const R dt = par[3];
     R acc[3] = {0, 0, 0};
-    for (long long t = tid; t < T; t += 256) {
+    const long long t = (long long)tile * 256 + tid;
+    if (t < T) {
         const R* xa = xp + ((long long)c * T + t) * 3;
         const R* xb = x + ((long long)c * T + t) * 3;
         const R* uu = u + ((long long)c * T + t) * 3;
@@ -819,9 +820,9 @@ __global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, R delta, con
             const R e1 = xa[k] - uu[k], e2 = xb[k] - uu[k];
             cr += (e1 * e1 - e2 * e2) / delta;
         }
-        acc[0] += tp;
-        acc[1] += tx;
-        acc[2] += cr;
+        acc[0] = tp;
+        acc[1] = tx;
+        acc[2] = cr;
     }
     for (int q = 0; q < 3; ++q) {
         sh[tid] = acc[q];
@@ -830,9 +831,23 @@ __global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, R delta, con
             if (tid < off) sh[tid] += sh[tid + off];
             __syncthreads();
         }
-        if (tid == 0) out[(long long)q * C + c] = sh[0];
+        if (tid == 0) part[((long long)q * C + c) * ntile + tile] = sh[0];
         __syncthreads();
     }
+}
+// out[r] = sum_tile part[r][tile], one workgroup per row, fixed order
+template <typename R> __global__ void __launch_bounds__(256) k_sum_tiles(int ntile, const R* __restrict__ part, R* __restrict__ out) {
+    __shared__ R sh[256];
+    const int r = blockIdx.x, tid = threadIdx.x;
+    R v = 0;
+    for (int k = tid; k < ntile; k += 256) v += part[(long long)r * ntile + k];
+    sh[tid] = v;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) sh[tid] += sh[tid + off];
+        __syncthreads();
+    }
+    if (tid == 0) out[r] = sh[0];
 }
 
 template <typename R>
@@ -853,6 +868,8 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     add(CT * D * D * sR);                                     // Ps
     add(2 * (size_t)C * n * (9 + 3) * sR + 1024);             // Fs1, bs1, Fs2, bs2
     add((size_t)16 * C * sR + 2048);
+    const int ntile = (T + 255) / 256;
+    add((size_t)3 * C * ntile * sR);
     add(ke->filter_ws(h, kd, parallel));
     add(se->sample_ws(h, kd, parallel));
     add(ke->logpdf_ws(h, kd));
@@ -862,6 +879,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     R* Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
     R* Rc = (R*)ws_take(h, (size_t)T * P * P * sR);
     R* cc = (R*)ws_take(h, (size_t)T * P * sR);
+    R* tpart = (R*)ws_take(h, (size_t)3 * C * ntile * sR);
     R* u = (R*)ws_take(h, CT * D * sR);
     R* ms = (R*)ws_take(h, CT * D * sR);
     R* xp = (R*)ws_take(h, CT * D * sR);
@@ -871,7 +889,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     R* Fs2 = (R*)ws_take(h, (size_t)C * n * 9 * sR);
     R* bs2 = (R*)ws_take(h, (size_t)C * n * 3 * sR);
     R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
-    if (!ysc || !Hc || !Rc || !cc || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc) return AUXSSM_ERR_NOMEM;
+    if (!ysc || !Hc || !Rc || !cc || !tpart || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc) return AUXSSM_ERR_NOMEM;
     R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
     const size_t mark = h->ws_off;
     const R* par = (const R*)model->Fs.ptr;  // [theta1, theta2, theta3, dt], chain stride model->Fs.sc (0 = one theta for all chains)
@@ -935,12 +953,14 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     if (rc) return rc;
     h->ws_off = mark;
 #define AX_LORENZ_TERMS(PO_)                                                                                                              \
-    hipLaunchKernelGGL((k_lorenz_terms<R, PO_>), dim3(C), dim3(256), 0, h->stream, C, T, (R)delta, par, psc, cv(model->m0), cv(model->P0), \
-                       cv(model->Qs), cv(model->Hs), cv(model->Rs), cv(model->cs), cv(*yobs), (const R*)x, (const R*)xp, (const R*)u, terms)
+    hipLaunchKernelGGL((k_lorenz_terms<R, PO_>), dim3(ntile, C), dim3(256), 0, h->stream, C, T, ntile, (R)delta, par, psc, cv(model->m0),     \
+                       cv(model->P0), cv(model->Qs), cv(model->Hs), cv(model->Rs), cv(model->cs), cv(*yobs), (const R*)x, (const R*)xp,          \
+                       (const R*)u, tpart)
     if (PO == 1) AX_LORENZ_TERMS(1);
     else if (PO == 2) AX_LORENZ_TERMS(2);
     else AX_LORENZ_TERMS(3);
 #undef AX_LORENZ_TERMS
+    hipLaunchKernelGGL((k_sum_tiles<R>), dim3(3 * C), dim3(256), 0, h->stream, ntile, (const R*)tpart, terms);
     hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
                        (const R*)ell2, (const R*)terms, (const R*)(terms + C), (const R*)(terms + 2 * C), (const R*)u_acc, accepted, (R*)logs);
     launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, 0);
