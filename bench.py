@@ -201,7 +201,8 @@ def main():
     ndev = torch.cuda.device_count()
     if args.dist_backend == "gloo":
         local_rank = local_rank % max(ndev, 1)  # rehearsal: ranks may share a GPU
-    if world > 1:
+    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run: initialise the group even for one rank
+    if world > 1 or launched:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
         if args.dist_backend == "nccl":
