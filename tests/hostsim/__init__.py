@@ -113,3 +113,21 @@ def joint_logpdf(ys, xs, lgssm, nan_policy=0, dtype=np.float64, chains=False, ch
     rc = lib().hs_logpdf(_dt(dtype), dx, dy, C_, T, B, g, C.byref(ya), C.byref(xa), int(nan_policy), out.ctypes.data_as(C.c_void_p))
     assert rc == 0, rc
     return out if chains else out[0]
+
+
+def sv_logpdf(lg5, yobs, x, xp, u, ys1, ys2, R1, R2, delta, chain_minor=False, dtype=np.float64):
+    """The SV sweep's fused log-density pass (csrc/kalman_bodies.h::body_sv_logpdf) on the host: x, xp, u, ys1, ys2 (C, T, D), R1 / R2
+    (C, T, D, D) or None; lg5 = (m0, P0, Fs, Qs, bs) chain-shared.  Returns (5, C): jp_prop, jp_rev, lt_prop, lt_rev, corr."""
+    x = np.asarray(x)
+    C_, T, D = x.shape
+    lg = list(lg5) + [None, None, None]
+    desc = _layout.describe_lgssm(lg, 1, T, 1, D, 1, False, dtype, False)
+    g, keep = _garr(desc)
+    cv = lambda a: None if a is None else np.ascontiguousarray(a, dtype)
+    arrs = [cv(a) for a in (yobs, x, xp, u, ys1, ys2, R1, R2)]
+    out = np.empty((5, C_), dtype)
+    ptr = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)
+    rc = lib().hs_sv_logpdf(_dt(dtype), D, C_, T, g, *[ptr(a) for a in arrs], C.c_double(float(delta)), int(bool(chain_minor)),
+                            out.ctypes.data_as(C.c_void_p))
+    assert rc == 0, rc
+    return out

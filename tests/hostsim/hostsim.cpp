@@ -190,6 +190,38 @@ static int logpdf_T(int C, int T, int B, const HsArr* g, const HsArr* ys, const 
     return 0;
 }
 
+// the SV sweep's fused log-density pass (kalman_bodies.h::body_sv_logpdf), dense or chain-minor views of the same dense inputs
+template <typename R, int D>
+static int sv_logpdf_T(int C, int T, const HsArr* g, const void* yobs, const void* x, const void* xp, const void* u, const void* ys1,
+                       const void* ys2, const void* R1, const void* R2, double delta, int cm, void* out) {
+    SvLogpdfArgs a;
+    a.d = KDims{C, T, 1};
+    a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Fs = cv(g[2]); a.Qs = cv(g[3]); a.bs = cv(g[4]);
+    a.yobs = Arr{yobs, 0, D, 0, 1};
+    a.delta = delta;
+    std::vector<std::vector<R>> keep;
+    auto view = [&](const void* p, int rec) -> Arr {
+        if (!p) return Arr{nullptr, 0, 0, 0, 1};
+        if (!cm) return dense_arr(p, a.d, rec);
+        keep.emplace_back((size_t)C * T * rec);
+        dense_to_cm<R>((const R*)p, a.d, rec, keep.back());
+        return cm_arr(keep.back().data(), a.d, rec);
+    };
+    a.x = view(x, D); a.xp = view(xp, D); a.u = view(u, D); a.ys1 = view(ys1, D); a.ys2 = view(ys2, D);
+    a.R1 = view(R1, D * D); a.R2 = view(R2, D * D);
+    for (int c = 0; c < C; ++c) {
+        R tot[5];
+        body_sv_logpdf_head<R, D>(a, c, tot);
+        for (int i = 0; i < T - 1; ++i) {
+            R w[5];
+            body_sv_logpdf<R, D>(a, c, i, true, w);
+            for (int k = 0; k < 5; ++k) tot[k] += w[k];
+        }
+        for (int k = 0; k < 5; ++k) ((R*)out)[(size_t)k * C + c] = tot[k];
+    }
+    return 0;
+}
+
 #define HS_P_SWITCH(CALL, R, D)                                           \
     switch (P) {                                                          \
         case 1: return CALL(R, D, 1); case 2: return CALL(R, D, 2);       \
@@ -230,6 +262,20 @@ int hs_logpdf(int dtype, int D, int P, int C, int T, int B, const HsArr* g, cons
 #define CALL(R, D, P) logpdf_T<R, D, P>(C, T, B, g, ys, xs, pol, out)
     if (dtype == 0) { HS_D_SWITCH(CALL, float) } else { HS_D_SWITCH(CALL, double) }
 #undef CALL
+}
+
+int hs_sv_logpdf(int dtype, int D, int C, int T, const HsArr* g, const void* yobs, const void* x, const void* xp, const void* u, const void* ys1,
+                 const void* ys2, const void* R1, const void* R2, double delta, int cm, void* out) {
+#define CALLS(R)                                                                                              \
+    switch (D) {                                                                                              \
+        case 1: return sv_logpdf_T<R, 1>(C, T, g, yobs, x, xp, u, ys1, ys2, R1, R2, delta, cm, out);          \
+        case 2: return sv_logpdf_T<R, 2>(C, T, g, yobs, x, xp, u, ys1, ys2, R1, R2, delta, cm, out);          \
+        case 3: return sv_logpdf_T<R, 3>(C, T, g, yobs, x, xp, u, ys1, ys2, R1, R2, delta, cm, out);          \
+        case 4: return sv_logpdf_T<R, 4>(C, T, g, yobs, x, xp, u, ys1, ys2, R1, R2, delta, cm, out);          \
+        default: return -2;                                                                                   \
+    }
+    if (dtype == 0) { CALLS(float) } else { CALLS(double) }
+#undef CALLS
 }
 
 }  // extern "C"

@@ -131,3 +131,38 @@ def test_block_diagonal_R_information_form(d, po, E):
     npt.assert_allclose(ms, oms, rtol=1e-8, atol=1e-10)
     npt.assert_allclose(Ps, oPs, rtol=1e-8, atol=1e-10)
     npt.assert_allclose(ell, oell, rtol=1e-9)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("d", [1, 2, 4])
+@pytest.mark.parametrize("chain_minor", [False, True])
+def test_sv_fused_logpdf_body(order, d, chain_minor):
+    """The SV sweep's fused log-density body (jp_prop, jp_rev, lt_prop, lt_rev, corr per chain) against the oracle's pieces: the
+    auxiliary model's joint log_likelihood + prior (base.py:99-166) and the target prior + potential, at both linearisation points."""
+    from tests import hostsim as HS
+    from tests.helpers import sv_setup
+    from aux_ssm_samplers_amd.kalman.models import SVModel
+    T, C, delta = 23, 3, 0.4
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, d, seed=d)
+    model = SVModel(y, m0, P0, F, Q, b, order=order)
+    rng = np.random.default_rng(order * 10 + d)
+    x = xtrue[None] + 0.3 * rng.standard_normal((C, T, d))
+    xp = xtrue[None] + 0.3 * rng.standard_normal((C, T, d))
+    u = x + np.sqrt(delta / 2) * rng.standard_normal((C, T, d))
+    ys1, ys2, R1, R2 = (np.zeros((C, T, d)), np.zeros((C, T, d)), np.zeros((C, T, d, d)), np.zeros((C, T, d, d)))
+    ref = np.zeros((5, C))
+    lgp = (model.m0, model.P0, model.Fs, model.Qs, model.bs, None, None, None)
+    for c in range(C):
+        y1, Hm, Ra, cc = model.observations_factory(x[c], u[c], delta)
+        y2, _, Rb, _ = model.observations_factory(xp[c], u[c], delta)
+        ys1[c], ys2[c], R1[c], R2[c] = y1, y2, Ra, Rb
+        lg1 = (model.m0, model.P0, model.Fs, model.Qs, model.bs, Hm, Ra, cc)
+        lg2 = (model.m0, model.P0, model.Fs, model.Qs, model.bs, Hm, Rb, cc)
+        ref[0, c] = K.log_likelihood(y1, xp[c], lg1) + K.prior_logpdf(xp[c], lg1)
+        ref[1, c] = K.log_likelihood(y2, x[c], lg2) + K.prior_logpdf(x[c], lg2)
+        ref[2, c] = K.prior_logpdf(xp[c], lgp) + model.log_potential(xp[c])
+        ref[3, c] = K.prior_logpdf(x[c], lgp) + model.log_potential(x[c])
+        ref[4, c] = np.sum(((xp[c] - u[c]) ** 2 - (x[c] - u[c]) ** 2) / delta)
+    got = HS.sv_logpdf((model.m0, model.P0, model.Fs, model.Qs, model.bs), y, x, xp, u, ys1, ys2,
+                            R1 if order == 2 else None, R2 if order == 2 else None, delta, chain_minor)
+    npt.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
