@@ -75,7 +75,10 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
     stats = tuple(handle.zeros(chains.x.shape, dtype) for _ in range(3))  # fold 0 overwrites: (0 u + v) / 1 = v, as stats_fn(x, x) would
     flags = chains.accepted if kalman else chains.ancestors
     m = 1 if kalman else chains.T
-    upd0 = np.broadcast_to(np.asarray(init_state.updated if init_state.updated is not None else True, dtype), (chains.C, m))
+    upd = init_state.updated if init_state.updated is not None else True
+    if hasattr(upd, "to_host"):  # the state a previous loop returned: flags still on the device
+        upd = upd.to_host().reshape(chains.C, m) != 0
+    upd0 = np.broadcast_to(np.asarray(upd, dtype), (chains.C, m))
     avg = handle.to_device(upd0, dtype)
     window = handle.to_device(upd0, dtype)
     if kalman:
