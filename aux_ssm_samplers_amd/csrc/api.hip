@@ -58,8 +58,10 @@ ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
     // longer chunks halve the aggregate-scan work (measured on C2 x 64 chains: E = 64 beats 16/32/48/96)
     const long long target = (long long)h->num_cu * 4 * 64;
     long long E = ((long long)S * n + target - 1) / target;
-    long long emin = (long long)(sqrt((double)n / 43.0) + 0.5);
-    if (emin < 2) emin = 2;
+    // few sequences (the chip is not full at any E): the lane-serial walk over a chunk dominates, the aggregate scan is cheap -- measured
+    // optimum E = 12 at n = 65535 (1 and 8 sequences, fp64 d = 4) and E = 8 at n = 16383 (8 sequences, fp32 d = 3): E ~ sqrt(n / 450)
+    long long emin = (long long)(sqrt((double)n / 450.0) + 0.5);
+    if (emin < 4) emin = 4;
     if (emin > 32) emin = 32;
     if (E < emin) E = emin;
     if (E > 512) E = 512;
