@@ -20,8 +20,11 @@
 //                       reciprocal diagonal of chol(Q) as a multiplier;
 //   M = max v (exact); e[p] = exp(v[p] - M);  the N^2 values are cut into NCH consecutive chunks of Lc = ceil(N^2/NCH), NCH = 64 (N <= 32),
 //   256 (N <= 128) or 1024 = the lanes of the stitch's workgroup; chunk sums are serial left to right, the cumsum over the NCH chunk sums is
-//   the block cumsum of csmc_dev.h; a draw r = total (1 - u) picks the first chunk with cumsum >= r, then the first p in it with
-//   (previous chunks' cumsum + serial prefix) >= r (last p of the chunk if none).
+//   the block cumsum of csmc_dev.h.  A chunk is cut again into SC = 8 consecutive sub-chunks of Ls = ceil(Lc/8): the chunk sum is the
+//   left-to-right sum of its sub-chunk sums, each a serial sum from 0.  A draw r = total (1 - u) picks the first chunk with cumsum >= r,
+//   inside it the first sub-chunk b with (previous chunks' cumsum + (S_0 + .. + S_b)) >= r (the last non-empty one if none), inside that
+//   the first p with (previous chunks' cumsum + ((S_0 + .. + S_{b-1}) + e .. + e_p)) >= r (its last p if none): a draw recomputes one
+//   sub-chunk, not the chunk.
 #include "csmc_dev.h"
 
 namespace ax {
@@ -110,6 +113,8 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_leave
     if (live) ((R*)a.lw0)[(long long)c * N + tid] = lw;
 }
 
+constexpr int PIT_SC = 8;  // sub-chunks per chunk (arithmetic contract, see the header)
+
 template <typename R, int D> __device__ __forceinline__ R gauss_r(const R* x, const R* mean, const R* L, const R* iL, R cst) {
     R z[D];
     R q = 0;
@@ -137,6 +142,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitc
     R* cs = hh + N;           // [NCH] cumsum of the chunk sums
     const int NCH = blockDim.x, nw = NCH >> 6;
     R* red = cs + NCH;        // [48]
+    R* sub = red + 48;        // [PIT_SC][NCH] sub-chunk sums
     const bool root = k == a.K - 1;
     const long long chain_nodes = (long long)c * a.tot;
     // children: left = (k-1, 2j), complete; right = (k-1, 2j+1), resolved through passthrough nodes down to a stitched node or a leaf
@@ -211,13 +217,22 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitc
         for (int q = 1; q < 16; ++q) vmax = (q < nw && t16[q] > vmax) ? t16[q] : vmax;
         if (!(vmax - vmax == 0)) vmax = 0;
     }
-    // pass 2: chunk sums of exp(v - M), block cumsum
+    // pass 2: sub-chunk sums of exp(v - M), chunk sums, block cumsum
+    const int Ls = (Lc + PIT_SC - 1) / PIT_SC;
     R s = 0;
     {
         int i = (int)(p0 / N), jj = (int)(p0 - (long long)i * N);
-        for (long long p = p0; p < p1; ++p) {
-            s = s + det_exp(value(i, jj) - vmax);
-            if (++jj == N) jj = 0, ++i;
+        long long p = p0;
+#pragma unroll 1
+        for (int b = 0; b < PIT_SC; ++b) {
+            const long long pe = p0 + (long long)(b + 1) * Ls < p1 ? p0 + (long long)(b + 1) * Ls : p1;
+            R sb = 0;
+            for (; p < pe; ++p) {
+                sb = sb + det_exp(value(i, jj) - vmax);
+                if (++jj == N) jj = 0, ++i;
+            }
+            sub[b * NCH + tid] = sb;
+            s = s + sb;
         }
     }
     block_cumsum<R>(s, cs, red, tid, nw);
@@ -235,11 +250,25 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitc
             const int last_chunk = (int)((NN - 1) / Lc);
             ts = ts < last_chunk ? ts : last_chunk;
             const R pre = ts > 0 ? cs[ts - 1] : (R)0;
-            const long long q0 = (long long)ts * Lc;
-            const long long q1 = q0 + Lc < NN ? q0 + Lc : NN;
+            const long long c0 = (long long)ts * Lc;
+            const long long c1 = c0 + Lc < NN ? c0 + Lc : NN;
+            // the sub-chunk: first b whose running sum reaches r, else the last non-empty one
+            const int nsub = (int)((c1 - c0 + Ls - 1) / Ls);
+            int bsel = nsub - 1;
+            R acc = 0;
+            for (int b = 0; b < nsub; ++b) {
+                const R nacc = acc + sub[b * NCH + ts];
+                const R cvb = ts > 0 ? pre + nacc : nacc;
+                if (cvb >= r || b == nsub - 1) {
+                    bsel = b;
+                    break;
+                }
+                acc = nacc;
+            }
+            const long long q0 = c0 + (long long)bsel * Ls;
+            const long long q1 = q0 + Ls < c1 ? q0 + Ls : c1;
             long long psel = q1 - 1;
             int i = (int)(q0 / N), jj = (int)(q0 - (long long)i * N);
-            R acc = 0;
             for (long long p = q0; p < q1; ++p) {
                 acc = acc + det_exp(value(i, jj) - vmax);
                 const R cv = ts > 0 ? pre + acc : acc;
@@ -282,7 +311,7 @@ template <typename R, int D> static int run_pit(auxssm_ctx* h, const auxssm_fk_m
     const int TB = (a.N + 63) / 64 * 64;
     hipLaunchKernelGGL((k_pit_leaves<R, D>), dim3(a.T, a.C), dim3(TB), 0, h->stream, a, m);
     const int NCH = a.N <= 32 ? 64 : (a.N <= 128 ? 256 : 1024);  // part of the arithmetic contract (header)
-    const size_t lds = ((size_t)a.N * (2 * D + 2) + NCH + 48) * sizeof(R) + 64;
+    const size_t lds = ((size_t)a.N * (2 * D + 2) + NCH + 48 + (size_t)PIT_SC * NCH) * sizeof(R) + 64;
     if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_pit_stitch<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     {
         ProfScope ps(h, AUXSSM_K_PIT_STITCH);

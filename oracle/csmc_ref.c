@@ -30,6 +30,7 @@
 #include <string.h>
 
 #define MAXD 4
+#define PIT_SC 8 /* sub-chunks per chunk in the stitch of the parallel-in-time sweep (csrc/pit.hip) */
 
 /* ------------------------------------------------------------------------------------------------ */
 /* real-type generic code via the preprocessor: this file includes itself twice                          */
@@ -465,6 +466,8 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
     const long long NN = (long long)N * N;
     const int NCH = N <= 32 ? 64 : (N <= 128 ? 256 : 1024);
     const int Lc = (int)((NN + NCH - 1) / NCH);
+    const int Ls = (Lc + PIT_SC - 1) / PIT_SC;
+    REAL* sub = (REAL*)malloc(sizeof(REAL) * PIT_SC * 1024);
     REAL* mu = (REAL*)malloc(sizeof(REAL) * N * D);
     REAL* pg = (REAL*)malloc(sizeof(REAL) * N);
     REAL* cs = (REAL*)malloc(sizeof(REAL) * 1024);
@@ -490,10 +493,17 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
             REAL vmax = -INFINITY;
             for (long long p = 0; p < NN; ++p) { const REAL v = PIT_V(p / N, p % N); vmax = v > vmax ? v : vmax; }
             if (!(vmax - vmax == 0)) vmax = 0;
-            for (int c = 0; c < NCH; ++c) {
+            for (int c = 0; c < NCH; ++c) { /* chunk = SC sub-chunks; the chunk sum is the left-to-right sum of the sub-chunk sums */
                 const long long p0 = (long long)c * Lc, p1 = p0 + Lc < NN ? p0 + Lc : NN;
                 REAL s = 0;
-                for (long long p = p0; p < p1; ++p) s = s + EXP(PIT_V(p / N, p % N) - vmax);
+                long long p = p0;
+                for (int b = 0; b < PIT_SC; ++b) {
+                    const long long pe = p0 + (long long)(b + 1) * Ls < p1 ? p0 + (long long)(b + 1) * Ls : p1;
+                    REAL sb = 0;
+                    for (; p < pe; ++p) sb = sb + EXP(PIT_V(p / N, p % N) - vmax);
+                    sub[(size_t)b * NCH + c] = sb;
+                    s = s + sb;
+                }
                 ss[c] = s;
             }
             SUF(cumsum)(ss, NCH, cs);
@@ -506,9 +516,18 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
                     int ts = SUF(lower_bound)(cs, NCH, r);
                     ts = ts < last_chunk ? ts : last_chunk;
                     const REAL pre = ts > 0 ? cs[ts - 1] : (REAL)0;
-                    const long long q0 = (long long)ts * Lc, q1 = q0 + Lc < NN ? q0 + Lc : NN;
-                    long long psel = q1 - 1;
+                    const long long c0 = (long long)ts * Lc, c1 = c0 + Lc < NN ? c0 + Lc : NN;
+                    const int nsub = (int)((c1 - c0 + Ls - 1) / Ls);
+                    int bsel = nsub - 1;
                     REAL acc = 0;
+                    for (int b = 0; b < nsub; ++b) {
+                        const REAL nacc = acc + sub[(size_t)b * NCH + ts];
+                        const REAL cvb = ts > 0 ? pre + nacc : nacc;
+                        if (cvb >= r || b == nsub - 1) { bsel = b; break; }
+                        acc = nacc;
+                    }
+                    const long long q0 = c0 + (long long)bsel * Ls, q1 = q0 + Ls < c1 ? q0 + Ls : c1;
+                    long long psel = q1 - 1;
                     for (long long p = q0; p < q1; ++p) {
                         acc = acc + EXP(PIT_V(p / N, p % N) - vmax);
                         const REAL cv = ts > 0 ? pre + acc : acc;
@@ -540,7 +559,7 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
         anc[t] = org[(size_t)t * N];
         for (int q = 0; q < D; ++q) x[t * D + q] = xs[((size_t)t * N) * D + q];
     }
-    free(xs); free(xt); free(lw); free(org); free(ot); free(mu); free(pg); free(cs); free(ss); free(li); free(ri);
+    free(xs); free(xt); free(lw); free(org); free(ot); free(mu); free(pg); free(cs); free(ss); free(li); free(ri); free(sub);
     return 0;
 }
 
