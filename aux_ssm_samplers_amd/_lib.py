@@ -97,7 +97,7 @@ def load():
         "auxssm_stats_update": ([vp, i32, i64, i64, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_accept_update": ([vp, i32, C.c_int32, C.c_int32, i64, dbl, vp, vp, vp], C.c_int),
         "auxssm_delta_adapt": ([vp, i32, C.c_int32, C.c_int32, vp, dbl, dbl, dbl, dbl, vp, vp], C.c_int),
-        "auxssm_lorenz_theta_update": ([vp, i32, C.c_int32, C.c_int32, vp, dbl, dbl, vp, vp, vp], C.c_int),
+        "auxssm_lorenz_theta_update": ([vp, i32, C.c_int32, C.c_int32, i32, vp, dbl, dbl, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
     }
@@ -212,11 +212,14 @@ class Handle:
                                           float(min_delta), float(max_delta), delta.ptr,
                                           sqrt_half_delta.ptr if sqrt_half_delta is not None else None))
 
-    def lorenz_theta_update(self, x, sigma_theta, sigma_x, eps, par, mean_chol=None):
-        """x (C, T, 3), eps (C, 3), par (C, 4) DeviceArrays"""
-        Cn, T, _ = x.shape
-        check(self.lib.auxssm_lorenz_theta_update(self.h, dtype_code(x.dtype), Cn, T, x.ptr, float(sigma_theta), float(sigma_x), eps.ptr,
-                                                  par.ptr, mean_chol.ptr if mean_chol is not None else None))
+    def lorenz_theta_update(self, x, sigma_theta, sigma_x, eps, par, mean_chol=None, layout=LAYOUT_DENSE):
+        """x (C, T, 3) [dense] or (T, 3, C) [chain-minor], eps (C, 3), par (C, 4) DeviceArrays"""
+        if layout == LAYOUT_CHAIN_MINOR:
+            T, _, Cn = x.shape
+        else:
+            Cn, T, _ = x.shape
+        check(self.lib.auxssm_lorenz_theta_update(self.h, dtype_code(x.dtype), Cn, T, int(layout), x.ptr, float(sigma_theta), float(sigma_x),
+                                                  eps.ptr, par.ptr, mean_chol.ptr if mean_chol is not None else None))
 
     # ---- RNG fill ----
     def rng_normal(self, key, stream, shape, dtype):

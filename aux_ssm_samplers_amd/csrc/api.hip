@@ -743,123 +743,39 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
 // analytic Jacobian in place of jacfwd:  F_t = I + dt J(x_t),  b_t = mean(x_t) - F_t x_t,  Q = model Qs;
 // observations_factory = the auxiliary observations concatenated with the real ones (as LG_CONCAT);
 // log_likelihood_fn(x) = log N(x_0; m0, P0) + sum_t log N(x_{t+1}; mean(x_t), Q) + nansum_t log N(y_t; H_t x_t + c_t, R_t).
-template <typename R> AX_HD void lorenz_mean(const R* th, R dt, const R* x, R* mu) {
-    mu[0] = x[0] + dt * (th[0] * (x[1] - x[0]));
-    mu[1] = x[1] + dt * (th[1] * x[0] - x[1] - x[0] * x[2]);
-    mu[2] = x[2] + dt * (x[0] * x[1] - th[2] * x[2]);
-}
 template <typename R>
-__global__ void k_lorenz_dyn(int C, int T, const R* __restrict__ par, long long psc, const R* __restrict__ xlin, R* __restrict__ Fs,
+__global__ void k_lorenz_dyn(int C, int T, int cfast, const R* __restrict__ par, long long psc, const R* __restrict__ xlin, R* __restrict__ Fs,
                              R* __restrict__ bs) {
+    // one thread per (chain, transition); dense: x (C, T, 3), Fs (C, n, 9), bs (C, n, 3); chain-minor: x (T, 3, C), Fs (n, 9, C), bs (n, 3, C)
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int n = T - 1;
     if (g >= (long long)C * n) return;
-    const long long c = g / n, i = g % n;
+    const long long c = cfast ? g % C : g / n, i = cfast ? g / C : g % n;
     par += c * psc;  // per-chain theta (a Gibbs sampler over (x, theta) keeps one theta per chain)
     const R th[3] = {par[0], par[1], par[2]};
     const R dt = par[3];
-    const R* x = xlin + (c * T + i) * 3;
-    const R J[9] = {-th[0], th[0], 0, th[1] - x[2], (R)-1, -x[0], x[1], x[0], -th[2]};
+    const long long xs_ = cfast ? C : 1;
+    const R* xq = xlin + (cfast ? i * 3 * (long long)C + c : (c * T + i) * 3);
+    const R x[3] = {xq[0], xq[xs_], xq[2 * xs_]};
     R F[9], mu[3];
-    for (int k = 0; k < 9; ++k) F[k] = ((k / 3 == k % 3) ? (R)1 : (R)0) + dt * J[k];
+    lorenz_lin_F<R>(th, dt, x, F);
     lorenz_mean<R>(th, dt, x, mu);
-    R* Fo = Fs + g * 9;
-    R* bo = bs + g * 3;
-    for (int k = 0; k < 9; ++k) Fo[k] = F[k];
-    for (int r = 0; r < 3; ++r) bo[r] = mu[r] - (F[r * 3] * x[0] + F[r * 3 + 1] * x[1] + F[r * 3 + 2] * x[2]);
-}
-// per (chain, tile of 256 time steps): partial sums of target(xp), target(x), corr.  part [3][C][ntile]; k_sum_tiles finishes
-template <typename R, int PO>
-__global__ void __launch_bounds__(256) k_lorenz_terms(int C, int T, int ntile, R delta, const R* __restrict__ par, long long psc, Arr m0, Arr P0,
-                                                      Arr Qs, Arr Hs, Arr Rs, Arr cs, Arr yobs, const R* __restrict__ x,
-                                                      const R* __restrict__ xp, const R* __restrict__ u, R* __restrict__ part) {
-    __shared__ R sh[256];
-    const int tile = blockIdx.x, c = blockIdx.y, tid = threadIdx.x;
-    par += (long long)c * psc;
-    const R th[3] = {par[0], par[1], par[2]};
-    const R dt = par[3];
-    R acc[3] = {0, 0, 0};
-    const long long t = (long long)tile * 256 + tid;
-    if (t < T) {
-        const R* xa = xp + ((long long)c * T + t) * 3;
-        const R* xb = x + ((long long)c * T + t) * 3;
-        const R* uu = u + ((long long)c * T + t) * 3;
-        R tp = 0, tx = 0;
-        R Hm[PO * 3], cv_[PO], yv[PO], Rm[PO * PO];
-        rd<R, PO * 3>(Hs, 0, t, 0, Hm);
-        rd<R, PO>(cs, 0, t, 0, cv_);
-        rd<R, PO>(yobs, 0, t, 0, yv);
-        rd_upper<R, PO>(Rs, 0, t, 0, Rm);
-        R r1[PO], r2[PO];
-        for (int k = 0; k < PO; ++k) {
-            R p1 = cv_[k], p2 = cv_[k];
-            for (int j = 0; j < 3; ++j) p1 += Hm[k * 3 + j] * xa[j], p2 += Hm[k * 3 + j] * xb[j];
-            r1[k] = yv[k] - p1;
-            r2[k] = yv[k] - p2;
-        }
-        R o1, o2;
-        gauss_logpdf2<R, PO>(r1, r2, Rm, nullptr, o1, o2);  // NaN steps -> 0 (the reference's nansum)
-        tp += o1;
-        tx += o2;
-        R d1[3], d2[3], cov[9];
-        if (t == 0) {
-            R m[3];
-            rd<R, 3>(m0, 0, 0, 0, m);
-            rd<R, 9>(P0, 0, 0, 0, cov);
-            for (int k = 0; k < 3; ++k) d1[k] = xa[k] - m[k], d2[k] = xb[k] - m[k];
-        } else {
-            R m1[3], m2[3];
-            lorenz_mean<R>(th, dt, xa - 3, m1);
-            lorenz_mean<R>(th, dt, xb - 3, m2);
-            rd<R, 9>(Qs, 0, t - 1, 0, cov);
-            for (int k = 0; k < 3; ++k) d1[k] = xa[k] - m1[k], d2[k] = xb[k] - m2[k];
-        }
-        gauss_logpdf2<R, 3>(d1, d2, cov, nullptr, o1, o2);
-        tp += o1;
-        tx += o2;
-        R cr = 0;
-        for (int k = 0; k < 3; ++k) {
-            const R e1 = xa[k] - uu[k], e2 = xb[k] - uu[k];
-            cr += (e1 * e1 - e2 * e2) / delta;
-        }
-        acc[0] = tp;
-        acc[1] = tx;
-        acc[2] = cr;
-    }
-    for (int q = 0; q < 3; ++q) {
-        sh[tid] = acc[q];
-        __syncthreads();
-        for (int off = 128; off > 0; off >>= 1) {
-            if (tid < off) sh[tid] += sh[tid + off];
-            __syncthreads();
-        }
-        if (tid == 0) part[((long long)q * C + c) * ntile + tile] = sh[0];
-        __syncthreads();
-    }
-}
-// out[r] = sum_tile part[r][tile], one workgroup per row, fixed order
-template <typename R> __global__ void __launch_bounds__(256) k_sum_tiles(int ntile, const R* __restrict__ part, R* __restrict__ out) {
-    __shared__ R sh[256];
-    const int r = blockIdx.x, tid = threadIdx.x;
-    R v = 0;
-    for (int k = tid; k < ntile; k += 256) v += part[(long long)r * ntile + k];
-    sh[tid] = v;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) sh[tid] += sh[tid + off];
-        __syncthreads();
-    }
-    if (tid == 0) out[r] = sh[0];
+    R* Fo = Fs + (cfast ? i * 9 * (long long)C + c : g * 9);
+    R* bo = bs + (cfast ? i * 3 * (long long)C + c : g * 3);
+    for (int k = 0; k < 9; ++k) Fo[k * xs_] = F[k];
+    for (int r = 0; r < 3; ++r) bo[r * xs_] = mu[r] - (F[r * 3] * x[0] + F[r * 3 + 1] * x[1] + F[r * 3 + 2] * x[2]);
 }
 
 template <typename R>
 static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs, double delta,
-                        int parallel, int nan_policy, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
+                        int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
                         int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = 3, PO = dims->dy, P = D + PO;
     const KalmanEntry* ke = need_kalman(dtype, D, P);
     const SampleEntry* se = sample_entry(dtype, D);
-    if (!ke || !se) return AUXSSM_ERR_UNSUPPORTED;
+    const SweepLogpdfEntry* sl = sweep_logpdf_entry(dtype, D, PO);
+    if (!ke || !se || !sl || !sl->lorenz) return AUXSSM_ERR_UNSUPPORTED;
+    const int cm = layout == AUXSSM_LAYOUT_CHAIN_MINOR ? 1 : 0;  // state, noise and every per-chain buffer (T, ., C): lanes <-> chains
     const KDims kd{C, T, 1};
     const size_t sR = sizeof(R), CT = (size_t)C * T, n = (size_t)(T > 1 ? T - 1 : 1);
     size_t need = 0;
@@ -870,18 +786,15 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     add(CT * D * D * sR);                                     // Ps
     add(2 * (size_t)C * n * (9 + 3) * sR + 1024);             // Fs1, bs1, Fs2, bs2
     add((size_t)16 * C * sR + 2048);
-    const int ntile = (T + 255) / 256;
-    add((size_t)3 * C * ntile * sR);
     add(ke->filter_ws(h, kd, parallel));
     add(se->sample_ws(h, kd, parallel));
-    add(ke->logpdf_ws(h, kd));
+    add(sl->ws(h, kd));
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     R* ysc = (R*)ws_take(h, CT * P * sR);
     R* Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
     R* Rc = (R*)ws_take(h, (size_t)T * P * P * sR);
     R* cc = (R*)ws_take(h, (size_t)T * P * sR);
-    R* tpart = (R*)ws_take(h, (size_t)3 * C * ntile * sR);
     R* u = (R*)ws_take(h, CT * D * sR);
     R* ms = (R*)ws_take(h, CT * D * sR);
     R* xp = (R*)ws_take(h, CT * D * sR);
@@ -891,19 +804,22 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     R* Fs2 = (R*)ws_take(h, (size_t)C * n * 9 * sR);
     R* bs2 = (R*)ws_take(h, (size_t)C * n * 3 * sR);
     R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
-    if (!ysc || !Hc || !Rc || !cc || !tpart || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc) return AUXSSM_ERR_NOMEM;
-    R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
+    if (!ysc || !Hc || !Rc || !cc || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc) return AUXSSM_ERR_NOMEM;
+    R* ell1 = sc; R* ell2 = sc + C; R* sums = sc + 2 * C;
     const size_t mark = h->ws_off;
     const R* par = (const R*)model->Fs.ptr;  // [theta1, theta2, theta3, dt], chain stride model->Fs.sc (0 = one theta for all chains)
     const long long psc = model->Fs.sc;
-    const Arr xA = dense_arr(x, kd, D), xpA = dense_arr(xp, kd, D), uA = dense_arr(u, kd, D), yscA = dense_arr(ysc, kd, P);
+    auto arr = [&](const void* p, long long rec) { return cm ? cm_arr(p, kd, rec) : dense_arr(p, kd, rec); };
+    const Arr xA = arr(x, D), xpA = arr(xp, D), uA = arr(u, D), yscA = arr(ysc, P);
+    // per-chain transition arrays have n = T - 1 rows: same strides as a T-row array of that record size
+    const Arr F1A = arr(Fs1, 9), b1A = arr(bs1, 3), F2A = arr(Fs2, 9), b2A = arr(bs2, 3);
     {
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs),
                            cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
         const long long n2 = (long long)CT * P;
         hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, T, D, PO, xA,
-                           dense_arr(eps_aux, kd, D), (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, 0);
+                           arr(eps_aux, D), (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, cm);
     }
     const unsigned gd = (unsigned)(((long long)C * (T - 1) + 255) / 256);
     auxssm_lgssm g1 = *model;
@@ -919,53 +835,61 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     dc.dy = P;
     dc.B = 1;
     const auxssm_arr yd{ysc, (int64_t)T * P, (int64_t)P, 0};
+    auto set_views = [&](FilterArgs& fa, const Arr& FA, const Arr& bA) {
+        fa.ys = yscA;
+        fa.ms = arr(ms, D);
+        fa.Ps = arr(Ps, (long long)D * D);
+        fa.lay.cm = cm;
+        fa.pblk = D;
+        if (cm) {
+            fa.Fs = FA;
+            fa.bs = bA;
+        }
+    };
 
     // proposal: dynamics linearised at x (generic.py:80-86)
-    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, par, psc, (const R*)x, Fs1, bs1);
+    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, cm, par, psc, (const R*)x, Fs1, bs1);
     FilterArgs fa;
     fill_filter_args(fa, &dc, &g1, &yd, ms, Ps);
-    fa.pblk = D;
+    set_views(fa, F1A, b1A);
     rc = ke->filter(h, fa, parallel, ell1);
     if (rc) return rc;
     h->ws_off = mark;
     SampleArgs sa;
     sa.d = kd;
     sa.dx = D;
-    sa.Fs = cv(g1.Fs); sa.Qs = cv(model->Qs); sa.bs = cv(g1.bs);
-    sa.ms = dense_arr(ms, kd, D); sa.Ps = dense_arr(Ps, kd, (long long)D * D);
-    sa.eps = dense_arr(eps_samp, kd, D); sa.xs = xpA; sa.elem = nullptr;
-    sa.lay = ScanLayout{1, 1, 1, 1, 0, C};
+    sa.Fs = cm ? F1A : cv(g1.Fs); sa.Qs = cv(model->Qs); sa.bs = cm ? b1A : cv(g1.bs);
+    sa.ms = arr(ms, D); sa.Ps = arr(Ps, (long long)D * D);
+    sa.eps = arr(eps_samp, D); sa.xs = xpA; sa.elem = nullptr;
+    sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;
     h->ws_off = mark;
     // reverse move: dynamics linearised at x_prop (generic.py:67)
-    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, par, psc, (const R*)xp, Fs2, bs2);
+    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, cm, par, psc, (const R*)xp, Fs2, bs2);
     fill_filter_args(fa, &dc, &g2, &yd, ms, Ps);
-    fa.pblk = D;
+    set_views(fa, F2A, b2A);
     rc = ke->filter(h, fa, parallel, ell2);
     if (rc) return rc;
     h->ws_off = mark;
-    LogpdfArgs la;
-    fill_logpdf_args(la, &dc, &g1, cv(yd), xpA, nan_policy);
-    rc = ke->logpdf(h, la, j1);
-    if (rc) return rc;
-    h->ws_off = mark;
-    fill_logpdf_args(la, &dc, &g2, cv(yd), xA, nan_policy);
-    rc = ke->logpdf(h, la, j2);
-    if (rc) return rc;
-    h->ws_off = mark;
-#define AX_LORENZ_TERMS(PO_)                                                                                                              \
-    hipLaunchKernelGGL((k_lorenz_terms<R, PO_>), dim3(ntile, C), dim3(256), 0, h->stream, C, T, ntile, (R)delta, par, psc, cv(model->m0),     \
-                       cv(model->P0), cv(model->Qs), cv(model->Hs), cv(model->Rs), cv(model->cs), cv(*yobs), (const R*)x, (const R*)xp,          \
-                       (const R*)u, tpart)
-    if (PO == 1) AX_LORENZ_TERMS(1);
-    else if (PO == 2) AX_LORENZ_TERMS(2);
-    else AX_LORENZ_TERMS(3);
-#undef AX_LORENZ_TERMS
-    hipLaunchKernelGGL((k_sum_tiles<R>), dim3(3 * C), dim3(256), 0, h->stream, ntile, (const R*)tpart, terms);
-    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
-                       (const R*)ell2, (const R*)terms, (const R*)(terms + C), (const R*)(terms + 2 * C), (const R*)u_acc, accepted, (R*)logs);
-    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, 0);
+    // every log-density of the MH ratio in one pass (generic.py:88-89, :98-106); the linearised transitions are rebuilt from x / x_prop
+    {
+        SweepLogpdfArgs la;
+        la.d = kd;
+        la.dx = D; la.po = PO;
+        la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Qs = cv(model->Qs);
+        la.Fs = Arr{nullptr, 0, 0, 0, 1}; la.bs = Arr{nullptr, 0, 0, 0, 1};
+        la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
+        la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
+        la.lor_par = par; la.lor_psc = psc;
+        rc = sl->lorenz(h, la, sums);  // [5][C]: jp_prop, jp_rev, lt_prop, lt_rev, corr
+        if (rc) return rc;
+        h->ws_off = mark;
+    }
+    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)sums, (const R*)(sums + C), (const R*)ell1,
+                       (const R*)ell2, (const R*)(sums + 2 * C), (const R*)(sums + 3 * C), (const R*)(sums + 4 * C), (const R*)u_acc, accepted,
+                       (R*)logs);
+    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -1284,13 +1208,9 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
         return AUXSSM_ERR_ARG;
     }
     if (lorenz) {
-        if (layout != AUXSSM_LAYOUT_DENSE) {
-            set_error("the Lorenz sweep takes the dense (C, T, dx) layout");
-            return AUXSSM_ERR_UNSUPPORTED;
-        }
         if (dtype == AUXSSM_F32)
-            return sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
-        return sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, x, eps_aux, eps_samp, u_acc, accepted, logs);
+            return sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        return sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
     if (sv) {
         const int order = model_kind == AUXSSM_KMODEL_SV_FIRST ? 1 : 2;

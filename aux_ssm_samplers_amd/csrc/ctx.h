@@ -93,6 +93,7 @@ typedef size_t (*sweep_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);
 struct SweepLogpdfEntry {
     sweep_logpdf_fn run;
     sweep_logpdf_ws_fn ws;
+    sweep_logpdf_fn lorenz = nullptr;  // the Lorenz-63 sweep's fused pass (dx = 3 units only); same workspace as `run`
 };
 typedef int (*sv_logpdf_fn)(auxssm_ctx*, const SvLogpdfArgs&, void* out /*[5][C]*/);
 typedef size_t (*sv_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);

@@ -717,6 +717,8 @@ struct SweepLogpdfArgs {
     int nan_policy;
     int dx = 0, po = 0;  // runtime sizes (wide.hip only)
     const void* tab = nullptr;  // chain-shared parameters: per time step the Cholesky rows of Q_{t-1} and Robs_t (else null)
+    const void* lor_par = nullptr;  // Lorenz-63 sweep: rows [theta1, theta2, theta3, dt], chain stride lor_psc (Fs / bs are not read then)
+    long long lor_psc = 0;
 };
 template <typename R, int D, int PO> struct LogShared {
     static constexpr int oQ = 0, oR = CholRow<R, D>::SZ, N = CholRow<R, D>::SZ + CholRow<R, PO>::SZ;
@@ -845,6 +847,72 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_head(const Swe
     out5[2] = ob_p + pr_p;
     out5[3] = ob_x + pr_x;
     out5[4] = corr;
+}
+
+// ---- the Lorenz-63 sweep's log-densities in one pass (examples/lorenz/auxiliary_kalman.py:14-52 + kalman/generic.py:88-89, :98-106) ----
+// mean(x) = x + dt (phi_0(x) + theta * phi(x)) (model.py:10-25); its Jacobian in closed form (the reference's jacfwd, linearisation.py:11-44)
+template <typename R> AX_HD void lorenz_mean(const R* th, R dt, const R* x, R* mu) {
+    mu[0] = x[0] + dt * (th[0] * (x[1] - x[0]));
+    mu[1] = x[1] + dt * (th[1] * x[0] - x[1] - x[0] * x[2]);
+    mu[2] = x[2] + dt * (x[0] * x[1] - th[2] * x[2]);
+}
+template <typename R> AX_HD void lorenz_lin_F(const R* th, R dt, const R* x, R* F) {
+    const R J[9] = {-th[0], th[0], 0, th[1] - x[2], (R)-1, -x[0], x[1], x[0], -th[2]};
+#pragma unroll
+    for (int k = 0; k < 9; ++k) F[k] = ((k / 3 == k % 3) ? (R)1 : (R)0) + dt * J[k];
+}
+// per chain the five sums  [0] joint of the auxiliary LGSSM linearised at x, evaluated at x'   [1] the one linearised at x', evaluated at x
+//                          [2] target(x')   [3] target(x)   [4] the MH correction;  the linearised transition F_t z + b_t is rebuilt from the
+// linearisation point (F_t = I + dt J(x_t), b_t = mean(x_t) - F_t x_t), so no F / b array is read.  lanes indexed by i = t - 1.
+template <typename R, int PO> AX_HD void body_lorenz_logpdf(const SweepLogpdfArgs& a, int c, int i, bool valid, R* out5) {
+    constexpr int D = 3;
+#pragma unroll
+    for (int k = 0; k < 5; ++k) out5[k] = 0;
+    if (!valid) return;
+    const long long t = (long long)i + 1;
+    const R* par = (const R*)a.lor_par + (long long)c * a.lor_psc;
+    const R th[3] = {par[0], par[1], par[2]};
+    const R dt = par[3];
+    R x[D], xp[D], u[D], xq[D], xpq[D], H[PO * D], cv[PO], y[PO], Rm[PO * PO], Q[D * D];
+    rd<R, D>(a.x, c, t, 0, x);
+    rd<R, D>(a.xp, c, t, 0, xp);
+    rd<R, D>(a.u, c, t, 0, u);
+    rd<R, D>(a.x, c, i, 0, xq);
+    rd<R, D>(a.xp, c, i, 0, xpq);
+    rd<R, PO * D>(a.Hs, c, t, 0, H);
+    rd<R, PO>(a.cs, c, t, 0, cv);
+    rd<R, PO>(a.ys, c, t, 0, y);
+    rd_upper<R, PO>(a.Rs, c, t, 0, Rm);
+    rd<R, D * D>(a.Qs, c, i, 0, Q);
+    R cc_p, cc_x, ob_p, ob_x, corr;
+    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
+    R mx[D], mp[D], F1[D * D], F2[D * D], dl[D], f1[D], f2[D];
+    lorenz_mean<R>(th, dt, xq, mx);
+    lorenz_mean<R>(th, dt, xpq, mp);
+    lorenz_lin_F<R>(th, dt, xq, F1);
+    lorenz_lin_F<R>(th, dt, xpq, F2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) dl[k] = xpq[k] - xq[k];
+    mv<R, D, D>(F1, dl, f1);
+    mv<R, D, D>(F2, dl, f2);
+    R r1[D], r2[D], rp[D], rx[D], l1, l2, tp, tx;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        r1[k] = xp[k] - (mx[k] + f1[k]);  // x'_t - (F1 x'_{t-1} + b1)
+        r2[k] = x[k] - (mp[k] - f2[k]);   // x_t  - (F2 x_{t-1}  + b2)
+        rp[k] = xp[k] - mp[k];
+        rx[k] = x[k] - mx[k];
+    }
+    gauss_logpdf2<R, D>(r1, r2, Q, nullptr, l1, l2);
+    gauss_logpdf2<R, D>(rp, rx, Q, nullptr, tp, tx);
+    out5[0] = cc_p + l1;
+    out5[1] = cc_x + l2;
+    out5[2] = ob_p + tp;
+    out5[3] = ob_x + tx;
+    out5[4] = corr;
+}
+template <typename R, int PO> AX_HD void body_lorenz_logpdf_head(const SweepLogpdfArgs& a, int c, R* out5) {
+    body_sweep_logpdf_head<R, 3, PO>(a, c, out5);  // at t = 0 the linear-Gaussian and the Lorenz models agree: N(m0, P0) + observations
 }
 
 // ---- the stochastic-volatility sweep's log-densities in one pass (examples/stochastic_volatility/auxiliary_kalman.py:22-48 +

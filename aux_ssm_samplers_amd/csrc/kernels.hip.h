@@ -294,6 +294,45 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArg
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
 
+// the Lorenz sweep's five per-chain sums (kalman_bodies.h::body_lorenz_logpdf); part layout [5][C][ntile]
+template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_lorenz_logpdf(SweepLogpdfArgs a, R* __restrict__ part, int ntile) {
+    __shared__ R sh[TB_ELEM];
+    const int C = a.d.C;
+    int tile, c;
+    decode_tile_seq(C, tile, c);
+    if (tile >= ntile) return;
+    const int n = a.d.T - 1;
+    const int i = tile * TB_ELEM + threadIdx.x;
+    R v[5];
+    body_lorenz_logpdf<R, PO>(a, c, i, i < n, v);
+    if (tile == 0 && threadIdx.x == 0) {
+        R h[5];
+        body_lorenz_logpdf_head<R, PO>(a, c, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += h[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const R tot = block_sum<R, TB_ELEM>(v[k], sh);
+        if (threadIdx.x == 0) part[((long long)k * C + c) * ntile + tile] = tot;
+    }
+}
+template <typename R, int PO> __global__ void __launch_bounds__(TB_CM) k_lorenz_logpdf_cm(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+    const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
+    if (!c.live) return;
+    R v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) body_lorenz_logpdf_head<R, PO>(a, c.s, v);
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) {
+        R w[5];
+        body_lorenz_logpdf<R, PO>(a, c.s, opaque_uniform(i), true, w);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
+}
+
 // the SV sweep's five per-chain sums (kalman_bodies.h::SvLogpdfArgs); part layout [5][C][ntile]
 template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_logpdf(SvLogpdfArgs a, R* __restrict__ part, int ntile) {
     __shared__ R sh[TB_ELEM];
@@ -736,6 +775,24 @@ template <typename R, int D> int run_sv_logpdf(auxssm_ctx* h, const SvLogpdfArgs
     return AUXSSM_OK;
 }
 
+// out: [5][C]; instantiated for D = 3 only (null entry otherwise)
+template <typename R, int PO> int run_lorenz_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
+    const bool cm = a.xp.se != 1;
+    const int n = a.d.T - 1, C = a.d.C;
+    const int nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
+    R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
+    ProfScope ps(h, AUXSSM_K_LOGPDF);
+    if (cm) hipLaunchKernelGGL((k_lorenz_logpdf_cm<R, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+    else hipLaunchKernelGGL((k_lorenz_logpdf<R, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
+    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+template <typename R, int D, int PO> constexpr sweep_logpdf_fn lorenz_logpdf_entry() {
+    if constexpr (D == 3 && PO <= 3) return &run_lorenz_logpdf<R, PO>;
+    else return nullptr;
+}
+
 // one instantiation unit = one (dtype, D): all P for the filter / logpdf, plus the sampler
 #define AX_KALMAN_ENTRY(R, D, P) \
     { &run_filter<R, D, P>, &filter_ws<R, D, P>, &run_logpdf<R, D, P>, &logpdf_ws<R, D, P> }
@@ -750,10 +807,10 @@ template <typename R, int D> int run_sv_logpdf(auxssm_ctx* h, const SvLogpdfArgs
         return (P >= 1 && P <= MAX_P) ? &tab[P - 1] : nullptr;                                       \
     }                                                                                                \
     const SweepLogpdfEntry* sweep_logpdf_unit_##NAME(int PO) {                                       \
-        static const SweepLogpdfEntry tab[4] = {{&run_sweep_logpdf<R, D, 1>, &sweep_logpdf_ws<R, D, 1>}, \
-                                                {&run_sweep_logpdf<R, D, 2>, &sweep_logpdf_ws<R, D, 2>}, \
-                                                {&run_sweep_logpdf<R, D, 3>, &sweep_logpdf_ws<R, D, 3>}, \
-                                                {&run_sweep_logpdf<R, D, 4>, &sweep_logpdf_ws<R, D, 4>}}; \
+        static const SweepLogpdfEntry tab[4] = {{&run_sweep_logpdf<R, D, 1>, &sweep_logpdf_ws<R, D, 1>, lorenz_logpdf_entry<R, D, 1>()}, \
+                                                {&run_sweep_logpdf<R, D, 2>, &sweep_logpdf_ws<R, D, 2>, lorenz_logpdf_entry<R, D, 2>()}, \
+                                                {&run_sweep_logpdf<R, D, 3>, &sweep_logpdf_ws<R, D, 3>, lorenz_logpdf_entry<R, D, 3>()}, \
+                                                {&run_sweep_logpdf<R, D, 4>, &sweep_logpdf_ws<R, D, 4>, lorenz_logpdf_entry<R, D, 4>()}}; \
         return (PO >= 1 && PO <= 4) ? &tab[PO - 1] : nullptr;                                        \
     }                                                                                                \
     const SampleEntry* sample_unit_##NAME() {                                                        \

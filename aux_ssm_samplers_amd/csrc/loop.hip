@@ -47,20 +47,22 @@ __global__ void k_delta_adapt(int C, int m, const R* __restrict__ window, R targ
 
 // one workgroup per chain: X = dt phi(x_t), Y = x_{t+1} - x_t - dt phi_0(x_t); sums in double whatever R is
 template <typename R>
-__global__ void __launch_bounds__(256) k_lorenz_theta(int T, const R* __restrict__ x, double sigma_theta, double sigma_x,
+__global__ void __launch_bounds__(256) k_lorenz_theta(int C, int T, int cfast, const R* __restrict__ x, double sigma_theta, double sigma_x,
                                                       const R* __restrict__ eps, R* __restrict__ par, R* __restrict__ mean_chol) {
     __shared__ double sh[6][256];
     const int c = blockIdx.x, tid = threadIdx.x;
-    const R* xc = x + (long long)c * T * 3;
+    // element (t, k) of chain c: dense (C, T, 3) or chain-minor (T, 3, C)
+    const R* xc = cfast ? x + c : x + (long long)c * T * 3;
+    const long long ks = cfast ? C : 1, ts = 3 * ks;
     R* pc = par + (long long)c * 4;
     const R dt = pc[3];
     double a[6] = {0, 0, 0, 0, 0, 0};
     for (long long t = tid; t + 1 < T; t += 256) {
-        const R x1 = xc[t * 3], x2 = xc[t * 3 + 1], x3 = xc[t * 3 + 2];
+        const R x1 = xc[t * ts], x2 = xc[t * ts + ks], x3 = xc[t * ts + 2 * ks];
         const R X[3] = {dt * (x2 - x1), dt * x1, dt * (-x3)};
         const R p0[3] = {(R)0, -x2 - x1 * x3, x1 * x2};
         for (int k = 0; k < 3; ++k) {
-            const R Y = (xc[(t + 1) * 3 + k] - xc[t * 3 + k]) - dt * p0[k];
+            const R Y = (xc[(t + 1) * ts + k * ks] - xc[t * ts + k * ks]) - dt * p0[k];
             a[k] += (double)(X[k] * X[k]);
             a[3 + k] += (double)(X[k] * Y);
         }
@@ -120,8 +122,8 @@ static int delta_adapt(auxssm_ctx* h, int C, int m, const void* win, double targ
     return AUXSSM_OK;
 }
 template <typename R>
-static int lorenz_theta(auxssm_ctx* h, int C, int T, const void* x, double sth, double sx, const void* eps, void* par, void* mc) {
-    hipLaunchKernelGGL((k_lorenz_theta<R>), dim3(C), dim3(256), 0, h->stream, T, (const R*)x, sth, sx, (const R*)eps, (R*)par, (R*)mc);
+static int lorenz_theta(auxssm_ctx* h, int C, int T, int cfast, const void* x, double sth, double sx, const void* eps, void* par, void* mc) {
+    hipLaunchKernelGGL((k_lorenz_theta<R>), dim3(C), dim3(256), 0, h->stream, C, T, cfast, (const R*)x, sth, sx, (const R*)eps, (R*)par, (R*)mc);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -202,7 +204,7 @@ int auxssm_delta_adapt(auxssm_handle h, int dtype, int32_t C, int32_t m, const v
                                : delta_adapt<double>(h, C, m, window, target, rate, min_delta, max_delta, delta, sqrt_half_delta);
 }
 
-int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T, const void* x, double sigma_theta, double sigma_x,
+int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T, int layout, const void* x, double sigma_theta, double sigma_x,
                                const void* eps, void* par, void* mean_chol) {
     AX_NEED_H(h);
     if (int rc = need_dtype(dtype)) return rc;
@@ -214,13 +216,18 @@ int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T,
         set_error("sigma_theta and sigma_x must be positive");
         return AUXSSM_ERR_ARG;
     }
+    if (layout != AUXSSM_LAYOUT_DENSE && layout != AUXSSM_LAYOUT_CHAIN_MINOR) {
+        set_error("layout must be AUXSSM_LAYOUT_DENSE (0) or AUXSSM_LAYOUT_CHAIN_MINOR (1)");
+        return AUXSSM_ERR_ARG;
+    }
     if (C == 0) return AUXSSM_OK;
     if (!x || !eps || !par) {
         set_error("x/eps/par must be non-NULL");
         return AUXSSM_ERR_ARG;
     }
-    return dtype == AUXSSM_F32 ? lorenz_theta<float>(h, C, T, x, sigma_theta, sigma_x, eps, par, mean_chol)
-                               : lorenz_theta<double>(h, C, T, x, sigma_theta, sigma_x, eps, par, mean_chol);
+    const int cf = layout == AUXSSM_LAYOUT_CHAIN_MINOR ? 1 : 0;
+    return dtype == AUXSSM_F32 ? lorenz_theta<float>(h, C, T, cf, x, sigma_theta, sigma_x, eps, par, mean_chol)
+                               : lorenz_theta<double>(h, C, T, cf, x, sigma_theta, sigma_x, eps, par, mean_chol);
 }
 
 }  // extern "C"

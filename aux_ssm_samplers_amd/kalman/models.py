@@ -157,7 +157,7 @@ class LorenzModel:
     ys (T, po) with NaN rows where nothing is observed; Hs (T, po, 3) may carry NaN rows there too (model.py:43-56).
     Pass the three bound methods to kalman.get_kernel: it runs the device sweep (model kind LORENZ63_EXT)."""
     kmodel = _lib.KMODEL_LORENZ63_EXT
-    dense_only = True
+    dense_only = False
 
     def __init__(self, ys, Hs, Rs, cs, m0, P0, theta, sigma_x, dt):
         self.yobs, self.Hobs, self.Robs, self.cobs = np.asarray(ys), np.asarray(Hs), np.asarray(Rs), np.asarray(cs)

@@ -44,7 +44,7 @@ class LorenzThetaStep:
         if self._eps is None or self._eps.handle is not handle or self._eps.shape != (chains.C, 3) or self._eps.dtype != chains.dtype:
             self._eps = handle.empty((chains.C, 3), chains.dtype)
         handle.rng_normal_into(key, 0, self._eps)
-        handle.lorenz_theta_update(chains.x, self.sigma_theta, self.model.sigma_x, self._eps, par)
+        handle.lorenz_theta_update(chains.x, self.sigma_theta, self.model.sigma_x, self._eps, par, layout=chains.layout)
 
     def theta(self, chains):
         return self.model.par_device(chains.handle, chains.dtype, chains.C).to_host()[:, :3]

@@ -152,7 +152,7 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
  *         per-chain buffer inside the sweep is [t][component][chain], so each wave access is one contiguous run and the
  *         chain-shared model parameters are wave-uniform loads; there is no transposition anywhere in the sweep.  This is the
  *         layout to use with >= 32 chains (bench.py); results are identical up to the combination tree of the scan.  LG_CONCAT and the
- *         SV factories (dx <= 4) take it; LORENZ63_EXT and the wide-state sizes (dx > 4) are dense only.
+ *         SV and LORENZ63_EXT factories (dx <= 4) take it; the wide-state sizes (dx > 4) are dense only.
  */
 typedef enum {
     AUXSSM_KMODEL_LG_CONCAT = 1,
@@ -168,7 +168,7 @@ typedef enum {
      * rebuilt at both linearisation points each sweep; observations_factory concatenates the auxiliary and the real observations as
      * LG_CONCAT does; log_likelihood_fn(x) = log N(x_0; m0, P0) + sum log N(x_{t+1}; mean(x_t), Q) + nansum_t log N(y_t; H_t x_t + c_t, R_t).
      * `model`: m0, P0, Qs as usual; Fs.ptr -> DEVICE array [theta1, theta2, theta3, dt] of `dtype`, chain stride Fs.sc (0: one theta for all chains; 4: one row per chain) (bs unused); Hs, Rs, cs = the
-     * real observation model (rows of unobserved steps may be NaN); yobs (T, dy) with NaN = missing; dx = 3, dy <= 3; dense layout. */
+     * real observation model (rows of unobserved steps may be NaN); yobs (T, dy) with NaN = missing; dx = 3, dy <= 3; dense or chain-minor layout. */
     AUXSSM_KMODEL_LORENZ63_EXT = 4
 } auxssm_kalman_model;
 typedef enum { AUXSSM_LAYOUT_DENSE = 0, AUXSSM_LAYOUT_CHAIN_MINOR = 1 } auxssm_layout;
@@ -279,7 +279,7 @@ int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t 
  *   and, if non-NULL, sqrt_half_delta (m) = sqrt(delta / 2) (the cSMC sweep's input) are DEVICE arrays of `dtype`.
  * auxssm_lorenz_theta_update: theta | x of the stochastic Lorenz-63 model (examples/lorenz/model.py:59-79: three independent conjugate
  *   linear regressions of dx - dt phi_0(x) on dt phi(x), prior N(0, sigma_theta^2)), then theta = mean + chol * eps
- *   (experiment.py:112-113).  x (C, T, 3) dense; eps (C, 3) ~ N(0, 1); par (C, 4) rows [theta1, theta2, theta3, dt]: dt is read, theta
+ *   (experiment.py:112-113).  x (C, T, 3) dense or (T, 3, C) chain-minor (`layout`, as the sweep's); eps (C, 3) ~ N(0, 1); par (C, 4) rows [theta1, theta2, theta3, dt]: dt is read, theta
  *   overwritten -- the array model->Fs points at for AUXSSM_KMODEL_LORENZ63_EXT (chain stride 4).  mean_chol (C, 6) out, may be NULL. */
 int auxssm_stats_attach(auxssm_handle h, void* sq_jump, void* mean, void* sq_mean, int64_t iter);
 int auxssm_stats_update(auxssm_handle h, int dtype, int64_t n, int64_t iter, const void* x_prev, const void* x_next, void* sq_jump,
@@ -288,8 +288,8 @@ int auxssm_accept_update(auxssm_handle h, int dtype, int32_t C, int32_t m, int64
                          void* window);
 int auxssm_delta_adapt(auxssm_handle h, int dtype, int32_t C, int32_t m, const void* window, double target, double rate, double min_delta,
                        double max_delta, void* delta, void* sqrt_half_delta);
-int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T, const void* x, double sigma_theta, double sigma_x,
-                               const void* eps, void* par, void* mean_chol);
+int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T, int layout, const void* x, double sigma_theta,
+                               double sigma_x, const void* eps, void* par, void* mean_chol);
 
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see

@@ -170,8 +170,10 @@ def test_kalman_loop_vs_oracle_loop(handle, C, chain_minor, adapt):
     npt.assert_array_equal(stats[1].to_host(), before)
 
 
-def test_lorenz_gibbs_loop_vs_oracle(handle):
-    """The (x, theta) Gibbs sampler of examples/lorenz/experiment.py:106-115 with one theta per chain, vs the oracle chain by chain."""
+@pytest.mark.parametrize("chain_minor", [False, True])
+def test_lorenz_gibbs_loop_vs_oracle(handle, chain_minor):
+    """The (x, theta) Gibbs sampler of examples/lorenz/experiment.py:106-115 with one theta per chain, vs the oracle chain by chain
+    (dense and chain-minor resident layouts: the theta step reads the state through the same layout as the sweep)."""
     from tests.test_gpu_nonlinear_kalman import lorenz_kalman_setup
     from aux_ssm_samplers_amd import random as R
     from aux_ssm_samplers_amd.kalman import get_kernel, LorenzModel
@@ -188,7 +190,7 @@ def test_lorenz_gibbs_loop_vs_oracle(handle):
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
     rng = np.random.default_rng(3)
     x0 = xtrue[None] + 0.05 * rng.standard_normal((C, T, 3))
-    chains = DeviceChains(handle, x0, chain_minor=False)
+    chains = DeviceChains(handle, x0, chain_minor=chain_minor)
     step = LorenzThetaStep(model, sth)
     key = R.PRNGKey(9)
     thetas = []

@@ -163,3 +163,41 @@ def test_lorenz_host_factory_path_equals_device_sweep():
     npt.assert_allclose(a.x, b.x, rtol=1e-8, atol=1e-9)
     npt.assert_allclose(a.log_alpha, b.log_alpha, rtol=1e-5, atol=1e-6)
     assert a.updated == b.updated
+
+
+@pytest.mark.parametrize("T,C", [(120, 33), (257, 64)])
+@pytest.mark.parametrize("per_chain_theta", [False, True])
+def test_lorenz_chain_minor_sweep_vs_oracle(T, C, per_chain_theta):
+    """>= 32 chains run the Lorenz sweep chain-minor (state (T, 3, C), lanes over chains, per-chain linearised dynamics (n, 9, C)): every 7th
+    chain vs the oracle's sweep on its own noise (and its own theta), all chains vs the dense-layout sweep."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, LorenzModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    base, xtrue = lorenz_kalman_setup(T)
+    rng = np.random.Generator(np.random.PCG64(8))
+    theta = base.theta + (0.5 * rng.standard_normal((C, 3)) if per_chain_theta else 0.0) * np.ones((C, 3))
+
+    def mk(th):
+        return LorenzModel(base.yobs, base.Hobs, base.Robs, base.cobs, base.m0, base.P0, th, base.sigma_x, base.dt)
+
+    x0 = xtrue[None] + 0.05 * rng.standard_normal((C, T, 3))
+    noise = dict(eps_aux=rng.standard_normal((C, T, 3)), eps_samp=rng.standard_normal((C, T, 3)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    outs = {}
+    for cmin in (True, False):
+        model = mk(theta if per_chain_theta else theta[0])
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        chains = DeviceChains(h, x0, chain_minor=cmin)
+        kernel(None, KalmanSampler(x=chains, updated=None), 0.02, noise=noise)
+        outs[cmin] = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    npt.assert_allclose(outs[True][0], outs[False][0], rtol=1e-8, atol=1e-9)
+    npt.assert_array_equal(outs[True][1], outs[False][1])
+    npt.assert_allclose(outs[True][2][:, 1:], outs[False][2][:, 1:], rtol=1e-8)
+    for c in range(0, C, 7):
+        mc = mk(theta[c])
+        ref = K.kalman_sweep(x0[c], 0.02, mc.dynamics_factory, mc.observations_factory, mc.log_likelihood_fn, True, eps_aux=noise["eps_aux"][c],
+                             eps_samp=noise["eps_samp"][c], u_accept=noise["u_accept"][c])
+        npt.assert_allclose(outs[True][2][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-8)
+        assert bool(outs[True][1][c]) == ref["accepted"]
+        npt.assert_allclose(outs[True][0][c], ref["x"], rtol=1e-8, atol=1e-9)
+    assert 0 < outs[True][1].sum() < C

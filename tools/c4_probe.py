@@ -17,7 +17,7 @@ T = 16384
 model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
 init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
 h = _lib.default_handle()
-ch = DeviceChains(h, np.repeat(xtrue[None], chains, axis=0).astype(np.float32), chain_minor=False)
+ch = DeviceChains(h, np.repeat(xtrue[None], chains, axis=0).astype(np.float32))
 st = KalmanSampler(x=ch, updated=None)
 keys = R.split(R.PRNGKey(1), steps + 2)
 kernel(keys[0], st, 1e-4)
