@@ -504,15 +504,18 @@ template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanB
     Full ex;
     Op::identity(ex);
     if (tid > 0) Op::load_rec(lds + (tid - 1) * Full::NPAD, ex);
+    // the exclusive prefixes inside this lane's run: only the reduced part (what the final pass reads) is carried, with the cheap
+    // "apply" form of the combine
+    Pre p;
+    Op::to_pre(ex, p);
     for (int j = j0; j < j1; ++j) {
-        Pre p;
-        Op::to_pre(ex, p);
         Op::store_pre(pre + (long long)j * Pre::NPAD, p);
         if (j + 1 < j1) {
-            Full e, o;
+            Full e;
+            Pre o;
             Op::load_rec(agg + (long long)j * Full::NPAD, e);
-            Op::combine(ex, e, o);
-            ex = o;
+            Op::apply(p, e, o);
+            p = o;
         }
     }
 }
