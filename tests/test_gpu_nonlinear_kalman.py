@@ -201,3 +201,40 @@ def test_lorenz_chain_minor_sweep_vs_oracle(T, C, per_chain_theta):
         assert bool(outs[True][1][c]) == ref["accepted"]
         npt.assert_allclose(outs[True][0][c], ref["x"], rtol=1e-8, atol=1e-9)
     assert 0 < outs[True][1].sum() < C
+
+
+@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("kind", ["sv1", "sv2", "lorenz"])
+def test_tiny_horizons_chain_minor_equals_dense(T, kind):
+    """T = 1 (no transition at all), 2, 3 in both layouts: the degenerate scans and the t = 0 head terms agree."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, SVModel, LorenzModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    C = 33
+    rng = np.random.default_rng(T)
+    if kind == "lorenz":
+        base, xtrue = lorenz_kalman_setup(max(T, 9))
+        model = LorenzModel(base.yobs[:T], base.Hobs[:T], base.Robs[:T], base.cobs[:T], base.m0, base.P0, base.theta, base.sigma_x, base.dt)
+        xtrue, d, delta = xtrue[:T], 3, 0.02
+    else:
+        y, xtrue, (m0, P0, F, Q, b) = sv_setup(max(T, 4), 2, seed=1)
+        model = SVModel(y[:T], m0, P0, F, Q, b, order=1 if kind == "sv1" else 2)
+        xtrue, d, delta = xtrue[:T], 2, 0.3
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    x0 = xtrue[None] + 0.1 * rng.standard_normal((C, T, d))
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    outs = {}
+    for cmin in (True, False):
+        chains = DeviceChains(h, x0, chain_minor=cmin)
+        kernel(None, KalmanSampler(x=chains, updated=None), delta, noise=noise)
+        outs[cmin] = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    assert np.isfinite(outs[True][2]).all()
+    npt.assert_allclose(outs[True][0], outs[False][0], rtol=1e-9, atol=1e-10)
+    npt.assert_array_equal(outs[True][1], outs[False][1])
+    npt.assert_allclose(outs[True][2], outs[False][2], rtol=1e-8, atol=1e-9)
+    ref = K.kalman_sweep(x0[0], delta, model.dynamics_factory, model.observations_factory,
+                         model.log_likelihood_fn if kind == "lorenz" else oracle_target(model), True, eps_aux=noise["eps_aux"][0],
+                         eps_samp=noise["eps_samp"][0], u_accept=noise["u_accept"][0])
+    npt.assert_allclose(outs[True][0][0], ref["x"], rtol=1e-8, atol=1e-9)
+    npt.assert_allclose(outs[True][2][0, 0], ref["log_alpha"], rtol=1e-6, atol=1e-7)
