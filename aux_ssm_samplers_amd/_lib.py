@@ -93,6 +93,7 @@ def load():
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_pit_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_systematic_resample": ([vp, i32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp], C.c_int),
         "auxssm_stats_attach": ([vp, vp, vp, vp, i64], C.c_int),
         "auxssm_stats_update": ([vp, i32, i64, i64, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_accept_update": ([vp, i32, C.c_int32, C.c_int32, i64, dbl, vp, vp, vp], C.c_int),

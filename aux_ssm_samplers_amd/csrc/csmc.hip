@@ -291,6 +291,55 @@ template <typename R> __global__ void __launch_bounds__(1024) k_normalize_resamp
     }
 }
 
+// conditional systematic resampling (resamplings.py:40-86; Chopin & Singh, Algorithm 4): M normalised weights -> N indices, index 0 kept at
+// position 0.  One workgroup per row; (U, V, W) ~ U[0,1)^3 given per row.  Same block cumsum as the multinomial path.
+template <typename R>
+__global__ void __launch_bounds__(1024) k_systematic(int M, int N, const R* __restrict__ w_in, const R* __restrict__ uvw, int32_t* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x;
+    R* c = (R*)smem;
+    R* red = c + TB;
+    int* idx = (int*)(red + 48);
+    __shared__ int nzero;
+    const long long row = blockIdx.x;
+    const R w = tid < M ? w_in[row * M + tid] : (R)0;
+    if (tid == 0) nzero = 0;
+    block_cumsum<R>(w, c, red, tid, nw);
+    const R U = uvw[row * 3], V = uvw[row * 3 + 1], W = uvw[row * 3 + 2];
+    const R tmp = (R)N * w_in[row * M];
+    const R fl = floor(tmp);
+    R uni;
+    if (tmp <= (R)1) {
+        uni = tmp * U;
+    } else {
+        const R rem = tmp - fl;
+        const R p_cond = rem * (fl + (R)1) / tmp;
+        uni = V < p_cond ? rem * U : rem + ((R)1 - rem) * U;
+    }
+    int i = 0;
+    if (tid < N) {
+        const R pos = ((R)tid + uni) / (R)N;
+        i = lower_bound<R>(c, M, pos);
+        idx[tid] = i;
+        if (i == 0) atomicAdd(&nzero, 1);
+    }
+    __syncthreads();
+    if (tid < N) {
+        const int nz = nzero;
+        int o = i;
+        if (nz != 1) {
+            // idx is non-decreasing, so its zeros are the first nz positions: zero_loc[k] = k for k < nz, the fill value -1 otherwise
+            const int roll_idx = (int)floor((R)nz * W);
+            const int shift = roll_idx < nz ? roll_idx : -1;
+            int src = (tid + shift) % N;
+            if (src < 0) src += N;
+            o = idx[src];
+        }
+        o = o < 0 ? 0 : (o > M - 1 ? M - 1 : o);
+        out[row * N + tid] = o;
+    }
+}
+
 template <typename R, int D>
 static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host_model, CsmcArgs& a) {
     FkDev<R> m;
@@ -348,6 +397,36 @@ extern "C" int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t row
     else
         hipLaunchKernelGGL((k_normalize_resample<double>), dim3(rows), dim3(TB), (size_t)TB * 8 + 48 * 8 + 64, h->stream, N,
                            (const double*)log_weights, (const double*)weights, (const double*)uniforms, (double*)weights_out, indices);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+extern "C" int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t rows, int32_t M, int32_t N, const void* weights, const void* uvw,
+                                          int32_t* indices) {
+    if (!h) {
+        set_error("handle is NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    AX_HIP(hipSetDevice(h->device));
+    if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
+        set_error("dtype must be 0 (f32) or 1 (f64)");
+        return AUXSSM_ERR_ARG;
+    }
+    if (rows < 1 || M < 1 || M > 1024 || N < 1 || N > 1024) {
+        set_error("need rows >= 1, 1 <= M <= 1024 weights and 1 <= N <= 1024 draws");
+        return AUXSSM_ERR_ARG;
+    }
+    if (!weights || !uvw || !indices) {
+        set_error("weights/uvw/indices must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    const int TB = ((M > N ? M : N) + 63) / 64 * 64;
+    const size_t sR = dtype == AUXSSM_F32 ? 4 : 8;
+    const size_t lds = (size_t)TB * sR + 48 * sR + (size_t)TB * 4 + 64;
+    if (dtype == AUXSSM_F32)
+        hipLaunchKernelGGL((k_systematic<float>), dim3(rows), dim3(TB), lds, h->stream, M, N, (const float*)weights, (const float*)uvw, indices);
+    else
+        hipLaunchKernelGGL((k_systematic<double>), dim3(rows), dim3(TB), lds, h->stream, M, N, (const double*)weights, (const double*)uvw, indices);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -291,6 +291,13 @@ int auxssm_delta_adapt(auxssm_handle h, int dtype, int32_t C, int32_t m, const v
 int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T, int layout, const void* x, double sigma_theta,
                                double sigma_x, const void* eps, void* par, void* mean_chol);
 
+/* auxssm_systematic_resample == systematic(key, weights, N) (_primitives/csmc/resamplings.py:40-86): conditional systematic resampling
+ * (Chopin & Singh, Algorithm 4) of `rows` independent weight vectors of length M <= 1024 into N <= 1024 indices each, index 0 kept at
+ * position 0; uvw (rows, 3) ~ U[0,1)^3 are the three uniforms of :61.  No reference kernel calls it (csmc.py uses multinomial); it
+ * completes resamplings.py.  Same cumsum order as the multinomial path (bit-exact vs oracle/csmc_ref.c::csmc_ref_systematic). */
+int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t rows, int32_t M, int32_t N, const void* weights, const void* uvw,
+                               int32_t* indices);
+
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see
  * oracle/rng_np.py for the restatement. */

@@ -98,6 +98,17 @@ def multinomial(w, un, dtype=np.float32):
     return idx
 
 
+def systematic(w, uvw, N=None, dtype=np.float32):
+    """conditional systematic resampling of one weight vector given (U, V, W) (csmc_ref.c::csmc_ref_systematic)"""
+    w = np.ascontiguousarray(w, dtype)
+    uvw = np.ascontiguousarray(uvw, dtype)
+    N = len(w) if N is None else int(N)
+    idx = np.zeros(N, np.int32)
+    fn = lib().csmc_ref_systematic_f32 if np.dtype(dtype) == np.float32 else lib().csmc_ref_systematic_f64
+    fn(_p(w), len(w), N, _p(uvw), _p(idx))
+    return idx
+
+
 def normalize(lw, dtype=np.float32):
     lw = np.ascontiguousarray(lw, dtype)
     w = np.zeros_like(lw)

@@ -570,6 +570,40 @@ void SUF(csmc_ref_multinomial)(const REAL* w, int N, const REAL* un, int32_t* id
     for (int i = 0; i < N; ++i) idx[i] = i == 0 ? 0 : SUF(choice)(c, N, un[i]);
     free(c);
 }
+/* conditional systematic resampling (resamplings.py:40-86), given the three uniforms (U, V, W) */
+void SUF(csmc_ref_systematic)(const REAL* w, int M, int N, const REAL* uvw, int32_t* out) {
+    REAL* c = (REAL*)malloc(sizeof(REAL) * M);
+    int* idx = (int*)malloc(sizeof(int) * N);
+    SUF(cumsum)(w, M, c);
+    const REAL U = uvw[0], V = uvw[1], W = uvw[2];
+    const REAL tmp = (REAL)N * w[0];
+    const REAL fl = (REAL)floor((double)tmp);
+    REAL uni;
+    if (tmp <= (REAL)1) uni = tmp * U;
+    else {
+        const REAL rem = tmp - fl;
+        const REAL p_cond = rem * (fl + (REAL)1) / tmp;
+        uni = V < p_cond ? rem * U : rem + ((REAL)1 - rem) * U;
+    }
+    int nz = 0;
+    for (int n = 0; n < N; ++n) {
+        const REAL pos = ((REAL)n + uni) / (REAL)N;
+        idx[n] = SUF(lower_bound)(c, M, pos);
+        nz += idx[n] == 0;
+    }
+    for (int n = 0; n < N; ++n) {
+        int o = idx[n];
+        if (nz != 1) {
+            const int roll_idx = (int)floor((double)((REAL)nz * W));
+            const int shift = roll_idx < nz ? roll_idx : -1; /* zero_loc[k] = k for k < nz (idx is non-decreasing), fill value -1 */
+            int src = (n + shift) % N;
+            if (src < 0) src += N;
+            o = idx[src];
+        }
+        out[n] = o < 0 ? 0 : (o > M - 1 ? M - 1 : o);
+    }
+    free(c); free(idx);
+}
 void SUF(csmc_ref_normalize)(const REAL* lw, int N, REAL* w) {
     REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
     SUF(normalize)(lw, N, w, tmp);

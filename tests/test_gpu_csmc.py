@@ -256,3 +256,30 @@ def test_lorenz63_particle_gibbs_tracks_the_truth():
     rmse = np.sqrt(np.mean((x[:, 1:] - xtrue[:, 1:]) ** 2))
     assert rmse < 3.0, rmse
     assert (anc != 0).mean() > 0.5
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("M,N", [(10, 10), (100, 100), (1000, 100), (50, 200), (1024, 1024), (1, 5)])
+def test_systematic_resampling_bit_exact_vs_oracle(dtype, M, N):
+    """conditional systematic resampling (resamplings.py:40-86) on the device vs the C oracle (itself equal to Chopin & Singh's Algorithm 4,
+    tests/test_oracle_csmc.py), rows of independent weight vectors in one launch, explicit (U, V, W)."""
+    from aux_ssm_samplers_amd._primitives.csmc.resamplings import systematic
+    rng = np.random.default_rng(M * 7 + N)
+    rows = 64
+    w = (rng.random((rows, M)) ** 2).astype(dtype)
+    w[3] = 0
+    w[3, 0] = 1                      # all the mass on the conditioned particle
+    if M > 1:
+        w[5, 0] = 0                  # a conditioned particle of zero weight
+    w = (w / w.sum(1, keepdims=True)).astype(dtype)
+    uvw = rng.random((rows, 3)).astype(dtype)
+    got = systematic(None, w, N, uvw=uvw)
+    assert got.shape == (rows, N)
+    for r in range(rows):
+        npt.assert_array_equal(got[r], O.systematic(w[r], uvw[r], N, dtype=dtype))
+    ok = np.ones(rows, bool)
+    if M > 1:
+        ok[5] = False
+    assert np.all(got[ok, 0] == 0)
+    one = systematic(7, w[0], N)     # keyed draw, single vector
+    assert one.shape == (N,) and one[0] == 0 and one.max() < M

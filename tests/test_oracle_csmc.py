@@ -131,3 +131,38 @@ def test_lorenz63_transition_and_masked_potential_in_the_oracle():
         obs = np.isfinite(y[t])
         want = np.sum(-0.5 * ((y[t][obs] - xs[t][:, obs]) / sig) ** 2 - np.log(sig) - 0.5 * np.log(2 * np.pi), axis=1)
         npt.assert_allclose(lws[t], want, rtol=1e-12, atol=1e-12)
+
+
+def _alg4(W, u, v, w, N):
+    """Conditional systematic resampling, Algorithm 4 of Chopin & Singh (doi:10.3150/14-BEJ629), written out independently (the reference's
+    own test carries the same restatement, test_resamplings.py:48-75, but counts the zeros of the result with len() of np.nonzero's tuple,
+    so it never rolls)."""
+    M = len(W)
+    nW1 = N * W[0]
+    if nW1 <= 1.0:
+        U = nW1 * u
+    else:
+        r1 = nW1 - np.floor(nW1)
+        U = r1 * u if v < r1 * (np.floor(nW1) + 1) / nW1 else r1 + (1.0 - r1) * u
+    a = np.searchsorted(np.cumsum(W), (np.arange(N) + U) / N)
+    zeros = np.flatnonzero(a == 0)
+    if len(zeros) == 1:
+        return np.clip(a, 0, M - 1)
+    return np.clip(np.roll(a, -zeros[int(len(zeros) * w)]), 0, M - 1)
+
+
+@pytest.mark.parametrize("M,N", [(10, 10), (100, 100), (1000, 100), (50, 200)])
+def test_systematic_resampling_oracle(M, N):
+    """The C oracle's conditional systematic resampling: equals Algorithm 4; position 0 keeps index 0; every particle gets floor or ceil of its
+    expected count (the defining property of systematic resampling).  (No marginal-unbiasedness check: the law is conditional on the
+    survival of particle 0, which tilts the other counts whenever N w_0 < 1.)"""
+    rng = np.random.default_rng(M + N)
+    w = rng.random(M) ** 2
+    w /= w.sum()
+    for k in range(2000):
+        uvw = rng.random(3)
+        idx = O.systematic(w, uvw, N, dtype=np.float64)
+        npt.assert_array_equal(idx, _alg4(w, *uvw, N))
+        assert idx[0] == 0 and idx.min() >= 0 and idx.max() < M
+        c = np.bincount(idx, minlength=M)
+        assert np.all(np.abs(c - N * w) < 1 + 1e-9)
