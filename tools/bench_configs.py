@@ -208,6 +208,34 @@ def pit(T=65536):
         print(json.dumps(row), flush=True)
 
 
+def c5_batched_scalar(T=8192, B=64):
+    """C5 as the reference's spatial example actually runs it (examples/spatial/model.py:103-112, auxiliary_kalman.py:18-28): d^2 = 64
+    INDEPENDENT scalar chains on the batch axis B, not one dense 64 x 64 state.  AR(1) rows of the grid model, first-order aux observations."""
+    import aux_ssm_samplers_amd._primitives.kalman as P
+    rng = np.random.default_rng(0)
+    delta = 0.1
+    f32 = np.float32
+    lg = P.LGSSM(np.zeros((B, 1), f32), np.ones((B, 1, 1), f32), np.full((T - 1, B, 1, 1), 0.9, f32), np.ones((T - 1, B, 1, 1), f32),
+                 np.zeros((T - 1, B, 1), f32), np.ones((T, B, 1, 1), f32), np.full((T, B, 1, 1), delta / 2, f32), np.zeros((T, B, 1), f32))
+    u = rng.standard_normal((T, B, 1)).astype(f32)
+    eps = rng.standard_normal((T, B, 1)).astype(f32)
+    h = _lib.default_handle()
+    for rep in range(2):
+        out = {}
+        for kid, name in ((_lib.K_FILTER_INIT, "filter_init_ms"), (_lib.K_FILTER_SCAN, "filter_scan_ms")):
+            h.prof_enable(kid, 4)
+            ms, Ps, ell = P.filtering(u, lg, True)
+            out[name] = round(h.prof_read()[1], 4)
+            h.prof_disable()
+        for kid, name in ((_lib.K_SAMPLE_INIT, "sampler_init_ms"), (_lib.K_SAMPLE_SCAN, "sampler_scan_ms")):
+            h.prof_enable(kid, 4)
+            xs = P.sampling(None, ms, Ps, lg, True, eps=eps)
+            out[name] = round(h.prof_read()[1], 4)
+            h.prof_disable()
+    print(json.dumps(dict(config=f"C5 as B = {B} independent scalar chains on the batch axis (the reference's spatial example), T={T} fp32, per-lane kernels",
+                          **out)))
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3k", "c4", "c5"]
     if "pit" in which:
@@ -222,3 +250,4 @@ if __name__ == "__main__":
         c4()
     if "c5" in which:
         c5()
+        c5_batched_scalar()
