@@ -214,7 +214,7 @@ def test_lorenz_gibbs_loop_vs_oracle(handle, chain_minor):
     assert np.abs(th[0] - th[1]).max() > 1e-3  # the chains really carry their own theta
 
 
-@pytest.mark.parametrize("backward", [False, True])
+@pytest.mark.parametrize("backward", [False, True, "pit"])
 def test_csmc_loop_statistics_and_per_step_adaptation(handle, backward):
     """cSMC chains resident on the device: the loop's moments / per-time-step acceptance equal a host recomputation from the states
     the sweeps leave (each sweep bit-exact vs the C oracle elsewhere), and delta_t follows the rule on the chain-pooled window."""
@@ -228,7 +228,10 @@ def test_csmc_loop_statistics_and_per_step_adaptation(handle, backward):
     M0 = GaussianInit(np.zeros(1), np.eye(1) * 5.0)
     Mt = LinearGaussianDynamics(0.9 * np.eye(1), np.zeros(1), np.eye(1))
     G0, Gt = SVPotential(y[0]), SVPotential(None, params=y[1:])
-    init, kernel = get_independent_kernel(M0, G0, Mt, Gt, N, backward=backward, Pt=Mt)
+    if backward == "pit":  # the parallel-in-time kernel drives the same loop
+        init, kernel = get_independent_kernel(M0, G0, Mt, Gt, N, parallel=True)
+    else:
+        init, kernel = get_independent_kernel(M0, G0, Mt, Gt, N, backward=backward, Pt=Mt)
     x0 = rng.standard_normal((C, T, 1)).astype(dtype)
     chains = CsmcChains(handle, x0)
     snaps = [x0.copy()]
