@@ -63,6 +63,7 @@ ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
     long long emin = (long long)(sqrt((double)n / 450.0) + 0.5);
     if (emin < 4) emin = 4;
     if (emin > 32) emin = 32;
+    if (E < 32) E = (4 * E + 2) / 3;  // a chip that is only just full of one-chunk lanes: slightly longer chunks win (24 sequences: E = 32 beats 24 by 9 %)
     if (E < emin) E = emin;
     if (E > 512) E = 512;
     if (const char* ev = getenv("AUXSSM_SCAN_E")) {  // tuning/debug override
