@@ -380,6 +380,141 @@ __device__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* 
     }
     __syncthreads();
 }
+// wave-wide maximum of one unsigned per lane (0 = identity) with DPP row shifts / row broadcasts (no LDS, no ds_bpermute): ~14 VALU
+__device__ __forceinline__ unsigned int wave_umax_dpp(unsigned int v) {
+    auto mx = [](unsigned int a, unsigned int b) { return a > b ? a : b; };
+    v = mx(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));  // row_shr:1
+    v = mx(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false));  // row_shr:2
+    v = mx(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, false));  // row_shr:4
+    v = mx(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, false));  // row_shr:8
+    v = mx(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    v = mx(v, (unsigned int)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+    return (unsigned int)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// The same elimination as gj_solve (same pivots: partial pivoting over the rows not yet used, deferred scaling, implicit permutation),
+// BLOCKED by NB = 16 pivots so that the per-pivot synchronisation disappears:
+//   A  every wave drops its rows' 16 panel columns into LDS;
+//   B  ONE wave (lane = row) eliminates the 64 x 16 panel in registers -- pivot search is a DPP wave reduction, pivot-row values are
+//      v_readlane broadcasts, no barrier, no LDS -- and accumulates D = T E_p - E_p (64 x 16), T = T_15 .. T_0 the block's elementary
+//      transformations, E_p the selector of its pivot rows;  T - I has non-zero columns only at the pivot rows, so for every column z of
+//      the augmented matrix  T z = z + D z[p]  with z[p] the pivot rows BEFORE the block;
+//   C  the owners publish those 16 rows, then every lane applies the rank-16 update to its 4 x 4 registers.
+// Three barriers per block of 16 pivots instead of two per pivot.  The LDS image of Z is free while Z lives in registers: the panel, D
+// and the published rows are carved from it.  Needs 32 <= n <= 64 (one panel row per lane) and nct <= 256.
+template <typename R>
+__device__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, int tid) {
+    constexpr int NRR = 4, NB = 16, PS = NB + 1;
+    const int ti = tid >> 6, tj = tid & 63;
+    R z[NRR][4];
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        const int r = ti + NWV * a;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = tj + 64 * b;
+            z[a][b] = (r < n && c < nct) ? Z[r * ld + c] : (R)0;
+        }
+    }
+    __syncthreads();  // Z is in registers: its LDS image is scratch until the write-back
+    R* panel = Z;                 // [n][PS]
+    R* Dm = panel + n * PS;       // [n][NB]
+    R* Zp = Dm + n * NB;          // [NB][nct]
+    int* pos = (int*)(Zp + NB * nct);  // [n] position of row r among the block's pivots, -1 if none
+    bool used_lane = false;       // (wave 0) row tj already served as a pivot row
+    for (int k0 = 0; k0 < n; k0 += NB) {
+        const int nb = n - k0 < NB ? n - k0 : NB;
+        const int kb = k0 >> 6, c0 = k0 & 63;
+        if (tj >= c0 && tj < c0 + nb) {
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) {
+                const int r = ti + NWV * a;
+                const R v = kb == 0 ? z[a][0] : (kb == 1 ? z[a][1] : (kb == 2 ? z[a][2] : z[a][3]));
+                if (r < n) panel[r * PS + (tj - c0)] = v;
+            }
+        }
+        __syncthreads();
+        if (ti == 0) {
+            const int r = tj;
+            const bool valid = r < n;
+            R pz[NB], g[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                pz[j] = (valid && j < nb) ? panel[r * PS + j] : (R)0;
+                g[j] = 0;
+            }
+            int mypos = -1;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                if (j < nb) {  // (uniform)
+                    const unsigned int ky = (valid && !used_lane) ? piv_key(pz[j], r) : 0u;
+                    const unsigned int best = wave_umax_dpp(ky);
+                    const int pr = 127 - (int)(best & 0x7fu);
+                    const R piv = bcast(pz[j], pr);
+                    const R inv = (R)1 / piv;
+                    const R f = r != pr ? pz[j] * inv : (R)0;
+#pragma unroll
+                    for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
+#pragma unroll
+                    for (int i = 0; i < j; ++i) g[i] -= f * bcast(g[i], pr);
+                    g[j] = -f;
+                    if (r == pr) {
+                        used_lane = true;
+                        mypos = j;
+                        pinv[pr] = inv;
+                        iperm[pr] = k0 + j;
+                    }
+                }
+            }
+            if (valid) {
+#pragma unroll
+                for (int j = 0; j < NB; ++j) Dm[r * NB + j] = g[j];
+                pos[r] = mypos;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < NRR; ++a) {
+            const int r = ti + NWV * a;
+            const int pp = r < n ? pos[r] : -1;
+            if (pp >= 0) {
+#pragma unroll
+                for (int b = 0; b < 4; ++b)
+                    if (tj + 64 * b < nct) Zp[pp * nct + tj + 64 * b] = z[a][b];
+            }
+        }
+        __syncthreads();
+        for (int j = 0; j < nb; ++j) {
+            R zk[4];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) zk[b] = (tj + 64 * b < nct) ? Zp[j * nct + tj + 64 * b] : (R)0;
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) {
+                const int r = ti + NWV * a;
+                const R dd = r < n ? Dm[r * NB + j] : (R)0;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) z[a][b] += dd * zk[b];
+            }
+        }
+        // the next block's panel writes touch `panel` only; D / Zp / pos are rewritten after its first barrier, which no wave passes
+        // before every wave has finished the update above
+    }
+    __syncthreads();
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        const int r = ti + NWV * a;
+        if (r < n) {
+            const R inv = pinv[r];
+            const int kr = iperm[r];
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const int c = tj + 64 * b;
+                if (c >= n && c < nct) Z[kr * ld + c] = z[a][b] * inv;
+            }
+        }
+    }
+    __syncthreads();
+}
 // Z = [S (n x n, symmetric positive definite, FULL storage) | RHS (n x (nct - n))] in LDS: RHS <- S^-1 RHS by Gauss-Jordan
 // elimination WITHOUT pivoting (the pivots are the squared Cholesky diagonal, so the failure test "pivot <= 0 or NaN" and
 // log|S| = sum log pivot are exactly what the Cholesky route gives), Z in registers as in gj_solve: one barrier per pivot.
@@ -387,7 +522,7 @@ __device__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* 
 // Replaces chol + trsm_l (+ trsm_lt) wherever the factor itself is not needed.  Needs n <= NWV * NRR, nct <= 256.
 // LDS scratch: rowbuf[2 (nct + 1)], piv[n] reals.  Returns ok (uniform); *half_logdet = 0.5 log|S| over the kept indices.
 template <typename R, int NRR>
-__device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid) {
+__device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free) {
     const int ti = tid >> 6, tj = tid & 63;
     R z[NRR][4];
 #pragma unroll
@@ -404,7 +539,83 @@ __device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* s
     }
     __syncthreads();
     const int rb = nct + 1;
-    for (int k = 0; k < n; ++k) {
+    // blocked elimination (the scheme of gj_solve_blk with the pivot of column k fixed to row k: no search at all): 16 pivots per three
+    // barriers; scratch carved from the LDS image of Z, which is free while Z lives in registers
+    // (z_free: the caller does not read S = Z[:, :n] again -- the unblocked path leaves it intact, this one does not)
+    const bool blocked = z_free && NRR == 4 && NWV == 16 && n >= 32 && n <= 64 &&
+                         (size_t)n * 33 * sizeof(R) + (size_t)16 * nct * sizeof(R) + 64 <= (size_t)n * ld * sizeof(R);
+    if (blocked) {
+        constexpr int NB = 16, PS = NB + 1;
+        R* panel = Z;
+        R* Dm = panel + n * PS;
+        R* Zp = Dm + n * NB;
+        for (int k0 = 0; k0 < n; k0 += NB) {
+            const int nb = n - k0 < NB ? n - k0 : NB;
+            const int kb = k0 >> 6, c0 = k0 & 63;
+            if (tj >= c0 && tj < c0 + nb) {
+#pragma unroll
+                for (int a = 0; a < NRR; ++a) {
+                    const int r = ti + NWV * a;
+                    const R v = kb == 0 ? z[a][0] : (kb == 1 ? z[a][1] : (kb == 2 ? z[a][2] : z[a][3]));
+                    if (r < n) panel[r * PS + (tj - c0)] = v;
+                }
+            }
+            __syncthreads();
+            if (ti == 0) {
+                const int r = tj;
+                const bool valid = r < n;
+                R pz[NB], g[NB];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    pz[j] = (valid && j < nb) ? panel[r * PS + j] : (R)0;
+                    g[j] = 0;
+                }
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    if (j < nb) {
+                        const int pr = k0 + j;
+                        const R pv = bcast(pz[j], pr);
+                        const R inv = (R)1 / pv;
+                        const R f = r != pr ? pz[j] * inv : (R)0;
+#pragma unroll
+                        for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
+#pragma unroll
+                        for (int i = 0; i < j; ++i) g[i] -= f * bcast(g[i], pr);
+                        g[j] = -f;
+                        if (r == pr) piv[pr] = pv;
+                    }
+                }
+                if (valid) {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j) Dm[r * NB + j] = g[j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < NRR; ++a) {
+                const int r = ti + NWV * a;
+                if (r >= k0 && r < k0 + nb) {
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+                        if (tj + 64 * b < nct) Zp[(r - k0) * nct + tj + 64 * b] = z[a][b];
+                }
+            }
+            __syncthreads();
+            for (int j = 0; j < nb; ++j) {
+                R zk[4];
+#pragma unroll
+                for (int b = 0; b < 4; ++b) zk[b] = (tj + 64 * b < nct) ? Zp[j * nct + tj + 64 * b] : (R)0;
+#pragma unroll
+                for (int a = 0; a < NRR; ++a) {
+                    const int r = ti + NWV * a;
+                    const R dd = r < n ? Dm[r * NB + j] : (R)0;
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) z[a][b] += dd * zk[b];
+                }
+            }
+        }
+    }
+    for (int k = blocked ? n : 0; k < n; ++k) {
         const int ka = k / NWV, kb = k >> 6, src = k & 63;
         R* rbuf = rowbuf + (k & 1) * rb;
         if (ti == k - ka * NWV) {  // the wave owning row k publishes it (current values) and the pivot
@@ -464,12 +675,18 @@ __device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* s
 }
 __host__ __device__ inline bool spd_fits(int n, int nct) { return n <= 8 * NWV && nct <= 256; }
 template <typename R>
-__device__ bool spd_solve(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid) {
-    if (n <= NWV * 4) return spd_solve_t<R, 4>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid);
-    return spd_solve_t<R, 8>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid);
+__device__ bool spd_solve(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free = false) {
+    if (n <= NWV * 4) return spd_solve_t<R, 4>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid, z_free);
+    return spd_solve_t<R, 8>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid, z_free);
 }
 
 template <typename R> __device__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
+    // blocked variant: one panel row per lane, and its scratch (panel, D, published rows, positions) must fit the LDS image of Z
+    if (NWV == 16 && n >= 32 && n <= 64 && nct <= 256 &&
+        (size_t)n * 33 * sizeof(R) + (size_t)16 * nct * sizeof(R) + (size_t)n * 4 + 64 <= (size_t)n * ld * sizeof(R)) {
+        gj_solve_blk<R>(Z, ld, n, nct, pinv, iperm, tid);
+        return;
+    }
     if (n <= NWV * 4) gj_solve<R, 4>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
     else if (n <= NWV * 8) gj_solve<R, 8>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
     else gj_solve<R, 128 / NWV>(Z, ld, n, nct, rowbuf, pinv, iperm, key, tid);
@@ -579,7 +796,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_t0(FilterA
         for (int j = tid & 63; j < d; j += 64) Z[i * ldz + p + j] = HP[i * ldd + j];
     __syncthreads();
     R hl;
-    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid);  // X = S^-1 HP (gain^T, :117), S^-1 yd
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);  // X = S^-1 HP (gain^T, :117), S^-1 yd
     R q = 0;
     for (int k = tid; k < p; k += NT) q += yd[k] * Z[k * ldz + p + d];
     q = block_sum<R>(q, rowbuf, tid);
@@ -680,7 +897,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_filter_init(Filte
     for (int k = tid; k < p; k += NT) rm[k] = Z[k * ldz + p + d];  // the residual y - H_ m_ - c_ itself (rm held H_ m_ so far)
     __syncthreads();
     R hl;
-    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid);
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
     {  // the element's log-scale: log N(y; H_ m_ + c_, S)
         R q = 0;
         for (int k = tid; k < p; k += NT) q += rm[k] * Z[k * ldz + p + d];
@@ -1030,7 +1247,11 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) Z[r * ldz + d + q] = F[r * ldd + q];
     __syncthreads();
-    const bool ok = spd_solve<R>(Z, ldz, d, 2 * d, nullptr, rowbuf, piv, (R*)nullptr, tid);  // S itself stays intact in Z[:, :d]
+    // (S is needed again below: kept in X, because the blocked elimination uses the LDS image of Z as scratch)
+    for (int r = tid / 64; r < d; r += NWV)
+        for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = Z[r * ldz + q];
+    __syncthreads();
+    const bool ok = spd_solve<R>(Z, ldz, d, 2 * d, nullptr, rowbuf, piv, (R*)nullptr, tid, true);
     gemm<false, true>(d, d, d, P, ldd, Z + d, ldz, G, ldd, (R)1, (R)0, tid);
     if (!ok) {
         for (int r = tid / 64; r < d; r += NWV)
@@ -1038,7 +1259,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
         __syncthreads();
     }
     // Sig = sym(P - G S G^T);  Lc = nan_to_num(chol(Sig))  (:98-104)
-    gemm<false, false>(d, d, d, G, ldd, Z, ldz, T1, ldd, (R)1, (R)0, tid);
+    gemm<false, false>(d, d, d, G, ldd, X, ldd, T1, ldd, (R)1, (R)0, tid);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = P[r * ldd + q];
     __syncthreads();
@@ -1168,7 +1389,7 @@ __device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* sk
     }
     const bool bad1 = __syncthreads_or(b1), bad2 = __syncthreads_or(b2);
     R hl;
-    const bool ok = spd_solve<R>(Z, ldz, n, nct, skip, rowbuf, piv, &hl, tid);
+    const bool ok = spd_solve<R>(Z, ldz, n, nct, skip, rowbuf, piv, &hl, tid, true);
     R q1 = 0, q2 = 0;
     for (int k = tid; k < n; k += NT) {
         q1 += r1[k] * Z[k * ldz + n];
