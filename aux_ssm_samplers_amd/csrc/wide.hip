@@ -380,6 +380,14 @@ __device__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* 
     }
     __syncthreads();
 }
+// 1 / v for the pivots of the blocked eliminations: hardware reciprocal + one Newton step (fp32: <= 1 ulp; the IEEE division sequence
+// is 11 dependent instructions on the panel wave's critical path), IEEE division in fp64
+__device__ __forceinline__ float rcp_nr(float v) {
+    const float r = __builtin_amdgcn_rcpf(v);
+    return fmaf(r, fmaf(-v, r, 1.0f), r);
+}
+__device__ __forceinline__ double rcp_nr(double v) { return 1.0 / v; }
+
 // wave-wide maximum of one unsigned per lane (0 = identity) with DPP row shifts / row broadcasts (no LDS, no ds_bpermute): ~14 VALU
 __device__ __forceinline__ unsigned int wave_umax_dpp(unsigned int v) {
     auto mx = [](unsigned int a, unsigned int b) { return a > b ? a : b; };
@@ -444,27 +452,34 @@ __device__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, 
                 g[j] = 0;
             }
             int mypos = -1;
+            R myinv = 0;
+            auto step = [&](int j) {
+                const unsigned int ky = (valid && !used_lane) ? piv_key(pz[j], r) : 0u;
+                const unsigned int best = wave_umax_dpp(ky);
+                const int pr = 127 - (int)(best & 0x7fu);
+                const R inv = rcp_nr(bcast(pz[j], pr));
+                const bool me = r == pr;
+                const R f = me ? (R)0 : pz[j] * inv;
 #pragma unroll
-            for (int j = 0; j < NB; ++j) {
-                if (j < nb) {  // (uniform)
-                    const unsigned int ky = (valid && !used_lane) ? piv_key(pz[j], r) : 0u;
-                    const unsigned int best = wave_umax_dpp(ky);
-                    const int pr = 127 - (int)(best & 0x7fu);
-                    const R piv = bcast(pz[j], pr);
-                    const R inv = (R)1 / piv;
-                    const R f = r != pr ? pz[j] * inv : (R)0;
+                for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
 #pragma unroll
-                    for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
+                for (int i = 0; i < j; ++i) g[i] -= f * bcast(g[i], pr);
+                g[j] = -f;
+                used_lane = used_lane || me;
+                mypos = me ? j : mypos;
+                myinv = me ? inv : myinv;
+            };
+            if (nb == NB) {  // full block: no per-step branches
 #pragma unroll
-                    for (int i = 0; i < j; ++i) g[i] -= f * bcast(g[i], pr);
-                    g[j] = -f;
-                    if (r == pr) {
-                        used_lane = true;
-                        mypos = j;
-                        pinv[pr] = inv;
-                        iperm[pr] = k0 + j;
-                    }
-                }
+                for (int j = 0; j < NB; ++j) step(j);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NB; ++j)
+                    if (j < nb) step(j);
+            }
+            if (valid && mypos >= 0) {  // this lane's row was a pivot of the block: its reciprocal pivot and its position
+                pinv[r] = myinv;
+                iperm[r] = k0 + mypos;
             }
             if (valid) {
 #pragma unroll
@@ -570,21 +585,29 @@ __device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* s
                     pz[j] = (valid && j < nb) ? panel[r * PS + j] : (R)0;
                     g[j] = 0;
                 }
+                R mypiv = 0;
+                auto step = [&](int j) {
+                    const int pr = k0 + j;
+                    const R pv = bcast(pz[j], pr);
+                    const R inv = rcp_nr(pv);
+                    const bool me = r == pr;
+                    const R f = me ? (R)0 : pz[j] * inv;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    if (j < nb) {
-                        const int pr = k0 + j;
-                        const R pv = bcast(pz[j], pr);
-                        const R inv = (R)1 / pv;
-                        const R f = r != pr ? pz[j] * inv : (R)0;
+                    for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
 #pragma unroll
-                        for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
+                    for (int i = 0; i < j; ++i) g[i] -= f * bcast(g[i], pr);
+                    g[j] = -f;
+                    mypiv = me ? pv : mypiv;
+                };
+                if (nb == NB) {
 #pragma unroll
-                        for (int i = 0; i < j; ++i) g[i] -= f * bcast(g[i], pr);
-                        g[j] = -f;
-                        if (r == pr) piv[pr] = pv;
-                    }
+                    for (int j = 0; j < NB; ++j) step(j);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NB; ++j)
+                        if (j < nb) step(j);
                 }
+                if (valid && r >= k0 && r < k0 + nb) piv[r] = mypiv;
                 if (valid) {
 #pragma unroll
                     for (int j = 0; j < NB; ++j) Dm[r * NB + j] = g[j];
