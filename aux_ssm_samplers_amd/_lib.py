@@ -99,6 +99,7 @@ def load():
         "auxssm_accept_update": ([vp, i32, C.c_int32, C.c_int32, i64, dbl, vp, vp, vp], C.c_int),
         "auxssm_delta_adapt": ([vp, i32, C.c_int32, C.c_int32, vp, dbl, dbl, dbl, dbl, vp, vp], C.c_int),
         "auxssm_lorenz_theta_update": ([vp, i32, C.c_int32, C.c_int32, i32, vp, dbl, dbl, vp, vp, vp], C.c_int),
+        "auxssm_kalman_draw": ([vp, i32, P(u32), i64, i64, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
     }
@@ -230,6 +231,11 @@ class Handle:
 
     def rng_normal_into(self, key, stream, out):
         check(self.lib.auxssm_rng_normal(self.h, dtype_code(out.dtype), int(key[0]), int(key[1]), stream, out.size, out.ptr))
+
+    def kalman_draw(self, k_aux, k_samp, k_acc, eps_aux, eps_samp, u_acc):
+        """the three noise fills of one Kalman sweep in one launch (same values as rng_normal_into x2 + rng_uniform_into, stream 0)"""
+        keys = (C.c_uint32 * 6)(int(k_aux[0]), int(k_aux[1]), int(k_samp[0]), int(k_samp[1]), int(k_acc[0]), int(k_acc[1]))
+        check(self.lib.auxssm_kalman_draw(self.h, dtype_code(eps_aux.dtype), keys, eps_aux.size, u_acc.size, eps_aux.ptr, eps_samp.ptr, u_acc.ptr))
 
     def rng_uniform_into(self, key, stream, out):
         check(self.lib.auxssm_rng_uniform(self.h, dtype_code(out.dtype), int(key[0]), int(key[1]), stream, out.size, out.ptr))

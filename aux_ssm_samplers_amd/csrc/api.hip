@@ -917,6 +917,34 @@ template <typename R> __global__ void k_rng_normal(uint32_t k0, uint32_t k1, uin
     if (2 * i + 1 < n) out[2 * i + 1] = z1;
 }
 
+// the three noise fills of one Kalman sweep in one launch: the same values as auxssm_rng_normal (keys a, b; stream 0; n each) and
+// auxssm_rng_uniform (key c; stream 0; nu) -- workgroups [0, g1) fill eps_aux, [g1, 2 g1) eps_samp, the rest u_acc
+template <typename R>
+__global__ void k_rng_sweep(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t c0, uint32_t c1, long long n, long long nu, unsigned g1,
+                            R* eps_aux, R* eps_samp, R* u_acc) {
+    const unsigned blk = blockIdx.x;
+    if (blk < 2 * g1) {
+        const bool second = blk >= g1;
+        const long long i = (long long)(second ? blk - g1 : blk) * blockDim.x + threadIdx.x;
+        if (2 * i >= n) return;
+        uint32_t x0, x1;
+        stream_counter(0, (unsigned long long)i, x0, x1);
+        threefry2x32(second ? b0 : a0, second ? b1 : a1, x0, x1);
+        R z0, z1;
+        bits_to_normal2<R>(x0, x1, z0, z1);
+        R* out = second ? eps_samp : eps_aux;
+        out[2 * i] = z0;
+        if (2 * i + 1 < n) out[2 * i + 1] = z1;
+    } else {
+        const long long i = (long long)(blk - 2 * g1) * blockDim.x + threadIdx.x;
+        if (2 * i >= nu) return;
+        R u0, u1;
+        stream_uniform2<R>(c0, c1, 0, (unsigned long long)i, u0, u1);
+        u_acc[2 * i] = u0;
+        if (2 * i + 1 < nu) u_acc[2 * i + 1] = u1;
+    }
+}
+
 }  // namespace ax
 
 using namespace ax;
@@ -1242,6 +1270,24 @@ static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32
         if (normal) hipLaunchKernelGGL((k_rng_normal<double>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
         else hipLaunchKernelGGL((k_rng_uniform<double>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (double*)out);
     }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+int auxssm_kalman_draw(auxssm_handle h, int dtype, const uint32_t* keys, int64_t n, int64_t nu, void* eps_aux, void* eps_samp, void* u_acc) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype))) return rc;
+    if (!keys || n < 1 || nu < 1 || !eps_aux || !eps_samp || !u_acc) {
+        set_error("keys/eps_aux/eps_samp/u_acc must be non-NULL and n, nu >= 1");
+        return AUXSSM_ERR_ARG;
+    }
+    const unsigned g1 = (unsigned)(((n + 1) / 2 + 255) / 256), g2 = (unsigned)(((nu + 1) / 2 + 255) / 256);
+    if (dtype == AUXSSM_F32)
+        hipLaunchKernelGGL((k_rng_sweep<float>), dim3(2 * g1 + g2), dim3(256), 0, h->stream, keys[0], keys[1], keys[2], keys[3], keys[4], keys[5],
+                           (long long)n, (long long)nu, g1, (float*)eps_aux, (float*)eps_samp, (float*)u_acc);
+    else
+        hipLaunchKernelGGL((k_rng_sweep<double>), dim3(2 * g1 + g2), dim3(256), 0, h->stream, keys[0], keys[1], keys[2], keys[3], keys[4], keys[5],
+                           (long long)n, (long long)nu, g1, (double*)eps_aux, (double*)eps_samp, (double*)u_acc);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

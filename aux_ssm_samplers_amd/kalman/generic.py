@@ -155,9 +155,7 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
 
     def draw(handle, key, chains):
         k_aux, k_samp, k_acc = _random.split(key, 3)
-        handle.rng_normal_into(k_aux, 0, chains.eps_aux)
-        handle.rng_normal_into(k_samp, 0, chains.eps_samp)
-        handle.rng_uniform_into(k_acc, 0, chains.u_acc)
+        handle.kalman_draw(k_aux, k_samp, k_acc, chains.eps_aux, chains.eps_samp, chains.u_acc)  # one launch, the values of the three fills
         return chains.eps_aux, chains.eps_samp, chains.u_acc
 
     def kernel(key, state, delta, noise=None):

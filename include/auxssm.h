@@ -302,6 +302,9 @@ int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t rows, int32_t
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see
  * oracle/rng_np.py for the restatement. */
 int auxssm_rng_normal(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);
+/* the noise of one auxssm_kalman_sweep in ONE launch: keys = {aux0, aux1, samp0, samp1, acc0, acc1} (the three children of the sweep's key,
+ * kalman/generic.py:58); eps_aux, eps_samp (n) <- auxssm_rng_normal(key, stream 0), u_acc (nu) <- auxssm_rng_uniform(key, stream 0): the same values. */
+int auxssm_kalman_draw(auxssm_handle h, int dtype, const uint32_t* keys, int64_t n, int64_t nu, void* eps_aux, void* eps_samp, void* u_acc);
 int auxssm_rng_uniform(auxssm_handle h, int dtype, uint32_t key0, uint32_t key1, uint32_t stream, int64_t n, void* out);
 
 #ifdef __cplusplus

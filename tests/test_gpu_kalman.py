@@ -347,3 +347,17 @@ def test_shared_model_mode_equals_general_path(dtype, nan_policy):
     assert same.mean() > (0.999 if dtype == np.float64 else 0.9)
     npt.assert_allclose(res[1][0][same], res[0][0][same], **tol)
     assert np.all(np.isfinite(res[1][0]))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n,nu", [(1, 1), (7, 3), (4096, 64), (100001, 257)])
+def test_fused_sweep_noise_draw_equals_the_three_fills(dtype, n, nu):
+    """auxssm_kalman_draw (one launch) == auxssm_rng_normal x 2 + auxssm_rng_uniform (stream 0) on the three child keys, bit for bit."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    h = _lib.default_handle()
+    ka, ks, kc = R.split(R.PRNGKey(n + nu), 3)
+    ea, es, ua = h.empty((n,), dtype), h.empty((n,), dtype), h.empty((nu,), dtype)
+    h.kalman_draw(ka, ks, kc, ea, es, ua)
+    npt.assert_array_equal(ea.to_host(), h.rng_normal(ka, 0, (n,), dtype).to_host())
+    npt.assert_array_equal(es.to_host(), h.rng_normal(ks, 0, (n,), dtype).to_host())
+    npt.assert_array_equal(ua.to_host(), h.rng_uniform(kc, 0, (nu,), dtype).to_host())
