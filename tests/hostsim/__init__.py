@@ -131,3 +131,22 @@ def sv_logpdf(lg5, yobs, x, xp, u, ys1, ys2, R1, R2, delta, chain_minor=False, d
                             out.ctypes.data_as(C.c_void_p))
     assert rc == 0, rc
     return out
+
+
+def lorenz_logpdf(lg, yobs, x, xp, u, par, delta, nan_policy=0, chain_minor=False, dtype=np.float64):
+    """The Lorenz sweep's fused log-density pass (csrc/kalman_bodies.h::body_lorenz_logpdf) on the host: x, xp, u (C, T, 3); par (C, 4) rows
+    [theta, dt] or (4,); lg = (m0, P0, Fs*, Qs, bs*, Hs, Rs, cs) with the REAL observation model (Fs / bs unused).  Returns (5, C)."""
+    x = np.asarray(x)
+    C_, T, _ = x.shape
+    po = np.shape(yobs)[-1]
+    desc = _layout.describe_lgssm(list(lg), 1, T, 1, 3, po, False, dtype, False)
+    g, keep = _garr(desc)
+    cv = lambda a: np.ascontiguousarray(a, dtype)
+    yo, xx, xxp, uu, pp = cv(yobs), cv(x), cv(xp), cv(u), cv(par)
+    psc = 4 if pp.ndim == 2 and pp.shape[0] > 1 else 0
+    out = np.empty((5, C_), dtype)
+    ptr = lambda a: a.ctypes.data_as(C.c_void_p)
+    rc = lib().hs_lorenz_logpdf(_dt(dtype), po, C_, T, g, ptr(yo), ptr(xx), ptr(xxp), ptr(uu), ptr(pp), psc, C.c_double(float(delta)), int(nan_policy),
+                                int(bool(chain_minor)), ptr(out))
+    assert rc == 0, rc
+    return out

@@ -222,6 +222,40 @@ static int sv_logpdf_T(int C, int T, const HsArr* g, const void* yobs, const voi
     return 0;
 }
 
+// the Lorenz sweep's fused log-density pass (kalman_bodies.h::body_lorenz_logpdf), dense or chain-minor views of the same dense inputs
+template <typename R, int PO>
+static int lorenz_logpdf_T(int C, int T, const HsArr* g, const void* yobs, const void* x, const void* xp, const void* u, const void* par, int psc,
+                           double delta, int pol, int cm, void* out) {
+    SweepLogpdfArgs a;
+    a.d = KDims{C, T, 1};
+    a.dx = 3; a.po = PO;
+    a.m0 = cv(g[0]); a.P0 = cv(g[1]); a.Qs = cv(g[3]);
+    a.Fs = Arr{nullptr, 0, 0, 0, 1}; a.bs = Arr{nullptr, 0, 0, 0, 1};
+    a.Hs = cv(g[5]); a.Rs = cv(g[6]); a.cs = cv(g[7]);
+    a.ys = Arr{yobs, 0, PO, 0, 1};
+    a.delta = delta; a.nan_policy = pol;
+    a.lor_par = par; a.lor_psc = psc;
+    std::vector<std::vector<R>> keep;
+    auto view = [&](const void* p) -> Arr {
+        if (!cm) return dense_arr(p, a.d, 3);
+        keep.emplace_back((size_t)C * T * 3);
+        dense_to_cm<R>((const R*)p, a.d, 3, keep.back());
+        return cm_arr(keep.back().data(), a.d, 3);
+    };
+    a.x = view(x); a.xp = view(xp); a.u = view(u);
+    for (int c = 0; c < C; ++c) {
+        R tot[5];
+        body_lorenz_logpdf_head<R, PO>(a, c, tot);
+        for (int i = 0; i < T - 1; ++i) {
+            R w[5];
+            body_lorenz_logpdf<R, PO>(a, c, i, true, w);
+            for (int k = 0; k < 5; ++k) tot[k] += w[k];
+        }
+        for (int k = 0; k < 5; ++k) ((R*)out)[(size_t)k * C + c] = tot[k];
+    }
+    return 0;
+}
+
 #define HS_P_SWITCH(CALL, R, D)                                           \
     switch (P) {                                                          \
         case 1: return CALL(R, D, 1); case 2: return CALL(R, D, 2);       \
@@ -273,6 +307,19 @@ int hs_sv_logpdf(int dtype, int D, int C, int T, const HsArr* g, const void* yob
         case 3: return sv_logpdf_T<R, 3>(C, T, g, yobs, x, xp, u, ys1, ys2, R1, R2, delta, cm, out);          \
         case 4: return sv_logpdf_T<R, 4>(C, T, g, yobs, x, xp, u, ys1, ys2, R1, R2, delta, cm, out);          \
         default: return -2;                                                                                   \
+    }
+    if (dtype == 0) { CALLS(float) } else { CALLS(double) }
+#undef CALLS
+}
+
+int hs_lorenz_logpdf(int dtype, int PO, int C, int T, const HsArr* g, const void* yobs, const void* x, const void* xp, const void* u,
+                     const void* par, int psc, double delta, int pol, int cm, void* out) {
+#define CALLS(R)                                                                                       \
+    switch (PO) {                                                                                      \
+        case 1: return lorenz_logpdf_T<R, 1>(C, T, g, yobs, x, xp, u, par, psc, delta, pol, cm, out);  \
+        case 2: return lorenz_logpdf_T<R, 2>(C, T, g, yobs, x, xp, u, par, psc, delta, pol, cm, out);  \
+        case 3: return lorenz_logpdf_T<R, 3>(C, T, g, yobs, x, xp, u, par, psc, delta, pol, cm, out);  \
+        default: return -2;                                                                            \
     }
     if (dtype == 0) { CALLS(float) } else { CALLS(double) }
 #undef CALLS

@@ -166,3 +166,37 @@ def test_sv_fused_logpdf_body(order, d, chain_minor):
     got = HS.sv_logpdf((model.m0, model.P0, model.Fs, model.Qs, model.bs), y, x, xp, u, ys1, ys2,
                             R1 if order == 2 else None, R2 if order == 2 else None, delta, chain_minor)
     npt.assert_allclose(got, ref, rtol=1e-10, atol=1e-10)
+
+
+@pytest.mark.parametrize("chain_minor", [False, True])
+@pytest.mark.parametrize("per_chain_theta", [False, True])
+def test_lorenz_fused_logpdf_body(chain_minor, per_chain_theta):
+    """The Lorenz sweep's fused log-density body against the oracle's pieces: the joint of the auxiliary LGSSM linearised at x (resp. x')
+    evaluated at x' (resp. x) -- base.py:99-166 on the NumPy factories of LorenzModel, NaN observation rows included -- and the target
+    log_likelihood_fn at both points."""
+    from tests import hostsim as HS
+    from tests.helpers import lorenz_kalman_setup
+    from aux_ssm_samplers_amd.kalman.models import LorenzModel
+    T, C, delta = 41, 3, 0.02
+    base, xtrue = lorenz_kalman_setup(T)
+    rng = np.random.default_rng(2)
+    theta = base.theta + (0.4 * rng.standard_normal((C, 3)) if per_chain_theta else np.zeros((C, 3)))
+    x = xtrue[None] + 0.05 * rng.standard_normal((C, T, 3))
+    xp = xtrue[None] + 0.05 * rng.standard_normal((C, T, 3))
+    u = x + np.sqrt(delta / 2) * rng.standard_normal((C, T, 3))
+    ref = np.zeros((5, C))
+    for c in range(C):
+        mc = LorenzModel(base.yobs, base.Hobs, base.Robs, base.cobs, base.m0, base.P0, theta[c], base.sigma_x, base.dt)
+        for k, (lin, ev) in enumerate(((x[c], xp[c]), (xp[c], x[c]))):
+            m0, P0, Fs, Qs, bs = mc.dynamics_factory(lin)
+            ys, Hs, Rs, cs = mc.observations_factory(lin, u[c], delta)
+            lg = (m0, P0, Fs, Qs, bs, Hs, Rs, cs)
+            ref[k, c] = K.log_likelihood(ys, ev, lg) + K.prior_logpdf(ev, lg)
+        ref[2, c] = mc.log_likelihood_fn(xp[c])
+        ref[3, c] = mc.log_likelihood_fn(x[c])
+        ref[4, c] = np.sum(((xp[c] - u[c]) ** 2 - (x[c] - u[c]) ** 2) / delta)
+    par = np.concatenate([theta, np.full((C, 1), base.dt)], 1)
+    n = T - 1
+    lg = (base.m0, base.P0, np.broadcast_to(np.eye(3), (n, 3, 3)), base.Qs, np.zeros((n, 3)), base.Hobs, base.Robs, base.cobs)
+    got = HS.lorenz_logpdf(lg, base.yobs, x, xp, u, par if per_chain_theta else par[0], delta, 0, chain_minor)
+    npt.assert_allclose(got, ref, rtol=1e-9, atol=1e-9)
