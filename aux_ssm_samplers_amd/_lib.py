@@ -18,7 +18,10 @@ KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND, KMODEL_LORENZ63_EXT = 1, 2,
 LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
 OPT_SHARE_MODEL = 1
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
- K_CSMC_BWD, K_PIT_STITCH) = range(10)
+ K_CSMC_BWD, K_PIT_STITCH, K_RNG, K_SELECT, K_FACTORY, K_FILTER_TAB, K_COUNT) = range(15)
+K_ALL = -1
+K_NAMES = ("none", "filter_init", "filter_scan", "filter_ell", "sample_init", "sample_scan", "logpdf", "csmc_fwd", "csmc_bwd",
+           "pit_stitch", "rng", "select", "factory", "filter_tab")
 
 
 class AuxSSMError(RuntimeError):
@@ -85,6 +88,7 @@ def load():
         "auxssm_memset": ([vp, vp, i32, C.c_size_t], C.c_int),
         "auxssm_prof_enable": ([vp, i32, i32], C.c_int),
         "auxssm_prof_read": ([vp, P(C.c_int), P(dbl)], C.c_int),
+        "auxssm_prof_read_groups": ([vp, i32, P(C.c_int), P(dbl)], C.c_int),
         "auxssm_prof_disable": ([vp], C.c_int),
         "auxssm_kalman_filter": ([vp, i32, P(Dims), P(Lgssm), P(Arr), i32, vp, vp, vp], C.c_int),
         "auxssm_kalman_sample": ([vp, i32, P(Dims), P(Lgssm), vp, vp, vp, i32, vp], C.c_int),
@@ -94,11 +98,12 @@ def load():
         "auxssm_csmc_pit_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_systematic_resample": ([vp, i32, C.c_int32, C.c_int32, C.c_int32, vp, vp, vp], C.c_int),
-        "auxssm_stats_attach": ([vp, vp, vp, vp, i64], C.c_int),
+        "auxssm_stats_attach": ([vp, i32, i64, vp, vp, vp, vp, i64], C.c_int),
         "auxssm_stats_update": ([vp, i32, i64, i64, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_accept_update": ([vp, i32, C.c_int32, C.c_int32, i64, dbl, vp, vp, vp], C.c_int),
         "auxssm_delta_adapt": ([vp, i32, C.c_int32, C.c_int32, vp, dbl, dbl, dbl, dbl, vp, vp], C.c_int),
         "auxssm_lorenz_theta_update": ([vp, i32, C.c_int32, C.c_int32, i32, vp, dbl, dbl, vp, vp, vp], C.c_int),
+        "auxssm_mvn_logpdf": ([vp, i32, i64, C.c_int32, vp, i64, vp, i64, vp, i64, vp], C.c_int),
         "auxssm_kalman_draw": ([vp, i32, P(u32), i64, i64, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
@@ -189,14 +194,25 @@ class Handle:
         check(self.lib.auxssm_prof_read(self.h, C.byref(n), C.byref(ms)))
         return n.value, ms.value
 
+    def prof_read_groups(self):
+        """after prof_enable(K_ALL, n): {group name: (launches, total ms)} for the groups that ran"""
+        n = (C.c_int * K_COUNT)()
+        ms = (C.c_double * K_COUNT)()
+        check(self.lib.auxssm_prof_read_groups(self.h, K_COUNT, n, ms))
+        return {K_NAMES[k]: (n[k], ms[k]) for k in range(K_COUNT) if n[k]}
+
     def prof_disable(self):
         check(self.lib.auxssm_prof_disable(self.h))
 
     # ---- the MCMC loop around the sweeps (include/auxssm.h: running statistics, adaptation, Lorenz theta step) ----
-    def stats_attach(self, stats, it):
-        """stats: (sq_jump, mean, sq_mean) DeviceArrays shaped like the resident state, or None to detach"""
-        p = [None, None, None] if stats is None else [a.ptr for a in stats]
-        check(self.lib.auxssm_stats_attach(self.h, p[0], p[1], p[2], int(it)))
+    def stats_attach(self, stats, it, x=None):
+        """stats: (sq_jump, mean, sq_mean) DeviceArrays shaped like the resident state `x` (a DeviceArray), or None to detach"""
+        if stats is None:
+            check(self.lib.auxssm_stats_attach(self.h, 0, 0, None, None, None, None, int(it)))
+            return
+        if x is None:
+            raise ValueError("stats_attach needs the resident state the moments belong to")
+        check(self.lib.auxssm_stats_attach(self.h, dtype_code(x.dtype), x.size, x.ptr, stats[0].ptr, stats[1].ptr, stats[2].ptr, int(it)))
 
     def stats_update(self, it, x_prev, x_next, stats):
         check(self.lib.auxssm_stats_update(self.h, dtype_code(x_next.dtype), x_next.size, int(it), x_prev.ptr, x_next.ptr, stats[0].ptr,

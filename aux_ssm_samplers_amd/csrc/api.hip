@@ -328,12 +328,20 @@ __global__ void k_select(int C, int T, int D, const int32_t* accepted, Arr xp, A
     mean[off] = fold_mean<R>(i, mean[off], xn);
     sq_mean[off] = fold_mean<R>(i, sq_mean[off], xn * xn);
 }
-// the accept/select step of every Kalman sweep
-template <typename R> static void launch_select(auxssm_ctx* h, int C, int T, int D, const int32_t* accepted, Arr xp, Arr x, int cfast) {
+// the accept/select step of every Kalman sweep.  Running moments attached to the handle are bound to one resident state
+// (auxssm_stats_attach: pointer, element count, dtype): a sweep over anything else is refused instead of folding out of bounds.
+template <typename R> static int launch_select(auxssm_ctx* h, int C, int T, int D, const int32_t* accepted, Arr xp, Arr x, int cfast) {
     const long long total = (long long)C * T * D;
+    if (h->st_mean && (h->st_x != x.ptr || h->st_n != total || h->st_dtype != (sizeof(R) == 4 ? AUXSSM_F32 : AUXSSM_F64))) {
+        set_error("running moments are attached to another state (x=%p, n=%lld, dtype=%d): detach them (auxssm_stats_attach with NULLs) "
+                  "before sweeping a different state on this handle", h->st_x, h->st_n, h->st_dtype);
+        return AUXSSM_ERR_ARG;
+    }
+    ProfScope ps(h, AUXSSM_K_SELECT);
     hipLaunchKernelGGL((k_select<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, C, T, D, accepted, xp, x, cfast,
                        (R*)h->st_sq_jump, (R*)h->st_mean, (R*)h->st_sq_mean, h->st_iter);
     if (h->st_mean) ++h->st_iter;
+    return AUXSSM_OK;
 }
 
 template <typename R>
@@ -389,6 +397,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     R* xp = (R*)ws_take(h, CT * D * sR);
     R* ell = (R*)ws_take(h, C * sR);
     R* sums = (R*)ws_take(h, (size_t)5 * C * sR);
+    if (!ysc || !Hc || !Rc || !cc || !u || !ms || !Ps || !xp || !ell || !sums) return AUXSSM_ERR_NOMEM;
     const size_t mark = h->ws_off;
     const Arr yscA = cm ? cm_arr(ysc, kd, P) : dense_arr(ysc, kd, P);
     const Arr uA = cm ? cm_arr(u, kd, D) : dense_arr(u, kd, D);
@@ -405,6 +414,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
                               model->cs.sc == 0 && model->P0.sc == 0 && yobs->sc == 0;
     const bool aux_fly = cm && h->share_model && model_shared && C > 1 && T > 1 && !wide;
     {
+        ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
                            cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
@@ -471,7 +481,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)jp_prop, (const R*)jp_rev,
                        (const R*)ell, (const R*)ell, (const R*)lt_prop, (const R*)lt_rev, (const R*)corr, (const R*)u_acc,
                        accepted, (R*)logs);
-    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm);
+    if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm))) return rc;
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -669,8 +679,11 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     const int ps_shared = (!second && C > 1 && model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0) ? 1 : 0;
 
     // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
-    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)x, (const R*)eps_aux,
-                       (R)sqrt(0.5 * delta), (R)delta, cv(*yobs), u, ys1, Rs1);
+    {
+        ProfScope ps(h, AUXSSM_K_FACTORY);
+        hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)x, (const R*)eps_aux,
+                           (R)sqrt(0.5 * delta), (R)delta, cv(*yobs), u, ys1, Rs1);
+    }
     FilterArgs fa;
     fill_filter_args(fa, &dc, &g1, &y1d, ms, Ps);
     fa.ys = y1A;
@@ -693,8 +706,11 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     if (rc) return rc;
     h->ws_off = mark;
     // reverse move: observations linearised at x_prop, filter for its marginal likelihood (generic.py:67)
-    hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)xp, (const R*)nullptr, (R)0,
-                       (R)delta, cv(*yobs), u, ys2, Rs2);
+    {
+        ProfScope ps(h, AUXSSM_K_FACTORY);
+        hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)xp, (const R*)nullptr, (R)0,
+                           (R)delta, cv(*yobs), u, ys2, Rs2);
+    }
     fill_filter_args(fa, &dc, &g2, &y2d, ms, Ps);
     fa.ys = y2A;
     fa.ms = arr(ms, D);
@@ -734,7 +750,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
                            (const R*)ell2, (const R*)terms, (const R*)u_acc, accepted, (R*)logs);
     }
-    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm);
+    if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm))) return rc;
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -815,6 +831,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     // per-chain transition arrays have n = T - 1 rows: same strides as a T-row array of that record size
     const Arr F1A = arr(Fs1, 9), b1A = arr(bs1, 3), F2A = arr(Fs2, 9), b2A = arr(bs2, 3);
     {
+        ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs),
                            cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
@@ -849,7 +866,10 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     };
 
     // proposal: dynamics linearised at x (generic.py:80-86)
-    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, cm, par, psc, (const R*)x, Fs1, bs1);
+    if (T > 1) {
+        ProfScope ps(h, AUXSSM_K_FACTORY);
+        hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, cm, par, psc, (const R*)x, Fs1, bs1);
+    }
     FilterArgs fa;
     fill_filter_args(fa, &dc, &g1, &yd, ms, Ps);
     set_views(fa, F1A, b1A);
@@ -867,7 +887,10 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     if (rc) return rc;
     h->ws_off = mark;
     // reverse move: dynamics linearised at x_prop (generic.py:67)
-    if (T > 1) hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, cm, par, psc, (const R*)xp, Fs2, bs2);
+    if (T > 1) {
+        ProfScope ps(h, AUXSSM_K_FACTORY);
+        hipLaunchKernelGGL((k_lorenz_dyn<R>), dim3(gd), dim3(256), 0, h->stream, C, T, cm, par, psc, (const R*)xp, Fs2, bs2);
+    }
     fill_filter_args(fa, &dc, &g2, &yd, ms, Ps);
     set_views(fa, F2A, b2A);
     rc = ke->filter(h, fa, parallel, ell2);
@@ -890,7 +913,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)sums, (const R*)(sums + C), (const R*)ell1,
                        (const R*)ell2, (const R*)(sums + 2 * C), (const R*)(sums + 3 * C), (const R*)(sums + 4 * C), (const R*)u_acc, accepted,
                        (R*)logs);
-    launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm);
+    if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm))) return rc;
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -1072,6 +1095,7 @@ int auxssm_prof_disable(auxssm_handle h) {
     for (auto e : p.stop) (void)hipEventDestroy(e);
     p.start.clear();
     p.stop.clear();
+    p.ids.clear();
     p.kernel_id = 0;
     p.max_launches = 0;
     p.used = 0;
@@ -1087,6 +1111,7 @@ int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches) {
     Prof& p = h->prof;
     p.start.resize(max_launches);
     p.stop.resize(max_launches);
+    p.ids.assign(max_launches, 0);
     for (int i = 0; i < max_launches; ++i) {
         AX_HIP(hipEventCreate(&p.start[i]));
         AX_HIP(hipEventCreate(&p.stop[i]));
@@ -1108,6 +1133,25 @@ int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms) {
     }
     if (launches) *launches = p.used;
     if (total_ms) *total_ms = tot;
+    p.used = 0;
+    return AUXSSM_OK;
+}
+
+int auxssm_prof_read_groups(auxssm_handle h, int n_ids, int* launches, double* total_ms) {
+    AX_NEED_H(h);
+    if (n_ids < 1 || !launches || !total_ms) {
+        set_error("n_ids must be >= 1 and launches / total_ms non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    AX_HIP(hipStreamSynchronize(h->stream));
+    Prof& p = h->prof;
+    for (int k = 0; k < n_ids; ++k) launches[k] = 0, total_ms[k] = 0;
+    for (int i = 0; i < p.used; ++i) {
+        float ms = 0;
+        AX_HIP(hipEventElapsedTime(&ms, p.start[i], p.stop[i]));
+        const int id = p.ids[i];
+        if (id >= 0 && id < n_ids) ++launches[id], total_ms[id] += ms;
+    }
     p.used = 0;
     return AUXSSM_OK;
 }
@@ -1236,6 +1280,17 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
         set_error("yobs/x/eps_aux/eps_samp/u_acc/accepted must be non-NULL");
         return AUXSSM_ERR_ARG;
     }
+    if (nan_policy != AUXSSM_NAN_REFERENCE && nan_policy != AUXSSM_NAN_MASKED) {
+        set_error("nan_policy must be 0 (reference) or 1 (masked)");
+        return AUXSSM_ERR_ARG;
+    }
+    // The data and the REAL observation model are what the chains have in common (the reference's factories close over them,
+    // examples/lorenz/auxiliary_kalman.py:26-35): the concatenated model is built once per time step, so per-chain copies are refused
+    // rather than silently read at chain 0.
+    if (yobs->sc != 0 || (!sv && (model->Hs.sc != 0 || model->Rs.sc != 0 || model->cs.sc != 0))) {
+        set_error("yobs and the observation model (Hs, Rs, cs) are shared by the chains of a sweep: their chain strides must be 0");
+        return AUXSSM_ERR_ARG;
+    }
     if (lorenz) {
         if (dtype == AUXSSM_F32)
             return sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
@@ -1263,6 +1318,7 @@ static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32
     if (n == 0) return AUXSSM_OK;
     const long long work = (n + 1) / 2;
     const unsigned grid = (unsigned)((work + 255) / 256);
+    ProfScope ps(h, AUXSSM_K_RNG);
     if (dtype == AUXSSM_F32) {
         if (normal) hipLaunchKernelGGL((k_rng_normal<float>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
         else hipLaunchKernelGGL((k_rng_uniform<float>), dim3(grid), dim3(256), 0, h->stream, k0, k1, stream, (long long)n, (float*)out);
@@ -1282,6 +1338,7 @@ int auxssm_kalman_draw(auxssm_handle h, int dtype, const uint32_t* keys, int64_t
         return AUXSSM_ERR_ARG;
     }
     const unsigned g1 = (unsigned)(((n + 1) / 2 + 255) / 256), g2 = (unsigned)(((nu + 1) / 2 + 255) / 256);
+    ProfScope ps(h, AUXSSM_K_RNG);
     if (dtype == AUXSSM_F32)
         hipLaunchKernelGGL((k_rng_sweep<float>), dim3(2 * g1 + g2), dim3(256), 0, h->stream, keys[0], keys[1], keys[2], keys[3], keys[4], keys[5],
                            (long long)n, (long long)nu, g1, (float*)eps_aux, (float*)eps_samp, (float*)u_acc);

@@ -352,6 +352,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     {
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
         const size_t lds = (size_t)2 * TB * (1 + D) * sizeof(R) + 48 * sizeof(R) + 64;
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_csmc_fwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
     }
     {

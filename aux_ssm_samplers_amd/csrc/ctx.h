@@ -22,10 +22,11 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 struct Prof {
-    int kernel_id = 0;
+    int kernel_id = 0;  // AUXSSM_K_ALL (-1): every kernel group is bracketed, each slot remembers its group
     int max_launches = 0;
     int used = 0;
     std::vector<hipEvent_t> start, stop;
+    std::vector<int> ids;
 };
 
 }  // namespace ax
@@ -45,6 +46,10 @@ struct auxssm_ctx {
     void* st_mean = nullptr;
     void* st_sq_mean = nullptr;
     long long st_iter = 0;
+    // ... bound to ONE resident state: its base pointer, element count and dtype; a sweep on any other state is refused while attached
+    const void* st_x = nullptr;
+    long long st_n = 0;
+    int st_dtype = -1;
 };
 
 namespace ax {
@@ -58,8 +63,9 @@ struct ProfScope {
     int slot;
     ProfScope(auxssm_ctx* h_, int kernel_id) : h(h_), slot(-1) {
         Prof& p = h->prof;
-        if (p.kernel_id == kernel_id && p.used < p.max_launches) {
+        if ((p.kernel_id == kernel_id || p.kernel_id == AUXSSM_K_ALL) && p.used < p.max_launches) {
             slot = p.used++;
+            p.ids[slot] = kernel_id;
             (void)hipEventRecord(p.start[slot], h->stream);
         }
     }

@@ -128,18 +128,61 @@ static int lorenz_theta(auxssm_ctx* h, int C, int T, int cfast, const void* x, d
     return AUXSSM_OK;
 }
 
+// mvn.logpdf (math/mvn/base.py:15-58) + tril_log_det (:108-128) for n independent (x, m, chol) triplets of runtime dimension dim <= 64, one
+// lane per triplet, IEEE-literal: non-finite entries of chol become +inf before the forward substitution (nan_to_num(chol, nan = inf, ...),
+// :52), the dimension counts the finite diagonal entries (:50) and non-finite diagonal entries drop out of the log-determinant (:123-128).
+constexpr int MVN_MAX_DIM = 64;
+template <typename R>
+__global__ void k_mvn_logpdf(long long n, int dim, const R* __restrict__ x, long long sx, const R* __restrict__ m, long long sm,
+                             const R* __restrict__ chol, long long sl, R* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    const R* xg = x + g * sx;
+    const R* mg = m + g * sm;
+    const R* Lg = chol + g * sl;
+    const R inf = (R)INFINITY;
+    R y[MVN_MAX_DIM];
+    R nrm = 0, logdet = 0;
+    int nfin = 0;
+    for (int i = 0; i < dim; ++i) {
+        R s = xg[i] - mg[i];
+        for (int k = 0; k < i; ++k) {
+            R l = Lg[(long long)i * dim + k];
+            if (!isfinite(l)) l = inf;
+            s -= l * y[k];
+        }
+        const R d = Lg[(long long)i * dim + i];
+        const bool fin = isfinite(d);
+        y[i] = s / (fin ? d : inf);
+        nrm += y[i] * y[i];
+        if (fin) {
+            ++nfin;
+            const R l = log(fabs(d));
+            if (!isnan(l)) logdet += l;  // nansum (:128)
+        }
+    }
+    out[g] = (R)-0.5 * nrm - (logdet + (R)0.5 * (R)nfin * (R)1.8378770664093453);
+}
+
 }  // namespace ax
 
 using namespace ax;
 
 extern "C" {
 
-int auxssm_stats_attach(auxssm_handle h, void* sq_jump, void* mean, void* sq_mean, int64_t iter) {
+int auxssm_stats_attach(auxssm_handle h, int dtype, int64_t n, const void* x, void* sq_jump, void* mean, void* sq_mean, int64_t iter) {
     AX_NEED_H(h);
     const int nn = (sq_jump != nullptr) + (mean != nullptr) + (sq_mean != nullptr);
     if (nn != 0 && nn != 3) {
         set_error("sq_jump, mean and sq_mean must be all non-NULL (attach) or all NULL (detach)");
         return AUXSSM_ERR_ARG;
+    }
+    if (nn == 3) {
+        if (int rc = need_dtype(dtype)) return rc;
+        if (!x || n < 1) {
+            set_error("attach needs the resident state x (non-NULL) and its element count n >= 1");
+            return AUXSSM_ERR_ARG;
+        }
     }
     if (iter < 0) {
         set_error("iter must be >= 0");
@@ -149,6 +192,9 @@ int auxssm_stats_attach(auxssm_handle h, void* sq_jump, void* mean, void* sq_mea
     h->st_mean = mean;
     h->st_sq_mean = sq_mean;
     h->st_iter = iter;
+    h->st_x = nn == 3 ? x : nullptr;
+    h->st_n = nn == 3 ? n : 0;
+    h->st_dtype = nn == 3 ? dtype : -1;
     return AUXSSM_OK;
 }
 
@@ -228,6 +274,30 @@ int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T,
     const int cf = layout == AUXSSM_LAYOUT_CHAIN_MINOR ? 1 : 0;
     return dtype == AUXSSM_F32 ? lorenz_theta<float>(h, C, T, cf, x, sigma_theta, sigma_x, eps, par, mean_chol)
                                : lorenz_theta<double>(h, C, T, cf, x, sigma_theta, sigma_x, eps, par, mean_chol);
+}
+
+int auxssm_mvn_logpdf(auxssm_handle h, int dtype, int64_t n, int32_t dim, const void* x, int64_t sx, const void* m, int64_t sm, const void* chol,
+                      int64_t sl, void* out) {
+    AX_NEED_H(h);
+    if (int rc = need_dtype(dtype)) return rc;
+    if (n < 0 || dim < 1 || dim > MVN_MAX_DIM) {
+        set_error("n must be >= 0 and 1 <= dim <= %d (got n=%lld, dim=%d)", MVN_MAX_DIM, (long long)n, dim);
+        return AUXSSM_ERR_ARG;
+    }
+    if (n == 0) return AUXSSM_OK;
+    if (!x || !m || !chol || !out || sx < 0 || sm < 0 || sl < 0) {
+        set_error("x/m/chol/out must be non-NULL and the strides >= 0");
+        return AUXSSM_ERR_ARG;
+    }
+    const unsigned grid = (unsigned)((n + 63) / 64);
+    if (dtype == AUXSSM_F32)
+        hipLaunchKernelGGL((k_mvn_logpdf<float>), dim3(grid), dim3(64), 0, h->stream, (long long)n, dim, (const float*)x, (long long)sx, (const float*)m,
+                           (long long)sm, (const float*)chol, (long long)sl, (float*)out);
+    else
+        hipLaunchKernelGGL((k_mvn_logpdf<double>), dim3(grid), dim3(64), 0, h->stream, (long long)n, dim, (const double*)x, (long long)sx, (const double*)m,
+                           (long long)sm, (const double*)chol, (long long)sl, (double*)out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
 }
 
 }  // extern "C"

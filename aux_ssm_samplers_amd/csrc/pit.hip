@@ -345,8 +345,8 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
         set_error("model/x/noise/ancestors/sqrt_half_delta must be non-NULL");
         return AUXSSM_ERR_ARG;
     }
-    if (C < 1 || T < 2 || N < 2 || N > 1024) {
-        set_error("need C >= 1, T >= 2, 2 <= N <= 1024 (got C=%d T=%d N=%d)", C, T, N);
+    if (C < 1 || C > 65535 || T < 2 || N < 2 || N > 1024) {  // the chain index is grid.y of the leaf / stitch launches
+        set_error("need 1 <= C <= 65535, T >= 2, 2 <= N <= 1024 (got C=%d T=%d N=%d)", C, T, N);
         return AUXSSM_ERR_ARG;
     }
     const int D = fk->dx;

@@ -91,7 +91,7 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
     rule = _is_reference_rule(delta_fn) if delta_fn is not None else None
     state = init_state
     if kalman:
-        handle.stats_attach(stats, 0)
+        handle.stats_attach(stats, 0, chains.x)
     try:
         for i in range(n_iter):
             if kalman:

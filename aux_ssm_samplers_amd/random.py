@@ -58,3 +58,25 @@ def uniform_scalar(key):
     key = as_key(key)
     a, _ = threefry2x32(key[0], key[1], np.uint32(0), np.uint32(0xFFFFFFFE))
     return float(a) * 2.3283064365386963e-10
+
+
+def normal(key, shape=(), dtype=np.float64, handle=None):
+    """N(0, 1) draws of `shape`, generated on the device (auxssm_rng_normal, stream 0) and returned as a NumPy array."""
+    from . import _lib
+    handle = handle or _lib.default_handle()
+    key = as_key(key)
+    shape = tuple(np.atleast_1d(shape).astype(int)) if not isinstance(shape, tuple) else shape
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    out = handle.rng_normal((int(key[0]), int(key[1])), 0, (n,), dtype).to_host()
+    return out.reshape(shape) if shape else out[0]
+
+
+def uniform(key, shape=(), dtype=np.float64, handle=None):
+    """U[0, 1) draws of `shape`, generated on the device (auxssm_rng_uniform, stream 0) and returned as a NumPy array."""
+    from . import _lib
+    handle = handle or _lib.default_handle()
+    key = as_key(key)
+    shape = tuple(np.atleast_1d(shape).astype(int)) if not isinstance(shape, tuple) else shape
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    out = handle.rng_uniform((int(key[0]), int(key[1])), 0, (n,), dtype).to_host()
+    return out.reshape(shape) if shape else out[0]

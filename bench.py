@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- Gibbs sweeps/sec of the auxiliary-Kalman hot path on MI355X (BASELINE.json metric).
+"""bench.py -- Gibbs sweeps/sec of the auxiliary-Kalman / conditional-SMC hot path on MI355X (BASELINE.json metric).
 
-Workload (config.workload): BASELINE configs[1] = SURVEY 8(d) C2: linear-Gaussian SSM, T = 65536, d = 4 (p = 8 with
-the auxiliary observations concatenated), parallel-in-time aux-Kalman sweep, fp64, `--chains` independent chains per
-GPU.  One "step" = one sweep (kalman/generic.py:53-76) of every chain resident on this GPU: device Threefry draws,
-proposal LGSSM, filter scan, pathwise-sampler scan, log-densities, MH accept.  Inputs are resident in HBM before
-the timed region.  value = chains * n_gpus * steps / seconds (independent chains: weak scaling, no data-path
-collective; torch.distributed (RCCL) is used only for the barrier / max-over-ranks / the final chain-gather).
+Headline (`value`, config.workload): BASELINE configs[1] = SURVEY 8(d) C2: linear-Gaussian SSM, T = 65536, d = 4 (p = 8 with the
+auxiliary observations concatenated), parallel-in-time aux-Kalman sweep, fp64, `--chains` independent chains per GPU.  One "step" =
+one sweep (kalman/generic.py:53-76) of every chain resident on this GPU: device Threefry draws, proposal LGSSM, filter scan, pathwise
+sampler scan, log-densities, MH accept.  Inputs are resident in HBM before the timed region.  value = chains * n_gpus * steps /
+seconds (independent chains: weak scaling, no data-path collective; torch.distributed (RCCL) is used only for the barrier, the
+max-over-ranks and the final chain-gather).
 
-Also reports, on the same JSON line:
-  roofline      -- the filter's associative scan (dominant kernel group: k_scan_reduce_cm + k_scan_aggs + k_scan_down_cm<FilterOp>);
-                   algorithmic bytes = K3 n(3d^2+2d)s read + n(d^2+d)s written per chain, divided by its HIP-event
-                   duration measured inside the timed region on the library's stream.  The marginal log-likelihood (K4, the
-                   reference's second pass over the filtered moments) is the log-scale the scan elements carry: it costs no pass.
-  general_path  -- the same workload with nothing hoisted out of the chain loop (what chain-specific parameters cost); `value`
-                   is the default mode: the model's parameters are the same for every chain, so the element matrices, gains and
-                   Cholesky factors are computed once per time step and sweep (what jax.vmap leaves unbatched in the reference).
-  cpu_baseline  -- the NumPy oracle (a port of the reference's parallel path) timed on this box's host, rank 0 only.
+On the same JSON line:
+  roofline      the kernel group that takes most of the timed region, timed with HIP events on the library's stream INSIDE the timed
+                region (auxssm_prof_*, every group bracketed); `achieved` = the bytes THAT group has to move (its per-chain inputs read
+                once + its outputs written once + chain-shared tables once; DESIGN.md section 5 lists the per-step reals of every
+                group) / its average duration.  `traffic` = HBM bytes from the committed PMC passes of the same kernels, with the
+                file it came from (null when no pass matches the kernels of this build).
+  kernels       every group's average ms per step and its own algorithmic GB/s (the whole sweep, not only the dominant group).
+  general_path  the same workload with nothing hoisted out of the chain loop (AUXSSM_OPT_SHARE_MODEL = 0: what every model with
+                chain-specific dynamics runs), with its own `roofline` on the filter scan: SURVEY 8(d)'s K3 bytes are reported as
+                `k3_equivalent_GBps`, never as the HBM fraction.
+  secondary     bounded legs on the other BASELINE configs, each with its own roofline: C3 cSMC (HBM), C4 Lorenz Kalman + cSMC with a
+                FIXED total of 64 chains sharded over the ranks (parallel.shard_chains), C5 wide-state filter (MFMA flops).
+  cpu_baseline  oracle/kalman_seq.c -- the reference's SEQUENTIAL sweep (its CPU code path) restated in C, chains over OpenMP threads
+                -- on this box's host cores: 1 thread and all cores (rank 0, N = 1 only).
+
+Launch: `python bench.py --gpus N ...`.  With N > 1 and no RANK in the environment this process starts
+`python -m torch.distributed.run --nproc-per-node N ... bench.py` as a CHILD (before anything touches the GPU) and exits with its
+code; under a launcher (RANK set) WORLD_SIZE must equal --gpus.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,8 +39,70 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+HBM_PEAK_GBPS = 8000.0       # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 / 32x32x2_f32 dense peak
 
 
+# ------------------------------------------------------------------------------------------------------------------------
+# launch
+# ------------------------------------------------------------------------------------------------------------------------
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chains", type=int, default=256, help="chains per GPU (SURVEY 8d lists 1, 8, 64, 256 for C2)")
+    ap.add_argument("--T", type=int, default=65536)
+    ap.add_argument("--d", type=int, default=4)
+    ap.add_argument("--dtype", default=None, choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket the kernel groups with HIP events")
+    ap.add_argument("--no-share-model", action="store_true",
+                    help="headline on the general per-chain path (AUXSSM_OPT_SHARE_MODEL = 0)")
+    ap.add_argument("--no-general-leg", action="store_true", help="skip the extra run of the general per-chain path")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5 legs")
+    ap.add_argument("--secondary", default="c3,c4,c5", help="comma list of secondary legs to run")
+    ap.add_argument("--small-secondary", action="store_true", help="shrink the secondary legs (contract tests): not the BASELINE sizes")
+    ap.add_argument("--workload", default="kalman", choices=["kalman", "csmc"],
+                    help="kalman = BASELINE configs[1] (C2, the headline); csmc = configs[2] (C3) as the only workload")
+    ap.add_argument("--N", type=int, default=1024, help="particles (csmc workload)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, one rank per GPU) is what the driver runs; gloo + ranks sharing a GPU is a rehearsal mode")
+    args = ap.parse_args(argv)
+    if args.dtype is None:
+        args.dtype = "f32" if args.workload == "csmc" else "f64"
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0:
+        ap.error("--gpus >= 1, --steps >= 1, --warmup >= 0")
+    return args
+
+
+def free_port():
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launcher_command(args, argv):
+    """The child command `--gpus N` (N > 1) turns into when no launcher set RANK: one rank per GPU over RCCL."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+
+
+def resolve_launch(args, argv, environ):
+    """('run', rank, world, local_rank) | ('spawn', cmd) | ('error', message).  Pure: tested on the CPU (tests/test_bench_launch.py)."""
+    if "RANK" in environ:
+        world = int(environ.get("WORLD_SIZE", "1"))
+        if world != args.gpus:
+            return ("error", f"bench.py --gpus {args.gpus} was launched with WORLD_SIZE={world}: they must agree")
+        return ("run", int(environ["RANK"]), world, int(environ.get("LOCAL_RANK", "0")))
+    if args.gpus == 1:
+        return ("run", 0, 1, 0)
+    return ("spawn", launcher_command(args, argv))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# workloads
+# ------------------------------------------------------------------------------------------------------------------------
 def build_model(T, d, dtype):
     from tests.helpers import lg_model
     from aux_ssm_samplers_amd.kalman import LGConcatModel
@@ -41,27 +114,6 @@ def build_model(T, d, dtype):
     model = LGConcatModel(m["m0"], m["P0"], full(m["F"], T - 1), full(m["Q"], T - 1), full(m["b"], T - 1),
                           full(m["Hobs"], T), full(m["Robs"], T), full(m["cobs"], T), m["y"])
     return m, model
-
-
-def cpu_baseline(T, d, budget_s=20.0):
-    """Oracle sweep (NumPy, 1 thread) on one chain; bounded sample."""
-    from oracle import kalman_np as K
-    m, model = build_model(T, d, np.float64)
-    lgo = (m["m0"], m["P0"], model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs)
-    rng = np.random.default_rng(0)
-    x = m["x_true"] + 0.3 * rng.standard_normal((T, d))
-    target = lambda z: K.log_likelihood(m["y"], z, lgo) + K.prior_logpdf(z, lgo)
-    n, t0 = 0, time.perf_counter()
-    while True:
-        noise = dict(eps_aux=rng.standard_normal((T, d)), eps_samp=rng.standard_normal((T, d)), u_accept=rng.random())
-        out = K.kalman_sweep(x, 0.5, model.dynamics_factory, model.observations_factory, target, True, **noise)
-        x = out["x"]
-        n += 1
-        el = time.perf_counter() - t0
-        if el > budget_s or n >= 8:
-            break
-    return dict(value=n / el, unit="sweeps/s", cores=1, kind="port",
-                sample=f"{n} sweep(s) of 1 chain, same T={T} d={d} fp64 workload, NumPy oracle parallel path, {el:.1f} s")
 
 
 def sv_data(T, seed=0):
@@ -78,21 +130,198 @@ def sv_data(T, seed=0):
     return phi, q, x[:, None], y[:, None]
 
 
-def run_csmc(args, rank, world, local_rank, dist, torch, coll_dev):
-    """Secondary workload: BASELINE configs[2] = C3, SV d=1 T=65536, auxiliary cSMC with independent proposals, N=1024,
-    backward sampling, fp32, in-kernel Threefry noise.  One step = one sweep of every chain on this GPU."""
+class Ctx:
+    """rank / collective plumbing shared by the legs"""
+
+    def __init__(self, args, rank, world, local_rank):
+        import torch
+        self.args, self.rank, self.world, self.torch = args, rank, world, torch
+        ndev = torch.cuda.device_count()
+        if args.dist_backend == "gloo":
+            local_rank = local_rank % max(ndev, 1)  # rehearsal: ranks may share a GPU
+        self.local_rank = local_rank
+        self.dist = None
+        launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run: initialise the group even for one rank
+        torch.cuda.set_device(local_rank)
+        if world > 1 or launched:
+            import torch.distributed as dist
+            if args.dist_backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            else:
+                dist.init_process_group("gloo")
+            self.dist = dist
+        self.coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
+        from aux_ssm_samplers_amd import _lib
+        self.lib = _lib
+        self.handle = _lib.default_handle(local_rank)
+
+    def barrier(self):
+        self.handle.sync()
+        self.torch.cuda.synchronize()
+        if self.dist is not None:
+            self.dist.barrier()
+        self.handle.sync()
+        self.torch.cuda.synchronize()
+
+    def max_over_ranks(self, v):
+        if self.dist is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sum_over_ranks(self, v):
+        if self.dist is None:
+            return v
+        t = self.torch.tensor([v], dtype=self.torch.float64, device=self.coll_dev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def timed(self, step, steps, warmup, prof=True):
+        """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize pairs; max over ranks.
+        Returns (seconds, {group: (launches, total ms)})."""
+        for k in range(warmup):
+            step(k)
+        self.barrier()
+        if prof:
+            self.handle.prof_enable(self.lib.K_ALL, 64 * (steps + 1))
+        self.barrier()
+        t0 = time.perf_counter()
+        for k in range(steps):
+            step(warmup + k)
+        self.barrier()
+        el = self.max_over_ranks(time.perf_counter() - t0)
+        groups = {}
+        if prof:
+            groups = self.handle.prof_read_groups()
+            self.handle.prof_disable()
+        return el, groups
+
+    def close(self):
+        if self.dist is not None:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+# ---- algorithmic bytes of the Kalman sweep's kernel groups (reals per chain and time step; DESIGN.md section 5) -------------------
+def kalman_group_reals(mode, d, po):
+    """{group: (per-chain reals read, per-chain reals written, chain-shared reals per time step)} for one sweep of the LG-concat model.
+    What each group HAS to move given its inputs and outputs (every input once, every output once); a kernel that re-reads shows up as
+    traffic > algorithmic.  mode: 'shared' (chain-shared model parameters hoisted) or 'general'."""
+    p = d + po
+    sym = lambda n: n * (n + 1) // 2
+    par = 2 * d * d + d + po * d + po * po + po  # F, Q, b, Hobs, Robs, cobs of one step
+    if mode == "shared":
+        return {
+            "rng": (0, 2 * d, 0),                                     # eps_aux, eps_samp
+            "factory": (0, 0, par),
+            "filter_tab": (0, 0, par + 3 * d * d + 2 * d * p + sym(p) + p),  # parameters in, gain rows out (one sequence)
+            "filter_init": (2 * d, 3 * d + 1, 0),                     # x, eps_aux -> u, (b, eta, z)
+            "filter_scan": (2 * d + 1, d, 3 * d * d),                 # per-chain (b, eta, z) -> filtered means; matrices once
+            "sample_init": (0, 0, 2 * d * d + 3 * d * d + d),         # gains / Cholesky factors once per time step
+            "sample_scan": (2 * d, d, 3 * d * d + d),                 # ms, eps_samp -> x'
+            "logpdf": (3 * d, 0, par),                                # x, x', u
+            "select": (d, d, 0),                                      # x' -> x (accepted chains)
+        }
+    return {
+        "rng": (0, 2 * d, 0),
+        "factory": (2 * d, d + p, par),                               # x, eps_aux -> u, concatenated observations
+        "filter_init": (p, 3 * d * d + 2 * d, par),                   # observations (+ per-chain parameters) -> elements
+        "filter_scan": (3 * d * d + 2 * d, d * d + d, 0),             # K3 of SURVEY 8(d): elements -> filtered means, covariances
+        "sample_scan": (d * d + 2 * d, d, 2 * d * d + d),             # ms, Ps, eps_samp -> x' (elements rebuilt on the fly)
+        "logpdf": (3 * d, 0, par),
+        "select": (d, d, 0),
+    }
+
+
+def kalman_rooflines(groups, mode, C, T, d, po, s, steps):
+    """per-group average ms per step and algorithmic GB/s; returns (kernels dict, dominant group name)"""
+    reals = kalman_group_reals(mode, d, po)
+    out, dom = {}, None
+    for g, (n, ms) in groups.items():
+        per_step = ms / steps
+        ent = {"ms_per_step": round(per_step, 4), "launch_groups_per_step": round(n / steps, 2)}
+        if g in reals:
+            r, w, sh = reals[g]
+            b = (C * (r + w) + sh) * T * s
+            ent["algorithmic_bytes_per_step"] = int(b)
+            ent["algorithmic_GBps"] = round(b / (per_step * 1e-3) / 1e9, 1) if per_step > 0 else None
+        out[g] = ent
+        if dom is None or per_step > out[dom]["ms_per_step"]:
+            dom = g
+    return out, dom
+
+
+def pmc_traffic(key):
+    """HBM bytes per launch group measured with the PMC counters (profiles/r02_traffic.json, written from committed rocprofv3 --pmc
+    passes by tools/pmc_traffic.py); None when no pass exists for these kernels."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
+        ent = tj.get(key)
+        if ent:
+            return ent.get("hbm_bytes"), ent.get("source")
+    except Exception:
+        pass
+    return None, None
+
+
+def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
+    """C2 aux-Kalman sweeps; returns dict(value, ms_per_step, kernels, roofline, accept...)"""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    _lib, handle = ctx.lib, ctx.handle
+    dtype = np.float64 if args.dtype == "f64" else np.float32
+    T, d, C = args.T, args.d, args.chains
+    if chains_obj is None:
+        m, model = build_model(T, d, dtype)
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        rng = np.random.Generator(np.random.PCG64(1000 + ctx.rank))
+        x0 = (m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
+        chains_obj = (DeviceChains(handle, x0), kernel)
+    chains, kernel = chains_obj
+    state = KalmanSampler(x=chains, updated=None)
+    handle.set_option(_lib.OPT_SHARE_MODEL, int(share))
+    keys = R.split(R.PRNGKey(2024 + ctx.rank + (0 if share else 7919)), steps + warmup + 1)
+    delta = 0.5
+    el, groups = ctx.timed(lambda k: kernel(keys[k], state, delta), steps, warmup, prof=not args.no_prof)
+    handle.set_option(_lib.OPT_SHARE_MODEL, 1)
+    s = np.dtype(dtype).itemsize
+    mode = "shared" if share and chains.chain_minor and C > 1 else "general"
+    kernels, dom = kalman_rooflines(groups, mode, C, T, d, d, s, steps)
+    out = dict(value=C * ctx.world * steps / el, ms_per_step=el / steps * 1e3, kernels=kernels, mode=mode, chains_obj=chains_obj)
+    roof = None
+    if dom is not None:
+        # the general path's roofline kernel is always the filter's associative scan (the d x d block-affine combine north_star names)
+        g = "filter_scan" if mode == "general" and "filter_scan" in kernels else dom
+        k = kernels[g]
+        if k.get("algorithmic_GBps"):
+            key = f"kalman_C2_{args.dtype}_T{T}_d{d}_chains{C}_{mode}_{g}"
+            traffic, src = pmc_traffic(key)
+            roof = dict(bound="hbm", achieved=k["algorithmic_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(k["algorithmic_GBps"] / HBM_PEAK_GBPS, 4),
+                        traffic=traffic, traffic_source=src, kernel=f"{g} ({mode} path)", avg_launch_ms=k["ms_per_step"],
+                        launches=int(groups[g][0]), algorithmic_bytes_per_launch=k["algorithmic_bytes_per_step"],
+                        share_of_step=round(k["ms_per_step"] / (el / steps * 1e3), 3))
+            if mode == "general" and g == "filter_scan":
+                n = T - 1
+                k3 = C * n * ((3 * d * d + 2 * d) + (d * d + d)) * s  # SURVEY 8(d): the reference's unpacked (A, b, C, eta, J) elements
+                roof["k3_equivalent_GBps"] = round(k3 / (k["ms_per_step"] * 1e-3) / 1e9, 1)
+                roof["k3_equivalent_frac"] = round(roof["k3_equivalent_GBps"] / HBM_PEAK_GBPS, 4)
+    out["roofline"] = roof
+    return out
+
+
+def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
+    """BASELINE configs[2] = C3: SV d=1, auxiliary cSMC with independent proposals, backward sampling, in-kernel Threefry noise."""
     import ctypes as C
-    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd import random as R
     from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics, SVPotential
-    from aux_ssm_samplers_amd.parallel import gather_chains
-    T, N, Cn = args.T, args.N, args.chains
-    dtype = np.float32 if args.dtype == "f32" else np.float64
+    _lib, handle = ctx.lib, ctx.handle
     phi, q, xtrue, y = sv_data(T)
     M0 = GaussianInit(m0=[0.0], P0=[[q]])
     Mt = LinearGaussianDynamics(F=[[phi]], b=[0.0], Q=[[q]])
     fk = _device.describe_independent(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), Mt)
-    handle = _lib.default_handle(local_rank)
-    rng = np.random.Generator(np.random.PCG64(1000 + rank))
+    rng = np.random.Generator(np.random.PCG64(1000 + ctx.rank))
     x0 = (xtrue[None] + 0.1 * rng.standard_normal((Cn, T, 1))).astype(dtype)
     xd = handle.to_device(x0)
     anc = handle.zeros((Cn, T), np.int32)
@@ -100,7 +329,7 @@ def run_csmc(args, rank, world, local_rank, dist, torch, coll_dev):
     shd = handle.to_device(np.full(T, np.sqrt(0.25)), dtype)
     m = _lib.FkModel(fk.proposal, fk.potential, 1, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
                      fk.b.ctypes.data, fk.chol_Q.ctypes.data, yd.ptr.value, 1.0)
-    keys = R.split(R.PRNGKey(77 + rank), args.steps + args.warmup + 1)
+    keys = R.split(R.PRNGKey(77 + ctx.rank), steps + warmup + 1)
 
     def step(k):
         nz = _lib.CsmcNoise()
@@ -108,247 +337,255 @@ def run_csmc(args, rank, world, local_rank, dist, torch, coll_dev):
         _lib.check(handle.lib.auxssm_csmc_sweep(handle.h, _lib.dtype_code(dtype), C.byref(m), Cn, T, N, 1, shd.ptr, xd.ptr,
                                                 C.byref(nz), anc.ptr, None, None, None))
 
-    def barrier():
-        handle.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        handle.sync()
-
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    handle.prof_enable(_lib.K_CSMC_FWD, args.steps + 1)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    fn, fms = handle.prof_read()
-    handle.prof_disable()
-    moved = (anc.to_host() != 0).mean(axis=1)  # per-chain fraction of updated time steps
-    if dist is not None:
-        g = gather_chains(moved[:, None], Cn * world, dist, dst=0, device=coll_dev)
-        moved = g[:, 0] if rank == 0 else moved
-    if rank == 0:
-        s = np.dtype(dtype).itemsize
-        alg = Cn * T * N * (1 * s + s)  # forward pass writes xs + log_ws (As is not stored with backward sampling)
-        roof = None
-        if fn:
-            ach = alg / (fms / fn * 1e-3) / 1e9
-            roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4), traffic=None,
-                        kernel="k_csmc_fwd<float,1> (persistent forward pass)", avg_launch_ms=round(fms / fn, 3), launches=fn,
-                        algorithmic_bytes_per_launch=alg)
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:
-            from oracle import csmc as O
-            Tb = min(T, 4096)
-            r2 = np.random.default_rng(0)
-            od = dict(proposal=O.AUX_INDEPENDENT, potential=O.POT_SV, m0=[0.0], chol_P0=[[np.sqrt(q)]], F=[[phi]], b=[0.0], chol_Q=[[np.sqrt(q)]])
-            kw = dict(y=y[:Tb], sqrt_half_delta=np.full(Tb, 0.5), eps_aux=r2.standard_normal((Tb, 1)), eps_prop=r2.standard_normal((Tb, N, 1)),
-                      u_res=r2.random((Tb - 1, N)), u_bwd=r2.random(Tb))
-            t1 = time.perf_counter()
-            O.sweep(od, xtrue[:Tb], N, True, dtype=np.float32, **kw)
-            dt = time.perf_counter() - t1
-            cpu = dict(value=1.0 / (dt * T / Tb), unit="sweeps/s", cores=1, kind="port",
-                       sample=f"1 sweep of 1 chain at T={Tb} (scaled linearly to T={T}), N={N}, C oracle csmc_ref.c, {dt:.1f} s")
-        print(json.dumps({
-            "metric": "Gibbs sweeps/sec (auxiliary cSMC, backward sampling)", "value": round(Cn * world * args.steps / el, 2),
-            "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"C3: stochastic volatility d=1 T={T}, auxiliary cSMC N={N}, independent proposals, backward sampling",
-                       "chains_per_gpu": Cn, "delta": 0.5, "parallelism": f"chains x{world} (independent, no collective)"},
-            "updated_fraction": float(np.mean(moved)), "roofline": roof, "cpu_baseline": cpu}))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    el, groups = ctx.timed(step, steps, warmup)
+    moved = float((anc.to_host() != 0).mean())
+    s = np.dtype(dtype).itemsize
+    out = dict(workload=f"C3: stochastic volatility d=1 T={T}, auxiliary cSMC N={N}, independent proposals, backward sampling",
+               chains_per_gpu=Cn, steps=steps, value=round(Cn * ctx.world * steps / el, 2), unit="sweeps/s", ms_per_step=round(el / steps * 1e3, 3),
+               dtype="f32" if s == 4 else "f64", updated_fraction=moved)
+    kern = {}
+    alg = {"csmc_fwd": Cn * T * N * (1 * s + s),   # forward pass writes xs + log_ws (As is not stored with backward sampling)
+           "csmc_bwd": Cn * T * N * (1 * s + s)}   # backward sampling re-reads them
+    for g, (n, ms) in groups.items():
+        kern[g] = {"ms_per_step": round(ms / steps, 3)}
+        if g in alg:
+            kern[g]["algorithmic_GBps"] = round(alg[g] / (ms / steps * 1e-3) / 1e9, 1)
+    out["kernels"] = kern
+    if "csmc_fwd" in groups:
+        g = max(("csmc_fwd", "csmc_bwd"), key=lambda q_: kern.get(q_, {}).get("ms_per_step", 0))
+        ach = kern[g]["algorithmic_GBps"]
+        out["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
+                               kernel=f"k_{g} (persistent, one workgroup per chain)", avg_launch_ms=kern[g]["ms_per_step"],
+                               algorithmic_bytes_per_launch=alg[g])
+    if cpu:
+        from oracle import csmc as O
+        Tb = min(T, 4096)
+        r2 = np.random.default_rng(0)
+        od = dict(proposal=O.AUX_INDEPENDENT, potential=O.POT_SV, m0=[0.0], chol_P0=[[np.sqrt(q)]], F=[[phi]], b=[0.0], chol_Q=[[np.sqrt(q)]])
+        kw = dict(y=y[:Tb], sqrt_half_delta=np.full(Tb, 0.5), eps_aux=r2.standard_normal((Tb, 1)), eps_prop=r2.standard_normal((Tb, N, 1)),
+                  u_res=r2.random((Tb - 1, N)), u_bwd=r2.random(Tb))
+        t1 = time.perf_counter()
+        O.sweep(od, xtrue[:Tb], N, True, dtype=np.float32, **kw)
+        dt = time.perf_counter() - t1
+        out["cpu_baseline"] = dict(value=round(1.0 / (dt * T / Tb), 4), unit="sweeps/s", cores=1, kind="port",
+                                   sample=f"1 sweep of 1 chain at T={Tb} (scaled linearly to T={T}), N={N}, oracle/csmc_ref.c, {dt:.1f} s")
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chains", type=int, default=256, help="chains per GPU (SURVEY 8d lists 1, 8, 64, 256 for C2)")
-    ap.add_argument("--T", type=int, default=65536)
-    ap.add_argument("--d", type=int, default=4)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-prof", action="store_true", help="do not bracket the scan with HIP events")
-    ap.add_argument("--no-share-model", action="store_true",
-                    help="force the general per-chain path (AUXSSM_OPT_SHARE_MODEL = 0): nothing is hoisted out of the chain loop even though "
-                         "the parameters of this linear-Gaussian model are the same for every chain")
-    ap.add_argument("--no-general-leg", action="store_true", help="skip the extra (untimed-for-value) run of the general per-chain path")
-    ap.add_argument("--workload", default="kalman", choices=["kalman", "csmc"],
-                    help="kalman = BASELINE configs[1] (C2, the headline); csmc = configs[2] (C3), secondary")
-    ap.add_argument("--N", type=int, default=1024, help="particles (csmc workload)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="nccl (= RCCL, one rank per GPU) is what the driver runs; gloo + ranks sharing a GPU is a rehearsal mode")
-    args = ap.parse_args()
-    if args.workload == "csmc" and args.dtype == "f64" and "--dtype" not in " ".join(sys.argv):
-        args.dtype = "f32"
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    import torch
-    ndev = torch.cuda.device_count()
-    if args.dist_backend == "gloo":
-        local_rank = local_rank % max(ndev, 1)  # rehearsal: ranks may share a GPU
-    launched = "RANK" in os.environ and "MASTER_ADDR" in os.environ  # under torch.distributed.run: initialise the group even for one rank
-    if world > 1 or launched:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        if args.dist_backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("gloo")
-    else:
-        torch.cuda.set_device(local_rank)
-    coll_dev = torch.device("cuda", local_rank) if args.dist_backend == "nccl" else torch.device("cpu")
-
-    if args.workload == "csmc":
-        return run_csmc(args, rank, world, local_rank, dist, torch, coll_dev)
-
-    from aux_ssm_samplers_amd import _lib, random as R
+def leg_c4(ctx, total_chains=64, T=16384, N=512, steps=20, warmup=3):
+    """BASELINE configs[3] = C4: Lorenz-63 T=16384, aux-Kalman sweep (extended linearisation on device) and cSMC N=512, a FIXED total of
+    `total_chains` chains sharded over the ranks (parallel.shard_chains: 64 -> 8 per GPU on 8 GPUs): strong scaling."""
+    from tests.helpers import lorenz_kalman_setup, lorenz_setup
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.parallel import shard_chains, chain_key
     from aux_ssm_samplers_amd.kalman import get_kernel
     from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
-
-    dtype = np.float64 if args.dtype == "f64" else np.float32
-    T, d, C = args.T, args.d, args.chains
-    handle = _lib.default_handle(local_rank)
-    m, model = build_model(T, d, dtype)
+    from aux_ssm_samplers_amd.csmc import CsmcChains, CSMCState
+    from aux_ssm_samplers_amd._primitives.csmc import get_kernel as get_csmc_kernel
+    handle = ctx.handle
+    lo, hi = shard_chains(total_chains, ctx.rank, ctx.world)
+    Cn = hi - lo
+    out = dict(workload=f"C4: Lorenz-63 T={T} dt=1.25e-4, (x2, x3) observed every 80 steps, fp32", total_chains=total_chains,
+               chains_this_rank=Cn, scaling="strong", parallelism=f"{total_chains} chains block-partitioned over {ctx.world} rank(s), no collective")
+    model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
-    rng = np.random.Generator(np.random.PCG64(1000 + rank))
-    x0 = (m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
-    chains = DeviceChains(handle, x0)
-    state = KalmanSampler(x=chains, updated=None)
+    ch = DeviceChains(handle, np.repeat(xtrue[None], Cn, axis=0).astype(np.float32))
+    st = KalmanSampler(x=ch, updated=None)
+    keys = R.split(chain_key(R.PRNGKey(4), lo), steps + warmup + 1)  # the rank's stream is folded from its first global chain id
+    el, groups = ctx.timed(lambda k: kernel(keys[k], st, 1e-4), steps, warmup)
+    acc = ctx.sum_over_ranks(float(ch.accepted.to_host().sum())) / total_chains
+    s = 4
+    d, po = 3, 2
+    # fused-sweep lower bound of SURVEY 8(d): x, eps_aux, eps_samp read, x' written per chain-step (the linearised F_t, b_t are functions of x)
+    alg = Cn * T * 4 * d * s
+    out["kalman"] = dict(value=round(total_chains * steps / el, 1), unit="sweeps/s", ms_per_step=round(el / steps * 1e3, 4), steps=steps,
+                         accept_rate=round(acc, 3), layout="chain-minor" if ch.chain_minor else "dense",
+                         kernels={g: round(ms / steps, 4) for g, (n, ms) in groups.items()},
+                         roofline=dict(bound="hbm", achieved=round(alg / (el / steps) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                       frac=round(alg / (el / steps) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None,
+                                       kernel="whole sweep (about 40 dependent launches; latency-bound at 8 chains per GPU)",
+                                       algorithmic_bytes_per_launch=alg))
+    del ch
+    M0, Mt, G0, Gt, xt, y, sig_y = lorenz_setup(T, every=80, dt=1.25e-4)
+    init, ck = get_csmc_kernel(M0, G0, Mt, Gt, N, backward=True, Pt=Mt)
+    cc = CsmcChains(handle, np.repeat(xt[None], Cn, axis=0).astype(np.float32))
+    cst = CSMCState(x=cc, updated=None)
+    ckeys = R.split(chain_key(R.PRNGKey(5), lo), 8)
+    csteps = 3
+    el, groups = ctx.timed(lambda k: ck(ckeys[k], cst), csteps, 1)
+    alg = Cn * T * N * (d * s + s)
+    fwd = groups.get("csmc_fwd", (0, 0.0))[1] / csteps
+    out["csmc"] = dict(value=round(total_chains * csteps / el, 2), unit="sweeps/s", ms_per_step=round(el / csteps * 1e3, 3), steps=csteps, particles=N,
+                       updated_fraction=float((cc.ancestors.to_host() != 0).mean()),
+                       kernels={g: round(ms / csteps, 3) for g, (n, ms) in groups.items()},
+                       roofline=None if not fwd else dict(bound="hbm", achieved=round(alg / (fwd * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                                          frac=round(alg / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None,
+                                                          kernel="k_csmc_fwd<float,3>", avg_launch_ms=round(fwd, 3), algorithmic_bytes_per_launch=alg))
+    return out
+
+
+def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
+    """BASELINE configs[4] = C5: dense d = p = 64, T = 8192, fp32 -- the wide-state filter (MFMA d x d combine), one sequence (latency) and
+    16 sequences per launch (throughput), resident in HBM.  Roofline = MFMA: SURVEY 8(d)'s K3 flops 2 n 19.3 d^3 per scan / scan time."""
+    import ctypes as C
+    from tests.helpers import c5_model
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    _lib, handle = ctx.lib, ctx.handle
+    u, lg64, x = c5_model(T, d)
+    f32 = np.float32
+    out = dict(workload=f"C5: dense LG-SSM d=p={d} T={T} fp32, first-order auxiliary observations, wide-state filter (parallel scan)", runs=[])
+    for S in seqs:
+        dl = DeviceLGSSM(handle, tuple(lg64), 1, T, 1, d, d, False, f32)  # chain-shared parameters (stride 0), S sequences of observations
+        ys = np.ascontiguousarray(np.broadcast_to(u.astype(f32)[None], (S, T, d)))
+        yd = handle.to_device(ys)
+        yarr = yd.arr(T * d, d, 0)
+        ms = handle.empty((S, T, 1, d), f32)
+        Ps = handle.empty((S, T, 1, d, d), f32)
+        ell = handle.empty((S,), f32)
+        dims = _lib.Dims(S, T, 1, d, d)
+
+        def step(k):
+            _lib.check(handle.lib.auxssm_kalman_filter(handle.h, _lib.F32, C.byref(dims), C.byref(dl.c), C.byref(yarr), 1, ms.ptr, Ps.ptr, ell.ptr))
+
+        el, groups = ctx.timed(step, steps, 1)
+        scan = groups.get("filter_scan", (0, 0.0))[1] / steps
+        flops = S * 2 * (T - 1) * 19.3 * d ** 3
+        ent = dict(sequences_per_launch=S, filters_per_s=round(S * ctx.world * steps / el, 2), ms_per_filter_call=round(el / steps * 1e3, 3),
+                   kernels={g: round(t / steps, 3) for g, (n, t) in groups.items()})
+        if scan:
+            tf = flops / (scan * 1e-3) / 1e12
+            ent["roofline"] = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
+                                   traffic=None, kernel="wide filter scan (wk_scan_reduce + aggregate levels + wk_scan_down)", avg_launch_ms=round(scan, 3),
+                                   algorithmic_flops_per_launch=flops)
+        out["runs"].append(ent)
+        del dl, yd, ms, Ps, ell
+    return out
+
+
+def cpu_baseline_c2(T, d, budget_s=12.0):
+    """oracle/kalman_seq.c (the reference's sequential sweep, its CPU code path) on this box's host cores: all cores and one thread."""
+    from oracle import kalman_seq as S
+    from tests.helpers import lg_model
+    m = lg_model(T, d)
+    cm = S.Model(m["m0"], m["P0"], m["F"], m["Q"], m["b"], m["Hobs"], m["Robs"], m["cobs"], m["y"])
+    ncore = os.cpu_count() or 1
+    nthr = min(S.max_threads(), ncore)
+    rng = np.random.default_rng(0)
+
+    def run(Cn, nt):
+        x = m["x_true"][None] + 0.3 * rng.standard_normal((Cn, T, d))
+        ea, es, ua = rng.standard_normal((Cn, T, d)), rng.standard_normal((Cn, T, d)), rng.random(Cn)
+        S.sweep(cm, x[:1], 0.5, ea[:1], es[:1], ua[:1], nthreads=1)  # warm the pages
+        reps, t0 = 0, time.perf_counter()
+        while True:
+            S.sweep(cm, x, 0.5, ea, es, ua, nthreads=nt)
+            reps += 1
+            el = time.perf_counter() - t0
+            if el > budget_s / 2 or reps >= 5:
+                return Cn * reps / el, reps, el
+
+    v1, r1, e1 = run(1, 1)
+    vn, rn, en = run(2 * nthr, nthr)
+    return dict(value=round(vn, 3), unit="sweeps/s", cores=nthr, kind="port", single_thread_value=round(v1, 3), host_cpus=ncore,
+                sample=(f"oracle/kalman_seq.c (C restatement of the reference's sequential filter / sampler sweep, its CPU path; not JAX): {rn} x {2 * nthr} chains "
+                        f"on {nthr} OpenMP threads in {en:.1f} s; 1 thread: {r1} sweep(s) in {e1:.1f} s; same T={T} d={d} fp64 workload"))
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    res = resolve_launch(args, argv, os.environ)
+    if res[0] == "error":
+        print("bench.py: " + res[1], file=sys.stderr)
+        return 2
+    if res[0] == "spawn":
+        # nothing in this process has touched the GPU (torch is not even imported): start the ranks as children and pass their code on
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        return subprocess.call(res[1], env=env)
+    _, rank, world, local_rank = res
+    ctx = Ctx(args, rank, world, local_rank)
+    assert ctx.world == args.gpus
+    sec_on = [] if args.no_secondary else [s for s in args.secondary.split(",") if s]
+
+    if args.workload == "csmc":
+        r = leg_c3_csmc(ctx, args.T, args.N, args.chains, args.steps, args.warmup, np.float32 if args.dtype == "f32" else np.float64,
+                        cpu=not args.no_cpu_baseline and world == 1 and rank == 0)
+        if rank == 0:
+            print(json.dumps({
+                "metric": "Gibbs sweeps/sec (auxiliary cSMC, backward sampling)", "value": r["value"], "unit": "sweeps/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": r["dtype"], "data": "synthetic",
+                "config": {"workload": r["workload"], "chains_per_gpu": args.chains, "delta": 0.5, "parallelism": f"chains x{world} (independent, no collective)"},
+                "updated_fraction": r["updated_fraction"], "kernels": r["kernels"], "roofline": r.get("roofline"), "cpu_baseline": r.get("cpu_baseline")}))
+        ctx.close()
+        return 0
+
     share = not args.no_share_model
-    handle.set_option(_lib.OPT_SHARE_MODEL, int(share))
-    key = R.PRNGKey(2024 + rank)
-    delta = 0.5
+    main_leg = leg_c2(ctx, args, share, args.steps, args.warmup)
+    chains, kernel = main_leg["chains_obj"]
 
-    def barrier():
-        handle.sync()
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        handle.sync()
-        torch.cuda.synchronize()
-
-    keys = R.split(key, args.steps + args.warmup + 1)
-
-    def step(k):
-        kernel(keys[k], state, delta)
-
-    for k in range(args.warmup):
-        step(k)
-    barrier()
-    if not args.no_prof:
-        handle.prof_enable(_lib.K_FILTER_SCAN, args.steps + 1)
-    barrier()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(args.warmup + k)
-    barrier()
-    el = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([el], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        el = float(t.item())
-    scan_n, scan_ms = (0, 0.0)
-    if not args.no_prof:
-        scan_n, scan_ms = handle.prof_read()
-        handle.prof_disable()
-
-    # second leg (reported beside the headline, never as `value`): the same workload on the general per-chain path, i.e. what a
-    # model with chain-specific parameters (any nonlinear model: a linearisation per chain) costs
     general = None
-    if share and not args.no_general_leg and not args.no_prof:
-        handle.set_option(_lib.OPT_SHARE_MODEL, 0)
-        gsteps = max(3, args.steps // 2)
-        step(args.warmup + args.steps)  # warm the other code path (workspace, code objects)
-        barrier()
-        handle.prof_enable(_lib.K_FILTER_SCAN, gsteps + 1)
-        barrier()
-        g0 = time.perf_counter()
-        for k in range(gsteps):
-            step(k % (args.steps + args.warmup))
-        barrier()
-        gel = time.perf_counter() - g0
-        if dist is not None:
-            t = torch.tensor([gel], dtype=torch.float64, device=coll_dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            gel = float(t.item())
-        gn, gms = handle.prof_read()
-        handle.prof_disable()
-        handle.set_option(_lib.OPT_SHARE_MODEL, 1)
-        general = dict(steps=gsteps, value=C * world * gsteps / gel, ms_per_step=gel / gsteps * 1e3, scan_ms=gms / max(gn, 1))
+    if share and not args.no_general_leg and not args.no_prof and main_leg["mode"] == "shared":
+        general = leg_c2(ctx, args, False, max(3, args.steps // 2), 1, chains_obj=main_leg["chains_obj"])
 
     # the trivial chain-gather (RCCL): acceptance flags + last log-alphas of every chain to rank 0
     from aux_ssm_samplers_amd.parallel import gather_chains
     acc = chains.accepted.to_host()
     logs = chains.logs.to_host()
-    if dist is not None:
+    C = args.chains
+    if ctx.dist is not None:
         per_chain = np.concatenate([acc[:, None].astype(np.float64), logs.astype(np.float64)], axis=1)  # (C, 6)
-        g = gather_chains(per_chain, C * world, dist, dst=0, device=coll_dev)
+        g = gather_chains(per_chain, C * world, ctx.dist, dst=0, device=ctx.coll_dev)
         if rank == 0:
             acc, logs = g[:, 0], g[:, 1:]
+    del chains, kernel
+    main_leg.pop("chains_obj")
+    if general is not None:
+        general.pop("chains_obj")
+
+    secondary = {}
+    for name in sec_on:
+        try:
+            small = args.small_secondary
+            if name == "c3":
+                secondary["C3_csmc"] = leg_c3_csmc(ctx, 2048 if small else 65536, 128 if small else 1024, 8 if small else 256, 2, 1,
+                                                   cpu=not args.no_cpu_baseline and world == 1 and rank == 0)
+            elif name == "c4":
+                secondary["C4_lorenz"] = leg_c4(ctx, 8, 1040, 64, 3, 1) if small else leg_c4(ctx)
+            elif name == "c5":
+                secondary["C5_wide"] = leg_c5(ctx, 96, 64, (1, 2), 2) if small else leg_c5(ctx)
+        except Exception as e:  # a secondary leg never takes the headline down; the failure is reported in the line
+            secondary[name] = {"error": f"{type(e).__name__}: {e}"}
+            ctx.barrier()
 
     if rank == 0:
-        s = np.dtype(dtype).itemsize
-        n = T - 1
-        # the timed group = the filter's associative scan (K3: read n(3d^2+2d)s, write n(d^2+d)s per chain); the marginal
-        # log-likelihood (K4, filtering.py:60-62) rides along as the elements' log-scale, so it adds no algorithmic bytes
-        alg_bytes = C * (n * (3 * d * d + 2 * d) * s + n * (d * d + d) * s)
-        roof = None
-        traffic = None  # HBM bytes per launch group from the PMC passes committed under profiles/ (same config only)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            ent = tj.get(f"kalman_C2_{args.dtype}_T{T}_d{d}_chains{C}" + ("_shared_model" if share else ""), {})
-            traffic = ent.get("filter_scan_group_hbm_bytes")
-        except Exception:
-            pass
-        if scan_n:
-            avg_s = scan_ms / scan_n * 1e-3
-            ach = alg_bytes / avg_s / 1e9
-            roof = dict(bound="hbm", achieved=round(ach, 1), peak=8000.0, unit="GB/s", frac=round(ach / 8000.0, 4),
-                        traffic=traffic, kernel="filter associative scan incl. the marginal log-likelihood (k_scan_reduce_cm + k_scan_aggs + k_scan_down_cm, " +
-                               ("FilterOpShared: element matrices read once per time step, (b, eta, z) per chain)" if share else "FilterOp: general per-chain elements)"),
-                        avg_launch_ms=round(scan_ms / scan_n, 4), launches=scan_n, algorithmic_bytes_per_launch=alg_bytes)
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(T, d)
+            cpu = cpu_baseline_c2(args.T, args.d)
+        T, d = args.T, args.d
         out = {
-            "metric": "Gibbs sweeps/sec (aux-Kalman, parallel-in-time scan)", "value": round(C * world * args.steps / el, 2),
+            "metric": "Gibbs sweeps/sec (aux-Kalman, parallel-in-time scan)", "value": round(main_leg["value"], 2),
             "unit": "sweeps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(el / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": round(main_leg["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C2: linear-Gaussian SSM T={T} d={d} p={2 * d}, aux-Kalman sweep, parallel scan",
-                       "chains_per_gpu": C, "delta": delta, "parallelism": f"chains x{world} (independent, no collective)"},
+                       "chains_per_gpu": C, "delta": 0.5, "parallelism": f"chains x{world} (independent, no collective)",
+                       "model_sharing": ("chain-shared model parameters hoisted out of the chain loop (jax.vmap semantics)" if main_leg["mode"] == "shared"
+                                         else "off: general per-chain path")},
             "accept_rate": float(np.mean(acc)), "max_abs_log_alpha": float(np.max(np.abs(logs[:, 0]))),
-            "roofline": roof, "cpu_baseline": cpu,
+            "roofline": main_leg["roofline"], "kernels": main_leg["kernels"], "cpu_baseline": cpu,
         }
-        out["config"]["model_sharing"] = ("chain-shared model parameters hoisted out of the chain loop (jax.vmap semantics)" if share
-                                          else "off: general per-chain path")
         if general is not None:
-            gach = alg_bytes / (general["scan_ms"] * 1e-3) / 1e9 if general["scan_ms"] else None
-            out["general_path"] = {"value": round(general["value"], 2), "unit": "sweeps/s", "steps": general["steps"],
-                                   "ms_per_step": round(general["ms_per_step"], 4), "scan_avg_launch_ms": round(general["scan_ms"], 4),
-                                   "scan_achieved_GBps": None if gach is None else round(gach, 1),
-                                   "scan_frac": None if gach is None else round(gach / 8000.0, 4),
+            out["general_path"] = {"value": round(general["value"], 2), "unit": "sweeps/s", "ms_per_step": round(general["ms_per_step"], 4),
+                                   "roofline": general["roofline"], "kernels": general["kernels"],
                                    "note": "same workload with AUXSSM_OPT_SHARE_MODEL = 0: every chain builds and combines its own d x d elements"}
+        if secondary:
+            out["secondary"] = secondary
         print(json.dumps(out))
-    if dist is not None:
-        dist.barrier()
-        dist.destroy_process_group()
+    ctx.close()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 100
+#define AUXSSM_VERSION 101
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -93,9 +93,12 @@ int auxssm_memcpy_d2d(auxssm_handle h, void* dst, const void* src, size_t bytes)
 int auxssm_memset(auxssm_handle h, void* dst, int value, size_t bytes);           /* async on stream */
 
 /* ---- in-library kernel timing with HIP events on the handle's stream ----------------------------
- * kernel_id: one of AUXSSM_K_*.  While enabled, every launch of that kernel is bracketed by a pair of
- * events from a pool of `max_launches`; read() synchronises and returns the count and the summed ms. */
+ * kernel_id: one of AUXSSM_K_*.  While enabled, every launch of that kernel group is bracketed by a pair of
+ * events from a pool of `max_launches`; read() synchronises and returns the count and the summed ms.
+ * AUXSSM_K_ALL brackets every group; read_groups() then returns launches[id] / total_ms[id] for id < n_ids
+ * (the event pairs serialise nothing: groups run back to back on one stream anyway). */
 typedef enum {
+    AUXSSM_K_ALL = -1,
     AUXSSM_K_NONE = 0,
     AUXSSM_K_FILTER_INIT = 1,
     AUXSSM_K_FILTER_SCAN = 2, /* the three launches of the filter's associative scan, timed as one unit */
@@ -105,10 +108,16 @@ typedef enum {
     AUXSSM_K_LOGPDF = 6,
     AUXSSM_K_CSMC_FWD = 7,
     AUXSSM_K_CSMC_BWD = 8,
-    AUXSSM_K_PIT_STITCH = 9 /* the log2(T) stitching launches of the parallel-in-time cSMC sweep, timed as one unit */
+    AUXSSM_K_PIT_STITCH = 9, /* the log2(T) stitching launches of the parallel-in-time cSMC sweep, timed as one unit */
+    AUXSSM_K_RNG = 10,       /* Threefry fills (auxssm_rng_*, auxssm_kalman_draw) */
+    AUXSSM_K_SELECT = 11,    /* accept / select step (+ running moments) of the Kalman sweep */
+    AUXSSM_K_FACTORY = 12,   /* device factories of a sweep: concatenated / linearised model, observation tables */
+    AUXSSM_K_FILTER_TAB = 13,/* chain-shared model: the one-sequence matrix filter and the gain tables derived from it */
+    AUXSSM_K_COUNT = 14
 } auxssm_kernel_id;
 int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches);
 int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms);
+int auxssm_prof_read_groups(auxssm_handle h, int n_ids, int* launches /* [n_ids] */, double* total_ms /* [n_ids] */);
 int auxssm_prof_disable(auxssm_handle h);
 
 /* ---- Kalman primitives --------------------------------------------------------------------------
@@ -270,7 +279,10 @@ int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t 
  * auxssm_stats_attach: from now on the accept/select step of every auxssm_kalman_sweep on this handle also folds the sweep into the
  *   running means  sq_jump <- (i sq_jump + (x' - x)^2) / (i + 1),  mean <- (i mean + x') / (i + 1),  sq_mean <- (i sq_mean + x'^2) / (i + 1)
  *   (x the state before the sweep, x' after), arrays of x's shape, layout and dtype, and advances i by one; `iter` sets i for the next
- *   sweep.  All three NULL detaches.  The fold costs no extra pass over x.
+ *   sweep.  The moments are bound to ONE resident state: `x` is its device pointer (the `x` argument of the sweeps to fold), `n` = C*T*dx
+ *   its element count, `dtype` its type; while attached, an auxssm_kalman_sweep on this handle over any other state (pointer, size or
+ *   dtype) returns AUXSSM_ERR_ARG instead of folding.  All three moment pointers NULL detaches (dtype, n, x ignored).  The fold costs no
+ *   extra pass over x.
  * auxssm_stats_update: the same fold as a standalone pass over n = C*T*dx elements (cSMC sweeps: keep a copy of x before the sweep).
  * auxssm_accept_update: flags (C, m) int32, nonzero = updated (`accepted` of a Kalman sweep, m = 1; `ancestors` of a cSMC sweep,
  *   m = T, csmc.py:59):  avg <- (i avg + f) / (i + 1),  window <- beta f + (1 - beta) window,  both (C, m) of `dtype`.
@@ -281,7 +293,7 @@ int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t 
  *   linear regressions of dx - dt phi_0(x) on dt phi(x), prior N(0, sigma_theta^2)), then theta = mean + chol * eps
  *   (experiment.py:112-113).  x (C, T, 3) dense or (T, 3, C) chain-minor (`layout`, as the sweep's); eps (C, 3) ~ N(0, 1); par (C, 4) rows [theta1, theta2, theta3, dt]: dt is read, theta
  *   overwritten -- the array model->Fs points at for AUXSSM_KMODEL_LORENZ63_EXT (chain stride 4).  mean_chol (C, 6) out, may be NULL. */
-int auxssm_stats_attach(auxssm_handle h, void* sq_jump, void* mean, void* sq_mean, int64_t iter);
+int auxssm_stats_attach(auxssm_handle h, int dtype, int64_t n, const void* x, void* sq_jump, void* mean, void* sq_mean, int64_t iter);
 int auxssm_stats_update(auxssm_handle h, int dtype, int64_t n, int64_t iter, const void* x_prev, const void* x_next, void* sq_jump,
                         void* mean, void* sq_mean);
 int auxssm_accept_update(auxssm_handle h, int dtype, int32_t C, int32_t m, int64_t iter, double beta, const int32_t* flags, void* avg,
@@ -297,6 +309,15 @@ int auxssm_lorenz_theta_update(auxssm_handle h, int dtype, int32_t C, int32_t T,
  * completes resamplings.py.  Same cumsum order as the multinomial path (bit-exact vs oracle/csmc_ref.c::csmc_ref_systematic). */
 int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t rows, int32_t M, int32_t N, const void* weights, const void* uvw,
                                int32_t* indices);
+
+/* auxssm_mvn_logpdf == mvn.logpdf(x, m, chol) (_primitives/math/mvn/base.py:15-58, with tril_log_det :108-128) for n independent triplets of
+ * dimension dim <= 64: x, m (dim), chol (dim, dim) lower-triangular row-major, triplet g at x + g sx, m + g sm, chol + g sl (ELEMENT strides;
+ * 0 broadcasts).  Reference semantics, IEEE-literal: non-finite entries of chol act as +inf in the forward substitution, the dimension
+ * counts the finite diagonal entries only, non-finite diagonal entries drop out of the log-determinant.  out (n).
+ * Inside the filter / log-density kernels the same function is csrc/kalman_math.h::gauss_logpdf; this is its standalone export
+ * (aux_samplers.mvn.logpdf, reference aux_samplers/__init__.py:3). */
+int auxssm_mvn_logpdf(auxssm_handle h, int dtype, int64_t n, int32_t dim, const void* x, int64_t sx, const void* m, int64_t sm, const void* chol,
+                      int64_t sl, void* out);
 
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see
