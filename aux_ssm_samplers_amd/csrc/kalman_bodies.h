@@ -109,8 +109,8 @@ struct FilterArgs {
     void* ellz;     // [S] log-scale of the whole scan = sum of the increments of t = 1..T-1 (written by the final pass)
     ScanLayout lay;
     int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
-    const void* tab = nullptr;  // chain-shared parameters: one FiltShared row per transition (else null)
-    void* pc = nullptr;         // ... and the per-chain element parts [i][b | eta | z][s]
+    const void* tab = nullptr;  // chain-shared parameters: one GainRow per transition (affine_shared.h; else null)
+    void* pc = nullptr;         // (unused)
     // Concatenated auxiliary observations built on the fly (sweep of the LG_CONCAT model, shared mode): for t >= 1 the observation
     // is y_t = [u_t ; yobs_t] with u = x + aux_shd * eps (kalman/generic.py:59-63); u is written to aux_u, ys holds row t = 0 only.
     int aux_on = 0;
@@ -292,131 +292,8 @@ template <typename R> using UniformRow = const __attribute__((address_space(4)))
 template <typename R> __device__ __forceinline__ UniformRow<R> uniform_row(const R* p) { return (UniformRow<R>)(unsigned long long)p; }
 #else
 template <typename R> using UniformRow = const R*;
-template <typename R> inline UniformRow<R> uniform_row(const R* p) { return p; }
+template <typename R> AX_HD UniformRow<R> uniform_row(const R* p) { return p; }
 #endif
-
-// ---- chain-shared model parameters (kalman_math.h::FiltShared) ---------------------------------------------------------------
-// table row of transition i -> i + 1, from chain 0's view of the shared parameters (the observation mask is the data's)
-template <typename R, int D, int P> AX_HD void body_filter_shared_tab(const FilterArgs& a, int i) {
-    using T = FiltShared<R, D, P>;
-    const long long t = (long long)i + 1;
-    R F[D * D], bd[D], P_[D * D], H[P * D], cv[P], y[P], Rm[P * P];
-    rd<R, D * D>(a.Fs, 0, i, 0, F);
-    rd<R, D>(a.bs, 0, i, 0, bd);
-    rd<R, D * D>(a.Qs, 0, i, 0, P_);
-    rd<R, P * D>(a.Hs, 0, t, 0, H);
-    rd<R, P>(a.cs, 0, t, 0, cv);
-    if (a.aux_on) {  // only the observation mask matters here: the auxiliary part is always present, the rest is the data's
-#pragma unroll
-        for (int k = 0; k < P; ++k) y[k] = k < D ? (R)0 : at<R>(a.aux_yobs, 0, t, 0)[k - D];
-    } else {
-        rd<R, P>(a.ys, 0, t, 0, y);
-    }
-    rd_upper<R, P>(a.Rs, 0, t, 0, Rm);
-    if (i == 0) {  // P_ = F P0+ F^T + Q, not symmetrised (filtering.py:200-201)
-        R P0p[D * D], FP[D * D], Pn[D * D];
-        rd<R, D * D>(a.Ps, 0, 0, 0, P0p);
-        mm<R, D, D, D>(F, P0p, FP);
-        mmt<R, D, D, D>(FP, F, Pn);
-#pragma unroll
-        for (int k = 0; k < D * D; ++k) P_[k] = Pn[k] + P_[k];
-    }
-    R row[T::N];
-    filter_shared_row<R, D, P>(F, bd, P_, H, cv, Rm, y, row);
-    stv<R, T::N>((R*)a.tab + (long long)i * T::NPAD, row);
-}
-// per-chain part of element i: b = m_ + K r_m, eta = Ke r_b, z = -1/2 r_m^T S^-1 r_m + c0
-template <typename R, int D, int P> AX_HD void body_filter_init_shared(const FilterArgs& a, int s, int i) {
-    using T = FiltShared<R, D, P>;
-    const int c = s / a.d.B, b = s % a.d.B;
-    const long long t = (long long)i + 1;
-    const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
-    R y[P], rb[P], rm[P], m_[D];
-    if (a.aux_on) {
-        if constexpr (P > D) {
-            R xv[D], ev[D], uv[D];
-            rd<R, D>(a.aux_x, c, t, b, xv);
-            rd<R, D>(a.aux_eps, c, t, b, ev);
-#pragma unroll
-            for (int k = 0; k < D; ++k) uv[k] = xv[k] + (R)a.aux_shd * ev[k], y[k] = uv[k];
-            wr<R, D>(a.aux_u, c, t, b, uv);
-#pragma unroll
-            for (int k = D; k < P; ++k) y[k] = at<R>(a.aux_yobs, 0, t, 0)[k - D];
-        }
-    } else {
-        rd<R, P>(a.ys, c, t, b, y);
-    }
-#pragma unroll
-    for (int k = 0; k < P; ++k) rb[k] = finite_(y[k]) ? y[k] - row[T::oYm + k] : (R)0, rm[k] = rb[k];
-#pragma unroll
-    for (int k = 0; k < D; ++k) m_[k] = row[T::oMd + k];
-    if (i == 0) {  // built around predict(m0+, P0+): m_ = b_dyn + F m0+, r_m = r_b - H F m0+
-        R m0p[D], F[D * D], Fm[D];
-        rd<R, D>(a.ms, c, 0, b, m0p);
-        rd<R, D * D>(a.Fs, 0, 0, 0, F);
-        mv<R, D, D>(F, m0p, Fm);
-#pragma unroll
-        for (int k = 0; k < D; ++k) m_[k] += Fm[k];
-#pragma unroll
-        for (int k = 0; k < P; ++k) {
-            R hf = 0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) hf += row[T::oHF + k * D + j] * m0p[j];
-            rm[k] = finite_(y[k]) ? rb[k] - hf : (R)0;
-        }
-    }
-    R out[T::NPC];
-#pragma unroll
-    for (int j = 0; j < D; ++j) {
-        R sb_ = m_[j], se_ = 0;
-#pragma unroll
-        for (int k = 0; k < P; ++k) sb_ += row[T::oK + j * P + k] * rm[k], se_ += row[T::oKe + j * P + k] * rb[k];
-        out[j] = sb_;
-        out[D + j] = se_;
-    }
-    R q = 0;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        R sk = 0;
-#pragma unroll
-        for (int l = 0; l < P; ++l) sk += row[T::oSi + sidx(P, k, l)] * rm[l];
-        q += rm[k] * sk;
-    }
-    out[2 * D] = (R)-0.5 * q + row[T::oC0];
-    sts_<R, T::NPC>((R*)a.pc + (long long)i * T::NPC * a.lay.S + s, a.lay.S, out);
-}
-// FilterOp whose elements are split: matrices from the shared table (wave-uniform loads), (b, eta, z) per chain
-template <typename R_, int D, int P> struct FilterOpShared : FilterOp<R_, D> {
-    using R = R_;
-    using Full = typename FilterOp<R_, D>::Full;
-    static constexpr int DS = symsize(D);
-    static AX_HD void load_elem(const FilterArgs& a, int s, int i, Full& e) {
-        using T = FiltShared<R, D, P>;
-        // plain (vector) loads here: the scan kernels issue the next element's reads before the combine, which scalar loads into
-        // SGPRs cannot do for 36 doubles (measured: 0.85 -> 1.65 ms with scalar loads)
-        const R* row = (const R*)a.tab + (long long)i * T::NPAD;
-#pragma unroll
-        for (int k = 0; k < D * D; ++k) e.A[k] = row[T::oA + k];
-#pragma unroll
-        for (int k = 0; k < DS; ++k) e.C[k] = row[T::oC + k], e.J[k] = row[T::oJ + k];
-        R pc[T::NPC];
-        lds_<R, T::NPC>((const R*)a.pc + (long long)i * T::NPC * a.lay.S + s, a.lay.S, pc);
-#pragma unroll
-        for (int k = 0; k < D; ++k) e.b[k] = pc[k], e.eta[k] = pc[D + k];
-        e.z = pc[2 * D];
-    }
-    // the filtered covariances are the same for every chain: only chain 0's copy is written (the sampler's table reads that one)
-    static AX_HD void write_out(const FilterArgs& a, int s, int i, const typename FilterOp<R_, D>::Pre& p) {
-        const int c = s / a.d.B, b = s % a.d.B;
-        wr<R, D>(a.ms, c, (long long)i + 1, b, p.b);
-        if (s == 0) {
-            R Pd[D * D];
-            symunpack<R, D>(p.C, Pd);
-            wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
-        }
-        if (i == a.d.n() - 1 && a.ellz) ((R*)a.ellz)[s] = p.z;
-    }
-};
 
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SampleArgs {
@@ -586,31 +463,6 @@ template <typename R, int D> AX_HD void body_sample_shared_tab(const SampleArgs&
     sample_shared_row<R, D>(F, Q, bd, Pd, last, row);
     stv<R, T::N>((R*)a.tab + (long long)t * T::NPAD, row);
 }
-template <typename R_, int D> struct SampleOpShared : SampleOp<R_, D> {
-    using R = R_;
-    using Full = typename SampleOp<R_, D>::Full;
-    static AX_HD void load_elem(const SampleArgs& a, int s, int j, Full& e) {
-        using T = SampShared<R, D>;
-        const int c = s / a.d.B, b = s % a.d.B;
-        const long long t = (long long)a.d.T - 1 - j;
-        const UniformRow<R> row = uniform_row<R>((const R*)a.tab + t * T::NPAD);
-        R m[D], eps[D];
-        rd<R, D>(a.ms, c, t, b, m);
-        rd<R, D>(a.eps, c, t, b, eps);
-#pragma unroll
-        for (int i = 0; i < D * D; ++i) e.G[i] = row[T::oG + i];
-#pragma unroll
-        for (int i = 0; i < D; ++i) {
-            R v = -row[T::oGb + i];
-#pragma unroll
-            for (int k = 0; k < D; ++k) v += row[T::oM + i * D + k] * m[k];
-#pragma unroll
-            for (int k = 0; k <= i; ++k) v += row[T::oL + i * D + k] * eps[k];
-            e.e[i] = v;
-        }
-    }
-};
-
 // ---- joint log-density of a trajectory: log_likelihood + prior_logpdf (base.py:99-166) ----------------
 struct LogpdfArgs {
     KDims d;

@@ -318,107 +318,6 @@ AX_HD void filter_elem(const R* F, const R* bdyn, const R* m_, const R* P_, cons
 }
 
 // ------------------------------------------------------------------------------------------------
-// Chain-shared model parameters.  When (F, Q, b, H, R, c, P0) do not depend on the chain -- the factories of a linear-Gaussian
-// model ignore the linearisation point -- everything in an element except (b, eta, z) is the same for every chain, and so are
-// the operators that produce those three from a chain's observations.  (Under jax.vmap the reference gets exactly this split:
-// whatever does not depend on the batched inputs is computed once, unbatched.)  One table row per time step:
-//   A, C, J            the element's matrices (filtering.py:224-236)
-//   K  = P_ H^T S^-1   b   = m_ + K (y - H m_ - c)
-//   Ke = (HF)^T S^-1   eta = Ke (y - H b_dyn - c)
-//   Si = S^-1, c0 = -log|S|/2 - dim/2 log 2 pi      z = -1/2 r^T Si r + c0,  r = y - H m_ - c
-//   ym = H b_dyn + c, md = b_dyn, HF = H F          (m_ = b_dyn except for the first transition, where m_ = b_dyn + F m0+)
-// ------------------------------------------------------------------------------------------------
-template <typename R, int D, int P> struct FiltShared {
-    static constexpr int DS = symsize(D), PS = symsize(P);
-    static constexpr int oA = 0, oC = D * D, oJ = oC + DS, oK = oJ + DS, oKe = oK + D * P, oSi = oKe + D * P, oYm = oSi + PS,
-                         oMd = oYm + P, oC0 = oMd + D, oHF = oC0 + 1, N = oHF + P * D;
-    static constexpr int VEC = 16 / sizeof(R);
-    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
-    static constexpr int NPC = 2 * D + 1;  // per-chain part of an element: [b | eta | z]
-};
-template <typename R, int D, int P>
-AX_HD void filter_shared_row(const R* F, const R* bdyn, const R* P_, const R* H, const R* c, const R* __restrict__ Rm, const R* y, R* row) {
-    using T = FiltShared<R, D, P>;
-    bool nan[P];
-    R H_[P * D], c_[P];
-    const bool any = obs_mask<R, D, P>(y, H, c, nan, H_, c_);
-#pragma unroll
-    for (int i = 0; i < T::N; ++i) row[i] = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) row[T::oMd + k] = bdyn[k];
-    if (!any) {  // _passthrough :239-248: A = F, C = P_, everything observation-related zero
-#pragma unroll
-        for (int i = 0; i < D * D; ++i) row[T::oA + i] = F[i];
-        sympack<R, D>(P_, row + T::oC);
-        return;
-    }
-    R L[symsize(P)], invd[P], PHt[D * P];
-    innovation_cov<R, D, P>(P_, H_, Rm, nan, PHt, L);
-    const bool ok = chol_inplace<R, P>(L, invd, nan);
-    R HF[P * D];
-    mm<R, P, D, D>(H_, F, HF);
-    R K[D * P], Ke[D * P];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        R g[P], e[P];
-#pragma unroll
-        for (int k = 0; k < P; ++k) g[k] = PHt[i * P + k], e[k] = HF[k * D + i];
-        cho_solve<R, P>(L, invd, g);
-        cho_solve<R, P>(L, invd, e);
-#pragma unroll
-        for (int k = 0; k < P; ++k) K[i * P + k] = g[k], Ke[i * P + k] = e[k];
-    }
-#pragma unroll
-    for (int k = 0; k < P; ++k) {  // column k of S^-1 (deleted components: zero)
-        R e[P];
-#pragma unroll
-        for (int l = 0; l < P; ++l) e[l] = (l == k && !nan[k]) ? (R)1 : (R)0;
-        cho_solve<R, P>(L, invd, e);
-#pragma unroll
-        for (int l = k; l < P; ++l) row[T::oSi + sidx_u(P, k, l)] = (nan[k] || nan[l]) ? (R)0 : e[l];
-    }
-    R Cd[D * D], Jd[D * D];
-#pragma unroll
-    for (int i = 0; i < D; ++i)
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            R sa = F[i * D + j], sc = P_[i * D + j], sj = 0;
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                sa -= K[i * P + k] * HF[k * D + j];
-                sc -= K[i * P + k] * PHt[j * P + k];
-                sj += Ke[i * P + k] * HF[k * D + j];
-            }
-            row[T::oA + i * D + j] = sa;
-            Cd[i * D + j] = sc;
-            Jd[i * D + j] = sj;
-        }
-    sympack<R, D>(Cd, row + T::oC);
-    sympack<R, D>(Jd, row + T::oJ);
-    R logdet = 0;
-    int dim = 0;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        R ymk = c_[k];
-#pragma unroll
-        for (int j = 0; j < D; ++j) ymk += H_[k * D + j] * bdyn[j];
-        row[T::oYm + k] = ymk;
-        logdet += nan[k] ? (R)0 : log_(L[lidx(k, k)]);
-        dim += nan[k] ? 0 : 1;
-    }
-#pragma unroll
-    for (int i = 0; i < D * P; ++i) row[T::oK + i] = K[i], row[T::oKe + i] = Ke[i];
-#pragma unroll
-    for (int i = 0; i < P * D; ++i) row[T::oHF + i] = HF[i];
-    row[T::oC0] = -logdet - (R)(0.5 * LOG_2PI) * (R)dim;
-    if (!ok) {
-        const R bad = r_nan<R>();
-#pragma unroll
-        for (int i = 0; i < T::N; ++i) row[i] = bad;
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Information form for a BLOCK-DIAGONAL observation covariance R = blkdiag(R_1 (P1 x P1), R_2 (P-P1 x P-P1)), e.g. the
 // auxiliary observations concatenated with the real ones (R = blkdiag(delta/2 I, Robs)).  With
 //     Lam = H^T R^-1 H = sum_b H_b^T R_b^-1 H_b,   g(r) = H^T R^-1 r = sum_b H_b^T R_b^-1 r_b,

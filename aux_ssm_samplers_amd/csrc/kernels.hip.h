@@ -15,6 +15,7 @@
 #include <cstdlib>
 
 #include "ctx.h"
+#include "affine_shared.h"
 
 namespace ax {
 
@@ -229,17 +230,6 @@ template <typename R, int D, int P, int P1> __global__ void __launch_bounds__(TB
     for (int i = c.i0; i < c.i1; ++i) {
         body_filter_init<R, D, P, DirectIO, P1>(a, io, c.s, opaque_uniform(i), true);
     }
-}
-// chain-shared parameters: the table (one lane per transition) and the per-chain element parts (lanes over chains)
-template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_shared_tab(FilterArgs a) {
-    const int i = blockIdx.x * TB_ELEM + threadIdx.x;
-    if (i < a.d.n()) body_filter_shared_tab<R, D, P>(a, i);
-}
-template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_filter_init_cm_shared(FilterArgs a, int TI) {
-    const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
-    if (!c.live) return;
-#pragma unroll 1
-    for (int i = c.i0; i < c.i1; ++i) body_filter_init_shared<R, D, P>(a, c.s, opaque_uniform(i));
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample_shared_tab(SampleArgs a) {
     const int t = blockIdx.x * TB_ELEM + threadIdx.x;
@@ -560,6 +550,143 @@ __global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, Scan
     }
 }
 
+// ---- chain-shared model parameters: per-chain affine scans (affine_shared.h) -------------------------------------------------------
+// grid of the per-chain passes: workgroup = one wave = 64 chains x one chunk of E positions.  Block id -> (chunk, chain tile) with
+// chunk % 8 in the low three bits, so the waves that read one chunk's table rows sit on one XCD (one L2 / scalar-cache fill per row).
+struct AffPlan {
+    int E, nchunk;
+};
+__device__ __forceinline__ bool decode_aff(int S, int nchunk, int& ch, int& s) {
+    const int stiles = (S + TB_CM - 1) / TB_CM;
+    const unsigned b = blockIdx.x, lo = b & 7u, rest = b >> 3;
+    s = (int)(rest % (unsigned)stiles) * TB_CM + threadIdx.x;
+    ch = (int)(rest / (unsigned)stiles) * 8 + (int)lo;
+    return ch < nchunk && s < S;
+}
+inline unsigned grid_aff(int S, int nchunk) { return (unsigned)(((nchunk + 7) / 8) * 8) * (unsigned)((S + TB_CM - 1) / TB_CM); }
+
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_gain_tab(FilterArgs a, const R* __restrict__ Ps1) {
+    const int i = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (i < a.d.n()) body_gain_tab<R, D, P>(a, Ps1, i);
+}
+// the mask carrier of the matrix filter when the concatenated observations are built on the fly: [0 ; yobs_t]
+template <typename R> __global__ void k_mask_obs(int T, int D, int P, Arr yobs, R* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)T * P) return;
+    const long long t = g / P;
+    const int k = (int)(g % P);
+    out[g] = k < D ? (R)0 : at<R>(yobs, 0, t, 0)[k - D];
+}
+// dense (T, D, D) covariances of the matrix filter -> chain 0's slot of the caller's (strided) covariance buffer
+template <typename R, int D> __global__ void k_copy_cov(int T, const R* __restrict__ src, Arr dst) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)T * D * D) return;
+    const long long t = g / (D * D);
+    const int e = (int)(g % (D * D));
+    const_cast<R*>(at<R>(dst, 0, t, 0))[(long long)e * dst.se] = src[g];
+}
+// product of the chunk's matrices (scan order), one lane per chunk: the G of the chunk aggregates
+template <class Op, int D> __global__ void __launch_bounds__(TB_CM) k_aff_chunkprod(typename Op::Args a, typename Op::R* __restrict__ cprod, int N, AffPlan pl) {
+    using R = typename Op::R;
+    const int ch = blockIdx.x * TB_CM + threadIdx.x;
+    if (ch >= pl.nchunk) return;
+    const int j0 = ch * pl.E, j1 = min(N, j0 + pl.E);
+    R M[D * D];
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) M[k] = (k / D == k % D) ? (R)1 : (R)0;
+    for (int j = j0; j < j1; ++j) {
+        R G[D * D], o[D * D];
+        Op::mat(a, j, G);
+        mm<R, D, D, D>(G, M, o);
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) M[k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) cprod[(long long)ch * D * D + k] = M[k];
+}
+template <class Op, int D>
+__global__ void __launch_bounds__(TB_CM) k_aff_reduce(typename Op::Args a, ScanBufs sb, const typename Op::R* __restrict__ cprod, int S, int N, AffPlan pl) {
+    using R = typename Op::R;
+    using Full = SampElem<R, D>;
+    int ch, s;
+    if (!decode_aff(S, pl.nchunk, ch, s)) return;
+    const int j0 = ch * pl.E, j1 = min(N, j0 + pl.E);
+    Full agg;
+    if (ch == 0) Op::init(a, s, agg.e);
+    else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) agg.e[k] = 0;
+    }
+#pragma unroll 1
+    for (int j = j0; j < j1; ++j) Op::fold(a, s, opaque_uniform(j), agg.e);
+    const UniformRow<R> cp = uniform_row<R>(cprod + (long long)ch * D * D);
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) agg.G[k] = cp[k];
+    SampleOp<R, D>::store_rec((R*)sb.agg + ((long long)s * pl.nchunk + ch) * Full::NPAD, agg);
+}
+template <class Op, int D>
+__global__ void __launch_bounds__(TB_CM) k_aff_down(typename Op::Args a, ScanBufs sb, typename Op::R* __restrict__ part, int S, int N, AffPlan pl) {
+    using R = typename Op::R;
+    int ch, s;
+    if (!decode_aff(S, pl.nchunk, ch, s)) return;
+    const int j0 = ch * pl.E, j1 = min(N, j0 + pl.E);
+    R h[D];
+    if (ch == 0) Op::init(a, s, h);
+    else ldv<R, D>((const R*)sb.pre + ((long long)s * pl.nchunk + ch) * SampPre<R, D>::NPAD, h);
+    R acc = 0;
+#pragma unroll 1
+    for (int j = j0; j < j1; ++j) Op::walk(a, s, opaque_uniform(j), h, acc);
+    if (part) part[(long long)s * pl.nchunk + ch] = acc;
+}
+// about eight waves per SIMD of (chain tile, chunk) lanes: a chain's state is a handful of registers, the passes stream their inputs
+inline AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
+    AffPlan p;
+    if (!parallel || N <= 2) {
+        p.E = N > 0 ? N : 1;
+        p.nchunk = 1;
+        return p;
+    }
+    const long long stiles = (S + TB_CM - 1) / TB_CM;
+    long long want = (long long)h->num_cu * 4 * 8 / stiles;  // chunks
+    if (want < 1) want = 1;
+    long long E = (N + want - 1) / want;
+    if (E < 16) E = 16;
+    if (E > 1024) E = 1024;
+    if (const char* ev = getenv("AUXSSM_AFF_E")) {  // tuning/debug override
+        const long long v = atoll(ev);
+        if (v >= 1 && v <= 65536) E = v;
+    }
+    p.E = (int)E;
+    p.nchunk = (int)((N + E - 1) / E);
+    return p;
+}
+template <typename R, int D> size_t aff_ws_bytes(const auxssm_ctx* h, int S, int N, int parallel) {
+    const AffPlan pl = plan_aff(h, S, N, parallel);
+    return (size_t)S * pl.nchunk * (SampElem<R, D>::NPAD + SampPre<R, D>::NPAD + 1) * sizeof(R) + (size_t)pl.nchunk * D * D * sizeof(R) + 1024;
+}
+// part: [S][nchunk] accumulators of the down pass (may be null); returns the chunk count through *nchunk_out
+template <class Op, int D> int run_affine(auxssm_ctx* h, const typename Op::Args& a, int S, int N, int parallel, typename Op::R** part_out, int* nchunk_out) {
+    using R = typename Op::R;
+    const AffPlan pl = plan_aff(h, S, N, parallel);
+    ScanBufs sb{nullptr, nullptr};
+    R* part = part_out ? (R*)ws_take(h, (size_t)S * pl.nchunk * sizeof(R)) : nullptr;
+    if (part_out) *part_out = part;
+    if (nchunk_out) *nchunk_out = pl.nchunk;
+    if (pl.nchunk > 1) {
+        R* cprod = (R*)ws_take(h, (size_t)pl.nchunk * D * D * sizeof(R));
+        sb.agg = ws_take(h, (size_t)S * pl.nchunk * SampElem<R, D>::NPAD * sizeof(R));
+        sb.pre = ws_take(h, (size_t)S * pl.nchunk * SampPre<R, D>::NPAD * sizeof(R));
+        if (!cprod || !sb.agg || !sb.pre || (part_out && !part)) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_aff_chunkprod<Op, D>), dim3((pl.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod, N, pl);
+        hipLaunchKernelGGL((k_aff_reduce<Op, D>), dim3(grid_aff(S, pl.nchunk)), dim3(TB_CM), 0, h->stream, a, sb, (const R*)cprod, S, N, pl);
+        const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
+        hipLaunchKernelGGL((k_scan_aggs<SampleOp<R, D>>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, pl.nchunk);
+    }
+    hipLaunchKernelGGL((k_aff_down<Op, D>), dim3(grid_aff(S, pl.nchunk)), dim3(TB_CM), 0, h->stream, a, sb, part, S, N, pl);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
 template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
     const ScanPlan pl = plan_scan(h, S, n, parallel);
     if (pl.nchunk <= 1) return 0;
@@ -612,7 +739,69 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     b += (size_t)S * sizeof(R) + 256;                           // ell0
     b += (size_t)S * (std::max(ntiles(n), lay.nchunk) + 1) * sizeof(R) + 256;  // ell partials (per tile, or per chunk)
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
+    // chain-shared parameters: the one-sequence matrix filter (elements, scan buffers, moments, mask carrier), the gain table and the
+    // per-chain affine scan
+    const ScanLayout l1 = make_layout(plan_scan(h, 1, n, 1), 0, 1);
+    b += (size_t)l1.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + scan_ws_bytes<FilterOp<R, D>>(h, 1, n, 1) + 1024;
+    b += (size_t)d.T * (D + D * D + P) * sizeof(R) + 1024;
+    b += (size_t)(n > 0 ? n : 1) * GainRow<R, D, P>::NPAD * sizeof(R) + 256;
+    b += aff_ws_bytes<R, D>(h, S, n, parallel);
     return b;
+}
+
+// Chain-shared model parameters (affine_shared.h): the d x d block-affine scan runs once, on one sequence (the matrix filter), the
+// chains carry an affine recursion with chain-shared matrices.  `a` holds the chain-minor views of ys / ms / Ps; ell0 is filled.
+template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterArgs& a, int parallel, void* ell_out) {
+    const int S = a.d.S(), n = a.d.n(), T = a.d.T;
+    R* ms1 = (R*)ws_take(h, (size_t)T * D * sizeof(R));
+    R* Ps1 = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+    R* sc1 = (R*)ws_take(h, 4 * sizeof(R));
+    if (!ms1 || !Ps1 || !sc1) return AUXSSM_ERR_NOMEM;
+    {
+        // the matrix filter: the parallel filter on ONE sequence, always the parallel plan (its means are not used: the observation
+        // values are the mask carrier's).  Dense (time-minor) layout.
+        ProfScope ps(h, AUXSSM_K_FILTER_TAB);
+        FilterArgs am = a;
+        am.d = KDims{1, T, 1};
+        am.aux_on = 0;
+        am.tab = nullptr;
+        am.pc = nullptr;
+        am.ms = dense_arr(ms1, am.d, D);
+        am.Ps = dense_arr(Ps1, am.d, (long long)D * D);
+        am.ell0 = sc1;
+        am.ellz = sc1 + 1;
+        if (a.aux_on) {
+            R* ym = (R*)ws_take(h, (size_t)T * P * sizeof(R));
+            if (!ym) return AUXSSM_ERR_NOMEM;
+            const long long tot = (long long)T * P;
+            hipLaunchKernelGGL((k_mask_obs<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, a.aux_yobs, ym);
+            am.ys = dense_arr(ym, am.d, P);
+        } else {
+            am.ys = Arr{a.ys.ptr, 0, a.ys.st, 0, a.ys.se};  // chain 0's observations
+        }
+        am.lay = make_layout(plan_scan(h, 1, n, 1), 0, 1);
+        am.elem = ws_take(h, (size_t)am.lay.total_reals(n, 1, FiltElem<R, D>::NPAD) * sizeof(R));
+        if (!am.elem) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3(1), dim3(TB_ELEM), 0, h->stream, am);
+        hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(ntiles(n), 1)), dim3(TB_ELEM), 0, h->stream, am);
+        const int rc = run_scan<FilterOp<R, D>>(h, am, 1, n);
+        if (rc) return rc;
+        a.tab = ws_take(h, (size_t)n * GainRow<R, D, P>::NPAD * sizeof(R));
+        if (!a.tab) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_gain_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a, (const R*)Ps1);
+        // the filtered covariances are the same for every chain: chain 0's slot of the caller's buffer holds them (the sampler's table reads it)
+        hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
+    }
+    R* part = nullptr;
+    int nchunk = 1;
+    {
+        ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+        const int rc = run_affine<FilterMeanOp<R, D, P>, D>(h, a, S, n, parallel, &part, &nchunk);
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0, a.d.B, nchunk, (R*)ell_out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
 }
 
 template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterArgs& a_in, int parallel, void* ell_out) {
@@ -623,40 +812,30 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     static const bool blk_on = [] { const char* e = getenv("AUXSSM_INFO_BLOCKS"); return e ? atoi(e) != 0 : true; }();
     const bool blk = blk_on && P > D && a_in.pblk == D;
     a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
-    // chain-shared model parameters (the factories of a linear-Gaussian model): element matrices and gain-type operators once per
-    // time step, only (b, eta, z) per chain -- what jax.vmap leaves unbatched in the reference
+    // chain-shared model parameters (the factories of a linear-Gaussian model): what jax.vmap leaves unbatched in the reference
     const bool shared_on = h->share_model != 0;
     const bool shared = shared_on && cm && n > 0 && a.d.B == 1 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 &&
                         a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
-    using TS = FiltShared<R, D, P>;
     if (!shared) a.aux_on = 0;  // (the caller materialised the concatenated observations in that case)
-    if (shared) {
-        a.tab = ws_take(h, (size_t)n * TS::NPAD * sizeof(R));
-        a.pc = ws_take(h, (size_t)n * TS::NPC * S * sizeof(R));
-        a.elem = nullptr;
-    } else {
-        a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
-    }
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
+    if (!a.ell0) return AUXSSM_ERR_NOMEM;
+    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
+    if (shared) return run_filter_shared<R, D, P>(h, a, parallel, ell_out);
+    a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final
     // pass writes it per sequence; the reference's second pass over the filtered moments (filtering.py:60-62) does not exist here
     a.ellz = ws_take(h, (size_t)S * sizeof(R));
     const int nt = cm ? a.lay.nchunk : ntiles(n);
-    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     if (n > 0) {
         {
             ProfScope ps(h, AUXSSM_K_FILTER_INIT);
-            if (shared) {
-                hipLaunchKernelGGL((k_filter_shared_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
-                hipLaunchKernelGGL((k_filter_init_cm_shared<R, D, P>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
-            } else if (cm && blk) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, (P > D ? D : 0)>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
+            if (cm && blk) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, (P > D ? D : 0)>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
             else if (cm) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, 0>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
             else hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(nt, S)), dim3(TB_ELEM), 0, h->stream, a);
         }
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-            const int rc = shared ? run_scan<FilterOp<R, D>, FilterOpShared<R, D, P>, FilterOpShared<R, D, P>>(h, a, S, n)
-                                  : run_scan<FilterOp<R, D>>(h, a, S, n);
+            const int rc = run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
     }
@@ -670,7 +849,7 @@ template <typename R, int D> size_t sample_ws(const auxssm_ctx* h, const KDims& 
     const int S = d.S();
     const ScanLayout lay = make_layout(plan_scan(h, S, d.T, parallel), 0, S);
     return (size_t)S * lay.seq_records() * SampElem<R, D>::NPAD * sizeof(R) + 256 + scan_ws_bytes<SampleOp<R, D>>(h, S, d.T, parallel) +
-           (size_t)d.T * SampShared<R, D>::NPAD * sizeof(R) + 256;
+           (size_t)d.T * SampShared<R, D>::NPAD * sizeof(R) + 256 + aff_ws_bytes<R, D>(h, S, d.T, parallel);
 }
 
 template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_in, int parallel) {
@@ -689,7 +868,7 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
             hipLaunchKernelGGL((k_sample_shared_tab<R, D>), dim3((T + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
         }
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
-        const int rc = run_scan<SampleOp<R, D>, SampleOpShared<R, D>, SampleOpShared<R, D>>(h, a, S, T);
+        const int rc = run_affine<SampleAffOp<R, D>, D>(h, a, S, T, parallel, nullptr, nullptr);
         if (rc) return rc;
         AX_HIP(hipGetLastError());
         return AUXSSM_OK;
