@@ -140,6 +140,11 @@ const SweepLogpdfEntry* sweep_logpdf_entry(int dtype, int D, int PO) {
 }
 
 static inline Arr cv(const auxssm_arr& a) { return Arr{a.ptr, (long long)a.sc, (long long)a.st, (long long)a.sb, 1}; }
+// AUXSSM_AUX_FLY=0 (debug / comparison runs): materialise the concatenated observations and the scan elements instead
+static bool aux_fly_enabled() {
+    static const bool on = [] { const char* e = getenv("AUXSSM_AUX_FLY"); return e ? atoi(e) != 0 : true; }();
+    return on;
+}
 
 static int check_dims(const auxssm_dims* d, bool need_dy) {
     if (!d) {
@@ -410,9 +415,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
 
     // observations_factory / dynamics_factory of the LG_CONCAT device model.  With chain-shared parameters in the chain-minor layout
     // the filter builds u and the concatenated observation on the fly for t >= 1 (FilterArgs::aux_*): only row t = 0 is materialised.
-    const bool model_shared = model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->Hs.sc == 0 && model->Rs.sc == 0 &&
-                              model->cs.sc == 0 && model->P0.sc == 0 && yobs->sc == 0;
-    const bool aux_fly = cm && h->share_model && model_shared && C > 1 && T > 1 && !wide;
+    // In the chain-minor layout the filter builds u and the concatenated observation on the fly for t >= 1 (FilterArgs::aux_*), in
+    // both of its modes (chain-shared parameters: gain-form recursion; otherwise: elements built inside the scan passes).
+    const bool aux_fly = cm && T > 1 && !wide && aux_fly_enabled();
     {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
@@ -828,6 +833,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     const long long psc = model->Fs.sc;
     auto arr = [&](const void* p, long long rec) { return cm ? cm_arr(p, kd, rec) : dense_arr(p, kd, rec); };
     const Arr xA = arr(x, D), xpA = arr(xp, D), uA = arr(u, D), yscA = arr(ysc, P);
+    const bool aux_fly = cm && T > 1 && aux_fly_enabled();  // u and the concatenated observations of t >= 1 are formed inside the filter
     // per-chain transition arrays have n = T - 1 rows: same strides as a T-row array of that record size
     const Arr F1A = arr(Fs1, 9), b1A = arr(bs1, 3), F2A = arr(Fs2, 9), b2A = arr(bs2, 3);
     {
@@ -835,8 +841,9 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs),
                            cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
-        const long long n2 = (long long)CT * P;
-        hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, T, D, PO, xA,
+        const int Tc = aux_fly ? 1 : T;
+        const long long n2 = (long long)C * Tc * P;
+        hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, Tc, D, PO, xA,
                            arr(eps_aux, D), (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, cm);
     }
     const unsigned gd = (unsigned)(((long long)C * (T - 1) + 255) / 256);
@@ -862,6 +869,14 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
         if (cm) {
             fa.Fs = FA;
             fa.bs = bA;
+        }
+        if (aux_fly) {
+            fa.aux_on = 1;
+            fa.aux_x = xA;
+            fa.aux_eps = arr(eps_aux, D);
+            fa.aux_u = uA;
+            fa.aux_yobs = cv(*yobs);
+            fa.aux_shd = sqrt(0.5 * delta);
         }
     };
 

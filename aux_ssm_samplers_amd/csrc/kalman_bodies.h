@@ -116,6 +116,7 @@ struct FilterArgs {
     int aux_on = 0;
     Arr aux_x{}, aux_eps{}, aux_u{}, aux_yobs{};
     double aux_shd = 0;
+    const void* obs_tab = nullptr;  // general chain-minor path with aux_on: one ObsInfoRow per transition (kalman_math.h), elements built on the fly
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
 AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
@@ -142,6 +143,16 @@ template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& 
     wr<R, D * D>(a.Ps, c, 0, b, Pd);
     ((R*)a.ell0)[s] = ell;
 }
+
+// A table row is read at a wave-uniform address and never written by the kernel that reads it: viewed through the constant
+// address space the loads become scalar (s_load into SGPRs) instead of 64 identical vector loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+template <typename R> using UniformRow = const __attribute__((address_space(4))) R*;
+template <typename R> __device__ __forceinline__ UniformRow<R> uniform_row(const R* p) { return (UniformRow<R>)(unsigned long long)p; }
+#else
+template <typename R> using UniformRow = const R*;
+template <typename R> AX_HD UniformRow<R> uniform_row(const R* p) { return p; }
+#endif
 
 template <typename R_, int D> struct FilterOp;
 // ---- scan element for transition i -> i+1 (filtering.py:188-250) ---------------------------------
@@ -283,17 +294,140 @@ template <typename R_, int D> struct FilterOp {
         for (int i = 0; i < DS; ++i) t[D * D + D + i] = e.C[i], t[D * D + 2 * D + DS + i] = e.J[i];
         t[Full::N - 1] = e.z;
     }
+    // Two-step element access of the chain-minor scan kernels: load_raw issues the global reads of element i (they fly during the
+    // previous element's combine), build turns them into the element.  Stored elements: the record itself.
+    using Raw = Full;
+    static AX_HD void load_raw(const Args& a, int s, int i, Raw& r) { load_elem(a, s, i, r); }
+    static AX_HD void build(const Args&, int, int, const Raw& r, Full& e) { e = r; }
+    static constexpr bool kFold = false;  // true: the operator folds raw steps onto the accumulated prefix itself (fold / walk)
 };
 
-// A table row is read at a wave-uniform address and never written by the kernel that reads it: viewed through the constant
-// address space the loads become scalar (s_load into SGPRs) instead of 64 identical vector loads.
-#if defined(__HIP_DEVICE_COMPILE__)
-template <typename R> using UniformRow = const __attribute__((address_space(4))) R*;
-template <typename R> __device__ __forceinline__ UniformRow<R> uniform_row(const R* p) { return (UniformRow<R>)(unsigned long long)p; }
-#else
-template <typename R> using UniformRow = const R*;
-template <typename R> AX_HD UniformRow<R> uniform_row(const R* p) { return p; }
-#endif
+// FilterOp that never materialises its elements (general chain-minor sweep, concatenated auxiliary observations): load_raw reads the
+// chain's linearisation-point data of transition i -> i+1 -- x_t, eps_t (u = x + sqrt(delta/2) eps) and its dynamics F, Q, b, which
+// are chain-strided (one linearisation per chain) or stride-0 broadcasts -- and build forms the element from them and the chain-shared
+// ObsInfoRow of the time step (kalman_math.h::filter_elem_aux: d x d work only, no p x p factorisation per chain).  Both scan passes
+// then stream 2d (+ per-chain dynamics) reals per step instead of writing and re-reading the (3d^2+2d)-real element, and the element
+// kernel disappears.  WRITE_U: the pass that also stores u for the log-density kernel (the final pass).
+template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp<R_, D> {
+    using R = R_;
+    using Full = typename FilterOp<R_, D>::Full;
+    using Args = FilterArgs;
+    struct Raw {
+        R F[D * D], Q[D * D], bd[D], x[D], eps[D];
+    };
+    static AX_HD void load_raw(const Args& a, int s, int i, Raw& r) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)i + 1;
+        rd<R, D>(a.aux_x, c, t, b, r.x);
+        rd<R, D>(a.aux_eps, c, t, b, r.eps);
+        rd<R, D * D>(a.Fs, c, i, b, r.F);
+        rd<R, D>(a.bs, c, i, b, r.bd);
+        rd<R, D * D>(a.Qs, c, i, b, r.Q);
+    }
+    static AX_HD void build(const Args& a, int s, int i, const Raw& r, Full& e) {
+        using T = ObsInfoRow<R, D>;
+        const int c = s / a.d.B, b = s % a.d.B;
+        R u[D], m_[D], P_[D * D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] = r.x[k] + (R)a.aux_shd * r.eps[k];
+        if constexpr (WRITE_U) wr<R, D>(a.aux_u, c, (long long)i + 1, b, u);
+        if (i == 0) {  // built around predict(m0+, P0+) (filtering.py:188-192, :200-201)
+            R m0p[D], P0p[D * D], tm[D], FP[D * D], Pn[D * D];
+            rd<R, D>(a.ms, c, 0, b, m0p);
+            rd<R, D * D>(a.Ps, c, 0, b, P0p);
+            mv<R, D, D>(r.F, m0p, tm);
+            mm<R, D, D, D>(r.F, P0p, FP);
+            mmt<R, D, D, D>(FP, r.F, Pn);
+#pragma unroll
+            for (int k = 0; k < D; ++k) m_[k] = tm[k] + r.bd[k];
+#pragma unroll
+            for (int k = 0; k < D * D; ++k) P_[k] = Pn[k] + r.Q[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < D; ++k) m_[k] = r.bd[k];
+#pragma unroll
+            for (int k = 0; k < D * D; ++k) P_[k] = r.Q[k];
+        }
+        const UniformRow<R> row = uniform_row<R>((const R*)a.obs_tab + (long long)i * T::NPAD);
+        const R inv_hd = (R)1 / ((R)a.aux_shd * (R)a.aux_shd);
+        filter_elem_aux<R, D>(r.F, r.bd, m_, P_, u, row, inv_hd, i == 0, e);
+    }
+    static AX_HD void load_elem(const Args& a, int s, int i, Full& e) {
+        Raw r;
+        load_raw(a, s, i, r);
+        build(a, s, i, r, e);
+    }
+    // ---- chunk-serial passes: fold the raw step onto the prefix (kalman_math.h::filter_fold_step / filter_apply_step) ----
+    static constexpr bool kFold = true;
+    using Pre = typename FilterOp<R_, D>::Pre;
+    static constexpr int DS = symsize(D);
+    // the prefix entering position 0 of the whole scan is the t = 0 posterior (m0+, P0+): a constant map (A = 0)
+    static AX_HD void init_acc(const Args& a, int s, int ch, Full& acc) {
+        fe_identity<R, D>(acc);
+        if (ch == 0) {
+            R P0p[D * D];
+#pragma unroll
+            for (int k = 0; k < D * D; ++k) acc.A[k] = 0;
+            rd<R, D>(a.ms, s / a.d.B, 0, s % a.d.B, acc.b);
+            rd<R, D * D>(a.Ps, s / a.d.B, 0, s % a.d.B, P0p);
+            sympack<R, D>(P0p, acc.C);
+        }
+    }
+    static AX_HD void init_pre(const Args& a, int s, Pre& p) {
+        R P0p[D * D];
+        rd<R, D>(a.ms, s / a.d.B, 0, s % a.d.B, p.b);
+        rd<R, D * D>(a.Ps, s / a.d.B, 0, s % a.d.B, P0p);
+        sympack<R, D>(P0p, p.C);
+        p.z = 0;
+    }
+    static AX_HD void step_info(const Args& a, int s, int i, const Raw& r, StepInfo<R, D>& si) {
+        using T = ObsInfoRow<R, D>;
+        const UniformRow<R> row = uniform_row<R>((const R*)a.obs_tab + (long long)i * T::NPAD);
+        const R inv_hd = (R)1 / ((R)a.aux_shd * (R)a.aux_shd);
+        R u[D];
+        R q0 = row[T::oK];
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            u[k] = r.x[k] + (R)a.aux_shd * r.eps[k];
+            si.g0[k] = u[k] * inv_hd + row[T::oG + k];
+            q0 += u[k] * u[k] * inv_hd;
+        }
+        if constexpr (WRITE_U) wr<R, D>(a.aux_u, s / a.d.B, (long long)i + 1, s % a.d.B, u);
+#pragma unroll
+        for (int k = 0; k < DS; ++k) si.Lam[k] = row[T::oL + k];
+#pragma unroll
+        for (int k = 0; k < D; ++k) si.Lam[sidx_u(D, k, k)] += inv_hd;
+        si.q0 = q0;
+        si.ldR = row[T::oLd];
+        si.dim = row[T::oDim];
+        si.ok = row[T::oOk] != (R)0;
+    }
+    static AX_HD void fold(const Args& a, int s, int i, const Raw& r, Full& acc) {
+        StepInfo<R, D> si;
+        step_info(a, s, i, r, si);
+        filter_fold_step<R, D>(r.F, r.Q, r.bd, si, acc);
+    }
+    static AX_HD void walk(const Args& a, int s, int i, const Raw& r, Pre& p) {
+        StepInfo<R, D> si;
+        step_info(a, s, i, r, si);
+        filter_apply_step<R, D>(r.F, r.Q, r.bd, si, p);
+    }
+};
+// table row of transition i -> i + 1 (time t = i + 1) from the concatenated model arrays and the data
+template <typename R, int D, int P> AX_HD void body_obs_info_tab(const FilterArgs& a, int i) {
+    using T = ObsInfoRow<R, D>;
+    const long long t = (long long)i + 1;
+    R H[P * D], cv[P], y[P], Rm[P * P], row[T::NPAD];
+    rd<R, P * D>(a.Hs, 0, t, 0, H);
+    rd<R, P>(a.cs, 0, t, 0, cv);
+    rd_upper<R, P>(a.Rs, 0, t, 0, Rm);
+#pragma unroll
+    for (int k = 0; k < P; ++k) y[k] = k < D ? (R)0 : at<R>(a.aux_yobs, 0, t, 0)[k - D];
+#pragma unroll
+    for (int k = T::N; k < T::NPAD; ++k) row[k] = 0;
+    obs_info_row<R, D, P>(H, cv, Rm, y, (R)a.aux_shd * (R)a.aux_shd, row);
+    stv<R, T::NPAD>((R*)a.obs_tab + (long long)i * T::NPAD, row);
+}
 
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SampleArgs {
@@ -421,6 +555,10 @@ template <typename R_, int D> struct SampleOp {
             load_rec(p, e);
         }
     }
+    using Raw = Full;
+    static AX_HD void load_raw(const Args& a, int s, int j, Raw& r) { load_elem(a, s, j, r); }
+    static AX_HD void build(const Args&, int, int, const Raw& r, Full& e) { e = r; }
+    static constexpr bool kFold = false;
 };
 
 // SampleOp that never materialises its elements: load_elem builds (G_t, inc_t) from the filtered moments, the dynamics and the
@@ -430,22 +568,29 @@ template <typename R_, int D> struct SampleOp {
 template <typename R_, int D> struct SampleOpFly : SampleOp<R_, D> {
     using R = R_;
     using Full = typename SampleOp<R_, D>::Full;
-    static AX_HD void load_elem(const SampleArgs& a, int s, int j, Full& e) {
+    struct Raw {
+        R m[D], Pd[D * D], eps[D], F[D * D], Q[D * D], bd[D];
+    };
+    static AX_HD void load_raw(const SampleArgs& a, int s, int j, Raw& r) {
         const int c = s / a.d.B, b = s % a.d.B;
         const long long t = (long long)a.d.T - 1 - j;
-        R m[D], Pd[D * D], eps[D];
-        rd<R, D>(a.ms, c, t, b, m);
-        rd<R, D * D>(a.Ps, c, t, b, Pd);
-        rd<R, D>(a.eps, c, t, b, eps);
-        if (j == 0) {
-            sample_last<R, D>(m, Pd, eps, e);
-        } else {
-            R F[D * D], Q[D * D], bd[D];
-            rd<R, D * D>(a.Fs, c, t, b, F);
-            rd<R, D * D>(a.Qs, c, t, b, Q);
-            rd<R, D>(a.bs, c, t, b, bd);
-            sample_elem<R, D>(F, Q, bd, m, Pd, eps, e);
+        rd<R, D>(a.ms, c, t, b, r.m);
+        rd<R, D * D>(a.Ps, c, t, b, r.Pd);
+        rd<R, D>(a.eps, c, t, b, r.eps);
+        if (j != 0) {
+            rd<R, D * D>(a.Fs, c, t, b, r.F);
+            rd<R, D * D>(a.Qs, c, t, b, r.Q);
+            rd<R, D>(a.bs, c, t, b, r.bd);
         }
+    }
+    static AX_HD void build(const SampleArgs&, int, int j, const Raw& r, Full& e) {
+        if (j == 0) sample_last<R, D>(r.m, r.Pd, r.eps, e);
+        else sample_elem<R, D>(r.F, r.Q, r.bd, r.m, r.Pd, r.eps, e);
+    }
+    static AX_HD void load_elem(const SampleArgs& a, int s, int j, Full& e) {
+        Raw r;
+        load_raw(a, s, j, r);
+        build(a, s, j, r, e);
     }
 };
 

@@ -373,6 +373,114 @@ AX_HD bool info_block(const R* H, const R* Rm, const bool* nan, const R* r1, con
     return ok;
 }
 
+// The element from the information quantities of the observation model (block-diagonal or not):
+//   Lam = H^T R^-1 H (packed sym), gm = H^T R^-1 (y - H m_ - c), gb = H^T R^-1 (y - H b_dyn - c), q = r_m^T R^-1 r_m,
+//   logdetR = log|R|/2 (sum of the log Cholesky diagonals), dim = number of observed components.
+// W2 = I + Lam P_;  [M | vm | vb] = W2^-1 [Lam | gm | gb];  scale = log N(r_m; 0, S) by the determinant / Woodbury identities
+// (log|S| = log|R| + log|I + Lam P|, r^T S^-1 r = r^T R^-1 r - g^T P (I + Lam P)^-1 g).
+template <typename R, int D>
+AX_HD void filter_elem_from_lam(const R* F, const R* m_, const R* P_, const R* Lam, const R* gm, const R* gb, R q, R logdetR, R dim, bool ok,
+                                FiltElem<R, D>& e) {
+    constexpr int NR = D + 2;
+    R W2[D * D], B[D * NR];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = (i == j) ? (R)1 : (R)0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += Lam[sidx(D, i, k)] * P_[k * D + j];
+            W2[i * D + j] = s;
+            B[i * NR + j] = Lam[sidx(D, i, j)];
+        }
+        B[i * NR + D] = gm[i];
+        B[i * NR + D + 1] = gb[i];
+    }
+    const R ldw = lu_solve_logdet<R, D, NR>(W2, B);
+    {
+        R Pg[D];
+        mv<R, D, D>(P_, gm, Pg);
+        R corr = 0;
+#pragma unroll
+        for (int i = 0; i < D; ++i) corr += Pg[i] * B[i * NR + D];
+        e.z = ok ? (R)-0.5 * (q - corr) - logdetR - (R)0.5 * ldw - (R)(0.5 * LOG_2PI) * dim : r_nan<R>();
+    }
+    R M[symsize(D)], vm[D], vb[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        vm[i] = ok ? B[i * NR + D] : r_nan<R>();
+        vb[i] = ok ? B[i * NR + D + 1] : r_nan<R>();
+#pragma unroll
+        for (int j = i; j < D; ++j) M[sidx_u(D, i, j)] = ok ? ((i == j) ? B[i * NR + i] : (R)0.5 * (B[i * NR + j] + B[j * NR + i])) : r_nan<R>();
+    }
+    filter_elem_from_info<R, D>(F, m_, P_, M, vm, vb, e);
+}
+
+// Observation-side information of the CONCATENATED auxiliary model y = [u ; yobs], H = [I ; Hobs], c = [0 ; cobs],
+// R = blkdiag(hd I, Robs), hd = delta / 2 (examples/lorenz/auxiliary_kalman.py:26-35): the real observation model and the data are
+// shared by the chains, so per time step
+//   Lobs = Hobs^T Robs^-1 Hobs,  gam = Hobs^T Robs^-1 (yobs - cobs),  kap = (yobs - cobs)^T Robs^-1 (yobs - cobs),
+//   ldR = D log sqrt(hd) + sum log chol(Robs)_kk,  dim = D + #observed      (missing components deleted inside the block)
+// come from a table and a chain's part is closed form in u and the predicted mean m:
+//   Lam = Lobs + I / hd;  g(m) = (u - m) / hd + gam - Lobs m;  q(m) = |u - m|^2 / hd + kap - 2 gam.m + m^T Lobs m.
+template <typename R, int D> struct ObsInfoRow {
+    static constexpr int DS = symsize(D);
+    static constexpr int oL = 0, oG = DS, oK = DS + D, oLd = oK + 1, oDim = oLd + 1, oOk = oDim + 1, N = oOk + 1;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
+};
+// H, Rm, c, y: the concatenated (P = D + PO) records of the time step (only the observation block, rows D.., is read)
+template <typename R, int D, int P> AX_HD void obs_info_row(const R* H, const R* c, const R* __restrict__ Rm, const R* y, R hd, R* row) {
+    using T = ObsInfoRow<R, D>;
+    static_assert(P > D, "concatenated model");
+    bool nan[P];
+    R r[P];
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        nan[k] = k < D ? false : !finite_(y[k]);
+        r[k] = k < D ? (R)0 : y[k] - c[k];
+    }
+    R Lam[symsize(D)], g1[D], g2[D];
+#pragma unroll
+    for (int i = 0; i < symsize(D); ++i) Lam[i] = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) g1[i] = 0, g2[i] = 0;
+    R q = 0, logdet = 0;
+    int dim = 0;
+    const bool ok = info_block<R, D, P, D, P - D>(H, Rm, nan, r, r, Lam, g1, g2, q, logdet, dim);
+#pragma unroll
+    for (int i = 0; i < symsize(D); ++i) row[T::oL + i] = Lam[i];
+#pragma unroll
+    for (int i = 0; i < D; ++i) row[T::oG + i] = g1[i];
+    row[T::oK] = q;
+    row[T::oLd] = logdet + (R)D * log_(sqrt_(hd));
+    row[T::oDim] = (R)(dim + D);
+    row[T::oOk] = ok ? (R)1 : (R)0;
+}
+// element of transition i -> i + 1 for one chain from the table row (any pointer-like `row`), the chain's u and its dynamics
+template <typename R, int D, typename RowP>
+AX_HD void filter_elem_aux(const R* F, const R* bdyn, const R* m_, const R* P_, const R* u, RowP row, R inv_hd, bool first, FiltElem<R, D>& e) {
+    using T = ObsInfoRow<R, D>;
+    constexpr int DS = symsize(D);
+    R Lam[DS], gm[D], gb[D];
+#pragma unroll
+    for (int i = 0; i < DS; ++i) Lam[i] = row[T::oL + i];
+    R q = row[T::oK];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R lm = 0, lb = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) lm += Lam[sidx(D, i, k)] * m_[k], lb += Lam[sidx(D, i, k)] * bdyn[k];
+        const R dm = u[i] - m_[i];
+        gm[i] = dm * inv_hd + row[T::oG + i] - lm;
+        gb[i] = first ? (u[i] - bdyn[i]) * inv_hd + row[T::oG + i] - lb : gm[i];
+        q += dm * dm * inv_hd - (R)2 * row[T::oG + i] * m_[i] + m_[i] * lm;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i) Lam[sidx_u(D, i, i)] += inv_hd;
+    filter_elem_from_lam<R, D>(F, m_, P_, Lam, gm, gb, q, row[T::oLd], row[T::oDim], row[T::oOk] != (R)0, e);
+}
+
 // scan element, block-diagonal R (same outputs as filter_elem)
 template <typename R, int D, int P, int P1>
 AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, const R* H, const R* c, const R* Rm, const R* y,
@@ -410,40 +518,7 @@ AX_HD void filter_elem_blk(const R* F, const R* bdyn, const R* m_, const R* P_, 
     int dim = 0;
     bool ok = info_block<R, D, P, 0, P1>(H, Rm, nan, rm, rb, Lam, gm, gb, q, logdet, dim);
     ok = info_block<R, D, P, P1, P - P1>(H, Rm, nan, rm, rb, Lam, gm, gb, q, logdet, dim) && ok;
-    // W2 = I + Lam P_ ;  [M | vm | vb] = W2^-1 [Lam | gm | gb]
-    constexpr int NR = D + 2;
-    R W2[D * D], B[D * NR];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-#pragma unroll
-        for (int j = 0; j < D; ++j) {
-            R s = (i == j) ? (R)1 : (R)0;
-#pragma unroll
-            for (int k = 0; k < D; ++k) s += Lam[sidx(D, i, k)] * P_[k * D + j];
-            W2[i * D + j] = s;
-            B[i * NR + j] = Lam[sidx(D, i, j)];
-        }
-        B[i * NR + D] = gm[i];
-        B[i * NR + D + 1] = gb[i];
-    }
-    const R ldw = lu_solve_logdet<R, D, NR>(W2, B);
-    {  // scale = log N(rm; 0, S) by the determinant / Woodbury identities above (log|S| = log|R| + log|I + Lam P|, r^T S^-1 r = r^T R^-1 r - g^T P (I + Lam P)^-1 g)
-        R Pg[D];
-        mv<R, D, D>(P_, gm, Pg);
-        R corr = 0;
-#pragma unroll
-        for (int i = 0; i < D; ++i) corr += Pg[i] * B[i * NR + D];
-        e.z = ok ? (R)-0.5 * (q - corr) - logdet - (R)0.5 * ldw - (R)(0.5 * LOG_2PI) * (R)dim : r_nan<R>();
-    }
-    R M[symsize(D)], vm[D], vb[D];
-#pragma unroll
-    for (int i = 0; i < D; ++i) {
-        vm[i] = ok ? B[i * NR + D] : r_nan<R>();
-        vb[i] = ok ? B[i * NR + D + 1] : r_nan<R>();
-#pragma unroll
-        for (int j = i; j < D; ++j) M[sidx_u(D, i, j)] = ok ? ((i == j) ? B[i * NR + i] : (R)0.5 * (B[i * NR + j] + B[j * NR + i])) : r_nan<R>();
-    }
-    filter_elem_from_info<R, D>(F, m_, P_, M, vm, vb, e);
+    filter_elem_from_lam<R, D>(F, m_, P_, Lam, gm, gb, q, logdet, (R)dim, ok, e);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -623,6 +698,152 @@ AX_HD void filter_apply(const FiltPre<R, D>& p, const FiltElem<R, D>& a2, FiltPr
             }
         sympack<R, D>(Cd, o.C);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Folding ONE filtering step onto an accumulated prefix without materialising the step's element.
+// With acc = (A, b, C, eta, J, z) (given x_0: x_k | y_1:k ~ N(A x_0 + b, C); p(y_1:k | x_0) = e^z N_I(x_0; eta, J)) and a step with
+// dynamics (F, Q, b_dyn) and observation information (Lam = H^T R^-1 H, g0 = H^T R^-1 (y - c), q0 = (y - c)^T R^-1 (y - c)):
+//   FA = F A,  mb = F b + b_dyn,  Pp = F C F^T + Q                                  (predict, filtering.py:134-139)
+//   W = I + Lam Pp,  [M | v] = W^-1 [Lam | g0 - Lam mb]                             (M = H^T S^-1 H, v = H^T S^-1 (y - H mb - c))
+//   A' = FA - Pp M FA,  b' = mb + Pp v,  C' = Pp - Pp M Pp                          (update, filtering.py:83-130 in information form)
+//   eta' = eta + FA^T v,  J' = J + FA^T M FA,  z' = z + log N(y; H mb + c, S)
+// which IS acc (+) element(step) of filtering.py:163-183 with the element's own (A2, b2, C2, eta2, J2) contracted away: 9 d^3 + one
+// (d + 1)-column LU instead of building the element (5 d^3 + LU) and a general combine (19 d^3 + a (2d + 1)-column LU).  The general
+// combine stays what the aggregate scan runs; this is the chunk-serial part of the scan (kernels.hip.h: k_scan_reduce_cm / k_scan_down_cm
+// of the on-the-fly operator).
+// ------------------------------------------------------------------------------------------------
+template <typename R, int D> struct StepInfo {
+    R Lam[symsize(D)];  // incl. the auxiliary block's I / hd
+    R g0[D];
+    R q0, ldR, dim;
+    bool ok;
+};
+// shared front end: predict + solve; returns through references.  Cp = packed C of the prefix.
+template <typename R, int D>
+AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, const R* bprev, const R* Cp, R* mb, R* Pp, R* M, R* v, R& zinc) {
+    R FC[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R sm = bd[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R sfc = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) sfc += F[i * D + k] * Cp[sidx(D, k, j)];
+            FC[i * D + j] = sfc;
+            sm += F[i * D + j] * bprev[j];
+        }
+        mb[i] = sm;
+    }
+#pragma unroll
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            R s1 = 0, s2 = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s1 += FC[i * D + k] * F[j * D + k], s2 += FC[j * D + k] * F[i * D + k];
+            const R vv = (i == j) ? s1 + Q[i * D + i] : (R)0.5 * (s1 + s2) + (R)0.5 * (Q[i * D + j] + Q[j * D + i]);
+            Pp[i * D + j] = vv;
+            Pp[j * D + i] = vv;
+        }
+    constexpr int NR = D + 1;
+    R W[D * D], B[D * NR], g[D];
+    R q = si.q0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R lm = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) lm += si.Lam[sidx(D, i, k)] * mb[k];
+        g[i] = si.g0[i] - lm;
+        q += mb[i] * (lm - (R)2 * si.g0[i]);
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R s = (i == j) ? (R)1 : (R)0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) s += si.Lam[sidx(D, i, k)] * Pp[k * D + j];
+            W[i * D + j] = s;
+            B[i * NR + j] = si.Lam[sidx(D, i, j)];
+        }
+        B[i * NR + D] = g[i];
+    }
+    const R ldw = lu_solve_logdet<R, D, NR>(W, B);
+    R corr = 0;
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R pg = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) pg += Pp[i * D + k] * g[k];
+        corr += pg * B[i * NR + D];
+    }
+    zinc = si.ok ? (R)-0.5 * (q - corr) - si.ldR - (R)0.5 * ldw - (R)(0.5 * LOG_2PI) * si.dim : r_nan<R>();
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        v[i] = si.ok ? B[i * NR + D] : r_nan<R>();
+#pragma unroll
+        for (int j = 0; j < D; ++j) M[i * D + j] = si.ok ? ((i == j) ? B[i * NR + i] : (R)0.5 * (B[i * NR + j] + B[j * NR + i])) : r_nan<R>();
+    }
+}
+template <typename R, int D>
+AX_HD void filter_fold_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltElem<R, D>& acc) {
+    R mb[D], Pp[D * D], M[D * D], v[D], zinc;
+    step_predict_solve<R, D>(F, Q, bd, si, acc.b, acc.C, mb, Pp, M, v, zinc);
+    R FA[D * D], PM[D * D], MFA[D * D];
+    mm<R, D, D, D>(F, acc.A, FA);
+    mm<R, D, D, D>(Pp, M, PM);
+    mm<R, D, D, D>(M, FA, MFA);
+    R Cd[D * D], Jd[D * D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R sb = mb[i], se = acc.eta[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R sa = FA[i * D + j], sc = Pp[i * D + j], sj = 0;
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                sa -= PM[i * D + k] * FA[k * D + j];
+                sc -= PM[i * D + k] * Pp[k * D + j];
+                sj += FA[k * D + i] * MFA[k * D + j];
+            }
+            acc.A[i * D + j] = sa;
+            Cd[i * D + j] = sc;
+            Jd[i * D + j] = sj;
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) sb += Pp[i * D + k] * v[k], se += FA[k * D + i] * v[k];
+        acc.b[i] = sb;
+        acc.eta[i] = se;
+    }
+    sympack<R, D>(Cd, acc.C);
+    R Js[symsize(D)];
+    sympack<R, D>(Jd, Js);
+#pragma unroll
+    for (int i = 0; i < symsize(D); ++i) acc.J[i] += Js[i];
+    acc.z += zinc;
+}
+// the (b, C, z) half: one Kalman step in information form
+template <typename R, int D>
+AX_HD void filter_apply_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltPre<R, D>& p) {
+    R mb[D], Pp[D * D], M[D * D], v[D], zinc;
+    step_predict_solve<R, D>(F, Q, bd, si, p.b, p.C, mb, Pp, M, v, zinc);
+    R PM[D * D], Cd[D * D];
+    mm<R, D, D, D>(Pp, M, PM);
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R sb = mb[i];
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R sc = Pp[i * D + j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) sc -= PM[i * D + k] * Pp[k * D + j];
+            Cd[i * D + j] = sc;
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) sb += Pp[i * D + k] * v[k];
+        p.b[i] = sb;
+    }
+    sympack<R, D>(Cd, p.C);
+    p.z += zinc;
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -373,15 +373,29 @@ __global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, S
     const int s = (blockIdx.x % stiles) * TB_CM + threadIdx.x;
     if (s >= S) return;
     const int i0 = ch * lay.E, i1 = min(n, i0 + lay.E);
-    Full acc, nxt;
-    Op::load_elem(a, s, i0, acc);
-    if (i0 + 1 < i1) Op::load_elem(a, s, i0 + 1, nxt);
-    for (int i = i0 + 1; i < i1; ++i) {
-        const Full cur = nxt;
-        if (i + 1 < i1) Op::load_elem(a, s, opaque_uniform(i + 1), nxt);  // next element's reads fly during the combine
-        Full o;
-        Op::combine(acc, cur, o);
-        acc = o;
+    using Raw = typename Op::Raw;
+    Full acc;
+    Raw nxt;
+    if constexpr (Op::kFold) {
+        // the operator folds raw steps onto the prefix itself (no element is formed); the next step's reads fly during the fold
+        Op::init_acc(a, s, ch, acc);
+        Op::load_raw(a, s, i0, nxt);
+        for (int i = i0; i < i1; ++i) {
+            const Raw cur = nxt;
+            if (i + 1 < i1) Op::load_raw(a, s, opaque_uniform(i + 1), nxt);
+            Op::fold(a, s, opaque_uniform(i), cur, acc);
+        }
+    } else {
+        Op::load_elem(a, s, i0, acc);
+        if (i0 + 1 < i1) Op::load_raw(a, s, i0 + 1, nxt);
+        for (int i = i0 + 1; i < i1; ++i) {
+            const Raw cur = nxt;
+            if (i + 1 < i1) Op::load_raw(a, s, opaque_uniform(i + 1), nxt);  // next element's reads fly during the build + combine
+            Full e, o;
+            Op::build(a, s, opaque_uniform(i), cur, e);
+            Op::combine(acc, e, o);
+            acc = o;
+        }
     }
     Op::store_rec((R*)sb.agg + ((long long)s * lay.nchunk + ch) * Full::NPAD, acc);
 }
@@ -397,22 +411,33 @@ __global__ void __launch_bounds__(TB_CM) k_scan_down_cm(typename Op::Args a, Sca
     if (s >= S) return;
     const int i0 = ch * lay.E, i1 = min(n, i0 + lay.E);
     Pre p;
-    if (lay.nchunk > 1) {
+    if (lay.nchunk > 1 && !(Op::kFold && ch == 0)) {
         Op::load_pre((const R*)sb.pre + ((long long)s * lay.nchunk + ch) * Pre::NPAD, p);
     } else {
-        Full id;
-        Op::identity(id);
-        Op::to_pre(id, p);
+        if constexpr (Op::kFold) {
+            Op::init_pre(a, s, p);
+        } else {
+            Full id;
+            Op::identity(id);
+            Op::to_pre(id, p);
+        }
     }
     {
-        Full nxt;
-        if (i0 < i1) Op::load_elem(a, s, i0, nxt);
+        using Raw = typename Op::Raw;
+        Raw nxt;
+        if (i0 < i1) Op::load_raw(a, s, i0, nxt);
         for (int i = i0; i < i1; ++i) {
-            const Full cur = nxt;
-            if (i + 1 < i1) Op::load_elem(a, s, opaque_uniform(i + 1), nxt);
-            Pre o;
-            Op::apply(p, cur, o);
-            p = o;
+            const Raw cur = nxt;
+            if (i + 1 < i1) Op::load_raw(a, s, opaque_uniform(i + 1), nxt);
+            if constexpr (Op::kFold) {
+                Op::walk(a, s, opaque_uniform(i), cur, p);
+            } else {
+                Full e;
+                Pre o;
+                Op::build(a, s, opaque_uniform(i), cur, e);
+                Op::apply(p, e, o);
+                p = o;
+            }
             Op::write_out(a, s, opaque_uniform(i), p);
         }
     }
@@ -568,6 +593,12 @@ inline unsigned grid_aff(int S, int nchunk) { return (unsigned)(((nchunk + 7) / 
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_gain_tab(FilterArgs a, const R* __restrict__ Ps1) {
     const int i = blockIdx.x * TB_ELEM + threadIdx.x;
     if (i < a.d.n()) body_gain_tab<R, D, P>(a, Ps1, i);
+}
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_obs_info_tab(FilterArgs a) {
+    const int i = blockIdx.x * TB_ELEM + threadIdx.x;
+    if constexpr (P > D) {
+        if (i < a.d.n()) body_obs_info_tab<R, D, P>(a, i);
+    }
 }
 // the mask carrier of the matrix filter when the concatenated observations are built on the fly: [0 ; yobs_t]
 template <typename R> __global__ void k_mask_obs(int T, int D, int P, Arr yobs, R* __restrict__ out) {
@@ -746,6 +777,7 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     b += (size_t)d.T * (D + D * D + P) * sizeof(R) + 1024;
     b += (size_t)(n > 0 ? n : 1) * GainRow<R, D, P>::NPAD * sizeof(R) + 256;
     b += aff_ws_bytes<R, D>(h, S, n, parallel);
+    b += (size_t)(n > 0 ? n : 1) * ObsInfoRow<R, D>::NPAD * sizeof(R) + 256;
     return b;
 }
 
@@ -816,11 +848,37 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     const bool shared_on = h->share_model != 0;
     const bool shared = shared_on && cm && n > 0 && a.d.B == 1 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 &&
                         a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
-    if (!shared) a.aux_on = 0;  // (the caller materialised the concatenated observations in that case)
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
     if (!a.ell0) return AUXSSM_ERR_NOMEM;
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     if (shared) return run_filter_shared<R, D, P>(h, a, parallel, ell_out);
+    // general chain-minor path on the concatenated auxiliary model: elements are built on the fly inside both scan passes
+    // (FilterArgs::aux_on is the caller's promise that ys holds row t = 0 only and that the model is the concatenated one)
+    const bool fly = a_in.aux_on != 0 && n > 0;
+    if (fly && !(cm && P > D && a_in.pblk == D && a.d.B == 1 && a.Hs.sc == 0 && a.Rs.sc == 0 && a.cs.sc == 0 && a_in.aux_yobs.sc == 0)) {
+        set_error("internal: on-the-fly auxiliary observations need the chain-minor layout and a chain-shared concatenated observation model");
+        return AUXSSM_ERR_ARG;
+    }
+    if (fly) {
+        if constexpr (P > D) {
+            a.elem = nullptr;
+            a.obs_tab = ws_take(h, (size_t)n * ObsInfoRow<R, D>::NPAD * sizeof(R));
+            a.ellz = ws_take(h, (size_t)S * sizeof(R));
+            if (!a.obs_tab || !a.ellz) return AUXSSM_ERR_NOMEM;
+            {
+                ProfScope ps(h, AUXSSM_K_FILTER_TAB);
+                hipLaunchKernelGGL((k_obs_info_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
+            }
+            {
+                ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+                const int rc = run_scan<FilterOp<R, D>, FilterOpFly<R, D, P, true>, FilterOpFly<R, D, P, false>>(h, a, S, n);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, 1, (R*)ell_out);
+            AX_HIP(hipGetLastError());
+            return AUXSSM_OK;
+        }
+    }
     a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final
     // pass writes it per sequence; the reference's second pass over the filtered moments (filtering.py:60-62) does not exist here

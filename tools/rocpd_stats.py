@@ -12,7 +12,7 @@ import sys
 
 def demangle(names):
     try:
-        out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True, timeout=60).stdout.splitlines()
+        out = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True, timeout=60).stdout.splitlines()
         if len(out) == len(names):
             return out
     except Exception:
