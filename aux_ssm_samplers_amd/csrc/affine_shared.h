@@ -7,7 +7,8 @@
 // filtered covariances P_t.  From them one table row per transition holds the operators of the chain's part of the prefixes:
 //     K_t  = P_t^- H^T S_t^-1            (P_t^- = F P_{t-1} F^T + Q, S_t = H P_t^- H^T + R; masked rows deleted)
 //     Mb_t = F - K_t H F,   kc_t = b - K_t (H b + c)          m_t = Mb_t m_{t-1} + kc_t + K_t y_t
-//     Si_t = S_t^-1, c0_t = -log|S_t|/2 - dim/2 log 2 pi        ell += -r^T Si_t r / 2 + c0_t,  r = y_t - H (F m_{t-1} + b) - c
+//     Si_t = S_t^-1, c0_t = -log|S_t|/2 - dim/2 log 2 pi        ell += -r^T Si_t r / 2 + c0_t,  r = y_t - HF_t m_{t-1} - ym_t
+//     HF_t = H F, ym_t = H b + c                                (r = y_t - H (F m_{t-1} + b) - c)
 // i.e. the (b, z) components of prefix k of the scan written as a recursion in k -- the composition of the same chain-shared
 // operators in the same order; the eta / J components are only needed to build prefixes of unknown incoming covariance, which the
 // matrix filter has already done.  What a chain carries is an AFFINE map with chain-shared matrices:
@@ -23,7 +24,7 @@ namespace ax {
 
 template <typename R, int D, int P> struct GainRow {
     static constexpr int PS = symsize(P);
-    static constexpr int oM = 0, oKc = D * D, oK = oKc + D, oSi = oK + D * P, oC0 = oSi + PS, N = oC0 + 1;
+    static constexpr int oM = 0, oKc = D * D, oK = oKc + D, oHF = oK + D * P, oYm = oHF + P * D, oSi = oYm + P, oC0 = oSi + PS, N = oC0 + 1;
     static constexpr int VEC = 16 / sizeof(R);
     static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
 };
@@ -104,7 +105,9 @@ AX_HD void gain_row(const R* F, const R* bdyn, const R* Q, const R* Pprev, const
         }
     }
 #pragma unroll
-    for (int i = 0; i < D * P; ++i) row[T::oK + i] = K[i];
+    for (int i = 0; i < D * P; ++i) row[T::oK + i] = K[i], row[T::oHF + i] = HF[i];
+#pragma unroll
+    for (int k = 0; k < P; ++k) row[T::oYm + k] = ym[k];
     row[T::oC0] = -logdet - (R)(0.5 * LOG_2PI) * (R)dim;
     if (!ok) {  // a failed Cholesky is an all-NaN factor in the reference (jnp.linalg.cholesky)
         const R bad = r_nan<R>();
@@ -189,30 +192,31 @@ template <typename R_, int D, int P> struct FilterMeanOp {
 #pragma unroll
         for (int r = 0; r < D; ++r) h[r] = o[r];
     }
+    // m_t = Mb m + kc + K y (the same affine step as fold) and the innovation r = y - H (F m + b) - c = y - HF m - ym for the
+    // log-likelihood increment -r^T S^-1 r / 2 + c0; both read the incoming mean only, so they issue independently
     static AX_HD void walk(const Args& a, int s, int i, R* m, R& acc) {
         const long long t = (long long)i + 1;
         const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
-        const UniformRow<R> F = uniform_row<R>(at<R>(a.Fs, 0, i, 0)), bd = uniform_row<R>(at<R>(a.bs, 0, i, 0));
-        const UniformRow<R> H = uniform_row<R>(at<R>(a.Hs, 0, t, 0)), cv = uniform_row<R>(at<R>(a.cs, 0, t, 0));
         R y[P];
-        aff_obs<R, D, P, true>(a, s, t, y);
-        R mp[D], r[P];
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            R v = bd[k * a.bs.se];
-#pragma unroll
-            for (int j = 0; j < D; ++j) v += F[(long long)(k * D + j) * a.Fs.se] * m[j];
-            mp[k] = v;
-        }
+        aff_obs<R, D, P, false>(a, s, t, y);
+        R r[P], o[D];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            R v = cv[k * a.cs.se];
+            const bool fin = finite_(y[k]);
+            y[k] = fin ? y[k] : (R)0;
+            R v = row[T::oYm + k];
 #pragma unroll
-            for (int j = 0; j < D; ++j) {
-                const R hkj = H[(long long)(k * D + j) * a.Hs.se];
-                v += (finite_(y[k]) ? hkj : (R)0) * mp[j];  // a missing component's row of H may be NaN (test_filtering.py:45-47)
-            }
-            r[k] = finite_(y[k]) ? y[k] - v : (R)0;
+            for (int j = 0; j < D; ++j) v += row[T::oHF + k * D + j] * m[j];
+            r[k] = fin ? y[k] - v : (R)0;
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            R v = row[T::oKc + k];
+#pragma unroll
+            for (int j = 0; j < D; ++j) v += row[T::oM + k * D + j] * m[j];
+#pragma unroll
+            for (int l = 0; l < P; ++l) v += row[T::oK + k * P + l] * y[l];
+            o[k] = v;
         }
         R q = 0;
 #pragma unroll
@@ -225,12 +229,7 @@ template <typename R_, int D, int P> struct FilterMeanOp {
         const R inc = (R)-0.5 * q + row[T::oC0];
         acc += isnan_(inc) ? (R)0 : inc;  // nansum (filtering.py:62)
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            R v = mp[k];
-#pragma unroll
-            for (int l = 0; l < P; ++l) v += row[T::oK + k * P + l] * r[l];
-            m[k] = v;
-        }
+        for (int k = 0; k < D; ++k) m[k] = o[k];
         wr<R, D>(a.ms, s / a.d.B, t, s % a.d.B, m);
     }
 };

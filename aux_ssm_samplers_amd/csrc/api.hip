@@ -407,7 +407,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     const Arr yscA = cm ? cm_arr(ysc, kd, P) : dense_arr(ysc, kd, P);
     const Arr uA = cm ? cm_arr(u, kd, D) : dense_arr(u, kd, D);
     const Arr msA = cm ? cm_arr(ms, kd, D) : dense_arr(ms, kd, D);
-    const Arr PsA = cm ? cm_arr(Ps, kd, (long long)D * D) : dense_arr(Ps, kd, (long long)D * D);
+    // chain-shared parameters: the filtered covariances do not depend on the chain and are stored once, (T, D, D) dense with chain stride 0
+    const bool shared_mode = !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0);
+    const Arr PsA = shared_mode ? Arr{Ps, 0, (long long)D * D, 0, 1} : cm ? cm_arr(Ps, kd, (long long)D * D) : dense_arr(Ps, kd, (long long)D * D);
     const Arr xpA = cm ? cm_arr(xp, kd, D) : dense_arr(xp, kd, D);
     const Arr xA = cm ? cm_arr(x, kd, D) : dense_arr(x, kd, D);
     const Arr epsauxA = cm ? cm_arr(eps_aux, kd, D) : dense_arr(eps_aux, kd, D);
@@ -464,8 +466,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     sa.ms = msA; sa.Ps = PsA; sa.eps = epsA; sa.xs = xpA; sa.elem = nullptr;
     sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
     // the filtered covariances of this model do not depend on the chain when its parameters do not
-    sa.ps_shared = (model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->Hs.sc == 0 && model->Rs.sc == 0 &&
-                    model->cs.sc == 0 && model->P0.sc == 0 && C > 1) ? 1 : 0;
+    sa.ps_shared = shared_mode ? 1 : 0;
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;
     h->ws_off = mark;
@@ -478,6 +479,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
         la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
         la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
+        la.u_fly = aux_fly ? 1 : 0; la.eps_aux = epsauxA; la.shd = sqrt(0.5 * delta);
         rc = sl->run(h, la, sums);
         if (rc) return rc;
         h->ws_off = mark;
@@ -681,7 +683,8 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     dc.B = 1;
     const auxssm_arr y1d{ys1, (int64_t)T * D, (int64_t)D, 0}, y2d{ys2, (int64_t)T * D, (int64_t)D, 0};
     // the filtered covariances do not depend on the chain when neither the dynamics nor R do (first order)
-    const int ps_shared = (!second && C > 1 && model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0) ? 1 : 0;
+    const int ps_shared = (!second && !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0)) ? 1 : 0;
+    const Arr PsA = ps_shared ? Arr{Ps, 0, (long long)D * D, 0, 1} : arr(Ps, (long long)D * D);
 
     // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
     {
@@ -693,7 +696,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fill_filter_args(fa, &dc, &g1, &y1d, ms, Ps);
     fa.ys = y1A;
     fa.ms = arr(ms, D);
-    fa.Ps = arr(Ps, (long long)D * D);
+    fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R1A;
     rc = ke->filter(h, fa, parallel, ell1);
@@ -703,7 +706,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     sa.d = kd;
     sa.dx = D;
     sa.Fs = cv(model->Fs); sa.Qs = cv(model->Qs); sa.bs = cv(model->bs);
-    sa.ms = arr(ms, D); sa.Ps = arr(Ps, (long long)D * D);
+    sa.ms = arr(ms, D); sa.Ps = PsA;
     sa.eps = arr(eps_samp, D); sa.xs = xpA; sa.elem = nullptr;
     sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
     sa.ps_shared = cm ? ps_shared : 0;
@@ -719,7 +722,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fill_filter_args(fa, &dc, &g2, &y2d, ms, Ps);
     fa.ys = y2A;
     fa.ms = arr(ms, D);
-    fa.Ps = arr(Ps, (long long)D * D);
+    fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R2A;
     rc = ke->filter(h, fa, parallel, ell2);
@@ -920,6 +923,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
         la.Fs = Arr{nullptr, 0, 0, 0, 1}; la.bs = Arr{nullptr, 0, 0, 0, 1};
         la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
         la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
+        la.u_fly = aux_fly ? 1 : 0; la.eps_aux = arr(eps_aux, D); la.shd = sqrt(0.5 * delta);
         la.lor_par = par; la.lor_psc = psc;
         rc = sl->lorenz(h, la, sums);  // [5][C]: jp_prop, jp_rev, lt_prop, lt_rev, corr
         if (rc) return rc;
@@ -1307,19 +1311,17 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
         return AUXSSM_ERR_ARG;
     }
     if (lorenz) {
-        if (dtype == AUXSSM_F32)
-            return sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
-        return sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
-    }
-    if (sv) {
+        rc = dtype == AUXSSM_F32 ? sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+    } else if (sv) {
         const int order = model_kind == AUXSSM_KMODEL_SV_FIRST ? 1 : 2;
-        if (dtype == AUXSSM_F32)
-            return sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
-        return sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        rc = dtype == AUXSSM_F32 ? sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+    } else {
+        rc = dtype == AUXSSM_F32 ? sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
-    if (dtype == AUXSSM_F32)
-        return sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
-    return sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+    return rc;
 }
 
 static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32_t k1, uint32_t stream, int64_t n, void* out) {

@@ -10,11 +10,10 @@
 // parents from LDS -> propagate -> pin particle 0 to the reference trajectory -> log-weights -> block max / sum
 // -> normalise.  xs, log_ws, As stream to HBM with the particle index fastest (coalesced).
 //
-// Reduction orders (the contract the oracle restates, SURVEY 7 "bit-exact ancestors"):
-//   cumsum : inside each group of 64 consecutive particles a Kogge-Stone scan (offsets 1,2,..,32); group totals are
-//            added left to right; c_i = (t_0 + t_1 + ... + t_{g-1}) + local_i.
-//   sum    : balanced binary tree inside each group of 64 (== last element of that Kogge-Stone scan), then left to
-//            right over groups.   max : exact.
+// Reduction orders (the contract the oracle restates, SURVEY 7 "bit-exact ancestors"): the sweep kernels follow the "sweep contract"
+// of csmc_dev.h (unnormalised weights exp(lw - max), the hardware's DPP scan order, two-level search, ballot-counted single draw);
+// the standalone primitives (normalize / multinomial / systematic) and the parallel-in-time sweep keep the Kogge-Stone-in-64 cumsum,
+// the balanced-tree-in-64 sum and the plain binary search of csmc_dev.h.
 #include "csmc_dev.h"
 
 namespace ax {
@@ -100,7 +99,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         for (int k = 0; k < D; ++k) xs[(long long)tid * D + k] = x[k];
         lws[tid] = lw;
     }
-    R w = block_normalize<R>(lw, red, tid, nw);
+    R w = block_expmax<R>(lw, red, tid, nw);
 
     for (int t = 1; t < T; ++t) {
         // issue this step's independent loads first
@@ -130,14 +129,11 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         R* xprev = xbuf + (t & 1) * TB * D;
 #pragma unroll
         for (int k = 0; k < D; ++k) xprev[tid * D + k] = x[k];
-        block_cumsum<R>(w, c, red, tid, nw);  // trailing barrier also publishes xprev
+        R Pg[16];
+        block_cumsum_dpp<R>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
         const R tot = c[N - 1];
         int idx = 0;
-        if (live && tid > 0) {
-            const R r = tot * ((R)1 - un);
-            idx = lower_bound<R>(c, N, r);
-            idx = idx < N - 1 ? idx : N - 1;
-        }
+        if (live && tid > 0) idx = search2<R>(c, Pg, N, nw, tot * ((R)1 - un));
         R xp[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
@@ -178,18 +174,33 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
             lws[o] = lw;
             if (As) As[(long long)(t - 1) * N + tid] = idx;
         }
-        w = block_normalize<R>(lw, red, tid, nw);
+        w = block_expmax<R>(lw, red, tid, nw);
     }
     if (live) ((R*)a.wT)[(long long)ch * N + tid] = w;
 }
 
 // ---- backward passes (csmc.py:110-149) ------------------------------------------------------------------------------------
+// One draw per step: B = #{j : c_j < r} by ballot + per-wave counts (no serial search), the candidate particles of the step are
+// published to LDS before the first barrier so that x_t^B is an LDS read, and the next step's rows (xs, log_ws) and uniform are
+// fetched one step ahead: no global-memory latency on the dependent chain.  4 barriers per step (max, wave totals, publish, counts).
+template <typename R> __device__ __forceinline__ int block_count_below(const R* c, R r, bool live, int tid, int nw, int* cnt, int N) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const unsigned long long bal = __ballot(live && c[tid] < r);
+    if (lane == 0) cnt[wv] = __popcll(bal);
+    __syncthreads();
+    int B = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) B += k < nw ? cnt[k] : 0;
+    return B < N - 1 ? B : N - 1;
+}
 template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
-    R* c = (R*)smem;
-    R* red = c + TB;
-    int& sB = *(int*)(red + 48);
+    R* c = (R*)smem;                 // [TB]
+    R* red = c + TB;                 // [48]
+    R* xpub = red + 48;              // [2][TB][D] candidate particles of the step, by step parity
+    R* ubuf = xpub + 2 * TB * D;     // [2] the step's uniform, by step parity
+    int* cnt = (int*)(ubuf + 2);     // [2][16] per-wave counts, by step parity
     const int ch = blockIdx.x;
     const bool live = tid < N;
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
@@ -200,20 +211,22 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(
     const long long ub_base = (long long)ch * T;
     const R ninf = -INFINITY;
 
-    // B_T ~ choice(w_T)   (csmc.py:111 / :131)
+    // B_T ~ choice(w_T)   (csmc.py:111 / :131); w_T are the forward pass's unnormalised weights
     R w = live ? ((const R*)a.wT)[(long long)ch * N + tid] : (R)0;
-    block_cumsum<R>(w, c, red, tid, nw);
-    if (tid == 0) {
-        const R un = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 1));
-        const R r = c[N - 1] * ((R)1 - un);
-        int B = lower_bound<R>(c, N, r);
-        sB = B < N - 1 ? B : N - 1;
+    if (tid == 0) ubuf[1] = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 1));
+    {
+        R xi[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[k] = live ? xs[((long long)(T - 1) * N + tid) * D + k] : (R)0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) xpub[(TB + tid) * D + k] = xi[k];
     }
-    __syncthreads();
-    int B = sB;
+    R Pg[16];
+    block_cumsum_dpp<R>(w, c, red, tid, nw, Pg);
+    int B = block_count_below<R>(c, c[N - 1] * ((R)1 - ubuf[1]), live, tid, nw, cnt + 16, N);
     R xn[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) xn[k] = xs[((long long)(T - 1) * N + B) * D + k];
+    for (int k = 0; k < D; ++k) xn[k] = xpub[(TB + B) * D + k];
     if (tid == 0) {
 #pragma unroll
         for (int k = 0; k < D; ++k) xout[(long long)(T - 1) * D + k] = xn[k];
@@ -232,28 +245,40 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(
         return;
     }
     // backward sampling (Whiteley), csmc.py:134-146
+    __syncthreads();  // the parity-1 slots of the first draw are free again
+    R xi_nx[D], lw_nx = ninf, un_nx = 0;
+    if (T >= 2) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi_nx[k] = live ? xs[((long long)(T - 2) * N + tid) * D + k] : (R)0;
+        lw_nx = live ? lws[(long long)(T - 2) * N + tid] : ninf;
+        if (tid == 0) un_nx = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 2));
+    }
     for (int t = T - 2; t >= 0; --t) {
+        const int par = t & 1;
+        R xi[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[k] = xi_nx[k];
+        const R lwi = lw_nx, un_t = un_nx;
+        if (t > 0) {  // the rows of step t - 1: independent of this step's draw
+#pragma unroll
+            for (int k = 0; k < D; ++k) xi_nx[k] = live ? xs[((long long)(t - 1) * N + tid) * D + k] : (R)0;
+            lw_nx = live ? lws[(long long)(t - 1) * N + tid] : ninf;
+            if (tid == 0) un_nx = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (t - 1));
+        }
         R lw = ninf;
         if (live) {
-            R xi[D], mu[D];
-#pragma unroll
-            for (int k = 0; k < D; ++k) xi[k] = xs[((long long)t * N + tid) * D + k];
+            R mu[D];
             trans_mean<R, D>(m, xi, mu);
-            lw = gauss_chol_logpdf<R, D>(xn, mu, m.LQ, m.c_trans) + lws[(long long)t * N + tid];
+            lw = gauss_chol_logpdf<R, D>(xn, mu, m.LQ, m.c_trans) + lwi;
         }
-        __syncthreads();  // c / sB of the previous iteration fully consumed
-        w = block_normalize<R>(lw, red, tid, nw);
-        block_cumsum<R>(w, c, red, tid, nw);
-        if (tid == 0) {
-            const R un = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + t);
-            const R r = c[N - 1] * ((R)1 - un);
-            int Bt = lower_bound<R>(c, N, r);
-            sB = Bt < N - 1 ? Bt : N - 1;
-        }
-        __syncthreads();
-        B = sB;
 #pragma unroll
-        for (int k = 0; k < D; ++k) xn[k] = xs[((long long)t * N + B) * D + k];
+        for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
+        if (tid == 0) ubuf[par] = un_t;
+        w = block_expmax<R>(lw, red, tid, nw);              // barrier (more than one wave)
+        block_cumsum_dpp<R>(w, c, red, tid, nw, Pg);        // two barriers: xpub / ubuf of this parity are published as well
+        B = block_count_below<R>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
+#pragma unroll
+        for (int k = 0; k < D; ++k) xn[k] = xpub[(par * TB + B) * D + k];
         if (tid == 0) {
 #pragma unroll
             for (int k = 0; k < D; ++k) xout[(long long)t * D + k] = xn[k];
@@ -357,7 +382,8 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_BWD);
-        const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + 64;
+        const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + (size_t)2 * TB * D * sizeof(R) + 2 * sizeof(R) + 32 * sizeof(int) + 64;
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         hipLaunchKernelGGL((k_csmc_bwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
     }
     AX_HIP(hipGetLastError());

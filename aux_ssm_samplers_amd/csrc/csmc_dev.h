@@ -213,6 +213,99 @@ template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int
     return lo;
 }
 
+// ---- sweep contract (k_csmc_fwd / k_csmc_bwd of csmc.hip; restated by oracle/csmc_ref.c::csmc_ref_sweep) ---------------------------
+// The sequential sweep carries UNNORMALISED weights e_i = exp(lw_i - max lw): conditional multinomial resampling only ever uses
+// searchsorted(cumsum(w), c[-1] (1 - u)) (resamplings.py:35-36 -> jax.random.choice), which is invariant to the scale of w, so the
+// normaliser of normalize() (math/utils.py:38-39: one block sum, one log and one more exp per particle and step) is never formed.
+//   cumsum : inside each group of 64 consecutive particles the DPP scan of the hardware -- Kogge-Stone with offsets 1, 2, 4, 8 inside
+//            every row of 16 lanes, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2 and 3 += last of row 1 --
+//            group totals added left to right: c_i = (t_0 + ... + t_{g-1}) + local_i.
+//   search : two levels.  g = #{k < ng - 1 : C_k < r} with C_k = c[64 k + 63] the cumulative total at the end of group k (ng groups),
+//            then lower_bound of r inside group g: first j in [64 g, min(64 g + 64, N)) with c[j] >= r (its end if none); clipped to N - 1.
+//            On a non-decreasing c this IS searchsorted(c, r, side='left').
+//   single draw (backward pass): B = #{j < N : c_j < r}, clipped to N - 1 (again searchsorted on a non-decreasing c), counted by ballot.
+//   max    : exact, any order.
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float old, float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+template <int CTRL, int ROW_MASK> __device__ __forceinline__ double dpp_mov(double old, double v) {
+    const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, ROW_MASK, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_ROW_SHR1 = 0x111, DPP_ROW_SHR2 = 0x112, DPP_ROW_SHR4 = 0x114, DPP_ROW_SHR8 = 0x118, DPP_ROW_BCAST15 = 0x142, DPP_ROW_BCAST31 = 0x143;
+// inclusive scan of the wave in the order stated above (lanes without a source add +0)
+template <typename R> __device__ __forceinline__ R wave_scan_dpp(R v) {
+    v = v + dpp_mov<DPP_ROW_SHR1, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_SHR2, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_SHR4, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_SHR8, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_BCAST15, 0xa>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_BCAST31, 0xc>((R)0, v);
+    return v;
+}
+// max of the wave, in every lane (exact: the order is immaterial)
+template <typename R> __device__ __forceinline__ R wave_max_dpp(R v) {
+    R o;
+    o = dpp_mov<DPP_ROW_SHR1, 0xf>(v, v); v = v > o ? v : o;
+    o = dpp_mov<DPP_ROW_SHR2, 0xf>(v, v); v = v > o ? v : o;
+    o = dpp_mov<DPP_ROW_SHR4, 0xf>(v, v); v = v > o ? v : o;
+    o = dpp_mov<DPP_ROW_SHR8, 0xf>(v, v); v = v > o ? v : o;
+    o = dpp_mov<DPP_ROW_BCAST15, 0xa>(v, v); v = v > o ? v : o;
+    o = dpp_mov<DPP_ROW_BCAST31, 0xc>(v, v); v = v > o ? v : o;
+    return __shfl(v, 63, 64);  // lane 63 holds the maximum of the wave
+}
+// e_i = exp(lw_i - max lw) (non-finite max -> 0, as jax's logsumexp); red slots [0, 16)
+template <typename R> __device__ __forceinline__ R block_expmax(R lw, R* red, int tid, int nw) {
+    const int lane = tid & 63, wv = tid >> 6;
+    R m = wave_max_dpp(lw);
+    if (nw > 1) {
+        if (lane == 0) red[wv] = m;
+        __syncthreads();
+        R t[16];
+        load16<R>(red, t);
+        m = t[0];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) m = (k < nw && t[k] > m) ? t[k] : m;
+    }
+    if (!(m - m == 0)) m = 0;
+    return det_exp(lw - m);
+}
+// inclusive cumsum of w into c[] in the sweep contract's order; P[k] = cumulative total at the end of group k (k < nw), the same
+// numbers as c[64 k + 63]; c[] valid after the trailing barrier.  red slots [32, 48).
+template <typename R> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const R v = wave_scan_dpp(w);
+    if (lane == 63) red[32 + wv] = v;
+    __syncthreads();
+    R t[16];
+    load16<R>(red + 32, t);
+    P[0] = t[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) P[k] = k < nw ? P[k - 1] + t[k] : P[k - 1];
+    R pre = 0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) pre = (k + 1 == wv) ? P[k] : pre;
+    c[tid] = wv > 0 ? pre + v : v;
+    __syncthreads();
+}
+// the two-level search of the sweep contract; P from block_cumsum_dpp, ng = number of groups of 64 covering [0, N)
+template <typename R> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
+    int g = 0;
+#pragma unroll
+    for (int k = 0; k < 15; ++k) g += (k < ng - 1 && P[k] < r) ? 1 : 0;
+    int lo = g << 6, hi = min(lo + 64, N);
+#pragma unroll
+    for (int it = 0; it < 7; ++it) {  // lower_bound over at most 64 entries: at most 7 probes
+        if (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (c[mid] < r) lo = mid + 1;
+            else hi = mid;
+        }
+    }
+    return lo < N - 1 ? lo : N - 1;
+}
+
 template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model* fk, const double* host) {
     // host = [m0 (D) | chol_P0 (D*D) | F (D*D) | b (D) | chol_Q (D*D)] as doubles
     const int D = fk->dx;

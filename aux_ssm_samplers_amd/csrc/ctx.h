@@ -74,6 +74,12 @@ struct ProfScope {
     }
 };
 
+// The chain-minor sweep treats a model as chain-shared (the filter's gain-form path of affine_shared.h, the sampler's gain tables, the
+// log-density factor tables) under exactly these conditions; callers use it to lay the (then chain-independent) covariances out once.
+inline bool chain_shared_mode(const auxssm_ctx* h, int cm, int C, int T, bool params_chain_stride_0) {
+    return h->share_model != 0 && cm != 0 && C > 1 && T > 1 && params_chain_stride_0;
+}
+
 // ---- type-erased launch entry points, one set per (dtype, D) instantiation unit ---------------------
 struct ScanPlan {
     int E;       // elements per thread chunk

@@ -716,7 +716,22 @@ struct SweepLogpdfArgs {
     const void* tab = nullptr;  // chain-shared parameters: per time step the Cholesky rows of Q_{t-1} and Robs_t (else null)
     const void* lor_par = nullptr;  // Lorenz-63 sweep: rows [theta1, theta2, theta3, dt], chain stride lor_psc (Fs / bs are not read then)
     long long lor_psc = 0;
+    // u_fly != 0: rows t >= 1 of u are not materialised (the filter built them on the fly, FilterArgs::aux_*): u_t = x_t + shd eps_t
+    int u_fly = 0;
+    Arr eps_aux{};
+    double shd = 0;
 };
+// the auxiliary variable of chain c at time t >= 1
+template <typename R, int D> AX_HD void sweep_u(const SweepLogpdfArgs& a, int c, long long t, const R* x, R* u) {
+    if (a.u_fly) {
+        R e[D];
+        rd<R, D>(a.eps_aux, c, t, 0, e);
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] = x[k] + (R)a.shd * e[k];
+    } else {
+        rd<R, D>(a.u, c, t, 0, u);
+    }
+}
 template <typename R, int D, int PO> struct LogShared {
     static constexpr int oQ = 0, oR = CholRow<R, D>::SZ, N = CholRow<R, D>::SZ + CholRow<R, PO>::SZ;
     static constexpr int VEC = 16 / sizeof(R);
@@ -748,23 +763,22 @@ AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, co
     bool b1 = false, b2 = false;
     corr = 0;
     {
+        // (x - u)^2 / delta and the N(u; x, delta/2 I) terms share the squared distances: one reciprocal of delta, no division per component
         const R hd = (R)(0.5 * a.delta);
-        const R sd = sqrt_(hd);
+        const R inv_delta = (R)1 / (R)a.delta;
         R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const R d1 = u[k] - xp[k], d2 = u[k] - x[k];
             b1 = b1 || !finite_(d1);
             b2 = b2 || !finite_(d2);
-            const R z1 = d1 / sd, z2 = d2 / sd;
-            q1 += z1 * z1;
-            q2 += z2 * z2;
-            const R e1 = xp[k] - u[k], e2 = x[k] - u[k];
-            corr += (e1 * e1 - e2 * e2) / (R)a.delta;
+            q1 += d1 * d1;
+            q2 += d2 * d2;
         }
-        const R cst = -(R)D * log_(sd) - (R)(0.5 * LOG_2PI) * (R)D;
-        ax_p = b1 ? (R)0 : (R)-0.5 * q1 + cst;
-        ax_x = b2 ? (R)0 : (R)-0.5 * q2 + cst;
+        corr = (q1 - q2) * inv_delta;
+        const R cst = (R)-0.5 * (R)D * log_(hd) - (R)(0.5 * LOG_2PI) * (R)D;
+        ax_p = b1 ? (R)0 : -q1 * inv_delta + cst;
+        ax_x = b2 ? (R)0 : -q2 * inv_delta + cst;
     }
     // reference policy (jnp.nansum over per-step logpdfs): a non-finite component anywhere in the stacked residual
     // [u - x ; y - H x - c] drops the whole step of the concatenated model; the target only sees the observation block.
@@ -780,7 +794,8 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
     R x[D], xp[D], u[D], xq[D], xpq[D], H[PO * D], cv[PO], y[PO], Rm[PO * PO], F[D * D], bd[D], Q[D * D];
     io.template fetch<R, D>(at<R>(a.x, c, t, 0), a.x.st, a.x.se, valid, x);
     io.template fetch<R, D>(at<R>(a.xp, c, t, 0), a.xp.st, a.xp.se, valid, xp);
-    io.template fetch<R, D>(at<R>(a.u, c, t, 0), a.u.st, a.u.se, valid, u);
+    const Arr& ua = a.u_fly ? a.eps_aux : a.u;
+    io.template fetch<R, D>(at<R>(ua, c, t, 0), ua.st, ua.se, valid, u);
     io.template fetch<R, D>(at<R>(a.x, c, i, 0), a.x.st, a.x.se, valid, xq);
     io.template fetch<R, D>(at<R>(a.xp, c, i, 0), a.xp.st, a.xp.se, valid, xpq);
     io.template fetch<R, PO * D>(at<R>(a.Hs, c, t, 0), a.Hs.st, a.Hs.se, valid, H);
@@ -792,7 +807,7 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
     io.template fetch<R, D * D>(at<R>(a.Qs, c, i, 0), a.Qs.st, a.Qs.se, valid, Q);
     io.template finish<R, D>(a.x.st, a.x.se, valid, x);
     io.template finish<R, D>(a.xp.st, a.xp.se, valid, xp);
-    io.template finish<R, D>(a.u.st, a.u.se, valid, u);
+    io.template finish<R, D>(ua.st, ua.se, valid, u);
     io.template finish<R, D>(a.x.st, a.x.se, valid, xq);
     io.template finish<R, D>(a.xp.st, a.xp.se, valid, xpq);
     io.template finish<R, PO * D>(a.Hs.st, a.Hs.se, valid, H);
@@ -804,6 +819,10 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
 #pragma unroll
     for (int k = 0; k < 5; ++k) out5[k] = 0;
     if (!valid) return;
+    if (a.u_fly) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] = x[k] + (R)a.shd * u[k];
+    }
     R cc_p, cc_x, ob_p, ob_x, corr;
     sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
     R pr_p, pr_x;
@@ -873,7 +892,7 @@ template <typename R, int PO> AX_HD void body_lorenz_logpdf(const SweepLogpdfArg
     R x[D], xp[D], u[D], xq[D], xpq[D], H[PO * D], cv[PO], y[PO], Rm[PO * PO], Q[D * D];
     rd<R, D>(a.x, c, t, 0, x);
     rd<R, D>(a.xp, c, t, 0, xp);
-    rd<R, D>(a.u, c, t, 0, u);
+    sweep_u<R, D>(a, c, t, x, u);
     rd<R, D>(a.x, c, i, 0, xq);
     rd<R, D>(a.xp, c, i, 0, xpq);
     rd<R, PO * D>(a.Hs, c, t, 0, H);
@@ -1013,24 +1032,20 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_tab(const Swee
     chol_row<R, PO>(Rm, a.nan_policy == 1 ? skip : nullptr, row + T::oR);
     stv<R, T::N>((R*)a.tab + (long long)i * T::NPAD, row);
 }
+// x, xp, u: the chain's values at time t = i + 1 (u: eps_t when a.u_fly); xq, xpq: at time t - 1.  The caller streams them (the
+// previous step's x / xp stay in registers, the next step's reads are issued before this one is evaluated).
 template <typename R, int D, int PO>
-AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int c, int i, R* out5) {
+AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int i, const R* x, const R* xp, const R* u_in, const R* xq, const R* xpq, R* out5) {
     using T = LogShared<R, D, PO>;
     using CQ = CholRow<R, D>;
     using CR = CholRow<R, PO>;
     const long long t = (long long)i + 1;
     const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
-    R x[D], xp[D], u[D], xq[D], xpq[D], H[PO * D], cv[PO], y[PO], F[D * D], bd[D];
-    rd<R, D>(a.x, c, t, 0, x);
-    rd<R, D>(a.xp, c, t, 0, xp);
-    rd<R, D>(a.u, c, t, 0, u);
-    rd<R, D>(a.x, c, i, 0, xq);
-    rd<R, D>(a.xp, c, i, 0, xpq);
-    rd<R, PO * D>(a.Hs, 0, t, 0, H);
-    rd<R, PO>(a.cs, 0, t, 0, cv);
-    rd<R, PO>(a.ys, 0, t, 0, y);
-    rd<R, D * D>(a.Fs, 0, i, 0, F);
-    rd<R, D>(a.bs, 0, i, 0, bd);
+    const UniformRow<R> H = uniform_row<R>(at<R>(a.Hs, 0, t, 0)), cv = uniform_row<R>(at<R>(a.cs, 0, t, 0)), y = uniform_row<R>(at<R>(a.ys, 0, t, 0));
+    const UniformRow<R> F = uniform_row<R>(at<R>(a.Fs, 0, i, 0)), bd = uniform_row<R>(at<R>(a.bs, 0, i, 0));
+    R u[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)a.shd * u_in[k] : u_in[k];
     // observation block (sweep_obs_terms with the factor from the table)
     R ob_p, ob_x;
     bool badobs_x = false, badobs_p = false;
@@ -1054,34 +1069,37 @@ AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int c, int i, R* o
     R ax_x, ax_p, corr = 0;
     bool b1 = false, b2 = false;
     {
+        // (x - u)^2 / delta and the N(u; x, delta/2 I) terms share the squared distances: one reciprocal of delta, no division per component
         const R hd = (R)(0.5 * a.delta);
-        const R sd = sqrt_(hd);
+        const R inv_delta = (R)1 / (R)a.delta;
         R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             const R d1 = u[k] - xp[k], d2 = u[k] - x[k];
             b1 = b1 || !finite_(d1);
             b2 = b2 || !finite_(d2);
-            const R z1 = d1 / sd, z2 = d2 / sd;
-            q1 += z1 * z1;
-            q2 += z2 * z2;
-            const R e1 = xp[k] - u[k], e2 = x[k] - u[k];
-            corr += (e1 * e1 - e2 * e2) / (R)a.delta;
+            q1 += d1 * d1;
+            q2 += d2 * d2;
         }
-        const R cst = -(R)D * log_(sd) - (R)(0.5 * LOG_2PI) * (R)D;
-        ax_p = b1 ? (R)0 : (R)-0.5 * q1 + cst;
-        ax_x = b2 ? (R)0 : (R)-0.5 * q2 + cst;
+        corr = (q1 - q2) * inv_delta;
+        const R cst = (R)-0.5 * (R)D * log_(hd) - (R)(0.5 * LOG_2PI) * (R)D;
+        ax_p = b1 ? (R)0 : -q1 * inv_delta + cst;
+        ax_x = b2 ? (R)0 : -q2 * inv_delta + cst;
     }
     const bool ref = a.nan_policy == 0;
     const R cc_p = (ref && (b1 || badobs_p)) ? (R)0 : ax_p + ob_p;
     const R cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
     R pr_p, pr_x;
     {
-        R r1[D], r2[D], m1[D], m2[D];
-        mv<R, D, D>(F, xpq, m1);
-        mv<R, D, D>(F, xq, m2);
+        R r1[D], r2[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
+        for (int k = 0; k < D; ++k) {
+            R m1 = bd[k], m2 = bd[k];
+#pragma unroll
+            for (int j = 0; j < D; ++j) m1 += F[k * D + j] * xpq[j], m2 += F[k * D + j] * xq[j];
+            r1[k] = xp[k] - m1;
+            r2[k] = x[k] - m2;
+        }
         gauss_logpdf2_fact<R, D>(r1, r2, row + T::oQ + CQ::oL, row + T::oQ + CQ::oI, row[T::oQ + CQ::oC], nullptr, pr_p, pr_x);
     }
     out5[0] = cc_p + pr_p;

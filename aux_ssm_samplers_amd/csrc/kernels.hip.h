@@ -273,10 +273,29 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArg
     if (!c.live) return;
     R v[5] = {0, 0, 0, 0, 0};
     if (c.tt == 0) body_sweep_logpdf_head<R, D, PO>(a, c.s, v);
+    // stream the chain's values: (x, xp) of the previous step stay in registers, the next step's reads fly during this step's arithmetic
+    const Arr& ua = a.u_fly ? a.eps_aux : a.u;
+    R xq[D], xpq[D], xn[D], xpn[D], un[D];
+    rd<R, D>(a.x, c.s, c.i0, 0, xq);
+    rd<R, D>(a.xp, c.s, c.i0, 0, xpq);
+    rd<R, D>(a.x, c.s, (long long)c.i0 + 1, 0, xn);
+    rd<R, D>(a.xp, c.s, (long long)c.i0 + 1, 0, xpn);
+    rd<R, D>(ua, c.s, (long long)c.i0 + 1, 0, un);
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
+        R xc[D], xpc[D], uc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xc[k] = xn[k], xpc[k] = xpn[k], uc[k] = un[k];
+        if (i + 1 < c.i1) {
+            const long long tn = (long long)opaque_uniform(i + 1) + 1;
+            rd<R, D>(a.x, c.s, tn, 0, xn);
+            rd<R, D>(a.xp, c.s, tn, 0, xpn);
+            rd<R, D>(ua, c.s, tn, 0, un);
+        }
         R w[5];
-        body_sweep_logpdf_shared<R, D, PO>(a, c.s, opaque_uniform(i), w);
+        body_sweep_logpdf_shared<R, D, PO>(a, opaque_uniform(i), xc, xpc, uc, xq, xpq, w);
+#pragma unroll
+        for (int k = 0; k < D; ++k) xq[k] = xc[k], xpq[k] = xpc[k];
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += w[k];
     }
@@ -669,7 +688,8 @@ __global__ void __launch_bounds__(TB_CM) k_aff_down(typename Op::Args a, ScanBuf
     for (int j = j0; j < j1; ++j) Op::walk(a, s, opaque_uniform(j), h, acc);
     if (part) part[(long long)s * pl.nchunk + ch] = acc;
 }
-// about eight waves per SIMD of (chain tile, chunk) lanes: a chain's state is a handful of registers, the passes stream their inputs
+// about four waves per SIMD of (chain tile, chunk) lanes (measured at C2 x 256 chains: E = 64 beats 16 / 32 by 4 %): a chain's state is
+// a handful of registers, the passes stream their inputs
 inline AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
     AffPlan p;
     if (!parallel || N <= 2) {
@@ -678,7 +698,7 @@ inline AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
         return p;
     }
     const long long stiles = (S + TB_CM - 1) / TB_CM;
-    long long want = (long long)h->num_cu * 4 * 8 / stiles;  // chunks
+    long long want = (long long)h->num_cu * 4 * 4 / stiles;  // chunks
     if (want < 1) want = 1;
     long long E = (N + want - 1) / want;
     if (E < 16) E = 16;
@@ -785,8 +805,11 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
 // chains carry an affine recursion with chain-shared matrices.  `a` holds the chain-minor views of ys / ms / Ps; ell0 is filled.
 template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterArgs& a, int parallel, void* ell_out) {
     const int S = a.d.S(), n = a.d.n(), T = a.d.T;
+    // the covariances are chain-independent: the caller lays them out once, (T, D, D) dense with chain stride 0 (ctx.h::chain_shared_mode),
+    // and the matrix filter writes them in place; any other layout gets chain 0's slot filled from a scratch copy
+    const bool ps_once = a.Ps.sc == 0 && a.Ps.se == 1 && a.Ps.st == (long long)D * D;
     R* ms1 = (R*)ws_take(h, (size_t)T * D * sizeof(R));
-    R* Ps1 = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+    R* Ps1 = ps_once ? const_cast<R*>((const R*)a.Ps.ptr) : (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
     R* sc1 = (R*)ws_take(h, 4 * sizeof(R));
     if (!ms1 || !Ps1 || !sc1) return AUXSSM_ERR_NOMEM;
     {
@@ -821,9 +844,11 @@ template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterA
         a.tab = ws_take(h, (size_t)n * GainRow<R, D, P>::NPAD * sizeof(R));
         if (!a.tab) return AUXSSM_ERR_NOMEM;
         hipLaunchKernelGGL((k_gain_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a, (const R*)Ps1);
-        // the filtered covariances are the same for every chain: chain 0's slot of the caller's buffer holds them (the sampler's table reads it)
-        hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
+        if (!ps_once)  // chain 0's slot of the caller's buffer (the sampler's table reads that one)
+            hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
     }
+    // t = 0 update of every chain (after the join: it reads the concatenated model and shares Ps[0]'s slot with the copy above)
+    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     R* part = nullptr;
     int nchunk = 1;
     {
@@ -850,8 +875,8 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
                         a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
     if (!a.ell0) return AUXSSM_ERR_NOMEM;
-    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     if (shared) return run_filter_shared<R, D, P>(h, a, parallel, ell_out);
+    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     // general chain-minor path on the concatenated auxiliary model: elements are built on the fly inside both scan passes
     // (FilterArgs::aux_on is the caller's promise that ys holds row t = 0 only and that the model is the concatenated one)
     const bool fly = a_in.aux_on != 0 && n > 0;
@@ -871,7 +896,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
             }
             {
                 ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-                const int rc = run_scan<FilterOp<R, D>, FilterOpFly<R, D, P, true>, FilterOpFly<R, D, P, false>>(h, a, S, n);
+                const int rc = run_scan<FilterOp<R, D>, FilterOpFly<R, D, P, false>, FilterOpFly<R, D, P, false>>(h, a, S, n);
                 if (rc) return rc;
             }
             hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, 1, (R*)ell_out);

@@ -15,9 +15,18 @@
  * "Parity unpinned" against JAX bits: JAX is not installed, and XLA's summation order / exp / log are unknowable here,
  * so the float-level contract is fixed HERE and the HIP kernels must reproduce it bit for bit:
  *   - exp/log: the fdlibm-derived fixed operation sequences below (IEEE +,-,*,/,fma,rint only);
- *   - cumsum : Kogge-Stone scan inside each group of 64 consecutive particles, group totals added left to right,
- *              c_i = (t_0 + ... + t_{g-1}) + local_i;
- *   - sum    : balanced binary tree inside each group of 64, then left to right over groups;  max: exact;
+ *   - standalone primitives (normalize / multinomial / systematic) and the parallel-in-time sweep:
+ *       cumsum : Kogge-Stone scan inside each group of 64 consecutive particles, group totals added left to right,
+ *                c_i = (t_0 + ... + t_{g-1}) + local_i;
+ *       sum    : balanced binary tree inside each group of 64, then left to right over groups;  max: exact;
+ *   - the sequential sweep (csmc_ref_sweep), "sweep contract" of csrc/csmc_dev.h: the weights carried between steps are
+ *     exp(lw - max lw), NOT divided by their sum -- resampling is searchsorted(cumsum(w), c[-1] (1 - u)) (resamplings.py:35-36 ->
+ *     jax.random.choice), invariant to the scale of w, so normalize()'s logsumexp (math/utils.py:38-39) is never formed;
+ *       cumsum : inside each group of 64 the scan order of the GPU's DPP network: Kogge-Stone with offsets 1, 2, 4, 8 inside each
+ *                row of 16, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2, 3 += last of row 1; group totals
+ *                left to right as above;
+ *       search : g = #{k < ng - 1 : c[64 k + 63] < r}, then lower_bound inside group g; clipped to N - 1 (== searchsorted on a
+ *                non-decreasing c);   single draw of the backward pass: B = #{j : c_j < r}, clipped to N - 1;
  *   - every multiply-add that is fused is written as fma(); compile with -ffp-contract=off.
  * What IS pinned: the statistical known answers of the reference's tests (test_csmc.py::test_flat_potential :18-69,
  * test_resamplings.py::test_multinomial_resampling :11-24) -- see tests/test_oracle_csmc.py.
@@ -305,6 +314,49 @@ static int SUF(choice)(const REAL* c, int N, REAL un) {
     return i < N - 1 ? i : N - 1;
 }
 
+/* ---- sweep contract (csrc/csmc_dev.h) ---- */
+static void SUF(expmax)(const REAL* lw, int N, REAL* w) {
+    REAL m = lw[0];
+    for (int i = 1; i < N; ++i) m = m > lw[i] ? m : lw[i];
+    if (!(m - m == 0)) m = 0;
+    for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - m);
+}
+static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) {
+    REAL pre = 0;
+    for (int g = 0; g * 64 < N; ++g) {
+        REAL t[64], o[64];
+        const int n = N - g * 64 < 64 ? N - g * 64 : 64;
+        for (int i = 0; i < 64; ++i) t[i] = i < n ? w[g * 64 + i] : (REAL)0;
+        for (int off = 1; off < 16; off <<= 1) { /* Kogge-Stone inside every row of 16 (row_shr:off; lanes without a source add +0) */
+            for (int i = 0; i < 64; ++i) o[i] = t[i] + ((i & 15) >= off ? t[i - off] : (REAL)0);
+            memcpy(t, o, sizeof t);
+        }
+        for (int i = 0; i < 64; ++i) o[i] = t[i] + (((i >> 4) & 1) ? t[(i & ~15) - 1] : (REAL)0); /* row_bcast:15, rows 1 and 3 */
+        memcpy(t, o, sizeof t);
+        for (int i = 0; i < 64; ++i) o[i] = t[i] + (i >= 32 ? t[31] : (REAL)0);                   /* row_bcast:31, rows 2 and 3 */
+        memcpy(t, o, sizeof t);
+        for (int i = 0; i < n; ++i) c[g * 64 + i] = g == 0 ? t[i] : pre + t[i];
+        pre = g == 0 ? t[63] : pre + t[63];
+    }
+}
+/* conditional-multinomial ancestor of one particle: two-level search */
+static int SUF(choice2)(const REAL* c, int N, REAL un) {
+    const REAL r = c[N - 1] * ((REAL)1 - un);
+    const int ng = (N + 63) / 64;
+    int g = 0;
+    for (int k = 0; k < ng - 1; ++k) g += c[64 * k + 63] < r;
+    int lo = 64 * g, hi = lo + 64 < N ? lo + 64 : N;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] < r) lo = mid + 1; else hi = mid; }
+    return lo < N - 1 ? lo : N - 1;
+}
+/* the single draw of the backward pass: count of the cumulative weights below r */
+static int SUF(choice_count)(const REAL* c, int N, REAL un) {
+    const REAL r = c[N - 1] * ((REAL)1 - un);
+    int B = 0;
+    for (int j = 0; j < N; ++j) B += c[j] < r;
+    return B < N - 1 ? B : N - 1;
+}
+
 /* One sweep of one chain.  x (T,D) in/out; y (T,D) or NULL; shd (T) or NULL; eps_aux (T,D) or NULL;
  * eps_prop (T,N,D); u_res (T-1,N); u_bwd (T); outputs anc (T), xs (T,N,D), lws (T,N), As (T-1,N) [all required]. */
 int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y, const REAL* shd, const REAL* eps_aux,
@@ -340,15 +392,15 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
         if (m.proposal == 1) gq = gq + SUF(gauss)(D, xi, m.m0, m.LP0, m.c_init);
         lws[i] = gq;
     }
-    SUF(normalize)(lws, N, w, tmp);
+    SUF(expmax)(lws, N, w);
     for (int t = 1; t < T; ++t) {
         const REAL* xprev = xs + (size_t)(t - 1) * N * D;
         REAL* xcur = xs + (size_t)t * N * D;
         const REAL* yt = y ? y + (size_t)t * D : zero;
-        SUF(cumsum)(w, N, c);
+        SUF(cumsum_dpp)(w, N, c);
         for (int i = 0; i < N; ++i) {
             int idx = 0;
-            if (i > 0) idx = SUF(choice)(c, N, u_res[(size_t)(t - 1) * N + i]); /* resamplings.py:35-36 */
+            if (i > 0) idx = SUF(choice2)(c, N, u_res[(size_t)(t - 1) * N + i]); /* resamplings.py:35-36 */
             As[(size_t)(t - 1) * N + i] = idx;
             const REAL* xp = xprev + (size_t)idx * D;
             const REAL* e = eps_prop + ((size_t)t * N + i) * D;
@@ -374,11 +426,11 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             lw[i] = gq;
         }
         memcpy(lws + (size_t)t * N, lw, sizeof(REAL) * N);
-        SUF(normalize)(lw, N, w, tmp);
+        SUF(expmax)(lw, N, w);
     }
     /* backward (csmc.py:110-149) */
-    SUF(cumsum)(w, N, c);
-    int B = SUF(choice)(c, N, u_bwd[T - 1]);
+    SUF(cumsum_dpp)(w, N, c);
+    int B = SUF(choice_count)(c, N, u_bwd[T - 1]);
     anc[T - 1] = B;
     REAL xn[MAXD];
     for (int k = 0; k < D; ++k) xn[k] = x[(T - 1) * D + k] = xs[((size_t)(T - 1) * N + B) * D + k];
@@ -391,9 +443,9 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
                 SUF(tmean)(&m, xs + ((size_t)t * N + i) * D, mu);
                 lw[i] = SUF(gauss)(D, xn, mu, m.LQ, m.c_trans) + lws[(size_t)t * N + i];
             }
-            SUF(normalize)(lw, N, w, tmp);
-            SUF(cumsum)(w, N, c);
-            B = SUF(choice)(c, N, u_bwd[t]);
+            SUF(expmax)(lw, N, w);
+            SUF(cumsum_dpp)(w, N, c);
+            B = SUF(choice_count)(c, N, u_bwd[t]);
         }
         anc[t] = B;
         for (int k = 0; k < D; ++k) xn[k] = x[t * D + k] = xs[((size_t)t * N + B) * D + k];
