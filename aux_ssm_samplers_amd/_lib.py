@@ -39,7 +39,8 @@ class Lgssm(C.Structure):
 class FkModel(C.Structure):
     _fields_ = [("proposal", C.c_int32), ("potential", C.c_int32), ("dx", C.c_int32), ("transition", C.c_int32),
                 ("m0", C.c_void_p), ("chol_P0", C.c_void_p), ("F", C.c_void_p), ("b", C.c_void_p), ("chol_Q", C.c_void_p),
-                ("y", C.c_void_p), ("sig_y", C.c_double)]
+                ("y", C.c_void_p), ("sig_y", C.c_double), ("F_t", C.c_void_p), ("b_t", C.c_void_p), ("chol_Q_t", C.c_void_p),
+                ("gradient", C.c_int32), ("reserved", C.c_int32)]
 
 
 class CsmcNoise(C.Structure):
@@ -51,6 +52,7 @@ PROP_BOOTSTRAP_LG, PROP_AUX_INDEPENDENT = 0, 1
 POT_FLAT, POT_GAUSS_OBS, POT_SV, POT_GAUSS_OBS_MASKED = 0, 1, 2, 3
 TRANS_LINEAR, TRANS_LORENZ63_EM = 0, 1
 NOISE_EXPLICIT, NOISE_THREEFRY = 0, 1
+GRAD_NONE, GRAD_REFERENCE, GRAD_EXACT = 0, 1, 2
 
 
 class Dims(C.Structure):

@@ -13,17 +13,51 @@ _UNSUPPORTED = ("{what} is a Python object the HIP kernels cannot evaluate. The 
 
 
 class FkDesc:
-    def __init__(self, proposal, potential, m0, chol_P0, F, b, chol_Q, y, sig_y, transition=_lib.TRANS_LINEAR):
+    def __init__(self, proposal, potential, m0, chol_P0, F, b, chol_Q, y, sig_y, transition=_lib.TRANS_LINEAR, gradient=_lib.GRAD_NONE):
         self.proposal, self.potential, self.sig_y, self.transition = proposal, potential, float(sig_y), int(transition)
+        self.gradient = int(gradient)
         self.m0 = np.ascontiguousarray(m0, np.float64).reshape(-1)
         self.dx = self.m0.shape[0]
         d = self.dx
         self.chol_P0 = np.ascontiguousarray(chol_P0, np.float64).reshape(d, d)
+        F, b, chol_Q = np.asarray(F, np.float64), np.asarray(b, np.float64), np.asarray(chol_Q, np.float64)
+        self.tv = None  # time-varying transitions: (F_t (T-1,d,d), b_t (T-1,d), chol_Q_t (T-1,d,d)), uploaded per handle / dtype
+        if F.ndim == 3:
+            n = F.shape[0]
+            self.tv = (np.ascontiguousarray(F.reshape(n, d, d)), np.ascontiguousarray(np.broadcast_to(b, (n, d))),
+                       np.ascontiguousarray(np.broadcast_to(chol_Q, (n, d, d))))
+            F, b, chol_Q = self.tv[0][0], self.tv[1][0], self.tv[2][0]  # (the invariant slots are not read then)
         self.F = np.ascontiguousarray(F, np.float64).reshape(d, d)
         self.b = np.ascontiguousarray(b, np.float64).reshape(d)
         self.chol_Q = np.ascontiguousarray(chol_Q, np.float64).reshape(d, d)
         self.y = None if y is None else np.asarray(y)
         self._ydev = {}
+        self._tvdev = {}
+
+    def tvdev(self, handle, dtype, T):
+        """device copies of the time-varying transition arrays (or None)"""
+        if self.tv is None:
+            return None
+        if self.tv[0].shape[0] != T - 1:
+            raise ValueError(f"time-varying dynamics have {self.tv[0].shape[0]} rows, the state has T - 1 = {T - 1} transitions")
+        key = (id(handle), np.dtype(dtype).str)
+        if key not in self._tvdev:
+            self._tvdev[key] = tuple(handle.to_device(a, dtype) for a in self.tv)
+        return self._tvdev[key]
+
+    def struct(self, handle, dtype, T):
+        """the auxssm_fk_model of this description on `handle` (keeps the device arrays alive through self)"""
+        m = _lib.FkModel(self.proposal, self.potential, self.dx, self.transition, self.m0.ctypes.data, self.chol_P0.ctypes.data,
+                         self.F.ctypes.data, self.b.ctypes.data, self.chol_Q.ctypes.data, None, self.sig_y, None, None, None, self.gradient, 0)
+        yd = self.ydev(handle, dtype)
+        if yd is not None:
+            if yd.shape[0] != T:
+                raise ValueError(f"observations have {yd.shape[0]} time steps, state has {T}")
+            m.y = yd.ptr.value
+        tv = self.tvdev(handle, dtype, T)
+        if tv is not None:
+            m.F_t, m.b_t, m.chol_Q_t = tv[0].ptr.value, tv[1].ptr.value, tv[2].ptr.value
+        return m
 
     def ydev(self, handle, dtype):
         if self.y is None:
@@ -91,15 +125,15 @@ def describe_bootstrap(M0, G0, Mt, Gt, Pt):
     return FkDesc(_lib.PROP_BOOTSTRAP_LG, pot, M0.m0, M0.chol(), F, b, Mt.chol(), y, sig, tk)
 
 
-def describe_independent(M0, G0, Mt, Gt, Pt):
-    """csmc.get_independent_kernel (classical): proposals N(u_t, delta_t/2 I); M0/Mt enter the weights."""
+def describe_independent(M0, G0, Mt, Gt, Pt, gradient=_lib.GRAD_NONE):
+    """csmc.get_independent_kernel (classical): proposals N(u_t [+ delta_t/2 grad_t], delta_t/2 I); M0/Mt enter the weights."""
     M0, Mt = _dyn(M0, Mt)
     if Pt is not None and Pt is not Mt:
         raise NotImplementedError("Pt must be the model dynamics Mt")
     d = np.size(M0.m0)
     pot, y, sig = _potential(G0, Gt, d)
     tk, F, b = _trans(Mt)
-    return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), F, b, Mt.chol(), y, sig, tk)
+    return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), F, b, Mt.chol(), y, sig, tk, gradient)
 
 
 def key_noise(handle, key, Cn, T, N, d, dtype):
@@ -149,13 +183,7 @@ def sweep_resident(fk, chains, N, backward, key):
     handle, d = chains.handle, chains.dx
     if d != fk.dx:
         raise ValueError(f"state dimension {d} != model dimension {fk.dx}")
-    m = _lib.FkModel(fk.proposal, fk.potential, d, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
-                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
-    yd = fk.ydev(handle, chains.dtype)
-    if yd is not None:
-        if yd.shape[0] != chains.T:
-            raise ValueError(f"observations have {yd.shape[0]} time steps, state has {chains.T}")
-        m.y = yd.ptr.value
+    m = fk.struct(handle, chains.dtype, chains.T)
     shd = None
     if fk.proposal == _lib.PROP_AUX_INDEPENDENT:
         if chains.sqrt_half_delta is None:
@@ -170,14 +198,7 @@ def sweep_resident(fk, chains, N, backward, key):
 
 
 def _fk_struct(fk, handle, dtype, T):
-    m = _lib.FkModel(fk.proposal, fk.potential, fk.dx, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
-                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
-    yd = fk.ydev(handle, dtype)
-    if yd is not None:
-        if yd.shape[0] != T:
-            raise ValueError(f"observations have {yd.shape[0]} time steps, state has {T}")
-        m.y = yd.ptr.value
-    return m
+    return fk.struct(handle, dtype, T)
 
 
 def pit_sweep_resident(fk, chains, N, key):
@@ -241,13 +262,7 @@ def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, 
     dtype = np.dtype(np.float32) if xc.dtype == np.float32 else np.dtype(np.float64)
     xd = handle.to_device(xc, dtype)
     anc = handle.zeros((Cn, T), np.int32)
-    m = _lib.FkModel(fk.proposal, fk.potential, d, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
-                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, None, fk.sig_y)
-    yd = fk.ydev(handle, dtype)
-    if yd is not None:
-        if yd.shape[0] != T:
-            raise ValueError(f"observations have {yd.shape[0]} time steps, state has {T}")
-        m.y = yd.ptr.value
+    m = fk.struct(handle, dtype, T)
     shd = None
     if fk.proposal == _lib.PROP_AUX_INDEPENDENT:
         if delta is None:

@@ -13,8 +13,8 @@ from . import _device
 class IndependentFactory:
     """The classical factory of csmc/independent.py:57-75 in device-describable form."""
 
-    def __init__(self, M0, G0, Mt, Gt, Pt):
-        self.fk = _device.describe_independent(M0, G0, Mt, Gt, Pt)
+    def __init__(self, M0, G0, Mt, Gt, Pt, gradient=0):
+        self.fk = _device.describe_independent(M0, G0, Mt, Gt, Pt, gradient)
 
     def __call__(self, u, scale):
         raise NotImplementedError("the auxiliary model is evaluated inside the HIP kernel; this factory is a descriptor")

@@ -4,7 +4,14 @@ paradigm (reference: aux_samplers/csmc/independent.py).
 get_kernel(M0, G0, Mt, Gt, N, backward=False, Pt=None, gradient=False, parallel=False) -> (init, kernel).
 parallel=False: the classical sequential sweep (independent.py:57-75, auxssm_csmc_sweep); parallel=True: the parallel-in-time cSMC
 (conditional dSMC, independent.py:78-118 on _primitives/csmc/pit, auxssm_csmc_pit_sweep: log2(T) stitching launches instead of T
-sequential steps; `backward` / `Pt` are unused there, as in the reference).  The gradient branch needs autodiff of the user model: raises."""
+sequential steps; `backward` / `Pt` are unused there, as in the reference).
+
+gradient=True (classical sweep): proposals N(u_t + delta_t/2 grad_t, delta_t/2 I) with grad the gradient at u of the model's joint
+log-density (independent.py:121-134), which the reference gets from jax.grad and the device kernel evaluates in closed form for the
+model family (csrc/csmc.hip::k_csmc_grad).  gradient=True follows the reference to the letter: the importance correction of the shifted
+proposal enters the weights at t = 0 (GradientAuxiliaryG0, :173-190) while for t >= 1 GradientAuxiliaryGt sums it over ALL particles
+(jnp.sum without an axis, :265-266), i.e. adds a constant that cancels -- no correction.  gradient="exact" applies the per-particle
+correction at every step (the weights the construction intends; AUXSSM_GRAD_EXACT)."""
 import numpy as np
 
 from .._primitives.csmc.base import CSMCState
@@ -34,10 +41,14 @@ def _get_parallel_kernel(M0, G0, Mt, Gt, N):
 
 
 def get_kernel(M0, G0, Mt, Gt, N, backward=False, Pt=None, gradient=False, parallel=False):
-    if gradient:
-        raise NotImplementedError("gradient-informed proposals (independent.py:62-63) need autodiff of the model: out of scope")
+    from .. import _lib
+    if gradient not in (False, True, "exact", "reference"):
+        raise ValueError("gradient must be False, True (the reference's weights) or 'exact'")
+    gmode = _lib.GRAD_NONE if not gradient else (_lib.GRAD_EXACT if gradient == "exact" else _lib.GRAD_REFERENCE)
     if parallel:
+        if gmode:
+            raise NotImplementedError("gradient-informed proposals are built for the sequential sweep (parallel=False)")
         return _get_parallel_kernel(M0, G0, Mt, Gt, N)
     if backward and Pt is None:
         Pt = Mt
-    return get_base_kernel(IndependentFactory(M0, G0, Mt, Gt, Pt), N, backward, Pt)
+    return get_base_kernel(IndependentFactory(M0, G0, Mt, Gt, Pt, gmode), N, backward, Pt)

@@ -23,14 +23,22 @@ class GaussianInit(Distribution, UnivariatePotential):
 
 @dataclass
 class LinearGaussianDynamics(Dynamics, Potential):
-    """x_{t+1} | x_t ~ N(F x_t + b, Q), time-invariant (test_csmc/common.py:11-31; SV auxiliary_csmc.py:29-37)."""
+    """x_{t+1} | x_t ~ N(F x_t + b, Q) (test_csmc/common.py:11-31; SV auxiliary_csmc.py:29-37).  Time-invariant: F (d, d), b (d,), Q (d, d);
+    time-varying (the reference scans Mt.params over time, _primitives/csmc/csmc.py:103): F (T-1, d, d), b (T-1, d), Q (T-1, d, d), row t =
+    the transition t -> t + 1."""
     F: Any
     b: Any
     Q: Any
     params: Optional[Any] = None
 
+    @property
+    def time_varying(self):
+        return np.ndim(self.F) == 3
+
     def chol(self):
-        return np.linalg.cholesky(np.atleast_2d(np.asarray(self.Q, np.float64)))
+        """lower Cholesky factor(s) of Q: (d, d), or (T-1, d, d) when time-varying"""
+        Q = np.asarray(self.Q, np.float64)
+        return np.linalg.cholesky(Q if Q.ndim == 3 else np.atleast_2d(Q))
 
 
 @dataclass

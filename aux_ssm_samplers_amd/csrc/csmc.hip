@@ -28,6 +28,117 @@ template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
     ((R*)a.u)[g] = fma_(((const R*)a.shd)[t], e, ((const R*)a.x)[g]);
 }
 
+// additive constants of time-varying transition densities: ct[t] = -sum_k log LQ_t[k][k] - D/2 log 2 pi
+template <typename R, int D> __global__ void k_csmc_ctrans(int n, const R* __restrict__ LQt, R* __restrict__ ct) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    R c = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) c -= det_log(LQt[((long long)t * D + k) * D + k]);
+    ct[t] = c - (R)D * (R)0.91893853320467274178;
+}
+// w <- (L L^T)^-1 r, L lower with leading dimension ld; fixed operation order (restated by oracle/csmc_ref.c::cho_solve_)
+template <typename R, int D> __device__ __forceinline__ void cho_solve_fixed(const R* L, int ld, const R* r, R* w) {
+    R z[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        R acc = r[k];
+#pragma unroll
+        for (int j = 0; j < k; ++j) acc = fma_(-L[k * ld + j], z[j], acc);
+        z[k] = acc / L[k * ld + k];
+    }
+#pragma unroll
+    for (int k = D - 1; k >= 0; --k) {
+        R acc = z[k];
+#pragma unroll
+        for (int j = k + 1; j < D; ++j) acc = fma_(-L[j * ld + k], w[j], acc);
+        w[k] = acc / L[k * ld + k];
+    }
+}
+// gradient at u of  log M0(u_0) + G0(u_0) + sum_t [log Mt(u_{t+1} | u_t) + Gt(u_{t+1})]  (csmc/independent.py:121-134, jax.grad there),
+// closed form for the model family: one thread per (chain, time step)
+template <typename R, int D> __global__ void k_csmc_grad(CsmcArgs a, FkDev<R> m) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)a.C * a.T) return;
+    const long long t = g % a.T;
+    const R* u = (const R*)a.u + g * D;
+    R ut[D], gr[D], r[D], w[D], mu[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) ut[k] = u[k];
+    const R* yv = (const R*)a.y;
+    // potential
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R y = yv ? yv[t * D + k] : (R)0;
+        R v = 0;
+        if (m.potential == 1 || (m.potential == 3 && y - y == 0)) v = ((y - ut[k]) * m.inv_sig_y) * m.inv_sig_y;
+        else if (m.potential == 2) {
+            const R e = det_exp(-ut[k]);
+            v = (R)0.5 * fma_(y * y, e, (R)-1);
+            v = (v == v) ? v : (R)0;
+        }
+        gr[k] = v;
+    }
+    // density of u_t given the past
+    if (t == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[k] = ut[k] - m.m0[k];
+        cho_solve_fixed<R, D>(m.LP0, CS_MAXD, r, w);
+    } else {
+        const TransT<R> tr = trans_at<R, D>(m, t - 1);
+        trans_mean_t<R, D>(m, tr, u - D, mu);
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[k] = ut[k] - mu[k];
+        cho_solve_fixed<R, D>(tr.LQ, tr.ld, r, w);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) gr[k] = gr[k] - w[k];
+    // density of u_{t+1} given u_t:  J(u_t)^T Q^-1 (u_{t+1} - mean(u_t))
+    if (t + 1 < a.T) {
+        const TransT<R> tr = trans_at<R, D>(m, t);
+        trans_mean_t<R, D>(m, tr, ut, mu);
+#pragma unroll
+        for (int k = 0; k < D; ++k) r[k] = u[D + k] - mu[k];
+        cho_solve_fixed<R, D>(tr.LQ, tr.ld, r, w);
+        if constexpr (D == 3) {
+            if (m.transition == 1) {  // Lorenz-63: J = I + dt dphi/dx (examples/lorenz/model.py:10-25)
+                const R th1 = m.F[0], th2 = m.F[1], th3 = m.F[2], dt = m.b[0];
+                const R J[9] = {-th1, th1, (R)0, th2 - ut[2], (R)-1, -ut[0], ut[1], ut[0], -th3};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    R acc = 0;
+#pragma unroll
+                    for (int j = 0; j < 3; ++j) acc = fma_(J[j * 3 + k], w[j], acc);
+                    gr[k] = gr[k] + fma_(dt, acc, w[k]);
+                }
+                goto done;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            R acc = 0;
+#pragma unroll
+            for (int j = 0; j < D; ++j) acc = fma_(tr.F[j * tr.ld + k], w[j], acc);
+            gr[k] = gr[k] + acc;
+        }
+    }
+done:
+#pragma unroll
+    for (int k = 0; k < D; ++k) ((R*)a.grad)[g * D + k] = gr[k];
+}
+
+// sum_k [log N(x_k; u_k, s) - log N(x_k; pm_k, s)] = sum_k ((x_k - pm_k)^2 - (x_k - u_k)^2) / (2 s^2)   (independent.py:184-189)
+template <typename R, int D> __device__ __forceinline__ R grad_correction(const R* x, const R* u, const R* pm, R s) {
+    R acc = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R d1 = x[k] - u[k], d2 = x[k] - pm[k];
+        acc = fma_(d2, d2, acc);
+        acc = fma_(-d1, d1, acc);
+    }
+    return acc * ((R)0.5 / (s * s));
+}
+
 // ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
 template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -41,6 +152,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
     const bool live = tid < N;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
+    const R* gaux = m.gradient ? (const R*)a.grad + (long long)ch * T * D : uaux;
     const R* yv = (const R*)a.y;
     R* xs = (R*)a.xs + (long long)ch * T * N * D;
     R* lws = (R*)a.lws + (long long)ch * T * N;
@@ -57,7 +169,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
     // (flat auxssm_rng_* indices; csmc/_device.py::key_noise builds the equivalent explicit arrays).
     const bool gen = a.noise_mode != 0;
     const long long T2 = (T + 1) >> 1;
-    R x[D], eps[D], eps_nx[D], ycur[D], un_nx = 0;
+    R x[D], eps[D], eps_nx[D], ycur[D], pm[D], un_nx = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         eps_nx[k] = 0;
@@ -79,10 +191,13 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
             for (int j = 0; j <= k; ++j) acc = fma_(m.LP0[k * CS_MAXD + j], eps[j], acc);
             x[k] = acc;
         }
-    } else {  // AuxiliaryM0: N(u_0, delta_0/2 I)  (independent.py:143-158)
+    } else {  // AuxiliaryM0: N(u_0 [+ delta_0/2 grad_0], delta_0/2 I)  (independent.py:143-158)
         const R s0 = ((const R*)a.shd)[0];
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = fma_(s0, eps[k], uaux[k]);
+        for (int k = 0; k < D; ++k) {
+            pm[k] = m.gradient ? fma_(s0 * s0, gaux[k], uaux[k]) : uaux[k];
+            x[k] = fma_(s0, eps[k], pm[k]);
+        }
     }
     if (tid == 0) {
 #pragma unroll
@@ -91,7 +206,10 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
     R lw;
     {
         R g = potential<R, D>(m, x, ycur);
-        if (m.proposal == 1) g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+        if (m.proposal == 1) {
+            g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+            if (m.gradient) g = g + grad_correction<R, D>(x, uaux, pm, ((const R*)a.shd)[0]);  // GradientAuxiliaryG0 (:173-190)
+        }
         lw = live ? g : ninf;
     }
     if (live) {
@@ -137,21 +255,25 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         R xp[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
-        // propagate (csmc.py:91-92)
+        // propagate (csmc.py:91-92); the transition t - 1 -> t (time-varying: row t - 1 of the device arrays)
+        const TransT<R> tr = trans_at<R, D>(m, t - 1);
         if (m.proposal == 0) {
             R mu[D];
-            trans_mean<R, D>(m, xp, mu);
+            trans_mean_t<R, D>(m, tr, xp, mu);
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 R acc = mu[k];
 #pragma unroll
-                for (int j = 0; j <= k; ++j) acc = fma_(m.LQ[k * CS_MAXD + j], eps[j], acc);
+                for (int j = 0; j <= k; ++j) acc = fma_(tr.LQ[k * tr.ld + j], eps[j], acc);
                 x[k] = acc;
             }
-        } else {  // AuxiliaryMtDynamics: N(u_t, delta_t/2 I), independent of the parent (independent.py:192-198)
+        } else {  // AuxiliaryMtDynamics: N(u_t [+ delta_t/2 grad_t], delta_t/2 I), independent of the parent (independent.py:192-198)
             const R st = ((const R*)a.shd)[t];
 #pragma unroll
-            for (int k = 0; k < D; ++k) x[k] = fma_(st, eps[k], uaux[(long long)t * D + k]);
+            for (int k = 0; k < D; ++k) {
+                pm[k] = m.gradient ? fma_(st * st, gaux[(long long)t * D + k], uaux[(long long)t * D + k]) : uaux[(long long)t * D + k];
+                x[k] = fma_(st, eps[k], pm[k]);
+            }
         }
         if (tid == 0) {
 #pragma unroll
@@ -162,8 +284,11 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
             R g = potential<R, D>(m, x, ycur);
             if (m.proposal == 1) {  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
                 R mu[D];
-                trans_mean<R, D>(m, xp, mu);
-                g = gauss_chol_logpdf<R, D>(x, mu, m.LQ, m.c_trans) + g;
+                trans_mean_t<R, D>(m, tr, xp, mu);
+                g = gauss_chol_logpdf<R, D>(x, mu, tr.LQ, tr.c_trans, tr.ld) + g;
+                // GradientAuxiliaryGt (:252-268): in the reference the correction is summed over all particles, i.e. a constant of the
+                // step (AUXSSM_GRAD_REFERENCE: nothing to add); AUXSSM_GRAD_EXACT applies it per particle
+                if (m.gradient == 2) g = g + grad_correction<R, D>(x, uaux + (long long)t * D, pm, ((const R*)a.shd)[t]);
             }
             lw = live ? g : ninf;
         }
@@ -268,8 +393,9 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(
         R lw = ninf;
         if (live) {
             R mu[D];
-            trans_mean<R, D>(m, xi, mu);
-            lw = gauss_chol_logpdf<R, D>(xn, mu, m.LQ, m.c_trans) + lwi;
+            const TransT<R> tr = trans_at<R, D>(m, t);  // Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136)
+            trans_mean_t<R, D>(m, tr, xi, mu);
+            lw = gauss_chol_logpdf<R, D>(xn, mu, tr.LQ, tr.c_trans, tr.ld) + lwi;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
@@ -366,13 +492,25 @@ __global__ void __launch_bounds__(1024) k_systematic(int M, int N, const R* __re
 }
 
 template <typename R, int D>
-static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host_model, CsmcArgs& a) {
+static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host_model, CsmcArgs& a, void* ctt) {
     FkDev<R> m;
     fill_model<R>(m, fk, host_model);
+    m.gradient = fk->gradient;
     const int TB = (a.N + 63) / 64 * 64;
+    if (fk->F_t && a.T > 1) {
+        m.Ft = (const R*)fk->F_t;
+        m.bt = (const R*)fk->b_t;
+        m.LQt = (const R*)fk->chol_Q_t;
+        m.ctt = (const R*)ctt;
+        hipLaunchKernelGGL((k_csmc_ctrans<R, D>), dim3((a.T - 1 + 255) / 256), dim3(256), 0, h->stream, a.T - 1, m.LQt, (R*)ctt);
+    }
     if (fk->proposal == 1) {
         const long long total = (long long)a.C * a.T * D;
         hipLaunchKernelGGL((k_csmc_aux<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a, D);
+        if (fk->gradient) {
+            const long long tot = (long long)a.C * a.T;
+            hipLaunchKernelGGL((k_csmc_grad<R, D>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, a, m);
+        }
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
@@ -507,6 +645,25 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         set_error("the auxiliary proposal needs sqrt_half_delta (T)");
         return AUXSSM_ERR_ARG;
     }
+    {
+        const int ntv = (fk->F_t != nullptr) + (fk->b_t != nullptr) + (fk->chol_Q_t != nullptr);
+        if (ntv != 0 && ntv != 3) {
+            set_error("time-varying transitions need F_t, b_t and chol_Q_t together");
+            return AUXSSM_ERR_ARG;
+        }
+        if (ntv && fk->transition != AUXSSM_TRANS_LINEAR) {
+            set_error("time-varying parameters are for the linear transition only");
+            return AUXSSM_ERR_ARG;
+        }
+    }
+    if (fk->gradient != AUXSSM_GRAD_NONE && fk->gradient != AUXSSM_GRAD_REFERENCE && fk->gradient != AUXSSM_GRAD_EXACT) {
+        set_error("unknown gradient mode %d", fk->gradient);
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->gradient != AUXSSM_GRAD_NONE && fk->proposal != AUXSSM_PROP_AUX_INDEPENDENT) {
+        set_error("gradient-informed proposals belong to AUXSSM_PROP_AUX_INDEPENDENT");
+        return AUXSSM_ERR_ARG;
+    }
     if (noise->mode == AUXSSM_NOISE_EXPLICIT) {
         if (!noise->eps_prop || !noise->u_bwd || (T > 1 && !noise->u_res) ||
             (fk->proposal == AUXSSM_PROP_AUX_INDEPENDENT && !noise->eps_aux)) {
@@ -534,7 +691,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     if (!log_ws_out) need += CT * N * sR + 256;
     if (!backward && !As_out) need += (size_t)C * (T > 1 ? T - 1 : 1) * N * 4 + 256;
     need += (size_t)C * N * sR + 256;
-    need += CT * D * sR + 256;
+    need += 2 * (CT * D * sR + 256) + (size_t)T * sR + 256;
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     CsmcArgs a;
@@ -543,6 +700,8 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.shd = sqrt_half_delta;
     a.x = x;
     a.u = ws_take(h, CT * D * sR);
+    a.grad = fk->gradient ? ws_take(h, CT * D * sR) : nullptr;
+    void* ctt = fk->F_t ? ws_take(h, (size_t)T * sR) : nullptr;
     a.xs = xs_out ? xs_out : ws_take(h, CT * N * D * sR);
     a.lws = log_ws_out ? log_ws_out : ws_take(h, CT * N * sR);
     a.As = As_out ? As_out : (!backward ? (int32_t*)ws_take(h, (size_t)C * (T > 1 ? T - 1 : 1) * N * 4) : nullptr);
@@ -551,13 +710,13 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.noise_mode = noise->mode;
     a.key0 = noise->key0; a.key1 = noise->key1;
     a.eps_aux = noise->eps_aux; a.eps_prop = noise->eps_prop; a.u_res = noise->u_res; a.u_bwd = noise->u_bwd;
-    if (!a.u || !a.xs || !a.lws || !a.wT || (!backward && !a.As)) return AUXSSM_ERR_NOMEM;
+    if (!a.u || !a.xs || !a.lws || !a.wT || (!backward && !a.As) || (fk->gradient && !a.grad) || (fk->F_t && !ctt)) return AUXSSM_ERR_NOMEM;
 #define AX_CSMC_D(R)                                                        \
     switch (D) {                                                            \
-        case 1: return run_csmc<R, 1>(h, fk, hm.data(), a);                 \
-        case 2: return run_csmc<R, 2>(h, fk, hm.data(), a);                 \
-        case 3: return run_csmc<R, 3>(h, fk, hm.data(), a);                 \
-        default: return run_csmc<R, 4>(h, fk, hm.data(), a);                \
+        case 1: return run_csmc<R, 1>(h, fk, hm.data(), a, ctt);                 \
+        case 2: return run_csmc<R, 2>(h, fk, hm.data(), a, ctt);                 \
+        case 3: return run_csmc<R, 3>(h, fk, hm.data(), a, ctt);                 \
+        default: return run_csmc<R, 4>(h, fk, hm.data(), a, ctt);                \
     }
     if (dtype == AUXSSM_F32) { AX_CSMC_D(float) } else { AX_CSMC_D(double) }
 #undef AX_CSMC_D

@@ -15,7 +15,25 @@ template <typename R> struct FkDev {
     int proposal, potential, D, transition;  // transition: 0 = linear-Gaussian (F, b); 1 = Lorenz-63 Euler-Maruyama (theta = F[0][0..2], dt = b[0])
     R m0[CS_MAXD], LP0[CS_MAXD * CS_MAXD], F[CS_MAXD * CS_MAXD], b[CS_MAXD], LQ[CS_MAXD * CS_MAXD];
     R c_init, c_trans, c_obs, inv_sig_y;  // additive constants: -sum log L_kk - D/2 log 2pi, etc.
+    // time-varying linear transitions (device arrays, row t = transition t -> t+1; null: the invariant F / b / LQ above)
+    const R* Ft;   // (T-1, D, D)
+    const R* bt;   // (T-1, D)
+    const R* LQt;  // (T-1, D, D) lower
+    const R* ctt;  // (T-1) additive constants of the transition densities (k_csmc_ctrans)
+    int gradient;  // AUXSSM_GRAD_*
 };
+// the transition t -> t+1 of the model: matrices through pointers (wave-uniform loads when time-varying)
+template <typename R> struct TransT {
+    const R* F;
+    const R* b;
+    const R* LQ;
+    int ld;  // leading dimension of F / LQ: CS_MAXD for the struct arrays, D for the device rows
+    R c_trans;
+};
+template <typename R, int D> __device__ __forceinline__ TransT<R> trans_at(const FkDev<R>& m, long long t) {
+    if (m.Ft) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t]};
+    return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans};
+}
 
 struct CsmcArgs {
     int C, T, N, backward;
@@ -23,6 +41,7 @@ struct CsmcArgs {
     const void* shd;     // (T) sqrt(delta_t / 2), AUX proposal only
     void* x;             // (C, T, D) reference trajectory in, new trajectory out
     void* u;             // (C, T, D) auxiliary variables (workspace), AUX only
+    void* grad;          // (C, T, D) gradient of the model's joint log-density at u (workspace), gradient proposals only
     void* xs;            // (C, T, N, D)
     void* lws;           // (C, T, N)
     int32_t* As;         // (C, T-1, N) or null
@@ -51,18 +70,33 @@ AXD_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 AXD_HD double fma_(double a, double b, double c) { return fma(a, b, c); }
 
 // log N(x; mean, L L^T) = cst - 0.5 |L^-1 (x - mean)|^2, forward substitution in a fixed order
-template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mean, const R* L, R cst) {
+template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mean, const R* L, R cst, int ld = CS_MAXD) {
     R z[D];
     R q = 0;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         R acc = x[k] - mean[k];
 #pragma unroll
-        for (int j = 0; j < k; ++j) acc = fma_(-L[k * CS_MAXD + j], z[j], acc);
-        z[k] = acc / L[k * CS_MAXD + k];
+        for (int j = 0; j < k; ++j) acc = fma_(-L[k * ld + j], z[j], acc);
+        z[k] = acc / L[k * ld + k];
         q = fma_(z[k], z[k], q);
     }
     return fma_((R)-0.5, q, cst);
+}
+template <typename R, int D> AXD_HD void trans_mean(const FkDev<R>& m, const R* xp, R* mu);
+// mean of the transition tr applied to xp (linear, or the Lorenz-63 Euler-Maruyama step of the invariant model)
+template <typename R, int D> __device__ __forceinline__ void trans_mean_t(const FkDev<R>& m, const TransT<R>& tr, const R* xp, R* mu) {
+    if (m.transition == 1) {
+        trans_mean<R, D>(m, xp, mu);
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        R acc = tr.b[k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) acc = fma_(tr.F[k * tr.ld + j], xp[j], acc);
+        mu[k] = acc;
+    }
 }
 template <typename R, int D> AXD_HD void trans_mean(const FkDev<R>& m, const R* xp, R* mu) {
     if constexpr (D == 3) {
@@ -309,7 +343,7 @@ template <typename R> __device__ __forceinline__ int search2(const R* c, const R
 template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model* fk, const double* host) {
     // host = [m0 (D) | chol_P0 (D*D) | F (D*D) | b (D) | chol_Q (D*D)] as doubles
     const int D = fk->dx;
-    memset(&m, 0, sizeof(m));
+    memset(&m, 0, sizeof(m));  // (also: no time-varying arrays, no gradient; the sweep entry point sets them)
     m.proposal = fk->proposal;
     m.potential = fk->potential;
     m.D = D;

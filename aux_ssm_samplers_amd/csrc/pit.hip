@@ -358,6 +358,10 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
         set_error("the parallel-in-time sweep needs proposals that are independent across time: AUXSSM_PROP_AUX_INDEPENDENT");
         return AUXSSM_ERR_ARG;
     }
+    if (fk->F_t || fk->b_t || fk->chol_Q_t || fk->gradient) {
+        set_error("time-varying transitions and gradient-informed proposals are built for the sequential sweep (auxssm_csmc_sweep) only");
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
     if (fk->potential < AUXSSM_POT_FLAT || fk->potential > AUXSSM_POT_GAUSS_OBS_MASKED) {
         set_error("unknown potential kind %d", fk->potential);
         return AUXSSM_ERR_ARG;

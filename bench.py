@@ -327,8 +327,7 @@ def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
     anc = handle.zeros((Cn, T), np.int32)
     yd = fk.ydev(handle, dtype)
     shd = handle.to_device(np.full(T, np.sqrt(0.25)), dtype)
-    m = _lib.FkModel(fk.proposal, fk.potential, 1, fk.transition, fk.m0.ctypes.data, fk.chol_P0.ctypes.data, fk.F.ctypes.data,
-                     fk.b.ctypes.data, fk.chol_Q.ctypes.data, yd.ptr.value, 1.0)
+    m = fk.struct(handle, dtype, T)
     keys = R.split(R.PRNGKey(77 + ctx.rank), steps + warmup + 1)
 
     def step(k):

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 101
+#define AUXSSM_VERSION 102
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -234,7 +234,23 @@ typedef struct {
     const double* chol_Q;  /* host (dx,dx) lower */
     const void* y;         /* device (T,dx), may be NULL for FLAT */
     double sig_y;
+    /* Time-varying LINEAR transitions (the reference scans Mt.params over time, _primitives/csmc/csmc.py:103, csmc/base.py:56-71):
+     * DEVICE arrays of `dtype`, row t = the transition x_t -> x_{t+1}: F_t (T-1,dx,dx), b_t (T-1,dx), chol_Q_t (T-1,dx,dx) lower.
+     * All three NULL: the time-invariant host F / b / chol_Q above; otherwise all three non-NULL (auxssm_csmc_sweep only). */
+    const void* F_t;
+    const void* b_t;
+    const void* chol_Q_t;
+    /* Gradient-informed independent proposals (csmc/independent.py:57-75 with gradient=True, :121-134, :173-190, :252-268), AUX_INDEPENDENT
+     * only: x_t^i ~ N(u_t + delta_t/2 grad_t, delta_t/2 I) with grad = the gradient at u of the model's joint log-density
+     * log M0(u_0) + G0(u_0) + sum_t [log Mt(u_{t+1} | u_t) + Gt(u_{t+1})], evaluated in closed form for the model family.  The weights get the
+     * importance correction  sum_k [log N(x_k; u_k, s) - log N(x_k; u_k + delta/2 grad_k, s)]:
+     *   AUXSSM_GRAD_REFERENCE  at t = 0 only -- the reference's GradientAuxiliaryGt sums its correction over ALL particles (jnp.sum without
+     *                          an axis, :265-266), a constant that cancels in every normalisation, so for t >= 1 it is no correction at all;
+     *   AUXSSM_GRAD_EXACT      at every step (the weights the construction intends). */
+    int32_t gradient;
+    int32_t reserved;
 } auxssm_fk_model;
+typedef enum { AUXSSM_GRAD_NONE = 0, AUXSSM_GRAD_REFERENCE = 1, AUXSSM_GRAD_EXACT = 2 } auxssm_fk_gradient;
 typedef struct {
     int32_t mode;
     uint32_t key0, key1;

@@ -18,7 +18,22 @@ TRANS_LINEAR, TRANS_LORENZ63_EM = 0, 1
 class _Model(C.Structure):
     _fields_ = [("proposal", C.c_int), ("potential", C.c_int), ("D", C.c_int), ("backward", C.c_int),
                 ("m0", C.c_void_p), ("LP0", C.c_void_p), ("F", C.c_void_p), ("b", C.c_void_p), ("LQ", C.c_void_p),
-                ("sig_y", C.c_double), ("transition", C.c_int)]
+                ("sig_y", C.c_double), ("transition", C.c_int), ("F_t", C.c_void_p), ("b_t", C.c_void_p), ("LQ_t", C.c_void_p),
+                ("gradient", C.c_int)]
+
+GRAD_NONE, GRAD_REFERENCE, GRAD_EXACT = 0, 1, 2
+
+
+def _model(model, D, backward):
+    """(ctypes struct, arrays to keep alive).  Optional keys: F_t, b_t, chol_Q_t (time-varying transitions, T-1 rows), gradient."""
+    keep = [np.ascontiguousarray(np.asarray(model[k], np.float64)) for k in ("m0", "chol_P0", "F", "b", "chol_Q")]
+    tv = [None, None, None]
+    if model.get("F_t") is not None:
+        tv = [np.ascontiguousarray(np.asarray(model[k], np.float64)) for k in ("F_t", "b_t", "chol_Q_t")]
+    m = _Model(int(model["proposal"]), int(model["potential"]), D, int(bool(backward)), _p(keep[0]), _p(keep[1]), _p(keep[2]),
+               _p(keep[3]), _p(keep[4]), float(model.get("sig_y", 1.0)), int(model.get("transition", 0)), _p(tv[0]), _p(tv[1]), _p(tv[2]),
+               int(model.get("gradient", 0)))
+    return m, keep + tv
 
 
 _lib = None
@@ -52,9 +67,7 @@ def sweep(model, x, N, backward, *, y=None, sqrt_half_delta=None, eps_aux=None, 
     dtype = np.dtype(dtype)
     x = np.array(x, dtype, order="C")
     T, D = x.shape
-    keep = [np.ascontiguousarray(np.asarray(model[k], np.float64)) for k in ("m0", "chol_P0", "F", "b", "chol_Q")]
-    m = _Model(int(model["proposal"]), int(model["potential"]), D, int(bool(backward)), _p(keep[0]), _p(keep[1]), _p(keep[2]),
-               _p(keep[3]), _p(keep[4]), float(model.get("sig_y", 1.0)), int(model.get("transition", 0)))
+    m, keep = _model(model, D, backward)
     cv = lambda a: None if a is None else np.ascontiguousarray(a, dtype)
     y, shd, eps_aux, eps_prop, u_res, u_bwd = map(cv, (y, sqrt_half_delta, eps_aux, eps_prop, u_res, u_bwd))
     assert eps_prop.shape == (T, N, D) and u_bwd.shape == (T,) and (T == 1 or u_res.shape == (T - 1, N))
@@ -75,9 +88,7 @@ def pit_sweep(model, x, N, *, y=None, sqrt_half_delta, eps_aux, eps_prop, u_res,
     dtype = np.dtype(dtype)
     x = np.array(x, dtype, order="C")
     T, D = x.shape
-    keep = [np.ascontiguousarray(np.asarray(model[k], np.float64)) for k in ("m0", "chol_P0", "F", "b", "chol_Q")]
-    m = _Model(int(model["proposal"]), int(model["potential"]), D, 0, _p(keep[0]), _p(keep[1]), _p(keep[2]),
-               _p(keep[3]), _p(keep[4]), float(model.get("sig_y", 1.0)), int(model.get("transition", 0)))
+    m, keep = _model(model, D, 0)
     cv = lambda a: None if a is None else np.ascontiguousarray(a, dtype)
     y, shd, eps_aux, eps_prop, u_res = map(cv, (y, sqrt_half_delta, eps_aux, eps_prop, u_res))
     assert T >= 2 and eps_prop.shape == (T, N, D) and u_res.shape == (T, N) and eps_aux.shape == (T, D) and shd.shape == (T,)
@@ -87,6 +98,19 @@ def pit_sweep(model, x, N, *, y=None, sqrt_half_delta, eps_aux, eps_prop, u_res,
     rc = fn(C.byref(m), T, N, _p(x), _p(y), _p(shd), _p(eps_aux), _p(eps_prop), _p(u_res), _p(anc), _p(xs))
     assert rc == 0
     return dict(x=x, ancestors=anc, xs=xs)
+
+
+def grad_logpi(model, u, y=None, dtype=np.float64):
+    """gradient at u (T, D) of the model's joint log-density (csmc_ref.c::grad_logpi; independent.py:121-134)"""
+    dtype = np.dtype(dtype)
+    u = np.ascontiguousarray(u, dtype)
+    T, D = u.shape
+    m, keep = _model(model, D, 0)
+    y = None if y is None else np.ascontiguousarray(y, dtype)
+    g = np.zeros((T, D), dtype)
+    fn = lib().csmc_ref_grad_f32 if dtype == np.float32 else lib().csmc_ref_grad_f64
+    fn(C.byref(m), T, _p(u), _p(y), _p(g))
+    return g
 
 
 def multinomial(w, un, dtype=np.float32):

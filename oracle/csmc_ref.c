@@ -152,6 +152,9 @@ typedef struct {
     const double *m0, *LP0, *F, *b, *LQ; /* (D), (D,D) lower, (D,D), (D), (D,D) lower */
     double sig_y;
     int transition; /* 0 linear (F, b); 1 Lorenz-63 Euler-Maruyama: theta = F[0..2], dt = b[0] (examples/lorenz/model.py:10-25) */
+    /* time-varying linear transitions (csmc.py:103 scans Mt.params): row t = transition t -> t+1; NULL = invariant F / b / LQ */
+    const double *F_t, *b_t, *LQ_t; /* (T-1,D,D), (T-1,D), (T-1,D,D) lower */
+    int gradient; /* 0 none; 1 reference (correction at t = 0 only: independent.py:265-266 sums it over all particles for t >= 1); 2 exact */
 } fk_model;
 
 #define CSMC_REF_BODY
@@ -357,6 +360,110 @@ static int SUF(choice_count)(const REAL* c, int N, REAL un) {
     return B < N - 1 ? B : N - 1;
 }
 
+/* ---- time-varying transitions and gradient-informed proposals (csmc/independent.py:57-75 gradient=True, :121-134, :173-190, :252-268) ---- */
+typedef struct { REAL F[MAXD * MAXD], b[MAXD], LQ[MAXD * MAXD], c_trans; } SUF(trans);
+static void SUF(trans_at)(const SUF(fk) * m, const fk_model* g, long t, SUF(trans) * tr) {
+    const int D = m->D;
+    if (!g->F_t) {
+        memcpy(tr->F, m->F, sizeof tr->F); memcpy(tr->b, m->b, sizeof tr->b); memcpy(tr->LQ, m->LQ, sizeof tr->LQ);
+        tr->c_trans = m->c_trans;
+        return;
+    }
+    memset(tr, 0, sizeof *tr);
+    REAL c = 0;
+    for (int i = 0; i < D; ++i) {
+        tr->b[i] = (REAL)g->b_t[t * D + i];
+        for (int j = 0; j < D; ++j) {
+            tr->F[i * MAXD + j] = (REAL)g->F_t[(t * D + i) * D + j];
+            tr->LQ[i * MAXD + j] = (REAL)g->LQ_t[(t * D + i) * D + j];
+        }
+    }
+    for (int k = 0; k < D; ++k) c -= LOG(tr->LQ[k * MAXD + k]);
+    tr->c_trans = c - (REAL)D * (REAL)0.91893853320467274178;
+}
+static void SUF(tmean_t)(const SUF(fk) * m, const SUF(trans) * tr, const REAL* xp, REAL* mu) {
+    if (m->transition == 1) { SUF(tmean)(m, xp, mu); return; }
+    for (int k = 0; k < m->D; ++k) {
+        REAL acc = tr->b[k];
+        for (int j = 0; j < m->D; ++j) acc = FMA(tr->F[k * MAXD + j], xp[j], acc);
+        mu[k] = acc;
+    }
+}
+static void SUF(cho_solve_)(int D, const REAL* L, const REAL* r, REAL* w) {
+    REAL z[MAXD];
+    for (int k = 0; k < D; ++k) {
+        REAL acc = r[k];
+        for (int j = 0; j < k; ++j) acc = FMA(-L[k * MAXD + j], z[j], acc);
+        z[k] = acc / L[k * MAXD + k];
+    }
+    for (int k = D - 1; k >= 0; --k) {
+        REAL acc = z[k];
+        for (int j = k + 1; j < D; ++j) acc = FMA(-L[j * MAXD + k], w[j], acc);
+        w[k] = acc / L[k * MAXD + k];
+    }
+}
+/* gradient at u (T, D) of log M0(u_0) + G0(u_0) + sum_t [log Mt(u_{t+1} | u_t) + Gt(u_{t+1})] (independent.py:121-134) */
+static void SUF(grad_logpi)(const SUF(fk) * m, const fk_model* g, int T, const REAL* u, const REAL* y, REAL* grad) {
+    const int D = m->D;
+    for (long t = 0; t < T; ++t) {
+        const REAL* ut = u + t * D;
+        REAL gr[MAXD], r[MAXD], w[MAXD], mu[MAXD];
+        for (int k = 0; k < D; ++k) {
+            const REAL yy = y ? y[t * D + k] : (REAL)0;
+            REAL v = 0;
+            if (m->potential == 1 || (m->potential == 3 && yy - yy == 0)) v = ((yy - ut[k]) * m->inv_sig_y) * m->inv_sig_y;
+            else if (m->potential == 2) {
+                const REAL e = EXP(-ut[k]);
+                v = (REAL)0.5 * FMA(yy * yy, e, (REAL)-1);
+                v = (v == v) ? v : (REAL)0;
+            }
+            gr[k] = v;
+        }
+        SUF(trans) tr;
+        if (t == 0) {
+            for (int k = 0; k < D; ++k) r[k] = ut[k] - m->m0[k];
+            SUF(cho_solve_)(D, m->LP0, r, w);
+        } else {
+            SUF(trans_at)(m, g, t - 1, &tr);
+            SUF(tmean_t)(m, &tr, ut - D, mu);
+            for (int k = 0; k < D; ++k) r[k] = ut[k] - mu[k];
+            SUF(cho_solve_)(D, tr.LQ, r, w);
+        }
+        for (int k = 0; k < D; ++k) gr[k] = gr[k] - w[k];
+        if (t + 1 < T) {
+            SUF(trans_at)(m, g, t, &tr);
+            SUF(tmean_t)(m, &tr, ut, mu);
+            for (int k = 0; k < D; ++k) r[k] = ut[D + k] - mu[k];
+            SUF(cho_solve_)(D, tr.LQ, r, w);
+            if (m->transition == 1) {
+                const REAL th1 = m->F[0], th2 = m->F[1], th3 = m->F[2], dt = m->b[0];
+                const REAL J[9] = {-th1, th1, (REAL)0, th2 - ut[2], (REAL)-1, -ut[0], ut[1], ut[0], -th3};
+                for (int k = 0; k < 3; ++k) {
+                    REAL acc = 0;
+                    for (int j = 0; j < 3; ++j) acc = FMA(J[j * 3 + k], w[j], acc);
+                    gr[k] = gr[k] + FMA(dt, acc, w[k]);
+                }
+            } else {
+                for (int k = 0; k < D; ++k) {
+                    REAL acc = 0;
+                    for (int j = 0; j < D; ++j) acc = FMA(tr.F[j * MAXD + k], w[j], acc);
+                    gr[k] = gr[k] + acc;
+                }
+            }
+        }
+        for (int k = 0; k < D; ++k) grad[t * D + k] = gr[k];
+    }
+}
+static REAL SUF(grad_corr)(int D, const REAL* x, const REAL* u, const REAL* pm, REAL s) {
+    REAL acc = 0;
+    for (int k = 0; k < D; ++k) {
+        const REAL d1 = x[k] - u[k], d2 = x[k] - pm[k];
+        acc = FMA(d2, d2, acc);
+        acc = FMA(-d1, d1, acc);
+    }
+    return acc * ((REAL)0.5 / (s * s));
+}
+
 /* One sweep of one chain.  x (T,D) in/out; y (T,D) or NULL; shd (T) or NULL; eps_aux (T,D) or NULL;
  * eps_prop (T,N,D); u_res (T-1,N); u_bwd (T); outputs anc (T), xs (T,N,D), lws (T,N), As (T-1,N) [all required]. */
 int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y, const REAL* shd, const REAL* eps_aux,
@@ -371,9 +478,13 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
     REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
     REAL* lw = (REAL*)malloc(sizeof(REAL) * N);
     REAL zero[MAXD] = {0, 0, 0, 0};
+    REAL* grad = (REAL*)malloc(sizeof(REAL) * (size_t)T * D);
     if (m.proposal == 1) /* csmc/generic.py:67 */
         for (int t = 0; t < T; ++t)
             for (int k = 0; k < D; ++k) u[t * D + k] = FMA(shd[t], eps_aux[t * D + k], x[t * D + k]);
+    if (m.proposal == 1 && g->gradient) SUF(grad_logpi)(&m, g, T, u, y, grad);
+    SUF(trans) tr;
+    REAL pm[MAXD];
     /* t = 0 (csmc.py:74-80) */
     for (int i = 0; i < N; ++i) {
         REAL* xi = xs + (size_t)i * D;
@@ -385,11 +496,17 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
                 xi[k] = acc;
             }
         } else {
-            for (int k = 0; k < D; ++k) xi[k] = FMA(shd[0], e[k], u[k]);
+            for (int k = 0; k < D; ++k) {
+                pm[k] = g->gradient ? FMA(shd[0] * shd[0], grad[k], u[k]) : u[k];
+                xi[k] = FMA(shd[0], e[k], pm[k]);
+            }
         }
         if (i == 0) for (int k = 0; k < D; ++k) xi[k] = x[k];
         REAL gq = SUF(pot)(&m, xi, y ? y : zero);
-        if (m.proposal == 1) gq = gq + SUF(gauss)(D, xi, m.m0, m.LP0, m.c_init);
+        if (m.proposal == 1) {
+            gq = gq + SUF(gauss)(D, xi, m.m0, m.LP0, m.c_init);
+            if (g->gradient) gq = gq + SUF(grad_corr)(D, xi, u, pm, shd[0]);
+        }
         lws[i] = gq;
     }
     SUF(expmax)(lws, N, w);
@@ -398,6 +515,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
         REAL* xcur = xs + (size_t)t * N * D;
         const REAL* yt = y ? y + (size_t)t * D : zero;
         SUF(cumsum_dpp)(w, N, c);
+        SUF(trans_at)(&m, g, t - 1, &tr);
         for (int i = 0; i < N; ++i) {
             int idx = 0;
             if (i > 0) idx = SUF(choice2)(c, N, u_res[(size_t)(t - 1) * N + i]); /* resamplings.py:35-36 */
@@ -407,21 +525,25 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             REAL* xi = xcur + (size_t)i * D;
             if (m.proposal == 0) {
                 REAL mu0[MAXD];
-                SUF(tmean)(&m, xp, mu0);
+                SUF(tmean_t)(&m, &tr, xp, mu0);
                 for (int k = 0; k < D; ++k) {
                     REAL acc = mu0[k];
-                    for (int j = 0; j <= k; ++j) acc = FMA(m.LQ[k * MAXD + j], e[j], acc);
+                    for (int j = 0; j <= k; ++j) acc = FMA(tr.LQ[k * MAXD + j], e[j], acc);
                     xi[k] = acc;
                 }
             } else {
-                for (int k = 0; k < D; ++k) xi[k] = FMA(shd[t], e[k], u[t * D + k]);
+                for (int k = 0; k < D; ++k) {
+                    pm[k] = g->gradient ? FMA(shd[t] * shd[t], grad[t * D + k], u[t * D + k]) : u[t * D + k];
+                    xi[k] = FMA(shd[t], e[k], pm[k]);
+                }
             }
             if (i == 0) for (int k = 0; k < D; ++k) xi[k] = x[t * D + k];
             REAL gq = SUF(pot)(&m, xi, yt);
             if (m.proposal == 1) {
                 REAL mu[MAXD];
-                SUF(tmean)(&m, xp, mu);
-                gq = SUF(gauss)(D, xi, mu, m.LQ, m.c_trans) + gq;
+                SUF(tmean_t)(&m, &tr, xp, mu);
+                gq = SUF(gauss)(D, xi, mu, tr.LQ, tr.c_trans) + gq;
+                if (g->gradient == 2) gq = gq + SUF(grad_corr)(D, xi, u + t * D, pm, shd[t]);
             }
             lw[i] = gq;
         }
@@ -438,10 +560,11 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
         if (!g->backward) {
             B = As[(size_t)t * N + B];
         } else {
+            SUF(trans_at)(&m, g, t, &tr); /* Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136) */
             for (int i = 0; i < N; ++i) {
                 REAL mu[MAXD];
-                SUF(tmean)(&m, xs + ((size_t)t * N + i) * D, mu);
-                lw[i] = SUF(gauss)(D, xn, mu, m.LQ, m.c_trans) + lws[(size_t)t * N + i];
+                SUF(tmean_t)(&m, &tr, xs + ((size_t)t * N + i) * D, mu);
+                lw[i] = SUF(gauss)(D, xn, mu, tr.LQ, tr.c_trans) + lws[(size_t)t * N + i];
             }
             SUF(expmax)(lw, N, w);
             SUF(cumsum_dpp)(w, N, c);
@@ -450,7 +573,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
         anc[t] = B;
         for (int k = 0; k < D; ++k) xn[k] = x[t * D + k] = xs[((size_t)t * N + B) * D + k];
     }
-    free(u); free(w); free(c); free(tmp); free(lw);
+    free(u); free(w); free(c); free(tmp); free(lw); free(grad);
     return 0;
 }
 
@@ -613,6 +736,13 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
     }
     free(xs); free(xt); free(lw); free(org); free(ot); free(mu); free(pg); free(cs); free(ss); free(li); free(ri); free(sub);
     return 0;
+}
+
+/* the closed-form gradient alone (tests pin it against finite differences of the joint log-density) */
+void SUF(csmc_ref_grad)(const fk_model* g, int T, const REAL* u, const REAL* y, REAL* grad) {
+    SUF(fk) m;
+    SUF(fk_fill)(&m, g);
+    SUF(grad_logpi)(&m, g, T, u, y, grad);
 }
 
 /* conditional multinomial resampling alone (resamplings.py:14-37), for the reference's statistical test */
