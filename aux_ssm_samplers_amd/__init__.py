@@ -9,5 +9,6 @@ library or a GPU is missing.
 __version__ = "0.1.0"
 
 from ._primitives.base import SamplerState  # noqa: E402,F401  (reference: aux_samplers/__init__.py:1)
+from ._primitives.linearisation import extended, gauss_hermite, cubature  # noqa: E402,F401  (reference: aux_samplers/__init__.py:2)
 from ._primitives.math import mvn  # noqa: E402,F401  (reference: aux_samplers/__init__.py:3)
 from .common import delta_adaptation  # noqa: E402,F401  (reference: aux_samplers/__init__.py:4)

@@ -1,0 +1,116 @@
+"""Host-side helpers around the hot path (SURVEY 8(f) ranks 1 "later" and 4): statistical linearisation
+(aux_samplers/_primitives/linearisation.py), the divide-and-conquer sampling API mode (_primitives/kalman/dnc_sampling.py), the
+effective sample size of the rare-event experiment (examples/rare_event/ess.py) and the result files of the experiment scripts."""
+import warnings
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+
+def test_linearisation_reference_test_linear():
+    """aux_samplers/_primitives/test_linearisation.py::test_linear (:15-46): extended == Gauss-Hermite == cubature == exact on a linear map"""
+    from aux_samplers import extended, gauss_hermite, cubature
+    np.random.seed(0)
+    A, b = np.random.randn(2, 4), np.random.randn(2)
+    q = np.random.randn(2, 5)
+    Q = q @ q.T
+    mean, cov = (lambda x, _: A @ x + b), (lambda *_: Q)
+    x_star = np.random.randn(4)
+    p_star = np.random.randn(4, 10)
+    P_star = p_star @ p_star.T
+    F_e, Q_e, b_e = extended(mean, cov, None, x_star, P_star)
+    F_gh, Q_gh, b_gh = gauss_hermite(mean, cov, None, x_star, P_star)
+    F_c, Q_c, b_c = cubature(mean, cov, None, x_star, P_star)
+    for got in ((F_gh, Q_gh, b_gh), (F_c, Q_c, b_c)):
+        npt.assert_allclose(got[0], F_e, rtol=1e-7, atol=1e-9)
+        npt.assert_allclose(got[1], Q_e, rtol=1e-7, atol=1e-9)
+        npt.assert_allclose(got[2], b_e, rtol=1e-7, atol=1e-9)
+    npt.assert_allclose(F_e, A, rtol=1e-7, atol=1e-9)
+    npt.assert_allclose(Q_e, Q)
+    npt.assert_allclose(b_e, b, rtol=1e-7, atol=1e-9)
+    F_j, _, b_j = extended(mean, cov, None, x_star, P_star, jac=lambda x, _: A)  # a user-supplied Jacobian is taken as is
+    npt.assert_array_equal(F_j, A)
+    npt.assert_allclose(b_j, b, atol=1e-14)
+
+
+def test_sigma_point_rules_integrate_gaussian_moments():
+    from aux_ssm_samplers_amd._primitives.linearisation import _cubature_rule, _gauss_hermite_rule
+    for w, xi in (_cubature_rule(3), _gauss_hermite_rule(3, 3), _gauss_hermite_rule(2, 5)):
+        npt.assert_allclose(w.sum(), 1.0, rtol=1e-13)
+        npt.assert_allclose(w @ xi, 0.0, atol=1e-13)
+        npt.assert_allclose((xi * w[:, None]).T @ xi, np.eye(xi.shape[1]), atol=1e-12)
+    w, xi = _gauss_hermite_rule(1, 5)  # degree 9 exact: E z^4 = 3, E z^6 = 15, E z^8 = 105
+    npt.assert_allclose([w @ xi[:, 0] ** 4, w @ xi[:, 0] ** 6, w @ xi[:, 0] ** 8], [3.0, 15.0, 105.0], rtol=1e-12)
+
+
+def test_nonlinear_linearisation_agrees_to_second_order():
+    """on a smooth nonlinear map the three linearisations agree up to terms of the order of the sigma-point spread"""
+    from aux_samplers import extended, gauss_hermite, cubature
+    mean = lambda x, th: np.array([np.sin(x[0]) + th * x[1], x[0] * x[1]])
+    cov = lambda x, th: 0.1 * np.eye(2)
+    x, P = np.array([0.3, -0.2]), 1e-6 * np.eye(2)
+    Fe, Qe, be = extended(mean, cov, 0.5, x, P)
+    for fn in (gauss_hermite, cubature):
+        F, Q, b = fn(mean, cov, 0.5, x, P)
+        npt.assert_allclose(F, Fe, atol=1e-5)
+        npt.assert_allclose(b, be, atol=1e-5)
+        npt.assert_allclose(Q, Qe, atol=1e-5)
+
+
+def test_ess_known_answers():
+    from aux_samplers.diagnostics import effective_sample_size
+    rng = np.random.default_rng(0)
+    M, N = 4, 20000
+    x = rng.standard_normal((M, N))
+    ess = effective_sample_size(x)
+    assert 0.9 * M * N < ess < 1.1 * M * N
+    for rho in (0.5, 0.9):
+        y = np.zeros((M, N))
+        y[:, 0] = rng.standard_normal(M)
+        e = np.sqrt(1 - rho ** 2) * rng.standard_normal((M, N))
+        for t in range(1, N):
+            y[:, t] = rho * y[:, t - 1] + e[:, t]
+        want = M * N * (1 - rho) / (1 + rho)
+        npt.assert_allclose(effective_sample_size(y), want, rtol=0.12)
+        npt.assert_allclose(effective_sample_size(y, var=1.0), want, rtol=0.12)  # the reference's addition: divide by the TRUE variance
+    # extra axes are kept, chain / sample axes are removable anywhere
+    z = rng.standard_normal((3, N, 2))
+    out = effective_sample_size(np.moveaxis(z, 1, 2), chain_axis=0, sample_axis=2)
+    assert out.shape == (2,) and np.all(out > 0.8 * 3 * N)
+
+
+def test_result_files_have_the_reference_schema(tmp_path):
+    from aux_samplers.diagnostics import save_experiment_npz, save_rare_event_csv
+    K, T, D = 3, 5, 2
+    p = save_experiment_npz(str(tmp_path / "results"), "kalman", D, T, 25, True, False, ejsd_per_key=np.zeros((K, T, D)),
+                            acceptance_rate_per_key=np.zeros((K, T)), delta_per_key=np.ones((K, T)), time_per_key=np.arange(K))
+    assert p.endswith("kalman-2-5-25-True-False.npz")  # examples/stochastic_volatility/experiment.py:238
+    f = np.load(p)
+    assert set(f.files) == {"ejsd_per_key", "acceptance_rate_per_key", "delta_per_key", "time_per_key"} and f["ejsd_per_key"].shape == (K, T, D)
+    res = {(0.9, 1.0, t, s): float(t) for t in range(T) for s in ("mean", "std")}
+    paths = save_rare_event_csv(str(tmp_path / "results"), "csmc", T, 25, False, False, res, true_values=res)
+    import pandas as pd
+    df = pd.read_csv(paths[0])
+    assert list(df.columns[:4]) == ["rho", "r2", "timestep", "statistic"] and paths[1].endswith("5-true.csv")
+
+
+@pytest.mark.gpu
+def test_dnc_sampling_mode_reference_statistical_test():
+    """test_sampling.py::test_parallel_vs_sequential (:23-68) runs `dnc` as a third mode against the RTS smoother; so does this"""
+    from aux_samplers._primitives.kalman import dnc_sampling
+    import aux_ssm_samplers_amd._primitives.kalman as P
+    from oracle import kalman_np as K
+    from tests.helpers import ref_lgssm_inputs
+    ys, lg = ref_lgssm_inputs(42, 5, 2, 3)
+    ms, Ps, ell = P.filtering(ys, P.LGSSM(*lg), True)
+    sm, sP = K.explicit_smoother(ms, Ps, lg[2], lg[3], lg[4])
+    n = 20000
+    rng = np.random.default_rng(0)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        xs = np.stack([dnc_sampling.sampling(None, ms, Ps, P.LGSSM(*lg), eps=rng.standard_normal(ms.shape)) for _ in range(200)])
+    assert any("proof-of-concept" in str(x.message) for x in w)
+    npt.assert_allclose(xs.mean(0), sm, atol=0.35)
+    with pytest.raises(ValueError):
+        dnc_sampling.sampling(None, np.zeros((3, 2, 2)), np.zeros((3, 2, 2, 2)), P.LGSSM(*lg))
