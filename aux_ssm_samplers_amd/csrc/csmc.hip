@@ -140,7 +140,7 @@ template <typename R, int D> __device__ __forceinline__ R grad_correction(const 
 }
 
 // ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
-template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
+template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     // two images of (c, xprev), alternated by time-step parity: readers of step t never race writers of step t+1,
@@ -152,7 +152,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
     const bool live = tid < N;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
-    const R* gaux = m.gradient ? (const R*)a.grad + (long long)ch * T * D : uaux;
+    const R* gaux = GRAD ? (const R*)a.grad + (long long)ch * T * D : uaux;
     const R* yv = (const R*)a.y;
     R* xs = (R*)a.xs + (long long)ch * T * N * D;
     R* lws = (R*)a.lws + (long long)ch * T * N;
@@ -195,7 +195,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         const R s0 = ((const R*)a.shd)[0];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            pm[k] = m.gradient ? fma_(s0 * s0, gaux[k], uaux[k]) : uaux[k];
+            pm[k] = GRAD ? fma_(s0 * s0, gaux[k], uaux[k]) : uaux[k];
             x[k] = fma_(s0, eps[k], pm[k]);
         }
     }
@@ -208,7 +208,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
         R g = potential<R, D>(m, x, ycur);
         if (m.proposal == 1) {
             g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
-            if (m.gradient) g = g + grad_correction<R, D>(x, uaux, pm, ((const R*)a.shd)[0]);  // GradientAuxiliaryG0 (:173-190)
+            if constexpr (GRAD) g = g + grad_correction<R, D>(x, uaux, pm, ((const R*)a.shd)[0]);  // GradientAuxiliaryG0 (:173-190)
         }
         lw = live ? g : ninf;
     }
@@ -256,7 +256,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
 #pragma unroll
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
         // propagate (csmc.py:91-92); the transition t - 1 -> t (time-varying: row t - 1 of the device arrays)
-        const TransT<R> tr = trans_at<R, D>(m, t - 1);
+        const TransT<R> tr = trans_at_c<R, D, TV>(m, t - 1);
         if (m.proposal == 0) {
             R mu[D];
             trans_mean_t<R, D>(m, tr, xp, mu);
@@ -271,7 +271,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
             const R st = ((const R*)a.shd)[t];
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                pm[k] = m.gradient ? fma_(st * st, gaux[(long long)t * D + k], uaux[(long long)t * D + k]) : uaux[(long long)t * D + k];
+                pm[k] = GRAD ? fma_(st * st, gaux[(long long)t * D + k], uaux[(long long)t * D + k]) : uaux[(long long)t * D + k];
                 x[k] = fma_(st, eps[k], pm[k]);
             }
         }
@@ -288,7 +288,9 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_fwd(
                 g = gauss_chol_logpdf<R, D>(x, mu, tr.LQ, tr.c_trans, tr.ld) + g;
                 // GradientAuxiliaryGt (:252-268): in the reference the correction is summed over all particles, i.e. a constant of the
                 // step (AUXSSM_GRAD_REFERENCE: nothing to add); AUXSSM_GRAD_EXACT applies it per particle
-                if (m.gradient == 2) g = g + grad_correction<R, D>(x, uaux + (long long)t * D, pm, ((const R*)a.shd)[t]);
+                if constexpr (GRAD) {
+                    if (m.gradient == 2) g = g + grad_correction<R, D>(x, uaux + (long long)t * D, pm, ((const R*)a.shd)[t]);
+                }
             }
             lw = live ? g : ninf;
         }
@@ -318,7 +320,7 @@ template <typename R> __device__ __forceinline__ int block_count_below(const R* 
     for (int k = 0; k < 16; ++k) B += k < nw ? cnt[k] : 0;
     return B < N - 1 ? B : N - 1;
 }
-template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
+template <typename R, int D, bool TV> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     R* c = (R*)smem;                 // [TB]
@@ -393,7 +395,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_csmc_bwd(
         R lw = ninf;
         if (live) {
             R mu[D];
-            const TransT<R> tr = trans_at<R, D>(m, t);  // Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136)
+            const TransT<R> tr = trans_at_c<R, D, TV>(m, t);  // Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136)
             trans_mean_t<R, D>(m, tr, xi, mu);
             lw = gauss_chol_logpdf<R, D>(xn, mu, tr.LQ, tr.c_trans, tr.ld) + lwi;
         }
@@ -515,14 +517,28 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     {
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
         const size_t lds = (size_t)2 * TB * (1 + D) * sizeof(R) + 48 * sizeof(R) + 64;
-        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_csmc_fwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+        const bool tv = m.Ft != nullptr, gr = m.gradient != 0;
+#define AX_FWD(TVv, GRv)                                                                                                                                   \
+    do {                                                                                                                                                   \
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D, TVv, GRv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_csmc_fwd<R, D, TVv, GRv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
+    } while (0)
+        if (tv && gr) AX_FWD(true, true);
+        else if (tv) AX_FWD(true, false);
+        else if (gr) AX_FWD(false, true);
+        else AX_FWD(false, false);
+#undef AX_FWD
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_BWD);
         const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + (size_t)2 * TB * D * sizeof(R) + 2 * sizeof(R) + 32 * sizeof(int) + 64;
-        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL((k_csmc_bwd<R, D>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+        if (m.Ft) {
+            if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_csmc_bwd<R, D, true>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+        } else {
+            if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((k_csmc_bwd<R, D, false>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+        }
     }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;

@@ -34,6 +34,11 @@ template <typename R, int D> __device__ __forceinline__ TransT<R> trans_at(const
     if (m.Ft) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t]};
     return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans};
 }
+// the same with the choice made at compile time (the persistent sweep kernels: no branch on the model kind inside the time loop)
+template <typename R, int D, bool TV> __device__ __forceinline__ TransT<R> trans_at_c(const FkDev<R>& m, long long t) {
+    if constexpr (TV) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t]};
+    else return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans};
+}
 
 struct CsmcArgs {
     int C, T, N, backward;

@@ -787,6 +787,32 @@ AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, co
     cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
 }
 
+// the five terms of one time step t >= 1 from values in registers: x, xp at t; u_in = u_t (or eps_t when a.u_fly); xq, xpq at t - 1;
+// the real observation model at t (Rm: upper triangle) and the transition t - 1 -> t
+template <typename R, int D, int PO>
+AX_HD void sweep_logpdf_core(const SweepLogpdfArgs& a, const R* x, const R* xp, const R* u_in, const R* xq, const R* xpq, const R* H, const R* cv,
+                             const R* y, const R* Rm, const R* F, const R* bd, const R* Q, R* out5) {
+    R u[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)a.shd * u_in[k] : u_in[k];
+    R cc_p, cc_x, ob_p, ob_x, corr;
+    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
+    R pr_p, pr_x;
+    {
+        R r1[D], r2[D], m1[D], m2[D];
+        mv<R, D, D>(F, xpq, m1);
+        mv<R, D, D>(F, xq, m2);
+#pragma unroll
+        for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
+        gauss_logpdf2<R, D>(r1, r2, Q, nullptr, pr_p, pr_x);
+    }
+    out5[0] = cc_p + pr_p;
+    out5[1] = cc_x + pr_x;
+    out5[2] = ob_p + pr_p;
+    out5[3] = ob_x + pr_x;
+    out5[4] = corr;
+}
+
 // lanes indexed by i = t - 1 (t >= 1)
 template <typename R, int D, int PO, class IO>
 AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, bool valid, R* out5) {
@@ -819,26 +845,7 @@ AX_HD void body_sweep_logpdf(const SweepLogpdfArgs& a, IO& io, int c, int i, boo
 #pragma unroll
     for (int k = 0; k < 5; ++k) out5[k] = 0;
     if (!valid) return;
-    if (a.u_fly) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) u[k] = x[k] + (R)a.shd * u[k];
-    }
-    R cc_p, cc_x, ob_p, ob_x, corr;
-    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
-    R pr_p, pr_x;
-    {
-        R r1[D], r2[D], m1[D], m2[D];
-        mv<R, D, D>(F, xpq, m1);
-        mv<R, D, D>(F, xq, m2);
-#pragma unroll
-        for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
-        gauss_logpdf2<R, D>(r1, r2, Q, nullptr, pr_p, pr_x);
-    }
-    out5[0] = cc_p + pr_p;
-    out5[1] = cc_x + pr_x;
-    out5[2] = ob_p + pr_p;
-    out5[3] = ob_x + pr_x;
-    out5[4] = corr;
+    sweep_logpdf_core<R, D, PO>(a, x, xp, u, xq, xpq, H, cv, y, Rm, F, bd, Q, out5);
 }
 // t = 0 terms (one lane per chain)
 template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_head(const SweepLogpdfArgs& a, int c, R* out5) {

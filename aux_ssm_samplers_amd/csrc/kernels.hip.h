@@ -249,13 +249,39 @@ template <typename R, int D, int PO>
 __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
-    DirectIO io;
     R v[5] = {0, 0, 0, 0, 0};
     if (c.tt == 0) body_sweep_logpdf_head<R, D, PO>(a, c.s, v);
+    // stream the chain's values: (x, xp) of the previous step stay in registers, the next step's reads fly during this step's arithmetic
+    const Arr& ua = a.u_fly ? a.eps_aux : a.u;
+    R xq[D], xpq[D], xn[D], xpn[D], un[D];
+    rd<R, D>(a.x, c.s, c.i0, 0, xq);
+    rd<R, D>(a.xp, c.s, c.i0, 0, xpq);
+    rd<R, D>(a.x, c.s, (long long)c.i0 + 1, 0, xn);
+    rd<R, D>(a.xp, c.s, (long long)c.i0 + 1, 0, xpn);
+    rd<R, D>(ua, c.s, (long long)c.i0 + 1, 0, un);
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
-        R w[5];
-        body_sweep_logpdf<R, D, PO>(a, io, c.s, opaque_uniform(i), true, w);
+        R xc[D], xpc[D], uc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xc[k] = xn[k], xpc[k] = xpn[k], uc[k] = un[k];
+        const int iu = opaque_uniform(i);
+        const long long t = (long long)iu + 1;
+        if (i + 1 < c.i1) {
+            rd<R, D>(a.x, c.s, t + 1, 0, xn);
+            rd<R, D>(a.xp, c.s, t + 1, 0, xpn);
+            rd<R, D>(ua, c.s, t + 1, 0, un);
+        }
+        R H[PO * D], cv[PO], y[PO], Rm[PO * PO], F[D * D], bd[D], Q[D * D], w[5];
+        rd<R, PO * D>(a.Hs, c.s, t, 0, H);
+        rd<R, PO>(a.cs, c.s, t, 0, cv);
+        rd<R, PO>(a.ys, c.s, t, 0, y);
+        rd_upper<R, PO>(a.Rs, c.s, t, 0, Rm);
+        rd<R, D * D>(a.Fs, c.s, iu, 0, F);
+        rd<R, D>(a.bs, c.s, iu, 0, bd);
+        rd<R, D * D>(a.Qs, c.s, iu, 0, Q);
+        sweep_logpdf_core<R, D, PO>(a, xc, xpc, uc, xq, xpq, H, cv, y, Rm, F, bd, Q, w);
+#pragma unroll
+        for (int k = 0; k < D; ++k) xq[k] = xc[k], xpq[k] = xpc[k];
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += w[k];
     }
