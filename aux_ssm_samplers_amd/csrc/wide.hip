@@ -42,16 +42,16 @@ struct Bump {
 // ---- cooperative primitives (all lanes of the workgroup call them; every one ENDS with a barrier) -------------------------
 
 // dst (rows x cols, ld) <- contiguous row-major record
-template <typename R> __device__ void load_mat(R* dst, int ld, const R* __restrict__ src, int rows, int cols, int tid) {
+template <typename R> __device__ __forceinline__ void load_mat(R* dst, int ld, const R* __restrict__ src, int rows, int cols, int tid) {
     for (int r = tid / 64; r < rows; r += NWV)
         for (int c = tid & 63; c < cols; c += 64) dst[r * ld + c] = src[(long long)r * cols + c];
     __syncthreads();
 }
-template <typename R> __device__ void store_mat(R* __restrict__ dst, const R* src, int ld, int rows, int cols, int tid) {
+template <typename R> __device__ __forceinline__ void store_mat(R* __restrict__ dst, const R* src, int ld, int rows, int cols, int tid) {
     for (int r = tid / 64; r < rows; r += NWV)
         for (int c = tid & 63; c < cols; c += 64) dst[(long long)r * cols + c] = src[r * ld + c];
 }
-template <typename R> __device__ void load_vec(R* dst, const R* __restrict__ src, int n, int tid) {
+template <typename R> __device__ __forceinline__ void load_vec(R* dst, const R* __restrict__ src, int n, int tid) {
     for (int i = tid; i < n; i += NT) dst[i] = src[i];
     __syncthreads();
 }
@@ -66,7 +66,7 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // fetched before their four MFMAs so the LDS latency is paid once per 16 k.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool TA, bool TB>
-__device__ void gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha, float beta, int tid) {
+__device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha, float beta, int tid) {
     const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
     for (int tile = wv; tile < ntile; tile += NWV) {
@@ -103,7 +103,7 @@ __device__ void gemm(int M, int N, int K, const float* A, int lda, const float* 
 }
 // fp64: v_mfma_f64_16x16x4_f64 -- A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D[row (l >> 4) + 4 r][col l & 15]
 template <bool TA, bool TB>
-__device__ void gemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, double alpha, double beta, int tid) {
+__device__ __forceinline__ void gemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, double alpha, double beta, int tid) {
     const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
     for (int tile = wv; tile < ntile; tile += NWV) {
@@ -139,7 +139,7 @@ __device__ void gemm(int M, int N, int K, const double* A, int lda, const double
     __syncthreads();
 }
 // y (M) = alpha op(A) x + beta y;  four lanes per row, each a quarter of the k range, combined by two shuffles
-template <typename R, bool TA> __device__ void gemv(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid) {
+template <typename R, bool TA> __device__ __forceinline__ void gemv(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid) {
     const int q = tid & 3;
     for (int i0 = 0; i0 < M; i0 += NT / 4) {
         const int i = i0 + (tid >> 2);
@@ -153,7 +153,7 @@ template <typename R, bool TA> __device__ void gemv(int M, int K, const R* A, in
     __syncthreads();
 }
 // y[i] = sum_j A[i lda + j] x[j], one wave per row, lanes over j: coalesced when A is a row-major record in global memory
-template <typename R> __device__ void gemv_rows(int M, int K, const R* __restrict__ A, long long lda, const R* x, R* y, int tid) {
+template <typename R> __device__ __forceinline__ void gemv_rows(int M, int K, const R* __restrict__ A, long long lda, const R* x, R* y, int tid) {
     const int lane = tid & 63;
     for (int i = tid >> 6; i < M; i += NWV) {
         R s = 0;
@@ -165,7 +165,7 @@ template <typename R> __device__ void gemv_rows(int M, int K, const R* __restric
     __syncthreads();
 }
 // sum of one value per lane over the workgroup (every lane gets it); red = NWV reals of LDS scratch
-template <typename R> __device__ R block_sum(R v, R* red, int tid) {
+template <typename R> __device__ __forceinline__ R block_sum(R v, R* red, int tid) {
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) v += __shfl_xor(v, off, 64);
     if ((tid & 63) == 0) red[tid >> 6] = v;
@@ -176,7 +176,7 @@ template <typename R> __device__ R block_sum(R v, R* red, int tid) {
     return s;
 }
 // M <- 0.5 (M + M^T)
-template <typename R> __device__ void symmetrise(R* M, int ld, int n, int tid) {
+template <typename R> __device__ __forceinline__ void symmetrise(R* M, int ld, int n, int tid) {
     for (int i = tid / 64; i < n; i += NWV)
         for (int j = i + 1 + (tid & 63); j < n; j += 64) {
             const R v = (R)0.5 * (M[i * ld + j] + M[j * ld + i]);
@@ -209,7 +209,7 @@ template <typename R> __device__ __forceinline__ void colupd(R* Xc, int ld, cons
 // In-place lower Cholesky of the LOWER triangle of S (n x n).  skip[k] (may be null): index k is deleted (L_kk = 1,
 // off-diagonals 0) -- the NaN-observation masking of filtering.py:89-100.  invd = 1 / diag; dg = scratch (n).  Returns false
 // (uniformly) on a non-positive / NaN pivot; the factor then holds NaNs, as JAX's does.  Same operation order as smallmat.h.
-template <typename R> __device__ bool chol(R* S, int ld, int n, const unsigned char* skip, R* invd, R* dg, int* flag, int tid) {
+template <typename R> __device__ __forceinline__ bool chol(R* S, int ld, int n, const unsigned char* skip, R* invd, R* dg, int* flag, int tid) {
     const int ti = tid >> 6, tj = tid & 63;
     if (tid == 0) *flag = 1;
     __syncthreads();
@@ -240,7 +240,7 @@ template <typename R> __device__ bool chol(R* S, int ld, int n, const unsigned c
 }
 
 // X (n x nc, ld) <- L^-1 X
-template <typename R> __device__ void trsm_l(const R* L, int ldl, int n, const R* invd, R* X, int ld, int nc, int tid) {
+template <typename R> __device__ __forceinline__ void trsm_l(const R* L, int ldl, int n, const R* invd, R* X, int ld, int nc, int tid) {
     const int ti = tid >> 6, tj = tid & 63;
     for (int i = 0; i + 1 < n; ++i) {
         const R inv = invd[i];
@@ -252,7 +252,7 @@ template <typename R> __device__ void trsm_l(const R* L, int ldl, int n, const R
     __syncthreads();
 }
 // X <- L^-T X
-template <typename R> __device__ void trsm_lt(const R* L, int ldl, int n, const R* invd, R* X, int ld, int nc, int tid) {
+template <typename R> __device__ __forceinline__ void trsm_lt(const R* L, int ldl, int n, const R* invd, R* X, int ld, int nc, int tid) {
     const int ti = tid >> 6, tj = tid & 63;
     for (int i = n - 1; i > 0; --i) {
         const R inv = invd[i];
@@ -296,7 +296,7 @@ __device__ __forceinline__ double bcast(double v, int src) {
 // Needs n <= NWV * NRR and nct <= 256.  LDS scratch: rowbuf[nct + 1], pinv[n] reals; iperm[n] ints; key[2].
 // (The reference's jnp.linalg.solve is LU + two triangular solves; same solution, rounding-level differences.)
 template <typename R, int NRR>
-__device__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
+__device__ __forceinline__ void gj_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
     const int ti = tid >> 6, tj = tid & 63;
     R z[NRR][4];
     bool used[NRR];
@@ -411,7 +411,7 @@ __device__ __forceinline__ unsigned int wave_umax_dpp(unsigned int v) {
 // Three barriers per block of 16 pivots instead of two per pivot.  The LDS image of Z is free while Z lives in registers: the panel, D
 // and the published rows are carved from it.  Needs 32 <= n <= 64 (one panel row per lane) and nct <= 256.
 template <typename R>
-__device__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, int tid) {
+__device__ __forceinline__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, int tid) {
     constexpr int NRR = 4, NB = 16, PS = NB + 1;
     const int ti = tid >> 6, tj = tid & 63;
     R z[NRR][4];
@@ -537,7 +537,7 @@ __device__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, 
 // Replaces chol + trsm_l (+ trsm_lt) wherever the factor itself is not needed.  Needs n <= NWV * NRR, nct <= 256.
 // LDS scratch: rowbuf[2 (nct + 1)], piv[n] reals.  Returns ok (uniform); *half_logdet = 0.5 log|S| over the kept indices.
 template <typename R, int NRR>
-__device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free) {
+__device__ __forceinline__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free) {
     const int ti = tid >> 6, tj = tid & 63;
     R z[NRR][4];
 #pragma unroll
@@ -698,12 +698,12 @@ __device__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* s
 }
 __host__ __device__ inline bool spd_fits(int n, int nct) { return n <= 8 * NWV && nct <= 256; }
 template <typename R>
-__device__ bool spd_solve(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free = false) {
+__device__ __forceinline__ bool spd_solve(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free = false) {
     if (n <= NWV * 4) return spd_solve_t<R, 4>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid, z_free);
     return spd_solve_t<R, 8>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid, z_free);
 }
 
-template <typename R> __device__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
+template <typename R> __device__ __forceinline__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
     // blocked variant: one panel row per lane, and its scratch (panel, D, published rows, positions) must fit the LDS image of Z
     if (NWV == 16 && n >= 32 && n <= 64 && nct <= 256 &&
         (size_t)n * 33 * sizeof(R) + (size_t)16 * nct * sizeof(R) + (size_t)n * 4 + 64 <= (size_t)n * ld * sizeof(R)) {
@@ -723,7 +723,7 @@ template <typename R> struct Obs {
     unsigned char* nan;
     int* cnt;  // #observed components
 };
-template <typename R> __device__ bool load_obs(const Obs<R>& o, const R* Hg, const R* cg, const R* yg, int p, int d, int ldh, int tid) {
+template <typename R> __device__ __forceinline__ bool load_obs(const Obs<R>& o, const R* Hg, const R* cg, const R* yg, int p, int d, int ldh, int tid) {
     const int ldd = ldh;
     if (tid == 0) *o.cnt = 0;
     __syncthreads();
@@ -745,7 +745,7 @@ template <typename R> __device__ bool load_obs(const Obs<R>& o, const R* Hg, con
 // covariance record in global memory (its upper entries are read, as the per-lane path does); deleted indices get a zero row /
 // column (spd_solve treats them as unit rows).
 template <typename R>
-__device__ void innovation(const Obs<R>& o, int ldh, const R* P_, const R* Rg, int p, int d, R* PHt, R* S, int lds, int tid) {
+__device__ __forceinline__ void innovation(const Obs<R>& o, int ldh, const R* P_, const R* Rg, int p, int d, R* PHt, R* S, int lds, int tid) {
     const int ldd = ldp_(d), ldp = ldp_(p);
     gemm<false, true>(d, p, d, P_, ldd, o.H_, ldh, PHt, ldp, (R)1, (R)0, tid);
     gemm<false, false>(p, p, d, o.H_, ldh, PHt, ldp, S, lds, (R)1, (R)0, tid);
@@ -759,7 +759,7 @@ __device__ void innovation(const Obs<R>& o, int ldh, const R* P_, const R* Rg, i
     __syncthreads();
 }
 // log N from the solved system: -0.5 r^T S^-1 r - 0.5 log|S| - dim/2 log 2 pi; NaN / failed factor -> 0 (the reference's nansum)
-template <typename R> __device__ R ell_value(R q, R half_logdet, int dim, bool ok) {
+template <typename R> __device__ __forceinline__ R ell_value(R q, R half_logdet, int dim, bool ok) {
     R ell = (R)-0.5 * q - half_logdet - (R)(0.5 * LOG_2PI) * (R)dim;
     if (!ok) ell = r_nan<R>();
     return isnan_(ell) ? (R)0 : ell;
@@ -982,7 +982,7 @@ template <typename R> struct Agg {
 };
 static size_t lds_combine(size_t s, int d) { return al16(d * (size_t)ldp_(3 * d + 1) * s) + 4 * al16(d * (size_t)ldp_(d) * s) + 6 * al16(d * s) + al16((3 * d + 2 + NWV) * s) + al16(d * 4) + 64; }
 
-template <typename R> __device__ void carve_combine(Bump& L, Agg<R>& g, int d, bool full) {
+template <typename R> __device__ __forceinline__ void carve_combine(Bump& L, Agg<R>& g, int d, bool full) {
     const int ldd = ldp_(d);
     g.nct = full ? 3 * d + 1 : 2 * d + 1;
     g.ldz = ldp_(g.nct);
@@ -1003,7 +1003,7 @@ template <typename R> __device__ void carve_combine(Bump& L, Agg<R>& g, int d, b
     g.iperm = L.take<int>(d);
     g.key = L.take<unsigned int>(2);
 }
-template <typename R> __device__ void agg_load(Agg<R>& g, const R* __restrict__ e, int d, int tid) {
+template <typename R> __device__ __forceinline__ void agg_load(Agg<R>& g, const R* __restrict__ e, int d, int tid) {
     const int ldd = ldp_(d);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
@@ -1015,7 +1015,7 @@ template <typename R> __device__ void agg_load(Agg<R>& g, const R* __restrict__ 
     g.z = e[fe_size(d) - 1];
     __syncthreads();
 }
-template <typename R> __device__ void agg_store(R* __restrict__ e, const Agg<R>& g, int d, int tid) {
+template <typename R> __device__ __forceinline__ void agg_store(R* __restrict__ e, const Agg<R>& g, int d, int tid) {
     const int ldd = ldp_(d);
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
@@ -1030,7 +1030,7 @@ template <typename R> __device__ void agg_store(R* __restrict__ e, const Agg<R>&
 //   W = I + C1 J2;  [X | Y | z] = W^-1 [A1 | C1 | b1 + C1 eta2]
 //   A = A2 X;  b = A2 z + b2;  C = sym(A2 Y A2^T + C2);  eta = X^T (eta2 - J2 b1) + eta1;  J = sym(X^T (J2 A1) + J1)
 // full = false: only (b, C) are updated (the down-sweep; they depend on a1 only through (b1, C1)).
-template <typename R> __device__ void combine(Agg<R>& g, const R* __restrict__ e2, int d, bool full, int tid) {
+template <typename R> __device__ __forceinline__ void combine(Agg<R>& g, const R* __restrict__ e2, int d, bool full, int tid) {
     const int ldd = ldp_(d), ldz = g.ldz;
     const R* A2 = e2;
     const R* b2 = e2 + d * d;
@@ -1213,7 +1213,7 @@ static size_t lds_sample_init(size_t s, int d) {
 }
 
 // Lc <- lower Cholesky factor of the symmetric matrix in Lc (full storage), nan_to_num'ed; a failed factorisation is all zero
-template <typename R> __device__ void chol_n2n(R* Lc, int ld, int n, R* invd, R* dg, int* flag, int tid) {
+template <typename R> __device__ __forceinline__ void chol_n2n(R* Lc, int ld, int n, R* invd, R* dg, int* flag, int tid) {
     const bool ok = chol<R>(Lc, ld, n, nullptr, invd, dg, flag, tid);
     for (int r = tid / 64; r < n; r += NWV)
         for (int q = tid & 63; q < n; q += 64) Lc[r * ld + q] = (q <= r && ok) ? nan_to_num<R>(Lc[r * ld + q]) : (R)0;
@@ -1307,7 +1307,7 @@ static size_t lds_sample_scan(size_t s, int d) { return 3 * al16(d * (size_t)ldp
 template <typename R> struct SAgg {
     R *G, *Gc, *Go, *e, *tv, *ec;
 };
-template <typename R> __device__ void carve_sample(Bump& L, SAgg<R>& g, int d) {
+template <typename R> __device__ __forceinline__ void carve_sample(Bump& L, SAgg<R>& g, int d) {
     const int ldd = ldp_(d);
     g.G = L.take<R>(d * ldd);
     g.Gc = L.take<R>(d * ldd);
@@ -1316,7 +1316,7 @@ template <typename R> __device__ void carve_sample(Bump& L, SAgg<R>& g, int d) {
     g.tv = L.take<R>(d);
     g.ec = L.take<R>(d);
 }
-template <typename R> __device__ void sample_combine_w(SAgg<R>& g, const R* __restrict__ cur, int d, bool full, int tid) {
+template <typename R> __device__ __forceinline__ void sample_combine_w(SAgg<R>& g, const R* __restrict__ cur, int d, bool full, int tid) {
     const int ldd = ldp_(d);
     load_mat<R>(g.Gc, ldd, cur, d, d, tid);
     load_vec<R>(g.ec, cur + d * d, d, tid);
@@ -1386,7 +1386,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_down(Sample
 // Cholesky of the covariance record `cov` (n x n in global memory, upper entries read) with deleted components `skip`, then
 // up to two residuals solved in place.  Returns through o1 / o2 (lane-0 values; 0 where the reference's nansum drops the term).
 template <typename R>
-__device__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* skip, R* r1, R* r2, R* Z, R* piv, R* rowbuf, int tid, R& o1, R& o2) {
+__device__ __forceinline__ void gauss2(const R* __restrict__ cov, int n, const unsigned char* skip, R* r1, R* r2, R* Z, R* piv, R* rowbuf, int tid, R& o1, R& o2) {
     const int nct = n + 2, ldz = ldp_(nct);
     // Z = [cov | r1 | r2]; the covariance record is symmetric: its lower triangle is read (row-contiguous, coalesced)
     for (int i = tid / 64; i < n; i += NWV)

@@ -35,7 +35,19 @@ def demangle(names):
         return names
 
 
+def table(unit):
+    """{demangled kernel or device-function name: resources} of one unit of csrc/"""
+    src = os.path.join(CSRC, unit)
+    res = resources(src, ["-ffp-contract=off"] if unit in ("csmc.hip", "pit.hip", "loop.hip") else [])
+    names = list(res)
+    return dict(zip(demangle(names), (res[n] for n in names)))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--json":  # python tools/kernel_resources.py --json wide.hip > profiles/r02_wide_resources.json
+        import json
+        print(json.dumps(table(sys.argv[2]), indent=1, sort_keys=True))
+        sys.exit(0)
     src = sys.argv[1]
     if not os.path.exists(src):
         src = os.path.join(CSRC, os.path.basename(src))
