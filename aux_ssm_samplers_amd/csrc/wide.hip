@@ -69,6 +69,61 @@ template <bool TA, bool TB>
 __device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha, float beta, int tid) {
     const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
+    if (((M | N | K) & 15) == 0) {  // whole tiles (d = 16, 32, 48, 64): no bounds tests, the next 16 k of fragments are in flight during the MFMAs
+        for (int tile = wv; tile < ntile; tile += NWV) {
+            const int ti = tile / tn, i0 = ti << 4, j0 = (tile - ti * tn) << 4;
+            const float* pa = TA ? A + hi * lda + i0 + lo : A + (i0 + lo) * lda + hi;
+            const float* pb = TB ? B + (j0 + lo) * ldb + hi : B + hi * ldb + j0 + lo;
+            const int sa = TA ? 4 * lda : 4, sb = TB ? 4 : 4 * ldb;
+            f32x4 acc = {0, 0, 0, 0};
+            if (K == 64) {  // the flagship size: all 16 k-steps of fragments issued up front, two accumulators
+                float fa[16], fb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) fa[u] = pa[u * sa], fb[u] = pb[u * sb];
+                f32x4 acc1 = {0, 0, 0, 0};
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u], fb[u], acc, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u + 1], fb[u + 1], acc1, 0, 0, 0);
+                }
+                acc += acc1;
+                float* q = &C[(i0 + 4 * hi) * ldc + j0 + lo];
+                if (beta != 0.f) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r] + beta * q[r * ldc];
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r];
+                }
+                continue;
+            }
+            float a[4], b[4], an[4], bn[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) a[u] = pa[u * sa], b[u] = pb[u * sb];
+            for (int k0 = 16; k0 < K; k0 += 16) {
+                pa += 4 * sa;
+                pb += 4 * sb;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) an[u] = pa[u * sa], bn[u] = pb[u * sb];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) a[u] = an[u], b[u] = bn[u];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+            float* q = &C[(i0 + 4 * hi) * ldc + j0 + lo];
+            if (beta != 0.f) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r] + beta * q[r * ldc];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r];
+            }
+        }
+        __syncthreads();
+        return;
+    }
     for (int tile = wv; tile < ntile; tile += NWV) {
         const int ti = tile / tn, i0 = ti << 4, j0 = (tile - ti * tn) << 4;
         const int i = i0 + lo, j = j0 + lo;
@@ -401,46 +456,109 @@ __device__ __forceinline__ unsigned int wave_umax_dpp(unsigned int v) {
 }
 
 // The same elimination as gj_solve (same pivots: partial pivoting over the rows not yet used, deferred scaling, implicit permutation),
-// BLOCKED by NB = 16 pivots so that the per-pivot synchronisation disappears:
-//   A  every wave drops its rows' 16 panel columns into LDS;
-//   B  ONE wave (lane = row) eliminates the 64 x 16 panel in registers -- pivot search is a DPP wave reduction, pivot-row values are
+// BLOCKED by NB = 16 pivots so that the per-pivot synchronisation disappears, with the trailing update on the matrix cores:
+//   Z lives in the MFMA accumulators of the 16 waves (ZTiles: wave w holds row tile w & 3 of column tiles (w >> 2) + 4 c);
+//   A  the four waves holding the block's column tile drop the 64 x 16 panel into LDS;
+//   B  ONE wave (lane = row) eliminates the panel in registers -- pivot search is a DPP wave reduction, pivot-row values are
 //      v_readlane broadcasts, no barrier, no LDS -- and accumulates D = T E_p - E_p (64 x 16), T = T_15 .. T_0 the block's elementary
 //      transformations, E_p the selector of its pivot rows;  T - I has non-zero columns only at the pivot rows, so for every column z of
 //      the augmented matrix  T z = z + D z[p]  with z[p] the pivot rows BEFORE the block;
-//   C  the owners publish those 16 rows, then every lane applies the rank-16 update to its 4 x 4 registers.
-// Three barriers per block of 16 pivots instead of two per pivot.  The LDS image of Z is free while Z lives in registers: the panel, D
-// and the published rows are carved from it.  Needs 32 <= n <= 64 (one panel row per lane) and nct <= 256.
-template <typename R>
-__device__ __forceinline__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, int tid) {
-    constexpr int NRR = 4, NB = 16, PS = NB + 1;
-    const int ti = tid >> 6, tj = tid & 63;
-    R z[NRR][4];
+//   C  the owners publish those 16 rows (Zp, 16 x nct), then every wave adds D Zp to its tiles: four 16x16x4 MFMAs per tile.
+// Three barriers per block of 16 pivots.  The LDS image of Z is free while Z lives in registers: the panel, D and the published rows are
+// carved from it.  Needs 32 <= n <= 64 (one panel row per lane), nct <= 256 and NWV == 16.
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f64x4 mfma16(double a, double b, f64x4 c) { return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0); }
+template <typename R> struct AccT;
+template <> struct AccT<float> {
+    typedef f32x4 V;
+    static __device__ __forceinline__ int row(int hi, int r) { return 4 * hi + r; }
+};
+template <> struct AccT<double> {
+    typedef f64x4 V;
+    static __device__ __forceinline__ int row(int hi, int r) { return hi + 4 * r; }
+};
+constexpr int BLK_NB = 16, BLK_PS = BLK_NB + 1;
+// LDS reals the blocked elimination carves from the image of Z (panel, D, published rows, positions)
+__host__ __device__ inline size_t blk_scratch(int n, int nct) { return (size_t)2 * n * BLK_PS + (size_t)BLK_NB * nct + n + 16; }
+template <typename R> struct ZTiles {
+    typename AccT<R>::V t[4];
+    int rt, cg, lo, hi;  // row tile, first column tile, lane coordinates inside a tile
+    __device__ __forceinline__ void init(int tid) {
+        const int wv = tid >> 6, lane = tid & 63;
+        rt = wv & 3, cg = wv >> 2, lo = lane & 15, hi = lane >> 4;
+    }
+    __device__ __forceinline__ int row(int r) const { return 16 * rt + AccT<R>::row(hi, r); }
+    __device__ __forceinline__ int col(int c) const { return 16 * (cg + 4 * c) + lo; }
+    // skip[k]: index k deleted -> unit row (the caller zeroed row / column k of the leading block)
+    __device__ __forceinline__ void load(const R* Z, int ld, int n, int nct, const unsigned char* skip) {
 #pragma unroll
-    for (int a = 0; a < NRR; ++a) {
-        const int r = ti + NWV * a;
+        for (int c = 0; c < 4; ++c)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int c = tj + 64 * b;
-            z[a][b] = (r < n && c < nct) ? Z[r * ld + c] : (R)0;
+            for (int r = 0; r < 4; ++r) {
+                const int i = row(r), j = col(c);
+                R v = (i < n && j < nct) ? Z[i * ld + j] : (R)0;
+                if (skip && i < n && skip[i]) v = i == j ? (R)1 : (R)0;
+                t[c][r] = v;
+            }
+    }
+    __device__ __forceinline__ void drop_panel(R* panel, int n, int k0) const {
+        const int ctp = k0 >> 4;
+        if (cg != (ctp & 3)) return;
+        const int c = ctp >> 2;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = row(r);
+            const R v = c == 0 ? t[0][r] : (c == 1 ? t[1][r] : (c == 2 ? t[2][r] : t[3][r]));
+            if (i < n) panel[i * BLK_PS + lo] = v;
         }
     }
+    // Zp[pos(i)][:] = row i for the block's pivot rows; pos(i) < 0: row i is not one of them
+    template <typename POS> __device__ __forceinline__ void publish(R* Zp, int n, int nct, POS pos) const {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = row(r), pp = i < n ? pos(i) : -1;
+            if (pp >= 0) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (col(c) < nct) Zp[pp * nct + col(c)] = t[c][r];
+            }
+        }
+    }
+    // tiles += D (n x nb, leading dimension BLK_PS) Zp (nb x nct) for the column tiles >= ctp (the earlier ones are finished pivot columns)
+    __device__ __forceinline__ void update(const R* Dm, const R* Zp, int n, int nct, int nb, int ctp) {
+        const int i = 16 * rt + lo;
+        R a[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (i < n && 4 * u + hi < nb) ? Dm[i * BLK_PS + 4 * u + hi] : (R)0;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int ct = cg + 4 * c;
+            if (ct < ctp || 16 * ct >= nct) continue;
+            const int j = col(c);
+            R b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) b[u] = (j < nct && 4 * u + hi < nb) ? Zp[(4 * u + hi) * nct + j] : (R)0;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) t[c] = mfma16(a[u], b[u], t[c]);
+        }
+    }
+};
+template <typename R>
+__device__ __forceinline__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pinv, int* iperm, int tid) {
+    constexpr int NB = BLK_NB, PS = BLK_PS;
+    const int ti = tid >> 6, tj = tid & 63;
+    ZTiles<R> z;
+    z.init(tid);
+    z.load(Z, ld, n, nct, nullptr);
     __syncthreads();  // Z is in registers: its LDS image is scratch until the write-back
     R* panel = Z;                 // [n][PS]
-    R* Dm = panel + n * PS;       // [n][NB]
-    R* Zp = Dm + n * NB;          // [NB][nct]
+    R* Dm = panel + n * PS;       // [n][PS]
+    R* Zp = Dm + n * PS;          // [NB][nct]
     int* pos = (int*)(Zp + NB * nct);  // [n] position of row r among the block's pivots, -1 if none
     bool used_lane = false;       // (wave 0) row tj already served as a pivot row
     for (int k0 = 0; k0 < n; k0 += NB) {
         const int nb = n - k0 < NB ? n - k0 : NB;
-        const int kb = k0 >> 6, c0 = k0 & 63;
-        if (tj >= c0 && tj < c0 + nb) {
-#pragma unroll
-            for (int a = 0; a < NRR; ++a) {
-                const int r = ti + NWV * a;
-                const R v = kb == 0 ? z[a][0] : (kb == 1 ? z[a][1] : (kb == 2 ? z[a][2] : z[a][3]));
-                if (r < n) panel[r * PS + (tj - c0)] = v;
-            }
-        }
+        z.drop_panel(panel, n, k0);
         __syncthreads();
         if (ti == 0) {
             const int r = tj;
@@ -483,48 +601,28 @@ __device__ __forceinline__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pi
             }
             if (valid) {
 #pragma unroll
-                for (int j = 0; j < NB; ++j) Dm[r * NB + j] = g[j];
+                for (int j = 0; j < NB; ++j) Dm[r * PS + j] = g[j];
                 pos[r] = mypos;
             }
         }
         __syncthreads();
-#pragma unroll
-        for (int a = 0; a < NRR; ++a) {
-            const int r = ti + NWV * a;
-            const int pp = r < n ? pos[r] : -1;
-            if (pp >= 0) {
-#pragma unroll
-                for (int b = 0; b < 4; ++b)
-                    if (tj + 64 * b < nct) Zp[pp * nct + tj + 64 * b] = z[a][b];
-            }
-        }
+        z.publish(Zp, n, nct, [&](int i) { return pos[i]; });
         __syncthreads();
-        for (int j = 0; j < nb; ++j) {
-            R zk[4];
-#pragma unroll
-            for (int b = 0; b < 4; ++b) zk[b] = (tj + 64 * b < nct) ? Zp[j * nct + tj + 64 * b] : (R)0;
-#pragma unroll
-            for (int a = 0; a < NRR; ++a) {
-                const int r = ti + NWV * a;
-                const R dd = r < n ? Dm[r * NB + j] : (R)0;
-#pragma unroll
-                for (int b = 0; b < 4; ++b) z[a][b] += dd * zk[b];
-            }
-        }
+        z.update(Dm, Zp, n, nct, nb, k0 >> 4);
         // the next block's panel writes touch `panel` only; D / Zp / pos are rewritten after its first barrier, which no wave passes
         // before every wave has finished the update above
     }
     __syncthreads();
 #pragma unroll
-    for (int a = 0; a < NRR; ++a) {
-        const int r = ti + NWV * a;
-        if (r < n) {
-            const R inv = pinv[r];
-            const int kr = iperm[r];
+    for (int r = 0; r < 4; ++r) {
+        const int i = z.row(r);
+        if (i < n) {
+            const R inv = pinv[i];
+            const int kr = iperm[i];
 #pragma unroll
-            for (int b = 0; b < 4; ++b) {
-                const int c = tj + 64 * b;
-                if (c >= n && c < nct) Z[kr * ld + c] = z[a][b] * inv;
+            for (int c = 0; c < 4; ++c) {
+                const int j = z.col(c);
+                if (j >= n && j < nct) Z[kr * ld + j] = z.t[c][r] * inv;
             }
         }
     }
@@ -539,42 +637,22 @@ __device__ __forceinline__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pi
 template <typename R, int NRR>
 __device__ __forceinline__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free) {
     const int ti = tid >> 6, tj = tid & 63;
-    R z[NRR][4];
-#pragma unroll
-    for (int a = 0; a < NRR; ++a) {
-        const int r = ti + NWV * a;
-        const bool sk = skip && r < n && skip[r];
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int c = tj + 64 * b;
-            R v = (r < n && c < nct) ? Z[r * ld + c] : (R)0;
-            if (sk) v = c == r ? (R)1 : (R)0;
-            z[a][b] = v;
-        }
-    }
-    __syncthreads();
-    const int rb = nct + 1;
     // blocked elimination (the scheme of gj_solve_blk with the pivot of column k fixed to row k: no search at all): 16 pivots per three
-    // barriers; scratch carved from the LDS image of Z, which is free while Z lives in registers
+    // barriers, trailing update on the matrix cores; scratch carved from the LDS image of Z, which is free while Z lives in registers
     // (z_free: the caller does not read S = Z[:, :n] again -- the unblocked path leaves it intact, this one does not)
-    const bool blocked = z_free && NRR == 4 && NWV == 16 && n >= 32 && n <= 64 &&
-                         (size_t)n * 33 * sizeof(R) + (size_t)16 * nct * sizeof(R) + 64 <= (size_t)n * ld * sizeof(R);
+    const bool blocked = z_free && NRR == 4 && NWV == 16 && n >= 32 && n <= 64 && blk_scratch(n, nct) <= (size_t)n * ld;
     if (blocked) {
-        constexpr int NB = 16, PS = NB + 1;
+        constexpr int NB = BLK_NB, PS = BLK_PS;
+        ZTiles<R> zt;
+        zt.init(tid);
+        zt.load(Z, ld, n, nct, skip);
+        __syncthreads();
         R* panel = Z;
         R* Dm = panel + n * PS;
-        R* Zp = Dm + n * NB;
+        R* Zp = Dm + n * PS;
         for (int k0 = 0; k0 < n; k0 += NB) {
             const int nb = n - k0 < NB ? n - k0 : NB;
-            const int kb = k0 >> 6, c0 = k0 & 63;
-            if (tj >= c0 && tj < c0 + nb) {
-#pragma unroll
-                for (int a = 0; a < NRR; ++a) {
-                    const int r = ti + NWV * a;
-                    const R v = kb == 0 ? z[a][0] : (kb == 1 ? z[a][1] : (kb == 2 ? z[a][2] : z[a][3]));
-                    if (r < n) panel[r * PS + (tj - c0)] = v;
-                }
-            }
+            zt.drop_panel(panel, n, k0);
             __syncthreads();
             if (ti == 0) {
                 const int r = tj;
@@ -610,35 +688,57 @@ __device__ __forceinline__ bool spd_solve_t(R* Z, int ld, int n, int nct, const 
                 if (valid && r >= k0 && r < k0 + nb) piv[r] = mypiv;
                 if (valid) {
 #pragma unroll
-                    for (int j = 0; j < NB; ++j) Dm[r * NB + j] = g[j];
+                    for (int j = 0; j < NB; ++j) Dm[r * PS + j] = g[j];
                 }
             }
             __syncthreads();
-#pragma unroll
-            for (int a = 0; a < NRR; ++a) {
-                const int r = ti + NWV * a;
-                if (r >= k0 && r < k0 + nb) {
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)
-                        if (tj + 64 * b < nct) Zp[(r - k0) * nct + tj + 64 * b] = z[a][b];
-                }
-            }
+            zt.publish(Zp, n, nct, [&](int i) { return (i >= k0 && i < k0 + nb) ? i - k0 : -1; });
             __syncthreads();
-            for (int j = 0; j < nb; ++j) {
-                R zk[4];
+            zt.update(Dm, Zp, n, nct, nb, k0 >> 4);
+        }
+        __syncthreads();
+        int bad = 0;
+        R hl = 0;
+        for (int k = tid; k < n; k += NT) {
+            const R d = piv[k];
+            if (!(skip && skip[k])) {
+                bad |= !(d > (R)0);
+                hl += (R)0.5 * log_(d);
+            }
+        }
+        const bool ok = !__syncthreads_or(bad);
+        if (half_logdet) *half_logdet = block_sum<R>(hl, rowbuf, tid);
 #pragma unroll
-                for (int b = 0; b < 4; ++b) zk[b] = (tj + 64 * b < nct) ? Zp[j * nct + tj + 64 * b] : (R)0;
+        for (int r = 0; r < 4; ++r) {
+            const int i = zt.row(r);
+            if (i < n) {
+                const R inv = (R)1 / piv[i];
 #pragma unroll
-                for (int a = 0; a < NRR; ++a) {
-                    const int r = ti + NWV * a;
-                    const R dd = r < n ? Dm[r * NB + j] : (R)0;
-#pragma unroll
-                    for (int b = 0; b < 4; ++b) z[a][b] += dd * zk[b];
+                for (int c = 0; c < 4; ++c) {
+                    const int j = zt.col(c);
+                    if (j >= n && j < nct) Z[i * ld + j] = zt.t[c][r] * inv;
                 }
             }
         }
+        __syncthreads();
+        return ok;
     }
-    for (int k = blocked ? n : 0; k < n; ++k) {
+    R z[NRR][4];
+#pragma unroll
+    for (int a = 0; a < NRR; ++a) {
+        const int r = ti + NWV * a;
+        const bool sk = skip && r < n && skip[r];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int c = tj + 64 * b;
+            R v = (r < n && c < nct) ? Z[r * ld + c] : (R)0;
+            if (sk) v = c == r ? (R)1 : (R)0;
+            z[a][b] = v;
+        }
+    }
+    __syncthreads();
+    const int rb = nct + 1;
+    for (int k = 0; k < n; ++k) {
         const int ka = k / NWV, kb = k >> 6, src = k & 63;
         R* rbuf = rowbuf + (k & 1) * rb;
         if (ti == k - ka * NWV) {  // the wave owning row k publishes it (current values) and the pivot
@@ -705,8 +805,7 @@ __device__ __forceinline__ bool spd_solve(R* Z, int ld, int n, int nct, const un
 
 template <typename R> __device__ __forceinline__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
     // blocked variant: one panel row per lane, and its scratch (panel, D, published rows, positions) must fit the LDS image of Z
-    if (NWV == 16 && n >= 32 && n <= 64 && nct <= 256 &&
-        (size_t)n * 33 * sizeof(R) + (size_t)16 * nct * sizeof(R) + (size_t)n * 4 + 64 <= (size_t)n * ld * sizeof(R)) {
+    if (NWV == 16 && n >= 32 && n <= 64 && nct <= 256 && blk_scratch(n, nct) <= (size_t)n * ld) {
         gj_solve_blk<R>(Z, ld, n, nct, pinv, iperm, tid);
         return;
     }

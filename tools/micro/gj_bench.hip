@@ -2,11 +2,11 @@
 #include "../../aux_ssm_samplers_amd/csrc/wide.hip"
 namespace ax { void set_error(const char*, ...) {} void* ws_take(auxssm_ctx*, size_t) { return nullptr; } }
 using namespace ax::wide;
-template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long* cyc, int d, int iters, int mode) {
+template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long* cyc, int d, int iters, int mode, int nsolve) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x;
     Bump L{smem};
-    const int nct = 3 * d + 1, ldz = ldp_(nct);
+    const int nct = 3 * d + 1, ldz = ldp_(nct), ncs = nsolve > 0 ? nsolve : nct;
     R* Z = L.take<R>(d * ldz);
     R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
     R* pinv = L.take<R>(d);
@@ -24,11 +24,11 @@ template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long
                 for (int c = tid & 63; c < r; c += 64) Z[r * ldz + c] = Z[c * ldz + r];
         __syncthreads();
         const long long t0 = clock64();
-        if (mode == 0) lu_solve<R>(Z, ldz, d, nct, rowbuf, pinv, iperm, key, tid);
+        if (mode == 0) lu_solve<R>(Z, ldz, d, ncs, rowbuf, pinv, iperm, key, tid);
         if (mode == 1) (void)chol<R>(Z, ldz, d, nullptr, invd, dg, flag, tid);
         if (mode == 2) trsm_l<R>(Z, ldz, d, pinv, Z + d, ldz, d + 2, tid);
         if (mode == 3) gemm<false, false>(d, d, d, Z, ldz, Z + d, ldz, Z + 2 * d, ldz, (R)1, (R)0, tid);
-        if (mode == 4) (void)spd_solve<R>(Z, ldz, d, 2 * d + 2, nullptr, rowbuf, pinv, (R*)nullptr, tid);
+        if (mode == 4) (void)spd_solve<R>(Z, ldz, d, nsolve > 0 ? nsolve : 2 * d + 2, nullptr, rowbuf, pinv, (R*)nullptr, tid, true);
         tot += clock64() - t0;
     }
     if (tid == 0) cyc[0] = tot;
@@ -42,10 +42,18 @@ int main() {
     hipFuncSetAttribute((const void*)kb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const char* names[] = {"gj_solve [W|A|C|v]", "chol", "trsm_l (d+2 cols)", "gemm 64^3", "spd_solve [S|H|r|r]"};
     for (int mode = 0; mode < 5; ++mode) {
-        hipLaunchKernelGGL(kb<float>, dim3(1), dim3(NT), lds, 0, out, cyc, d, iters, mode);
+        hipLaunchKernelGGL(kb<float>, dim3(1), dim3(NT), lds, 0, out, cyc, d, iters, mode, 0);
         hipDeviceSynchronize();
         long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
         printf("%-22s d=%d NT=%d: %.0f cycles/call (%.1f per step)\n", names[mode], d, NT, (double)c / iters, (double)c / iters / d);
     }
+    const int ncols[] = {65, 129, 130, 193};
+    for (int mode : {0, 4})
+        for (int nc : ncols) {
+            hipLaunchKernelGGL(kb<float>, dim3(1), dim3(NT), lds, 0, out, cyc, d, iters, mode, nc);
+            hipDeviceSynchronize();
+            long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
+            printf("%-22s nct=%d (z_free) d=%d: %.0f cycles/call\n", mode == 0 ? "lu_solve" : "spd_solve", nc, d, (double)c / iters);
+        }
     return 0;
 }
