@@ -66,7 +66,8 @@ typedef double f64x4 __attribute__((ext_vector_type(4)));
 // fetched before their four MFMAs so the LDS latency is paid once per 16 k.)
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha, float beta, int tid) {
+__device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int lda, const float* B, int ldb, float* C, int ldc, float alpha, float beta, int tid,
+                                     const float* Cin = nullptr, int ldi = 0, bool sync = true) {
     const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
     if (((M | N | K) & 15) == 0) {  // whole tiles (d = 16, 32, 48, 64): no bounds tests, the next 16 k of fragments are in flight during the MFMAs
@@ -89,8 +90,10 @@ __device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int ld
                 acc += acc1;
                 float* q = &C[(i0 + 4 * hi) * ldc + j0 + lo];
                 if (beta != 0.f) {
+                    const float* qi = Cin ? &Cin[(i0 + 4 * hi) * ldi + j0 + lo] : q;
+                    const int li = Cin ? ldi : ldc;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r] + beta * q[r * ldc];
+                    for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r] + beta * qi[r * li];
                 } else {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r];
@@ -114,14 +117,16 @@ __device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int ld
             for (int u = 0; u < 4; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
             float* q = &C[(i0 + 4 * hi) * ldc + j0 + lo];
             if (beta != 0.f) {
+                const float* qi = Cin ? &Cin[(i0 + 4 * hi) * ldi + j0 + lo] : q;
+                const int li = Cin ? ldi : ldc;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r] + beta * q[r * ldc];
+                for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r] + beta * qi[r * li];
             } else {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) q[r * ldc] = alpha * acc[r];
             }
         }
-        __syncthreads();
+        if (sync) __syncthreads();
         return;
     }
     for (int tile = wv; tile < ntile; tile += NWV) {
@@ -149,16 +154,17 @@ __device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int ld
                 const int row = i0 + 4 * hi + r;
                 if (row < M) {
                     float* q = &C[row * ldc + j];
-                    *q = beta != 0.f ? alpha * acc[r] + beta * *q : alpha * acc[r];
+                    *q = beta != 0.f ? alpha * acc[r] + beta * (Cin ? Cin[row * ldi + j] : *q) : alpha * acc[r];
                 }
             }
         }
     }
-    __syncthreads();
+    if (sync) __syncthreads();
 }
 // fp64: v_mfma_f64_16x16x4_f64 -- A[i = l & 15][k = l >> 4], B[k = l >> 4][j = l & 15]; D[row (l >> 4) + 4 r][col l & 15]
 template <bool TA, bool TB>
-__device__ __forceinline__ void gemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, double alpha, double beta, int tid) {
+__device__ __forceinline__ void gemm(int M, int N, int K, const double* A, int lda, const double* B, int ldb, double* C, int ldc, double alpha, double beta, int tid,
+                                     const double* Cin = nullptr, int ldi = 0, bool sync = true) {
     const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4;
     const int tn = (N + 15) >> 4, ntile = ((M + 15) >> 4) * tn;
     for (int tile = wv; tile < ntile; tile += NWV) {
@@ -186,26 +192,31 @@ __device__ __forceinline__ void gemm(int M, int N, int K, const double* A, int l
                 const int row = i0 + hi + 4 * r;
                 if (row < M) {
                     double* q = &C[row * ldc + j];
-                    *q = beta != 0.0 ? alpha * acc[r] + beta * *q : alpha * acc[r];
+                    *q = beta != 0.0 ? alpha * acc[r] + beta * (Cin ? Cin[row * ldi + j] : *q) : alpha * acc[r];
                 }
             }
         }
     }
-    __syncthreads();
+    if (sync) __syncthreads();
 }
-// y (M) = alpha op(A) x + beta y;  four lanes per row, each a quarter of the k range, combined by two shuffles
-template <typename R, bool TA> __device__ __forceinline__ void gemv(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid) {
-    const int q = tid & 3;
-    for (int i0 = 0; i0 < M; i0 += NT / 4) {
-        const int i = i0 + (tid >> 2);
+// y (M) = alpha op(A) x + beta y;  LPR lanes per row (16 when the whole product fits one pass, else 4), each a strided share of the k
+// range, combined by shuffles
+template <typename R, bool TA, int LPR> __device__ __forceinline__ void gemv_t(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid) {
+    const int q = tid & (LPR - 1);
+    for (int i0 = 0; i0 < M; i0 += NT / LPR) {
+        const int i = i0 + tid / LPR;
         R s = 0;
         if (i < M)
-            for (int k = q; k < K; k += 4) s += (TA ? A[k * lda + i] : A[i * lda + k]) * x[k];
-        s += __shfl_xor(s, 1, 64);
-        s += __shfl_xor(s, 2, 64);
+            for (int k = q; k < K; k += LPR) s += (TA ? A[k * lda + i] : A[i * lda + k]) * x[k];
+#pragma unroll
+        for (int off = 1; off < LPR; off <<= 1) s += __shfl_xor(s, off, 64);
         if (i < M && q == 0) y[i] = beta != (R)0 ? alpha * s + beta * y[i] : alpha * s;
     }
-    __syncthreads();
+}
+template <typename R, bool TA> __device__ __forceinline__ void gemv(int M, int K, const R* A, int lda, const R* x, R* y, R alpha, R beta, int tid, bool sync = true) {
+    if (M <= NT / 16) gemv_t<R, TA, 16>(M, K, A, lda, x, y, alpha, beta, tid);
+    else gemv_t<R, TA, 4>(M, K, A, lda, x, y, alpha, beta, tid);
+    if (sync) __syncthreads();
 }
 // y[i] = sum_j A[i lda + j] x[j], one wave per row, lanes over j: coalesced when A is a row-major record in global memory
 template <typename R> __device__ __forceinline__ void gemv_rows(int M, int K, const R* __restrict__ A, long long lda, const R* x, R* y, int tid) {
@@ -1130,6 +1141,8 @@ template <typename R> __device__ __forceinline__ void agg_store(R* __restrict__ 
 //   A = A2 X;  b = A2 z + b2;  C = sym(A2 Y A2^T + C2);  eta = X^T (eta2 - J2 b1) + eta1;  J = sym(X^T (J2 A1) + J1)
 // full = false: only (b, C) are updated (the down-sweep; they depend on a1 only through (b1, C1)).
 template <typename R> __device__ __forceinline__ void combine(Agg<R>& g, const R* __restrict__ e2, int d, bool full, int tid) {
+    asm volatile("" : "+v"(tid));  // opaque per call: keeps the lane addresses of the products from being hoisted out of the caller's loop
+    asm volatile("" : "+s"(d));    // (see fold_step)
     const int ldd = ldp_(d), ldz = g.ldz;
     const R* A2 = e2;
     const R* b2 = e2 + d * d;
@@ -1279,6 +1292,320 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_scan_down(FilterA
         for (int k = tid; k < d; k += NT) mo[k] = g.b[k];
         store_mat<R>(Po, g.C, g.ldz, d, d, tid);
         if (i == n - 1 && tid == 0) ((R*)a.ellz)[s] = g.z;  // log-scale of the full product = log p(y_1..T-1 | y_0)
+        __syncthreads();
+    }
+}
+
+// ---- level 0 of the filter scan WITHOUT scan elements: fold one step onto the running prefix (kalman_math.h::filter_fold_step) ----
+// The chunk-serial part of the scan never needs a step's own element (A2, b2, C2, eta2, J2): with the step's observation information
+// (Lam = H_^T R_^-1 H_, g0 = H_^T R_^-1 (y - c_), q0 = (y - c_)^T R_^-1 (y - c_), missing components deleted -- one InfoRow per step,
+// wk_obs_info) the prefix advances by
+//   FA = F A,  mb = F b + b_dyn,  Pp = sym(F C F^T + Q)                               (predict, filtering.py:134-139)
+//   W = I + Lam Pp,  [M | v] = W^-1 [Lam | g0 - Lam mb]                               (M = H^T S^-1 H, v = H^T S^-1 (y - H mb - c))
+//   A' = FA - Pp M FA,  b' = mb + Pp v,  C' = sym(Pp - Pp M Pp)                       (update, filtering.py:83-130, information form)
+//   eta' = eta + FA^T v,  J' = sym(J + FA^T M FA),  z' = z + log N(y; H mb + c, S)
+// which IS prefix (+) element(step) of filtering.py:163-183: nine d^3 products and one pivoted elimination with d + 1 right-hand sides,
+// no element build (wk_filter_init: a p x p elimination + eight products), no element record in HBM (3 d^2 + 2 d + 1 reals written and
+// read twice per step; an InfoRow is d^2 + d + 3).  The aggregate levels keep the general combine.  Info row: [Lam | g0 | q0, ldR, dim].
+__host__ __device__ inline long long info_size(int d) { return (long long)d * d + d + 3; }
+static size_t lds_obs_info(size_t s, int d, int p) {
+    const size_t ldd = ldp_(d), ldz = ldp_(p + d + 1);
+    return al16(p * ldd * s) + al16(p * ldz * s) + al16(d * ldd * s) + al16(d * s) + 5 * al16(p * s) + al16((2 * (p + d + 2) + NWV) * s) + al16(p) + 128;
+}
+template <typename R> __global__ void __launch_bounds__(NT) wk_obs_info(FilterArgs a, R* __restrict__ info) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1;
+    const int s = blockIdx.x / n, i = blockIdx.x - s * n, c = s / a.d.B, b = s % a.d.B;
+    const long long t = (long long)i + 1;
+    const int ldd = ldp_(d), nct = p + d + 1, ldz = ldp_(nct);
+    Bump L{smem};
+    Obs<R> o;
+    o.H_ = L.take<R>(p * ldd);
+    R* Z = L.take<R>(p * ldz);  // [R_ | H_ | r] -> [. | R_^-1 H_ | R_^-1 r]
+    R* Lam = L.take<R>(d * ldd);
+    R* g0 = L.take<R>(d);
+    o.c_ = L.take<R>(p);
+    o.y = L.take<R>(p);
+    R* rr = L.take<R>(p);
+    R* w = L.take<R>(p);
+    R* piv = L.take<R>(p);
+    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
+    o.nan = L.take<unsigned char>(p);
+    o.cnt = L.take<int>(1);
+    R* e = info + ((long long)s * n + i) * info_size(d);
+    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
+    if (!any) {  // nothing observed: Lam = 0 makes the fold a pure prediction (_passthrough, filtering.py:239-248)
+        for (long long k = tid; k < info_size(d); k += NT) e[k] = 0;
+        return;
+    }
+    const R* Rg = at<R>(a.Rs, c, t, b);
+    for (int r = tid / 64; r < p; r += NWV)
+        for (int q = tid & 63; q <= r; q += 64) {  // the upper entry (q, r) of the record, as the per-lane path reads it
+            const R v = (o.nan[r] || o.nan[q]) ? (R)0 : Rg[(long long)q * p + r];
+            Z[r * ldz + q] = v;
+            Z[q * ldz + r] = v;
+        }
+    for (int k = tid / 64; k < p; k += NWV)
+        for (int j = tid & 63; j < d; j += 64) Z[k * ldz + p + j] = o.H_[k * ldd + j];
+    for (int k = tid; k < p; k += NT) {
+        rr[k] = o.nan[k] ? (R)0 : o.y[k] - o.c_[k];
+        Z[k * ldz + p + d] = rr[k];
+    }
+    __syncthreads();
+    R hl;
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
+    R q0 = 0;
+    for (int k = tid; k < p; k += NT) {
+        w[k] = Z[k * ldz + p + d];
+        q0 += rr[k] * w[k];
+    }
+    q0 = block_sum<R>(q0, rowbuf, tid);
+    gemm<true, false>(d, d, p, o.H_, ldd, Z + p, ldz, Lam, ldd, (R)1, (R)0, tid);
+    symmetrise<R>(Lam, ldd, d, tid);
+    gemv<R, true>(d, p, o.H_, ldd, w, g0, (R)1, (R)0, tid);
+    const R bad = r_nan<R>();
+    for (int r = tid / 64; r < d; r += NWV)
+        for (int q = tid & 63; q < d; q += 64) e[r * d + q] = ok ? Lam[r * ldd + q] : bad;
+    for (int k = tid; k < d; k += NT) e[d * d + k] = ok ? g0[k] : bad;
+    if (tid == 0) {
+        e[d * d + d] = ok ? q0 : bad;
+        e[d * d + d + 1] = hl;
+        e[d * d + d + 2] = (R)*o.cnt;
+    }
+}
+
+template <typename R> struct Fold {
+    R *A, *C, *J, *F, *Fn, *Pp, *T1, *Z;  // Z = [W | Lam -> M | g -> v] (d x (2d + 1)); after the elimination its W part holds Pp M; Fn: the next step's F
+    R *b, *eta, *mb, *bd, *g0, *lm, *g, *v, *pg, *tv;
+    R *rowbuf, *pinv;
+    int* iperm;
+    unsigned int* key;
+    R z;
+    int ldz;
+#ifdef AUXSSM_FOLD_PROF  // tools/micro/fold_phase.hip: s_memtime at the phase boundaries of fold_step
+    long long ph[16], t0;
+#endif
+};
+#ifdef AUXSSM_FOLD_PROF
+#define FOLD_TICK(k)                   \
+    do {                               \
+        const long long t_ = clock64(); \
+        g.ph[k] += t_ - g.t0;          \
+        g.t0 = t_;                     \
+    } while (0)
+#else
+#define FOLD_TICK(k)
+#endif
+__host__ __device__ inline size_t lds_fold(size_t s, int d, bool full) {
+    const size_t ldd = ldp_(d), ldz = ldp_(2 * d + 1);
+    return (full ? 7 : 5) * al16(d * ldd * s) + al16(d * ldz * s) + 9 * al16(d * s) + al16((d + 3) * s) + al16((2 * d + 2 + NWV) * s) + al16(d * s) + al16(d * 4) + 128;
+}
+__host__ __device__ inline bool fold_fits(size_t s, int d) { return d <= 64 && lds_fold(s, d, true) <= LDS_BUDGET; }
+template <typename R> __device__ __forceinline__ void carve_fold(Bump& L, Fold<R>& g, int d, bool full) {
+    const int ldd = ldp_(d);
+    g.ldz = ldp_(2 * d + 1);
+    g.A = full ? L.take<R>(d * ldd) : nullptr;
+    g.C = L.take<R>(d * ldd);
+    g.J = full ? L.take<R>(d * ldd) : nullptr;
+    g.F = L.take<R>(d * ldd);
+    g.Fn = L.take<R>(d * ldd);
+    g.Pp = L.take<R>(d * ldd);
+    g.T1 = L.take<R>(d * ldd);
+    g.Z = L.take<R>(d * g.ldz);
+    g.b = L.take<R>(d);
+    g.eta = L.take<R>(d);
+    g.mb = L.take<R>(d);
+    g.bd = L.take<R>(d);
+    g.g0 = L.take<R>(d + 3);
+    g.lm = L.take<R>(d);
+    g.g = L.take<R>(d);
+    g.v = L.take<R>(d);
+    g.pg = L.take<R>(d);
+    g.tv = L.take<R>(d);
+    g.rowbuf = L.take<R>(2 * d + 2 > NWV ? 2 * d + 2 : NWV);
+    g.pinv = L.take<R>(d);
+    g.iperm = L.take<int>(d);
+    g.key = L.take<unsigned int>(2);
+}
+// The records of step i + 1 travel HBM -> registers -> LDS inside step i: the loads are issued right after the elimination, the registers
+// are dropped into LDS buffers that step i has finished with (Q over Pp, Lam over M, F into the spare matrix Fn, the vectors into their
+// own doubles) after the next barrier-closed group of products, so they are live across four products only and the HBM latency is hidden.
+template <typename R> struct StepSrc {
+    const R *Fg, *Qg, *bdg, *info;  // records of one step in global memory (info: its InfoRow)
+};
+template <typename R> struct StepRegs {
+    R f[4], q[4], l[4];
+    R bd, g0;  // lane k < d: entry k of b_dyn and of g0; lanes d .. d + 2 of g0: q0, ldR, dim (the tail of the InfoRow)
+};
+// every load is unconditional (clamped address; the mask is applied when the registers are dropped into LDS)
+template <typename R> __device__ __forceinline__ void step_fetch(StepRegs<R>& sr, const StepSrc<R>& src, int d, int tid) {
+    // explicit global address space: through the StepSrc aggregate the compiler loses it and emits FLAT loads, which also count on
+    // lgkmcnt -- the next LDS wait would then sit out the whole HBM latency
+    typedef const R __attribute__((address_space(1))) * GP;
+    const GP Fg = (GP)src.Fg, Qg = (GP)src.Qg, bdg = (GP)src.bdg, info = (GP)src.info;
+    const int cq = min(tid & 63, d - 1);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const long long o = (long long)min((tid >> 6) + NWV * k, d - 1) * d + cq;
+        sr.f[k] = Fg[o];
+        sr.q[k] = Qg[o];
+        sr.l[k] = info[o];
+    }
+    sr.bd = bdg[min(tid, d - 1)];
+    sr.g0 = info[(long long)d * d + min(tid, d + 2)];
+}
+template <typename R> __device__ __forceinline__ void step_drop(Fold<R>& g, const StepRegs<R>& sr, R* Fdst, int d, int tid) {
+    const int ldd = ldp_(d), ldz = g.ldz, cq = tid & 63;
+    R* Lam = g.Z + d;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = (tid >> 6) + NWV * k;
+        if (r < d && cq < d) {
+            Fdst[r * ldd + cq] = sr.f[k];
+            g.Pp[r * ldd + cq] = sr.q[k];
+            Lam[r * ldz + cq] = sr.l[k];
+        }
+    }
+    if (tid < d) g.bd[tid] = sr.bd;
+    if (tid < d + 3) g.g0[tid] = sr.g0;
+}
+// prefix <- prefix (+) step.  FULL: (A, b, C, eta, J, z); else (b, C, z) only.  On entry the step's F, Q (in Pp), Lam (in Z[:, d:2d]), b_dyn and
+// the InfoRow tail are in LDS; on exit those of step `next` are (next == nullptr: none) and g.F / g.Fn have changed roles.
+template <typename R, bool FULL> __device__ __forceinline__ void fold_step(Fold<R>& g, const StepSrc<R>* next, int d, int tid) {
+    // opaque per step: without this the compiler hoists every lane address of the nine products out of the step loop, runs out of
+    // registers and reloads them from scratch inside the loop (each reload a vmcnt(0) that also sits out the prefetch below)
+    asm volatile("" : "+v"(tid));
+    asm volatile("" : "+s"(d));
+    const int ldd = ldp_(d), ldz = g.ldz;
+    R* Lam = g.Z + d;  // becomes M
+    FOLD_TICK(15);
+    const R q0 = g.g0[d], ldR = g.g0[d + 1], dim = g.g0[d + 2];
+    gemm<false, false>(d, d, d, g.F, ldd, g.C, ldd, g.T1, ldd, (R)1, (R)0, tid, (const R*)nullptr, 0, false);  // F C
+    gemv<R, false>(d, d, g.F, ldd, g.b, g.mb, (R)1, (R)0, tid);
+    for (int k = tid; k < d; k += NT) g.mb[k] += g.bd[k];
+    gemm<false, true>(d, d, d, g.T1, ldd, g.F, ldd, g.Pp, ldd, (R)1, (R)1, tid);  // Pp = F C F^T + Q (symmetric up to rounding; C' and J' are symmetrised)
+    FOLD_TICK(1);
+    if (FULL) gemm<false, false>(d, d, d, g.F, ldd, g.A, ldd, g.T1, ldd, (R)1, (R)0, tid, (const R*)nullptr, 0, false);  // FA
+    gemm<false, false>(d, d, d, Lam, ldz, g.Pp, ldd, g.Z, ldz, (R)1, (R)0, tid, (const R*)nullptr, 0, false);             // W - I
+    gemv<R, false>(d, d, Lam, ldz, g.mb, g.lm, (R)1, (R)0, tid);
+    R t = 0;  // per-lane share of q - q0 - corr + log|W| (summed once below)
+    for (int k = tid; k < d; k += NT) {
+        g.Z[k * ldz + k] += (R)1;
+        const R gk = g.g0[k] - g.lm[k];
+        g.g[k] = gk;
+        g.Z[k * ldz + 2 * d] = gk;
+        t += g.mb[k] * (g.lm[k] - (R)2 * g.g0[k]);
+    }
+    __syncthreads();
+    FOLD_TICK(2);
+    lu_solve<R>(g.Z, ldz, d, 2 * d + 1, g.rowbuf, g.pinv, g.iperm, g.key, tid);
+    FOLD_TICK(3);
+    StepRegs<R> sr;
+    if (next) step_fetch<R>(sr, *next, d, tid);
+    for (int k = tid; k < d; k += NT) g.v[k] = g.Z[k * ldz + 2 * d];
+    gemm<false, false>(d, d, d, g.Pp, ldd, Lam, ldz, g.Z, ldz, (R)1, (R)0, tid);  // PM (over W, which is spent; its barrier publishes v)
+    gemv<R, false>(d, d, g.Pp, ldd, g.g, g.pg, (R)1, (R)0, tid, false);
+    gemv<R, false>(d, d, g.Pp, ldd, g.v, g.tv, (R)1, (R)0, tid, false);
+    if (FULL) {
+        gemv<R, true>(d, d, g.T1, ldd, g.v, g.eta, (R)1, (R)1, tid, false);
+        gemm<false, false>(d, d, d, Lam, ldz, g.T1, ldd, g.F, ldd, (R)1, (R)0, tid, (const R*)nullptr, 0, false);  // M FA (over F, which is spent)
+        gemm<false, false>(d, d, d, g.Z, ldz, g.T1, ldd, g.A, ldd, (R)-1, (R)1, tid, g.T1, ldd, false);            // A' = FA - PM FA
+    }
+    gemm<false, false>(d, d, d, g.Z, ldz, g.Pp, ldd, g.C, ldd, (R)-1, (R)1, tid, g.Pp, ldd);                       // C' = Pp - PM Pp
+    FOLD_TICK(4);
+    if (next) step_drop<R>(g, sr, g.Fn, d, tid);  // Pp, M, b_dyn, g0 are spent; F still holds M FA for the J product below
+    for (int k = tid; k < d; k += NT) {
+        t += log_(abs_((R)1 / g.pinv[k])) - g.pg[k] * g.v[k];
+        g.b[k] = g.mb[k] + g.tv[k];
+    }
+    t = block_sum<R>(t, g.rowbuf, tid);
+    g.z += (R)-0.5 * (q0 + t) - ldR - (R)(0.5 * LOG_2PI) * dim;
+    if (FULL) gemm<true, false>(d, d, d, g.T1, ldd, g.F, ldd, g.J, ldd, (R)1, (R)1, tid, (const R*)nullptr, 0, false);  // J + FA^T (M FA)
+    symmetrise<R>(g.C, ldd, d, tid);
+    FOLD_TICK(5);
+    if (FULL) symmetrise<R>(g.J, ldd, d, tid);
+    R* sw = g.F;
+    g.F = g.Fn;
+    g.Fn = sw;
+    FOLD_TICK(6);
+}
+template <typename R> __device__ __forceinline__ StepSrc<R> step_src(const FilterArgs& a, const R* __restrict__ info, int s, int c, int b, int n, long long i) {
+    return StepSrc<R>{at<R>(a.Fs, c, i, b), at<R>(a.Qs, c, i, b), at<R>(a.bs, c, i, b), info + ((long long)s * n + i) * info_size(a.dx)};
+}
+// chunk aggregate of steps [ch E, min(n, (ch+1) E)) of sequence s, record layout of the general combine ([A | b | C | eta | J | z]).
+// Chunk 0 starts from the t = 0 posterior (A = 0, b = m0+, C = P0+: its A / eta / J never reach an output), the others from the identity.
+template <typename R> __global__ void __launch_bounds__(NT) wk_fold_reduce(FilterArgs a, const R* __restrict__ info, R* __restrict__ aggs, int E, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, n = a.d.T - 1;
+    const int s = blockIdx.x / nchunk, ch = blockIdx.x - s * nchunk, c = s / a.d.B, b = s % a.d.B;
+    const int ldd = ldp_(d);
+    Bump L{smem};
+    Fold<R> g;
+    carve_fold<R>(L, g, d, true);
+    const long long ne = fe_size(d);
+    const int i0 = ch * E, i1 = min(n, i0 + E);
+    {
+        StepRegs<R> sr;
+        step_fetch<R>(sr, step_src<R>(a, info, s, c, b, n, i0), d, tid);
+        step_drop<R>(g, sr, g.F, d, tid);
+    }
+    for (int r = tid / 64; r < d; r += NWV)
+        for (int q = tid & 63; q < d; q += 64) {
+            g.A[r * ldd + q] = (ch > 0 && r == q) ? (R)1 : (R)0;
+            g.C[r * ldd + q] = ch > 0 ? (R)0 : at<R>(a.Ps, c, 0, b)[(long long)r * d + q];
+            g.J[r * ldd + q] = 0;
+        }
+    for (int k = tid; k < d; k += NT) g.b[k] = ch > 0 ? (R)0 : at<R>(a.ms, c, 0, b)[k], g.eta[k] = 0;
+    g.z = 0;
+    __syncthreads();
+    for (int i = i0; i < i1; ++i) {
+        const StepSrc<R> nx = step_src<R>(a, info, s, c, b, n, i + 1 < i1 ? i + 1 : i);
+        fold_step<R, true>(g, i + 1 < i1 ? &nx : nullptr, d, tid);
+    }
+    R* e = aggs + ((long long)s * nchunk + ch) * ne;
+    for (int r = tid / 64; r < d; r += NWV)
+        for (int q = tid & 63; q < d; q += 64) {
+            e[r * d + q] = g.A[r * ldd + q];
+            e[d * d + d + r * d + q] = g.C[r * ldd + q];
+            e[2 * d * d + 2 * d + r * d + q] = g.J[r * ldd + q];
+        }
+    for (int k = tid; k < d; k += NT) e[d * d + k] = g.b[k], e[2 * d * d + d + k] = g.eta[k];
+    if (tid == 0) e[ne - 1] = g.z;
+}
+// down-sweep: filtered moments ms[i + 1], Ps[i + 1] = (b, C) of the inclusive prefix i, one Kalman step (information form) per time step
+template <typename R> __global__ void __launch_bounds__(NT) wk_fold_down(FilterArgs a, const R* __restrict__ info, const R* __restrict__ pre, int E, int nchunk) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, n = a.d.T - 1;
+    const int s = blockIdx.x / nchunk, ch = blockIdx.x - s * nchunk, c = s / a.d.B, b = s % a.d.B;
+    const int ldd = ldp_(d);
+    Bump L{smem};
+    Fold<R> g;
+    carve_fold<R>(L, g, d, false);
+    const long long np = pre_size(d);
+    const int i0 = ch * E, i1 = min(n, i0 + E);
+    {
+        StepRegs<R> sr;
+        step_fetch<R>(sr, step_src<R>(a, info, s, c, b, n, i0), d, tid);
+        step_drop<R>(g, sr, g.F, d, tid);
+    }
+    if (ch == 0) {
+        load_vec<R>(g.b, at<R>(a.ms, c, 0, b), d, tid);
+        load_mat<R>(g.C, ldd, at<R>(a.Ps, c, 0, b), d, d, tid);
+        g.z = 0;
+    } else {
+        const R* q = pre + ((long long)s * nchunk + ch) * np;
+        load_vec<R>(g.b, q, d, tid);
+        load_mat<R>(g.C, ldd, q + d, d, d, tid);
+        g.z = q[np - 1];
+    }
+    for (int i = i0; i < i1; ++i) {
+        const StepSrc<R> nx = step_src<R>(a, info, s, c, b, n, i + 1 < i1 ? i + 1 : i);
+        fold_step<R, false>(g, i + 1 < i1 ? &nx : nullptr, d, tid);
+        R* mo = const_cast<R*>(at<R>(a.ms, c, (long long)i + 1, b));
+        R* Po = const_cast<R*>(at<R>(a.Ps, c, (long long)i + 1, b));
+        for (int k = tid; k < d; k += NT) mo[k] = g.b[k];
+        store_mat<R>(Po, g.C, ldd, d, d, tid);
+        if (i == n - 1 && tid == 0) ((R*)a.ellz)[s] = g.z;
         __syncthreads();
     }
 }
@@ -1710,6 +2037,11 @@ template <typename K> static int set_lds(K kern, size_t bytes) {
         hipLaunchKernelGGL(kern, dim3((unsigned)(grid)), dim3(NT), lds, h->stream, __VA_ARGS__);  \
     } while (0)
 
+static bool fold_enabled() {
+    static const bool on = !getenv("AUXSSM_WIDE_NO_FOLD");
+    return on;
+}
+template <typename R> static bool use_fold(int d, int p) { return fold_enabled() && fold_fits(sizeof(R), d) && lds_obs_info(sizeof(R), d, p) <= LDS_BUDGET; }
 template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims& kd, int parallel, int d) {
     const int S = kd.S(), n = kd.n();
     const WPlan p = plan(h, S, n, parallel);
@@ -1720,8 +2052,9 @@ template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims
 template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int parallel, void* ell_out) {
     const int S = a.d.S(), n = a.d.n(), d = a.dx, p = a.dy;
     const WPlan pl = plan(h, S, n, parallel);
+    const bool fold = use_fold<R>(d, p);
     const size_t ne = (size_t)fe_size(d), np = (size_t)pre_size(d);
-    R* elem = (R*)ws_take(h, (size_t)S * std::max(n, 1) * ne * sizeof(R));
+    R* elem = (R*)ws_take(h, (size_t)S * std::max(n, 1) * (fold ? (size_t)info_size(d) : ne) * sizeof(R));  // fold: one InfoRow per step
     R* aggs = (R*)ws_take(h, (size_t)S * pl.nchunk * ne * sizeof(R));
     R* pre = (R*)ws_take(h, (size_t)S * pl.nchunk * np * sizeof(R));
     R* aggs1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * ne * sizeof(R));
@@ -1735,14 +2068,18 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
     {
         ProfScope ps(h, AUXSSM_K_FILTER_INIT);
         WK_LAUNCH((wk_filter_t0<R>), S, lds_filter_t0(sizeof(R), d, p), fa);
-        if (n > 0) WK_LAUNCH((wk_filter_init<R>), (long long)S * n, lds_filter_init(sizeof(R), d, p), fa, elem);
+        if (n > 0) {
+            if (fold) WK_LAUNCH((wk_obs_info<R>), (long long)S * n, lds_obs_info(sizeof(R), d, p), fa, elem);
+            else WK_LAUNCH((wk_filter_init<R>), (long long)S * n, lds_filter_init(sizeof(R), d, p), fa, elem);
+        }
     }
     if (n > 0) {
         const size_t lc = lds_combine(sizeof(R), d);
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
             if (pl.nchunk > 1) {
-                WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk, lc, (const R*)elem, aggs, n, pl.E, pl.nchunk, d);
+                if (fold) WK_LAUNCH((wk_fold_reduce<R>), (long long)S * pl.nchunk, lds_fold(sizeof(R), d, true), fa, (const R*)elem, aggs, pl.E, pl.nchunk);
+                else WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk, lc, (const R*)elem, aggs, n, pl.E, pl.nchunk, d);
                 if (pl.nchunk1 > 1) {  // second level over the chunk aggregates: the sequential aggregate scan shrinks from nchunk to nchunk1
                     WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk1, lc, (const R*)aggs, aggs1, pl.nchunk, pl.E1, pl.nchunk1, d);
                     WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs1, pre1, pl.nchunk1, d);
@@ -1751,7 +2088,8 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
                     WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs, pre, pl.nchunk, d);
                 }
             }
-            WK_LAUNCH((wk_scan_down<R>), (long long)S * pl.nchunk, lc, fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
+            if (fold) WK_LAUNCH((wk_fold_down<R>), (long long)S * pl.nchunk, lds_fold(sizeof(R), d, false), fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
+            else WK_LAUNCH((wk_scan_down<R>), (long long)S * pl.nchunk, lc, fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
         }
     }
     // ell = t = 0 term + the scan's log-scale (the reference's second pass, filtering.py:60-62, is not needed)
