@@ -77,10 +77,15 @@ __device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int ld
             const float* pb = TB ? B + (j0 + lo) * ldb + hi : B + hi * ldb + j0 + lo;
             const int sa = TA ? 4 * lda : 4, sb = TB ? 4 : 4 * ldb;
             f32x4 acc = {0, 0, 0, 0};
-            if (K == 64) {  // the flagship size: all 16 k-steps of fragments issued up front, two accumulators
+            if (K == 64) {  // the flagship size: all 16 k-steps of fragments issued up front, two accumulators.  The MFMA's k index is a
+                // summation index, so lane (lo, hi) takes k = 16 hi + u instead of 4 u + hi: with an odd leading dimension the 64 lanes of
+                // a fragment read then hit 64 different LDS banks (lo + 16 hi + u mod 64) for A, A^T, B and B^T alike
+                const float* qa = TA ? A + 16 * hi * lda + i0 + lo : A + (i0 + lo) * lda + 16 * hi;
+                const float* qb = TB ? B + (j0 + lo) * ldb + 16 * hi : B + 16 * hi * ldb + j0 + lo;
+                const int ua = TA ? lda : 1, ub = TB ? 1 : ldb;
                 float fa[16], fb[16];
 #pragma unroll
-                for (int u = 0; u < 16; ++u) fa[u] = pa[u * sa], fb[u] = pb[u * sb];
+                for (int u = 0; u < 16; ++u) fa[u] = qa[u * ua], fb[u] = qb[u * ub];
                 f32x4 acc1 = {0, 0, 0, 0};
 #pragma unroll
                 for (int u = 0; u < 16; u += 2) {
@@ -1351,9 +1356,31 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_obs_info(FilterAr
         rr[k] = o.nan[k] ? (R)0 : o.y[k] - o.c_[k];
         Z[k * ldz + p + d] = rr[k];
     }
-    __syncthreads();
+    // diagonal R_ (the usual observation noise; the masked entries are zero already): R_^-1 is a row scaling, no elimination
+    int offd = 0;
+    for (int r = tid / 64; r < p; r += NWV)
+        for (int q = tid & 63; q < r; q += 64) offd |= (!(o.nan[r] || o.nan[q]) && Rg[(long long)q * p + r] != (R)0) ? 1 : 0;
+    const bool diag = !__syncthreads_or(offd);  // (also the barrier that publishes Z)
     R hl;
-    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
+    bool ok;
+    if (diag) {
+        int bad = 0;
+        R hs = 0;
+        for (int k = tid; k < p; k += NT)
+            if (!o.nan[k]) {
+                const R rk = Z[k * ldz + k];
+                bad |= !(rk > (R)0);
+                hs += (R)0.5 * log_(rk);
+            }
+        for (int k = tid / 64; k < p; k += NWV) {
+            const R inv = o.nan[k] ? (R)0 : (R)1 / Z[k * ldz + k];
+            for (int j = tid & 63; j <= d; j += 64) Z[k * ldz + p + j] *= inv;
+        }
+        ok = !__syncthreads_or(bad);
+        hl = block_sum<R>(hs, rowbuf, tid);
+    } else {
+        ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
+    }
     R q0 = 0;
     for (int k = tid; k < p; k += NT) {
         w[k] = Z[k * ldz + p + d];
@@ -1998,26 +2025,37 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------------------
+constexpr int WMAXLEV = 4;
 struct WPlan {
-    int E, nchunk;    // level 0: chunks of E consecutive elements
-    int E1, nchunk1;  // level 1 (filter scan only): chunks of E1 consecutive level-0 aggregates; nchunk1 = 1: single level
+    int E, nchunk;  // level 0: chunks of E consecutive elements
+    // filter scan only: the nchunk level-0 aggregates are scanned by a tree.  Level l (l < nlev) groups El[l] consecutive aggregates of the cnt[l]
+    // below it into cnt[l + 1] = ceil(cnt[l] / El[l]); the top cnt[nlev] are scanned by one workgroup per sequence.  cnt[0] = nchunk.
+    // Critical path ~ sum_l 1.7 (El[l] - 1) + cnt[nlev] - 1 general combines (reduce + the cheaper (b, C) down pass per level): groups of
+    // four keep it at ~18 for 256 chunks where one level of 21 cost 51.
+    int nlev, El[WMAXLEV], cnt[WMAXLEV + 1];
 };
 static WPlan plan(const auxssm_ctx* h, int S, int n, int parallel) {
-    WPlan p{n > 0 ? n : 1, 1, 1, 1};
+    WPlan p{};
+    p.E = n > 0 ? n : 1;
+    p.nchunk = 1;
+    p.cnt[0] = 1;
     if (!parallel || n <= 3) return p;
-    long long nchunk = ((long long)2 * h->num_cu + S - 1) / S;
-    const long long cap = (long long)std::sqrt(2.0 * n);
-    nchunk = std::max(1ll, std::min(nchunk, cap));
+    // one sequence: a chunk per CU; many sequences: two rounds of workgroups; never chunks shorter than ~sqrt(n / 2) steps
+    long long nchunk = std::max(1ll, std::min(((long long)2 * h->num_cu + S - 1) / S, std::max((long long)std::sqrt(2.0 * n), (long long)h->num_cu / S)));
     if (const char* ev = getenv("AUXSSM_WIDE_NCHUNK")) {  // tuning/debug override
         const long long v = atoll(ev);
         if (v >= 1 && v <= n) nchunk = v;
     }
+    nchunk = std::min<long long>(nchunk, n);
     p.E = (int)((n + nchunk - 1) / nchunk);
     p.nchunk = (n + p.E - 1) / p.E;
-    p.E1 = p.nchunk;
-    if (p.nchunk >= 16 && !getenv("AUXSSM_WIDE_ONE_LEVEL")) {  // the aggregate scan is sequential per sequence: split it once more
-        p.E1 = (int)std::ceil(std::sqrt(1.6 * p.nchunk));
-        p.nchunk1 = (p.nchunk + p.E1 - 1) / p.E1;
+    p.cnt[0] = p.nchunk;
+    int group = 4;
+    if (const char* ev = getenv("AUXSSM_WIDE_GROUP")) group = std::max(2, atoi(ev));
+    while (p.nlev < WMAXLEV && p.cnt[p.nlev] > 2 * group && !getenv("AUXSSM_WIDE_ONE_LEVEL")) {
+        p.El[p.nlev] = group;
+        p.cnt[p.nlev + 1] = (p.cnt[p.nlev] + group - 1) / group;
+        ++p.nlev;
     }
     return p;
 }
@@ -2046,7 +2084,9 @@ template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims
     const int S = kd.S(), n = kd.n();
     const WPlan p = plan(h, S, n, parallel);
     const size_t ne = (size_t)fe_size(d);
-    return ((size_t)S * std::max(n, 1) * ne + (size_t)S * (p.nchunk + p.nchunk1) * (ne + (size_t)pre_size(d)) + (size_t)S * (std::max(n, 1) + 2)) * sizeof(R) + 8192;
+    size_t nagg = 0;
+    for (int l = 0; l <= p.nlev; ++l) nagg += p.cnt[l];
+    return ((size_t)S * std::max(n, 1) * ne + (size_t)S * nagg * (ne + (size_t)pre_size(d)) + (size_t)S * (std::max(n, 1) + 2)) * sizeof(R) + 8192 + 256 * (2 * (WMAXLEV + 1) + 4);
 }
 
 template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int parallel, void* ell_out) {
@@ -2055,13 +2095,15 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
     const bool fold = use_fold<R>(d, p);
     const size_t ne = (size_t)fe_size(d), np = (size_t)pre_size(d);
     R* elem = (R*)ws_take(h, (size_t)S * std::max(n, 1) * (fold ? (size_t)info_size(d) : ne) * sizeof(R));  // fold: one InfoRow per step
-    R* aggs = (R*)ws_take(h, (size_t)S * pl.nchunk * ne * sizeof(R));
-    R* pre = (R*)ws_take(h, (size_t)S * pl.nchunk * np * sizeof(R));
-    R* aggs1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * ne * sizeof(R));
-    R* pre1 = (R*)ws_take(h, (size_t)S * pl.nchunk1 * np * sizeof(R));
+    R *aggs[WMAXLEV + 1], *pre[WMAXLEV + 1];
+    for (int l = 0; l <= pl.nlev; ++l) {
+        aggs[l] = (R*)ws_take(h, (size_t)S * pl.cnt[l] * ne * sizeof(R));
+        pre[l] = (R*)ws_take(h, (size_t)S * pl.cnt[l] * np * sizeof(R));
+        if (!aggs[l] || !pre[l]) return AUXSSM_ERR_NOMEM;
+    }
     R* ell0 = (R*)ws_take(h, (size_t)S * sizeof(R));
     R* ellz = (R*)ws_take(h, (size_t)S * sizeof(R));
-    if (!elem || !aggs || !pre || !aggs1 || !pre1 || !ell0 || !ellz) return AUXSSM_ERR_NOMEM;
+    if (!elem || !ell0 || !ellz) return AUXSSM_ERR_NOMEM;
     FilterArgs fa = a;
     fa.ell0 = ell0;
     fa.ellz = ellz;
@@ -2078,18 +2120,17 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
         {
             ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
             if (pl.nchunk > 1) {
-                if (fold) WK_LAUNCH((wk_fold_reduce<R>), (long long)S * pl.nchunk, lds_fold(sizeof(R), d, true), fa, (const R*)elem, aggs, pl.E, pl.nchunk);
-                else WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk, lc, (const R*)elem, aggs, n, pl.E, pl.nchunk, d);
-                if (pl.nchunk1 > 1) {  // second level over the chunk aggregates: the sequential aggregate scan shrinks from nchunk to nchunk1
-                    WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk1, lc, (const R*)aggs, aggs1, pl.nchunk, pl.E1, pl.nchunk1, d);
-                    WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs1, pre1, pl.nchunk1, d);
-                    WK_LAUNCH((wk_scan_down_pre<R>), (long long)S * pl.nchunk1, lc, (const R*)aggs, (const R*)pre1, pre, pl.nchunk, pl.E1, pl.nchunk1, d);
-                } else {
-                    WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs, pre, pl.nchunk, d);
-                }
+                if (fold) WK_LAUNCH((wk_fold_reduce<R>), (long long)S * pl.nchunk, lds_fold(sizeof(R), d, true), fa, (const R*)elem, aggs[0], pl.E, pl.nchunk);
+                else WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.nchunk, lc, (const R*)elem, aggs[0], n, pl.E, pl.nchunk, d);
+                // the tree over the chunk aggregates: up (group aggregates), top (one workgroup per sequence), down ((b, C) prefixes per group)
+                for (int l = 0; l < pl.nlev; ++l)
+                    WK_LAUNCH((wk_scan_reduce<R>), (long long)S * pl.cnt[l + 1], lc, (const R*)aggs[l], aggs[l + 1], pl.cnt[l], pl.El[l], pl.cnt[l + 1], d);
+                WK_LAUNCH((wk_scan_aggs<R>), S, lc, (const R*)aggs[pl.nlev], pre[pl.nlev], pl.cnt[pl.nlev], d);
+                for (int l = pl.nlev - 1; l >= 0; --l)
+                    WK_LAUNCH((wk_scan_down_pre<R>), (long long)S * pl.cnt[l + 1], lc, (const R*)aggs[l], (const R*)pre[l + 1], pre[l], pl.cnt[l], pl.El[l], pl.cnt[l + 1], d);
             }
-            if (fold) WK_LAUNCH((wk_fold_down<R>), (long long)S * pl.nchunk, lds_fold(sizeof(R), d, false), fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
-            else WK_LAUNCH((wk_scan_down<R>), (long long)S * pl.nchunk, lc, fa, (const R*)elem, (const R*)pre, pl.E, pl.nchunk);
+            if (fold) WK_LAUNCH((wk_fold_down<R>), (long long)S * pl.nchunk, lds_fold(sizeof(R), d, false), fa, (const R*)elem, (const R*)pre[0], pl.E, pl.nchunk);
+            else WK_LAUNCH((wk_scan_down<R>), (long long)S * pl.nchunk, lc, fa, (const R*)elem, (const R*)pre[0], pl.E, pl.nchunk);
         }
     }
     // ell = t = 0 term + the scan's log-scale (the reference's second pass, filtering.py:60-62, is not needed)
