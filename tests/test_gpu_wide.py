@@ -193,3 +193,40 @@ def test_device_sweep_wide_multichain_resident():
     assert np.all(st.x.accepted.to_host() == 1)
     assert np.all(np.abs(st.x.logs.to_host()[:, 0]) < 1e-6)
     assert np.abs(xa - x0).max() > 1e-3 and np.all(np.isfinite(xa))
+
+
+@pytest.mark.parametrize("d,p,T", [(12, 7, 257), (33, 40, 60)])
+def test_diagonal_observation_noise_with_missing_data(P, d, p, T):
+    """wk_obs_info takes a diagonal R without elimination (row scaling): same numbers as the dense route, NaN entries and all-NaN rows included."""
+    rng = np.random.default_rng(d + T)
+    ys, (m0, P0, Fs, Qs, bs, Hs, Rs, cs) = stable_model(rng, T, d, p)
+    Rs = np.stack([np.diag(0.2 + rng.random(p)) for _ in range(T)])
+    lg64 = (m0, P0, Fs, Qs, bs, Hs, Rs, cs)
+    oms, oPs, oell = K.filtering(ys, lg64, True)
+    for par in (True, False):
+        ms, Ps, ell = P.filtering(ys, P.LGSSM(*lg64), par)
+        npt.assert_allclose(ms, oms, rtol=1e-8, atol=1e-10)
+        npt.assert_allclose(Ps, oPs, rtol=1e-8, atol=1e-10)
+        npt.assert_allclose(ell, oell, rtol=1e-9)
+
+
+def test_element_path_kept_for_sizes_the_fold_does_not_hold():
+    """AUXSSM_WIDE_NO_FOLD=1 routes the filter through the element build + general combine (what d > 64 or a too-small LDS budget falls back
+    to); it must give the oracle's numbers too.  Own process: the switch is read once per process."""
+    import os
+    import subprocess
+    import sys
+    code = ("import numpy as np, numpy.testing as npt\n"
+            "import aux_ssm_samplers_amd._primitives.kalman as P\n"
+            "from oracle import kalman_np as K\n"
+            "from tests.test_gpu_wide import stable_model\n"
+            "rng = np.random.default_rng(3)\n"
+            "for d, p, T in ((8, 16, 300), (32, 32, 40)):\n"
+            "    ys, lg64 = stable_model(rng, T, d, p)\n"
+            "    o = K.filtering(ys, lg64, True)\n"
+            "    r = P.filtering(ys, P.LGSSM(*lg64), True)\n"
+            "    for a, b in zip(r, o): npt.assert_allclose(a, b, rtol=1e-8, atol=1e-10)\n"
+            "print('ok')\n")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, AUXSSM_WIDE_NO_FOLD="1"))
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
