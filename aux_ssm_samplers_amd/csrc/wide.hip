@@ -1425,13 +1425,13 @@ template <typename R> struct Fold {
 #endif
 __host__ __device__ inline size_t lds_fold(size_t s, int d, bool full) {
     const size_t ldd = ldp_(d), ldz = ldp_(2 * d + 1);
-    return (full ? 7 : 5) * al16(d * ldd * s) + al16(d * ldz * s) + 9 * al16(d * s) + al16((d + 3) * s) + al16((2 * d + 2 + NWV) * s) + al16(d * s) + al16(d * 4) + 128;
+    return (full ? 7 : 6) * al16(d * ldd * s) + al16(d * ldz * s) + 9 * al16(d * s) + al16((d + 3) * s) + al16((2 * d + 2 + NWV) * s) + al16(d * s) + al16(d * 4) + 128;
 }
 __host__ __device__ inline bool fold_fits(size_t s, int d) { return d <= 64 && lds_fold(s, d, true) <= LDS_BUDGET; }
 template <typename R> __device__ __forceinline__ void carve_fold(Bump& L, Fold<R>& g, int d, bool full) {
     const int ldd = ldp_(d);
     g.ldz = ldp_(2 * d + 1);
-    g.A = full ? L.take<R>(d * ldd) : nullptr;
+    g.A = L.take<R>(d * ldd);  // the (b, C, z) half keeps Lam here
     g.C = L.take<R>(d * ldd);
     g.J = full ? L.take<R>(d * ldd) : nullptr;
     g.F = L.take<R>(d * ldd);
@@ -1481,16 +1481,15 @@ template <typename R> __device__ __forceinline__ void step_fetch(StepRegs<R>& sr
     sr.bd = bdg[min(tid, d - 1)];
     sr.g0 = info[(long long)d * d + min(tid, d + 2)];
 }
-template <typename R> __device__ __forceinline__ void step_drop(Fold<R>& g, const StepRegs<R>& sr, R* Fdst, int d, int tid) {
-    const int ldd = ldp_(d), ldz = g.ldz, cq = tid & 63;
-    R* Lam = g.Z + d;
+template <typename R> __device__ __forceinline__ void step_drop(Fold<R>& g, const StepRegs<R>& sr, R* Fdst, R* Ldst, int ldl, int d, int tid) {
+    const int ldd = ldp_(d), cq = tid & 63;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int r = (tid >> 6) + NWV * k;
         if (r < d && cq < d) {
             Fdst[r * ldd + cq] = sr.f[k];
             g.Pp[r * ldd + cq] = sr.q[k];
-            Lam[r * ldz + cq] = sr.l[k];
+            Ldst[r * ldl + cq] = sr.l[k];
         }
     }
     if (tid < d) g.bd[tid] = sr.bd;
@@ -1540,7 +1539,7 @@ template <typename R, bool FULL> __device__ __forceinline__ void fold_step(Fold<
     }
     gemm<false, false>(d, d, d, g.Z, ldz, g.Pp, ldd, g.C, ldd, (R)-1, (R)1, tid, g.Pp, ldd);                       // C' = Pp - PM Pp
     FOLD_TICK(4);
-    if (next) step_drop<R>(g, sr, g.Fn, d, tid);  // Pp, M, b_dyn, g0 are spent; F still holds M FA for the J product below
+    if (next) step_drop<R>(g, sr, g.Fn, g.Z + d, ldz, d, tid);  // Pp, M, b_dyn, g0 are spent; F still holds M FA for the J product below
     for (int k = tid; k < d; k += NT) {
         t += log_(abs_((R)1 / g.pinv[k])) - g.pg[k] * g.v[k];
         g.b[k] = g.mb[k] + g.tv[k];
@@ -1554,6 +1553,56 @@ template <typename R, bool FULL> __device__ __forceinline__ void fold_step(Fold<
     R* sw = g.F;
     g.F = g.Fn;
     g.Fn = sw;
+    FOLD_TICK(6);
+}
+// The (b, C, z) half alone (the down-sweep; the sequential filter): with G = I - Pp M = (I + Pp Lam)^-1 (push-through identity)
+//   C' = G Pp,  b' = G (mb + Pp g0)   ->   one elimination  (I + Pp Lam) [C' | b'] = [Pp | mb + Pp g0]
+// and Pp v = b' - mb, log|I + Pp Lam| = log|W| for the log-scale: three products instead of five, no M.  LDS roles here: g.Pp holds Q,
+// g.A holds Lam (leading dimension ldd), Pp itself is formed inside Z[:, d:2d].
+template <typename R> __device__ __forceinline__ void fold_step_down(Fold<R>& g, const StepSrc<R>* next, int d, int tid) {
+    asm volatile("" : "+v"(tid));  // (see fold_step)
+    asm volatile("" : "+s"(d));
+    const int ldd = ldp_(d), ldz = g.ldz;
+    R* Pp = g.Z + d;
+    const R* Lam = g.A;
+    FOLD_TICK(15);
+    const R q0 = g.g0[d], ldR = g.g0[d + 1], dim = g.g0[d + 2];
+    gemm<false, false>(d, d, d, g.F, ldd, g.C, ldd, g.T1, ldd, (R)1, (R)0, tid, (const R*)nullptr, 0, false);  // F C
+    gemv<R, false>(d, d, g.F, ldd, g.b, g.mb, (R)1, (R)0, tid, false);
+    __syncthreads();
+    for (int k = tid; k < d; k += NT) g.mb[k] += g.bd[k];
+    gemm<false, true>(d, d, d, g.T1, ldd, g.F, ldd, Pp, ldz, (R)1, (R)1, tid, g.Pp, ldd);  // Pp = F C F^T + Q
+    FOLD_TICK(1);
+    gemm<false, false>(d, d, d, Pp, ldz, Lam, ldd, g.Z, ldz, (R)1, (R)0, tid, (const R*)nullptr, 0, false);  // (I + Pp Lam) - I
+    gemv<R, false>(d, d, Lam, ldd, g.mb, g.lm, (R)1, (R)0, tid, false);
+    gemv<R, false>(d, d, Pp, ldz, g.g0, g.tv, (R)1, (R)0, tid);
+    R t = 0;
+    for (int k = tid; k < d; k += NT) {
+        g.Z[k * ldz + k] += (R)1;
+        g.g[k] = g.g0[k] - g.lm[k];
+        g.Z[k * ldz + 2 * d] = g.mb[k] + g.tv[k];
+        t += g.mb[k] * (g.lm[k] - (R)2 * g.g0[k]);
+    }
+    StepRegs<R> sr;
+    if (next) step_fetch<R>(sr, *next, d, tid);
+    __syncthreads();
+    FOLD_TICK(2);
+    lu_solve<R>(g.Z, ldz, d, 2 * d + 1, g.rowbuf, g.pinv, g.iperm, g.key, tid);
+    FOLD_TICK(3);
+    if (next) step_drop<R>(g, sr, g.Fn, g.A, ldd, d, tid);  // F, Q, Lam, b_dyn, g0 are spent (g, mb and the scalars were copied out)
+    for (int k = tid; k < d; k += NT) {
+        const R bk = g.Z[k * ldz + 2 * d];
+        t += log_(abs_((R)1 / g.pinv[k])) - g.g[k] * (bk - g.mb[k]);
+        g.b[k] = bk;
+    }
+    for (int r = tid / 64; r < d; r += NWV)  // C' = sym(G Pp)
+        for (int q = tid & 63; q < d; q += 64) g.C[r * ldd + q] = r == q ? Pp[r * ldz + r] : (R)0.5 * (Pp[r * ldz + q] + Pp[q * ldz + r]);
+    t = block_sum<R>(t, g.rowbuf, tid);
+    g.z += (R)-0.5 * (q0 + t) - ldR - (R)(0.5 * LOG_2PI) * dim;
+    R* sw = g.F;
+    g.F = g.Fn;
+    g.Fn = sw;
+    FOLD_TICK(5);
     FOLD_TICK(6);
 }
 template <typename R> __device__ __forceinline__ StepSrc<R> step_src(const FilterArgs& a, const R* __restrict__ info, int s, int c, int b, int n, long long i) {
@@ -1574,7 +1623,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_fold_reduce(Filte
     {
         StepRegs<R> sr;
         step_fetch<R>(sr, step_src<R>(a, info, s, c, b, n, i0), d, tid);
-        step_drop<R>(g, sr, g.F, d, tid);
+        step_drop<R>(g, sr, g.F, g.Z + d, g.ldz, d, tid);
     }
     for (int r = tid / 64; r < d; r += NWV)
         for (int q = tid & 63; q < d; q += 64) {
@@ -1613,7 +1662,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_fold_down(FilterA
     {
         StepRegs<R> sr;
         step_fetch<R>(sr, step_src<R>(a, info, s, c, b, n, i0), d, tid);
-        step_drop<R>(g, sr, g.F, d, tid);
+        step_drop<R>(g, sr, g.F, g.A, ldd, d, tid);
     }
     if (ch == 0) {
         load_vec<R>(g.b, at<R>(a.ms, c, 0, b), d, tid);
@@ -1627,7 +1676,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_fold_down(FilterA
     }
     for (int i = i0; i < i1; ++i) {
         const StepSrc<R> nx = step_src<R>(a, info, s, c, b, n, i + 1 < i1 ? i + 1 : i);
-        fold_step<R, false>(g, i + 1 < i1 ? &nx : nullptr, d, tid);
+        fold_step_down<R>(g, i + 1 < i1 ? &nx : nullptr, d, tid);
         R* mo = const_cast<R*>(at<R>(a.ms, c, (long long)i + 1, b));
         R* Po = const_cast<R*>(at<R>(a.Ps, c, (long long)i + 1, b));
         for (int k = tid; k < d; k += NT) mo[k] = g.b[k];

@@ -211,23 +211,25 @@ def kalman_group_reals(mode, d, po):
     p = d + po
     sym = lambda n: n * (n + 1) // 2
     par = 2 * d * d + d + po * d + po * po + po  # F, Q, b, Hobs, Robs, cobs of one step
+    gain = d * d + d + 2 * d * p + p + sym(p) + 1  # one GainRow (affine_shared.h): Mb, kc, K, HF, ym, Si, c0
     if mode == "shared":
         return {
             "rng": (0, 2 * d, 0),                                     # eps_aux, eps_samp
             "factory": (0, 0, par),
-            "filter_tab": (0, 0, par + 3 * d * d + 2 * d * p + sym(p) + p),  # parameters in, gain rows out (one sequence)
-            "filter_init": (2 * d, 3 * d + 1, 0),                     # x, eps_aux -> u, (b, eta, z)
-            "filter_scan": (2 * d + 1, d, 3 * d * d),                 # per-chain (b, eta, z) -> filtered means; matrices once
-            "sample_init": (0, 0, 2 * d * d + 3 * d * d + d),         # gains / Cholesky factors once per time step
-            "sample_scan": (2 * d, d, 3 * d * d + d),                 # ms, eps_samp -> x'
-            "logpdf": (3 * d, 0, par),                                # x, x', u
+            "filter_tab": (0, 0, par + gain + d * d),                 # parameters in; gain rows and filtered covariances out (ONE sequence)
+            "filter_scan": (2 * d, d, gain),                          # x, eps_aux (u = x + sd eps rebuilt on the fly) -> filtered means; + ell
+            "sample_init": (0, 0, 2 * d * d + d),                     # filtered covariances -> sampler gains / factors, once per time step
+            "sample_scan": (2 * d, d, d * d + d),                     # ms, eps_samp -> x'
+            "logpdf": (3 * d, 0, par),                                # x, x', eps_aux
             "select": (d, d, 0),                                      # x' -> x (accepted chains)
         }
     return {
         "rng": (0, 2 * d, 0),
-        "factory": (2 * d, d + p, par),                               # x, eps_aux -> u, concatenated observations
-        "filter_init": (p, 3 * d * d + 2 * d, par),                   # observations (+ per-chain parameters) -> elements
-        "filter_scan": (3 * d * d + 2 * d, d * d + d, 0),             # K3 of SURVEY 8(d): elements -> filtered means, covariances
+        "factory": (0, 0, par),
+        "filter_tab": (0, 0, po * d + po * po + 2 * po + sym(d) + d + 4),  # observation-information rows (kalman_math.h ObsInfoRow)
+        # the reference's element buffer in, filtered moments out.  This build never materialises the elements (they are
+        # folded onto the prefix from x, eps_aux and the information rows), so its real traffic is BELOW this figure (profiles/r02_traffic.json).
+        "filter_scan": (3 * d * d + 2 * d, d * d + d, 0),
         "sample_scan": (d * d + 2 * d, d, 2 * d * d + d),             # ms, Ps, eps_samp -> x' (elements rebuilt on the fly)
         "logpdf": (3 * d, 0, par),
         "select": (d, d, 0),

@@ -3,7 +3,7 @@
 #include "../../aux_ssm_samplers_amd/csrc/wide.hip"
 namespace ax { void set_error(const char*, ...) {} void* ws_take(auxssm_ctx*, size_t) { return nullptr; } }
 using namespace ax::wide;
-template <typename R, bool FULL> __global__ void __launch_bounds__(NT) kb(const R* src, R* out, long long* cyc, int d, int iters) {
+template <typename R, bool FULL> __global__ void __launch_bounds__(NT) kb(const R* src, R* out, long long* cyc, int d, int iters, int fetch) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, ldd = ldp_(d);
     Bump L{smem};
@@ -23,12 +23,16 @@ template <typename R, bool FULL> __global__ void __launch_bounds__(NT) kb(const 
     {
         StepRegs<R> sr;
         step_fetch<R>(sr, nx, d, tid);
-        step_drop<R>(g, sr, g.F, d, tid);
+        if (FULL) step_drop<R>(g, sr, g.F, g.Z + d, g.ldz, d, tid);
+        else step_drop<R>(g, sr, g.F, g.A, ldd, d, tid);
     }
     __syncthreads();
     const long long t0 = clock64();
     g.t0 = t0;
-    for (int it = 0; it < iters; ++it) fold_step<R, FULL>(g, &nx, d, tid);
+    for (int it = 0; it < iters; ++it) {
+        if (FULL) fold_step<R, true>(g, fetch ? &nx : nullptr, d, tid);
+        else fold_step_down<R>(g, fetch ? &nx : nullptr, d, tid);
+    }
     const long long tot = clock64() - t0;
     if (tid == 0) {
         cyc[0] = tot;
@@ -52,13 +56,14 @@ int main() {
     (void)hipMalloc(&src, hs.size() * 4); (void)hipMalloc(&out, 1 << 20); (void)hipMalloc(&cyc, 256);
     (void)hipMemcpy(src, hs.data(), hs.size() * 4, hipMemcpyHostToDevice);
     const char* names[] = {"-", "FC, mb, Pp", "FA, W, lm, g", "lu_solve (2d+1)", "fetch, v, PM, pg, tv, eta, MFA, A', C'", "drop, z, b, J, sym C", "sym J"};
+    for (int fetch = 1; fetch >= 0; --fetch)
     for (int full = 1; full >= 0; --full) {
         const size_t lds = lds_fold(4, d, full);
-        if (full) { (void)hipFuncSetAttribute((const void*)kb<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((kb<float, true>), dim3(1), dim3(NT), lds, 0, src, out, cyc, d, iters); }
-        else { (void)hipFuncSetAttribute((const void*)kb<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((kb<float, false>), dim3(1), dim3(NT), lds, 0, src, out, cyc, d, iters); }
+        if (full) { (void)hipFuncSetAttribute((const void*)kb<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((kb<float, true>), dim3(1), dim3(NT), lds, 0, src, out, cyc, d, iters, fetch); }
+        else { (void)hipFuncSetAttribute((const void*)kb<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); hipLaunchKernelGGL((kb<float, false>), dim3(1), dim3(NT), lds, 0, src, out, cyc, d, iters, fetch); }
         (void)hipDeviceSynchronize();
         long long c[17]; (void)hipMemcpy(c, cyc, 17 * 8, hipMemcpyDeviceToHost);
-        printf("fold_step<%s> d=%d: %.0f cycles/step (lds %zu)\n", full ? "FULL" : "down", d, (double)c[0] / iters, lds);
+        printf("fold_step<%s> fetch=%d d=%d: %.0f cycles/step (lds %zu)\n", full ? "FULL" : "down", fetch, d, (double)c[0] / iters, lds);
         for (int k = 0; k < 7; ++k) printf("   %-28s %8.0f\n", names[k], (double)c[1 + k] / iters);
         printf("   %-28s %8.0f\n", "(loop / fetch issue)", (double)c[16] / iters);
     }

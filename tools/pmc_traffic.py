@@ -1,0 +1,95 @@
+#!/usr/bin/env python3
+"""HBM traffic per launch group from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE, collected separately as the guide prescribes).
+
+  python tools/pmc_traffic.py <fetch counter_collection.csv> <write counter_collection.csv> <prefix> [--config c2|c3] [--out profiles/r02_traffic.json]
+
+Units / corrections (MI355X_MICROARCH.md, "HBM [CDNA4]"): both counters are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests
+of wide coalesced reads at 64 bytes, so it is doubled (calibrated in round 1 on k_scan_reduce_cm, which reads exactly its element buffer);
+WRITE_SIZE is taken as is.  Per kernel: mean over its dispatches.  Per launch group: sum over the group's kernels of mean bytes x
+dispatches per sweep (dispatches / number of sweeps of that mode in the run).  Keys match bench.py's pmc_traffic() lookups."""
+import collections
+import csv
+import json
+import re
+import subprocess
+import sys
+
+# launch groups (ctx.h ProfScope ids) -> kernels, per mode.  A kernel used by both modes (k_rng_sweep, k_select, ...) has the same
+# bytes per dispatch in both; dispatches are split by the modes' sweep counts.
+SHARED = {
+    "filter_tab": [r"^k_filter_t0<", r"^k_filter_init<", r"^k_scan_reduce<ax::FilterOp<", r"^k_scan_aggs<ax::FilterOp<", r"^k_scan_down<ax::FilterOp<", r"^k_gain_tab<", r"^k_mask_obs<", r"^k_copy_cov<"],
+    "filter_scan": [r"^k_aff_chunkprod<ax::FilterMeanOp<", r"^k_aff_reduce<ax::FilterMeanOp<", r"^k_aff_down<ax::FilterMeanOp<"],
+    "sample_scan": [r"^k_sample_shared_tab<", r"^k_aff_chunkprod<ax::SampleAffOp<", r"^k_aff_reduce<ax::SampleAffOp<", r"^k_aff_down<ax::SampleAffOp<"],
+    "logpdf": [r"^k_sweep_logpdf_tab<", r"^k_sweep_logpdf_cm_shared<"],
+}
+GENERAL = {
+    "filter_scan": [r"^k_scan_reduce_cm<ax::FilterOpFly<", r"^k_scan_down_cm<ax::FilterOpFly<"],
+    "sample_scan": [r"^k_scan_reduce_cm<ax::SampleOpFly<", r"^k_scan_down_cm<ax::SampleOpFly<"],
+    "logpdf": [r"^k_sweep_logpdf_cm<"],
+    "filter_tab": [r"^k_obs_info_tab<"],
+}
+BOTH = {"rng": [r"^k_rng_sweep<"], "select": [r"^k_select<", r"^k_accept<"], "factory": [r"^k_concat_model<", r"^k_concat_obs<"]}
+CSMC = {"csmc_fwd": [r"^k_csmc_fwd<"], "csmc_bwd": [r"^k_csmc_bwd<"], "csmc_ctrans": [r"^k_csmc_ctrans<"]}
+
+
+def per_kernel(path):
+    rows = list(csv.DictReader(open(path)))
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for r in rows:
+        a = acc[r["Kernel_Name"]]
+        a[0] += 1
+        a[1] += float(r["Counter_Value"])
+    names = list(acc)
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    dem = [re.sub(r"^void ax::", "", d) for d in dem]
+    return {d: (acc[n][0], acc[n][1] / acc[n][0] * 1024.0) for n, d in zip(names, dem)}  # name -> (dispatches, mean bytes)
+
+
+def group_bytes(fetch, write, pats, sweeps):
+    tot_f = tot_w = 0.0
+    kern = {}
+    for name in fetch:
+        if any(re.search(p, name) for p in pats):
+            n, fb = fetch[name]
+            wb = write.get(name, (0, 0.0))[1]
+            per_sweep = n / sweeps
+            tot_f += 2.0 * fb * per_sweep
+            tot_w += wb * per_sweep
+            kern[re.sub(r"\(.*$", "", name)] = dict(dispatches_per_sweep=round(per_sweep, 3), fetch_bytes=int(2 * fb), write_bytes=int(wb))
+    return tot_f, tot_w, kern
+
+
+def main():
+    fetch, write, prefix = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
+    cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "c2"
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r02_traffic.json"
+    src = f"{sys.argv[1]} + {sys.argv[2]} (FETCH_SIZE x2 per the gfx950 rule, + WRITE_SIZE; mean per dispatch x dispatches per sweep)"
+    try:
+        out = json.load(open(out_path))
+    except Exception:
+        out = {}
+    if cfg == "c2":
+        n_sh = next(n for k, (n, _) in fetch.items() if k.startswith("k_sweep_logpdf_cm_shared<"))
+        n_ge = next(n for k, (n, _) in fetch.items() if re.match(r"k_sweep_logpdf_cm<", k))
+        for mode, table, sweeps in (("shared", SHARED, n_sh), ("general", GENERAL, n_ge)):
+            for g, pats in list(table.items()) + list(BOTH.items()):
+                f, w, kern = group_bytes(fetch, write, pats, sweeps if g not in BOTH else n_sh + n_ge)
+                if kern:
+                    out[f"{prefix}_{mode}_{g}"] = dict(hbm_bytes=int(f + w), fetch_bytes=int(f), write_bytes=int(w), kernels=kern, source=src)
+    else:
+        sweeps = next(n for k, (n, _) in fetch.items() if k.startswith("k_csmc_bwd<"))
+        tf = tw = 0.0
+        for g, pats in CSMC.items():
+            f, w, kern = group_bytes(fetch, write, pats, sweeps)
+            if kern:
+                out[f"{prefix}_{g}"] = dict(hbm_bytes=int(f + w), fetch_bytes=int(f), write_bytes=int(w), kernels=kern, source=src)
+                tf, tw = tf + f, tw + w
+        out[f"{prefix}_sweep"] = dict(hbm_bytes=int(tf + tw), fetch_bytes=int(tf), write_bytes=int(tw), source=src)
+    json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+    for k in sorted(out):
+        if k.startswith(prefix):
+            print(f"{k:70s} {out[k]['hbm_bytes'] / 1e9:9.3f} GB  (fetch {out[k]['fetch_bytes'] / 1e9:.3f}, write {out[k]['write_bytes'] / 1e9:.3f})")
+
+
+if __name__ == "__main__":
+    main()
