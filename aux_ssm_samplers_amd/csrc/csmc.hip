@@ -140,7 +140,8 @@ template <typename R, int D> __device__ __forceinline__ R grad_correction(const 
 }
 
 // ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
-template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
+// NW = 16: exactly 16 full waves (N = blockDim = 1024, the C3 shape): no liveness / group-bound selects (csmc_dev.h); NW = 0: any N
+template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     // two images of (c, xprev), alternated by time-step parity: readers of step t never race writers of step t+1,
@@ -149,7 +150,7 @@ template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds
     R* xbuf = cbuf + 2 * TB;            // [2][TB][D]
     R* red = xbuf + 2 * TB * D;         // [48]
     const int ch = blockIdx.x;
-    const bool live = tid < N;
+    const bool live = NW == 16 ? true : tid < N;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
     const R* gaux = GRAD ? (const R*)a.grad + (long long)ch * T * D : uaux;
@@ -217,7 +218,7 @@ template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds
         for (int k = 0; k < D; ++k) xs[(long long)tid * D + k] = x[k];
         lws[tid] = lw;
     }
-    R w = block_expmax<R>(lw, red, tid, nw);
+    R w = block_expmax<R, NW>(lw, red, tid, nw);
 
     for (int t = 1; t < T; ++t) {
         // issue this step's independent loads first
@@ -248,10 +249,10 @@ template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds
 #pragma unroll
         for (int k = 0; k < D; ++k) xprev[tid * D + k] = x[k];
         R Pg[16];
-        block_cumsum_dpp<R>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
+        block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
         const R tot = c[N - 1];
         int idx = 0;
-        if (live && tid > 0) idx = search2<R>(c, Pg, N, nw, tot * ((R)1 - un));
+        if (live && tid > 0) idx = search2<R, NW>(c, Pg, N, nw, tot * ((R)1 - un));
         R xp[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
@@ -301,7 +302,7 @@ template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds
             lws[o] = lw;
             if (As) As[(long long)(t - 1) * N + tid] = idx;
         }
-        w = block_expmax<R>(lw, red, tid, nw);
+        w = block_expmax<R, NW>(lw, red, tid, nw);
     }
     if (live) ((R*)a.wT)[(long long)ch * N + tid] = w;
 }
@@ -310,17 +311,17 @@ template <typename R, int D, bool TV, bool GRAD> __global__ void __launch_bounds
 // One draw per step: B = #{j : c_j < r} by ballot + per-wave counts (no serial search), the candidate particles of the step are
 // published to LDS before the first barrier so that x_t^B is an LDS read, and the next step's rows (xs, log_ws) and uniform are
 // fetched one step ahead: no global-memory latency on the dependent chain.  4 barriers per step (max, wave totals, publish, counts).
-template <typename R> __device__ __forceinline__ int block_count_below(const R* c, R r, bool live, int tid, int nw, int* cnt, int N) {
+template <typename R, int NW = 0> __device__ __forceinline__ int block_count_below(const R* c, R r, bool live, int tid, int nw, int* cnt, int N) {
     const int lane = tid & 63, wv = tid >> 6;
     const unsigned long long bal = __ballot(live && c[tid] < r);
     if (lane == 0) cnt[wv] = __popcll(bal);
     __syncthreads();
     int B = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) B += k < nw ? cnt[k] : 0;
+    for (int k = 0; k < 16; ++k) B += (NW == 16 || k < nw) ? cnt[k] : 0;
     return B < N - 1 ? B : N - 1;
 }
-template <typename R, int D, bool TV> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
+template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     R* c = (R*)smem;                 // [TB]
@@ -329,7 +330,7 @@ template <typename R, int D, bool TV> __global__ void __launch_bounds__(1024) k_
     R* ubuf = xpub + 2 * TB * D;     // [2] the step's uniform, by step parity
     int* cnt = (int*)(ubuf + 2);     // [2][16] per-wave counts, by step parity
     const int ch = blockIdx.x;
-    const bool live = tid < N;
+    const bool live = NW == 16 ? true : tid < N;
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
     const R* lws = (const R*)a.lws + (long long)ch * T * N;
     const int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
@@ -349,8 +350,8 @@ template <typename R, int D, bool TV> __global__ void __launch_bounds__(1024) k_
         for (int k = 0; k < D; ++k) xpub[(TB + tid) * D + k] = xi[k];
     }
     R Pg[16];
-    block_cumsum_dpp<R>(w, c, red, tid, nw, Pg);
-    int B = block_count_below<R>(c, c[N - 1] * ((R)1 - ubuf[1]), live, tid, nw, cnt + 16, N);
+    block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);
+    int B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[1]), live, tid, nw, cnt + 16, N);
     R xn[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) xn[k] = xpub[(TB + B) * D + k];
@@ -402,9 +403,9 @@ template <typename R, int D, bool TV> __global__ void __launch_bounds__(1024) k_
 #pragma unroll
         for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
         if (tid == 0) ubuf[par] = un_t;
-        w = block_expmax<R>(lw, red, tid, nw);              // barrier (more than one wave)
-        block_cumsum_dpp<R>(w, c, red, tid, nw, Pg);        // two barriers: xpub / ubuf of this parity are published as well
-        B = block_count_below<R>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
+        w = block_expmax<R, NW>(lw, red, tid, nw);              // barrier (more than one wave)
+        block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);        // two barriers: xpub / ubuf of this parity are published as well
+        B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
 #pragma unroll
         for (int k = 0; k < D; ++k) xn[k] = xpub[(par * TB + B) * D + k];
         if (tid == 0) {
@@ -518,27 +519,41 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
         const size_t lds = (size_t)2 * TB * (1 + D) * sizeof(R) + 48 * sizeof(R) + 64;
         const bool tv = m.Ft != nullptr, gr = m.gradient != 0;
-#define AX_FWD(TVv, GRv)                                                                                                                                   \
-    do {                                                                                                                                                   \
-        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D, TVv, GRv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_csmc_fwd<R, D, TVv, GRv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
+        const bool full16 = TB == 1024 && a.N == 1024;
+#define AX_FWD1(TVv, GRv, NWv)                                                                                                                                  \
+    do {                                                                                                                                                        \
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D, TVv, GRv, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_csmc_fwd<R, D, TVv, GRv, NWv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
+    } while (0)
+#define AX_FWD(TVv, GRv)                \
+    do {                                \
+        if (full16) AX_FWD1(TVv, GRv, 16); \
+        else AX_FWD1(TVv, GRv, 0);      \
     } while (0)
         if (tv && gr) AX_FWD(true, true);
         else if (tv) AX_FWD(true, false);
         else if (gr) AX_FWD(false, true);
         else AX_FWD(false, false);
 #undef AX_FWD
+#undef AX_FWD1
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_BWD);
         const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + (size_t)2 * TB * D * sizeof(R) + 2 * sizeof(R) + 32 * sizeof(int) + 64;
+        const bool full16 = TB == 1024 && a.N == 1024;
+#define AX_BWD(TVv, NWv)                                                                                                                                 \
+    do {                                                                                                                                                 \
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, TVv, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((k_csmc_bwd<R, D, TVv, NWv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
+    } while (0)
         if (m.Ft) {
-            if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_csmc_bwd<R, D, true>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+            if (full16) AX_BWD(true, 16);
+            else AX_BWD(true, 0);
         } else {
-            if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL((k_csmc_bwd<R, D, false>), dim3(a.C), dim3(TB), lds, h->stream, a, m);
+            if (full16) AX_BWD(false, 16);
+            else AX_BWD(false, 0);
         }
+#undef AX_BWD
     }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;

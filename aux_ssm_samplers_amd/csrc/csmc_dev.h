@@ -260,8 +260,9 @@ template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int
 //            every row of 16 lanes, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2 and 3 += last of row 1 --
 //            group totals added left to right: c_i = (t_0 + ... + t_{g-1}) + local_i.
 //   search : two levels.  g = #{k < ng - 1 : C_k < r} with C_k = c[64 k + 63] the cumulative total at the end of group k (ng groups),
-//            then lower_bound of r inside group g: first j in [64 g, min(64 g + 64, N)) with c[j] >= r (its end if none); clipped to N - 1.
-//            On a non-decreasing c this IS searchsorted(c, r, side='left').
+//            then the number of entries of group g below r by descent: pos = 64 g; for s = 32, 16, 8, 4, 2, 1: if (pos + s - 1 < end and
+//            c[pos + s - 1] < r) pos += s, end = min(64 g + 64, N); clipped to N - 1.  On a non-decreasing c this IS
+//            searchsorted(c, r, side='left') (the group's last entry is >= r by the choice of g).
 //   single draw (backward pass): B = #{j < N : c_j < r}, clipped to N - 1 (again searchsorted on a non-decreasing c), counted by ballot.
 //   max    : exact, any order.
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float old, float v) {
@@ -294,11 +295,17 @@ template <typename R> __device__ __forceinline__ R wave_max_dpp(R v) {
     o = dpp_mov<DPP_ROW_BCAST31, 0xc>(v, v); v = v > o ? v : o;
     return __shfl(v, 63, 64);  // lane 63 holds the maximum of the wave
 }
-// e_i = exp(lw_i - max lw) (non-finite max -> 0, as jax's logsumexp); red slots [0, 16)
-template <typename R> __device__ __forceinline__ R block_expmax(R lw, R* red, int tid, int nw) {
+// e_i = exp(lw_i - max lw) (non-finite max -> 0, as jax's logsumexp); red slots [0, 16).
+// NW = 16: the workgroup is exactly 16 full waves (N = 1024 particles) -- no per-group bounds selects, the 16 wave maxima are reduced by
+// one more DPP pass instead of fifteen compare / select pairs per lane.
+template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw, R* red, int tid, int nw) {
     const int lane = tid & 63, wv = tid >> 6;
     R m = wave_max_dpp(lw);
-    if (nw > 1) {
+    if constexpr (NW == 16) {
+        if (lane == 0) red[wv] = m;
+        __syncthreads();
+        m = wave_max_dpp(red[lane & 15]);
+    } else if (nw > 1) {
         if (lane == 0) red[wv] = m;
         __syncthreads();
         R t[16];
@@ -312,7 +319,7 @@ template <typename R> __device__ __forceinline__ R block_expmax(R lw, R* red, in
 }
 // inclusive cumsum of w into c[] in the sweep contract's order; P[k] = cumulative total at the end of group k (k < nw), the same
 // numbers as c[64 k + 63]; c[] valid after the trailing barrier.  red slots [32, 48).
-template <typename R> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
+template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
     const int lane = tid & 63, wv = tid >> 6;
     const R v = wave_scan_dpp(w);
     if (lane == 63) red[32 + wv] = v;
@@ -320,29 +327,45 @@ template <typename R> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c
     R t[16];
     load16<R>(red + 32, t);
     P[0] = t[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) P[k] = k < nw ? P[k - 1] + t[k] : P[k - 1];
     R pre = 0;
+    if constexpr (NW == 16) {
 #pragma unroll
-    for (int k = 0; k < 15; ++k) pre = (k + 1 == wv) ? P[k] : pre;
+        for (int k = 1; k < 16; ++k) P[k] = P[k - 1] + t[k];
+        switch (wv) {  // wave-uniform: one scalar branch instead of fifteen compare / select triples
+#define AX_PRE_CASE(K) case K + 1: pre = P[K]; break;
+            AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
+            AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
+#undef AX_PRE_CASE
+            default: break;
+        }
+    } else {
+#pragma unroll
+        for (int k = 1; k < 16; ++k) P[k] = k < nw ? P[k - 1] + t[k] : P[k - 1];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) pre = (k + 1 == wv) ? P[k] : pre;
+    }
     c[tid] = wv > 0 ? pre + v : v;
     __syncthreads();
 }
 // the two-level search of the sweep contract; P from block_cumsum_dpp, ng = number of groups of 64 covering [0, N)
-template <typename R> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
+template <typename R, int NW = 0> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
     int g = 0;
+    if constexpr (NW == 16) {
 #pragma unroll
-    for (int k = 0; k < 15; ++k) g += (k < ng - 1 && P[k] < r) ? 1 : 0;
-    int lo = g << 6, hi = min(lo + 64, N);
+        for (int k = 0; k < 15; ++k) g += P[k] < r ? 1 : 0;
+        int pos = g << 6;
 #pragma unroll
-    for (int it = 0; it < 7; ++it) {  // lower_bound over at most 64 entries: at most 7 probes
-        if (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (c[mid] < r) lo = mid + 1;
-            else hi = mid;
-        }
+        for (int s = 32; s > 0; s >>= 1) pos += c[pos + s - 1] < r ? s : 0;
+        return pos < N - 1 ? pos : N - 1;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 15; ++k) g += (k < ng - 1 && P[k] < r) ? 1 : 0;
+        int pos = g << 6;
+        const int end = min(pos + 64, N);
+#pragma unroll
+        for (int s = 32; s > 0; s >>= 1) pos += (pos + s - 1 < end && c[min(pos + s - 1, N - 1)] < r) ? s : 0;
+        return pos < N - 1 ? pos : N - 1;
     }
-    return lo < N - 1 ? lo : N - 1;
 }
 
 template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model* fk, const double* host) {

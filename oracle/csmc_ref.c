@@ -348,9 +348,11 @@ static int SUF(choice2)(const REAL* c, int N, REAL un) {
     const int ng = (N + 63) / 64;
     int g = 0;
     for (int k = 0; k < ng - 1; ++k) g += c[64 * k + 63] < r;
-    int lo = 64 * g, hi = lo + 64 < N ? lo + 64 : N;
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (c[mid] < r) lo = mid + 1; else hi = mid; }
-    return lo < N - 1 ? lo : N - 1;
+    const int end = 64 * g + 64 < N ? 64 * g + 64 : N;
+    int pos = 64 * g; /* number of entries of the group below r, by descent: six probes, no data-dependent branch on the device */
+    for (int s = 32; s > 0; s >>= 1)
+        if (pos + s - 1 < end && c[pos + s - 1] < r) pos += s;
+    return pos < N - 1 ? pos : N - 1;
 }
 /* the single draw of the backward pass: count of the cumulative weights below r */
 static int SUF(choice_count)(const REAL* c, int N, REAL un) {
