@@ -404,8 +404,19 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
         if (tid == 0) ubuf[par] = un_t;
         w = block_expmax<R, NW>(lw, red, tid, nw);              // barrier (more than one wave)
-        block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);        // two barriers: xpub / ubuf of this parity are published as well
-        B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
+        if constexpr (NW == 16) {  // cumulative weight in a register: one barrier (it publishes xpub / ubuf of this parity as well), no c[] image
+            const R cv = block_cumsum_reg16<R>(w, red, tid, Pg);
+            const unsigned long long bal = __ballot(cv < Pg[15] * ((R)1 - ubuf[par]));
+            if ((tid & 63) == 0) cnt[par * 16 + (tid >> 6)] = __popcll(bal);
+            __syncthreads();
+            B = 0;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) B += cnt[par * 16 + k];
+            B = B < N - 1 ? B : N - 1;
+        } else {
+            block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);    // two barriers: xpub / ubuf of this parity are published as well
+            B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
+        }
 #pragma unroll
         for (int k = 0; k < D; ++k) xn[k] = xpub[(par * TB + B) * D + k];
         if (tid == 0) {

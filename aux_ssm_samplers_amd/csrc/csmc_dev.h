@@ -331,7 +331,7 @@ template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_d
     if constexpr (NW == 16) {
 #pragma unroll
         for (int k = 1; k < 16; ++k) P[k] = P[k - 1] + t[k];
-        switch (wv) {  // wave-uniform: one scalar branch instead of fifteen compare / select triples
+        switch (__builtin_amdgcn_readfirstlane(wv)) {  // wave-uniform (told to the compiler): one scalar branch instead of fifteen compare / select triples
 #define AX_PRE_CASE(K) case K + 1: pre = P[K]; break;
             AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
             AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
@@ -346,6 +346,28 @@ template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_d
     }
     c[tid] = wv > 0 ? pre + v : v;
     __syncthreads();
+}
+// 16 full waves, the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two
+// and no c[] image -- for the backward pass, whose single draw only counts {c_j < r}.  P[15] = c[N - 1] bit for bit (full groups).
+template <typename R> __device__ __forceinline__ R block_cumsum_reg16(R w, R* red, int tid, R* P) {
+    const int lane = tid & 63, wv = tid >> 6;
+    const R v = wave_scan_dpp(w);
+    if (lane == 63) red[32 + wv] = v;
+    __syncthreads();
+    R t[16];
+    load16<R>(red + 32, t);
+    P[0] = t[0];
+#pragma unroll
+    for (int k = 1; k < 16; ++k) P[k] = P[k - 1] + t[k];
+    R pre = 0;
+    switch (__builtin_amdgcn_readfirstlane(wv)) {
+#define AX_PRE_CASE(K) case K + 1: pre = P[K]; break;
+        AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
+        AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
+#undef AX_PRE_CASE
+        default: break;
+    }
+    return wv > 0 ? pre + v : v;
 }
 // the two-level search of the sweep contract; P from block_cumsum_dpp, ng = number of groups of 64 covering [0, N)
 template <typename R, int NW = 0> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {

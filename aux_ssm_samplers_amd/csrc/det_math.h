@@ -28,11 +28,12 @@ AXD_HD uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
 
 // ---- exp, fp32: x = k ln2 + r, |r| <= ln2/2, degree-7 Taylor in Horner form with fma ----------------
 AXD_HD float det_exp(float x) {
-    if (!(x == x)) return x;                 // NaN
-    if (x > 88.72f) return INFINITY;
-    if (x < -87.3f) return 0.0f;             // results below the normal range are flushed to +0 (documented)
-    const float kf = rintf(x * 1.44269504088896341f);
-    float r = fmaf(-kf, 6.93145751953125e-1f, x);      // ln2 hi (few mantissa bits -> kf*hi exact)
+    // no early returns: the special cases are selected at the end, so that the GPU runs one straight instruction stream (three nested
+    // exec-mask branches per call otherwise); inside the range the operation sequence and its bits are unchanged
+    const bool isnan = !(x == x), big = x > 88.72f, small = x < -87.3f;  // results below the normal range are flushed to +0 (documented)
+    const float xs = (isnan || big || small) ? 0.0f : x;
+    const float kf = rintf(xs * 1.44269504088896341f);
+    float r = fmaf(-kf, 6.93145751953125e-1f, xs);     // ln2 hi (few mantissa bits -> kf*hi exact)
     r = fmaf(-kf, 1.42860682030941723212e-6f, r);      // ln2 lo
     float p = 1.9841270114e-4f;                         // 1/5040
     p = fmaf(p, r, 1.3888889225e-3f);                   // 1/720
@@ -45,7 +46,10 @@ AXD_HD float det_exp(float x) {
     const int k = (int)kf;                              // in [-126, 128]
     // scale by 2^k in two exact steps (k may be 128)
     const int k1 = k / 2, k2 = k - k1;
-    return p * u2f((uint32_t)(k1 + 127) << 23) * u2f((uint32_t)(k2 + 127) << 23);
+    float res = p * u2f((uint32_t)(k1 + 127) << 23) * u2f((uint32_t)(k2 + 127) << 23);
+    res = small ? 0.0f : res;
+    res = big ? INFINITY : res;
+    return isnan ? x : res;
 }
 
 // ---- log, fp32 (fdlibm e_logf): x = 2^e * m, m in [sqrt(1/2), sqrt(2)); f = m - 1; s = f/(2+f) ------------------
