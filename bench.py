@@ -355,8 +355,9 @@ def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
     if "csmc_fwd" in groups:
         g = max(("csmc_fwd", "csmc_bwd"), key=lambda q_: kern.get(q_, {}).get("ms_per_step", 0))
         ach = kern[g]["algorithmic_GBps"]
-        out["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=None,
-                               kernel=f"k_{g} (persistent, one workgroup per chain)", avg_launch_ms=kern[g]["ms_per_step"],
+        traffic, src = pmc_traffic(f"csmc_C3_{'f32' if dtype == np.float32 else 'f64'}_T{T}_N{N}_chains{Cn}_{g}")
+        out["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
+                               traffic_source=src, kernel=f"k_{g} (persistent, one workgroup per chain)", avg_launch_ms=kern[g]["ms_per_step"],
                                algorithmic_bytes_per_launch=alg[g])
     if cpu:
         from oracle import csmc as O
@@ -456,8 +457,15 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
         if scan:
             tf = flops / (scan * 1e-3) / 1e12
             ent["roofline"] = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
-                                   traffic=None, kernel="wide filter scan (wk_scan_reduce + aggregate levels + wk_scan_down)", avg_launch_ms=round(scan, 3),
+                                   traffic=None, kernel="wide filter scan (wk_fold_reduce + tree of wk_scan_reduce / wk_scan_aggs / wk_scan_down_pre + wk_fold_down)", avg_launch_ms=round(scan, 3),
                                    algorithmic_flops_per_launch=flops)
+            try:  # matrix-core busy fraction of the two level-0 kernels from the committed PMC pass (profiles/r02_traffic.json)
+                mb = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(f"wide_C5_f32_d{d}_T{T}")
+                if mb:
+                    ent["roofline"]["mfma_busy_pmc"] = mb["mfma_busy"]
+                    ent["roofline"]["mfma_busy_source"] = mb["source"]
+            except Exception:
+                pass
         out["runs"].append(ent)
         del dl, yd, ms, Ps, ell
     return out

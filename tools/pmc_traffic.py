@@ -59,7 +59,33 @@ def group_bytes(fetch, write, pats, sweeps):
     return tot_f, tot_w, kern
 
 
+def mfma_busy(path, key, out_path):
+    """MFMA busy fraction per wide kernel: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES), summed over the dispatches of the pass"""
+    rows = list(csv.DictReader(open(path)))
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in rows:
+        acc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+    names = [n for n in acc if "wide" in n]
+    dem = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    try:
+        out = json.load(open(out_path))
+    except Exception:
+        out = {}
+    ent = {}
+    for n, d in zip(names, dem):
+        d = re.sub(r"\(.*$", "", re.sub(r"^void ax::", "", d))
+        cu = acc[n].get("SQ_BUSY_CU_CYCLES", 0.0)
+        if cu > 0:
+            ent[d] = round(acc[n].get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (4.0 * cu), 4)
+    out[key] = dict(mfma_busy=ent, source=f"{path}: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), all dispatches of the pass")
+    json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
+    print(key, ent)
+
+
 def main():
+    if "--mfma" in sys.argv:  # python tools/pmc_traffic.py --mfma <counter_collection.csv> <key> [--out ...]
+        i = sys.argv.index("--mfma")
+        return mfma_busy(sys.argv[i + 1], sys.argv[i + 2], sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r02_traffic.json")
     fetch, write, prefix = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "c2"
     out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r02_traffic.json"
