@@ -150,3 +150,15 @@ def lorenz_logpdf(lg, yobs, x, xp, u, par, delta, nan_policy=0, chain_minor=Fals
                                 int(bool(chain_minor)), ptr(out))
     assert rc == 0, rc
     return out
+
+
+def fold_check(F, Q, bd, Lam, g0, q0, ldR, dim, acc):
+    """max |prefix (+) element(step) - fold(prefix, step)| over all fields (kalman_math.h::filter_fold_step / filter_apply_step vs
+    filter_elem_from_lam + filter_combine); Lam packed upper-symmetric, acc = [A | b | C packed | eta | J packed | z]"""
+    d = len(bd)
+    f = lib().hs_fold_check
+    f.restype = C.c_double
+    a = [np.ascontiguousarray(v, np.float64) for v in (F, Q, bd, Lam, g0, acc)]
+    P = C.POINTER(C.c_double)
+    return f(C.c_int(d), a[0].ctypes.data_as(P), a[1].ctypes.data_as(P), a[2].ctypes.data_as(P), a[3].ctypes.data_as(P), a[4].ctypes.data_as(P),
+             C.c_double(q0), C.c_double(ldR), C.c_double(dim), a[5].ctypes.data_as(P))

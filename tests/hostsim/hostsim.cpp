@@ -4,6 +4,7 @@
 // so that the math and the indexing of the HIP path can be checked against the oracle in the build container,
 // which has no GPU.  It is never loaded by the product package: the product fails loudly without libauxssm.so.
 #include <algorithm>
+#include <cmath>
 #include <cstdint>
 #include <cstring>
 #include <vector>
@@ -271,7 +272,63 @@ static int lorenz_logpdf_T(int C, int T, const HsArr* g, const void* yobs, const
         default: return -2;                                               \
     }
 
+
+// fold-vs-combine identity of the general path (kalman_math.h): prefix (+) element(step) built from the step's observation information and
+// combined with filter_combine, against filter_fold_step / filter_apply_step on the same inputs.  Returns the largest absolute difference.
+template <int D> static double fold_check_T(const double* F, const double* Q, const double* bd, const double* Lam, const double* g0, double q0, double ldR,
+                                            double dim, const double* acc_in) {
+    constexpr int DS = symsize(D);
+    FiltElem<double, D> acc, e2, o, f;
+    const double* p = acc_in;
+    for (int i = 0; i < D * D; ++i) acc.A[i] = *p++;
+    for (int i = 0; i < D; ++i) acc.b[i] = *p++;
+    for (int i = 0; i < DS; ++i) acc.C[i] = *p++;
+    for (int i = 0; i < D; ++i) acc.eta[i] = *p++;
+    for (int i = 0; i < DS; ++i) acc.J[i] = *p++;
+    acc.z = *p++;
+    // the step's own element: built around (m_, P_) = (b_dyn, Q)  (_filtering_init_one for t >= 1)
+    double gm[D], q = q0;
+    for (int i = 0; i < D; ++i) {
+        double lm = 0;
+        for (int k = 0; k < D; ++k) lm += Lam[sidx(D, i, k)] * bd[k];
+        gm[i] = g0[i] - lm;
+        q += bd[i] * (lm - 2 * g0[i]);
+    }
+    filter_elem_from_lam<double, D>(F, bd, Q, Lam, gm, gm, q, ldR, dim, true, e2);
+    filter_combine<double, D>(acc, e2, o);
+    StepInfo<double, D> si;
+    for (int i = 0; i < DS; ++i) si.Lam[i] = Lam[i];
+    for (int i = 0; i < D; ++i) si.g0[i] = g0[i];
+    si.q0 = q0, si.ldR = ldR, si.dim = dim, si.ok = true;
+    f = acc;
+    filter_fold_step<double, D>(F, Q, bd, si, f);
+    FiltPre<double, D> pre;
+    for (int i = 0; i < D; ++i) pre.b[i] = acc.b[i];
+    for (int i = 0; i < DS; ++i) pre.C[i] = acc.C[i];
+    pre.z = acc.z;
+    filter_apply_step<double, D>(F, Q, bd, si, pre);
+    double m = 0;
+    auto upd = [&](double a, double b) { m = std::max(m, std::abs(a - b)); };
+    for (int i = 0; i < D * D; ++i) upd(o.A[i], f.A[i]);
+    for (int i = 0; i < D; ++i) upd(o.b[i], f.b[i]), upd(o.eta[i], f.eta[i]), upd(o.b[i], pre.b[i]);
+    for (int i = 0; i < DS; ++i) upd(o.C[i], f.C[i]), upd(o.J[i], f.J[i]), upd(o.C[i], pre.C[i]);
+    upd(o.z, f.z);
+    upd(o.z, pre.z);
+    return m;
+}
+
 extern "C" {
+
+double hs_fold_check(int D, const double* F, const double* Q, const double* bd, const double* Lam, const double* g0, double q0, double ldR, double dim,
+                     const double* acc) {
+    switch (D) {
+        case 1: return fold_check_T<1>(F, Q, bd, Lam, g0, q0, ldR, dim, acc);
+        case 2: return fold_check_T<2>(F, Q, bd, Lam, g0, q0, ldR, dim, acc);
+        case 3: return fold_check_T<3>(F, Q, bd, Lam, g0, q0, ldR, dim, acc);
+        case 4: return fold_check_T<4>(F, Q, bd, Lam, g0, q0, ldR, dim, acc);
+    }
+    return -1;
+}
 
 int hs_filter(int dtype, int D, int P, int C, int T, int B, const HsArr* g, const HsArr* ys, int E, void* ms, void* Ps, void* ell, int pblk) {
 #define CALL(R, D, P) filter_T<R, D, P>(C, T, B, g, ys, E, ms, Ps, ell, pblk)

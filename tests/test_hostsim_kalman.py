@@ -7,6 +7,7 @@ import pytest
 
 from oracle import kalman_np as K
 from tests import hostsim as H
+from tests import hostsim as Hs
 from tests.helpers import ref_lgssm_inputs, ref_batched_inputs, lg_model
 
 TOL64 = dict(rtol=1e-8, atol=1e-10)
@@ -200,3 +201,22 @@ def test_lorenz_fused_logpdf_body(chain_minor, per_chain_theta):
     lg = (base.m0, base.P0, np.broadcast_to(np.eye(3), (n, 3, 3)), base.Qs, np.zeros((n, 3)), base.Hobs, base.Robs, base.cobs)
     got = HS.lorenz_logpdf(lg, base.yobs, x, xp, u, par if per_chain_theta else par[0], delta, 0, chain_minor)
     npt.assert_allclose(got, ref, rtol=1e-9, atol=1e-9)
+
+
+
+@pytest.mark.parametrize("d", [1, 2, 3, 4])
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_fold_step_is_prefix_combined_with_the_steps_element(d, seed):
+    """The general path never builds a step's scan element: it folds the raw step onto the prefix (kalman_math.h::filter_fold_step, 9 d^3 + one
+    (d+1)-column LU).  That must be the reference operator applied to (prefix, element(step)) (filtering.py:163-183 on the element of :196-250)."""
+    rng = np.random.default_rng(100 * d + seed)
+    spd = lambda n, s=1.0: (lambda a: a @ a.T / (2 * n) + s * np.eye(n))(rng.standard_normal((n, 2 * n)))
+    pack = lambda m: np.array([m[i, j] for i in range(d) for j in range(i, d)])
+    p = d + 2
+    Hm, R, y = rng.standard_normal((p, d)), spd(p, 0.3), rng.standard_normal(p)
+    Ri = np.linalg.inv(R)
+    Lam, g0, q0 = Hm.T @ Ri @ Hm, Hm.T @ Ri @ y, float(y @ Ri @ y)
+    ldR = 0.5 * np.linalg.slogdet(R)[1]
+    F, Q, bd = 0.7 * rng.standard_normal((d, d)), spd(d, 0.2), rng.standard_normal(d)
+    acc = np.concatenate([rng.standard_normal(d * d), rng.standard_normal(d), pack(spd(d, 0.1)), rng.standard_normal(d), pack(spd(d, 0.05)), [rng.standard_normal()]])
+    assert Hs.fold_check(F, Q, bd, pack(Lam), g0, q0, ldR, float(p), acc) < 1e-10
