@@ -39,7 +39,8 @@ struct Bump {
     }
 };
 
-// ---- cooperative primitives (all lanes of the workgroup call them; every one ENDS with a barrier) -------------------------
+// ---- cooperative primitives (all lanes of the workgroup call them; every one that WRITES LDS ends with a barrier unless called with
+// sync = false; store_mat only reads LDS: its callers put a barrier before the source is overwritten) ---------------------------------
 
 // dst (rows x cols, ld) <- contiguous row-major record
 template <typename R> __device__ __forceinline__ void load_mat(R* dst, int ld, const R* __restrict__ src, int rows, int cols, int tid) {
