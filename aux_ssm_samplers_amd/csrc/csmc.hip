@@ -140,7 +140,7 @@ template <typename R, int D> __device__ __forceinline__ R grad_correction(const 
 }
 
 // ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
-// NW = 16: exactly 16 full waves (N = blockDim = 1024, the C3 shape): no liveness / group-bound selects (csmc_dev.h); NW = 0: any N
+// NW = 8 / 16: exactly NW full waves (N = blockDim = 64 NW: the C4 / C3 shapes): no liveness / group-bound selects (csmc_dev.h); NW = 0: any N
 template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
@@ -150,7 +150,7 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     R* xbuf = cbuf + 2 * TB;            // [2][TB][D]
     R* red = xbuf + 2 * TB * D;         // [48]
     const int ch = blockIdx.x;
-    const bool live = NW == 16 ? true : tid < N;
+    const bool live = NW > 0 ? true : tid < N;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
     const R* gaux = GRAD ? (const R*)a.grad + (long long)ch * T * D : uaux;
@@ -318,7 +318,7 @@ template <typename R, int NW = 0> __device__ __forceinline__ int block_count_bel
     __syncthreads();
     int B = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) B += (NW == 16 || k < nw) ? cnt[k] : 0;
+    for (int k = 0; k < 16; ++k) B += (NW > 0 ? k < NW : k < nw) ? cnt[k] : 0;
     return B < N - 1 ? B : N - 1;
 }
 template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
@@ -330,7 +330,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
     R* ubuf = xpub + 2 * TB * D;     // [2] the step's uniform, by step parity
     int* cnt = (int*)(ubuf + 2);     // [2][16] per-wave counts, by step parity
     const int ch = blockIdx.x;
-    const bool live = NW == 16 ? true : tid < N;
+    const bool live = NW > 0 ? true : tid < N;
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
     const R* lws = (const R*)a.lws + (long long)ch * T * N;
     const int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
@@ -404,14 +404,14 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
         if (tid == 0) ubuf[par] = un_t;
         w = block_expmax<R, NW>(lw, red, tid, nw);              // barrier (more than one wave)
-        if constexpr (NW == 16) {  // cumulative weight in a register: one barrier (it publishes xpub / ubuf of this parity as well), no c[] image
-            const R cv = block_cumsum_reg16<R>(w, red, tid, Pg);
-            const unsigned long long bal = __ballot(cv < Pg[15] * ((R)1 - ubuf[par]));
+        if constexpr (NW > 0) {  // cumulative weight in a register: one barrier (it publishes xpub / ubuf of this parity as well), no c[] image
+            const R cv = block_cumsum_reg<R, NW>(w, red, tid, Pg);
+            const unsigned long long bal = __ballot(cv < Pg[NW - 1] * ((R)1 - ubuf[par]));
             if ((tid & 63) == 0) cnt[par * 16 + (tid >> 6)] = __popcll(bal);
             __syncthreads();
             B = 0;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) B += cnt[par * 16 + k];
+            for (int k = 0; k < NW; ++k) B += cnt[par * 16 + k];
             B = B < N - 1 ? B : N - 1;
         } else {
             block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);    // two barriers: xpub / ubuf of this parity are published as well
@@ -530,7 +530,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
         const size_t lds = (size_t)2 * TB * (1 + D) * sizeof(R) + 48 * sizeof(R) + 64;
         const bool tv = m.Ft != nullptr, gr = m.gradient != 0;
-        const bool full16 = TB == 1024 && a.N == 1024;
+        const int fullw = (TB == a.N && (a.N == 1024 || a.N == 512)) ? a.N / 64 : 0;
 #define AX_FWD1(TVv, GRv, NWv)                                                                                                                                  \
     do {                                                                                                                                                        \
         if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D, TVv, GRv, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
@@ -538,7 +538,8 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     } while (0)
 #define AX_FWD(TVv, GRv)                \
     do {                                \
-        if (full16) AX_FWD1(TVv, GRv, 16); \
+        if (fullw == 16) AX_FWD1(TVv, GRv, 16); \
+        else if (fullw == 8) AX_FWD1(TVv, GRv, 8); \
         else AX_FWD1(TVv, GRv, 0);      \
     } while (0)
         if (tv && gr) AX_FWD(true, true);
@@ -551,17 +552,19 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     {
         ProfScope ps(h, AUXSSM_K_CSMC_BWD);
         const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + (size_t)2 * TB * D * sizeof(R) + 2 * sizeof(R) + 32 * sizeof(int) + 64;
-        const bool full16 = TB == 1024 && a.N == 1024;
+        const int fullw = (TB == a.N && (a.N == 1024 || a.N == 512)) ? a.N / 64 : 0;
 #define AX_BWD(TVv, NWv)                                                                                                                                 \
     do {                                                                                                                                                 \
         if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, TVv, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
         hipLaunchKernelGGL((k_csmc_bwd<R, D, TVv, NWv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
     } while (0)
         if (m.Ft) {
-            if (full16) AX_BWD(true, 16);
+            if (fullw == 16) AX_BWD(true, 16);
+            else if (fullw == 8) AX_BWD(true, 8);
             else AX_BWD(true, 0);
         } else {
-            if (full16) AX_BWD(false, 16);
+            if (fullw == 16) AX_BWD(false, 16);
+            else if (fullw == 8) AX_BWD(false, 8);
             else AX_BWD(false, 0);
         }
 #undef AX_BWD

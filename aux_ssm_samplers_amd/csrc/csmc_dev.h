@@ -296,15 +296,15 @@ template <typename R> __device__ __forceinline__ R wave_max_dpp(R v) {
     return __shfl(v, 63, 64);  // lane 63 holds the maximum of the wave
 }
 // e_i = exp(lw_i - max lw) (non-finite max -> 0, as jax's logsumexp); red slots [0, 16).
-// NW = 16: the workgroup is exactly 16 full waves (N = 1024 particles) -- no per-group bounds selects, the 16 wave maxima are reduced by
+// NW = 8 / 16: the workgroup is exactly NW full waves (N = 64 NW particles) -- no per-group bounds selects, the NW wave maxima are reduced by
 // one more DPP pass instead of fifteen compare / select pairs per lane.
 template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw, R* red, int tid, int nw) {
     const int lane = tid & 63, wv = tid >> 6;
     R m = wave_max_dpp(lw);
-    if constexpr (NW == 16) {
+    if constexpr (NW > 0) {
         if (lane == 0) red[wv] = m;
         __syncthreads();
-        m = wave_max_dpp(red[lane & 15]);
+        m = wave_max_dpp(red[lane & (NW - 1)]);
     } else if (nw > 1) {
         if (lane == 0) red[wv] = m;
         __syncthreads();
@@ -317,6 +317,22 @@ template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw
     if (!(m - m == 0)) m = 0;
     return det_exp(lw - m);
 }
+// P[wv - 1] (0 for the first wave) by ONE scalar branch on the wave id (readfirstlane tells the compiler it is wave-uniform; a plain
+// switch on tid >> 6 becomes a tree of exec-mask branches, a select chain fifteen compare / select triples)
+template <typename R, int NW> __device__ __forceinline__ R wave_base(const R* P, int wv) {
+    R pre = 0;
+    switch (__builtin_amdgcn_readfirstlane(wv)) {
+#define AX_PRE_CASE(K) \
+    case K + 1:        \
+        if (K + 1 < NW) pre = P[K]; \
+        break;
+        AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
+        AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
+#undef AX_PRE_CASE
+        default: break;
+    }
+    return pre;
+}
 // inclusive cumsum of w into c[] in the sweep contract's order; P[k] = cumulative total at the end of group k (k < nw), the same
 // numbers as c[64 k + 63]; c[] valid after the trailing barrier.  red slots [32, 48).
 template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
@@ -328,16 +344,10 @@ template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_d
     load16<R>(red + 32, t);
     P[0] = t[0];
     R pre = 0;
-    if constexpr (NW == 16) {
+    if constexpr (NW > 0) {
 #pragma unroll
-        for (int k = 1; k < 16; ++k) P[k] = P[k - 1] + t[k];
-        switch (__builtin_amdgcn_readfirstlane(wv)) {  // wave-uniform (told to the compiler): one scalar branch instead of fifteen compare / select triples
-#define AX_PRE_CASE(K) case K + 1: pre = P[K]; break;
-            AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
-            AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
-#undef AX_PRE_CASE
-            default: break;
-        }
+        for (int k = 1; k < 16; ++k) P[k] = k < NW ? P[k - 1] + t[k] : P[k - 1];  // (k < NW: compile time)
+        pre = wave_base<R, NW>(P, wv);
     } else {
 #pragma unroll
         for (int k = 1; k < 16; ++k) P[k] = k < nw ? P[k - 1] + t[k] : P[k - 1];
@@ -347,9 +357,9 @@ template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_d
     c[tid] = wv > 0 ? pre + v : v;
     __syncthreads();
 }
-// 16 full waves, the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two
-// and no c[] image -- for the backward pass, whose single draw only counts {c_j < r}.  P[15] = c[N - 1] bit for bit (full groups).
-template <typename R> __device__ __forceinline__ R block_cumsum_reg16(R w, R* red, int tid, R* P) {
+// NW full waves, the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two
+// and no c[] image -- for the backward pass, whose single draw only counts {c_j < r}.  P[NW - 1] = c[N - 1] bit for bit (full groups).
+template <typename R, int NW> __device__ __forceinline__ R block_cumsum_reg(R w, R* red, int tid, R* P) {
     const int lane = tid & 63, wv = tid >> 6;
     const R v = wave_scan_dpp(w);
     if (lane == 63) red[32 + wv] = v;
@@ -358,23 +368,16 @@ template <typename R> __device__ __forceinline__ R block_cumsum_reg16(R w, R* re
     load16<R>(red + 32, t);
     P[0] = t[0];
 #pragma unroll
-    for (int k = 1; k < 16; ++k) P[k] = P[k - 1] + t[k];
-    R pre = 0;
-    switch (__builtin_amdgcn_readfirstlane(wv)) {
-#define AX_PRE_CASE(K) case K + 1: pre = P[K]; break;
-        AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
-        AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
-#undef AX_PRE_CASE
-        default: break;
-    }
+    for (int k = 1; k < 16; ++k) P[k] = k < NW ? P[k - 1] + t[k] : P[k - 1];
+    const R pre = wave_base<R, NW>(P, wv);
     return wv > 0 ? pre + v : v;
 }
 // the two-level search of the sweep contract; P from block_cumsum_dpp, ng = number of groups of 64 covering [0, N)
 template <typename R, int NW = 0> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
     int g = 0;
-    if constexpr (NW == 16) {
+    if constexpr (NW > 0) {
 #pragma unroll
-        for (int k = 0; k < 15; ++k) g += P[k] < r ? 1 : 0;
+        for (int k = 0; k < NW - 1; ++k) g += P[k] < r ? 1 : 0;
         int pos = g << 6;
 #pragma unroll
         for (int s = 32; s > 0; s >>= 1) pos += c[pos + s - 1] < r ? s : 0;
