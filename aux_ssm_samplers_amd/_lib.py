@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libauxssm.so")
+LIB_PATH = os.environ.get("AUXSSM_LIB", os.path.join(_HERE, "libauxssm.so"))  # override: diagnostic builds (tools/csmc_ablate.sh)
 
 F32, F64 = 0, 1
 NAN_REFERENCE, NAN_MASKED = 0, 1

@@ -139,6 +139,13 @@ template <typename R, int D> __device__ __forceinline__ R grad_correction(const 
     return acc * ((R)0.5 / (s * s));
 }
 
+// Diagnostic builds only (tools/csmc_ablate.sh): -DAUXSSM_CSMC_ABLATE=<mask> removes one phase of the forward step at a time (wrong results, right
+// shape) to attribute its time: 1 search, 2 in-kernel draws, 4 potential / transition log-density, 8 max + exp, 16 cumsum.  0 in the product.
+#ifndef AUXSSM_CSMC_ABLATE
+#define AUXSSM_CSMC_ABLATE 0
+#endif
+constexpr int CSMC_ABL = AUXSSM_CSMC_ABLATE;
+
 // ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
 // NW = 8 / 16: exactly NW full waves (N = blockDim = 64 NW: the C4 / C3 shapes): no liveness / group-bound selects (csmc_dev.h); NW = 0: any N
 template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
@@ -146,8 +153,9 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     // two images of (c, xprev), alternated by time-step parity: readers of step t never race writers of step t+1,
     // which removes the end-of-step barrier (4 barriers per step: max, sum, wave totals, publish)
-    R* cbuf = (R*)smem;                 // [2][TB]
-    R* xbuf = cbuf + 2 * TB;            // [2][TB][D]
+    const int CP = cpad(TB);            // the cumsum image is padded against LDS bank conflicts of the search (csmc_dev.h::cpad)
+    R* cbuf = (R*)smem;                 // [2][CP]
+    R* xbuf = cbuf + 2 * CP;            // [2][TB][D]
     R* red = xbuf + 2 * TB * D;         // [48]
     const int ch = blockIdx.x;
     const bool live = NW > 0 ? true : tid < N;
@@ -229,6 +237,10 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
 #pragma unroll
             for (int k = 0; k < D; ++k) eps[k] = live ? ((const R*)a.eps_prop)[eps_base + ((long long)t * N + tid) * D + k] : (R)0;
             if (live) un = ((const R*)a.u_res)[ures_base + (long long)(t - 1) * N + tid];
+        } else if (CSMC_ABL & 2) {
+#pragma unroll
+            for (int k = 0; k < D; ++k) eps[k] = (R)0.25;
+            un = (R)0.37;
         } else if (t & 1) {  // normals cached by step t - 1; uniforms of steps t and t + 1
 #pragma unroll
             for (int k = 0; k < D; ++k) eps[k] = eps_nx[k];
@@ -244,15 +256,22 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
             }
         }
         // conditional multinomial resampling (resamplings.py:14-37 -> jax.random.choice: cumsum, r = c[-1] (1-u), searchsorted)
-        R* c = cbuf + (t & 1) * TB;
+        R* c = cbuf + (t & 1) * CP;
         R* xprev = xbuf + (t & 1) * TB * D;
 #pragma unroll
         for (int k = 0; k < D; ++k) xprev[tid * D + k] = x[k];
         R Pg[16];
-        block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
-        const R tot = c[N - 1];
+        if (CSMC_ABL & 16) {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) Pg[k] = (R)(k + 1);
+            c[cpad(tid)] = w;
+            __syncthreads();
+        } else
+            block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
+        const R tot = NW > 0 ? Pg[NW > 0 ? NW - 1 : 0] : c[cpad(N - 1)];  // full groups: the last total IS c[N - 1], bit for bit
         int idx = 0;
-        if (live && tid > 0) idx = search2<R, NW>(c, Pg, N, nw, tot * ((R)1 - un));
+        if (CSMC_ABL & 1) idx = (tid * 7) & (N - 1);
+        else if (live && tid > 0) idx = search2<R, NW, true>(c, Pg, N, nw, tot * ((R)1 - un));
         R xp[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
@@ -281,7 +300,8 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
             for (int k = 0; k < D; ++k) x[k] = xstar[(long long)t * D + k];
         }
         // weights (csmc.py:95-96)
-        {
+        if (CSMC_ABL & 4) lw = x[0] * (R)0.01;
+        else {
             R g = potential<R, D>(m, x, ycur);
             if (m.proposal == 1) {  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
                 R mu[D];
@@ -302,7 +322,8 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
             lws[o] = lw;
             if (As) As[(long long)(t - 1) * N + tid] = idx;
         }
-        w = block_expmax<R, NW>(lw, red, tid, nw);
+        if (CSMC_ABL & 8) w = lw * (R)0.001 + (R)1;
+        else w = block_expmax<R, NW>(lw, red, tid, nw);
     }
     if (live) ((R*)a.wT)[(long long)ch * N + tid] = w;
 }
@@ -528,7 +549,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
-        const size_t lds = (size_t)2 * TB * (1 + D) * sizeof(R) + 48 * sizeof(R) + 64;
+        const size_t lds = (size_t)2 * (cpad(TB) + TB * D) * sizeof(R) + 48 * sizeof(R) + 64;
         const bool tv = m.Ft != nullptr, gr = m.gradient != 0;
         const int fullw = (TB == a.N && (a.N == 1024 || a.N == 512)) ? a.N / 64 : 0;
 #define AX_FWD1(TVv, GRv, NWv)                                                                                                                                  \

@@ -335,7 +335,10 @@ template <typename R, int NW> __device__ __forceinline__ R wave_base(const R* P,
 }
 // inclusive cumsum of w into c[] in the sweep contract's order; P[k] = cumulative total at the end of group k (k < nw), the same
 // numbers as c[64 k + 63]; c[] valid after the trailing barrier.  red slots [32, 48).
-template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
+// PAD: c[] is stored with one spare slot per 32 entries (index cpad(i) = i + (i >> 5)): the probes of the search below sit at strides of 64, 32,
+// 16 ... entries, which without the padding all fall into one or two LDS banks (a 16- to 32-way conflict on the first probes of every lane).
+__host__ __device__ __forceinline__ constexpr int cpad(int i) { return i + (i >> 5); }
+template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
     const int lane = tid & 63, wv = tid >> 6;
     const R v = wave_scan_dpp(w);
     if (lane == 63) red[32 + wv] = v;
@@ -354,7 +357,7 @@ template <typename R, int NW = 0> __device__ __forceinline__ void block_cumsum_d
 #pragma unroll
         for (int k = 0; k < 15; ++k) pre = (k + 1 == wv) ? P[k] : pre;
     }
-    c[tid] = wv > 0 ? pre + v : v;
+    c[PAD ? cpad(tid) : tid] = wv > 0 ? pre + v : v;
     __syncthreads();
 }
 // NW full waves, the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two
@@ -373,14 +376,14 @@ template <typename R, int NW> __device__ __forceinline__ R block_cumsum_reg(R w,
     return wv > 0 ? pre + v : v;
 }
 // the two-level search of the sweep contract; P from block_cumsum_dpp, ng = number of groups of 64 covering [0, N)
-template <typename R, int NW = 0> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
+template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
     int g = 0;
     if constexpr (NW > 0) {
 #pragma unroll
         for (int k = 0; k < NW - 1; ++k) g += P[k] < r ? 1 : 0;
         int pos = g << 6;
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) pos += c[pos + s - 1] < r ? s : 0;
+        for (int s = 32; s > 0; s >>= 1) pos += c[PAD ? cpad(pos + s - 1) : pos + s - 1] < r ? s : 0;
         return pos < N - 1 ? pos : N - 1;
     } else {
 #pragma unroll
@@ -388,7 +391,7 @@ template <typename R, int NW = 0> __device__ __forceinline__ int search2(const R
         int pos = g << 6;
         const int end = min(pos + 64, N);
 #pragma unroll
-        for (int s = 32; s > 0; s >>= 1) pos += (pos + s - 1 < end && c[min(pos + s - 1, N - 1)] < r) ? s : 0;
+        for (int s = 32; s > 0; s >>= 1) pos += (pos + s - 1 < end && c[PAD ? cpad(min(pos + s - 1, N - 1)) : min(pos + s - 1, N - 1)] < r) ? s : 0;
         return pos < N - 1 ? pos : N - 1;
     }
 }

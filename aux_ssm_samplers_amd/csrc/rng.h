@@ -85,7 +85,13 @@ template <> AX_HD void bits_to_normal2<double>(uint32_t b0, uint32_t b1, double&
 template <> AX_HD void bits_to_normal2<float>(uint32_t b0, uint32_t b1, float& z0, float& z1) {
     const float u1 = ((float)(b0 >> 8) + 0.5f) * 5.9604644775390625e-8f;
     const float u2 = ((float)(b1 >> 8) + 0.5f) * 5.9604644775390625e-8f;
+    // device: the hardware log2 / sqrt (1 ulp each) instead of libm's correctly-rounded sequences (~35 instructions): a normal deviate does
+    // not need them, and the cSMC forward pass draws N of these per time step.  (The host build keeps libm; the two agree to ~1e-7.)
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln 2 log2(u1)
+#else
     const float r = sqrtf(-2.0f * logf(u1));
+#endif
     float c, s;
     sincos_2pi<float>(u2, c, s);
     z0 = r * c;
