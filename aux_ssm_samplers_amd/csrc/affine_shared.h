@@ -147,7 +147,7 @@ template <typename R, int D, int P, bool WRITE_U> AX_HD void aff_obs(const Filte
             rd<R, D>(a.aux_x, c, t, b, xv);
             rd<R, D>(a.aux_eps, c, t, b, ev);
 #pragma unroll
-            for (int k = 0; k < D; ++k) uv[k] = xv[k] + (R)a.aux_shd * ev[k], y[k] = uv[k];
+            for (int k = 0; k < D; ++k) uv[k] = xv[k] + (R)arg_aux_shd(a) * ev[k], y[k] = uv[k];
             if constexpr (WRITE_U) wr<R, D>(a.aux_u, c, t, b, uv);
             const UniformRow<R> yo = uniform_row<R>(at<R>(a.aux_yobs, 0, t, 0));
 #pragma unroll

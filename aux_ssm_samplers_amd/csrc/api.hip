@@ -216,9 +216,17 @@ static void fill_logpdf_args(LogpdfArgs& a, const auxssm_dims* d, const auxssm_l
 
 // ---- sweep helper kernels (pure data movement / reductions; runtime sizes) --------------------------------
 
+// device-resident step size: blk = {delta, sqrt(delta / 2)} from the caller's device scalar (auxssm_kalman_sweep_dd)
+template <typename R> __global__ void k_delta_block(const R* __restrict__ delta, double* __restrict__ blk) {
+    const double d = (double)delta[0];
+    blk[0] = d;
+    blk[1] = sqrt(0.5 * d);
+}
+
 // concatenated observation model of AUXSSM_KMODEL_LG_CONCAT, chain-shared part: H = [I; Hobs], R = blkdiag(d/2 I, Robs), c = [0; cobs]
 template <typename R>
-__global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cobs, R half_delta, R* Hc, R* Rc, R* cc) {
+__global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cobs, R half_delta, const double* dptr, R* Hc, R* Rc, R* cc) {
+    if (dptr) half_delta = (R)(0.5 * dptr[0]);  // device-resident step size (auxssm_kalman_sweep_dd)
     const int P = D + PO;
     const int per_t = P * D + P * P + P;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -244,7 +252,8 @@ __global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cob
 // x, eps, u, ysc through strided views.  cfast != 0 (chain-minor layout everywhere): consecutive lanes = consecutive chains;
 // otherwise lanes run over (t, k) of one chain (dense layout everywhere).  Either way every access of a wave is contiguous.
 template <typename R>
-__global__ void k_concat_obs(int C, int T, int D, int PO, Arr x, Arr eps, R shd, Arr yobs, Arr u, Arr ysc, int cfast) {
+__global__ void k_concat_obs(int C, int T, int D, int PO, Arr x, Arr eps, R shd, const double* dptr, Arr yobs, Arr u, Arr ysc, int cfast) {
+    if (dptr) shd = (R)dptr[1];
     const int P = D + PO;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)C * T * P) return;
@@ -351,7 +360,7 @@ template <typename R> static int launch_select(auxssm_ctx* h, int C, int T, int 
 
 template <typename R>
 static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
-                           double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
+                           double delta, const double* dptr, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
                            const void* u_acc, int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy, P = D + PO;
     // one path for the whole sweep: the register kernels when every piece is instantiated, else the wide-state path
@@ -424,11 +433,11 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
-                           cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
+                           cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), dptr, Hc, Rc, cc);
         const int Tc = aux_fly ? 1 : T;
         const long long n2 = (long long)C * Tc * P;
         hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, Tc, D, PO,
-                           xA, epsauxA, (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, cm);
+                           xA, epsauxA, (R)sqrt(0.5 * delta), dptr, cv(*yobs), uA, yscA, cm);
     }
     auxssm_lgssm gc = *model;
     gc.Hs = auxssm_arr{Hc, 0, (int64_t)P * D, 0};
@@ -455,6 +464,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         fa.aux_u = uA;
         fa.aux_yobs = cv(*yobs);
         fa.aux_shd = sqrt(0.5 * delta);
+        fa.dptr = dptr;
     }
     rc = ke->filter(h, fa, parallel, ell);
     if (rc) return rc;
@@ -479,7 +489,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
         la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
         la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
-        la.u_fly = aux_fly ? 1 : 0; la.eps_aux = epsauxA; la.shd = sqrt(0.5 * delta);
+        la.u_fly = aux_fly ? 1 : 0; la.eps_aux = epsauxA; la.shd = sqrt(0.5 * delta); la.dptr = dptr;
         rc = sl->run(h, la, sums);
         if (rc) return rc;
         h->ws_off = mark;
@@ -501,7 +511,8 @@ template <typename R> AX_HD R sv_nan_to_num(R v) { return nan_to_num<R>(v); }
 // pass 1 (eps != null): u = x + sqrt(delta/2) eps and the observations linearised at x; pass 2: linearised at xlin, u given
 template <typename R>
 __global__ void k_sv_obs(long long total, int C, int T, int D, int order, int cfast, const R* __restrict__ xlin, const R* __restrict__ eps, R shd,
-                         R delta, Arr yobs, R* __restrict__ u, R* __restrict__ ys, R* __restrict__ Rs) {
+                         R delta, const double* dptr, Arr yobs, R* __restrict__ u, R* __restrict__ ys, R* __restrict__ Rs) {
+    if (dptr) delta = (R)dptr[0], shd = (R)dptr[1];
     // flat index g walks the (C, T, D) arrays in storage order, dense (c, t, k) or chain-minor (t, k, c)
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= total) return;
@@ -541,7 +552,8 @@ __global__ void k_sv_obs(long long total, int C, int T, int D, int order, int cf
         for (int j = 0; j < D; ++j) Rs[base + j * js] = j == k ? om : (R)0;
     }
 }
-template <typename R> __global__ void k_scaled_eye(int D, R v, R* eye) {
+template <typename R> __global__ void k_scaled_eye(int D, R v, R* eye, const double* half_of = nullptr) {
+    if (half_of) v = (R)(0.5 * half_of[0]);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < D * D) eye[i] = (i / D == i % D) ? v : (R)0;
 }
@@ -552,9 +564,10 @@ template <typename R> __global__ void k_fill(long long n, R v, R* out) {
 // per chain (one workgroup): pot(xp), pot(x), la1 = sum_t log N(ys1_t; xp_t, R1_t), la2 = sum_t log N(ys2_t; x_t, R2_t) (R diagonal;
 // a step whose term is NaN is dropped, as the reference's nansum over time steps does), corr (generic.py:103-105).  out [5][C].
 template <typename R>
-__global__ void __launch_bounds__(256) k_sv_terms(int C, int T, int D, R delta, const R* __restrict__ x, const R* __restrict__ xp, const R* __restrict__ u,
+__global__ void __launch_bounds__(256) k_sv_terms(int C, int T, int D, R delta, const double* dptr, const R* __restrict__ x, const R* __restrict__ xp, const R* __restrict__ u,
                                                   Arr yobs, const R* __restrict__ ys1, const R* __restrict__ ys2, const R* __restrict__ R1,
                                                   const R* __restrict__ R2, R* __restrict__ out) {
+    if (dptr) delta = (R)dptr[0];
     __shared__ R sh[256];
     const int c = blockIdx.x, tid = threadIdx.x;
     R acc[5] = {0, 0, 0, 0, 0};
@@ -617,7 +630,7 @@ __global__ void k_sv_accept(int C, const R* j1, const R* j2, const R* ell1, cons
 // x_prop for the reverse move) get their own observation set and filter pass, as in the reference.
 template <typename R>
 static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
-                    double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
+                    double delta, const double* dptr, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
                     const void* u_acc, int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = dims->dx;
     const bool wide = is_wide(D, D);
@@ -677,7 +690,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     g1.Rs = second ? auxssm_arr{Rs1, (int64_t)T * D * D, (int64_t)D * D, 0} : auxssm_arr{Rc, 0, 0, 0};
     auxssm_lgssm g2 = g1;
     if (second) g2.Rs = auxssm_arr{Rs2, (int64_t)T * D * D, (int64_t)D * D, 0};
-    if (!second) hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)(0.5 * delta), Rc);
+    if (!second) hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)(0.5 * delta), Rc, dptr);
     auxssm_dims dc = *dims;
     dc.dy = D;
     dc.B = 1;
@@ -690,7 +703,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)x, (const R*)eps_aux,
-                           (R)sqrt(0.5 * delta), (R)delta, cv(*yobs), u, ys1, Rs1);
+                           (R)sqrt(0.5 * delta), (R)delta, dptr, cv(*yobs), u, ys1, Rs1);
     }
     FilterArgs fa;
     fill_filter_args(fa, &dc, &g1, &y1d, ms, Ps);
@@ -717,7 +730,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)xp, (const R*)nullptr, (R)0,
-                           (R)delta, cv(*yobs), u, ys2, Rs2);
+                           (R)delta, dptr, cv(*yobs), u, ys2, Rs2);
     }
     fill_filter_args(fa, &dc, &g2, &y2d, ms, Ps);
     fa.ys = y2A;
@@ -736,6 +749,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         la.yobs = cv(*yobs);
         la.x = xA; la.xp = xpA; la.u = uA; la.ys1 = y1A; la.ys2 = y2A; la.R1 = R1A; la.R2 = R2A;
         la.delta = delta;
+        la.dptr = dptr;
         rc = se->sv_logpdf(h, la, j1);  // j1 .. : [5][C] = jp_prop, jp_rev, lt_prop, lt_rev, corr
         if (rc) return rc;
         h->ws_off = mark;
@@ -753,7 +767,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         rc = ke->logpdf(h, la, j2);
         if (rc) return rc;
         h->ws_off = mark;
-        hipLaunchKernelGGL((k_sv_terms<R>), dim3(C), dim3(256), 0, h->stream, C, T, D, (R)delta, (const R*)x, (const R*)xp, (const R*)u,
+        hipLaunchKernelGGL((k_sv_terms<R>), dim3(C), dim3(256), 0, h->stream, C, T, D, (R)delta, dptr, (const R*)x, (const R*)xp, (const R*)u,
                            cv(*yobs), (const R*)ys1, (const R*)ys2, (const R*)Rs1, (const R*)Rs2, terms);
         hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,
                            (const R*)ell2, (const R*)terms, (const R*)u_acc, accepted, (R*)logs);
@@ -792,7 +806,7 @@ __global__ void k_lorenz_dyn(int C, int T, int cfast, const R* __restrict__ par,
 }
 
 template <typename R>
-static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs, double delta,
+static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, const double* dptr,
                         int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
                         int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = 3, PO = dims->dy, P = D + PO;
@@ -843,11 +857,11 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
         ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs),
-                           cv(model->Rs), cv(model->cs), (R)(0.5 * delta), Hc, Rc, cc);
+                           cv(model->Rs), cv(model->cs), (R)(0.5 * delta), dptr, Hc, Rc, cc);
         const int Tc = aux_fly ? 1 : T;
         const long long n2 = (long long)C * Tc * P;
         hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, Tc, D, PO, xA,
-                           arr(eps_aux, D), (R)sqrt(0.5 * delta), cv(*yobs), uA, yscA, cm);
+                           arr(eps_aux, D), (R)sqrt(0.5 * delta), dptr, cv(*yobs), uA, yscA, cm);
     }
     const unsigned gd = (unsigned)(((long long)C * (T - 1) + 255) / 256);
     auxssm_lgssm g1 = *model;
@@ -880,6 +894,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
             fa.aux_u = uA;
             fa.aux_yobs = cv(*yobs);
             fa.aux_shd = sqrt(0.5 * delta);
+        fa.dptr = dptr;
         }
     };
 
@@ -923,7 +938,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
         la.Fs = Arr{nullptr, 0, 0, 0, 1}; la.bs = Arr{nullptr, 0, 0, 0, 1};
         la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
         la.x = xA; la.xp = xpA; la.u = uA; la.delta = delta; la.nan_policy = nan_policy;
-        la.u_fly = aux_fly ? 1 : 0; la.eps_aux = arr(eps_aux, D); la.shd = sqrt(0.5 * delta);
+        la.u_fly = aux_fly ? 1 : 0; la.eps_aux = arr(eps_aux, D); la.shd = sqrt(0.5 * delta); la.dptr = dptr;
         la.lor_par = par; la.lor_psc = psc;
         rc = sl->lorenz(h, la, sums);  // [5][C]: jp_prop, jp_rev, lt_prop, lt_rev, corr
         if (rc) return rc;
@@ -1031,6 +1046,7 @@ int auxssm_destroy(auxssm_handle h) {
     (void)hipStreamSynchronize(h->stream);
     auxssm_prof_disable(h);
     if (h->ws) (void)hipFree(h->ws);
+    if (h->dblock) (void)hipFree(h->dblock);
     (void)hipStreamDestroy(h->stream);
     delete h;
     return AUXSSM_OK;
@@ -1250,9 +1266,10 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
     return e->logpdf(h, a, out);
 }
 
-int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
-                        const auxssm_arr* yobs, double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux,
-                        const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
+// delta_dev != NULL: the step size is a device scalar of `dtype` (auxssm_kalman_sweep_dd); `delta` is then only a placeholder
+static int kalman_sweep_impl(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
+                             const auxssm_arr* yobs, double delta, const void* delta_dev, int parallel, int nan_policy, int layout, void* x,
+                             const void* eps_aux, const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
     AX_NEED_H(h);
     int rc;
     if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true))) return rc;
@@ -1310,18 +1327,42 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
         set_error("yobs and the observation model (Hs, Rs, cs) are shared by the chains of a sweep: their chain strides must be 0");
         return AUXSSM_ERR_ARG;
     }
+    const double* dptr = nullptr;
+    if (delta_dev) {  // {delta, sqrt(delta / 2)} for the kernels of this sweep, on the stream: nothing returns to the host
+        if (!h->dblock) AX_HIP(hipMalloc((void**)&h->dblock, 2 * sizeof(double)));
+        if (dtype == AUXSSM_F32) hipLaunchKernelGGL((k_delta_block<float>), dim3(1), dim3(1), 0, h->stream, (const float*)delta_dev, h->dblock);
+        else hipLaunchKernelGGL((k_delta_block<double>), dim3(1), dim3(1), 0, h->stream, (const double*)delta_dev, h->dblock);
+        dptr = h->dblock;
+    }
     if (lorenz) {
-        rc = dtype == AUXSSM_F32 ? sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
-                                 : sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        rc = dtype == AUXSSM_F32 ? sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     } else if (sv) {
         const int order = model_kind == AUXSSM_KMODEL_SV_FIRST ? 1 : 2;
-        rc = dtype == AUXSSM_F32 ? sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
-                                 : sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        rc = dtype == AUXSSM_F32 ? sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     } else {
-        rc = dtype == AUXSSM_F32 ? sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
-                                 : sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        rc = dtype == AUXSSM_F32 ? sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
     return rc;
+}
+
+int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
+                        const auxssm_arr* yobs, double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux,
+                        const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
+    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, delta, nullptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted,
+                             logs);
+}
+int auxssm_kalman_sweep_dd(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
+                           const auxssm_arr* yobs, const void* delta_dev, int parallel, int nan_policy, int layout, void* x, const void* eps_aux,
+                           const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
+    if (!delta_dev) {
+        set_error("delta_dev must be a device pointer to one scalar of `dtype`");
+        return AUXSSM_ERR_ARG;
+    }
+    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, 1.0, delta_dev, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted,
+                             logs);
 }
 
 static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32_t k1, uint32_t stream, int64_t n, void* out) {

@@ -50,6 +50,7 @@ struct auxssm_ctx {
     const void* st_x = nullptr;
     long long st_n = 0;
     int st_dtype = -1;
+    double* dblock = nullptr;  // {delta, sqrt(delta / 2)} of a sweep whose step size is device-resident (auxssm_kalman_sweep_dd); lazily allocated
 };
 
 namespace ax {

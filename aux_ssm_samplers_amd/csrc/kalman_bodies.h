@@ -99,6 +99,11 @@ struct DirectIO {
     }
 };
 
+// the step size of a sweep: host scalars in the argument structs, or -- auxssm_kalman_sweep_dd -- a device block {delta, sqrt(delta / 2)}
+// written by k_delta_block from the caller's device scalar (wave-uniform loads; nothing is read back to the host)
+template <typename A> AX_HD double arg_delta(const A& a) { return a.dptr ? a.dptr[0] : a.delta; }
+template <typename A> AX_HD double arg_shd(const A& a) { return a.dptr ? a.dptr[1] : a.shd; }
+template <typename A> AX_HD double arg_aux_shd(const A& a) { return a.dptr ? a.dptr[1] : a.aux_shd; }
 struct FilterArgs {
     KDims d;
     Arr m0, P0, Fs, Qs, bs, Hs, Rs, cs, ys;
@@ -116,6 +121,7 @@ struct FilterArgs {
     int aux_on = 0;
     Arr aux_x{}, aux_eps{}, aux_u{}, aux_yobs{};
     double aux_shd = 0;
+    const double* dptr = nullptr;  // device-resident step size: {delta, sqrt(delta / 2)} (auxssm_kalman_sweep_dd); null: the host values above
     const void* obs_tab = nullptr;  // general chain-minor path with aux_on: one ObsInfoRow per transition (kalman_math.h), elements built on the fly
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
@@ -329,7 +335,7 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
         const int c = s / a.d.B, b = s % a.d.B;
         R u[D], m_[D], P_[D * D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) u[k] = r.x[k] + (R)a.aux_shd * r.eps[k];
+        for (int k = 0; k < D; ++k) u[k] = r.x[k] + (R)arg_aux_shd(a) * r.eps[k];
         if constexpr (WRITE_U) wr<R, D>(a.aux_u, c, (long long)i + 1, b, u);
         if (i == 0) {  // built around predict(m0+, P0+) (filtering.py:188-192, :200-201)
             R m0p[D], P0p[D * D], tm[D], FP[D * D], Pn[D * D];
@@ -349,7 +355,7 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
             for (int k = 0; k < D * D; ++k) P_[k] = r.Q[k];
         }
         const UniformRow<R> row = uniform_row<R>((const R*)a.obs_tab + (long long)i * T::NPAD);
-        const R inv_hd = (R)1 / ((R)a.aux_shd * (R)a.aux_shd);
+        const R inv_hd = (R)1 / ((R)arg_aux_shd(a) * (R)arg_aux_shd(a));
         filter_elem_aux<R, D>(r.F, r.bd, m_, P_, u, row, inv_hd, i == 0, e);
     }
     static AX_HD void load_elem(const Args& a, int s, int i, Full& e) {
@@ -383,12 +389,12 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
     static AX_HD void step_info(const Args& a, int s, int i, const Raw& r, StepInfo<R, D>& si) {
         using T = ObsInfoRow<R, D>;
         const UniformRow<R> row = uniform_row<R>((const R*)a.obs_tab + (long long)i * T::NPAD);
-        const R inv_hd = (R)1 / ((R)a.aux_shd * (R)a.aux_shd);
+        const R inv_hd = (R)1 / ((R)arg_aux_shd(a) * (R)arg_aux_shd(a));
         R u[D];
         R q0 = row[T::oK];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            u[k] = r.x[k] + (R)a.aux_shd * r.eps[k];
+            u[k] = r.x[k] + (R)arg_aux_shd(a) * r.eps[k];
             si.g0[k] = u[k] * inv_hd + row[T::oG + k];
             q0 += u[k] * u[k] * inv_hd;
         }
@@ -425,7 +431,7 @@ template <typename R, int D, int P> AX_HD void body_obs_info_tab(const FilterArg
     for (int k = 0; k < P; ++k) y[k] = k < D ? (R)0 : at<R>(a.aux_yobs, 0, t, 0)[k - D];
 #pragma unroll
     for (int k = T::N; k < T::NPAD; ++k) row[k] = 0;
-    obs_info_row<R, D, P>(H, cv, Rm, y, (R)a.aux_shd * (R)a.aux_shd, row);
+    obs_info_row<R, D, P>(H, cv, Rm, y, (R)arg_aux_shd(a) * (R)arg_aux_shd(a), row);
     stv<R, T::NPAD>((R*)a.obs_tab + (long long)i * T::NPAD, row);
 }
 
@@ -720,6 +726,7 @@ struct SweepLogpdfArgs {
     int u_fly = 0;
     Arr eps_aux{};
     double shd = 0;
+    const double* dptr = nullptr;  // device-resident {delta, sqrt(delta / 2)}; null: the host values
 };
 // the auxiliary variable of chain c at time t >= 1
 template <typename R, int D> AX_HD void sweep_u(const SweepLogpdfArgs& a, int c, long long t, const R* x, R* u) {
@@ -727,7 +734,7 @@ template <typename R, int D> AX_HD void sweep_u(const SweepLogpdfArgs& a, int c,
         R e[D];
         rd<R, D>(a.eps_aux, c, t, 0, e);
 #pragma unroll
-        for (int k = 0; k < D; ++k) u[k] = x[k] + (R)a.shd * e[k];
+        for (int k = 0; k < D; ++k) u[k] = x[k] + (R)arg_shd(a) * e[k];
     } else {
         rd<R, D>(a.u, c, t, 0, u);
     }
@@ -764,8 +771,8 @@ AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, co
     corr = 0;
     {
         // (x - u)^2 / delta and the N(u; x, delta/2 I) terms share the squared distances: one reciprocal of delta, no division per component
-        const R hd = (R)(0.5 * a.delta);
-        const R inv_delta = (R)1 / (R)a.delta;
+        const R hd = (R)(0.5 * arg_delta(a));
+        const R inv_delta = (R)1 / (R)arg_delta(a);
         R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -794,7 +801,7 @@ AX_HD void sweep_logpdf_core(const SweepLogpdfArgs& a, const R* x, const R* xp, 
                              const R* y, const R* Rm, const R* F, const R* bd, const R* Q, R* out5) {
     R u[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)a.shd * u_in[k] : u_in[k];
+    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)arg_shd(a) * u_in[k] : u_in[k];
     R cc_p, cc_x, ob_p, ob_x, corr;
     sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
     R pr_p, pr_x;
@@ -952,6 +959,7 @@ struct SvLogpdfArgs {
     Arr x, xp, u, ys1, ys2;  // (C, T, D)
     Arr R1, R2;              // (C, T, D, D), ptr null for the first-order factory
     double delta;
+    const double* dptr = nullptr;  // device-resident {delta, sqrt(delta / 2)}; null: the host value
 };
 template <typename R, int D>
 AX_HD void sv_step_terms(const SvLogpdfArgs& a, int c, long long t, const R* x, const R* xp, R* o5) {
@@ -966,14 +974,14 @@ AX_HD void sv_step_terms(const SvLogpdfArgs& a, int c, long long t, const R* x, 
         const R av = xp[k], bv = x[k];
         pp += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * av - (R)0.5 * y[k] * y[k] * exp_(-av));
         px += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * bv - (R)0.5 * y[k] * y[k] * exp_(-bv));
-        const R r1 = a.R1.ptr ? at<R>(a.R1, c, t, 0)[(long long)(k * D + k) * a.R1.se] : (R)(0.5 * a.delta);
-        const R r2 = a.R2.ptr ? at<R>(a.R2, c, t, 0)[(long long)(k * D + k) * a.R2.se] : (R)(0.5 * a.delta);
+        const R r1 = a.R1.ptr ? at<R>(a.R1, c, t, 0)[(long long)(k * D + k) * a.R1.se] : (R)(0.5 * arg_delta(a));
+        const R r2 = a.R2.ptr ? at<R>(a.R2, c, t, 0)[(long long)(k * D + k) * a.R2.se] : (R)(0.5 * arg_delta(a));
         const R s1 = sqrt_(r1), s2 = sqrt_(r2);
         const R z1 = (y1[k] - av) / s1, z2 = (y2[k] - bv) / s2;
         l1 += (R)-0.5 * z1 * z1 - log_(s1) - (R)(0.5 * LOG_2PI);
         l2 += (R)-0.5 * z2 * z2 - log_(s2) - (R)(0.5 * LOG_2PI);
         const R e1 = av - u[k], e2 = bv - u[k];
-        cr += (e1 * e1 - e2 * e2) / (R)a.delta;
+        cr += (e1 * e1 - e2 * e2) / (R)arg_delta(a);
     }
     o5[0] = isnan_(l1) ? (R)0 : l1;
     o5[1] = isnan_(l2) ? (R)0 : l2;
@@ -1052,7 +1060,7 @@ AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int i, const R* x,
     const UniformRow<R> F = uniform_row<R>(at<R>(a.Fs, 0, i, 0)), bd = uniform_row<R>(at<R>(a.bs, 0, i, 0));
     R u[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)a.shd * u_in[k] : u_in[k];
+    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)arg_shd(a) * u_in[k] : u_in[k];
     // observation block (sweep_obs_terms with the factor from the table)
     R ob_p, ob_x;
     bool badobs_x = false, badobs_p = false;
@@ -1077,8 +1085,8 @@ AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int i, const R* x,
     bool b1 = false, b2 = false;
     {
         // (x - u)^2 / delta and the N(u; x, delta/2 I) terms share the squared distances: one reciprocal of delta, no division per component
-        const R hd = (R)(0.5 * a.delta);
-        const R inv_delta = (R)1 / (R)a.delta;
+        const R hd = (R)(0.5 * arg_delta(a));
+        const R inv_delta = (R)1 / (R)arg_delta(a);
         R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) {

@@ -2023,7 +2023,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
     R ob_p, ob_x, pr_p, pr_x;
     gauss2<R>(at<R>(a.Rs, c, t, 0), po, a.nan_policy == 1 ? skip : nullptr, r1, r2, Lb, piv, rowbuf, tid, ob_p, ob_x);
     // auxiliary block N(u; x, delta/2 I) and the MH correction (generic.py:103-105)
-    const R hd = (R)(0.5 * a.delta), sd = sqrt_(hd);
+    const R hd = (R)(0.5 * arg_delta(a)), sd = sqrt_(hd);
     R q1 = 0, q2 = 0, corr = 0;
     int ib1 = 0, ib2 = 0;
     for (int k = tid; k < d; k += NT) {
@@ -2034,7 +2034,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
         q1 += z1 * z1;
         q2 += z2 * z2;
         const R f1 = xp[k] - u[k], f2 = x[k] - u[k];
-        corr += (f1 * f1 - f2 * f2) / (R)a.delta;
+        corr += (f1 * f1 - f2 * f2) / (R)arg_delta(a);
     }
     const bool b1 = __syncthreads_or(ib1), b2 = __syncthreads_or(ib2);
     q1 = block_sum<R>(q1, rowbuf, tid);

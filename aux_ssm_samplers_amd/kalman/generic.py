@@ -148,6 +148,14 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         if "lorenz_par" in dl.bufs and dl.bufs["lorenz_par"].shape[0] not in (1, chains.C):
             raise ValueError(f"the model holds {dl.bufs['lorenz_par'].shape[0]} theta rows, the chains are {chains.C}")
         dims = _lib.Dims(chains.C, chains.T, 1, chains.dx, model.p_obs)
+        if isinstance(delta, _lib.DeviceArray):  # device-resident step size (one scalar of the chains' dtype): no host round trip
+            if delta.dtype != np.dtype(chains.dtype) or delta.size < 1:
+                raise ValueError("a device-resident delta must be a DeviceArray of one scalar of the chains' dtype")
+            _lib.check(handle.lib.auxssm_kalman_sweep_dd(
+                handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
+                delta.ptr, int(bool(parallel)), pol, chains.layout, chains.x.ptr, eps_aux.ptr, eps_samp.ptr, u_acc.ptr,
+                chains.accepted.ptr, chains.logs.ptr))
+            return
         _lib.check(handle.lib.auxssm_kalman_sweep(
             handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
             float(delta), int(bool(parallel)), pol, chains.layout, chains.x.ptr, eps_aux.ptr, eps_samp.ptr, u_acc.ptr,

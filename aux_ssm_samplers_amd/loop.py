@@ -8,7 +8,8 @@ same argument order and return order as the reference.  The chains stay resident
 csmc.CsmcChains); per sweep the loop enqueues: the sweep, the running squared-jump / first / second moments (folded into the Kalman
 sweep's accept step, a separate pass for cSMC), the acceptance averages and, while adapting, the step-size rule -- all HIP kernels on
 the handle's stream (include/auxssm.h, "the MCMC loop around the sweeps").  A sampling run (delta_fn None) never synchronises with
-the host.  While adapting, the Kalman sweep takes delta as a host scalar, so each burn-in sweep reads back the C windowed acceptances.
+the host.  While adapting with the reference's rule the Kalman step size is a device scalar as well (auxssm_kalman_sweep_dd): no read-back per sweep;
+a user-supplied rule runs on the host and reads the C windowed acceptances back each burn-in sweep.
 
 Chains of one call share delta: the adaptation rule sees the chain-mean of the windowed acceptance (one chain: the reference exactly).
 """
@@ -81,14 +82,18 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
     upd0 = np.broadcast_to(np.asarray(upd, dtype), (chains.C, m))
     avg = handle.to_device(upd0, dtype)
     window = handle.to_device(upd0, dtype)
+    rule = _is_reference_rule(delta_fn) if delta_fn is not None else None
     if kalman:
         delta = float(init_delta)
+        # the reference's rule while adapting: delta stays on the DEVICE (one scalar, updated by auxssm_delta_adapt from the chain-mean of the
+        # windowed acceptance and read by auxssm_kalman_sweep_dd) -- no host round trip per sweep.  A user rule still runs on the host.
+        delta_dev = handle.to_device(np.full(1, delta, dtype), dtype) if rule is not None else None
     else:
         if init_delta is not None:
             chains.set_delta(init_delta)
         delta = None
+        delta_dev = None
         x_prev = handle.empty(chains.x.shape, dtype)
-    rule = _is_reference_rule(delta_fn) if delta_fn is not None else None
     state = init_state
     if kalman:
         handle.stats_attach(stats, 0, chains.x)
@@ -96,7 +101,7 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
         for i in range(n_iter):
             if kalman:
                 k_sweep, k_theta = (keys[i], None) if theta_step is None else _random.split(keys[i], 2)
-                state = kernel_fn(k_sweep, state, delta)  # folds the moments in its accept step
+                state = kernel_fn(k_sweep, state, delta if delta_dev is None else delta_dev)  # folds the moments in its accept step
                 if theta_step is not None:
                     theta_step(k_theta, chains)
             else:
@@ -106,7 +111,9 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
             handle.accept_update(i, beta, flags, avg, window)
             if delta_fn is not None:
                 lr_i = (n_iter - i) * lr / n_iter
-                if kalman:
+                if kalman and delta_dev is not None:
+                    handle.delta_adapt(window, target_alpha, lr_i, delta_dev, None, rule[0], rule[1])
+                elif kalman:
                     delta = float(delta_fn(delta, target_alpha, float(np.mean(window.to_host())), lr_i))
                 elif rule is not None:
                     handle.delta_adapt(window, target_alpha, lr_i, chains.delta, chains.sqrt_half_delta, rule[0], rule[1])
@@ -117,4 +124,6 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
     finally:
         if kalman:
             handle.stats_attach(None, 0)
+    if kalman and delta_dev is not None:
+        delta = float(delta_dev.to_host()[0])  # one read at the END of the run (the return value is a float, as the reference's)
     return n_iter, stats, state, (delta if kalman else chains.delta), window, avg

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 102
+#define AUXSSM_VERSION 103
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -185,6 +185,14 @@ int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm
                         const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, int parallel,
                         int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
                         int32_t* accepted, void* logs);
+/* The same sweep with a DEVICE-RESIDENT step size: delta_dev points at one scalar of `dtype` in device memory (e.g. the array
+ * auxssm_delta_adapt updates, m = 1), read by the sweep's kernels on the handle's stream -- the adaptation loop of
+ * the experiment drivers under examples/ (common.py:4-32 delta_adaptation between sweeps) then runs without any host round trip.  Results are bit-identical
+ * to auxssm_kalman_sweep called with the same value.  delta_dev must hold a value > 0 (not checked: that would need a read-back). */
+int auxssm_kalman_sweep_dd(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims,
+                           const auxssm_lgssm* model, const auxssm_arr* yobs, const void* delta_dev, int parallel,
+                           int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
+                           int32_t* accepted, void* logs);
 
 /* ---- conditional SMC (particle Gibbs) sweep ------------------------------------------------------------
  * == kernel(key, state) of aux_samplers._primitives.csmc.get_kernel (csmc.py:16-66: forward pass _csmc :69-107 with
