@@ -740,10 +740,11 @@ AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInf
     for (int i = 0; i < D; ++i)
 #pragma unroll
         for (int j = i; j < D; ++j) {
-            R s1 = 0, s2 = 0;
+            // F C F^T is symmetric for symmetric C: the upper entry alone, mirrored (exactly symmetric by construction, half the products)
+            R s1 = 0;
 #pragma unroll
-            for (int k = 0; k < D; ++k) s1 += FC[i * D + k] * F[j * D + k], s2 += FC[j * D + k] * F[i * D + k];
-            const R vv = (i == j) ? s1 + Q[i * D + i] : (R)0.5 * (s1 + s2) + (R)0.5 * (Q[i * D + j] + Q[j * D + i]);
+            for (int k = 0; k < D; ++k) s1 += FC[i * D + k] * F[j * D + k];
+            const R vv = (i == j) ? s1 + Q[i * D + i] : s1 + (R)0.5 * (Q[i * D + j] + Q[j * D + i]);
             Pp[i * D + j] = vv;
             Pp[j * D + i] = vv;
         }
@@ -792,33 +793,33 @@ AX_HD void filter_fold_step(const R* F, const R* Q, const R* bd, const StepInfo<
     mm<R, D, D, D>(F, acc.A, FA);
     mm<R, D, D, D>(Pp, M, PM);
     mm<R, D, D, D>(M, FA, MFA);
-    R Cd[D * D], Jd[D * D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         R sb = mb[i], se = acc.eta[i];
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            R sa = FA[i * D + j], sc = Pp[i * D + j], sj = 0;
+            R sa = FA[i * D + j];
+#pragma unroll
+            for (int k = 0; k < D; ++k) sa -= PM[i * D + k] * FA[k * D + j];
+            acc.A[i * D + j] = sa;  // (A itself was consumed by FA)
+        }
+        // C' = Pp - Pp M Pp and FA^T M FA are symmetric (M, Pp symmetric): upper entries only, packed directly
+#pragma unroll
+        for (int j = i; j < D; ++j) {
+            R sc = Pp[i * D + j], sj = 0;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                sa -= PM[i * D + k] * FA[k * D + j];
                 sc -= PM[i * D + k] * Pp[k * D + j];
                 sj += FA[k * D + i] * MFA[k * D + j];
             }
-            acc.A[i * D + j] = sa;
-            Cd[i * D + j] = sc;
-            Jd[i * D + j] = sj;
+            acc.C[sidx_u(D, i, j)] = sc;
+            acc.J[sidx_u(D, i, j)] += sj;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) sb += Pp[i * D + k] * v[k], se += FA[k * D + i] * v[k];
         acc.b[i] = sb;
         acc.eta[i] = se;
     }
-    sympack<R, D>(Cd, acc.C);
-    R Js[symsize(D)];
-    sympack<R, D>(Jd, Js);
-#pragma unroll
-    for (int i = 0; i < symsize(D); ++i) acc.J[i] += Js[i];
     acc.z += zinc;
 }
 // the (b, C, z) half: one Kalman step in information form
@@ -826,23 +827,22 @@ template <typename R, int D>
 AX_HD void filter_apply_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltPre<R, D>& p) {
     R mb[D], Pp[D * D], M[D * D], v[D], zinc;
     step_predict_solve<R, D>(F, Q, bd, si, p.b, p.C, mb, Pp, M, v, zinc);
-    R PM[D * D], Cd[D * D];
+    R PM[D * D];
     mm<R, D, D, D>(Pp, M, PM);
 #pragma unroll
     for (int i = 0; i < D; ++i) {
         R sb = mb[i];
 #pragma unroll
-        for (int j = 0; j < D; ++j) {
+        for (int j = i; j < D; ++j) {  // symmetric: upper entries only
             R sc = Pp[i * D + j];
 #pragma unroll
             for (int k = 0; k < D; ++k) sc -= PM[i * D + k] * Pp[k * D + j];
-            Cd[i * D + j] = sc;
+            p.C[sidx_u(D, i, j)] = sc;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) sb += Pp[i * D + k] * v[k];
         p.b[i] = sb;
     }
-    sympack<R, D>(Cd, p.C);
     p.z += zinc;
 }
 
