@@ -84,15 +84,31 @@ __device__ __forceinline__ void gemm(int M, int N, int K, const float* A, int ld
                 const float* qa = TA ? A + 16 * hi * lda + i0 + lo : A + (i0 + lo) * lda + 16 * hi;
                 const float* qb = TB ? B + (j0 + lo) * ldb + 16 * hi : B + 16 * hi * ldb + j0 + lo;
                 const int ua = TA ? lda : 1, ub = TB ? 1 : ldb;
+                // Software pipeline in four groups of four k-steps, pinned with sched_barrier: the loads of group g + 2 are issued BEFORE the MFMAs of
+                // group g, so they are in flight while the wave waits for the matrix pipe (all 16 waves run this in lockstep: with every load
+                // ahead of every MFMA a streamed product costs 3.6 k cycles, pipelined 3.4 k, against 2.1 k for its MFMAs alone and 1.3 k for its loads alone --
+                // tools/micro/gj_bench.hip; staggering the odd waves by s_sleep made it slower).
                 float fa[16], fb[16];
-#pragma unroll
-                for (int u = 0; u < 16; ++u) fa[u] = qa[u * ua], fb[u] = qb[u * ub];
                 f32x4 acc1 = {0, 0, 0, 0};
-#pragma unroll
-                for (int u = 0; u < 16; u += 2) {
-                    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u], fb[u], acc, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[u + 1], fb[u + 1], acc1, 0, 0, 0);
-                }
+#define AX_LD(G)                                  \
+    _Pragma("unroll") for (int u = 4 * (G); u < 4 * (G) + 4; ++u) fa[u] = qa[u * ua], fb[u] = qb[u * ub];
+#define AX_MM(G)                                                                                  \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * (G)], fb[4 * (G)], acc, 0, 0, 0);             \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * (G) + 1], fb[4 * (G) + 1], acc1, 0, 0, 0);   \
+    acc = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * (G) + 2], fb[4 * (G) + 2], acc, 0, 0, 0);     \
+    acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[4 * (G) + 3], fb[4 * (G) + 3], acc1, 0, 0, 0);
+                AX_LD(0) AX_LD(1)
+                __builtin_amdgcn_sched_barrier(0);
+                AX_LD(2)
+                AX_MM(0)
+                __builtin_amdgcn_sched_barrier(0);
+                AX_LD(3)
+                AX_MM(1)
+                __builtin_amdgcn_sched_barrier(0);
+                AX_MM(2)
+                AX_MM(3)
+#undef AX_LD
+#undef AX_MM
                 acc += acc1;
                 float* q = &C[(i0 + 4 * hi) * ldc + j0 + lo];
                 if (beta != 0.f) {
@@ -1548,9 +1564,8 @@ template <typename R, bool FULL> __device__ __forceinline__ void fold_step(Fold<
     t = block_sum<R>(t, g.rowbuf, tid);
     g.z += (R)-0.5 * (q0 + t) - ldR - (R)(0.5 * LOG_2PI) * dim;
     if (FULL) gemm<true, false>(d, d, d, g.T1, ldd, g.F, ldd, g.J, ldd, (R)1, (R)1, tid, (const R*)nullptr, 0, false);  // J + FA^T (M FA)
-    symmetrise<R>(g.C, ldd, d, tid);
+    symmetrise<R>(g.C, ldd, d, tid);  // (its barrier also closes the J product; J itself is symmetrised once, when the chunk's aggregate is stored)
     FOLD_TICK(5);
-    if (FULL) symmetrise<R>(g.J, ldd, d, tid);
     R* sw = g.F;
     g.F = g.Fn;
     g.Fn = sw;
@@ -1644,7 +1659,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_fold_reduce(Filte
         for (int q = tid & 63; q < d; q += 64) {
             e[r * d + q] = g.A[r * ldd + q];
             e[d * d + d + r * d + q] = g.C[r * ldd + q];
-            e[2 * d * d + 2 * d + r * d + q] = g.J[r * ldd + q];
+            e[2 * d * d + 2 * d + r * d + q] = r == q ? g.J[r * ldd + r] : (R)0.5 * (g.J[r * ldd + q] + g.J[q * ldd + r]);  // J = sum of FA^T M FA: symmetric up to rounding
         }
     for (int k = tid; k < d; k += NT) e[d * d + k] = g.b[k], e[2 * d * d + d + k] = g.eta[k];
     if (tid == 0) e[ne - 1] = g.z;

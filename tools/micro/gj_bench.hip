@@ -28,6 +28,41 @@ template <typename R> __global__ void __launch_bounds__(NT) kb(R* out, long long
         if (mode == 1) (void)chol<R>(Z, ldz, d, nullptr, invd, dg, flag, tid);
         if (mode == 2) trsm_l<R>(Z, ldz, d, pinv, Z + d, ldz, d + 2, tid);
         if (mode == 3) gemm<false, false>(d, d, d, Z, ldz, Z + d, ldz, Z + 2 * d, ldz, (R)1, (R)0, tid);
+        if (mode == 5) {  // eight independent products back to back, one barrier: the steady-state cost of a product
+#pragma unroll 1
+            for (int q = 0; q < 8; ++q) gemm<false, false>(d, d, d, Z, ldz, Z + d, ldz, Z + 2 * d, ldz, (R)1, (R)0, tid, (const R*)nullptr, 0, false);
+            __syncthreads();
+        }
+        if (mode == 6) {  // matrix cores alone: 8 x 16 MFMAs per wave on two accumulators, operands already in registers
+            const float a0 = (float)Z[tid], b0 = (float)Z[tid + 7];
+            f32x4 c0 = {0, 0, 0, 0}, c1 = {0, 0, 0, 0};
+#pragma unroll 1
+            for (int q = 0; q < 8; ++q) {
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b0, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x4f32(b0, a0, c1, 0, 0, 0);
+                }
+            }
+            Z[tid] = (R)(c0[0] + c1[1] + c0[2] + c1[3]);
+            __syncthreads();
+        }
+        if (mode == 7) {  // fragment loads alone: 8 x 32 LDS reads per lane in the K = 64 pattern
+            const int lane = tid & 63, wv = tid >> 6, lo = lane & 15, hi = lane >> 4, i0 = (wv >> 2) << 4, j0 = (wv & 3) << 4;
+            float acc = 0;
+#pragma unroll 1
+            for (int q = 0; q < 8; ++q) {
+                const float* qa = (const float*)Z + (i0 + lo) * ldz + 16 * hi + q;
+                const float* qb = (const float*)Z + d + 16 * hi * ldz + j0 + lo + q;
+                float fa[16], fb[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) fa[u] = qa[u], fb[u] = qb[u * ldz];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) acc += fa[u] * fb[u];
+            }
+            Z[tid] = (R)acc;
+            __syncthreads();
+        }
         if (mode == 4) (void)spd_solve<R>(Z, ldz, d, nsolve > 0 ? nsolve : 2 * d + 2, nullptr, rowbuf, pinv, (R*)nullptr, tid, true);
         tot += clock64() - t0;
     }
@@ -40,8 +75,8 @@ int main() {
     const int d = 64, iters = 50;
     const size_t lds = 120 * 1024;
     hipFuncSetAttribute((const void*)kb<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const char* names[] = {"gj_solve [W|A|C|v]", "chol", "trsm_l (d+2 cols)", "gemm 64^3", "spd_solve [S|H|r|r]"};
-    for (int mode = 0; mode < 5; ++mode) {
+    const char* names[] = {"gj_solve [W|A|C|v]", "chol", "trsm_l (d+2 cols)", "gemm 64^3", "spd_solve [S|H|r|r]", "8 x gemm 64^3, one barrier", "8 x 16 MFMAs per wave, no loads", "8 x 32 fragment loads per lane, no MFMA"};
+    for (int mode = 0; mode < 8; ++mode) {
         hipLaunchKernelGGL(kb<float>, dim3(1), dim3(NT), lds, 0, out, cyc, d, iters, mode, 0);
         hipDeviceSynchronize();
         long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
