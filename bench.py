@@ -9,15 +9,18 @@ seconds (independent chains: weak scaling, no data-path collective; torch.distri
 max-over-ranks and the final chain-gather).
 
 On the same JSON line:
-  roofline      the kernel group that takes most of the timed region, timed with HIP events on the library's stream INSIDE the timed
-                region (auxssm_prof_*, every group bracketed); `achieved` = the bytes THAT group has to move (its per-chain inputs read
-                once + its outputs written once + chain-shared tables once; DESIGN.md section 5 lists the per-step reals of every
-                group) / its average duration.  `traffic` = HBM bytes from the committed PMC passes of the same kernels, with the
+  roofline      the kernel group that takes most of the step, timed LIVE with HIP events on the library's stream inside the timed region
+                (auxssm_prof_*, one event pair per launch of that group); `achieved` = the bytes THAT group has to move (its per-chain
+                inputs read once + its outputs written once + chain-shared tables once; DESIGN.md section 4 lists the per-step reals of
+                every group) / its average duration.  `traffic` = HBM bytes from the committed PMC passes of the same kernels, with the
                 file it came from (null when no pass matches the kernels of this build).
-  kernels       every group's average ms per step and its own algorithmic GB/s (the whole sweep, not only the dominant group).
+  kernels       every group's average ms per step and its own algorithmic GB/s, from an UNTIMED profile pass of up to 3 steps right
+                before the timed region (bracketing every group with events inside the timed region costs 2.7 % of the headline); the
+                roofline group's entry is its live measurement.
   general_path  the same workload with nothing hoisted out of the chain loop (AUXSSM_OPT_SHARE_MODEL = 0: what every model with
-                chain-specific dynamics runs), with its own `roofline` on the filter scan: SURVEY 8(d)'s K3 bytes are reported as
-                `k3_equivalent_GBps`, never as the HBM fraction.
+                chain-specific dynamics runs), with its own `roofline` on the filter's associative scan, priced at SURVEY 8(d)'s K3
+                bytes (the reference's element buffer in, filtered moments out).  This build never materialises the elements, so the
+                PMC `traffic` is BELOW that figure.
   secondary     bounded legs on the other BASELINE configs, each with its own roofline: C3 cSMC (HBM), C4 Lorenz Kalman + cSMC with a
                 FIXED total of 64 chains sharded over the ranks (parallel.shard_chains), C5 wide-state filter (MFMA flops).
   cpu_baseline  oracle/kalman_seq.c -- the reference's SEQUENTIAL sweep (its CPU code path) restated in C, chains over OpenMP threads
@@ -177,24 +180,46 @@ class Ctx:
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
         return float(t.item())
 
-    def timed(self, step, steps, warmup, prof=True):
+    def timed(self, step, steps, warmup, prof=True, focus=None):
         """`warmup` untimed steps, then EXACTLY `steps` steps between barrier + synchronize pairs; max over ranks.
-        Returns (seconds, {group: (launches, total ms)})."""
+        Returns (seconds, {group: (launches, total ms)}) with the totals scaled to `steps` steps.
+        Per-group times come from an UNTIMED profile pass (up to 3 extra steps with one HIP-event pair per launch group, right before the
+        timed region): recording ~20 events per step inside the timed region costs 2.7 % of the headline (10 % at one chain).  Inside the
+        timed region only ONE group is measured live -- `focus(per_step_ms) -> name` picks it (default: the slowest), it is the group
+        `roofline` describes -- and its live measurement replaces the profile-pass figure."""
         for k in range(warmup):
             step(k)
-        self.barrier()
+        groups, live_id = {}, None
         if prof:
-            self.handle.prof_enable(self.lib.K_ALL, 64 * (steps + 1))
+            pp = max(1, min(3, steps))
+            self.barrier()
+            self.handle.prof_enable(self.lib.K_ALL, 64 * (pp + 1))
+            for k in range(pp):
+                step(k)
+            self.barrier()
+            prof_pass = self.handle.prof_read_groups()
+            self.handle.prof_disable()
+            groups = {g: (n * steps / pp, ms * steps / pp) for g, (n, ms) in prof_pass.items()}
+            if groups:
+                per_step = {g: ms / steps for g, (n, ms) in groups.items()}
+                name = focus(per_step) if focus else max(per_step, key=per_step.get)
+                if name in self.lib.K_NAMES:
+                    live_id = self.lib.K_NAMES.index(name)
+        self.barrier()
+        if live_id is not None:
+            self.handle.prof_enable(live_id, 8 * (steps + 1))
         self.barrier()
         t0 = time.perf_counter()
         for k in range(steps):
             step(warmup + k)
         self.barrier()
         el = self.max_over_ranks(time.perf_counter() - t0)
-        groups = {}
-        if prof:
-            groups = self.handle.prof_read_groups()
+        if live_id is not None:
+            n, ms = self.handle.prof_read()
             self.handle.prof_disable()
+            if n:
+                groups[self.lib.K_NAMES[live_id]] = (n, ms)
+                self.live_group = self.lib.K_NAMES[live_id]
         return el, groups
 
     def close(self):
@@ -286,7 +311,10 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
     handle.set_option(_lib.OPT_SHARE_MODEL, int(share))
     keys = R.split(R.PRNGKey(2024 + ctx.rank + (0 if share else 7919)), steps + warmup + 1)
     delta = 0.5
-    el, groups = ctx.timed(lambda k: kernel(keys[k], state, delta), steps, warmup, prof=not args.no_prof)
+    mode_hint = "shared" if share and chains.chain_minor and C > 1 else "general"
+    # the roofline group: the slowest group of the step; on the general path always the filter's associative scan (the kernel north_star names)
+    focus = (lambda ps: "filter_scan" if "filter_scan" in ps else max(ps, key=ps.get)) if mode_hint == "general" else None
+    el, groups = ctx.timed(lambda k: kernel(keys[k], state, delta), steps, warmup, prof=not args.no_prof, focus=focus)
     handle.set_option(_lib.OPT_SHARE_MODEL, 1)
     s = np.dtype(dtype).itemsize
     mode = "shared" if share and chains.chain_minor and C > 1 else "general"
