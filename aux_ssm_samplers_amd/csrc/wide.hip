@@ -668,7 +668,8 @@ __device__ __forceinline__ void gj_solve_blk(R* Z, int ld, int n, int nct, R* pi
 // Replaces chol + trsm_l (+ trsm_lt) wherever the factor itself is not needed.  Needs n <= NWV * NRR, nct <= 256.
 // LDS scratch: rowbuf[2 (nct + 1)], piv[n] reals.  Returns ok (uniform); *half_logdet = 0.5 log|S| over the kept indices.
 template <typename R, int NRR>
-__device__ __forceinline__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free) {
+__device__ __forceinline__ bool spd_solve_t(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid, bool z_free,
+                                            R* Lout = nullptr, int ldl = 0) {
     const int ti = tid >> 6, tj = tid & 63;
     // blocked elimination (the scheme of gj_solve_blk with the pivot of column k fixed to row k: no search at all): 16 pivots per three
     // barriers, trailing update on the matrix cores; scratch carved from the LDS image of Z, which is free while Z lives in registers
@@ -703,6 +704,8 @@ __device__ __forceinline__ bool spd_solve_t(R* Z, int ld, int n, int nct, const 
                     const R inv = rcp_nr(pv);
                     const bool me = r == pr;
                     const R f = me ? (R)0 : pz[j] * inv;
+                    // the multipliers below the pivot are the columns of the unit-lower factor of S = L D L^T (blocked path only, see chol_blk_n2n)
+                    if (Lout && valid && r > pr) Lout[r * ldl + pr] = f;
 #pragma unroll
                     for (int jj = j + 1; jj < NB; ++jj) pz[jj] -= f * bcast(pz[jj], pr);
 #pragma unroll
@@ -1737,6 +1740,28 @@ template <typename R> __device__ __forceinline__ void chol_n2n(R* Lc, int ld, in
         for (int q = tid & 63; q < n; q += 64) Lc[r * ld + q] = (q <= r && ok) ? nan_to_num<R>(Lc[r * ld + q]) : (R)0;
     __syncthreads();
 }
+// The same factor from the BLOCKED SPD elimination (41 k cycles at n = 64 against 87 k for the column-by-column Cholesky above): eliminating
+// S without pivoting is S = L' D L'^T with the multipliers below each pivot as the columns of the unit-lower L' and the pivots as D, so
+// chol(S) = L' sqrt(D).  X: S in full storage on entry, the nan_to_num'ed lower factor on exit (all zero if a pivot is <= 0 or NaN, as
+// chol_n2n).  Zs: scratch of n x ldp_(n + 1) reals at least (the elimination runs on a copy with one dummy right-hand side).
+template <typename R> __device__ __forceinline__ void chol_blk_n2n(R* X, int ld, int n, R* Zs, int ldzs, R* rowbuf, R* piv, R* invd, R* dg, int* flag, int tid) {
+    const int nct = n + 1;
+    if (!(NWV == 16 && n >= 32 && n <= 64 && blk_scratch(n, nct) <= (size_t)n * ldzs)) {
+        chol_n2n<R>(X, ld, n, invd, dg, flag, tid);
+        return;
+    }
+    for (int r = tid / 64; r < n; r += NWV)
+        for (int q = tid & 63; q <= n; q += 64) Zs[r * ldzs + q] = q < n ? X[r * ld + q] : (R)0;
+    __syncthreads();
+    const bool ok = spd_solve_t<R, 4>(Zs, ldzs, n, nct, nullptr, rowbuf, piv, (R*)nullptr, tid, true, X, ld);
+    for (int r = tid / 64; r < n; r += NWV)
+        for (int q = tid & 63; q < n; q += 64) {
+            R v = 0;
+            if (ok && q <= r) v = nan_to_num<R>(q == r ? sqrt_(piv[r]) : X[r * ld + q] * sqrt_(piv[q]));
+            X[r * ld + q] = v;
+        }
+    __syncthreads();
+}
 template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(SampleArgs a, R* __restrict__ elem) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, T = a.d.T;
@@ -1768,14 +1793,11 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = r == q ? P[r * ldd + r] : (R)0.5 * (P[r * ldd + q] + P[q * ldd + r]);
         __syncthreads();
-        chol_n2n<R>(X, ldd, d, invd, dg, flag, tid);
+        chol_blk_n2n<R>(X, ldd, d, Z, ldz, rowbuf, piv, invd, dg, flag, tid);
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) e[r * d + q] = 0;
-        for (int k = tid; k < d; k += NT) {
-            R v = m[k];
-            for (int q = 0; q <= k; ++q) v += X[k * ldd + q] * eps[q];
-            e[d * d + k] = v;
-        }
+        gemv<R, false>(d, d, X, ldd, eps, tv, (R)1, (R)0, tid);  // Lc eps (the factor's upper part is zero)
+        for (int k = tid; k < d; k += NT) e[d * d + k] = m[k] + tv[k];
         return;
     }
     load_mat<R>(F, ldd, at<R>(a.Fs, c, t, b), d, d, tid);
@@ -1806,18 +1828,16 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     __syncthreads();
     gemm<false, true>(d, d, d, T1, ldd, G, ldd, X, ldd, (R)-1, (R)1, tid);
     symmetrise<R>(X, ldd, d, tid);
-    chol_n2n<R>(X, ldd, d, invd, dg, flag, tid);
+    chol_blk_n2n<R>(X, ldd, d, Z, ldz, rowbuf, piv, invd, dg, flag, tid);
     // inc = m - G (F m + b) + Lc eps  (:108-112)
     gemv<R, false>(d, d, F, ldd, m, pm, (R)1, (R)0, tid);
     for (int k = tid; k < d; k += NT) pm[k] += bd[k];
     __syncthreads();
-    gemv<R, false>(d, d, G, ldd, pm, tv, (R)1, (R)0, tid);
+    gemv<R, false>(d, d, G, ldd, pm, tv, (R)1, (R)0, tid, false);
+    gemv<R, false>(d, d, X, ldd, eps, invd, (R)1, (R)0, tid, false);  // Lc eps (upper part of the factor is zero; invd is free after the factorisation)
+    __syncthreads();
     store_mat<R>(e, G, ldd, d, d, tid);
-    for (int k = tid; k < d; k += NT) {
-        R v = m[k] - tv[k];
-        for (int q = 0; q <= k; ++q) v += X[k * ldd + q] * eps[q];
-        e[d * d + k] = v;
-    }
+    for (int k = tid; k < d; k += NT) e[d * d + k] = m[k] - tv[k] + invd[k];
 }
 
 // _sampling_op_impl (sampling.py:51-55): acc = later times already composed, cur = this step: G = Gc Ga, e = Gc ea + ec
@@ -1864,6 +1884,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_reduce(cons
     store_mat<R>(q, g.G, ldd, d, d, tid);
     for (int k = tid; k < d; k += NT) q[d * d + k] = g.e[k];
 }
+// One workgroup per sequence walks the chunk aggregates in order.  Only e of the exclusive prefix is handed down (the final pass composes
+// e' = G e + e_c), so the walk is a mat-vec per aggregate, no product; the next aggregate's record is fetched into registers while the
+// current one is applied (d <= 64: four entries of G per lane; wider states load it directly).
 template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_aggs(const R* __restrict__ aggs, R* __restrict__ pre, int nchunk, int d) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, s = blockIdx.x;
@@ -1872,13 +1895,39 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_aggs(const 
     carve_sample<R>(L, g, d);
     const long long ne = (long long)d * d + d;
     const int ldd = ldp_(d);
-    load_mat<R>(g.G, ldd, aggs + (long long)s * nchunk * ne, d, d, tid);
-    load_vec<R>(g.e, aggs + (long long)s * nchunk * ne + d * d, d, tid);
+    const R* base = aggs + (long long)s * nchunk * ne;
+    load_vec<R>(g.e, base + d * d, d, tid);
+    const bool small = d <= 64;
+    const int cq = min(tid & 63, d - 1);
+    R pg[4], pe = 0;
+    auto fetch = [&](int ch) {
+        const R* q = base + (long long)ch * ne;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) pg[k] = q[(long long)min((tid >> 6) + NWV * k, d - 1) * d + cq];
+        pe = q[d * d + min(tid, d - 1)];
+    };
+    if (small && nchunk > 2) fetch(1);
     for (int ch = 1; ch < nchunk; ++ch) {
         R* q = pre + ((long long)s * nchunk + ch) * d;
         for (int k = tid; k < d; k += NT) q[k] = g.e[k];
-        __syncthreads();
-        if (ch + 1 < nchunk) sample_combine_w<R>(g, aggs + ((long long)s * nchunk + ch) * ne, d, true, tid);
+        if (ch + 1 < nchunk) {
+            if (small) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int r = (tid >> 6) + NWV * k;
+                    if (r < d && (tid & 63) < d) g.Gc[r * ldd + (tid & 63)] = pg[k];
+                }
+                if (tid < d) g.ec[tid] = pe;
+                __syncthreads();
+                if (ch + 2 < nchunk) fetch(ch + 1);
+                gemv<R, false>(d, d, g.Gc, ldd, g.e, g.tv, (R)1, (R)0, tid);
+                for (int k = tid; k < d; k += NT) g.e[k] = g.tv[k] + g.ec[k];
+                __syncthreads();
+            } else {
+                __syncthreads();
+                sample_combine_w<R>(g, base + (long long)ch * ne, d, false, tid);
+            }
+        }
     }
 }
 template <typename R> __global__ void __launch_bounds__(NT) wk_sscan_down(SampleArgs a, const R* __restrict__ elem, const R* __restrict__ pre, int E, int nchunk) {
