@@ -1978,8 +1978,32 @@ __device__ __forceinline__ void gauss2(const R* __restrict__ cov, int n, const u
         Z[k * ldz + n + 1] = (sk || !r2) ? (R)0 : r2[k];
     }
     const bool bad1 = __syncthreads_or(b1), bad2 = __syncthreads_or(b2);
+    // a diagonal covariance (the usual noise model; the kept entries only) needs no elimination: the solve is a division per component
+    int offd = 0;
+    for (int i = tid / 64; i < n; i += NWV)
+        for (int j = tid & 63; j < i; j += 64) offd |= Z[i * ldz + j] != (R)0 ? 1 : 0;
+    const bool diag = !__syncthreads_or(offd);
     R hl;
-    const bool ok = spd_solve<R>(Z, ldz, n, nct, skip, rowbuf, piv, &hl, tid, true);
+    bool ok;
+    if (diag) {
+        int bad = 0;
+        R hs = 0;
+        for (int k = tid; k < n; k += NT) {
+            const bool sk = skip && skip[k];
+            const R ck = Z[k * ldz + k];
+            if (!sk) {
+                bad |= !(ck > (R)0);
+                hs += (R)0.5 * log_(ck);
+            }
+            const R inv = sk ? (R)0 : (R)1 / ck;
+            Z[k * ldz + n] *= inv;
+            Z[k * ldz + n + 1] *= inv;
+        }
+        ok = !__syncthreads_or(bad);
+        hl = block_sum<R>(hs, rowbuf, tid);
+    } else {
+        ok = spd_solve<R>(Z, ldz, n, nct, skip, rowbuf, piv, &hl, tid, true);
+    }
     R q1 = 0, q2 = 0;
     for (int k = tid; k < n; k += NT) {
         q1 += r1[k] * Z[k * ldz + n];

@@ -496,6 +496,33 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
                 pass
         out["runs"].append(ent)
         del dl, yd, ms, Ps, ell
+    # one whole pass of the path on one chain (filter -> pathwise sampler -> joint log-density, what a sweep of this size strings together):
+    # device time of each launch group (HIP events), host <-> device copies of the NumPy front end excluded
+    try:
+        import aux_ssm_samplers_amd._primitives.kalman as P
+        lg = P.LGSSM(*[np.ascontiguousarray(a, f32) for a in lg64])
+        uu, eps = u.astype(f32), np.random.default_rng(0).standard_normal((T, d)).astype(f32)
+        tm = {}
+        for rep in range(2):
+            for kid, name in ((_lib.K_FILTER_INIT, "filter_init"), (_lib.K_FILTER_SCAN, "filter_scan")):
+                handle.prof_enable(kid, 8)
+                fm, fP, fell = P.filtering(uu, lg, True)
+                tm[name] = handle.prof_read()[1]
+                handle.prof_disable()
+            for kid, name in ((_lib.K_SAMPLE_INIT, "sample_init"), (_lib.K_SAMPLE_SCAN, "sample_scan")):
+                handle.prof_enable(kid, 8)
+                xs = P.sampling(None, fm, fP, lg, True, eps=eps)
+                tm[name] = handle.prof_read()[1]
+                handle.prof_disable()
+            handle.prof_enable(_lib.K_LOGPDF, 8)
+            P.posterior_logpdf(uu, xs, fell, lg)
+            tm["logpdf"] = handle.prof_read()[1]
+            handle.prof_disable()
+        tot = sum(tm.values())
+        out["one_chain_pass"] = dict(kernels_ms={k: round(v, 3) for k, v in tm.items()}, total_ms=round(tot, 3), passes_per_s=round(1e3 / tot, 1),
+                                     note="filter + pathwise sampler + joint log-density, device time of the launch groups (second repetition)")
+    except Exception as e:
+        out["one_chain_pass"] = {"error": f"{type(e).__name__}: {e}"}
     return out
 
 

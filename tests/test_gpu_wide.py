@@ -208,6 +208,13 @@ def test_diagonal_observation_noise_with_missing_data(P, d, p, T):
         npt.assert_allclose(ms, oms, rtol=1e-8, atol=1e-10)
         npt.assert_allclose(Ps, oPs, rtol=1e-8, atol=1e-10)
         npt.assert_allclose(ell, oell, rtol=1e-9)
+    # the joint log-density takes diagonal covariances without elimination too (wk_logpdf / gauss2): diagonal Q as well, NaN rows kept
+    Qd = np.stack([np.diag(0.1 + rng.random(d)) for _ in range(T - 1)])
+    lgd = (m0, P0, Fs, Qd, bs, Hs, Rs, cs)
+    xr = rng.standard_normal((T, d))
+    npt.assert_allclose(P.log_likelihood(ys, xr, P.LGSSM(*lgd)), K.log_likelihood(ys, xr, lgd), rtol=1e-9)
+    npt.assert_allclose(P.prior_logpdf(xr, P.LGSSM(*lgd)), K.prior_logpdf(xr, lgd), rtol=1e-9)
+    npt.assert_allclose(P.posterior_logpdf(ys, xr, oell, P.LGSSM(*lgd)), K.posterior_logpdf(ys, xr, oell, lgd), rtol=1e-9)
 
 
 def test_element_path_kept_for_sizes_the_fold_does_not_hold():
