@@ -314,6 +314,9 @@ template <typename R_, int D> struct FilterOp {
 // ObsInfoRow of the time step (kalman_math.h::filter_elem_aux: d x d work only, no p x p factorisation per chain).  Both scan passes
 // then stream 2d (+ per-chain dynamics) reals per step instead of writing and re-reading the (3d^2+2d)-real element, and the element
 // kernel disappears.  WRITE_U: the pass that also stores u for the log-density kernel (the final pass).
+#ifndef AUXSSM_FLY_DOWN_WAVES
+#define AUXSSM_FLY_DOWN_WAVES 1  // 2 was measured: 10 spilled registers, filter scan 2.17 -> 2.73 ms at C2 / 256 chains
+#endif
 template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp<R_, D> {
     using R = R_;
     using Full = typename FilterOp<R_, D>::Full;
@@ -365,6 +368,7 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
     }
     // ---- chunk-serial passes: fold the raw step onto the prefix (kalman_math.h::filter_fold_step / filter_apply_step) ----
     static constexpr bool kFold = true;
+    static constexpr int kDownWaves = AUXSSM_FLY_DOWN_WAVES;  // the (b, C, z) walk needs 264 unified registers at fp64 d = 4: 8 over two waves per SIMD (forcing it costs more than it gains)
     using Pre = typename FilterOp<R_, D>::Pre;
     static constexpr int DS = symsize(D);
     // the prefix entering position 0 of the whole scan is the t = 0 posterior (m0+, P0+): a constant map (A = 0)

@@ -444,8 +444,11 @@ __global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, S
     }
     Op::store_rec((R*)sb.agg + ((long long)s * lay.nchunk + ch) * Full::NPAD, acc);
 }
+// (operators may ask for two waves per SIMD in the down pass -- Op::kDownWaves -- when their walk is within a few registers of that budget)
+template <class Op, typename = void> struct DownWaves { static constexpr int value = 1; };
+template <class Op> struct DownWaves<Op, decltype((void)Op::kDownWaves)> { static constexpr int value = Op::kDownWaves; };
 template <class Op>
-__global__ void __launch_bounds__(TB_CM) k_scan_down_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
+__global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
     using R = typename Op::R;
     using Full = typename Op::Full;
     using Pre = typename Op::Pre;
