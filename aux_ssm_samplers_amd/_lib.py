@@ -97,6 +97,7 @@ def load():
         "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_kalman_sweep_dd": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_kalman_sweep_keyed": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, vp, P(C.c_uint32), i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_pit_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),

@@ -18,6 +18,7 @@
 // The pathwise sampler (sampling.py:51-55) is the same recursion backwards in time: x_t = G_t x_{t+1} + inc_t, G_t chain-shared.
 // Lanes run over chains (chain-minor buffers), table rows are wave-uniform scalar loads.
 #pragma once
+#include "rng.h"
 #include "kalman_bodies.h"
 
 namespace ax {
@@ -139,13 +140,19 @@ template <typename R, int D, int P> AX_HD void body_gain_tab(const FilterArgs& a
 }
 
 // the observation of chain s at time t (>= 1): given, or the concatenated auxiliary observation built on the fly (FilterArgs::aux_*)
-template <typename R, int D, int P, bool WRITE_U> AX_HD void aff_obs(const FilterArgs& a, int s, long long t, R* y) {
+// GEN: this is the FIRST reader of eps_aux[c, t] and the sweep is keyed (FilterArgs::aux_gen): draw it here and store it for the later readers
+template <typename R, int D, int P, bool WRITE_U, bool GEN = false> AX_HD void aff_obs(const FilterArgs& a, int s, long long t, R* y) {
     const int c = s / a.d.B, b = s % a.d.B;
     if (a.aux_on) {
         if constexpr (P > D) {
             R xv[D], ev[D], uv[D];
             rd<R, D>(a.aux_x, c, t, b, xv);
-            rd<R, D>(a.aux_eps, c, t, b, ev);
+            if constexpr (GEN) {
+                normals_cm<R, D>(a.gen_k0, a.gen_k1, (long long)c * a.aux_eps.sc + t * a.aux_eps.st + (long long)b * a.aux_eps.sb, a.aux_eps.se, ev);
+                wr<R, D>(a.aux_eps, c, t, b, ev);
+            } else {
+                rd<R, D>(a.aux_eps, c, t, b, ev);
+            }
 #pragma unroll
             for (int k = 0; k < D; ++k) uv[k] = xv[k] + (R)arg_aux_shd(a) * ev[k], y[k] = uv[k];
             if constexpr (WRITE_U) wr<R, D>(a.aux_u, c, t, b, uv);
@@ -178,7 +185,8 @@ template <typename R_, int D, int P> struct FilterMeanOp {
     static AX_HD void fold(const Args& a, int s, int i, R* h) {
         const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
         R y[P];
-        aff_obs<R, D, P, false>(a, s, (long long)i + 1, y);
+        if (a.aux_gen) aff_obs<R, D, P, false, true>(a, s, (long long)i + 1, y);  // (the reduce pass reads every position first)
+        else aff_obs<R, D, P, false>(a, s, (long long)i + 1, y);
         R o[D];
 #pragma unroll
         for (int r = 0; r < D; ++r) {
@@ -249,13 +257,22 @@ template <typename R_, int D> struct SampleAffOp {
 #pragma unroll
         for (int k = 0; k < D; ++k) h[k] = 0;  // G_{T-1} = 0: the first position ignores the incoming state
     }
-    static AX_HD void fold(const Args& a, int s, int j, R* h) {
+    static AX_HD void fold(const Args& a, int s, int j, R* h) {  // the reduce pass: the first reader of eps
+        if (a.eps_gen) step<true>(a, s, j, h);
+        else step<false>(a, s, j, h);
+    }
+    template <bool GEN> static AX_HD void step(const Args& a, int s, int j, R* h) {
         const int c = s / a.d.B, b = s % a.d.B;
         const long long t = (long long)a.d.T - 1 - j;
         const UniformRow<R> row = uniform_row<R>((const R*)a.tab + t * T::NPAD);
         R m[D], eps[D], o[D];
         rd<R, D>(a.ms, c, t, b, m);
-        rd<R, D>(a.eps, c, t, b, eps);
+        if constexpr (GEN) {
+            normals_cm<R, D>(a.gen_k0, a.gen_k1, (long long)c * a.eps.sc + t * a.eps.st + (long long)b * a.eps.sb, a.eps.se, eps);
+            wr<R, D>(a.eps, c, t, b, eps);
+        } else {
+            rd<R, D>(a.eps, c, t, b, eps);
+        }
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             R v = -row[T::oGb + i];
@@ -271,7 +288,7 @@ template <typename R_, int D> struct SampleAffOp {
         for (int i = 0; i < D; ++i) h[i] = o[i];
     }
     static AX_HD void walk(const Args& a, int s, int j, R* h, R&) {
-        fold(a, s, j, h);
+        step<false>(a, s, j, h);
         wr<R, D>(a.xs, s / a.d.B, (long long)a.d.T - 1 - j, s % a.d.B, h);
     }
 };

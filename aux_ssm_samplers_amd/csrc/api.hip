@@ -47,6 +47,30 @@ void* ws_take(auxssm_ctx* h, size_t bytes) {
     return h->ws + off;
 }
 
+// about four waves per SIMD of (chain tile, chunk) lanes (measured at C2 x 256 chains: E = 64 beats 16 / 32 by 4 %): a chain's state is
+// a handful of registers, the passes stream their inputs
+AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
+    AffPlan p;
+    if (!parallel || N <= 2) {
+        p.E = N > 0 ? N : 1;
+        p.nchunk = 1;
+        return p;
+    }
+    const long long stiles = (S + 64 /* TB_CM */ - 1) / 64 /* TB_CM */;
+    long long want = (long long)h->num_cu * 4 * 4 / stiles;  // chunks
+    if (want < 1) want = 1;
+    long long E = (N + want - 1) / want;
+    if (E < 16) E = 16;
+    if (E > 1024) E = 1024;
+    if (const char* ev = getenv("AUXSSM_AFF_E")) {  // tuning/debug override
+        const long long v = atoll(ev);
+        if (v >= 1 && v <= 65536) E = v;
+    }
+    p.E = (int)E;
+    p.nchunk = (int)((N + E - 1) / E);
+    return p;
+}
+
 ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
     ScanPlan p;
     if (!parallel || n <= 2) {
@@ -214,6 +238,17 @@ static void fill_logpdf_args(LogpdfArgs& a, const auxssm_dims* d, const auxssm_l
     a.dx = d->dx; a.dy = d->dy;
 }
 
+template <typename R>
+__global__ void k_rng_sweep(uint32_t a0, uint32_t a1, uint32_t b0, uint32_t b1, uint32_t c0, uint32_t c1, long long n, long long nu, unsigned g1,
+                            R* eps_aux, R* eps_samp, R* u_acc);  // (defined below)
+// the noise fills of a keyed sweep: the first n entries of eps_aux and eps_samp and the nu uniforms, on the handle's stream
+template <typename R> static void launch_rng_sweep(auxssm_ctx* h, const uint32_t* keys, long long n, long long nu, void* eps_aux, void* eps_samp, void* u_acc) {
+    const unsigned g1 = (unsigned)(((n + 1) / 2 + 255) / 256), g2 = (unsigned)(((nu + 1) / 2 + 255) / 256);
+    ProfScope ps(h, AUXSSM_K_RNG);
+    hipLaunchKernelGGL((k_rng_sweep<R>), dim3(2 * g1 + g2), dim3(256), 0, h->stream, keys[0], keys[1], keys[2], keys[3], keys[4], keys[5], n, nu, g1,
+                       (R*)eps_aux, (R*)eps_samp, (R*)u_acc);
+}
+
 // ---- sweep helper kernels (pure data movement / reductions; runtime sizes) --------------------------------
 
 // device-resident step size: blk = {delta, sqrt(delta / 2)} from the caller's device scalar (auxssm_kalman_sweep_dd)
@@ -360,7 +395,7 @@ template <typename R> static int launch_select(auxssm_ctx* h, int C, int T, int 
 
 template <typename R>
 static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
-                           double delta, const double* dptr, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
+                           double delta, const double* dptr, const uint32_t* keys, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
                            const void* u_acc, int32_t* accepted, void* logs) {
     const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy, P = D + PO;
     // one path for the whole sweep: the register kernels when every piece is instantiated, else the wide-state path
@@ -429,6 +464,15 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     // In the chain-minor layout the filter builds u and the concatenated observation on the fly for t >= 1 (FilterArgs::aux_*), in
     // both of its modes (chain-shared parameters: gain-form recursion; otherwise: elements built inside the scan passes).
     const bool aux_fly = cm && T > 1 && !wide && aux_fly_enabled();
+    // Keyed sweep (auxssm_kalman_sweep_keyed): the noise is a function of the keys.  Where the chain-shared affine scans run, their reduce
+    // passes -- the first readers of eps_aux (t >= 1) and eps_samp -- GENERATE it and store it for the later readers (the fill kernel then
+    // only draws row t = 0 and the acceptance uniforms); everywhere else the fill kernel draws all of it first.  Same values either way.
+    bool gen = false;
+    if (keys) {
+        static const bool gen_on = !getenv("AUXSSM_NO_GEN");
+        gen = gen_on && aux_fly && shared_mode && parallel && (C % 2 == 0) && plan_aff(h, C, T - 1, 1).nchunk > 1 && plan_aff(h, C, T, 1).nchunk > 1;
+        launch_rng_sweep<R>(h, keys, gen ? (long long)D * C : (long long)C * T * D, C, const_cast<void*>(eps_aux), const_cast<void*>(eps_samp), const_cast<void*>(u_acc));
+    }
     {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
@@ -465,6 +509,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         fa.aux_yobs = cv(*yobs);
         fa.aux_shd = sqrt(0.5 * delta);
         fa.dptr = dptr;
+        if (gen) fa.aux_gen = 1, fa.gen_k0 = keys[0], fa.gen_k1 = keys[1];
     }
     rc = ke->filter(h, fa, parallel, ell);
     if (rc) return rc;
@@ -477,6 +522,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
     // the filtered covariances of this model do not depend on the chain when its parameters do not
     sa.ps_shared = shared_mode ? 1 : 0;
+    if (gen) sa.eps_gen = 1, sa.gen_k0 = keys[2], sa.gen_k1 = keys[3];
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;
     h->ws_off = mark;
@@ -1268,8 +1314,8 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
 
 // delta_dev != NULL: the step size is a device scalar of `dtype` (auxssm_kalman_sweep_dd); `delta` is then only a placeholder
 static int kalman_sweep_impl(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
-                             const auxssm_arr* yobs, double delta, const void* delta_dev, int parallel, int nan_policy, int layout, void* x,
-                             const void* eps_aux, const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
+                             const auxssm_arr* yobs, double delta, const void* delta_dev, const uint32_t* keys, int parallel, int nan_policy, int layout,
+                             void* x, const void* eps_aux, const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
     AX_NEED_H(h);
     int rc;
     if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true))) return rc;
@@ -1334,6 +1380,11 @@ static int kalman_sweep_impl(auxssm_handle h, int dtype, int model_kind, const a
         else hipLaunchKernelGGL((k_delta_block<double>), dim3(1), dim3(1), 0, h->stream, (const double*)delta_dev, h->dblock);
         dptr = h->dblock;
     }
+    if (keys && (lorenz || sv)) {  // these sweeps read the noise from the arrays: draw all of it first (auxssm_kalman_draw)
+        const long long nn = (long long)dims->C * dims->T * dims->dx;
+        if (dtype == AUXSSM_F32) launch_rng_sweep<float>(h, keys, nn, dims->C, const_cast<void*>(eps_aux), const_cast<void*>(eps_samp), const_cast<void*>(u_acc));
+        else launch_rng_sweep<double>(h, keys, nn, dims->C, const_cast<void*>(eps_aux), const_cast<void*>(eps_samp), const_cast<void*>(u_acc));
+    }
     if (lorenz) {
         rc = dtype == AUXSSM_F32 ? sweep_lorenz<float>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
                                  : sweep_lorenz<double>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
@@ -1342,8 +1393,8 @@ static int kalman_sweep_impl(auxssm_handle h, int dtype, int model_kind, const a
         rc = dtype == AUXSSM_F32 ? sweep_sv<float>(h, dtype, order, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
                                  : sweep_sv<double>(h, dtype, order, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     } else {
-        rc = dtype == AUXSSM_F32 ? sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
-                                 : sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, dptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
+        rc = dtype == AUXSSM_F32 ? sweep_lg_concat<float>(h, dtype, dims, model, yobs, delta, dptr, keys, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs)
+                                 : sweep_lg_concat<double>(h, dtype, dims, model, yobs, delta, dptr, keys, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted, logs);
     }
     return rc;
 }
@@ -1351,8 +1402,8 @@ static int kalman_sweep_impl(auxssm_handle h, int dtype, int model_kind, const a
 int auxssm_kalman_sweep(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
                         const auxssm_arr* yobs, double delta, int parallel, int nan_policy, int layout, void* x, const void* eps_aux,
                         const void* eps_samp, const void* u_acc, int32_t* accepted, void* logs) {
-    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, delta, nullptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted,
-                             logs);
+    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, delta, nullptr, nullptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc,
+                             accepted, logs);
 }
 int auxssm_kalman_sweep_dd(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
                            const auxssm_arr* yobs, const void* delta_dev, int parallel, int nan_policy, int layout, void* x, const void* eps_aux,
@@ -1361,8 +1412,18 @@ int auxssm_kalman_sweep_dd(auxssm_handle h, int dtype, int model_kind, const aux
         set_error("delta_dev must be a device pointer to one scalar of `dtype`");
         return AUXSSM_ERR_ARG;
     }
-    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, 1.0, delta_dev, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc, accepted,
-                             logs);
+    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, 1.0, delta_dev, nullptr, parallel, nan_policy, layout, x, eps_aux, eps_samp, u_acc,
+                             accepted, logs);
+}
+int auxssm_kalman_sweep_keyed(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
+                              const auxssm_arr* yobs, double delta, const void* delta_dev, const uint32_t* keys, int parallel, int nan_policy, int layout,
+                              void* x, void* eps_aux, void* eps_samp, void* u_acc, int32_t* accepted, void* logs) {
+    if (!keys) {
+        set_error("keys must point at six uint32: {aux0, aux1, samp0, samp1, acc0, acc1}");
+        return AUXSSM_ERR_ARG;
+    }
+    return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, delta_dev ? 1.0 : delta, delta_dev, keys, parallel, nan_policy, layout, x, eps_aux,
+                             eps_samp, u_acc, accepted, logs);
 }
 
 static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32_t k1, uint32_t stream, int64_t n, void* out) {

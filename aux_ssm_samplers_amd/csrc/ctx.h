@@ -87,6 +87,10 @@ struct ScanPlan {
     int nchunk;  // chunks per sequence
 };
 ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel);
+struct AffPlan {  // chunking of the chain-shared affine scans (kernels.hip.h: run_affine)
+    int E, nchunk;
+};
+AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel);
 
 typedef int (*filter_fn)(auxssm_ctx*, const FilterArgs&, int parallel, void* ell_out /*[C]*/);
 typedef int (*sample_fn)(auxssm_ctx*, const SampleArgs&, int parallel);

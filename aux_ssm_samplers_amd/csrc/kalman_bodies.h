@@ -122,6 +122,10 @@ struct FilterArgs {
     Arr aux_x{}, aux_eps{}, aux_u{}, aux_yobs{};
     double aux_shd = 0;
     const double* dptr = nullptr;  // device-resident step size: {delta, sqrt(delta / 2)} (auxssm_kalman_sweep_dd); null: the host values above
+    // aux_gen != 0 (auxssm_kalman_sweep_keyed): rows t >= 1 of aux_eps are GENERATED by the reduce pass (the first reader) from the key and
+    // written for the later readers (down pass, log-density); the values are those of auxssm_rng_normal(key, stream 0) at the same indices
+    int aux_gen = 0;
+    unsigned int gen_k0 = 0, gen_k1 = 0;
     const void* obs_tab = nullptr;  // general chain-minor path with aux_on: one ObsInfoRow per transition (kalman_math.h), elements built on the fly
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
@@ -451,6 +455,8 @@ struct SampleArgs {
     ScanLayout lay;
     int dx = 0;       // runtime size (wide.hip only)
     int ps_shared = 0;        // != 0: Ps (and Fs, Qs, bs) do not depend on the chain (filter ran on chain-shared parameters)
+    int eps_gen = 0;          // != 0: eps is generated by the reduce pass from (gen_k0, gen_k1) and written for the down pass (as FilterArgs::aux_gen)
+    unsigned int gen_k0 = 0, gen_k1 = 0;
     const void* tab = nullptr;  // then: one SampShared row per time step
 };
 

@@ -626,9 +626,6 @@ __global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, Scan
 // ---- chain-shared model parameters: per-chain affine scans (affine_shared.h) -------------------------------------------------------
 // grid of the per-chain passes: workgroup = one wave = 64 chains x one chunk of E positions.  Block id -> (chunk, chain tile) with
 // chunk % 8 in the low three bits, so the waves that read one chunk's table rows sit on one XCD (one L2 / scalar-cache fill per row).
-struct AffPlan {
-    int E, nchunk;
-};
 __device__ __forceinline__ bool decode_aff(int S, int nchunk, int& ch, int& s) {
     const int stiles = (S + TB_CM - 1) / TB_CM;
     const unsigned b = blockIdx.x, lo = b & 7u, rest = b >> 3;
@@ -716,29 +713,6 @@ __global__ void __launch_bounds__(TB_CM) k_aff_down(typename Op::Args a, ScanBuf
 #pragma unroll 1
     for (int j = j0; j < j1; ++j) Op::walk(a, s, opaque_uniform(j), h, acc);
     if (part) part[(long long)s * pl.nchunk + ch] = acc;
-}
-// about four waves per SIMD of (chain tile, chunk) lanes (measured at C2 x 256 chains: E = 64 beats 16 / 32 by 4 %): a chain's state is
-// a handful of registers, the passes stream their inputs
-inline AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
-    AffPlan p;
-    if (!parallel || N <= 2) {
-        p.E = N > 0 ? N : 1;
-        p.nchunk = 1;
-        return p;
-    }
-    const long long stiles = (S + TB_CM - 1) / TB_CM;
-    long long want = (long long)h->num_cu * 4 * 4 / stiles;  // chunks
-    if (want < 1) want = 1;
-    long long E = (N + want - 1) / want;
-    if (E < 16) E = 16;
-    if (E > 1024) E = 1024;
-    if (const char* ev = getenv("AUXSSM_AFF_E")) {  // tuning/debug override
-        const long long v = atoll(ev);
-        if (v >= 1 && v <= 65536) E = v;
-    }
-    p.E = (int)E;
-    p.nchunk = (int)((N + E - 1) / E);
-    return p;
 }
 template <typename R, int D> size_t aff_ws_bytes(const auxssm_ctx* h, int S, int N, int parallel) {
     const AffPlan pl = plan_aff(h, S, N, parallel);

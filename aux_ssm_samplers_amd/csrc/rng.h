@@ -133,4 +133,41 @@ template <typename R> AX_HD void stream_uniform2(uint32_t k0, uint32_t k1, uint3
     u1 = bits_to_uniform<R>(x1);
 }
 
+
+// ---- noise generated INSIDE its first consumer (chain-minor layout; auxssm_kalman_sweep_keyed) ----------------------------------------
+// The D normals of chain c at one time step sit at flat indices base + k stride (k < D) of a (T, D, C) array, base = (t D) C + c, stride = C:
+// chains c (even) and c + 1 share every Threefry block.  The lane pair splits the blocks (the even lane computes those of the even
+// components, the odd lane those of the odd ones, each both outputs) and swaps the halves with one DPP move, so a lane pays for D / 2 blocks
+// and gets the values auxssm_rng_normal(key, stream 0) puts at those indices, bit for bit.  Needs C even and both lanes of a pair active.
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ float swap_neighbour(float v) { return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true)); }
+__device__ __forceinline__ double swap_neighbour(double v) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(v), 0xB1, 0xF, 0xF, true), hi = __builtin_amdgcn_mov_dpp(__double2hiint(v), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+}
+#endif
+template <typename R, int D> AX_HD void normals_cm(uint32_t k0, uint32_t k1, long long base, long long stride, R* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const bool odd = base & 1;
+    const long long be = base - (odd ? 1 : 0);  // the even partner's index
+#pragma unroll
+    for (int k = 0; k + 1 < D; k += 2) {
+        const int kk = odd ? k + 1 : k;
+        R z0, z1;
+        stream_normal2<R>(k0, k1, 0, (unsigned long long)((be + kk * stride) >> 1), z0, z1);
+        const R recv = swap_neighbour(odd ? z0 : z1);
+        out[kk] = odd ? z1 : z0;
+        out[odd ? k : k + 1] = recv;
+    }
+    if (D & 1) {
+        R z0, z1;
+        stream_normal2<R>(k0, k1, 0, (unsigned long long)((be + (D - 1) * stride) >> 1), z0, z1);
+        out[D - 1] = odd ? z1 : z0;
+    }
+#else
+#pragma unroll
+    for (int k = 0; k < D; ++k) out[k] = stream_normal<R>(k0, k1, 0, (unsigned long long)(base + k * stride));
+#endif
+}
+
 }  // namespace ax

@@ -142,12 +142,23 @@ class DeviceChains:
 def _get_device_kernel(model, parallel, nan_policy="reference"):
     pol = {"reference": _lib.NAN_REFERENCE, "masked": _lib.NAN_MASKED}[nan_policy]
 
-    def sweep(handle, chains, delta, eps_aux, eps_samp, u_acc):
-        """One auxssm_kalman_sweep on resident buffers (all DeviceArray). Asynchronous."""
+    def sweep(handle, chains, delta, eps_aux, eps_samp, u_acc, keys=None):
+        """One auxssm_kalman_sweep on resident buffers (all DeviceArray). Asynchronous.  keys (three Threefry keys): the keyed sweep -- the
+        library draws the noise itself (into the three buffers), inside its first consumer where it can."""
         dl, ybuf, yarr = model.device(handle, chains.dtype)
         if "lorenz_par" in dl.bufs and dl.bufs["lorenz_par"].shape[0] not in (1, chains.C):
             raise ValueError(f"the model holds {dl.bufs['lorenz_par'].shape[0]} theta rows, the chains are {chains.C}")
         dims = _lib.Dims(chains.C, chains.T, 1, chains.dx, model.p_obs)
+        if keys is not None:
+            dev = isinstance(delta, _lib.DeviceArray)
+            if dev and (delta.dtype != np.dtype(chains.dtype) or delta.size < 1):
+                raise ValueError("a device-resident delta must be a DeviceArray of one scalar of the chains' dtype")
+            k6 = (C.c_uint32 * 6)(*[int(v) for k in keys for v in np.asarray(k, np.uint32).reshape(2)])
+            _lib.check(handle.lib.auxssm_kalman_sweep_keyed(
+                handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
+                1.0 if dev else float(delta), delta.ptr if dev else None, k6, int(bool(parallel)), pol, chains.layout, chains.x.ptr,
+                eps_aux.ptr, eps_samp.ptr, u_acc.ptr, chains.accepted.ptr, chains.logs.ptr))
+            return
         if isinstance(delta, _lib.DeviceArray):  # device-resident step size (one scalar of the chains' dtype): no host round trip
             if delta.dtype != np.dtype(chains.dtype) or delta.size < 1:
                 raise ValueError("a device-resident delta must be a DeviceArray of one scalar of the chains' dtype")
@@ -171,15 +182,17 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         resident = isinstance(state.x, DeviceChains)
         handle = state.x.handle if resident else _lib.default_handle()  # resident chains carry their device
         chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None)
-        if noise is None:
-            eps_aux, eps_samp, u_acc = draw(handle, key, chains)
+        keys = None
+        if noise is None:  # the keyed sweep: same values as draw() + sweep(), in one call
+            keys = _random.split(key, 3)
+            eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc
         else:
             shape = (chains.C, chains.T, chains.dx)
             eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc
             eps_aux.copy_from_host(chains._to_layout(np.asarray(noise["eps_aux"], chains.dtype)).reshape(eps_aux.shape))
             eps_samp.copy_from_host(chains._to_layout(np.asarray(noise["eps_samp"], chains.dtype)).reshape(eps_samp.shape))
             u_acc.copy_from_host(np.asarray(noise["u_accept"], chains.dtype).reshape(chains.C))
-        sweep(handle, chains, delta, eps_aux, eps_samp, u_acc)
+        sweep(handle, chains, delta, eps_aux, eps_samp, u_acc, keys)
         if resident:
             return KalmanSampler(x=chains, updated=chains.accepted)
         acc = chains.accepted.to_host().astype(bool)

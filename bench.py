@@ -239,12 +239,13 @@ def kalman_group_reals(mode, d, po):
     gain = d * d + d + 2 * d * p + p + sym(p) + 1  # one GainRow (affine_shared.h): Mb, kc, K, HF, ym, Si, c0
     if mode == "shared":
         return {
-            "rng": (0, 2 * d, 0),                                     # eps_aux, eps_samp
+            # keyed sweep (auxssm_kalman_sweep_keyed): the noise is drawn inside the scans' reduce passes; the fill kernel only draws row t = 0 of
+            # the two arrays and the acceptance uniforms (no per-step bytes)
             "factory": (0, 0, par),
             "filter_tab": (0, 0, par + gain + d * d),                 # parameters in; gain rows and filtered covariances out (ONE sequence)
-            "filter_scan": (2 * d, d, gain),                          # x, eps_aux (u = x + sd eps rebuilt on the fly) -> filtered means; + ell
+            "filter_scan": (d, 2 * d, gain),                          # x in; filtered means and eps_aux (drawn here, read again by the log-density) out; + ell
             "sample_init": (0, 0, 2 * d * d + d),                     # filtered covariances -> sampler gains / factors, once per time step
-            "sample_scan": (2 * d, d, d * d + d),                     # ms, eps_samp -> x'
+            "sample_scan": (d, d, d * d + d),                         # ms in (eps_samp drawn here), x' out
             "logpdf": (3 * d, 0, par),                                # x, x', eps_aux
             "select": (d, d, 0),                                      # x' -> x (accepted chains)
         }

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 103
+#define AUXSSM_VERSION 104
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -193,6 +193,16 @@ int auxssm_kalman_sweep_dd(auxssm_handle h, int dtype, int model_kind, const aux
                            const auxssm_lgssm* model, const auxssm_arr* yobs, const void* delta_dev, int parallel,
                            int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp, const void* u_acc,
                            int32_t* accepted, void* logs);
+/* The sweep as the reference's kernel(key, state, delta) takes it: with the KEYS of its three draws instead of the drawn arrays
+ * (keys = {aux0, aux1, samp0, samp1, acc0, acc1}, the three children of the sweep's key, kalman/generic.py:58).  Equivalent to
+ * auxssm_kalman_draw(keys, ...) into (eps_aux, eps_samp, u_acc) followed by auxssm_kalman_sweep[_dd] on them -- the three buffers (caller-owned
+ * scratch of x's size / C entries) hold exactly those values afterwards -- but the library may generate the noise inside its first
+ * consumer instead of in a separate pass (chain-minor LG_CONCAT sweeps with chain-shared parameters do).  delta_dev != NULL: device-resident
+ * step size as auxssm_kalman_sweep_dd (delta ignored). */
+int auxssm_kalman_sweep_keyed(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims,
+                              const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, const void* delta_dev,
+                              const uint32_t* keys, int parallel, int nan_policy, int layout, void* x, void* eps_aux, void* eps_samp,
+                              void* u_acc, int32_t* accepted, void* logs);
 
 /* ---- conditional SMC (particle Gibbs) sweep ------------------------------------------------------------
  * == kernel(key, state) of aux_samplers._primitives.csmc.get_kernel (csmc.py:16-66: forward pass _csmc :69-107 with

@@ -4,5 +4,6 @@ import json
 for l in open("gpurun_out/g.log"):
     if l.startswith("{"):
         d = json.loads(l); g = d["general_path"]
-        print("headline", round(d["value"]), "general", round(g["value"]), g["roofline"]["frac"], {k: v["ms_per_step"] for k, v in g["kernels"].items()})
+        print("headline", round(d["value"]), {k: v["ms_per_step"] for k, v in d["kernels"].items()})
+        print("general", round(g["value"]), g["roofline"]["frac"], {k: v["ms_per_step"] for k, v in g["kernels"].items()})
 PY
