@@ -453,7 +453,14 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     const Arr msA = cm ? cm_arr(ms, kd, D) : dense_arr(ms, kd, D);
     // chain-shared parameters: the filtered covariances do not depend on the chain and are stored once, (T, D, D) dense with chain stride 0
     const bool shared_mode = !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0);
-    const Arr PsA = shared_mode ? Arr{Ps, 0, (long long)D * D, 0, 1} : cm ? cm_arr(Ps, kd, (long long)D * D) : dense_arr(Ps, kd, (long long)D * D);
+    // general chain-minor sweep: the filtered covariances are an internal buffer the sampler reads twice -- kept symmetric-packed (10 instead of 16
+    // reals at d = 4)
+    static const bool ps_pack_on = [] { const char* e = getenv("AUXSSM_PS_PACK"); return e ? atoi(e) != 0 : true; }();
+    static const bool samp_fly_on = [] { const char* e = getenv("AUXSSM_SAMPLE_FLY"); return e ? atoi(e) != 0 : true; }();
+    const bool ps_pack = ps_pack_on && samp_fly_on && cm && !shared_mode && !wide;
+    const Arr PsA = shared_mode ? Arr{Ps, 0, (long long)D * D, 0, 1}
+                    : cm        ? cm_arr(Ps, kd, ps_pack ? (long long)symsize(D) : (long long)D * D)
+                                : dense_arr(Ps, kd, (long long)D * D);
     const Arr xpA = cm ? cm_arr(xp, kd, D) : dense_arr(xp, kd, D);
     const Arr xA = cm ? cm_arr(x, kd, D) : dense_arr(x, kd, D);
     const Arr epsauxA = cm ? cm_arr(eps_aux, kd, D) : dense_arr(eps_aux, kd, D);
@@ -501,6 +508,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     fa.Ps = PsA;
     fa.lay.cm = cm;
     fa.pblk = D;  // R = blkdiag(delta/2 I_d, Robs) by construction
+    fa.ps_packed = ps_pack ? 1 : 0;
     if (aux_fly) {
         fa.aux_on = 1;
         fa.aux_x = xA;
@@ -522,6 +530,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     sa.lay = ScanLayout{1, 1, 1, 1, cm, C};
     // the filtered covariances of this model do not depend on the chain when its parameters do not
     sa.ps_shared = shared_mode ? 1 : 0;
+    sa.ps_packed = ps_pack ? 1 : 0;
     if (gen) sa.eps_gen = 1, sa.gen_k0 = keys[2], sa.gen_k1 = keys[3];
     rc = se->sample(h, sa, parallel);
     if (rc) return rc;

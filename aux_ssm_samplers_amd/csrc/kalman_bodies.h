@@ -126,6 +126,9 @@ struct FilterArgs {
     // written for the later readers (down pass, log-density); the values are those of auxssm_rng_normal(key, stream 0) at the same indices
     int aux_gen = 0;
     unsigned int gen_k0 = 0, gen_k1 = 0;
+    // ps_packed != 0: Ps records are symmetric-packed (symsize(D) reals, upper storage) -- the internal chain-minor buffer of the general
+    // fused sweep, which the pathwise sampler reads twice (SampleArgs::ps_packed)
+    int ps_packed = 0;
     const void* obs_tab = nullptr;  // general chain-minor path with aux_on: one ObsInfoRow per transition (kalman_math.h), elements built on the fly
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
 };
@@ -138,6 +141,25 @@ AX_HD Arr cm_arr(const void* p, const KDims& d, long long rec) {
     return Arr{p, (long long)d.B, rec * S, 1, S};
 }
 
+// a covariance record: full D x D, or symmetric-packed (ps_packed)
+template <typename R, int D> AX_HD void rd_cov(const Arr& a, int c, long long t, int b, int packed, R* Pd) {
+    if (packed) {
+        R pk[symsize(D)];
+        rd<R, symsize(D)>(a, c, t, b, pk);
+        symunpack<R, D>(pk, Pd);
+    } else {
+        rd<R, D * D>(a, c, t, b, Pd);
+    }
+}
+template <typename R, int D> AX_HD void wr_cov(const Arr& a, int c, long long t, int b, int packed, const R* Pd) {
+    if (packed) {
+        R pk[symsize(D)];
+        sympack<R, D>(Pd, pk);
+        wr<R, symsize(D)>(a, c, t, b, pk);
+    } else {
+        wr<R, D * D>(a, c, t, b, Pd);
+    }
+}
 // ---- t = 0 measurement update (filtering.py:52) -------------------------------------------------
 template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& a, int s) {
     const int c = s / a.d.B, b = s % a.d.B;
@@ -150,7 +172,7 @@ template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& 
     rd_upper<R, P>(a.Rs, c, 0, b, Rm);
     const R ell = kalman_update<R, D, P>(m, Pd, H, cv, Rm, y);
     wr<R, D>(a.ms, c, 0, b, m);
-    wr<R, D * D>(a.Ps, c, 0, b, Pd);
+    wr_cov<R, D>(a.Ps, c, 0, b, a.ps_packed, Pd);
     ((R*)a.ell0)[s] = ell;
 }
 
@@ -189,7 +211,7 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
         // first transition: built around predict(m0+, P0+)  (m_ = F m + b, P_ = F P F^T + Q, not symmetrised: filtering.py:200-201)
         R m0p[D], P0p[D * D], tm[D], FP[D * D], Pn[D * D];
         rd<R, D>(a.ms, c, 0, b, m0p);
-        rd<R, D * D>(a.Ps, c, 0, b, P0p);
+        rd_cov<R, D>(a.Ps, c, 0, b, a.ps_packed, P0p);
         mv<R, D, D>(F, m0p, tm);
         mm<R, D, D, D>(F, P0p, FP);
         mmt<R, D, D, D>(FP, F, Pn);
@@ -269,9 +291,13 @@ template <typename R_, int D> struct FilterOp {
     static AX_HD void write_out(const Args& a, int s, int i, const Pre& p) {
         const int c = s / a.d.B, b = s % a.d.B;
         wr<R, D>(a.ms, c, (long long)i + 1, b, p.b);
-        R Pd[D * D];
-        symunpack<R, D>(p.C, Pd);
-        wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
+        if (a.ps_packed) {
+            wr<R, symsize(D)>(a.Ps, c, (long long)i + 1, b, p.C);  // the prefix carries C packed already
+        } else {
+            R Pd[D * D];
+            symunpack<R, D>(p.C, Pd);
+            wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
+        }
         if (i == a.d.n() - 1 && a.ellz) ((R*)a.ellz)[s] = p.z;  // scale of the full product = log p(y_1..T-1 | y_0)
     }
     // element i of sequence s in either element layout
@@ -347,7 +373,7 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
         if (i == 0) {  // built around predict(m0+, P0+) (filtering.py:188-192, :200-201)
             R m0p[D], P0p[D * D], tm[D], FP[D * D], Pn[D * D];
             rd<R, D>(a.ms, c, 0, b, m0p);
-            rd<R, D * D>(a.Ps, c, 0, b, P0p);
+            rd_cov<R, D>(a.Ps, c, 0, b, a.ps_packed, P0p);
             mv<R, D, D>(r.F, m0p, tm);
             mm<R, D, D, D>(r.F, P0p, FP);
             mmt<R, D, D, D>(FP, r.F, Pn);
@@ -383,14 +409,14 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
 #pragma unroll
             for (int k = 0; k < D * D; ++k) acc.A[k] = 0;
             rd<R, D>(a.ms, s / a.d.B, 0, s % a.d.B, acc.b);
-            rd<R, D * D>(a.Ps, s / a.d.B, 0, s % a.d.B, P0p);
+            rd_cov<R, D>(a.Ps, s / a.d.B, 0, s % a.d.B, a.ps_packed, P0p);
             sympack<R, D>(P0p, acc.C);
         }
     }
     static AX_HD void init_pre(const Args& a, int s, Pre& p) {
         R P0p[D * D];
         rd<R, D>(a.ms, s / a.d.B, 0, s % a.d.B, p.b);
-        rd<R, D * D>(a.Ps, s / a.d.B, 0, s % a.d.B, P0p);
+        rd_cov<R, D>(a.Ps, s / a.d.B, 0, s % a.d.B, a.ps_packed, P0p);
         sympack<R, D>(P0p, p.C);
         p.z = 0;
     }
@@ -455,6 +481,7 @@ struct SampleArgs {
     ScanLayout lay;
     int dx = 0;       // runtime size (wide.hip only)
     int ps_shared = 0;        // != 0: Ps (and Fs, Qs, bs) do not depend on the chain (filter ran on chain-shared parameters)
+    int ps_packed = 0;        // != 0: Ps records are symmetric-packed (as FilterArgs::ps_packed)
     int eps_gen = 0;          // != 0: eps is generated by the reduce pass from (gen_k0, gen_k1) and written for the down pass (as FilterArgs::aux_gen)
     unsigned int gen_k0 = 0, gen_k1 = 0;
     const void* tab = nullptr;  // then: one SampShared row per time step
@@ -492,7 +519,7 @@ template <typename R, int D> AX_HD void body_sample_last(const SampleArgs& a, in
     const long long tl = (long long)a.d.T - 1;
     R m[D], Pd[D * D], eps[D];
     rd<R, D>(a.ms, c, tl, b, m);
-    rd<R, D * D>(a.Ps, c, tl, b, Pd);
+    rd_cov<R, D>(a.Ps, c, tl, b, a.ps_packed, Pd);
     rd<R, D>(a.eps, c, tl, b, eps);
     SampElem<R, D> e;
     sample_last<R, D>(m, Pd, eps, e);
@@ -591,7 +618,7 @@ template <typename R_, int D> struct SampleOpFly : SampleOp<R_, D> {
         const int c = s / a.d.B, b = s % a.d.B;
         const long long t = (long long)a.d.T - 1 - j;
         rd<R, D>(a.ms, c, t, b, r.m);
-        rd<R, D * D>(a.Ps, c, t, b, r.Pd);
+        rd_cov<R, D>(a.Ps, c, t, b, a.ps_packed, r.Pd);
         rd<R, D>(a.eps, c, t, b, r.eps);
         if (j != 0) {
             rd<R, D * D>(a.Fs, c, t, b, r.F);

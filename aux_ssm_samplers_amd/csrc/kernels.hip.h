@@ -959,6 +959,10 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
         AX_HIP(hipGetLastError());
         return AUXSSM_OK;
     }
+    if (a.ps_packed && !(cm && fly)) {
+        set_error("internal: packed covariance records are read by the on-the-fly chain-minor sampler only");
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
     if (cm && fly) {
         // chain-minor: elements are recomputed on the fly by both scan passes (SampleOpFly), nothing to initialise
         a.elem = nullptr;
