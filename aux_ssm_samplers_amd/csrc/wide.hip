@@ -1358,28 +1358,78 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_obs_info(FilterAr
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
     R* e = info + ((long long)s * n + i) * info_size(d);
-    const bool any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
+    const R* Rg = at<R>(a.Rs, c, t, b);
+    const bool small = p <= 64 && d <= 64;  // then every record of the step is fetched at once (four entries of H and of R per lane): ONE exposed
+                                            // HBM latency instead of four dependent load phases
+    R ph[4], pr[4];
+    if (small) {
+        const R* Hg = at<R>(a.Hs, c, t, b);
+        const int q = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = min((tid >> 6) + NWV * k, p - 1);
+            ph[k] = Hg[(long long)r * d + min(q, d - 1)];
+            pr[k] = Rg[(long long)min(q, r) * p + r];  // the upper entry (q, r), q <= r, as the per-lane path reads it
+        }
+    }
+    bool any;
+    if (small) {
+        const R* cg = at<R>(a.cs, c, t, b);
+        const R* yg = at<R>(a.ys, c, t, b);
+        const R yv = yg[min(tid, p - 1)], cv = cg[min(tid, p - 1)];
+        const bool nn = !finite_(yv);
+        if (tid < p) {
+            o.nan[tid] = nn;
+            o.y[tid] = yv;
+            o.c_[tid] = nn ? (R)0 : cv;
+        }
+        any = __syncthreads_or(tid < p && !nn);  // (publishes nan / y / c_)
+        if (tid == 0) *o.cnt = 0;
+        __syncthreads();
+        if (tid < p && !nn) atomicAdd(o.cnt, 1);
+    } else {
+        any = load_obs<R>(o, at<R>(a.Hs, c, t, b), at<R>(a.cs, c, t, b), at<R>(a.ys, c, t, b), p, d, ldd, tid);
+    }
     if (!any) {  // nothing observed: Lam = 0 makes the fold a pure prediction (_passthrough, filtering.py:239-248)
         for (long long k = tid; k < info_size(d); k += NT) e[k] = 0;
         return;
     }
-    const R* Rg = at<R>(a.Rs, c, t, b);
-    for (int r = tid / 64; r < p; r += NWV)
-        for (int q = tid & 63; q <= r; q += 64) {  // the upper entry (q, r) of the record, as the per-lane path reads it
-            const R v = (o.nan[r] || o.nan[q]) ? (R)0 : Rg[(long long)q * p + r];
-            Z[r * ldz + q] = v;
-            Z[q * ldz + r] = v;
+    int offd = 0;
+    if (small) {
+        const int q = tid & 63;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int r = (tid >> 6) + NWV * k;
+            if (r < p) {
+                if (q < d) {
+                    const R hv = o.nan[r] ? (R)0 : ph[k];
+                    o.H_[r * ldd + q] = hv;
+                    Z[r * ldz + p + q] = hv;
+                }
+                if (q <= r) {
+                    const R v = (o.nan[r] || o.nan[q]) ? (R)0 : pr[k];
+                    Z[r * ldz + q] = v;
+                    Z[q * ldz + r] = v;
+                    offd |= (q < r && v != (R)0) ? 1 : 0;
+                }
+            }
         }
-    for (int k = tid / 64; k < p; k += NWV)
-        for (int j = tid & 63; j < d; j += 64) Z[k * ldz + p + j] = o.H_[k * ldd + j];
+    } else {
+        for (int r = tid / 64; r < p; r += NWV)
+            for (int q = tid & 63; q <= r; q += 64) {  // the upper entry (q, r) of the record, as the per-lane path reads it
+                const R v = (o.nan[r] || o.nan[q]) ? (R)0 : Rg[(long long)q * p + r];
+                Z[r * ldz + q] = v;
+                Z[q * ldz + r] = v;
+                offd |= (q < r && v != (R)0) ? 1 : 0;
+            }
+        for (int k = tid / 64; k < p; k += NWV)
+            for (int j = tid & 63; j < d; j += 64) Z[k * ldz + p + j] = o.H_[k * ldd + j];
+    }
     for (int k = tid; k < p; k += NT) {
         rr[k] = o.nan[k] ? (R)0 : o.y[k] - o.c_[k];
         Z[k * ldz + p + d] = rr[k];
     }
     // diagonal R_ (the usual observation noise; the masked entries are zero already): R_^-1 is a row scaling, no elimination
-    int offd = 0;
-    for (int r = tid / 64; r < p; r += NWV)
-        for (int q = tid & 63; q < r; q += 64) offd |= (!(o.nan[r] || o.nan[q]) && Rg[(long long)q * p + r] != (R)0) ? 1 : 0;
     const bool diag = !__syncthreads_or(offd);  // (also the barrier that publishes Z)
     R hl;
     bool ok;
