@@ -140,7 +140,8 @@ template <typename R, int D> __device__ __forceinline__ R grad_correction(const 
 }
 
 // Diagnostic builds only (tools/csmc_ablate.sh): -DAUXSSM_CSMC_ABLATE=<mask> removes one phase of the forward step at a time (wrong results, right
-// shape) to attribute its time: 1 search, 2 in-kernel draws, 4 potential / transition log-density, 8 max + exp, 16 cumsum.  0 in the product.
+// shape) to attribute its time: 1 search, 2 in-kernel draws, 4 potential / transition log-density, 8 max + exp, 16 cumsum; 32: max + exp of the
+// BACKWARD pass.  0 in the product.
 #ifndef AUXSSM_CSMC_ABLATE
 #define AUXSSM_CSMC_ABLATE 0
 #endif
@@ -226,7 +227,10 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
         for (int k = 0; k < D; ++k) xs[(long long)tid * D + k] = x[k];
         lws[tid] = lw;
     }
-    R w = block_expmax<R, NW>(lw, red, tid, nw);
+    R* fmax = a.fmax ? (R*)a.fmax + (long long)ch * T : nullptr;
+    R mstep;
+    R w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
+    if (fmax && tid == 0) fmax[0] = mstep;
 
     for (int t = 1; t < T; ++t) {
         // issue this step's independent loads first
@@ -323,7 +327,10 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
             if (As) As[(long long)(t - 1) * N + tid] = idx;
         }
         if (CSMC_ABL & 8) w = lw * (R)0.001 + (R)1;
-        else w = block_expmax<R, NW>(lw, red, tid, nw);
+        else {
+            w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
+            if (fmax && tid == 0) fmax[t] = mstep;
+        }
     }
     if (live) ((R*)a.wT)[(long long)ch * N + tid] = w;
 }
@@ -395,11 +402,13 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
     }
     // backward sampling (Whiteley), csmc.py:134-146
     __syncthreads();  // the parity-1 slots of the first draw are free again
-    R xi_nx[D], lw_nx = ninf, un_nx = 0;
+    R xi_nx[D], lw_nx = ninf, un_nx = 0, fm_nx = 0;
+    const R* fmax = (const R*)a.fmax + (long long)ch * T;
     if (T >= 2) {
 #pragma unroll
         for (int k = 0; k < D; ++k) xi_nx[k] = live ? xs[((long long)(T - 2) * N + tid) * D + k] : (R)0;
         lw_nx = live ? lws[(long long)(T - 2) * N + tid] : ninf;
+        fm_nx = fmax[T - 2];
         if (tid == 0) un_nx = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 2));
     }
     for (int t = T - 2; t >= 0; --t) {
@@ -407,26 +416,36 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         R xi[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) xi[k] = xi_nx[k];
-        const R lwi = lw_nx, un_t = un_nx;
+        const R lwi = lw_nx, un_t = un_nx, fm_t = fm_nx;
         if (t > 0) {  // the rows of step t - 1: independent of this step's draw
 #pragma unroll
             for (int k = 0; k < D; ++k) xi_nx[k] = live ? xs[((long long)(t - 1) * N + tid) * D + k] : (R)0;
             lw_nx = live ? lws[(long long)(t - 1) * N + tid] : ninf;
+            fm_nx = fmax[t - 1];
             if (tid == 0) un_nx = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (t - 1));
         }
         R lw = ninf;
+        const TransT<R> tr = trans_at_c<R, D, TV>(m, t);  // Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136)
         if (live) {
             R mu[D];
-            const TransT<R> tr = trans_at_c<R, D, TV>(m, t);  // Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136)
             trans_mean_t<R, D>(m, tr, xi, mu);
             lw = gauss_chol_logpdf<R, D>(xn, mu, tr.LQ, tr.c_trans, tr.ld) + lwi;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
         if (tid == 0) ubuf[par] = un_t;
-        w = block_expmax<R, NW>(lw, red, tid, nw);              // barrier (more than one wave)
+        // weights shifted by a bound of their maximum that needs no reduction (sweep contract): the forward pass's block maximum of
+        // log_ws[t] plus the transition's log-normaliser; the exact maximum only if everything underflowed
+        R Mb = fm_t + tr.c_trans;
+        if (!(Mb - Mb == 0)) Mb = 0;
+        if (CSMC_ABL & 32) w = lw * (R)0.001 + (R)1;  // (diagnostic build: the backward pass without its exp)
+        else w = det_exp(lw - Mb);
         if constexpr (NW > 0) {  // cumulative weight in a register: one barrier (it publishes xpub / ubuf of this parity as well), no c[] image
-            const R cv = block_cumsum_reg<R, NW>(w, red, tid, Pg);
+            R cv = block_cumsum_reg<R, NW>(w, red, tid, Pg);
+            if (!(Pg[NW - 1] > (R)0)) {  // (uniform: every lane holds the same totals)
+                w = block_expmax<R, NW>(lw, red, tid, nw);
+                cv = block_cumsum_reg<R, NW>(w, red, tid, Pg);
+            }
             const unsigned long long bal = __ballot(cv < Pg[NW - 1] * ((R)1 - ubuf[par]));
             if ((tid & 63) == 0) cnt[par * 16 + (tid >> 6)] = __popcll(bal);
             __syncthreads();
@@ -436,6 +455,11 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
             B = B < N - 1 ? B : N - 1;
         } else {
             block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);    // two barriers: xpub / ubuf of this parity are published as well
+            if (!(c[N - 1] > (R)0)) {
+                __syncthreads();  // (every lane has read c[N - 1] before it is rewritten)
+                w = block_expmax<R, NW>(lw, red, tid, nw);
+                block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);
+            }
             B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
         }
 #pragma unroll
@@ -757,6 +781,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     if (!log_ws_out) need += CT * N * sR + 256;
     if (!backward && !As_out) need += (size_t)C * (T > 1 ? T - 1 : 1) * N * 4 + 256;
     need += (size_t)C * N * sR + 256;
+    need += CT * sR + 256;  // fmax
     need += 2 * (CT * D * sR + 256) + (size_t)T * sR + 256;
     int rc = ws_reserve(h, need);
     if (rc) return rc;
@@ -772,11 +797,12 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.lws = log_ws_out ? log_ws_out : ws_take(h, CT * N * sR);
     a.As = As_out ? As_out : (!backward ? (int32_t*)ws_take(h, (size_t)C * (T > 1 ? T - 1 : 1) * N * 4) : nullptr);
     a.wT = ws_take(h, (size_t)C * N * sR);
+    a.fmax = ws_take(h, (size_t)C * T * sR);
     a.anc = ancestors;
     a.noise_mode = noise->mode;
     a.key0 = noise->key0; a.key1 = noise->key1;
     a.eps_aux = noise->eps_aux; a.eps_prop = noise->eps_prop; a.u_res = noise->u_res; a.u_bwd = noise->u_bwd;
-    if (!a.u || !a.xs || !a.lws || !a.wT || (!backward && !a.As) || (fk->gradient && !a.grad) || (fk->F_t && !ctt)) return AUXSSM_ERR_NOMEM;
+    if (!a.u || !a.xs || !a.lws || !a.wT || !a.fmax || (!backward && !a.As) || (fk->gradient && !a.grad) || (fk->F_t && !ctt)) return AUXSSM_ERR_NOMEM;
 #define AX_CSMC_D(R)                                                        \
     switch (D) {                                                            \
         case 1: return run_csmc<R, 1>(h, fk, hm.data(), a, ctt);                 \

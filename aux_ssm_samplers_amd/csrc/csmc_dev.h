@@ -51,6 +51,7 @@ struct CsmcArgs {
     void* lws;           // (C, T, N)
     int32_t* As;         // (C, T-1, N) or null
     void* wT;            // (C, N)
+    void* fmax;          // (C, T) max_i log_ws[t][i] of the forward pass (non-finite -> 0): the backward pass shifts its weights by it (sweep contract)
     int32_t* anc;        // (C, T)
     int noise_mode;      // 0 explicit arrays, 1 Threefry
     uint32_t key0, key1;
@@ -264,6 +265,10 @@ template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int
 //            c[pos + s - 1] < r) pos += s, end = min(64 g + 64, N); clipped to N - 1.  On a non-decreasing c this IS
 //            searchsorted(c, r, side='left') (the group's last entry is >= r by the choice of g).
 //   single draw (backward pass): B = #{j < N : c_j < r}, clipped to N - 1 (again searchsorted on a non-decreasing c), counted by ballot.
+//   backward weights: lw_i = log_ws[t][i] + log p(x_{t+1} | x_t^i) <= M := max_i log_ws[t][i] + c_t (the forward pass's block maximum of
+//            that step, which it stores, plus the log-normaliser of the transition density: an upper bound of lw known WITHOUT a reduction);
+//            e_i = exp(lw_i - M) (M non-finite -> 0).  Only if every e_i underflows (their cumulative total is not > 0) the step falls
+//            back to the exact maximum, e_i = exp(lw_i - max lw).  Scale-invariant as above.
 //   max    : exact, any order.
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
@@ -298,7 +303,7 @@ template <typename R> __device__ __forceinline__ R wave_max_dpp(R v) {
 // e_i = exp(lw_i - max lw) (non-finite max -> 0, as jax's logsumexp); red slots [0, 16).
 // NW = 8 / 16: the workgroup is exactly NW full waves (N = 64 NW particles) -- no per-group bounds selects, the NW wave maxima are reduced by
 // one more DPP pass instead of fifteen compare / select pairs per lane.
-template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw, R* red, int tid, int nw) {
+template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw, R* red, int tid, int nw, R* m_out = nullptr) {
     const int lane = tid & 63, wv = tid >> 6;
     R m = wave_max_dpp(lw);
     if constexpr (NW > 0) {
@@ -315,6 +320,7 @@ template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw
         for (int k = 1; k < 16; ++k) m = (k < nw && t[k] > m) ? t[k] : m;
     }
     if (!(m - m == 0)) m = 0;
+    if (m_out) *m_out = m;
     return det_exp(lw - m);
 }
 // P[wv - 1] (0 for the first wave) by ONE scalar branch on the wave id (readfirstlane tells the compiler it is wave-uniform; a plain

@@ -318,11 +318,12 @@ static int SUF(choice)(const REAL* c, int N, REAL un) {
 }
 
 /* ---- sweep contract (csrc/csmc_dev.h) ---- */
-static void SUF(expmax)(const REAL* lw, int N, REAL* w) {
+static REAL SUF(expmax)(const REAL* lw, int N, REAL* w) {
     REAL m = lw[0];
     for (int i = 1; i < N; ++i) m = m > lw[i] ? m : lw[i];
     if (!(m - m == 0)) m = 0;
     for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - m);
+    return m;
 }
 static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) {
     REAL pre = 0;
@@ -511,7 +512,8 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
         }
         lws[i] = gq;
     }
-    SUF(expmax)(lws, N, w);
+    REAL* fmax = (REAL*)malloc(sizeof(REAL) * (size_t)T); /* block maximum of log_ws[t] (non-finite -> 0): the backward pass shifts by it */
+    fmax[0] = SUF(expmax)(lws, N, w);
     for (int t = 1; t < T; ++t) {
         const REAL* xprev = xs + (size_t)(t - 1) * N * D;
         REAL* xcur = xs + (size_t)t * N * D;
@@ -550,7 +552,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             lw[i] = gq;
         }
         memcpy(lws + (size_t)t * N, lw, sizeof(REAL) * N);
-        SUF(expmax)(lw, N, w);
+        fmax[t] = SUF(expmax)(lw, N, w);
     }
     /* backward (csmc.py:110-149) */
     SUF(cumsum_dpp)(w, N, c);
@@ -568,14 +570,22 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
                 SUF(tmean_t)(&m, &tr, xs + ((size_t)t * N + i) * D, mu);
                 lw[i] = SUF(gauss)(D, xn, mu, tr.LQ, tr.c_trans) + lws[(size_t)t * N + i];
             }
-            SUF(expmax)(lw, N, w);
+            /* sweep contract: weights shifted by a bound of their maximum (forward block maximum + log-normaliser of the transition density);
+               the exact maximum only when every weight underflowed */
+            REAL Mb = fmax[t] + tr.c_trans;
+            if (!(Mb - Mb == 0)) Mb = 0;
+            for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - Mb);
             SUF(cumsum_dpp)(w, N, c);
+            if (!(c[N - 1] > 0)) {
+                SUF(expmax)(lw, N, w);
+                SUF(cumsum_dpp)(w, N, c);
+            }
             B = SUF(choice_count)(c, N, u_bwd[t]);
         }
         anc[t] = B;
         for (int k = 0; k < D; ++k) xn[k] = x[t * D + k] = xs[((size_t)t * N + B) * D + k];
     }
-    free(u); free(w); free(c); free(tmp); free(lw); free(grad);
+    free(u); free(w); free(c); free(tmp); free(lw); free(grad); free(fmax);
     return 0;
 }
 
