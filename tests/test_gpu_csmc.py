@@ -283,3 +283,34 @@ def test_systematic_resampling_bit_exact_vs_oracle(dtype, M, N):
     assert np.all(got[ok, 0] == 0)
     one = systematic(7, w[0], N)     # keyed draw, single vector
     assert one.shape == (N,) and one[0] == 0 and one.max() < M
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [64, 512, 1024])
+def test_backward_weights_fall_back_to_the_exact_maximum_after_underflow(dtype, N):
+    """The backward pass shifts its weights by a reduction-free BOUND of their maximum (forward block maximum + transition log-normaliser, sweep
+    contract).  With a transition far tighter than the independent proposal every such weight underflows and the step must fall back to the exact
+    maximum -- in the kernels and in the oracle alike (bit-exact), and the draw must still pick the particle the transition favours."""
+    from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics
+    d, T = 1, 24
+    rng = np.random.default_rng(5 + N)
+    M0 = GaussianInit(m0=np.zeros(d), P0=np.eye(d))
+    Mt = LinearGaussianDynamics(F=0.9 * np.eye(d), b=np.zeros(d), Q=1e-8 * np.eye(d))   # sd 1e-4 against proposals of sd 0.5
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(O.POT_GAUSS_OBS, y)
+    x0 = rng.standard_normal((T, d)).astype(dtype)
+    delta = np.full(T, 0.5)
+    noise = dict(eps_prop=rng.standard_normal((T, N, d)), u_res=rng.random((T - 1, N)), u_bwd=rng.random(T), eps_aux=rng.standard_normal((T, d)))
+    fk = _device.describe_independent(M0, G0, Mt, Gt, Mt)
+    noise32 = {k: np.asarray(v, dtype) for k, v in noise.items()}
+    x, anc, hist = _device.sweep(fk, x0, N, True, noise={k: v[None] for k, v in noise32.items()}, delta=delta, want_history=True)
+    ref = O.sweep(_odesc(O.AUX_INDEPENDENT, O.POT_GAUSS_OBS, M0, Mt, 0.7), x0, N, True, y=y, eps_prop=noise["eps_prop"], u_res=noise["u_res"],
+                  u_bwd=noise["u_bwd"], dtype=dtype, sqrt_half_delta=np.sqrt(0.5 * delta), eps_aux=noise["eps_aux"])
+    npt.assert_array_equal(anc, ref["ancestors"])
+    npt.assert_array_equal(x, ref["x"])
+    # the bound really underflows on some steps: log p(x_{t+1} | x_t^i) - c_t = -z_i^2 / 2 with z of order 0.5 / 1e-4; a step falls back when
+    # even the nearest particle is beyond the exp underflow of the dtype
+    xs = hist["xs"].astype(np.float64)
+    lim = 2 * (88.0 if dtype == np.float32 else 746.0)
+    zmin = [(((float(x[k + 1, 0]) - 0.9 * xs[k, :, 0]) / 1e-4) ** 2).min() for k in range(T - 1)]
+    assert sum(z > lim for z in zmin) >= 1, zmin
