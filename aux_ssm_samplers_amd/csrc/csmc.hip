@@ -37,6 +37,28 @@ template <typename R, int D> __global__ void k_csmc_ctrans(int n, const R* __res
     for (int k = 0; k < D; ++k) c -= det_log(LQt[((long long)t * D + k) * D + k]);
     ct[t] = c - (R)D * (R)0.91893853320467274178;
 }
+// gb[t] = sup_x G_t(x): the reduction-free part of the forward weights' shift (sweep contract, csmc_dev.h); +inf where the potential is unbounded
+template <typename R, int D> __global__ void k_csmc_potbound(int T, FkDev<R> m, const R* __restrict__ y, R* __restrict__ gb) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= T) return;
+    R b = 0;
+    if (m.potential == 1) b = m.c_obs;
+    else if (m.potential == 3) {
+        int nobs = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) nobs += (y[(long long)t * D + k] - y[(long long)t * D + k] == 0) ? 1 : 0;
+        b = (R)nobs * m.c_obs;
+    } else if (m.potential == 2) {  // sum_k [c_obs - (x + y^2 e^-x) / 2] <= sum_k max(0, c_obs - (1 + log y^2) / 2)  (a NaN term counts 0)
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const R yk = y[(long long)t * D + k], y2 = yk * yk;
+            R v = (R)0;
+            if (y2 - y2 == 0) v = y2 > (R)0 ? fma_((R)-0.5, (R)1 + det_log(y2), m.c_obs) : (R)INFINITY;
+            b += v > (R)0 ? v : (R)0;
+        }
+    }
+    gb[t] = b;
+}
 // w <- (L L^T)^-1 r, L lower with leading dimension ld; fixed operation order (restated by oracle/csmc_ref.c::cho_solve_)
 template <typename R, int D> __device__ __forceinline__ void cho_solve_fixed(const R* L, int ld, const R* r, R* w) {
     R z[D];
@@ -231,10 +253,14 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     R mstep;
     R w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
     if (fmax && tid == 0) fmax[0] = mstep;
+    const R* gbp = (const R*)a.gb;
+    const bool bmode = gbp != nullptr && !(GRAD && m.gradient == 2);  // (the exact-gradient correction is unbounded in x)
+    bool used_bound = false;
 
     for (int t = 1; t < T; ++t) {
         // issue this step's independent loads first
         R un = 0;
+        const R gbt = bmode ? gbp[t] : (R)0;
 #pragma unroll
         for (int k = 0; k < D; ++k) ycur[k] = yv ? yv[(long long)t * D + k] : (R)0;
         if (!gen) {
@@ -272,7 +298,14 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
             __syncthreads();
         } else
             block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
-        const R tot = NW > 0 ? Pg[NW > 0 ? NW - 1 : 0] : c[cpad(N - 1)];  // full groups: the last total IS c[N - 1], bit for bit
+        R tot = NW > 0 ? Pg[NW > 0 ? NW - 1 : 0] : c[cpad(N - 1)];  // full groups: the last total IS c[N - 1], bit for bit
+        if (used_bound && !(tot > (R)0)) {  // every weight of step t - 1 underflowed under its bound: the exact maximum after all (uniform)
+            if (NW == 0) __syncthreads();   // (c[N - 1] has been read by every lane before it is rewritten)
+            w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
+            if (fmax && tid == 0) fmax[t - 1] = mstep;
+            block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, Pg);
+            tot = NW > 0 ? Pg[NW > 0 ? NW - 1 : 0] : c[cpad(N - 1)];
+        }
         int idx = 0;
         if (CSMC_ABL & 1) idx = (tid * 7) & (N - 1);
         else if (live && tid > 0) idx = search2<R, NW, true>(c, Pg, N, nw, tot * ((R)1 - un));
@@ -328,7 +361,15 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
         }
         if (CSMC_ABL & 8) w = lw * (R)0.001 + (R)1;
         else {
-            w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
+            // the shift of this step's weights (sweep contract): a reduction-free bound where there is one, else the block maximum
+            R Mb = gbt + (m.proposal == 1 ? tr.c_trans : (R)0);
+            used_bound = bmode && t < T - 1 && (Mb - Mb == 0);
+            if (used_bound) {
+                w = det_exp(lw - Mb);
+                mstep = Mb;
+            } else {
+                w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
+            }
             if (fmax && tid == 0) fmax[t] = mstep;
         }
     }
@@ -563,6 +604,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
         m.ctt = (const R*)ctt;
         hipLaunchKernelGGL((k_csmc_ctrans<R, D>), dim3((a.T - 1 + 255) / 256), dim3(256), 0, h->stream, a.T - 1, m.LQt, (R*)ctt);
     }
+    if (a.gb) hipLaunchKernelGGL((k_csmc_potbound<R, D>), dim3((a.T + 255) / 256), dim3(256), 0, h->stream, a.T, m, (const R*)a.y, (R*)a.gb);
     if (fk->proposal == 1) {
         const long long total = (long long)a.C * a.T * D;
         hipLaunchKernelGGL((k_csmc_aux<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a, D);
@@ -782,6 +824,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     if (!backward && !As_out) need += (size_t)C * (T > 1 ? T - 1 : 1) * N * 4 + 256;
     need += (size_t)C * N * sR + 256;
     need += CT * sR + 256;  // fmax
+    need += (size_t)T * sR + 256;  // gb
     need += 2 * (CT * D * sR + 256) + (size_t)T * sR + 256;
     int rc = ws_reserve(h, need);
     if (rc) return rc;
@@ -798,6 +841,8 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.As = As_out ? As_out : (!backward ? (int32_t*)ws_take(h, (size_t)C * (T > 1 ? T - 1 : 1) * N * 4) : nullptr);
     a.wT = ws_take(h, (size_t)C * N * sR);
     a.fmax = ws_take(h, (size_t)C * T * sR);
+    static const bool bound_on = !getenv("AUXSSM_CSMC_NO_BOUND");
+    a.gb = (bound_on && (fk->potential == 0 || fk->y)) ? ws_take(h, (size_t)T * sR) : nullptr;
     a.anc = ancestors;
     a.noise_mode = noise->mode;
     a.key0 = noise->key0; a.key1 = noise->key1;

@@ -51,7 +51,9 @@ struct CsmcArgs {
     void* lws;           // (C, T, N)
     int32_t* As;         // (C, T-1, N) or null
     void* wT;            // (C, N)
-    void* fmax;          // (C, T) max_i log_ws[t][i] of the forward pass (non-finite -> 0): the backward pass shifts its weights by it (sweep contract)
+    void* fmax;          // (C, T) the shift the forward pass used for the weights of step t (an upper bound of max_i log_ws[t][i], or that maximum;
+                         // non-finite -> 0): the backward pass builds its own bound from it (sweep contract)
+    const void* gb;      // (T) upper bound of the potential G_t over x (a function of y_t only; +inf where there is none); null: exact maxima only
     int32_t* anc;        // (C, T)
     int noise_mode;      // 0 explicit arrays, 1 Threefry
     uint32_t key0, key1;
@@ -265,10 +267,13 @@ template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int
 //            c[pos + s - 1] < r) pos += s, end = min(64 g + 64, N); clipped to N - 1.  On a non-decreasing c this IS
 //            searchsorted(c, r, side='left') (the group's last entry is >= r by the choice of g).
 //   single draw (backward pass): B = #{j < N : c_j < r}, clipped to N - 1 (again searchsorted on a non-decreasing c), counted by ballot.
-//   backward weights: lw_i = log_ws[t][i] + log p(x_{t+1} | x_t^i) <= M := max_i log_ws[t][i] + c_t (the forward pass's block maximum of
-//            that step, which it stores, plus the log-normaliser of the transition density: an upper bound of lw known WITHOUT a reduction);
-//            e_i = exp(lw_i - M) (M non-finite -> 0).  Only if every e_i underflows (their cumulative total is not > 0) the step falls
-//            back to the exact maximum, e_i = exp(lw_i - max lw).  Scale-invariant as above.
+//   shifts   : the weights of a step are e_i = exp(lw_i - M) with M an upper bound of max_i lw_i that needs NO reduction where one exists, the
+//            exact maximum otherwise, and the exact maximum after all whenever every e_i underflowed (cumulative total not > 0: detected where
+//            the total is formed -- one step later in the forward pass, in the same step in the backward pass).  Scale-invariant as above.
+//            Forward, 1 <= t < T - 1, not the exact-gradient proposals: M_t = gb_t (+ c_t for the auxiliary proposals), gb_t = sup_x G_t(x)
+//            (k_csmc_potbound: 0 | c_obs | nobs c_obs | sum_k max(0, c_obs - (1 + log y_k^2) / 2); +inf -> no bound), c_t the log-normaliser
+//            of the transition density; t = 0 and t = T - 1 use the exact maximum.  fmax[t] = the shift finally used.
+//            Backward: lw_i = log_ws[t][i] + log p(x_{t+1} | x_t^i) <= M := fmax[t] + c_t.
 //   max    : exact, any order.
 template <int CTRL, int ROW_MASK> __device__ __forceinline__ float dpp_mov(float old, float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, ROW_MASK, 0xf, false));

@@ -317,6 +317,26 @@ static int SUF(choice)(const REAL* c, int N, REAL un) {
     return i < N - 1 ? i : N - 1;
 }
 
+/* sup_x G(x) of the potential given y (csrc/csmc.hip::k_csmc_potbound); +inf where the potential is unbounded */
+static REAL SUF(pot_bound)(const SUF(fk) * m, const REAL* y) {
+    const int D = m->D;
+    if (m->potential == 0) return (REAL)0;
+    if (m->potential == 1) return m->c_obs;
+    if (m->potential == 3) {
+        int nobs = 0;
+        for (int k = 0; k < D; ++k) nobs += (y[k] - y[k] == 0) ? 1 : 0;
+        return (REAL)nobs * m->c_obs;
+    }
+    REAL b = 0;
+    for (int k = 0; k < D; ++k) {
+        const REAL y2 = y[k] * y[k];
+        REAL v = 0;
+        if (y2 - y2 == 0) v = y2 > 0 ? FMA((REAL)-0.5, (REAL)1 + LOG(y2), m->c_obs) : (REAL)INFINITY;
+        b += v > 0 ? v : (REAL)0;
+    }
+    return b;
+}
+
 /* ---- sweep contract (csrc/csmc_dev.h) ---- */
 static REAL SUF(expmax)(const REAL* lw, int N, REAL* w) {
     REAL m = lw[0];
@@ -514,11 +534,20 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
     }
     REAL* fmax = (REAL*)malloc(sizeof(REAL) * (size_t)T); /* block maximum of log_ws[t] (non-finite -> 0): the backward pass shifts by it */
     fmax[0] = SUF(expmax)(lws, N, w);
+    /* sweep contract, shifts: gb[t] = sup_x G_t(x) (+inf: none), the reduction-free part of the forward shift (k_csmc_potbound) */
+    const int bmode = (m.potential == 0 || y) && g->gradient != 2;
+    REAL* gb = (REAL*)malloc(sizeof(REAL) * (size_t)T);
+    for (int t = 0; t < T; ++t) gb[t] = bmode ? SUF(pot_bound)(&m, y ? y + (size_t)t * D : zero) : (REAL)0;
+    int used_bound = 0;
     for (int t = 1; t < T; ++t) {
         const REAL* xprev = xs + (size_t)(t - 1) * N * D;
         REAL* xcur = xs + (size_t)t * N * D;
         const REAL* yt = y ? y + (size_t)t * D : zero;
         SUF(cumsum_dpp)(w, N, c);
+        if (used_bound && !(c[N - 1] > 0)) { /* every weight of step t - 1 underflowed under its bound: the exact maximum after all */
+            fmax[t - 1] = SUF(expmax)(lw, N, w);
+            SUF(cumsum_dpp)(w, N, c);
+        }
         SUF(trans_at)(&m, g, t - 1, &tr);
         for (int i = 0; i < N; ++i) {
             int idx = 0;
@@ -552,8 +581,18 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             lw[i] = gq;
         }
         memcpy(lws + (size_t)t * N, lw, sizeof(REAL) * N);
-        fmax[t] = SUF(expmax)(lw, N, w);
+        {
+            const REAL Mb = gb[t] + (m.proposal == 1 ? tr.c_trans : (REAL)0);
+            used_bound = bmode && t < T - 1 && (Mb - Mb == 0);
+            if (used_bound) {
+                for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - Mb);
+                fmax[t] = Mb;
+            } else {
+                fmax[t] = SUF(expmax)(lw, N, w);
+            }
+        }
     }
+    free(gb);
     /* backward (csmc.py:110-149) */
     SUF(cumsum_dpp)(w, N, c);
     int B = SUF(choice_count)(c, N, u_bwd[T - 1]);

@@ -314,3 +314,41 @@ def test_backward_weights_fall_back_to_the_exact_maximum_after_underflow(dtype, 
     lim = 2 * (88.0 if dtype == np.float32 else 746.0)
     zmin = [(((float(x[k + 1, 0]) - 0.9 * xs[k, :, 0]) / 1e-4) ** 2).min() for k in range(T - 1)]
     assert sum(z > lim for z in zmin) >= 1, zmin
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("N", [100, 512, 1024])
+@pytest.mark.parametrize("case", ["tight_obs", "sv_zero_obs"])
+def test_forward_weights_bound_and_its_fallbacks(dtype, N, case):
+    """The forward pass shifts the weights of a step by sup_x G_t(x) (+ the transition's log-normaliser) instead of their block maximum (sweep
+    contract).  tight_obs: observation noise far below the particles' spread, so every weight underflows under the bound and the NEXT step must
+    redo it with the exact maximum; sv_zero_obs: a stochastic-volatility potential with y_t = 0 has no upper bound (that step keeps the block
+    maximum).  Bit-exact against the oracle either way."""
+    from aux_ssm_samplers_amd.csmc import _device
+    d, T = 1, 20
+    rng = np.random.default_rng(17 + N)
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    if case == "tight_obs":
+        pot, sig = O.POT_GAUSS_OBS, 1e-6
+    else:
+        pot, sig = O.POT_SV, 0.7
+        y[[3, 9]] = 0.0
+    G0, Gt = _pot(pot, y, sig)
+    x0 = rng.standard_normal((T, d)).astype(dtype)
+    noise = dict(eps_prop=rng.standard_normal((T, N, d)), u_res=rng.random((T - 1, N)), u_bwd=rng.random(T))
+    fk = _device.describe_bootstrap(M0, G0, Mt, Gt, Mt)
+    noise32 = {k: np.asarray(v, dtype) for k, v in noise.items()}
+    x, anc, hist = _device.sweep(fk, x0, N, True, noise={k: v[None] for k, v in noise32.items()}, want_history=True)
+    ref = O.sweep(_odesc(O.BOOTSTRAP_LG, pot, M0, Mt, sig), x0, N, True, y=y, eps_prop=noise["eps_prop"], u_res=noise["u_res"], u_bwd=noise["u_bwd"],
+                  dtype=dtype)
+    npt.assert_array_equal(hist["xs"], ref["xs"])
+    npt.assert_array_equal(hist["log_ws"], ref["log_ws"])
+    npt.assert_array_equal(hist["As"], ref["As"])
+    npt.assert_array_equal(anc, ref["ancestors"])
+    npt.assert_array_equal(x, ref["x"])
+    if case == "tight_obs":  # the bound c_obs is far above every log-weight: exp(lw - bound) = 0 for all particles on (nearly) every step
+        lw = hist["log_ws"].astype(np.float64)
+        c_obs = -np.log(sig) - 0.5 * np.log(2 * np.pi)
+        under = (lw[1:-1] - c_obs).max(axis=1) < (-104 if dtype == np.float32 else -746)
+        assert under.sum() >= 3, under
