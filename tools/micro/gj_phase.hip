@@ -1,4 +1,5 @@
-// phase profile of wide.hip's blocked Gauss-Jordan solve (copy of gj_solve_blk with s_memtime at the phase boundaries)
+// phase profile of the blocked Gauss-Jordan solve AS IT WAS before its trailing update moved onto the matrix cores (a copy of that gj_solve_blk with s_memtime at
+// the phase boundaries): the measurement that showed the VALU rank-16 update at 35 k of 64 k cycles and the single-wave panel phase at 28 k
 #include "../../aux_ssm_samplers_amd/csrc/wide.hip"
 namespace ax { void set_error(const char*, ...) {} void* ws_take(auxssm_ctx*, size_t) { return nullptr; } }
 using namespace ax::wide;
