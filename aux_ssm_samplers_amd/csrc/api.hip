@@ -314,25 +314,26 @@ __global__ void k_concat_obs(int C, int T, int D, int PO, Arr x, Arr eps, R shd,
         *yo = at<R>(yobs, c, t, 0)[k - D];
     }
 }
-// _get_alpha + bernoulli (generic.py:70-73, 98-106)
+// _get_alpha + bernoulli (generic.py:70-73, 98-106).  The five totals arrive in Acc (smallmat.h) and the ratio is formed in Acc: the fp32 sweep
+// rounds log alpha once, at the end, instead of differencing six rounded ~1e5-sized totals (fp64: the same arithmetic as before).
 template <typename R>
-__global__ void k_accept(int C, const R* jp_prop, const R* jp_rev, const R* ell_prop, const R* ell_rev, const R* lt_prop,
-                         const R* lt_rev, const R* corr, const R* u_acc, int32_t* accepted, R* logs) {
+__global__ void k_accept(int C, const Acc* jp_prop, const Acc* jp_rev, const R* ell_prop, const R* ell_rev, const Acc* lt_prop,
+                         const Acc* lt_rev, const Acc* corr, const R* u_acc, int32_t* accepted, R* logs) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const R lp_prop = jp_prop[c] - ell_prop[c];
-    const R lp_rev = jp_rev[c] - ell_rev[c];
-    R la = lt_prop[c] - lt_rev[c];
+    const Acc lp_prop = jp_prop[c] - (Acc)ell_prop[c];
+    const Acc lp_rev = jp_rev[c] - (Acc)ell_rev[c];
+    Acc la = lt_prop[c] - lt_rev[c];
     la += lp_rev - lp_prop;
     la -= corr[c];
-    const R alpha = exp_(min_(la, (R)0));
-    accepted[c] = (u_acc[c] < alpha) ? 1 : 0;  // NaN alpha -> reject, as jax.random.bernoulli(key, nan)
+    const Acc alpha = exp_(min_(la, (Acc)0));
+    accepted[c] = ((Acc)u_acc[c] < alpha) ? 1 : 0;  // NaN alpha -> reject, as jax.random.bernoulli(key, nan)
     if (logs) {
-        logs[c * 5 + 0] = la;
-        logs[c * 5 + 1] = lp_prop;
-        logs[c * 5 + 2] = lp_rev;
-        logs[c * 5 + 3] = lt_prop[c];
-        logs[c * 5 + 4] = lt_rev[c];
+        logs[c * 5 + 0] = (R)la;
+        logs[c * 5 + 1] = (R)lp_prop;
+        logs[c * 5 + 2] = (R)lp_rev;
+        logs[c * 5 + 3] = (R)lt_prop[c];
+        logs[c * 5 + 4] = (R)lt_rev[c];
     }
 }
 // x <- xp for accepted chains, both through strided views; cfast as in k_concat_obs.  With running moments attached
@@ -430,7 +431,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     add(CT * D * sR);                                  // ms
     add(CT * D * D * sR);                              // Ps
     add(CT * D * sR);                                  // x_prop
-    add((size_t)C * 8 * sR + 2048);                    // scalars
+    add((size_t)C * sR + (size_t)5 * C * sizeof(Acc) + 2048);  // ell, the five totals
     add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : sl->ws(h, kd));
@@ -445,7 +446,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     R* Ps = (R*)ws_take(h, CT * D * D * sR);
     R* xp = (R*)ws_take(h, CT * D * sR);
     R* ell = (R*)ws_take(h, C * sR);
-    R* sums = (R*)ws_take(h, (size_t)5 * C * sR);
+    Acc* sums = (Acc*)ws_take(h, (size_t)5 * C * sizeof(Acc));
     if (!ysc || !Hc || !Rc || !cc || !u || !ms || !Ps || !xp || !ell || !sums) return AUXSSM_ERR_NOMEM;
     const size_t mark = h->ws_off;
     const Arr yscA = cm ? cm_arr(ysc, kd, P) : dense_arr(ysc, kd, P);
@@ -549,10 +550,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         if (rc) return rc;
         h->ws_off = mark;
     }
-    R* jp_prop = sums; R* jp_rev = sums + C; R* lt_prop = sums + 2 * C; R* lt_rev = sums + 3 * C; R* corr = sums + 4 * C;
-    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)jp_prop, (const R*)jp_rev,
-                       (const R*)ell, (const R*)ell, (const R*)lt_prop, (const R*)lt_rev, (const R*)corr, (const R*)u_acc,
-                       accepted, (R*)logs);
+    const Acc* jp_prop = sums; const Acc* jp_rev = sums + C; const Acc* lt_prop = sums + 2 * C; const Acc* lt_rev = sums + 3 * C; const Acc* corr = sums + 4 * C;
+    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, jp_prop, jp_rev, (const R*)ell, (const R*)ell, lt_prop, lt_rev,
+                       corr, (const R*)u_acc, accepted, (R*)logs);
     if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm))) return rc;
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
@@ -707,7 +707,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     if (second) add(2 * CT * D * D * sR);                    // Rs1, Rs2
     add(CT * D * sR);                                        // ms
     add(CT * D * D * sR);                                    // Ps
-    add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + 4096);
+    add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + (size_t)5 * C * sizeof(Acc) + 4096);
     add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : std::max(ke->logpdf_ws(h, kd), se->sv_logpdf_ws(h, kd)));
@@ -725,7 +725,8 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     R* Rc = (R*)ws_take(h, (size_t)D * D * sR);
     R* zero = (R*)ws_take(h, (size_t)D * sR);
     R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
-    if (!u || !ys1 || !ys2 || !xp || !ms || !Ps || !eye || !Rc || !zero || !sc) return AUXSSM_ERR_NOMEM;
+    Acc* sums = (Acc*)ws_take(h, (size_t)5 * C * sizeof(Acc));
+    if (!u || !ys1 || !ys2 || !xp || !ms || !Ps || !eye || !Rc || !zero || !sc || !sums) return AUXSSM_ERR_NOMEM;
     R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
     const size_t mark = h->ws_off;
     const long long tot = (long long)CT * D;
@@ -805,11 +806,11 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         la.x = xA; la.xp = xpA; la.u = uA; la.ys1 = y1A; la.ys2 = y2A; la.R1 = R1A; la.R2 = R2A;
         la.delta = delta;
         la.dptr = dptr;
-        rc = se->sv_logpdf(h, la, j1);  // j1 .. : [5][C] = jp_prop, jp_rev, lt_prop, lt_rev, corr
+        rc = se->sv_logpdf(h, la, sums);  // [5][C] = jp_prop, jp_rev, lt_prop, lt_rev, corr
         if (rc) return rc;
         h->ws_off = mark;
-        hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)(j1 + C), (const R*)ell1,
-                           (const R*)ell2, (const R*)(j1 + 2 * C), (const R*)(j1 + 3 * C), (const R*)(j1 + 4 * C), (const R*)u_acc, accepted,
+        hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const Acc*)sums, (const Acc*)(sums + C), (const R*)ell1,
+                           (const R*)ell2, (const Acc*)(sums + 2 * C), (const Acc*)(sums + 3 * C), (const Acc*)(sums + 4 * C), (const R*)u_acc, accepted,
                            (R*)logs);
     } else {
         // wide-state path: joint log-densities of both auxiliary models (posterior_logpdf + ell, base.py:72-96), then the SV terms
@@ -879,7 +880,7 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     for (int q = 0; q < 4; ++q) add(CT * D * sR);             // u, ms, xp, (spare)
     add(CT * D * D * sR);                                     // Ps
     add(2 * (size_t)C * n * (9 + 3) * sR + 1024);             // Fs1, bs1, Fs2, bs2
-    add((size_t)16 * C * sR + 2048);
+    add((size_t)16 * C * sR + (size_t)5 * C * sizeof(Acc) + 2048);
     add(ke->filter_ws(h, kd, parallel));
     add(se->sample_ws(h, kd, parallel));
     add(sl->ws(h, kd));
@@ -898,8 +899,9 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
     R* Fs2 = (R*)ws_take(h, (size_t)C * n * 9 * sR);
     R* bs2 = (R*)ws_take(h, (size_t)C * n * 3 * sR);
     R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
-    if (!ysc || !Hc || !Rc || !cc || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc) return AUXSSM_ERR_NOMEM;
-    R* ell1 = sc; R* ell2 = sc + C; R* sums = sc + 2 * C;
+    Acc* sums = (Acc*)ws_take(h, (size_t)5 * C * sizeof(Acc));
+    if (!ysc || !Hc || !Rc || !cc || !u || !ms || !xp || !Ps || !Fs1 || !bs1 || !Fs2 || !bs2 || !sc || !sums) return AUXSSM_ERR_NOMEM;
+    R* ell1 = sc; R* ell2 = sc + C;
     const size_t mark = h->ws_off;
     const R* par = (const R*)model->Fs.ptr;  // [theta1, theta2, theta3, dt], chain stride model->Fs.sc (0 = one theta for all chains)
     const long long psc = model->Fs.sc;
@@ -999,8 +1001,8 @@ static int sweep_lorenz(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const
         if (rc) return rc;
         h->ws_off = mark;
     }
-    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)sums, (const R*)(sums + C), (const R*)ell1,
-                       (const R*)ell2, (const R*)(sums + 2 * C), (const R*)(sums + 3 * C), (const R*)(sums + 4 * C), (const R*)u_acc, accepted,
+    hipLaunchKernelGGL((k_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const Acc*)sums, (const Acc*)(sums + C), (const R*)ell1,
+                       (const R*)ell2, (const Acc*)(sums + 2 * C), (const Acc*)(sums + 3 * C), (const Acc*)(sums + 4 * C), (const R*)u_acc, accepted,
                        (R*)logs);
     if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, xpA, xA, cm))) return rc;
     AX_HIP(hipGetLastError());

@@ -142,8 +142,8 @@ __global__ void __launch_bounds__(TB_ELEM) k_joint_logpdf(LogpdfArgs a, R* __res
 
 // five per-chain sums of the fused sweep log-density pass; part layout [5][C][ntile]
 template <typename R, int D, int PO>
-__global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, R* __restrict__ part, int ntile) {
-    __shared__ R sh[TB_ELEM];
+__global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile) {
+    __shared__ Acc sh[TB_ELEM];
     const int C = a.d.C;
     int tile, c;
     decode_tile_seq(C, tile, c);
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, R* 
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const R tot = block_sum<R, TB_ELEM>(v[k], sh);
+        const Acc tot = block_sum<Acc, TB_ELEM>((Acc)v[k], sh);
         if (threadIdx.x == 0) part[((long long)k * C + c) * ntile + tile] = tot;
     }
 }
@@ -246,11 +246,16 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_i
     }
 }
 template <typename R, int D, int PO>
-__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
-    R v[5] = {0, 0, 0, 0, 0};
-    if (c.tt == 0) body_sweep_logpdf_head<R, D, PO>(a, c.s, v);
+    Acc v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) {
+        R h[5];
+        body_sweep_logpdf_head<R, D, PO>(a, c.s, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
+    }
     // stream the chain's values: (x, xp) of the previous step stay in registers, the next step's reads fly during this step's arithmetic
     const Arr& ua = a.u_fly ? a.eps_aux : a.u;
     R xq[D], xpq[D], xn[D], xpn[D], un[D];
@@ -283,7 +288,7 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, R*
 #pragma unroll
         for (int k = 0; k < D; ++k) xq[k] = xc[k], xpq[k] = xpc[k];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += w[k];
+        for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
@@ -294,11 +299,16 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_ELEM) 
     if (i < a.d.T - 1) body_sweep_logpdf_tab<R, D, PO>(a, i);
 }
 template <typename R, int D, int PO>
-__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
-    R v[5] = {0, 0, 0, 0, 0};
-    if (c.tt == 0) body_sweep_logpdf_head<R, D, PO>(a, c.s, v);
+    Acc v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) {
+        R h[5];
+        body_sweep_logpdf_head<R, D, PO>(a, c.s, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
+    }
     // stream the chain's values: (x, xp) of the previous step stay in registers, the next step's reads fly during this step's arithmetic
     const Arr& ua = a.u_fly ? a.eps_aux : a.u;
     R xq[D], xpq[D], xn[D], xpn[D], un[D];
@@ -323,15 +333,15 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArg
 #pragma unroll
         for (int k = 0; k < D; ++k) xq[k] = xc[k], xpq[k] = xpc[k];
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += w[k];
+        for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
 
 // the Lorenz sweep's five per-chain sums (kalman_bodies.h::body_lorenz_logpdf); part layout [5][C][ntile]
-template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_lorenz_logpdf(SweepLogpdfArgs a, R* __restrict__ part, int ntile) {
-    __shared__ R sh[TB_ELEM];
+template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_lorenz_logpdf(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile) {
+    __shared__ Acc sh[TB_ELEM];
     const int C = a.d.C;
     int tile, c;
     decode_tile_seq(C, tile, c);
@@ -348,29 +358,34 @@ template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_loren
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const R tot = block_sum<R, TB_ELEM>(v[k], sh);
+        const Acc tot = block_sum<Acc, TB_ELEM>((Acc)v[k], sh);
         if (threadIdx.x == 0) part[((long long)k * C + c) * ntile + tile] = tot;
     }
 }
-template <typename R, int PO> __global__ void __launch_bounds__(TB_CM) k_lorenz_logpdf_cm(SweepLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+template <typename R, int PO> __global__ void __launch_bounds__(TB_CM) k_lorenz_logpdf_cm(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
-    R v[5] = {0, 0, 0, 0, 0};
-    if (c.tt == 0) body_lorenz_logpdf_head<R, PO>(a, c.s, v);
+    Acc v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) {
+        R h[5];
+        body_lorenz_logpdf_head<R, PO>(a, c.s, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
+    }
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
         R w[5];
         body_lorenz_logpdf<R, PO>(a, c.s, opaque_uniform(i), true, w);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += w[k];
+        for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
 
 // the SV sweep's five per-chain sums (kalman_bodies.h::SvLogpdfArgs); part layout [5][C][ntile]
-template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_logpdf(SvLogpdfArgs a, R* __restrict__ part, int ntile) {
-    __shared__ R sh[TB_ELEM];
+template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_logpdf(SvLogpdfArgs a, Acc* __restrict__ part, int ntile) {
+    __shared__ Acc sh[TB_ELEM];
     const int C = a.d.C;
     int tile, c;
     decode_tile_seq(C, tile, c);
@@ -387,21 +402,26 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_log
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
-        const R tot = block_sum<R, TB_ELEM>(v[k], sh);
+        const Acc tot = block_sum<Acc, TB_ELEM>((Acc)v[k], sh);
         if (threadIdx.x == 0) part[((long long)k * C + c) * ntile + tile] = tot;
     }
 }
-template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sv_logpdf_cm(SvLogpdfArgs a, R* __restrict__ part, int ntile, int TI) {
+template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sv_logpdf_cm(SvLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
-    R v[5] = {0, 0, 0, 0, 0};
-    if (c.tt == 0) body_sv_logpdf_head<R, D>(a, c.s, v);
+    Acc v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) {
+        R h[5];
+        body_sv_logpdf_head<R, D>(a, c.s, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
+    }
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
         R w[5];
         body_sv_logpdf<R, D>(a, c.s, opaque_uniform(i), true, w);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) v[k] += w[k];
+        for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
@@ -1005,15 +1025,15 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
 }
 
 template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256 +
+    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(Acc) + 256 +
            (size_t)d.T * LogShared<R, D, PO>::NPAD * sizeof(R) + 256;
 }
-// out: [5][C]
+// out: [5][C] of Acc
 template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
     const bool cm = a.xp.se != 1;  // chain-minor proposal buffer -> lanes over chains
     const int n = a.d.T - 1;
     const int C = a.d.C, nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
-    R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
+    Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
     const bool shared_on = h->share_model != 0;
     const bool shared = shared_on && cm && n > 0 && C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 &&
@@ -1025,38 +1045,38 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
         hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, as, part, nt, TI_CM);
     } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
     else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
-    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
+    hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
 
 template <typename R, int D> size_t sv_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(R) + 256;
+    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(Acc) + 256;
 }
-// out: [5][C]
+// out: [5][C] of Acc
 template <typename R, int D> int run_sv_logpdf(auxssm_ctx* h, const SvLogpdfArgs& a, void* out) {
     const bool cm = a.xp.se != 1;
     const int n = a.d.T - 1, C = a.d.C;
     const int nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
-    R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
+    Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
     if (cm) hipLaunchKernelGGL((k_sv_logpdf_cm<R, D>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
     else hipLaunchKernelGGL((k_sv_logpdf<R, D>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
-    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
+    hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
 
-// out: [5][C]; instantiated for D = 3 only (null entry otherwise)
+// out: [5][C] of Acc; instantiated for D = 3 only (null entry otherwise)
 template <typename R, int PO> int run_lorenz_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
     const bool cm = a.xp.se != 1;
     const int n = a.d.T - 1, C = a.d.C;
     const int nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
-    R* part = (R*)ws_take(h, (size_t)5 * C * nt * sizeof(R));
+    Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
     if (cm) hipLaunchKernelGGL((k_lorenz_logpdf_cm<R, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
     else hipLaunchKernelGGL((k_lorenz_logpdf<R, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
-    hipLaunchKernelGGL((k_reduce_rows<R>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)nullptr, 1, nt, (R*)out);
+    hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -34,6 +34,10 @@ template <typename R> AX_HD R min_(R a, R b) { return a < b ? a : b; }
 
 constexpr double LOG_2PI = 1.8378770664093454835606594728112;
 
+// The per-chain log-density totals of a sweep (sums over T terms of the Metropolis-Hastings ratio) are accumulated, reduced and compared in
+// fp64 whatever the working precision: at T = 65536 an fp32 total is ~3e5 with a 0.03 ulp, and log alpha is a difference of six of them.
+typedef double Acc;
+
 // packed symmetric storage: upper triangle, row-major.  (i <= j)
 AX_HD constexpr int symsize(int D) { return D * (D + 1) / 2; }
 AX_HD constexpr int sidx_u(int D, int i, int j) { return i * D - (i * (i - 1)) / 2 + (j - i); }

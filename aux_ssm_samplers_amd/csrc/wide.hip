@@ -1756,13 +1756,15 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_fold_down(FilterA
 }
 
 // out[r] = sum_{b < B} ( add0[r B + b] + sum_{i < n} part[(r B + b) n + i] ), fixed order; one workgroup per output
-template <typename R> __global__ void __launch_bounds__(NT) wk_reduce(const R* __restrict__ part, const R* __restrict__ add0, int B, long long n, R* __restrict__ out) {
-    __shared__ R sh[NT];
+// (O: the type of the sum -- Acc for the sweep's log-density totals, smallmat.h)
+template <typename R, typename O = R>
+__global__ void __launch_bounds__(NT) wk_reduce(const R* __restrict__ part, const R* __restrict__ add0, int B, long long n, O* __restrict__ out) {
+    __shared__ O sh[NT];
     const int tid = threadIdx.x, r = blockIdx.x;
-    R acc = 0;
+    O acc = 0;
     for (int b = 0; b < B; ++b) {
         const R* q = part + ((long long)r * B + b) * n;
-        for (long long i = tid; i < n; i += NT) acc += q[i];
+        for (long long i = tid; i < n; i += NT) acc += (O)q[i];
     }
     sh[tid] = acc;
     __syncthreads();
@@ -1771,9 +1773,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_reduce(const R* _
         __syncthreads();
     }
     if (tid == 0) {
-        R v = sh[0];
+        O v = sh[0];
         if (add0)
-            for (int b = 0; b < B; ++b) v += add0[(long long)r * B + b];
+            for (int b = 0; b < B; ++b) v += (O)add0[(long long)r * B + b];
         out[r] = v;
     }
 }
@@ -2366,7 +2368,7 @@ template <typename R> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs&
     if (!part) return AUXSSM_ERR_NOMEM;
     ProfScope ps(h, AUXSSM_K_LOGPDF);
     WK_LAUNCH((wk_sweep_logpdf<R>), (long long)C * T, lds_sweep_logpdf(sizeof(R), a.dx, a.po), a, part);
-    hipLaunchKernelGGL((wk_reduce<R>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (R*)out);
+    hipLaunchKernelGGL((wk_reduce<R, Acc>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (Acc*)out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -349,6 +349,37 @@ def test_shared_model_mode_equals_general_path(dtype, nan_policy):
     assert np.all(np.isfinite(res[1][0]))
 
 
+@pytest.mark.parametrize("layout", ["cm_shared", "cm_general", "dense"])
+def test_fp32_sweep_log_alpha_uses_fp64_totals(layout):
+    """fp32 sweep at T = 32768: the five per-chain log-density totals are ~1e5, where an fp32 ulp is 0.008-0.016, and log alpha differences six of
+    them -- held in fp32 that was |log alpha| ~ 0.1 and 1-2 % spurious rejections of an exact proposal (C2 in fp32: 0.13, acceptance 0.988).  The
+    device sweep accumulates, reduces and compares them in fp64 (csrc/smallmat.h::Acc): on a linear-Gaussian model, where log alpha == 0 exactly,
+    what is left is the rounding of the individual fp32 terms."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import LGConcatModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler, _get_device_kernel
+    d, T, C = 4, 32768, 64
+    m = lg_model(T, d)
+    bt = np.broadcast_to
+    model = LGConcatModel(m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)),
+                          bt(m["Hobs"], (T, d, d)), bt(m["Robs"], (T, d, d)), bt(m["cobs"], (T, d)), m["y"])
+    init, kernel = _get_device_kernel(model, True, "reference")
+    rng = np.random.default_rng(5)
+    x0 = (m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))).astype(np.float32)
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    try:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1 if layout == "cm_shared" else 0)
+        chains = DeviceChains(h, x0, chain_minor=layout != "dense")
+        kernel(None, KalmanSampler(x=chains, updated=None), 0.5, noise=noise)
+        logs, acc = chains.logs.to_host(), chains.accepted.to_host()
+    finally:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    assert np.abs(logs[:, 1:]).min() > 1e4  # the totals are large ...
+    assert np.abs(logs[:, 0]).max() < 5e-3, np.abs(logs[:, 0]).max()  # ... and their combination is not rounded to their ulp
+    assert acc.all()
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("n,nu", [(1, 1), (7, 3), (4096, 64), (100001, 257)])
 def test_fused_sweep_noise_draw_equals_the_three_fills(dtype, n, nu):
