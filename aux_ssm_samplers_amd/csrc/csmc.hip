@@ -180,7 +180,7 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     R* cbuf = (R*)smem;                 // [2][CP]
     R* xbuf = cbuf + 2 * CP;            // [2][TB][D]
     R* red = xbuf + 2 * TB * D;         // [48]
-    const int ch = blockIdx.x;
+    const int ch = a.c0 + blockIdx.x;
     const bool live = NW > 0 ? true : tid < N;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
@@ -398,7 +398,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
     R* xpub = red + 48;              // [2][TB][D] candidate particles of the step, by step parity
     R* ubuf = xpub + 2 * TB * D;     // [2] the step's uniform, by step parity
     int* cnt = (int*)(ubuf + 2);     // [2][16] per-wave counts, by step parity
-    const int ch = blockIdx.x;
+    const int ch = a.c0 + blockIdx.x;
     const bool live = NW > 0 ? true : tid < N;
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
     const R* lws = (const R*)a.lws + (long long)ch * T * N;
@@ -613,6 +613,15 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
             hipLaunchKernelGGL((k_csmc_grad<R, D>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, a, m);
         }
     }
+    // forward + backward pass, batch of chains by batch (CsmcArgs::c0; one batch unless the particle systems of all chains do not fit the device)
+    const int cb = a.cb > 0 ? a.cb : a.C;
+    for (int c0 = 0; c0 < a.C; c0 += cb) {
+    CsmcArgs ab = a;
+    ab.c0 = c0;
+    ab.C = a.C - c0 < cb ? a.C - c0 : cb;
+    ab.xs = (char*)a.xs - (size_t)c0 * a.xs_rec;
+    ab.lws = (char*)a.lws - (size_t)c0 * a.lws_rec;
+    if (a.As) ab.As = (int32_t*)((char*)a.As - (size_t)c0 * a.As_rec);
     {
         ProfScope ps(h, AUXSSM_K_CSMC_FWD);
         const size_t lds = (size_t)2 * (cpad(TB) + TB * D) * sizeof(R) + 48 * sizeof(R) + 64;
@@ -621,7 +630,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
 #define AX_FWD1(TVv, GRv, NWv)                                                                                                                                  \
     do {                                                                                                                                                        \
         if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D, TVv, GRv, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_csmc_fwd<R, D, TVv, GRv, NWv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
+        hipLaunchKernelGGL((k_csmc_fwd<R, D, TVv, GRv, NWv>), dim3(ab.C), dim3(TB), lds, h->stream, ab, m);                                                   \
     } while (0)
 #define AX_FWD(TVv, GRv)                \
     do {                                \
@@ -643,7 +652,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
 #define AX_BWD(TVv, NWv)                                                                                                                                 \
     do {                                                                                                                                                 \
         if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_bwd<R, D, TVv, NWv>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((k_csmc_bwd<R, D, TVv, NWv>), dim3(a.C), dim3(TB), lds, h->stream, a, m);                                                     \
+        hipLaunchKernelGGL((k_csmc_bwd<R, D, TVv, NWv>), dim3(ab.C), dim3(TB), lds, h->stream, ab, m);                                                   \
     } while (0)
         if (m.Ft) {
             if (fullw == 16) AX_BWD(true, 16);
@@ -655,6 +664,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
             else AX_BWD(false, 0);
         }
 #undef AX_BWD
+    }
     }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
@@ -818,10 +828,37 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     }
     const size_t sR = dtype == AUXSSM_F32 ? 4 : 8;
     const size_t CT = (size_t)C * T;
+    // the particle systems (xs, lws, As) dominate: T N (D + 1) reals per chain.  When those of all C chains do not fit what the device has free
+    // (counting the handle's current workspace, which a larger reservation replaces), the sweep runs in batches of cb chains (CsmcArgs::c0)
+    const size_t xs_rec = xs_out ? 0 : (size_t)T * N * D * sR, lws_rec = log_ws_out ? 0 : (size_t)T * N * sR;
+    const size_t As_rec = (!backward && !As_out) ? (size_t)(T > 1 ? T - 1 : 1) * N * 4 : 0;
+    const size_t big = xs_rec + lws_rec + As_rec;
+    int cb = C;
+    if (big) {
+        const size_t small = 4096 + 8 * 256 + (size_t)C * N * sR + CT * sR + 2 * (size_t)T * sR + 2 * CT * D * sR;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
+            const double budget = 0.8 * (double)(fr + h->ws_bytes);  // (ws_reserve adds an eighth)
+            if ((double)small + (double)C * (double)big > budget) {
+                const double fit = (budget - (double)small) / (double)big;
+                if (fit < 1.0) {
+                    set_error("one chain's particle system (%zu bytes) does not fit the device (%zu free)", big, fr + h->ws_bytes);
+                    return AUXSSM_ERR_NOMEM;
+                }
+                if (fit < (double)cb) cb = (int)fit;
+                if (cb > h->num_cu) cb -= cb % h->num_cu;  // one workgroup per chain and CU: whole rounds of the chip per batch
+            }
+        }
+        if (const char* ev = getenv("AUXSSM_CSMC_BATCH")) {  // tests: force small batches
+            const int v = atoi(ev);
+            if (v >= 1 && v < cb) cb = v;
+        }
+    }
+    const size_t CBT = (size_t)cb * T;
     size_t need = 4096;
-    if (!xs_out) need += CT * N * D * sR + 256;
-    if (!log_ws_out) need += CT * N * sR + 256;
-    if (!backward && !As_out) need += (size_t)C * (T > 1 ? T - 1 : 1) * N * 4 + 256;
+    if (!xs_out) need += CBT * N * D * sR + 256;
+    if (!log_ws_out) need += CBT * N * sR + 256;
+    if (!backward && !As_out) need += (size_t)cb * (T > 1 ? T - 1 : 1) * N * 4 + 256;
     need += (size_t)C * N * sR + 256;
     need += CT * sR + 256;  // fmax
     need += (size_t)T * sR + 256;  // gb
@@ -836,9 +873,10 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.u = ws_take(h, CT * D * sR);
     a.grad = fk->gradient ? ws_take(h, CT * D * sR) : nullptr;
     void* ctt = fk->F_t ? ws_take(h, (size_t)T * sR) : nullptr;
-    a.xs = xs_out ? xs_out : ws_take(h, CT * N * D * sR);
-    a.lws = log_ws_out ? log_ws_out : ws_take(h, CT * N * sR);
-    a.As = As_out ? As_out : (!backward ? (int32_t*)ws_take(h, (size_t)C * (T > 1 ? T - 1 : 1) * N * 4) : nullptr);
+    a.cb = cb; a.xs_rec = xs_rec; a.lws_rec = lws_rec; a.As_rec = As_rec;
+    a.xs = xs_out ? xs_out : ws_take(h, CBT * N * D * sR);
+    a.lws = log_ws_out ? log_ws_out : ws_take(h, CBT * N * sR);
+    a.As = As_out ? As_out : (!backward ? (int32_t*)ws_take(h, (size_t)cb * (T > 1 ? T - 1 : 1) * N * 4) : nullptr);
     a.wT = ws_take(h, (size_t)C * N * sR);
     a.fmax = ws_take(h, (size_t)C * T * sR);
     static const bool bound_on = !getenv("AUXSSM_CSMC_NO_BOUND");

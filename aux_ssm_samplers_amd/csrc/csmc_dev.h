@@ -61,6 +61,13 @@ struct CsmcArgs {
     const void* eps_prop;  // (C, T, N, D)
     const void* u_res;     // (C, T-1, N)
     const void* u_bwd;     // (C, T)
+    // chain batching (csmc.hip::auxssm_csmc_sweep): the particle system of one chain is T N (D + 1) reals -- 537 MB at C3 -- so a sweep over more chains
+    // than the device holds runs the forward + backward pair batch by batch, [c0, c0 + C) per launch.  Every array above is indexed by the GLOBAL
+    // chain c0 + blockIdx.x (so are the random streams: a batched sweep is bit for bit the unbatched one); the workspace-owned xs / lws / As of a
+    // batch are passed with their base moved back by c0 records.
+    int c0 = 0;
+    int cb = 0;                               // host side: chains per batch
+    size_t xs_rec = 0, lws_rec = 0, As_rec = 0;  // host side: bytes per chain of the workspace-owned arrays (0: caller-owned, indexed globally anyway)
 };
 
 enum { STREAM_EPS_AUX = 1, STREAM_EPS_PROP = 2, STREAM_U_RES = 3, STREAM_U_BWD = 4 };

@@ -278,6 +278,10 @@ typedef struct {
     const void* u_res;
     const void* u_bwd;
 } auxssm_csmc_noise;
+/* xs_out / log_ws_out / As_out NULL: the particle systems live in the handle's workspace, T N (dx + 1) reals (+ 4 T N bytes of traced ancestors)
+ * per chain.  When those of all C chains exceed what the device has free, the forward + backward pair runs over batches of chains (whole rounds of
+ * the chip: one workgroup per chain and CU) -- same results bit for bit, every array and random stream being indexed by the global chain;
+ * AUXSSM_ERR_NOMEM only when a single chain does not fit. */
 int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_model* model, int32_t C, int32_t T, int32_t N,
                       int32_t backward, const void* sqrt_half_delta, void* x, const auxssm_csmc_noise* noise,
                       int32_t* ancestors, void* xs_out, void* log_ws_out, int32_t* As_out);

@@ -100,6 +100,33 @@ def test_multichain_equals_single_chain_and_threefry_equals_explicit(T):
 
 
 @pytest.mark.parametrize("backward", [True, False])
+@pytest.mark.parametrize("mode", ["threefry", "explicit"])
+def test_chain_batched_sweep_equals_one_launch(backward, mode, monkeypatch):
+    """A chain's particle system is T N (D + 1) reals (537 MB at C3), so a sweep over more chains than the device holds runs the forward + backward pair
+    batch by batch (csrc/csmc.hip, CsmcArgs::c0).  Forced here with AUXSSM_CSMC_BATCH = 2 on 5 chains: the same trajectories and ancestors bit for bit,
+    for in-kernel Threefry noise (streams indexed by the global chain) and explicit arrays, backward sampling and ancestor tracing (As in the workspace)."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.csmc import _device
+    rng = np.random.default_rng(8)
+    d, N, C, T = 2, 192, 5, 37
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(O.POT_GAUSS_OBS, y)
+    fk = _device.describe_independent(M0, G0, Mt, Gt, Mt)
+    x0 = rng.standard_normal((C, T, d)).astype(np.float32)
+    key = R.PRNGKey(123)
+    kw = dict(key=key) if mode == "threefry" else dict(noise=_device.key_noise(_lib.default_handle(), key, C, T, N, d, np.float32))
+    monkeypatch.delenv("AUXSSM_CSMC_BATCH", raising=False)
+    xa, anca, _ = _device.sweep(fk, x0, N, backward, delta=0.5, **kw)
+    for cb in ("2", "1", "4"):
+        monkeypatch.setenv("AUXSSM_CSMC_BATCH", cb)
+        xb, ancb, _ = _device.sweep(fk, x0, N, backward, delta=0.5, **kw)
+        npt.assert_array_equal(xa, xb)
+        npt.assert_array_equal(anca, ancb)
+    assert len({xa[c].tobytes() for c in range(C)}) == C  # (the chains do differ)
+
+
+@pytest.mark.parametrize("backward", [True, False])
 def test_flat_potential_reference_statistical_test(backward):
     """aux_samplers/_primitives/test_csmc/test_csmc.py::test_flat_potential (:18-69) on the HIP path: AR(1) prior is
     invariant: mean 0, var 1, lag-1 cov rho, atol 0.05.  2048 chains x 40 sweeps instead of 1 chain x 50_000."""
