@@ -106,17 +106,21 @@ AXD_HD double det_exp(double x) {
 }
 
 // ---- log, fp64 (fdlibm e_log) ----------------------------------------------------------------------------------------
-AXD_HD double det_log(double x) {
-    if (!(x == x)) return x;
-    if (x < 0.0) return NAN;
-    if (x == 0.0) return -INFINITY;
-    if (x == INFINITY) return x;
+// NORMAL: the caller guarantees a positive, finite, normal x (the Box-Muller uniforms (b + 0.5) 2^-32 are in [2^-33, 1)): the same value bit for bit
+// without the special-case branches, which split the noise-drawing scan passes into a dozen basic blocks.
+template <bool NORMAL = false> AXD_HD double det_log(double x) {
     uint64_t ix = d2u(x);
     int e = 0;
-    if (ix < 0x0010000000000000ull) {
-        x = x * 18014398509481984.0;  // 2^54
-        ix = d2u(x);
-        e = -54;
+    if constexpr (!NORMAL) {
+        if (!(x == x)) return x;
+        if (x < 0.0) return NAN;
+        if (x == 0.0) return -INFINITY;
+        if (x == INFINITY) return x;
+        if (ix < 0x0010000000000000ull) {
+            x = x * 18014398509481984.0;  // 2^54
+            ix = d2u(x);
+            e = -54;
+        }
     }
     uint32_t hx = (uint32_t)(ix >> 32);
     e += (int)(hx >> 20) - 1023;

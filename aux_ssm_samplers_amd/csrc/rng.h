@@ -79,7 +79,7 @@ template <> AX_HD void bits_to_normal2<double>(uint32_t b0, uint32_t b1, double&
     const double u2 = ((double)b1 + 0.5) * 2.3283064365386963e-10;
     // det_log: the fdlibm-style sequence of det_math.h (about thirty fp64 operations; libm's log is about sixty on the device, and the
     // chain-shared scans draw their noise inside memory-bound passes where every fp64 instruction shows).  1-2 ulp, as before.
-    const double r = sqrt(-2.0 * det_log(u1));
+    const double r = sqrt(-2.0 * det_log<true>(u1));
     double c, s;
     sincos_2pi<double>(u2, c, s);
     z0 = r * c;
