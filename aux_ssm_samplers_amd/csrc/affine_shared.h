@@ -174,6 +174,7 @@ template <typename R, int D, int P, bool WRITE_U, bool GEN = false> AX_HD void a
 template <typename R_, int D, int P> struct FilterMeanOp {
     using R = R_;
     using Args = FilterArgs;
+    static constexpr int kAffWaves = 11;
     using T = GainRow<R, D, P>;
     static AX_HD int length(const Args& a) { return a.d.n(); }
     static AX_HD void mat(const Args& a, int i, R* G) {

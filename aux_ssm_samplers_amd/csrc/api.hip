@@ -47,9 +47,10 @@ void* ws_take(auxssm_ctx* h, size_t bytes) {
     return h->ws + off;
 }
 
-// about four waves per SIMD of (chain tile, chunk) lanes (measured at C2 x 256 chains: E = 64 beats 16 / 32 by 4 %): a chain's state is
-// a handful of registers, the passes stream their inputs
-AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
+// `waves` (chain tile, chunk) lanes per SIMD: a chain's state is a handful of registers and the passes stream their inputs, so more, shorter chunks
+// hide more latency until the aggregate pass grows.  Measured at C2 x 256 chains, three runs each, after the noise-drawing reduce pass went from 89 to
+// 60 registers: filter scan 0.909 / 0.872 / 0.816 ms at E = 64 / 32 / 24, sampler scan 0.762 / 0.727 / 0.742 -- hence 11 and 8 (kernels.hip.h::AffWaves)
+AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel, int waves) {
     AffPlan p;
     if (!parallel || N <= 2) {
         p.E = N > 0 ? N : 1;
@@ -57,7 +58,7 @@ AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel) {
         return p;
     }
     const long long stiles = (S + 64 /* TB_CM */ - 1) / 64 /* TB_CM */;
-    long long want = (long long)h->num_cu * 4 * 4 / stiles;  // chunks
+    long long want = (long long)h->num_cu * 4 * waves / stiles;  // chunks
     if (want < 1) want = 1;
     long long E = (N + want - 1) / want;
     if (E < 16) E = 16;

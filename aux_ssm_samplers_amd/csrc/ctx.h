@@ -90,7 +90,7 @@ ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel);
 struct AffPlan {  // chunking of the chain-shared affine scans (kernels.hip.h: run_affine)
     int E, nchunk;
 };
-AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel);
+AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel, int waves = 8);
 
 typedef int (*filter_fn)(auxssm_ctx*, const FilterArgs&, int parallel, void* ell_out /*[C]*/);
 typedef int (*sample_fn)(auxssm_ctx*, const SampleArgs&, int parallel);

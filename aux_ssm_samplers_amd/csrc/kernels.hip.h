@@ -734,14 +734,19 @@ __global__ void __launch_bounds__(TB_CM) k_aff_down(typename Op::Args a, ScanBuf
     for (int j = j0; j < j1; ++j) Op::walk(a, s, opaque_uniform(j), h, acc);
     if (part) part[(long long)s * pl.nchunk + ch] = acc;
 }
+// chunks per SIMD lane of an affine recursion (api.hip::plan_aff): the operator's own figure, else 8
+template <class Op, typename = void> struct AffWaves { static constexpr int value = 8; };
+template <class Op> struct AffWaves<Op, decltype((void)Op::kAffWaves)> { static constexpr int value = Op::kAffWaves; };
+constexpr int kAffWavesMax = 11;
 template <typename R, int D> size_t aff_ws_bytes(const auxssm_ctx* h, int S, int N, int parallel) {
-    const AffPlan pl = plan_aff(h, S, N, parallel);
+    const AffPlan pl = plan_aff(h, S, N, parallel, kAffWavesMax);  // (the workspace of the operator with the most chunks)
     return (size_t)S * pl.nchunk * (SampElem<R, D>::NPAD + SampPre<R, D>::NPAD + 1) * sizeof(R) + (size_t)pl.nchunk * D * D * sizeof(R) + 1024;
 }
 // part: [S][nchunk] accumulators of the down pass (may be null); returns the chunk count through *nchunk_out
 template <class Op, int D> int run_affine(auxssm_ctx* h, const typename Op::Args& a, int S, int N, int parallel, typename Op::R** part_out, int* nchunk_out) {
     using R = typename Op::R;
-    const AffPlan pl = plan_aff(h, S, N, parallel);
+    static_assert(AffWaves<Op>::value <= kAffWavesMax, "aff_ws_bytes sizes for kAffWavesMax");
+    const AffPlan pl = plan_aff(h, S, N, parallel, AffWaves<Op>::value);
     ScanBufs sb{nullptr, nullptr};
     R* part = part_out ? (R*)ws_take(h, (size_t)S * pl.nchunk * sizeof(R)) : nullptr;
     if (part_out) *part_out = part;
