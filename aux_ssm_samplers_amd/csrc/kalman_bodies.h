@@ -998,6 +998,25 @@ struct SvLogpdfArgs {
     double delta;
     const double* dptr = nullptr;  // device-resident {delta, sqrt(delta / 2)}; null: the host value
 };
+// Kernels call resolve_step(a) on their by-value argument struct first: a device-resident step size (dptr) is read ONCE, into the host fields, and the
+// pointer cleared, so that arg_delta / arg_shd / arg_aux_shd are loop-invariant scalars in every per-step body.  (Left to the bodies, the conditional
+// load sat inside the time loops with an `s_waitcnt vmcnt(0)` behind it -- which also waited for the next step's prefetched reads.)
+template <typename A> AX_HD void resolve_step(A&) {}
+AX_HD void resolve_step(FilterArgs& a) {
+    const double* p = a.dptr;
+    a.dptr = nullptr;
+    if (p) a.aux_shd = p[1];
+}
+AX_HD void resolve_step(SweepLogpdfArgs& a) {
+    const double* p = a.dptr;
+    a.dptr = nullptr;
+    if (p) a.delta = p[0], a.shd = p[1];
+}
+AX_HD void resolve_step(SvLogpdfArgs& a) {
+    const double* p = a.dptr;
+    a.dptr = nullptr;
+    if (p) a.delta = p[0];
+}
 template <typename R, int D>
 AX_HD void sv_step_terms(const SvLogpdfArgs& a, int c, long long t, const R* x, const R* xp, R* o5) {
     R u[D], y[D], y1[D], y2[D];

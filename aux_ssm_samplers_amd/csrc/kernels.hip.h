@@ -115,6 +115,7 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
 // grid = ntile * S, sequence index fastest so that workgroups of different chains touching the same time
 // tile (hence the same chain-shared model parameters) are co-scheduled and share them through L2.
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_init(FilterArgs a) {
+    resolve_step(a);
     int tile, s;
     decode_tile_seq(a.d.S(), tile, s);
     const int i = tile * TB_ELEM + threadIdx.x;
@@ -143,6 +144,7 @@ __global__ void __launch_bounds__(TB_ELEM) k_joint_logpdf(LogpdfArgs a, R* __res
 // five per-chain sums of the fused sweep log-density pass; part layout [5][C][ntile]
 template <typename R, int D, int PO>
 __global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile) {
+    resolve_step(a);
     __shared__ Acc sh[TB_ELEM];
     const int C = a.d.C;
     int tile, c;
@@ -223,6 +225,7 @@ __device__ __forceinline__ CmTile decode_cm(int S, int n, int TI) {
 inline unsigned grid_cm(int S, int n, int TI) { return (unsigned)((S + TB_CM - 1) / TB_CM) * (unsigned)((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1); }
 
 template <typename R, int D, int P, int P1> __global__ void __launch_bounds__(TB_CM) k_filter_init_cm(FilterArgs a, int TI) {
+    resolve_step(a);
     const CmTile c = decode_cm(a.d.S(), a.d.n(), TI);
     if (!c.live) return;
     DirectIO io;
@@ -247,6 +250,7 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sample_i
 }
 template <typename R, int D, int PO>
 __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
+    resolve_step(a);
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
     Acc v[5] = {0, 0, 0, 0, 0};
@@ -300,6 +304,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_ELEM) 
 }
 template <typename R, int D, int PO>
 __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
+    resolve_step(a);
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
     Acc v[5] = {0, 0, 0, 0, 0};
@@ -341,6 +346,7 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArg
 
 // the Lorenz sweep's five per-chain sums (kalman_bodies.h::body_lorenz_logpdf); part layout [5][C][ntile]
 template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_lorenz_logpdf(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile) {
+    resolve_step(a);
     __shared__ Acc sh[TB_ELEM];
     const int C = a.d.C;
     int tile, c;
@@ -363,6 +369,7 @@ template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_loren
     }
 }
 template <typename R, int PO> __global__ void __launch_bounds__(TB_CM) k_lorenz_logpdf_cm(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
+    resolve_step(a);
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
     Acc v[5] = {0, 0, 0, 0, 0};
@@ -385,6 +392,7 @@ template <typename R, int PO> __global__ void __launch_bounds__(TB_CM) k_lorenz_
 
 // the SV sweep's five per-chain sums (kalman_bodies.h::SvLogpdfArgs); part layout [5][C][ntile]
 template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_logpdf(SvLogpdfArgs a, Acc* __restrict__ part, int ntile) {
+    resolve_step(a);
     __shared__ Acc sh[TB_ELEM];
     const int C = a.d.C;
     int tile, c;
@@ -407,6 +415,7 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_log
     }
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sv_logpdf_cm(SvLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
+    resolve_step(a);
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
     Acc v[5] = {0, 0, 0, 0, 0};
@@ -430,6 +439,7 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sv_logpd
 // scan passes: lane <-> sequence, workgroup <-> (chunk, 64 sequences)
 template <class Op>
 __global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
+    resolve_step(a);
     using R = typename Op::R;
     using Full = typename Op::Full;
     const ScanLayout lay = Op::layout(a);
@@ -469,6 +479,7 @@ template <class Op, typename = void> struct DownWaves { static constexpr int val
 template <class Op> struct DownWaves<Op, decltype((void)Op::kDownWaves)> { static constexpr int value = Op::kDownWaves; };
 template <class Op>
 __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(typename Op::Args a, ScanBufs sb, int S, int n) {
+    resolve_step(a);
     using R = typename Op::R;
     using Full = typename Op::Full;
     using Pre = typename Op::Pre;
@@ -515,6 +526,7 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
 // one wave = one group of 64 chunks of one sequence; row k of the group is 64 contiguous records (ScanLayout)
 template <class Op>
 __global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, ScanBufs sb, int n) {
+    resolve_step(a);
     using R = typename Op::R;
     using Full = typename Op::Full;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -605,6 +617,7 @@ template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanB
 
 template <class Op>
 __global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, ScanBufs sb, int n) {
+    resolve_step(a);
     using R = typename Op::R;
     using Full = typename Op::Full;
     using Pre = typename Op::Pre;
@@ -660,6 +673,7 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
     if (i < a.d.n()) body_gain_tab<R, D, P>(a, Ps1, i);
 }
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_obs_info_tab(FilterArgs a) {
+    resolve_step(a);
     const int i = blockIdx.x * TB_ELEM + threadIdx.x;
     if constexpr (P > D) {
         if (i < a.d.n()) body_obs_info_tab<R, D, P>(a, i);
@@ -702,6 +716,7 @@ template <class Op, int D> __global__ void __launch_bounds__(TB_CM) k_aff_chunkp
 }
 template <class Op, int D>
 __global__ void __launch_bounds__(TB_CM) k_aff_reduce(typename Op::Args a, ScanBufs sb, const typename Op::R* __restrict__ cprod, int S, int N, AffPlan pl) {
+    resolve_step(a);
     using R = typename Op::R;
     using Full = SampElem<R, D>;
     int ch, s;
@@ -722,6 +737,7 @@ __global__ void __launch_bounds__(TB_CM) k_aff_reduce(typename Op::Args a, ScanB
 }
 template <class Op, int D>
 __global__ void __launch_bounds__(TB_CM) k_aff_down(typename Op::Args a, ScanBufs sb, typename Op::R* __restrict__ part, int S, int N, AffPlan pl) {
+    resolve_step(a);
     using R = typename Op::R;
     int ch, s;
     if (!decode_aff(S, pl.nchunk, ch, s)) return;
