@@ -136,6 +136,20 @@ template <typename R, int D, int P> AX_HD void body_gain_tab(const FilterArgs& a
     rd_upper<R, P>(a.Rs, 0, t, 0, Rm);
     ld<R, D * D>(Ps1 + (long long)i * D * D, Pp);
     gain_row<R, D, P>(F, bd, Q, Pp, H, cv, Rm, y, row);
+    if constexpr (P > D) {
+        // concatenated observations y_t = [u_t ; yobs_t]: the yobs part is the data's, the same for every chain, so its contribution goes into the
+        // row once -- kc += K[:, D:] yobs_t and ym[D:] -= yobs_t (masked components: K columns, HF rows and ym are zero already) -- and a chain's
+        // fold / walk only touch its own D auxiliary components (FilterMeanOp, `folded`)
+        if (a.aux_on) {
+#pragma unroll
+            for (int k = D; k < P; ++k) {
+                const R yk = finite_(y[k]) ? y[k] : (R)0;
+#pragma unroll
+                for (int r = 0; r < D; ++r) row[T::oKc + r] += row[T::oK + r * P + k] * yk;
+                row[T::oYm + k] -= yk;
+            }
+        }
+    }
     stv<R, T::N>((R*)a.tab + (long long)i * T::NPAD, row);
 }
 
@@ -165,6 +179,21 @@ template <typename R, int D, int P, bool WRITE_U, bool GEN = false> AX_HD void a
     }
 }
 
+// the chain's own part of a concatenated observation: u_t = x_t + shd eps_t (GEN: drawn here, as in aff_obs)
+template <typename R, int D, bool GEN> AX_HD void aff_aux(const FilterArgs& a, int s, long long t, R* u) {
+    const int c = s / a.d.B, b = s % a.d.B;
+    R xv[D], ev[D];
+    rd<R, D>(a.aux_x, c, t, b, xv);
+    if constexpr (GEN) {
+        normals_cm<R, D>(a.gen_k0, a.gen_k1, (long long)c * a.aux_eps.sc + t * a.aux_eps.st + (long long)b * a.aux_eps.sb, a.aux_eps.se, ev);
+        wr<R, D>(a.aux_eps, c, t, b, ev);
+    } else {
+        rd<R, D>(a.aux_eps, c, t, b, ev);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = xv[k] + (R)arg_aux_shd(a) * ev[k];
+}
+
 // ---- the two chain-shared affine recursions behind one interface ------------------------------------------------------------------
 //   N                    number of scan positions
 //   mat(a, j, G)         the chain-shared matrix of position j                              (table kernels, lane = chunk)
@@ -185,6 +214,25 @@ template <typename R_, int D, int P> struct FilterMeanOp {
     static AX_HD void init(const Args& a, int s, R* h) { rd<R, D>(a.ms, s / a.d.B, 0, s % a.d.B, h); }  // m0+ of the chain (k_filter_t0)
     static AX_HD void fold(const Args& a, int s, int i, R* h) {
         const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
+        if constexpr (P > D) {
+            if (a.aux_on) {  // folded rows (body_gain_tab): only the chain's D auxiliary components are left
+                R u[D], o[D];
+                if (a.aux_gen) aff_aux<R, D, true>(a, s, (long long)i + 1, u);  // (the reduce pass reads every position first)
+                else aff_aux<R, D, false>(a, s, (long long)i + 1, u);
+#pragma unroll
+                for (int r = 0; r < D; ++r) {
+                    R v = row[T::oKc + r];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v += row[T::oM + r * D + k] * h[k];
+#pragma unroll
+                    for (int k = 0; k < D; ++k) v += row[T::oK + r * P + k] * (finite_(u[k]) ? u[k] : (R)0);
+                    o[r] = v;
+                }
+#pragma unroll
+                for (int r = 0; r < D; ++r) h[r] = o[r];
+                return;
+            }
+        }
         R y[P];
         if (a.aux_gen) aff_obs<R, D, P, false, true>(a, s, (long long)i + 1, y);  // (the reduce pass reads every position first)
         else aff_obs<R, D, P, false>(a, s, (long long)i + 1, y);
@@ -204,19 +252,33 @@ template <typename R_, int D, int P> struct FilterMeanOp {
     // m_t = Mb m + kc + K y (the same affine step as fold) and the innovation r = y - H (F m + b) - c = y - HF m - ym for the
     // log-likelihood increment -r^T S^-1 r / 2 + c0; both read the incoming mean only, so they issue independently
     static AX_HD void walk(const Args& a, int s, int i, R* m, R& acc) {
+        if constexpr (P > D) {
+            if (a.aux_on) return walk_impl<true>(a, s, i, m, acc);
+        }
+        walk_impl<false>(a, s, i, m, acc);
+    }
+    // FOLDED: rows of body_gain_tab with the data's part of a concatenated observation folded in -- y[D:] does not appear: its K columns are in kc,
+    // and r[k >= D] = -(HF_k m + ym'_k) with ym' = ym - yobs (all zero for a masked component)
+    template <bool FOLDED> static AX_HD void walk_impl(const Args& a, int s, int i, R* m, R& acc) {
+        constexpr int PA = FOLDED ? D : P;  // the chain's own components
         const long long t = (long long)i + 1;
         const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
-        R y[P];
-        aff_obs<R, D, P, false>(a, s, t, y);
+        R y[PA];
+        if constexpr (FOLDED) aff_aux<R, D, false>(a, s, t, y);
+        else aff_obs<R, D, P, false>(a, s, t, y);
         R r[P], o[D];
 #pragma unroll
         for (int k = 0; k < P; ++k) {
-            const bool fin = finite_(y[k]);
-            y[k] = fin ? y[k] : (R)0;
             R v = row[T::oYm + k];
 #pragma unroll
             for (int j = 0; j < D; ++j) v += row[T::oHF + k * D + j] * m[j];
-            r[k] = fin ? y[k] - v : (R)0;
+            if (k < PA) {
+                const bool fin = finite_(y[k < PA ? k : 0]);
+                y[k < PA ? k : 0] = fin ? y[k < PA ? k : 0] : (R)0;
+                r[k] = fin ? y[k < PA ? k : 0] - v : (R)0;
+            } else {
+                r[k] = -v;
+            }
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) {
@@ -224,7 +286,7 @@ template <typename R_, int D, int P> struct FilterMeanOp {
 #pragma unroll
             for (int j = 0; j < D; ++j) v += row[T::oM + k * D + j] * m[j];
 #pragma unroll
-            for (int l = 0; l < P; ++l) v += row[T::oK + k * P + l] * y[l];
+            for (int l = 0; l < PA; ++l) v += row[T::oK + k * P + l] * y[l];
             o[k] = v;
         }
         R q = 0;
