@@ -17,6 +17,7 @@ NAN_REFERENCE, NAN_MASKED = 0, 1
 KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND, KMODEL_LORENZ63_EXT = 1, 2, 3, 4
 LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
 OPT_SHARE_MODEL = 1
+OPT_OVERLAP_MODEL_STAGE = 2
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
  K_CSMC_BWD, K_PIT_STITCH, K_RNG, K_SELECT, K_FACTORY, K_FILTER_TAB, K_COUNT) = range(15)
 K_ALL = -1
@@ -169,7 +170,8 @@ class Handle:
         check(self.lib.auxssm_sync(self.h))
 
     def set_option(self, option, value):
-        """auxssm_set_option: e.g. (OPT_SHARE_MODEL, 0) forces the general per-chain path of the chain-minor sweep."""
+        """auxssm_set_option: e.g. (OPT_SHARE_MODEL, 0) forces the general per-chain path of the chain-minor sweep, (OPT_OVERLAP_MODEL_STAGE, 0)
+        keeps the chain-shared sweep's model stage on the one stream."""
         check(self.lib.auxssm_set_option(self.h, int(option), int(value)))
 
     # ---- memory ----

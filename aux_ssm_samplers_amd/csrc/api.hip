@@ -47,6 +47,69 @@ void* ws_take(auxssm_ctx* h, size_t bytes) {
     return h->ws + off;
 }
 
+// ---- model stage on the side stream (ctx.h: auxssm_ctx::SideStage) --------------------------------------------------------------------------
+int side_open(auxssm_ctx* h, size_t need) {
+    auxssm_ctx::SideStage& s = h->side;
+    if (s.inside) {
+        set_error("internal: side stage opened inside a side scope");
+        return AUXSSM_ERR_ARG;
+    }
+    if (!s.stream) {
+        // lowest priority: the stage has a whole sweep of slack, the chain passes it overlaps do not
+        int lo = 0, hi = 0;
+        AX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        static const bool prio_on = [] { const char* e = getenv("AUXSSM_SIDE_PRIO"); return e ? atoi(e) != 0 : true; }();
+        AX_HIP(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_on ? lo : 0));
+        for (int p = 0; p < 2; ++p) {
+            AX_HIP(hipEventCreateWithFlags(&s.done[p], hipEventDisableTiming));
+            AX_HIP(hipEventCreateWithFlags(&s.sweep_end[p], hipEventDisableTiming));
+        }
+        AX_HIP(hipEventCreateWithFlags(&s.fence, hipEventDisableTiming));
+    }
+    if (s.open) AX_HIP(hipStreamSynchronize(h->stream));  // a sweep that failed half way never marked its end: no reader may be left behind
+    s.open = false;
+    const int p = s.parity ^ 1;
+    if (need > s.bytes[p]) {  // (first sweeps of a shape only) nobody may still use the old slab
+        AX_HIP(hipStreamSynchronize(h->stream));
+        AX_HIP(hipStreamSynchronize(s.stream));
+        if (s.ws[p]) AX_HIP(hipFree(s.ws[p]));
+        s.ws[p] = nullptr;
+        s.bytes[p] = 0;
+        const size_t want = need + need / 8 + (1u << 20);
+        hipError_t e = hipMalloc((void**)&s.ws[p], want);
+        if (e != hipSuccess) {
+            set_error("side workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            return AUXSSM_ERR_NOMEM;
+        }
+        s.bytes[p] = want;
+        s.end_valid[p] = false;
+    }
+    if (s.end_valid[p]) AX_HIP(hipStreamWaitEvent(s.stream, s.sweep_end[p], 0));
+    if (h->api_calls != s.last_call + 1) {  // something other than a staged sweep went through the handle since: its work comes first
+        AX_HIP(hipEventRecord(s.fence, h->stream));
+        AX_HIP(hipStreamWaitEvent(s.stream, s.fence, 0));
+    }
+    s.last_call = h->api_calls;
+    s.parity = p;
+    s.off = 0;
+    s.open = true;
+    return AUXSSM_OK;
+}
+int side_close(auxssm_ctx* h) {
+    auxssm_ctx::SideStage& s = h->side;
+    if (!s.open || s.inside) return AUXSSM_OK;
+    AX_HIP(hipEventRecord(s.done[s.parity], s.stream));
+    AX_HIP(hipStreamWaitEvent(h->stream, s.done[s.parity], 0));
+    return AUXSSM_OK;
+}
+void side_sweep_end(auxssm_ctx* h) {
+    auxssm_ctx::SideStage& s = h->side;
+    if (!s.open) return;
+    (void)hipEventRecord(s.sweep_end[s.parity], h->stream);
+    s.end_valid[s.parity] = true;
+    s.open = false;
+}
+
 // `waves` (chain tile, chunk) lanes per SIMD: a chain's state is a handful of registers and the passes stream their inputs, so more, shorter chunks
 // hide more latency until the aggregate pass grows.  Measured at C2 x 256 chains, three runs each, after the noise-drawing reduce pass went from 89 to
 // 60 registers: filter scan 0.909 / 0.872 / 0.816 ms at E = 64 / 32 / 24, sampler scan 0.762 / 0.727 / 0.742 -- hence 11 and 8 (kernels.hip.h::AffWaves)
@@ -480,11 +543,33 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     Acc* sums = (Acc*)ws_take(h, (size_t)5 * C * sizeof(Acc));
     if (!ysc || !Hc || !Rc || !cc || !u || !ms || !Ps || !xp || !ell || !sums) return AUXSSM_ERR_NOMEM;
     const size_t mark = h->ws_off;
+    // chain-shared parameters: the filtered covariances do not depend on the chain and are stored once, (T, D, D) dense with chain stride 0
+    const bool shared_mode = !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0);
+    const bool aux_fly = cm && T > 1 && !wide && aux_fly_enabled();  // u and the concatenated observations of t >= 1 are formed inside the filter
+    // Chain-shared sweep with a host step size: the MODEL STAGE (concatenated observation model here, matrix filter + gain table in
+    // run_filter_shared) reads neither a chain nor anything the previous sweep wrote, so it goes to the side stream with its own double-buffered
+    // slab (ctx.h::SideStage) and overlaps the chain passes of the sweep before; its products -- Hc, Rc, cc, the shared covariances, the gain
+    // rows -- live in that slab.  AUXSSM_OPT_OVERLAP_MODEL_STAGE = 0 (environment AUXSSM_OVERLAP_TAB=0): everything on the one stream, as before.
+    const bool overlap = h->overlap_model_stage != 0 && shared_mode && aux_fly && parallel && !dptr;
+    struct SweepEnd {  // whatever way the sweep returns: everything it enqueued on `stream` precedes the mark the next stage of this parity waits for
+        auxssm_ctx* h;
+        ~SweepEnd() { side_sweep_end(h); }
+    } sweep_end{h};
+    if (overlap) {
+        const size_t gain = (size_t)D * D + D + 2 * (size_t)D * P + P + (size_t)P * (P + 1) / 2 + 4, felem = 3 * (size_t)D * D + 2 * D + 8;
+        const size_t need_side = (size_t)(T + 64) * sR * ((size_t)P * D + (size_t)P * P + P + (size_t)D * D + P + D + gain + 2 * felem +
+                                                          8 * (size_t)D * D + 8 * D + 2 * (size_t)PO * PO + 4 * PO + 32) + (4u << 20);  // + sampler / log-density tables, chunk products
+        if ((rc = side_open(h, need_side))) return rc;
+        SideScope sc(h);
+        Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
+        Rc = (R*)ws_take(h, (size_t)T * P * P * sR);
+        cc = (R*)ws_take(h, (size_t)T * P * sR);
+        Ps = (R*)ws_take(h, (size_t)T * D * D * sR);
+        if (!Hc || !Rc || !cc || !Ps) return AUXSSM_ERR_NOMEM;
+    }
     const Arr yscA = cm ? cm_arr(ysc, kd, P) : dense_arr(ysc, kd, P);
     const Arr uA = cm ? cm_arr(u, kd, D) : dense_arr(u, kd, D);
     const Arr msA = cm ? cm_arr(ms, kd, D) : dense_arr(ms, kd, D);
-    // chain-shared parameters: the filtered covariances do not depend on the chain and are stored once, (T, D, D) dense with chain stride 0
-    const bool shared_mode = !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0);
     // general chain-minor sweep: the filtered covariances are an internal buffer the sampler reads twice -- kept symmetric-packed (10 instead of 16
     // reals at d = 4)
     static const bool ps_pack_on = [] { const char* e = getenv("AUXSSM_PS_PACK"); return e ? atoi(e) != 0 : true; }();
@@ -502,7 +587,6 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     // the filter builds u and the concatenated observation on the fly for t >= 1 (FilterArgs::aux_*): only row t = 0 is materialised.
     // In the chain-minor layout the filter builds u and the concatenated observation on the fly for t >= 1 (FilterArgs::aux_*), in
     // both of its modes (chain-shared parameters: gain-form recursion; otherwise: elements built inside the scan passes).
-    const bool aux_fly = cm && T > 1 && !wide && aux_fly_enabled();
     // Keyed sweep (auxssm_kalman_sweep_keyed): the noise is a function of the keys.  Where the chain-shared affine scans run, their reduce
     // passes -- the first readers of eps_aux (t >= 1) and eps_samp -- GENERATE it and store it for the later readers (the fill kernel then
     // only draws row t = 0 and the acceptance uniforms); everywhere else the fill kernel draws all of it first.  Same values either way.
@@ -515,8 +599,11 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
-        hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
-                           cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), dptr, Hc, Rc, cc);
+        {
+            SideScope sc(h);  // (model stage)
+            hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
+                               cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), dptr, Hc, Rc, cc);
+        }
         const int Tc = aux_fly ? 1 : T;
         const long long n2 = (long long)C * Tc * P;
         hipLaunchKernelGGL((k_concat_obs<R>), dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, h->stream, C, Tc, D, PO,
@@ -1124,6 +1211,7 @@ int auxssm_create(int device, auxssm_handle* out) {
     h->num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     AX_HIP(hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking));
     if (const char* e = getenv("AUXSSM_SHARED")) h->share_model = atoi(e) != 0;  // default of AUXSSM_OPT_SHARE_MODEL
+    if (const char* e = getenv("AUXSSM_OVERLAP_TAB")) h->overlap_model_stage = atoi(e) != 0;  // default of AUXSSM_OPT_OVERLAP_MODEL_STAGE
     *out = h;
     return AUXSSM_OK;
 }
@@ -1135,6 +1223,16 @@ int auxssm_destroy(auxssm_handle h) {
     auxssm_prof_disable(h);
     if (h->ws) (void)hipFree(h->ws);
     if (h->dblock) (void)hipFree(h->dblock);
+    if (h->side.stream) {
+        (void)hipStreamSynchronize(h->side.stream);
+        for (int p = 0; p < 2; ++p) {
+            if (h->side.ws[p]) (void)hipFree(h->side.ws[p]);
+            (void)hipEventDestroy(h->side.done[p]);
+            (void)hipEventDestroy(h->side.sweep_end[p]);
+        }
+        (void)hipEventDestroy(h->side.fence);
+        (void)hipStreamDestroy(h->side.stream);
+    }
     (void)hipStreamDestroy(h->stream);
     delete h;
     return AUXSSM_OK;
@@ -1147,10 +1245,17 @@ int auxssm_destroy(auxssm_handle h) {
             return AUXSSM_ERR_ARG;           \
         }                                    \
         AX_HIP(hipSetDevice((h)->device));   \
+        ++(h)->api_calls;                    \
+    } while (0)
+// entry points that neither enqueue work nor change device data (ctx.h: SideStage::last_call)
+#define AX_NEED_H_RO(h)                      \
+    do {                                     \
+        AX_NEED_H(h);                        \
+        --(h)->api_calls;                    \
     } while (0)
 
 int auxssm_sync(auxssm_handle h) {
-    AX_NEED_H(h);
+    AX_NEED_H_RO(h);
     AX_HIP(hipStreamSynchronize(h->stream));
     return AUXSSM_OK;
 }
@@ -1185,7 +1290,7 @@ int auxssm_memcpy_h2d(auxssm_handle h, void* dst, const void* src, size_t bytes)
     return AUXSSM_OK;
 }
 int auxssm_memcpy_d2h(auxssm_handle h, void* dst, const void* src, size_t bytes) {
-    AX_NEED_H(h);
+    AX_NEED_H_RO(h);
     AX_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, h->stream));
     AX_HIP(hipStreamSynchronize(h->stream));
     return AUXSSM_OK;
@@ -1205,6 +1310,10 @@ int auxssm_set_option(auxssm_handle h, int option, int value) {
     AX_NEED_H(h);
     if (option == AUXSSM_OPT_SHARE_MODEL) {
         h->share_model = value != 0;
+        return AUXSSM_OK;
+    }
+    if (option == AUXSSM_OPT_OVERLAP_MODEL_STAGE) {
+        h->overlap_model_stage = value != 0;
         return AUXSSM_OK;
     }
     set_error("unknown option %d", option);
@@ -1245,7 +1354,7 @@ int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches) {
     return AUXSSM_OK;
 }
 int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms) {
-    AX_NEED_H(h);
+    AX_NEED_H_RO(h);
     AX_HIP(hipStreamSynchronize(h->stream));
     Prof& p = h->prof;
     double tot = 0;
@@ -1261,7 +1370,7 @@ int auxssm_prof_read(auxssm_handle h, int* launches, double* total_ms) {
 }
 
 int auxssm_prof_read_groups(auxssm_handle h, int n_ids, int* launches, double* total_ms) {
-    AX_NEED_H(h);
+    AX_NEED_H_RO(h);
     if (n_ids < 1 || !launches || !total_ms) {
         set_error("n_ids must be >= 1 and launches / total_ms non-NULL");
         return AUXSSM_ERR_ARG;

@@ -681,6 +681,7 @@ extern "C" int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t row
         return AUXSSM_ERR_ARG;
     }
     AX_HIP(hipSetDevice(h->device));
+    ++h->api_calls;
     if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
         set_error("dtype must be 0 (f32) or 1 (f64)");
         return AUXSSM_ERR_ARG;
@@ -715,6 +716,7 @@ extern "C" int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t ro
         return AUXSSM_ERR_ARG;
     }
     AX_HIP(hipSetDevice(h->device));
+    ++h->api_calls;
     if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
         set_error("dtype must be 0 (f32) or 1 (f64)");
         return AUXSSM_ERR_ARG;
@@ -746,6 +748,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         return AUXSSM_ERR_ARG;
     }
     AX_HIP(hipSetDevice(h->device));
+    ++h->api_calls;
     if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
         set_error("dtype must be 0 (f32) or 1 (f64)");
         return AUXSSM_ERR_ARG;

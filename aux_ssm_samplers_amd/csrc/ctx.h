@@ -50,7 +50,32 @@ struct auxssm_ctx {
     const void* st_x = nullptr;
     long long st_n = 0;
     int st_dtype = -1;
+    unsigned long long api_calls = 0;  // entry points that may enqueue work or change device data (not: sync, device-to-host copies, profiler reads)
+    int overlap_model_stage = 1;       // AUXSSM_OPT_OVERLAP_MODEL_STAGE
     double* dblock = nullptr;  // {delta, sqrt(delta / 2)} of a sweep whose step size is device-resident (auxssm_kalman_sweep_dd); lazily allocated
+    // The MODEL STAGE of a chain-shared sweep -- concatenated observation model, matrix filter on one sequence, gain table: ~0.4 ms of short dependent
+    // launches that read the model and the step size only, never a chain -- runs on a second stream with its own double-buffered slab, so that the
+    // stage of sweep k + 1 overlaps the chain passes of sweep k (api.hip: side_*).  Joined into `stream` before its first consumer.
+    struct SideStage {
+        hipStream_t stream = nullptr;
+        hipEvent_t done[2] = {nullptr, nullptr};       // stage of this parity finished (recorded on the side stream)
+        hipEvent_t sweep_end[2] = {nullptr, nullptr};  // last sweep that read this parity's slab finished enqueueing (recorded on `stream`)
+        bool end_valid[2] = {false, false};
+        char* ws[2] = {nullptr, nullptr};
+        size_t bytes[2] = {0, 0};
+        int parity = 0;
+        bool open = false, inside = false;
+        // A stage runs ahead of whatever `stream` still holds.  That is safe behind another sweep (a sweep writes none of a stage's inputs), not
+        // behind anything else the caller may have enqueued through the handle (an upload of new parameters, a memset, another kind of call): every
+        // entry point counts itself in auxssm_ctx::api_calls, and a stage that is not opened by the call right after the last staged sweep first
+        // waits for the tail of `stream` (one sweep without overlap).
+        unsigned long long last_call = 0;
+        hipEvent_t fence = nullptr;
+        size_t off = 0;                                // bump offset inside the open slab
+        hipStream_t m_stream = nullptr;                // the main context while `inside`
+        char* m_ws = nullptr;
+        size_t m_bytes = 0, m_off = 0;
+    } side;
 };
 
 namespace ax {
@@ -58,6 +83,31 @@ namespace ax {
 // Reserve the slab for one API call (sum of the call's needs), then carve from it.
 int ws_reserve(auxssm_ctx* h, size_t bytes);
 void* ws_take(auxssm_ctx* h, size_t bytes);
+
+// model stage on the side stream (see auxssm_ctx::SideStage).  side_open: next parity, slab of at least `need` bytes, the side stream waits for the
+// last sweep that read it; SideScope: launches and ws_take inside the scope go to the side stream / slab (no-op unless a stage is open);
+// side_close: `stream` waits for the stage; side_sweep_end: marks the end of the sweep that consumed it.
+int side_open(auxssm_ctx* h, size_t need);
+int side_close(auxssm_ctx* h);
+void side_sweep_end(auxssm_ctx* h);
+struct SideScope {
+    auxssm_ctx* h;
+    bool on;
+    explicit SideScope(auxssm_ctx* h_) : h(h_), on(h_->side.open && !h_->side.inside) {
+        if (!on) return;
+        auxssm_ctx::SideStage& s = h->side;
+        s.m_stream = h->stream; s.m_ws = h->ws; s.m_bytes = h->ws_bytes; s.m_off = h->ws_off;
+        h->stream = s.stream; h->ws = s.ws[s.parity]; h->ws_bytes = s.bytes[s.parity]; h->ws_off = s.off;
+        s.inside = true;
+    }
+    ~SideScope() {
+        if (!on) return;
+        auxssm_ctx::SideStage& s = h->side;
+        s.off = h->ws_off;
+        h->stream = s.m_stream; h->ws = s.m_ws; h->ws_bytes = s.m_bytes; h->ws_off = s.m_off;
+        s.inside = false;
+    }
+};
 
 struct ProfScope {
     auxssm_ctx* h;

@@ -121,6 +121,7 @@ struct FilterArgs {
     int aux_on = 0;
     Arr aux_x{}, aux_eps{}, aux_u{}, aux_yobs{};
     double aux_shd = 0;
+    int t0_keep_ps = 0;  // k_filter_t0: leave Ps[0] alone (chain-shared covariances: the matrix filter wrote the one slot all chains would write)
     const double* dptr = nullptr;  // device-resident step size: {delta, sqrt(delta / 2)} (auxssm_kalman_sweep_dd); null: the host values above
     // aux_gen != 0 (auxssm_kalman_sweep_keyed): rows t >= 1 of aux_eps are GENERATED by the reduce pass (the first reader) from the key and
     // written for the later readers (down pass, log-density); the values are those of auxssm_rng_normal(key, stream 0) at the same indices
@@ -172,7 +173,7 @@ template <typename R, int D, int P> AX_HD void body_filter_t0(const FilterArgs& 
     rd_upper<R, P>(a.Rs, c, 0, b, Rm);
     const R ell = kalman_update<R, D, P>(m, Pd, H, cv, Rm, y);
     wr<R, D>(a.ms, c, 0, b, m);
-    wr_cov<R, D>(a.Ps, c, 0, b, a.ps_packed, Pd);
+    if (!a.t0_keep_ps) wr_cov<R, D>(a.Ps, c, 0, b, a.ps_packed, Pd);
     ((R*)a.ell0)[s] = ell;
 }
 

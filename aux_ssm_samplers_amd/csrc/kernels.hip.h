@@ -768,11 +768,20 @@ template <class Op, int D> int run_affine(auxssm_ctx* h, const typename Op::Args
     if (part_out) *part_out = part;
     if (nchunk_out) *nchunk_out = pl.nchunk;
     if (pl.nchunk > 1) {
-        R* cprod = (R*)ws_take(h, (size_t)pl.nchunk * D * D * sizeof(R));
+        R* cprod;
+        {
+            SideScope side(h);  // the chunk products of the chain-shared matrices belong to the model stage (ctx.h::SideStage) when one is open
+            cprod = (R*)ws_take(h, (size_t)pl.nchunk * D * D * sizeof(R));
+            if (!cprod) return AUXSSM_ERR_NOMEM;
+            hipLaunchKernelGGL((k_aff_chunkprod<Op, D>), dim3((pl.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod, N, pl);
+        }
+        {
+            const int rc = side_close(h);
+            if (rc) return rc;
+        }
         sb.agg = ws_take(h, (size_t)S * pl.nchunk * SampElem<R, D>::NPAD * sizeof(R));
         sb.pre = ws_take(h, (size_t)S * pl.nchunk * SampPre<R, D>::NPAD * sizeof(R));
-        if (!cprod || !sb.agg || !sb.pre || (part_out && !part)) return AUXSSM_ERR_NOMEM;
-        hipLaunchKernelGGL((k_aff_chunkprod<Op, D>), dim3((pl.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod, N, pl);
+        if (!sb.agg || !sb.pre || (part_out && !part)) return AUXSSM_ERR_NOMEM;
         hipLaunchKernelGGL((k_aff_reduce<Op, D>), dim3(grid_aff(S, pl.nchunk)), dim3(TB_CM), 0, h->stream, a, sb, (const R*)cprod, S, N, pl);
         const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
         hipLaunchKernelGGL((k_scan_aggs<SampleOp<R, D>>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, pl.nchunk);
@@ -852,13 +861,19 @@ template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterA
     // the covariances are chain-independent: the caller lays them out once, (T, D, D) dense with chain stride 0 (ctx.h::chain_shared_mode),
     // and the matrix filter writes them in place; any other layout gets chain 0's slot filled from a scratch copy
     const bool ps_once = a.Ps.sc == 0 && a.Ps.se == 1 && a.Ps.st == (long long)D * D;
-    R* ms1 = (R*)ws_take(h, (size_t)T * D * sizeof(R));
-    R* Ps1 = ps_once ? const_cast<R*>((const R*)a.Ps.ptr) : (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
-    R* sc1 = (R*)ws_take(h, 4 * sizeof(R));
-    if (!ms1 || !Ps1 || !sc1) return AUXSSM_ERR_NOMEM;
     {
         // the matrix filter: the parallel filter on ONE sequence, always the parallel plan (its means are not used: the observation
-        // values are the mask carrier's).  Dense (time-minor) layout.
+        // values are the mask carrier's).  Dense (time-minor) layout.  Inside a sweep that opened a side stage (ctx.h::SideStage) all of this block --
+        // launches, scratch and the gain table -- goes to the side stream and its slab; the caller then put Ps there too.
+        SideScope side(h);
+        if (side.on && !ps_once) {
+            set_error("internal: the side stage needs the shared covariance layout");
+            return AUXSSM_ERR_ARG;
+        }
+        R* ms1 = (R*)ws_take(h, (size_t)T * D * sizeof(R));
+        R* Ps1 = ps_once ? const_cast<R*>((const R*)a.Ps.ptr) : (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+        R* sc1 = (R*)ws_take(h, 4 * sizeof(R));
+        if (!ms1 || !Ps1 || !sc1) return AUXSSM_ERR_NOMEM;
         ProfScope ps(h, AUXSSM_K_FILTER_TAB);
         FilterArgs am = a;
         am.d = KDims{1, T, 1};
@@ -891,7 +906,13 @@ template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterA
         if (!ps_once)  // chain 0's slot of the caller's buffer (the sampler's table reads that one)
             hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
     }
-    // t = 0 update of every chain (after the join: it reads the concatenated model and shares Ps[0]'s slot with the copy above)
+    {
+        const int rc = side_close(h);  // (no-op without a side stage) `stream` waits for the model stage before the first kernel that reads its products
+        if (rc) return rc;
+    }
+    // t = 0 update of every chain (after the join: it reads the concatenated model).  The one shared Ps[0] slot is the matrix filter's: the chains do
+    // not rewrite it (same value; and the sampler's table may be reading it on the side stream by now)
+    a.t0_keep_ps = ps_once ? 1 : 0;
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     R* part = nullptr;
     int nchunk = 1;
@@ -989,8 +1010,10 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
     if (cm && shared_on && a.ps_shared && a.d.B == 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0) {
         // chain-shared covariances: gains and Cholesky factors once per time step, a chain's element is two small mat-vecs
         a.elem = nullptr;
-        a.tab = ws_take(h, (size_t)T * SampShared<R, D>::NPAD * sizeof(R));
         {
+            SideScope side(h);  // (model stage, when the sweep opened one: the table reads the shared covariances and the model only)
+            a.tab = ws_take(h, (size_t)T * SampShared<R, D>::NPAD * sizeof(R));
+            if (!a.tab) return AUXSSM_ERR_NOMEM;
             ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
             hipLaunchKernelGGL((k_sample_shared_tab<R, D>), dim3((T + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
         }
@@ -1061,8 +1084,16 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
                         a.cs.sc == 0 && a.ys.sc == 0;
     if (shared) {  // chain-shared parameters: factor Q_{t-1} and Robs_t once per time step
         SweepLogpdfArgs as = a;
-        as.tab = ws_take(h, (size_t)n * LogShared<R, D, PO>::NPAD * sizeof(R));
-        hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, as);
+        {
+            SideScope side(h);  // (model stage)
+            as.tab = ws_take(h, (size_t)n * LogShared<R, D, PO>::NPAD * sizeof(R));
+            if (!as.tab) return AUXSSM_ERR_NOMEM;
+            hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, as);
+        }
+        {
+            const int rc = side_close(h);
+            if (rc) return rc;
+        }
         hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, as, part, nt, TI_CM);
     } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
     else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);

@@ -93,6 +93,7 @@ __global__ void __launch_bounds__(256) k_lorenz_theta(int C, int T, int cfast, c
             return AUXSSM_ERR_ARG;           \
         }                                    \
         AX_HIP(hipSetDevice((h)->device));   \
+        ++(h)->api_calls;                    \
     } while (0)
 
 static int need_dtype(int dtype) {

@@ -337,6 +337,7 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
         return AUXSSM_ERR_ARG;
     }
     AX_HIP(hipSetDevice(h->device));
+    ++h->api_calls;
     if (dtype != AUXSSM_F32 && dtype != AUXSSM_F64) {
         set_error("dtype must be 0 (f32) or 1 (f64)");
         return AUXSSM_ERR_ARG;

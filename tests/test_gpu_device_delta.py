@@ -90,3 +90,60 @@ def test_keyed_sweep_equals_draw_then_sweep(dtype, C, chain_minor, share):
             npt.assert_array_equal(a.logs.to_host(), b.logs.to_host(), err_msg=name)
     finally:
         h.set_option(_lib.OPT_SHARE_MODEL, 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_model_stage_on_the_side_stream_equals_the_single_stream_sweep(dtype):
+    """AUXSSM_OPT_OVERLAP_MODEL_STAGE: the chain-independent model stage of a chain-shared keyed sweep (concatenated observation model, matrix filter,
+    gain / sampler / log-density tables) runs on a second stream with a double-buffered slab and overlaps the previous sweep.  Sequences of sweeps --
+    step size changing from sweep to sweep, two resident states taking turns on the handle, the data (yobs) replaced on the device between two
+    sweeps by an asynchronous device-to-device copy (the fence behind a foreign call), a general-path sweep in between -- must give bit for bit the
+    single-stream results."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import LGConcatModel
+    h = _lib.default_handle()
+    T, d, C = 1500, 2, 64
+    m = lg_model(T, d, dtype=dtype)
+    full = lambda a, n: np.ascontiguousarray(np.broadcast_to(a, (n,) + a.shape))
+    rng = np.random.default_rng(3)
+    y2 = (m["y"] + 0.5 * rng.standard_normal(m["y"].shape)).astype(m["y"].dtype)
+    x0 = rng.standard_normal((2, C, T, d)).astype(dtype) * 0.3
+    deltas = [0.4, 0.4, 0.25, 0.25, 0.6, 0.4, 0.4, 0.4]
+
+    def run(overlap):
+        h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, overlap)
+        model = LGConcatModel(m["m0"], m["P0"], full(m["F"], T - 1), full(m["Q"], T - 1), full(m["b"], T - 1), full(m["Hobs"], T), full(m["Robs"], T),
+                              full(m["cobs"], T), m["y"])
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        chains = [DeviceChains(h, x0[0], chain_minor=True), DeviceChains(h, x0[1], chain_minor=True)]
+        _, ybuf, _ = model.device(h, dtype)
+        ynew = _lib.DeviceArray(h, ybuf.shape, ybuf.dtype)
+        ynew.copy_from_host(np.ascontiguousarray(y2, dtype=dtype).reshape(ybuf.shape))
+        out, junk = [], None
+        for i, dl in enumerate(deltas):
+            key = R.PRNGKey(1000 + i)
+            st = chains[i % 2]
+            if i == 4:  # new data, enqueued asynchronously on the handle's stream BEHIND a few milliseconds of other work: the next model stage must
+                # still come after it (without the fence of ctx.h::SideStage it would read the old data while the fill below is running)
+                junk = h.rng_normal(R.PRNGKey(5), 9, (1 << 28,), np.float32)  # (kept alive: freeing it would synchronise the device)
+                ybuf.copy_from(ynew)
+            if i == 6:  # a general-path sweep in between (no model stage)
+                h.set_option(_lib.OPT_SHARE_MODEL, 0)
+            kernel(key, KalmanSampler(x=st, updated=None), dl)
+            if i == 6:
+                h.set_option(_lib.OPT_SHARE_MODEL, 1)
+            if i in (1, 5, 7):
+                out.append((st.to_host(), st.accepted.to_host(), st.logs.to_host()))
+        out.append((chains[0].to_host(), chains[1].to_host()))
+        return out
+
+    try:
+        a = run(1)
+        b = run(0)
+    finally:
+        h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, 1)
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    for u, v in zip(a, b):
+        for p, q in zip(u, v):
+            npt.assert_array_equal(p, q)
+    assert not np.array_equal(a[-1][0], x0[0])
