@@ -28,7 +28,7 @@ GENERAL = {
     "logpdf": [r"^k_sweep_logpdf_cm<"],
     "filter_tab": [r"^k_obs_info_tab<"],
 }
-BOTH = {"rng": [r"^k_rng_sweep<"], "select": [r"^k_select<", r"^k_accept<"], "factory": [r"^k_concat_model<", r"^k_concat_obs<"]}
+BOTH = {"rng": [r"^k_rng_sweep<"], "select": [r"^k_select(_rows)?<", r"^k_accept<"], "factory": [r"^k_concat_model<", r"^k_concat_obs<"]}
 CSMC = {"csmc_fwd": [r"^k_csmc_fwd<"], "csmc_bwd": [r"^k_csmc_bwd<"], "csmc_ctrans": [r"^k_csmc_ctrans<"]}
 
 
