@@ -219,6 +219,7 @@ int auxssm_stats_update(auxssm_handle h, int dtype, int64_t n, int64_t iter, con
 int auxssm_accept_update(auxssm_handle h, int dtype, int32_t C, int32_t m, int64_t iter, double beta, const int32_t* flags, void* avg,
                          void* window) {
     AX_NEED_H(h);
+    --h->api_calls;  // (reads the sweep's flags, writes its own averages: a chain-shared sweep's model stage may still run ahead of it, ctx.h::SideStage)
     if (int rc = need_dtype(dtype)) return rc;
     if (C < 0 || m < 0 || iter < 0) {
         set_error("C, m and iter must be >= 0");
