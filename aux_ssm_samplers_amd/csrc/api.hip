@@ -57,14 +57,20 @@ int side_open(auxssm_ctx* h, size_t need) {
     if (!s.stream) {
         // lowest priority: the stage has a whole sweep of slack, the chain passes it overlaps do not
         int lo = 0, hi = 0;
-        AX_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
         static const bool prio_on = [] { const char* e = getenv("AUXSSM_SIDE_PRIO"); return e ? atoi(e) != 0 : true; }();
-        AX_HIP(hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, prio_on ? lo : 0));
-        for (int p = 0; p < 2; ++p) {
-            AX_HIP(hipEventCreateWithFlags(&s.done[p], hipEventDisableTiming));
-            AX_HIP(hipEventCreateWithFlags(&s.sweep_end[p], hipEventDisableTiming));
+        bool ok = true;
+        if (!prio_on || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) != hipSuccess)
+            ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
+        for (int p = 0; ok && p < 2; ++p)
+            ok = hipEventCreateWithFlags(&s.done[p], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.sweep_end[p], hipEventDisableTiming) == hipSuccess;
+        ok = ok && hipEventCreateWithFlags(&s.fence, hipEventDisableTiming) == hipSuccess;
+        if (!ok) {  // no second stream on this device / runtime: the sweeps stay on the one stream (s.open stays false)
+            (void)hipGetLastError();
+            if (s.stream) (void)hipStreamDestroy(s.stream);
+            s.stream = nullptr;
+            h->overlap_model_stage = 0;
+            return AUXSSM_OK;
         }
-        AX_HIP(hipEventCreateWithFlags(&s.fence, hipEventDisableTiming));
     }
     if (s.open) AX_HIP(hipStreamSynchronize(h->stream));  // a sweep that failed half way never marked its end: no reader may be left behind
     s.open = false;
@@ -77,9 +83,10 @@ int side_open(auxssm_ctx* h, size_t need) {
         s.bytes[p] = 0;
         const size_t want = need + need / 8 + (1u << 20);
         hipError_t e = hipMalloc((void**)&s.ws[p], want);
-        if (e != hipSuccess) {
-            set_error("side workspace hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-            return AUXSSM_ERR_NOMEM;
+        if (e != hipSuccess) {  // no room for the second slab: this sweep stays on the one stream
+            (void)hipGetLastError();
+            s.ws[p] = nullptr;
+            return AUXSSM_OK;
         }
         s.bytes[p] = want;
         s.end_valid[p] = false;
@@ -550,7 +557,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     // run_filter_shared) reads neither a chain nor anything the previous sweep wrote, so it goes to the side stream with its own double-buffered
     // slab (ctx.h::SideStage) and overlaps the chain passes of the sweep before; its products -- Hc, Rc, cc, the shared covariances, the gain
     // rows -- live in that slab.  AUXSSM_OPT_OVERLAP_MODEL_STAGE = 0 (environment AUXSSM_OVERLAP_TAB=0): everything on the one stream, as before.
-    const bool overlap = h->overlap_model_stage != 0 && shared_mode && aux_fly && parallel && !dptr;
+    bool overlap = h->overlap_model_stage != 0 && shared_mode && aux_fly && parallel && !dptr;
     struct SweepEnd {  // whatever way the sweep returns: everything it enqueued on `stream` precedes the mark the next stage of this parity waits for
         auxssm_ctx* h;
         ~SweepEnd() { side_sweep_end(h); }
@@ -560,6 +567,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         const size_t need_side = (size_t)(T + 64) * sR * ((size_t)P * D + (size_t)P * P + P + (size_t)D * D + P + D + gain + 2 * felem +
                                                           8 * (size_t)D * D + 8 * D + 2 * (size_t)PO * PO + 4 * PO + 32) + (4u << 20);  // + sampler / log-density tables, chunk products
         if ((rc = side_open(h, need_side))) return rc;
+        overlap = h->side.open;  // (false when the device gave no second stream)
+    }
+    if (overlap) {
         SideScope sc(h);
         Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
         Rc = (R*)ws_take(h, (size_t)T * P * P * sR);
