@@ -777,8 +777,12 @@ template <typename R, int D> AX_HD void sweep_u(const SweepLogpdfArgs& a, int c,
         rd<R, D>(a.u, c, t, 0, u);
     }
 }
+// table row of the chain-shared log-density pass, WHITENED: with W = chol(.)^-1 (lower triangular; a deleted component's row and column are zero)
+//   transition t-1 -> t:  z = WQ x_t - WF x_{t-1} - wb,   WF = WQ F, wb = WQ b          log N(x_t; F x_{t-1} + b, Q)     = -|z|^2 / 2 + cQ
+//   observation at t:     z = yw - WH x_t,                WH = WR H, yw = WR (y - c)     log N(y_t; H x_t + c, R) (kept) = -|z|^2 / 2 + cR
+// built once per time step by the model stage; a chain's step reads 52 scalars at d = po = 4 instead of the 74 of (F, b, H, c, y, two factors).
 template <typename R, int D, int PO> struct LogShared {
-    static constexpr int oQ = 0, oR = CholRow<R, D>::SZ, N = CholRow<R, D>::SZ + CholRow<R, PO>::SZ;
+    static constexpr int oWQ = 0, oWF = symsize(D), oWb = oWF + D * D, oCQ = oWb + D, oWH = oCQ + 1, oYw = oWH + PO * D, oCR = oYw + PO, N = oCR + 1;
     static constexpr int VEC = 16 / sizeof(R);
     static constexpr int NPAD = (N + VEC - 1) / VEC * VEC;
 };
@@ -1090,18 +1094,69 @@ template <typename R, int D> AX_HD void body_sv_logpdf_head(const SvLogpdfArgs& 
 }
 
 // ---- the same pass with chain-shared parameters: Cholesky factors and log-determinants of Q_{t-1}, Robs_t once per time step ---
+template <typename R, int N> AX_HD void chol_inverse_lower(const R* L, const R* invd, const bool* skip, R* W) {  // W = L^-1, lower-packed (lidx)
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        R e[N];
+#pragma unroll
+        for (int l = 0; l < N; ++l) e[l] = (l == k) ? (R)1 : (R)0;
+        lsolve<R, N>(L, invd, e);
+#pragma unroll
+        for (int l = k; l < N; ++l) W[lidx(l, k)] = (skip && (skip[k] || skip[l])) ? (R)0 : e[l];
+    }
+}
 template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_tab(const SweepLogpdfArgs& a, int i) {
     using T = LogShared<R, D, PO>;
+    using CQ = CholRow<R, D>;
+    using CR = CholRow<R, PO>;
     const long long t = (long long)i + 1;
-    R Q[D * D], Rm[PO * PO], y[PO], row[T::N];
+    R Q[D * D], Rm[PO * PO], y[PO], H[PO * D], cv[PO], F[D * D], bd[D], row[T::N], cq[CQ::SZ], cr[CR::SZ];
     rd<R, D * D>(a.Qs, 0, i, 0, Q);
     rd_upper<R, PO>(a.Rs, 0, t, 0, Rm);
     rd<R, PO>(a.ys, 0, t, 0, y);
+    rd<R, PO * D>(a.Hs, 0, t, 0, H);
+    rd<R, PO>(a.cs, 0, t, 0, cv);
+    rd<R, D * D>(a.Fs, 0, i, 0, F);
+    rd<R, D>(a.bs, 0, i, 0, bd);
     bool skip[PO];
 #pragma unroll
     for (int k = 0; k < PO; ++k) skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
-    chol_row<R, D>(Q, nullptr, row + T::oQ);
-    chol_row<R, PO>(Rm, a.nan_policy == 1 ? skip : nullptr, row + T::oR);
+    chol_row<R, D>(Q, nullptr, cq);
+    chol_row<R, PO>(Rm, a.nan_policy == 1 ? skip : nullptr, cr);
+    R* WQ = row + T::oWQ;
+    chol_inverse_lower<R, D>(cq + CQ::oL, cq + CQ::oI, nullptr, WQ);
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        R wb = 0;
+#pragma unroll
+        for (int l = 0; l <= r; ++l) wb += WQ[lidx(r, l)] * bd[l];
+        row[T::oWb + r] = wb;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R v = 0;
+#pragma unroll
+            for (int l = 0; l <= r; ++l) v += WQ[lidx(r, l)] * F[l * D + j];
+            row[T::oWF + r * D + j] = v;
+        }
+    }
+    row[T::oCQ] = cq[CQ::oC];
+    R WR[symsize(PO)];
+    chol_inverse_lower<R, PO>(cr + CR::oL, cr + CR::oI, a.nan_policy == 1 ? skip : nullptr, WR);
+#pragma unroll
+    for (int r = 0; r < PO; ++r) {
+        R yw = 0;
+#pragma unroll
+        for (int l = 0; l <= r; ++l) yw += skip[l] ? (R)0 : WR[lidx(r, l)] * (y[l] - cv[l]);  // (a NaN observation the policy keeps makes the row NaN: dropped below)
+        row[T::oYw + r] = yw;
+#pragma unroll
+        for (int j = 0; j < D; ++j) {
+            R v = 0;
+#pragma unroll
+            for (int l = 0; l <= r; ++l) v += WR[lidx(r, l)] * H[l * D + j];
+            row[T::oWH + r * D + j] = v;
+        }
+    }
+    row[T::oCR] = cr[CR::oC];
     stv<R, T::N>((R*)a.tab + (long long)i * T::NPAD, row);
 }
 // x, xp, u: the chain's values at time t = i + 1 (u: eps_t when a.u_fly); xq, xpq: at time t - 1.  The caller streams them (the
@@ -1109,34 +1164,30 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_tab(const Swee
 template <typename R, int D, int PO>
 AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int i, const R* x, const R* xp, const R* u_in, const R* xq, const R* xpq, R* out5) {
     using T = LogShared<R, D, PO>;
-    using CQ = CholRow<R, D>;
-    using CR = CholRow<R, PO>;
-    const long long t = (long long)i + 1;
     const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
-    const UniformRow<R> H = uniform_row<R>(at<R>(a.Hs, 0, t, 0)), cv = uniform_row<R>(at<R>(a.cs, 0, t, 0)), y = uniform_row<R>(at<R>(a.ys, 0, t, 0));
-    const UniformRow<R> F = uniform_row<R>(at<R>(a.Fs, 0, i, 0)), bd = uniform_row<R>(at<R>(a.bs, 0, i, 0));
     R u[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)arg_shd(a) * u_in[k] : u_in[k];
-    // observation block (sweep_obs_terms with the factor from the table)
+    // observation block, whitened rows (LogShared): z = yw - WH x; a deleted component's row is zero; a non-finite kept residual <=> a non-finite z
+    // (W is triangular with a non-zero diagonal) drops the term, as does a failed factorisation (cR = NaN) -- the reference's nansum
     R ob_p, ob_x;
     bool badobs_x = false, badobs_p = false;
     {
-        R r1[PO], r2[PO];
-        bool skip[PO];
+        R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < PO; ++k) {
-            R p1 = cv[k], p2 = cv[k];
+            R z1 = row[T::oYw + k], z2 = z1;
 #pragma unroll
-            for (int j = 0; j < D; ++j) p1 += H[k * D + j] * xp[j], p2 += H[k * D + j] * x[j];
-            r1[k] = y[k] - p1;
-            r2[k] = y[k] - p2;
-            skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
-            badobs_p = badobs_p || (!skip[k] && !finite_(r1[k]));
-            badobs_x = badobs_x || (!skip[k] && !finite_(r2[k]));
+            for (int j = 0; j < D; ++j) z1 -= row[T::oWH + k * D + j] * xp[j], z2 -= row[T::oWH + k * D + j] * x[j];
+            badobs_p = badobs_p || !finite_(z1);
+            badobs_x = badobs_x || !finite_(z2);
+            q1 += z1 * z1;
+            q2 += z2 * z2;
         }
-        gauss_logpdf2_fact<R, PO>(r1, r2, row + T::oR + CR::oL, row + T::oR + CR::oI, row[T::oR + CR::oC], a.nan_policy == 1 ? skip : nullptr,
-                                  ob_p, ob_x);
+        ob_p = (R)-0.5 * q1 + row[T::oCR];
+        ob_x = (R)-0.5 * q2 + row[T::oCR];
+        if (badobs_p || isnan_(ob_p)) ob_p = 0;
+        if (badobs_x || isnan_(ob_x)) ob_x = 0;
     }
     R ax_x, ax_p, corr = 0;
     bool b1 = false, b2 = false;
@@ -1163,16 +1214,25 @@ AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int i, const R* x,
     const R cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
     R pr_p, pr_x;
     {
-        R r1[D], r2[D];
+        // transition, whitened: z = WQ x_t - WF x_{t-1} - wb
+        R q1 = 0, q2 = 0;
+        bool bad1 = false, bad2 = false;
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            R m1 = bd[k], m2 = bd[k];
+            R z1 = -row[T::oWb + k], z2 = z1;
 #pragma unroll
-            for (int j = 0; j < D; ++j) m1 += F[k * D + j] * xpq[j], m2 += F[k * D + j] * xq[j];
-            r1[k] = xp[k] - m1;
-            r2[k] = x[k] - m2;
+            for (int l = 0; l <= k; ++l) z1 += row[T::oWQ + lidx(k, l)] * xp[l], z2 += row[T::oWQ + lidx(k, l)] * x[l];
+#pragma unroll
+            for (int j = 0; j < D; ++j) z1 -= row[T::oWF + k * D + j] * xpq[j], z2 -= row[T::oWF + k * D + j] * xq[j];
+            bad1 = bad1 || !finite_(z1);
+            bad2 = bad2 || !finite_(z2);
+            q1 += z1 * z1;
+            q2 += z2 * z2;
         }
-        gauss_logpdf2_fact<R, D>(r1, r2, row + T::oQ + CQ::oL, row + T::oQ + CQ::oI, row[T::oQ + CQ::oC], nullptr, pr_p, pr_x);
+        pr_p = (R)-0.5 * q1 + row[T::oCQ];
+        pr_x = (R)-0.5 * q2 + row[T::oCQ];
+        if (bad1 || isnan_(pr_p)) pr_p = 0;
+        if (bad2 || isnan_(pr_x)) pr_x = 0;
     }
     out5[0] = cc_p + pr_p;
     out5[1] = cc_x + pr_x;
