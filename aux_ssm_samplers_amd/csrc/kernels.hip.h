@@ -715,7 +715,7 @@ template <class Op, int D> __global__ void __launch_bounds__(TB_CM) k_aff_chunkp
     for (int k = 0; k < D * D; ++k) cprod[(long long)ch * D * D + k] = M[k];
 }
 template <class Op, int D>
-__global__ void __launch_bounds__(TB_CM) k_aff_reduce(typename Op::Args a, ScanBufs sb, const typename Op::R* __restrict__ cprod, int S, int N, AffPlan pl) {
+__global__ void __launch_bounds__(TB_CM) k_aff_reduce(typename Op::Args a, ScanBufs sb, int S, int N, AffPlan pl) {
     resolve_step(a);
     using R = typename Op::R;
     using Full = SampElem<R, D>;
@@ -730,10 +730,65 @@ __global__ void __launch_bounds__(TB_CM) k_aff_reduce(typename Op::Args a, ScanB
     }
 #pragma unroll 1
     for (int j = j0; j < j1; ++j) Op::fold(a, s, opaque_uniform(j), agg.e);
-    const UniformRow<R> cp = uniform_row<R>(cprod + (long long)ch * D * D);
-#pragma unroll
-    for (int k = 0; k < D * D; ++k) agg.G[k] = cp[k];
-    SampleOp<R, D>::store_rec((R*)sb.agg + ((long long)s * pl.nchunk + ch) * Full::NPAD, agg);
+    // the aggregate of (chain, chunk) is the affine map (G_chunk, e): G_chunk is the chain-shared chunk product (k_aff_chunkprod's table, read by
+    // k_aff_aggs), only the offset is the chain's -- D reals per record instead of D^2 + D
+    stv<R, D>((R*)sb.agg + ((long long)s * pl.nchunk + ch) * SampPre<R, D>::NPAD, agg.e);
+}
+// k_scan_aggs<SampleOp> for these aggregates: one workgroup per chain scans (G_j, e_j), j < nchunk, with G_j from the shared table
+template <typename R, int D> __global__ void __launch_bounds__(TB_AGGS) k_aff_aggs(ScanBufs sb, const R* __restrict__ cprod, int nchunk) {
+    using Op = SampleOp<R, D>;
+    using Full = SampElem<R, D>;
+    using Pre = SampPre<R, D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lds = (R*)smem;
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x;
+    const int E2 = (nchunk + TB_AGGS - 1) / TB_AGGS;
+    const int j0 = min(nchunk, tid * E2), j1 = min(nchunk, j0 + E2);
+    const R* agg = (const R*)sb.agg + (long long)s * nchunk * Pre::NPAD;
+    R* pre = (R*)sb.pre + (long long)s * nchunk * Pre::NPAD;
+    auto load = [&](int j, Full& e) {
+        ldv<R, D * D>(cprod + (long long)j * D * D, e.G);
+        ldv<R, D>(agg + (long long)j * Pre::NPAD, e.e);
+    };
+    Full acc;
+    Op::identity(acc);
+    if (j0 < j1) load(j0, acc);
+    for (int j = j0 + 1; j < j1; ++j) {
+        Full e, o;
+        load(j, e);
+        Op::combine(acc, e, o);
+        acc = o;
+    }
+    for (int off = 1; off < TB_AGGS; off <<= 1) {  // Kogge-Stone inclusive scan of the per-lane totals
+        Op::store_rec(lds + tid * Full::NPAD, acc);
+        __syncthreads();
+        Full left;
+        if (tid >= off) Op::load_rec(lds + (tid - off) * Full::NPAD, left);
+        __syncthreads();
+        if (tid >= off) {
+            Full o;
+            Op::combine(left, acc, o);
+            acc = o;
+        }
+    }
+    Op::store_rec(lds + tid * Full::NPAD, acc);
+    __syncthreads();
+    Full ex;
+    Op::identity(ex);
+    if (tid > 0) Op::load_rec(lds + (tid - 1) * Full::NPAD, ex);
+    Pre p;
+    Op::to_pre(ex, p);
+    for (int j = j0; j < j1; ++j) {
+        Op::store_pre(pre + (long long)j * Pre::NPAD, p);
+        if (j + 1 < j1) {
+            Full e;
+            Pre o;
+            load(j, e);
+            Op::apply(p, e, o);
+            p = o;
+        }
+    }
 }
 template <class Op, int D>
 __global__ void __launch_bounds__(TB_CM) k_aff_down(typename Op::Args a, ScanBufs sb, typename Op::R* __restrict__ part, int S, int N, AffPlan pl) {
@@ -779,12 +834,12 @@ template <class Op, int D> int run_affine(auxssm_ctx* h, const typename Op::Args
             const int rc = side_close(h);
             if (rc) return rc;
         }
-        sb.agg = ws_take(h, (size_t)S * pl.nchunk * SampElem<R, D>::NPAD * sizeof(R));
+        sb.agg = ws_take(h, (size_t)S * pl.nchunk * SampPre<R, D>::NPAD * sizeof(R));
         sb.pre = ws_take(h, (size_t)S * pl.nchunk * SampPre<R, D>::NPAD * sizeof(R));
         if (!sb.agg || !sb.pre || (part_out && !part)) return AUXSSM_ERR_NOMEM;
-        hipLaunchKernelGGL((k_aff_reduce<Op, D>), dim3(grid_aff(S, pl.nchunk)), dim3(TB_CM), 0, h->stream, a, sb, (const R*)cprod, S, N, pl);
+        hipLaunchKernelGGL((k_aff_reduce<Op, D>), dim3(grid_aff(S, pl.nchunk)), dim3(TB_CM), 0, h->stream, a, sb, S, N, pl);
         const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
-        hipLaunchKernelGGL((k_scan_aggs<SampleOp<R, D>>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, pl.nchunk);
+        hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(S), dim3(TB_AGGS), lds, h->stream, sb, (const R*)cprod, pl.nchunk);
     }
     hipLaunchKernelGGL((k_aff_down<Op, D>), dim3(grid_aff(S, pl.nchunk)), dim3(TB_CM), 0, h->stream, a, sb, part, S, N, pl);
     AX_HIP(hipGetLastError());
