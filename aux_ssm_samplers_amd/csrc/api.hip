@@ -1344,7 +1344,7 @@ int auxssm_prof_disable(auxssm_handle h) {
     return AUXSSM_OK;
 }
 int auxssm_prof_enable(auxssm_handle h, int kernel_id, int max_launches) {
-    AX_NEED_H(h);
+    AX_NEED_H_RO(h);
     if (max_launches < 1 || max_launches > (1 << 16)) {
         set_error("max_launches must be in [1, 65536]");
         return AUXSSM_ERR_ARG;
