@@ -861,6 +861,11 @@ inline int ti_cm() {
     return v;
 }
 #define TI_CM ti_cm()
+// ... and of the chain-shared log-density pass (run_sweep_logpdf; AUXSSM_TI_SHARED overrides)
+inline int ti_shared() {
+    static int v = [] { const char* e = getenv("AUXSSM_TI_SHARED"); const int t = e ? atoi(e) : 64; return t >= 1 && t <= 1024 ? t : 64; }();
+    return v;
+}
 
 // `a` must already carry the layout the element buffer was written with (make_layout(plan_scan(...)))
 // DownOp: the operator of the final pass (same element/prefix types as Op; e.g. SampleOpFly, which rebuilds its elements)
@@ -1124,19 +1129,23 @@ template <typename R, int D, int P> int run_logpdf(auxssm_ctx* h, const LogpdfAr
 }
 
 template <typename R, int D, int PO> size_t sweep_logpdf_ws(const auxssm_ctx*, const KDims& d) {
-    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + TI_CM - 1) / TI_CM) + 1) * sizeof(Acc) + 256 +
+    const int ti = std::min(TI_CM, ti_shared());
+    return (size_t)5 * d.C * (std::max(ntiles(d.T), (d.T + ti - 1) / ti) + 1) * sizeof(Acc) + 256 +
            (size_t)d.T * LogShared<R, D, PO>::NPAD * sizeof(R) + 256;
 }
 // out: [5][C] of Acc
 template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
     const bool cm = a.xp.se != 1;  // chain-minor proposal buffer -> lanes over chains
     const int n = a.d.T - 1;
-    const int C = a.d.C, nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
+    const bool shared_on = h->share_model != 0;
+    const bool shared = shared_on && cm && n > 0 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 &&
+                        a.cs.sc == 0 && a.ys.sc == 0;
+    // time steps per lane: the streamed shared pass (52 scalars per step from its table) likes longer runs than the per-chain pass -- measured at C2,
+    // two runs each: 0.41-0.44 / 0.39 / 0.38-0.41 / 0.38-0.40 ms at 16 / 32 / 48 / 64 steps; the per-chain pass 1.28 / 1.31 / 1.37 / 1.34 ms
+    const int TI = shared ? ti_shared() : TI_CM;
+    const int C = a.d.C, nt = cm ? ((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    const bool shared_on = h->share_model != 0;
-    const bool shared = shared_on && cm && n > 0 && C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 &&
-                        a.cs.sc == 0 && a.ys.sc == 0;
     if (shared) {  // chain-shared parameters: factor Q_{t-1} and Robs_t once per time step
         SweepLogpdfArgs as = a;
         {
@@ -1149,7 +1158,7 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
             const int rc = side_close(h);
             if (rc) return rc;
         }
-        hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, as, part, nt, TI_CM);
+        hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, as, part, nt, TI);
     } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
     else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
