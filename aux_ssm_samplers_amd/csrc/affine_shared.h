@@ -130,6 +130,8 @@ template <typename R, int D, int P> AX_HD void body_gain_tab(const FilterArgs& a
     if (a.aux_on) {
 #pragma unroll
         for (int k = 0; k < P; ++k) y[k] = k < D ? (R)0 : at<R>(a.aux_yobs, 0, t, 0)[k - D];
+    } else if (a.mask_ys.ptr) {
+        rd<R, P>(a.mask_ys, 0, t, 0, y);
     } else {
         rd<R, P>(a.ys, 0, t, 0, y);
     }

@@ -99,6 +99,7 @@ int side_open(auxssm_ctx* h, size_t need) {
     s.last_call = h->api_calls;
     s.parity = p;
     s.off = 0;
+    s.last_tab = nullptr;
     s.open = true;
     return AUXSSM_OK;
 }
@@ -864,8 +865,38 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     const Arr R1A = second ? arr(Rs1, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
     const Arr R2A = second ? arr(Rs2, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
 
-    hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)1, eye);
-    hipLaunchKernelGGL((k_fill<R>), dim3(1), dim3(256), 0, h->stream, (long long)D, (R)0, zero);
+    // First-order factory with chain-shared dynamics: the filtered covariances and the gain rows depend on the model and the step size only (the
+    // pseudo-observations are finite whatever the data: every component is observed), the same for the proposal and the reverse filter.  That MODEL
+    // STAGE runs once per sweep, on the side stream beside the previous sweep (ctx.h::SideStage, as in sweep_lg_concat); the reverse filter reuses
+    // its gain rows.
+    const int ps_shared = (!second && !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0)) ? 1 : 0;
+    bool overlap = h->overlap_model_stage != 0 && ps_shared && cm && parallel && !dptr;
+    struct SweepEnd {
+        auxssm_ctx* h;
+        ~SweepEnd() { side_sweep_end(h); }
+    } sweep_end{h};
+    R* mask_carrier = nullptr;
+    if (overlap) {
+        const size_t P_ = D, gain = (size_t)D * D + D + 2 * (size_t)D * P_ + P_ + P_ * (P_ + 1) / 2 + 4, felem = 3 * (size_t)D * D + 2 * D + 8;
+        const size_t need_side = (size_t)(T + 64) * sR * (3 * (size_t)D * D + 4 * D + gain + 2 * felem + 8 * (size_t)D * D + 8 * D + 32) + (4u << 20);
+        if ((rc = side_open(h, need_side))) return rc;
+        overlap = h->side.open;
+    }
+    if (overlap) {
+        SideScope sc_(h);
+        eye = (R*)ws_take(h, (size_t)D * D * sR);
+        Rc = (R*)ws_take(h, (size_t)D * D * sR);
+        zero = (R*)ws_take(h, (size_t)D * sR);
+        Ps = (R*)ws_take(h, (size_t)T * D * D * sR);
+        mask_carrier = (R*)ws_take(h, (size_t)T * D * sR);
+        if (!eye || !Rc || !zero || !Ps || !mask_carrier) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_fill<R>), dim3((unsigned)(((long long)T * D + 255) / 256)), dim3(256), 0, h->stream, (long long)T * D, (R)0, mask_carrier);
+    }
+    {
+        SideScope sc_(h);
+        hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)1, eye);
+        hipLaunchKernelGGL((k_fill<R>), dim3(1), dim3(256), 0, h->stream, (long long)D, (R)0, zero);
+    }
     AX_HIP(hipGetLastError());
     // observation LGSSMs of the two linearisation points (H = I, c = 0; R = delta/2 I or the per-step diagonal Omega)
     auxssm_lgssm g1 = *model;
@@ -874,13 +905,15 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     g1.Rs = second ? auxssm_arr{Rs1, (int64_t)T * D * D, (int64_t)D * D, 0} : auxssm_arr{Rc, 0, 0, 0};
     auxssm_lgssm g2 = g1;
     if (second) g2.Rs = auxssm_arr{Rs2, (int64_t)T * D * D, (int64_t)D * D, 0};
-    if (!second) hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)(0.5 * delta), Rc, dptr);
+    if (!second) {
+        SideScope sc_(h);
+        hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)(0.5 * delta), Rc, dptr);
+    }
     auxssm_dims dc = *dims;
     dc.dy = D;
     dc.B = 1;
     const auxssm_arr y1d{ys1, (int64_t)T * D, (int64_t)D, 0}, y2d{ys2, (int64_t)T * D, (int64_t)D, 0};
     // the filtered covariances do not depend on the chain when neither the dynamics nor R do (first order)
-    const int ps_shared = (!second && !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0)) ? 1 : 0;
     const Arr PsA = ps_shared ? Arr{Ps, 0, (long long)D * D, 0, 1} : arr(Ps, (long long)D * D);
 
     // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
@@ -896,6 +929,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R1A;
+    if (overlap) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
     rc = ke->filter(h, fa, parallel, ell1);
     if (rc) return rc;
     h->ws_off = mark;
@@ -922,6 +956,11 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R2A;
+    if (overlap && h->side.last_tab) {  // the proposal filter's gain rows (same model, step size and mask)
+        fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
+        fa.tab = h->side.last_tab;
+        fa.tab_ready = 1;
+    }
     rc = ke->filter(h, fa, parallel, ell2);
     if (rc) return rc;
     h->ws_off = mark;

@@ -69,6 +69,7 @@ struct auxssm_ctx {
         // behind anything else the caller may have enqueued through the handle (an upload of new parameters, a memset, another kind of call): every
         // entry point counts itself in auxssm_ctx::api_calls, and a stage that is not opened by the call right after the last staged sweep first
         // waits for the tail of `stream` (one sweep without overlap).
+        const void* last_tab = nullptr;  // gain rows the open stage built (run_filter_shared), for a second filter of the same sweep
         unsigned long long last_call = 0;
         hipEvent_t fence = nullptr;
         size_t off = 0;                                // bump offset inside the open slab

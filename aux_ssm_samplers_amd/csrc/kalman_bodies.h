@@ -121,6 +121,11 @@ struct FilterArgs {
     int aux_on = 0;
     Arr aux_x{}, aux_eps{}, aux_u{}, aux_yobs{};
     double aux_shd = 0;
+    // chain-shared filter with per-chain observations (SV first order): the observation MASK the gain table is built for comes from mask_ys (T, P; a
+    // chain-independent carrier) when set, else from chain 0's ys; tab_ready: `tab` already holds this sweep's gain rows (the reverse filter of a sweep
+    // reuses the proposal filter's: same model, same step size, same mask)
+    Arr mask_ys{nullptr, 0, 0, 0, 1};
+    int tab_ready = 0;
     int t0_keep_ps = 0;  // k_filter_t0: leave Ps[0] alone (chain-shared covariances: the matrix filter wrote the one slot all chains would write)
     const double* dptr = nullptr;  // device-resident step size: {delta, sqrt(delta / 2)} (auxssm_kalman_sweep_dd); null: the host values above
     // aux_gen != 0 (auxssm_kalman_sweep_keyed): rows t >= 1 of aux_eps are GENERATED by the reduce pass (the first reader) from the key and

@@ -921,7 +921,7 @@ template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterA
     // the covariances are chain-independent: the caller lays them out once, (T, D, D) dense with chain stride 0 (ctx.h::chain_shared_mode),
     // and the matrix filter writes them in place; any other layout gets chain 0's slot filled from a scratch copy
     const bool ps_once = a.Ps.sc == 0 && a.Ps.se == 1 && a.Ps.st == (long long)D * D;
-    {
+    if (!(a.tab && a.tab_ready)) {
         // the matrix filter: the parallel filter on ONE sequence, always the parallel plan (its means are not used: the observation
         // values are the mask carrier's).  Dense (time-minor) layout.  Inside a sweep that opened a side stage (ctx.h::SideStage) all of this block --
         // launches, scratch and the gain table -- goes to the side stream and its slab; the caller then put Ps there too.
@@ -950,6 +950,8 @@ template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterA
             const long long tot = (long long)T * P;
             hipLaunchKernelGGL((k_mask_obs<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, a.aux_yobs, ym);
             am.ys = dense_arr(ym, am.d, P);
+        } else if (a.mask_ys.ptr) {
+            am.ys = a.mask_ys;  // a chain-independent mask carrier
         } else {
             am.ys = Arr{a.ys.ptr, 0, a.ys.st, 0, a.ys.se};  // chain 0's observations
         }
@@ -963,6 +965,7 @@ template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterA
         a.tab = ws_take(h, (size_t)n * GainRow<R, D, P>::NPAD * sizeof(R));
         if (!a.tab) return AUXSSM_ERR_NOMEM;
         hipLaunchKernelGGL((k_gain_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a, (const R*)Ps1);
+        if (side.on) h->side.last_tab = a.tab;
         if (!ps_once)  // chain 0's slot of the caller's buffer (the sampler's table reads that one)
             hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
     }

@@ -147,3 +147,32 @@ def test_model_stage_on_the_side_stream_equals_the_single_stream_sweep(dtype):
         for p, q in zip(u, v):
             npt.assert_array_equal(p, q)
     assert not np.array_equal(a[-1][0], x0[0])
+
+
+def test_sv_first_order_model_stage_on_the_side_stream_equals_the_single_stream_sweep():
+    """The first-order SV factory with chain-shared dynamics: covariances and gain rows depend on the model and the step size only, so the sweep builds
+    them once (the reverse filter reuses the proposal filter's rows) on the second stream -- bit for bit the single-stream sweep, over changing step sizes."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import SVModel
+    from tests.helpers import sv_setup
+    h = _lib.default_handle()
+    T, d, C = 3000, 2, 64
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, d)
+    x0 = np.repeat(xtrue[None], C, axis=0) + 0.1 * np.random.default_rng(2).standard_normal((C, T, d))
+
+    def run(overlap):
+        h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, overlap)
+        model = SVModel(y, m0, P0, F, Q, b, order=1)
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        st = DeviceChains(h, x0, chain_minor=True)
+        for i, dl in enumerate([0.05, 0.05, 0.03, 0.03, 0.08, 0.05]):
+            kernel(R.PRNGKey(77 + i), KalmanSampler(x=st, updated=None), dl)
+        return st.to_host(), st.accepted.to_host(), st.logs.to_host()
+
+    try:
+        a, b_ = run(1), run(0)
+    finally:
+        h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, 1)
+    for p, q in zip(a, b_):
+        npt.assert_array_equal(p, q)
+    assert 0 < a[1].mean() < 1  # (some chains moved, some did not)
