@@ -29,7 +29,11 @@
  *                non-decreasing c);   single draw of the backward pass: B = #{j : c_j < r}, clipped to N - 1;
  *   - every multiply-add that is fused is written as fma(); compile with -ffp-contract=off.
  * What IS pinned: the statistical known answers of the reference's tests (test_csmc.py::test_flat_potential :18-69,
- * test_resamplings.py::test_multinomial_resampling :11-24) -- see tests/test_oracle_csmc.py.
+ * test_resamplings.py::test_multinomial_resampling :11-24) -- see tests/test_oracle_csmc.py -- and, since round 3, the LITERAL
+ * restatement of the reference's own arithmetic order, oracle/csmc_np.py (normalised weights, plain cumsum, searchsorted, generic
+ * Python model objects): tests/test_oracle_csmc_literal.py demands the same ancestors / backward indices / trajectories from both in
+ * fp64 for every member of the closed family (and over the 50 000 sweeps of the reference's flat-potential protocol), and bounds the
+ * fp32 tie rate of the two orders (1.4e-4 per draw at N = 1024, always a neighbouring particle).
  *
  * Build: gcc -O2 -ffp-contract=off -shared -fPIC csmc_ref.c -o _build/libcsmc_ref.so -lm   (oracle/Makefile)
  */

@@ -152,6 +152,30 @@ def test_flat_potential_reference_statistical_test(backward):
     npt.assert_allclose(np.diag(cov, 1), rho, atol=0.05)
 
 
+@pytest.mark.parametrize("backward", [True, False])
+def test_flat_potential_at_the_reference_protocol(backward):
+    """the same known answer at the reference's OWN protocol (test_csmc.py:18-69): ONE chain, T = 5, N = 32, 50_000 sweeps, the first
+    10 % discarded, atol 0.05 -- the literal restatement and the contract oracle run it in tests/test_oracle_csmc_literal.py."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd._primitives.csmc import get_kernel
+    from aux_ssm_samplers_amd.csmc import GaussianInit, LinearGaussianDynamics, FlatPotential
+    T, N, rho, M = 5, 32, 0.9, 50_000
+    M0 = GaussianInit(m0=[0.0], P0=[[1.0]])
+    Mt = LinearGaussianDynamics(F=[[rho]], b=[0.0], Q=[[1 - rho ** 2]])
+    init, kernel = get_kernel(M0, FlatPotential(), Mt, FlatPotential(), N=N, backward=backward, Pt=Mt)
+    state = init(np.random.default_rng(0).standard_normal((T, 1)).astype(np.float32))
+    keys = R.split(R.PRNGKey(0), M)
+    xs = np.empty((M, T))
+    for it in range(M):
+        state = kernel(keys[it], state)
+        xs[it] = state.x[:, 0]
+    xs = xs[M // 10:]
+    cov = np.cov(xs, rowvar=False)
+    npt.assert_allclose(xs.mean(0), 0.0, atol=0.05)
+    npt.assert_allclose(np.diag(cov), 1.0, atol=0.05)
+    npt.assert_allclose(np.diag(cov, 1), rho, atol=0.05)
+
+
 def test_independent_kernel_api_and_C3_shape_smoke():
     """csmc.get_independent_kernel on the SV model of BASELINE config C3 (d=1, N=1024, backward sampling), reduced T.
     Checks the API surface (init/kernel/CSMCState) and bit-exactness against the oracle given the same noise."""
