@@ -9,7 +9,7 @@ import aux_ssm_samplers_amd as _impl
 _ALIASES = ["kalman", "csmc", "common", "loop", "random", "parallel", "_primitives", "_primitives.base", "_primitives.kalman",
             "_primitives.kalman.base", "_primitives.kalman.filtering", "_primitives.kalman.sampling", "_primitives.kalman.dnc_sampling",
             "_primitives.linearisation", "diagnostics", "_primitives.csmc",
-            "_primitives.csmc.base", "_primitives.csmc.csmc", "_primitives.csmc.resamplings", "_primitives.math",
+            "_primitives.csmc.base", "_primitives.csmc.csmc", "_primitives.csmc.resamplings", "_primitives.csmc.pit", "_primitives.math",
             "_primitives.math.utils", "_primitives.math.mvn", "_primitives.math.mvn.base", "csmc.generic", "csmc.independent", "kalman.generic"]
 for _name in _ALIASES:
     sys.modules[f"{__name__}.{_name}"] = importlib.import_module(f"aux_ssm_samplers_amd.{_name}")

@@ -83,6 +83,7 @@ def load():
         "auxssm_sync": ([vp], C.c_int),
         "auxssm_stream": ([vp, P(vp)], C.c_int),
         "auxssm_set_option": ([vp, C.c_int, C.c_int], C.c_int),
+        "auxssm_get_option": ([vp, C.c_int, P(C.c_int)], C.c_int),
         "auxssm_malloc": ([vp, C.c_size_t, P(vp)], C.c_int),
         "auxssm_free": ([vp, vp], C.c_int),
         "auxssm_memcpy_h2d": ([vp, vp, vp, C.c_size_t], C.c_int),
@@ -154,6 +155,10 @@ class Handle:
         h = C.c_void_p()
         check(lib.auxssm_create(int(device), C.byref(h)))
         self.lib, self.h, self.device = lib, h, int(device)
+        # the C ABI ships the model-stage overlap OFF (include/auxssm.h); this layer routes every device write through an auxssm_* entry
+        # point (which the library fences), so it opts in -- unless the environment pins the default
+        if "AUXSSM_OVERLAP_TAB" not in os.environ:
+            check(lib.auxssm_set_option(h, OPT_OVERLAP_MODEL_STAGE, 1))
 
     def close(self):
         if self.h:
@@ -168,6 +173,18 @@ class Handle:
 
     def sync(self):
         check(self.lib.auxssm_sync(self.h))
+
+    def stream(self):
+        """auxssm_stream: the raw hipStream_t (as an int).  Handing it out makes every later model stage wait for the tail of the stream (the caller
+        may queue work on it the library cannot see)."""
+        s = C.c_void_p()
+        check(self.lib.auxssm_stream(self.h, C.byref(s)))
+        return s.value
+
+    def get_option(self, option):
+        v = C.c_int()
+        check(self.lib.auxssm_get_option(self.h, int(option), C.byref(v)))
+        return v.value
 
     def set_option(self, option, value):
         """auxssm_set_option: e.g. (OPT_SHARE_MODEL, 0) forces the general per-chain path of the chain-minor sweep, (OPT_OVERLAP_MODEL_STAGE, 0)

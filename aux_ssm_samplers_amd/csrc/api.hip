@@ -92,7 +92,9 @@ int side_open(auxssm_ctx* h, size_t need) {
         s.end_valid[p] = false;
     }
     if (s.end_valid[p]) AX_HIP(hipStreamWaitEvent(s.stream, s.sweep_end[p], 0));
-    if (h->api_calls != s.last_call + 1) {  // something other than a staged sweep went through the handle since: its work comes first
+    // something other than a staged sweep went through the handle since -- or the caller holds the raw stream and may have queued work on it the
+    // library never saw (auxssm_stream): that work comes first
+    if (h->api_calls != s.last_call + 1 || h->stream_exposed) {
         AX_HIP(hipEventRecord(s.fence, h->stream));
         AX_HIP(hipStreamWaitEvent(s.stream, s.fence, 0));
     }
@@ -1312,6 +1314,7 @@ int auxssm_stream(auxssm_handle h, void** stream) {
     AX_NEED_H(h);
     if (!stream) return AUXSSM_ERR_ARG;
     *stream = (void*)h->stream;
+    h->stream_exposed = true;
     return AUXSSM_OK;
 }
 int auxssm_malloc(auxssm_handle h, size_t bytes, void** dptr) {
@@ -1367,6 +1370,18 @@ int auxssm_set_option(auxssm_handle h, int option, int value) {
     }
     set_error("unknown option %d", option);
     return AUXSSM_ERR_ARG;
+}
+
+int auxssm_get_option(auxssm_handle h, int option, int* value) {
+    AX_NEED_H_RO(h);
+    if (!value) return AUXSSM_ERR_ARG;
+    if (option == AUXSSM_OPT_SHARE_MODEL) *value = h->share_model;
+    else if (option == AUXSSM_OPT_OVERLAP_MODEL_STAGE) *value = h->overlap_model_stage;
+    else {
+        set_error("unknown option %d", option);
+        return AUXSSM_ERR_ARG;
+    }
+    return AUXSSM_OK;
 }
 
 int auxssm_prof_disable(auxssm_handle h) {

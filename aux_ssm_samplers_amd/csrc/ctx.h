@@ -51,7 +51,9 @@ struct auxssm_ctx {
     long long st_n = 0;
     int st_dtype = -1;
     unsigned long long api_calls = 0;  // entry points that may enqueue work or change device data (not: sync, device-to-host copies, profiler reads)
-    int overlap_model_stage = 1;       // AUXSSM_OPT_OVERLAP_MODEL_STAGE
+    int overlap_model_stage = 0;       // AUXSSM_OPT_OVERLAP_MODEL_STAGE (off unless the caller opts in: include/auxssm.h)
+    bool stream_exposed = false;       // auxssm_stream() has handed out `stream`: work the library cannot see may be queued on it, so a model stage
+                                       // always waits for the tail of `stream` from then on (side_open)
     double* dblock = nullptr;  // {delta, sqrt(delta / 2)} of a sweep whose step size is device-resident (auxssm_kalman_sweep_dd); lazily allocated
     // The MODEL STAGE of a chain-shared sweep -- concatenated observation model, matrix filter on one sequence, gain table: ~0.4 ms of short dependent
     // launches that read the model and the step size only, never a chain -- runs on a second stream with its own double-buffered slab, so that the

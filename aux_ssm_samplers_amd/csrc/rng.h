@@ -70,6 +70,11 @@ template <typename R> AX_HD void sincos_2pi(R u, R& c, R& s) {
     s = (qi >= 2) ? -b : b;
 }
 
+// CONTRACT of the normal transform (restated in oracle/rng_np.py, to rounding): the BITS are pinned (Threefry-2x32-20, Random123 KATs; uniforms are
+// bit-exact against the oracle); the normals are pinned to a TOLERANCE -- fp64: det_log<true> + sqrt + sincos_2pi with explicit fma, within 1e-12 of
+// the oracle's libm / no-fma restatement; fp32 on the DEVICE: the hardware v_log_f32 / v_sqrt_f32 (1 ulp each), within 2e-5 relative / 2e-6 absolute
+// of the oracle (tests/test_rng.py), so device fp32 normals are reproducible on the device only: every bit-exact cSMC / PIT check that uses keyed
+// noise draws it on the device first (csmc/_device.py::key_noise) and hands the arrays to the oracle.
 // Box-Muller on one Threefry block (two 32-bit words) -> TWO normals (cos and sin branch).  Normal number `idx` of a stream
 // is branch (idx & 1) of the block with counter idx >> 1.  fp64: u = (b + 0.5) 2^-32 in (0,1), double math.  fp32:
 // u = ((b >> 8) + 0.5) 2^-24, float math throughout (the cSMC kernels draw N of these per time step).

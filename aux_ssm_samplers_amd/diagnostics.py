@@ -49,7 +49,7 @@ def effective_sample_size(input_array, var=None, chain_axis=0, sample_axis=1):
         upd = s > np.concatenate([[s[0]], run[:-1]])
         e_f = np.where(upd, run / 2.0, e)
         o_f = np.where(upd, run / 2.0, o)
-        extra = e_f[last + 1] if last + 1 < len(e) else 0.0
+        extra = e_f[min(last + 1, len(e) - 1)]                        # (ess.py:156: the gather clamps an out-of-range index to the last even term)
         tau = -1.0 + 2.0 * np.sum(e_f + o_f) - extra
         tau = max(tau, 1.0 / np.log10(M * N))
         ess[k] = M * N / tau

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 105
+#define AUXSSM_VERSION 106
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -78,14 +78,17 @@ int auxssm_sync(auxssm_handle h);
  *   linearisation point), everything that depends on the parameters only -- element matrices, gains, Cholesky factors of Q_t /
  *   R_t, the filtered covariances -- is computed once per time step and sweep instead of once per chain (what jax.vmap leaves
  *   unbatched in the reference).  0 forces the general per-chain path.  Results agree to rounding.
- * AUXSSM_OPT_OVERLAP_MODEL_STAGE (default 1; environment AUXSSM_OVERLAP_TAB=0 changes the default): a chain-shared sweep with a host step
+ * AUXSSM_OPT_OVERLAP_MODEL_STAGE (default 0 = every call ordered on the one stream; environment AUXSSM_OVERLAP_TAB=1 / 0 changes the default;
+ *   the Python host layer, whose every device write goes through an auxssm_* call, switches it on): a chain-shared sweep with a host step
  *   size runs its MODEL STAGE -- the concatenated observation model, the matrix filter on one sequence, the gain / sampler / log-density
  *   tables: everything that reads the model and the step size only -- on a second stream with a double-buffered workspace, so that the stage
- *   of one sweep overlaps the chain passes of the sweep before (same results bit for bit).  The stage waits for earlier work only when
- *   another call went through the handle since the last such sweep; a caller that changes the model arrays by work it enqueues ITSELF on
- *   auxssm_stream() between two sweeps must call auxssm_sync first, or set the option to 0. */
+ *   of one sweep overlaps the chain passes of the sweep before (same results bit for bit).  The stage runs ahead of earlier SWEEPS only: when
+ *   any other call went through the handle since the last such sweep, or once auxssm_stream() has handed the raw stream to the caller (who
+ *   may queue work on it the library cannot see), the stage first waits for the tail of the stream.  Still outside the library's sight with
+ *   the option on: model arrays written by ANOTHER stream or handle without host synchronisation -- call auxssm_sync first, or leave it 0. */
 typedef enum { AUXSSM_OPT_SHARE_MODEL = 1, AUXSSM_OPT_OVERLAP_MODEL_STAGE = 2 } auxssm_option;
 int auxssm_set_option(auxssm_handle h, int option, int value);
+int auxssm_get_option(auxssm_handle h, int option, int* value);
 
 /* the hipStream_t the handle launches on (as an opaque pointer) */
 int auxssm_stream(auxssm_handle h, void** stream);

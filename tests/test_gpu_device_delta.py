@@ -176,3 +176,65 @@ def test_sv_first_order_model_stage_on_the_side_stream_equals_the_single_stream_
     for p, q in zip(a, b_):
         npt.assert_array_equal(p, q)
     assert 0 < a[1].mean() < 1  # (some chains moved, some did not)
+
+
+def test_model_array_rewritten_through_the_raw_stream_between_two_sweeps():
+    """a caller that holds auxssm_stream() can queue a write of a model array on it that the library never sees.  Once the stream
+    has been handed out every model stage waits for the tail of the stream, so the sweep after such a write reads the NEW data: bit for bit the
+    single-stream result.  (The write here is a hipMemcpyAsync issued straight through the HIP runtime behind milliseconds of queued work.)"""
+    import ctypes
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import LGConcatModel
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+    T, d, C, dtype = 1500, 2, 64, np.float64
+    m = lg_model(T, d, dtype=dtype)
+    full = lambda a, n: np.ascontiguousarray(np.broadcast_to(a, (n,) + a.shape))
+    rng = np.random.default_rng(11)
+    y2 = (m["y"] + 0.5 * rng.standard_normal(m["y"].shape)).astype(dtype)
+    x0 = rng.standard_normal((C, T, d)).astype(dtype) * 0.3
+
+    def run(overlap, raw):
+        h = _lib.Handle()
+        try:
+            h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, overlap)
+            model = LGConcatModel(m["m0"], m["P0"], full(m["F"], T - 1), full(m["Q"], T - 1), full(m["b"], T - 1), full(m["Hobs"], T),
+                                  full(m["Robs"], T), full(m["cobs"], T), m["y"])
+            init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+            st = DeviceChains(h, x0, chain_minor=True)
+            _, ybuf, _ = model.device(h, dtype)
+            ynew = _lib.DeviceArray(h, ybuf.shape, ybuf.dtype)
+            ynew.copy_from_host(np.ascontiguousarray(y2).reshape(ybuf.shape))
+            stream = h.stream() if raw else None
+            junk = None
+            for i in range(6):
+                if i == 3:
+                    junk = h.rng_normal(R.PRNGKey(5), 9, (1 << 28,), np.float32)  # milliseconds of queued work in front of the write
+                    if raw:
+                        assert hip.hipMemcpyAsync(ybuf.ptr, ynew.ptr, ybuf.nbytes, 3, ctypes.c_void_p(stream)) == 0  # hipMemcpyDeviceToDevice
+                    else:
+                        ybuf.copy_from(ynew)
+                kernel(R.PRNGKey(2000 + i), KalmanSampler(x=st, updated=None), 0.4)
+            return st.to_host(), st.accepted.to_host(), st.logs.to_host()
+        finally:
+            h.sync()
+            h.close()
+
+    a, b, c = run(1, True), run(0, True), run(0, False)
+    for p, q, r in zip(a, b, c):
+        npt.assert_array_equal(p, q)
+        npt.assert_array_equal(p, r)
+
+
+def test_c_abi_default_is_the_single_stream_sweep():
+    """the C ABI ships AUXSSM_OPT_OVERLAP_MODEL_STAGE off (include/auxssm.h); only the Python layer's Handle opts in"""
+    import ctypes
+    lib = _lib.load()
+    h = ctypes.c_void_p()
+    assert lib.auxssm_create(0, ctypes.byref(h)) == 0
+    try:
+        v = ctypes.c_int(-1)
+        assert lib.auxssm_get_option(h, _lib.OPT_OVERLAP_MODEL_STAGE, ctypes.byref(v)) == 0 and v.value == 0
+    finally:
+        lib.auxssm_destroy(h)
+    assert _lib.Handle().get_option(_lib.OPT_OVERLAP_MODEL_STAGE) == 1

@@ -80,6 +80,31 @@ def test_ess_known_answers():
     assert out.shape == (2,) and np.all(out > 0.8 * 3 * N)
 
 
+def test_ess_all_positive_initial_sequence_clamps_like_the_reference():
+    """when the WHOLE initial sequence is positive (max_t + 1 == number of pairs) the reference's gather
+    `rho_hat_even_final[indices]` (ess.py:122-123,156) clamps the out-of-range index, so the LAST even term is subtracted -- not 0.
+    Hand computation on a short, strongly autocorrelated pair of chains."""
+    from aux_samplers.diagnostics import effective_sample_size
+    M, N = 2, 6
+    x = np.array([[0.0, 1.0, 2.1, 2.9, 4.2, 5.0], [0.2, 0.9, 2.0, 3.1, 3.9, 5.1]]) + np.array([[0.0], [3.0]])
+    # ess.py:60-111 written out for this input
+    xc = x - x.mean(axis=1, keepdims=True)
+    acov = np.array([[np.sum(xc[m, :N - k] * xc[m, k:]) / N for k in range(N)] for m in range(M)])
+    mean_acov = acov.mean(axis=0)
+    var0 = mean_acov[0] * N / (N - 1.0)
+    wvar = mean_acov[0] + np.var(x.mean(axis=1), ddof=1)     # weighted_var = mean_var0 (N-1)/N + between-chain variance
+    rho = np.concatenate([[1.0], 1.0 - (var0 - mean_acov[1:N]) / wvar])
+    e, o = rho[0::2], rho[1::2]
+    assert np.all(e + o > 0)                                  # the whole sequence is positive: max_t + 1 = 3 = len(e)
+    s = e + o
+    run = np.minimum.accumulate(s)
+    upd = s > np.concatenate([[s[0]], run[:-1]])
+    e_f, o_f = np.where(upd, run / 2, e), np.where(upd, run / 2, o)
+    tau = -1.0 + 2.0 * np.sum(e_f + o_f) - e_f[-1]            # clamped gather: the last even term
+    want = M * N / max(tau, 1.0 / np.log10(M * N))
+    npt.assert_allclose(effective_sample_size(x), want, rtol=1e-12)
+
+
 def test_result_files_have_the_reference_schema(tmp_path):
     from aux_samplers.diagnostics import save_experiment_npz, save_rare_event_csv
     K, T, D = 3, 5, 2
