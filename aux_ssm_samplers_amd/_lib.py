@@ -18,6 +18,7 @@ KMODEL_LG_CONCAT, KMODEL_SV_FIRST, KMODEL_SV_SECOND, KMODEL_LORENZ63_EXT = 1, 2,
 LAYOUT_DENSE, LAYOUT_CHAIN_MINOR = 0, 1
 OPT_SHARE_MODEL = 1
 OPT_OVERLAP_MODEL_STAGE = 2
+ERR_ARG, ERR_UNSUPPORTED, ERR_HIP, ERR_NOMEM = -1, -2, -3, -4
 (K_NONE, K_FILTER_INIT, K_FILTER_SCAN, K_FILTER_ELL, K_SAMPLE_INIT, K_SAMPLE_SCAN, K_LOGPDF, K_CSMC_FWD,
  K_CSMC_BWD, K_PIT_STITCH, K_RNG, K_SELECT, K_FACTORY, K_FILTER_TAB, K_COUNT) = range(15)
 K_ALL = -1
@@ -100,6 +101,8 @@ def load():
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_kalman_sweep_dd": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_kalman_sweep_keyed": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, vp, P(C.c_uint32), i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_kalman_sweep_fused": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, vp, P(C.c_uint32), i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
+        "auxssm_kalman_state_resolve": ([vp, i32, P(Dims), vp, vp, vp], C.c_int),
         "auxssm_csmc_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp, vp, vp, vp], C.c_int),
         "auxssm_csmc_pit_sweep": ([vp, i32, P(FkModel), C.c_int32, C.c_int32, C.c_int32, vp, vp, P(CsmcNoise), vp], C.c_int),
         "auxssm_normalize_resample": ([vp, i32, C.c_int32, C.c_int32, vp, vp, vp, vp, vp], C.c_int),

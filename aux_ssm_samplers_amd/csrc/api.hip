@@ -689,6 +689,147 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     return AUXSSM_OK;
 }
 
+// ---- the chain-shared LG_CONCAT sweep in three streaming passes (fused_shared.h) -----------------------------------------------------------
+// row t = 0 of u and of the concatenated observation [u_0 ; yobs_0] from the chain's own buffer (lazy state: x of chain c lives in xa or xb);
+// eps0 (D, C) = row 0 of eps_aux.  One lane per (component, chain).
+template <typename R>
+__global__ void k_fs_concat0(int C, int D, int PO, const R* __restrict__ xa, const R* __restrict__ xb, const int32_t* __restrict__ sel, const R* __restrict__ eps0, R shd,
+                             const double* dptr, Arr yobs, R* __restrict__ u, R* __restrict__ ysc0) {
+    if (dptr) shd = (R)dptr[1];
+    const int P = D + PO;
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= C * P) return;
+    const int c = g % C, k = g / C;
+    if (k < D) {
+        const R* x = (sel && sel[c]) ? xb : xa;
+        const R v = x[(long long)k * C + c] + shd * eps0[(long long)k * C + c];
+        u[(long long)k * C + c] = v;
+        ysc0[(long long)k * C + c] = v;
+    } else {
+        ysc0[(long long)k * C + c] = at<R>(yobs, 0, 0, 0)[k - D];
+    }
+}
+// chain c's state gathered into xa: xa[:, :, c] <- xb[:, :, c] where sel[c]; rows of C contiguous chains (blockIdx.x = (t, k), blockIdx.y = block of chains)
+template <typename R> __global__ void __launch_bounds__(256) k_fs_resolve(int C, const int32_t* __restrict__ sel, const R* __restrict__ xb, R* __restrict__ xa) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long off = (long long)blockIdx.x * C + c;
+    if (sel[c]) xa[off] = xb[off];
+}
+// whether (and why not) a sweep can run the fused passes
+static const char* fused_refusal(const auxssm_ctx* h, const auxssm_dims* dims, const auxssm_lgssm* model, int parallel, int layout) {
+    const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy;
+    static const bool off = [] { const char* e = getenv("AUXSSM_FUSED"); return e && atoi(e) == 0; }();
+    if (off) return "AUXSSM_FUSED=0";
+    if (layout != AUXSSM_LAYOUT_CHAIN_MINOR) return "the fused sweep takes the chain-minor layout";
+    if (D > MAX_D || PO < 1 || PO > 4) return "the fused sweep is instantiated for dx <= 4, 1 <= dy <= 4";
+    if (!parallel) return "the fused sweep is the parallel-in-time one";
+    if (!h->share_model) return "AUXSSM_OPT_SHARE_MODEL is off";
+    if (!(model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0 && model->m0.sc == 0))
+        return "the fused sweep needs chain-shared model parameters (chain stride 0)";
+    if (C < 2 || (C % 2) != 0) return "the fused sweep pairs chains for its in-kernel draws: the chain count must be even";
+    if (T < 64) return "the fused sweep needs T >= 64";
+    if (h->st_mean) return "running moments are attached (auxssm_stats_attach): their fold lives in the select pass";
+    return nullptr;
+}
+template <typename R>
+static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, const double* dptr,
+                                 const uint32_t* keys, int nan_policy, void* x, void* x_alt, int32_t* sel, void* u_acc, int32_t* accepted, void* logs) {
+    const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy, P = D + PO;
+    const SweepLogpdfEntry* sl = sweep_logpdf_entry(dtype, D, PO);
+    if (!sl || !sl->fused) {
+        set_error("(dx=%d, dy=%d) has no fused sweep in this build", D, PO);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    const KDims kd{C, T, 1};
+    const size_t sR = sizeof(R), CT = (size_t)C * T;
+    size_t need = 0;
+    auto add = [&](size_t b) { need += b + 256; };
+    add(CT * D * sR);                                   // u
+    add(CT * D * sR);                                   // inc
+    add((size_t)T * (P * D + P * P + P + D * D) * sR);  // Hc, Rc, cc, Ps (four takes; in the side slab when the stage overlaps)
+    add(1024);
+    add((size_t)C * (P + 3 * D) * sR + 1024);           // ysc0, m0p, eps0a, eps0s
+    add(sl->fused_ws(h, kd));
+    int rc = ws_reserve(h, need);
+    if (rc) return rc;
+    R* u = (R*)ws_take(h, CT * D * sR);
+    R* inc = (R*)ws_take(h, CT * D * sR);
+    R* ysc0 = (R*)ws_take(h, (size_t)C * P * sR);
+    R* m0p = (R*)ws_take(h, (size_t)C * D * sR);
+    R* eps0a = (R*)ws_take(h, (size_t)C * D * sR);
+    R* eps0s = (R*)ws_take(h, (size_t)C * D * sR);
+    if (!u || !inc || !ysc0 || !m0p || !eps0a || !eps0s) return AUXSSM_ERR_NOMEM;
+    bool overlap = h->overlap_model_stage != 0 && !dptr;
+    struct SweepEnd {
+        auxssm_ctx* h;
+        ~SweepEnd() { side_sweep_end(h); }
+    } sweep_end{h};
+    if (overlap) {
+        const size_t need_side = sl->fused_ws(h, kd) + (size_t)(T + 64) * sR * ((size_t)P * D + (size_t)P * P + P + (size_t)D * D) + (4u << 20);
+        if ((rc = side_open(h, need_side))) return rc;
+        overlap = h->side.open;
+    }
+    R *Hc, *Rc, *cc, *Ps;
+    {
+        SideScope sc(h);  // (model stage: the side slab when a stage is open, else the main one)
+        Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
+        Rc = (R*)ws_take(h, (size_t)T * P * P * sR);
+        cc = (R*)ws_take(h, (size_t)T * P * sR);
+        Ps = (R*)ws_take(h, (size_t)T * D * D * sR);
+        if (!Hc || !Rc || !cc || !Ps) return AUXSSM_ERR_NOMEM;
+        ProfScope ps(h, AUXSSM_K_FACTORY);
+        const long long n1 = (long long)T * (P * D + P * P + P);
+        hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs), cv(model->Rs), cv(model->cs),
+                           (R)(0.5 * delta), dptr, Hc, Rc, cc);
+    }
+    // row 0 of the two normal draws and the acceptance uniforms (the rest is drawn inside passes A and C), then u_0 and [u_0 ; yobs_0]
+    launch_rng_sweep<R>(h, keys, (long long)D * C, C, eps0a, eps0s, u_acc);
+    hipLaunchKernelGGL((k_fs_concat0<R>), dim3((unsigned)((C * P + 255) / 256)), dim3(256), 0, h->stream, C, D, PO, (const R*)x, (const R*)x_alt, (const int32_t*)sel,
+                       (const R*)eps0a, (R)sqrt(0.5 * delta), dptr, cv(*yobs), u, ysc0);
+    FusedHost f{};
+    auxssm_lgssm gc = *model;
+    gc.Hs = auxssm_arr{Hc, 0, (int64_t)P * D, 0};
+    gc.Rs = auxssm_arr{Rc, 0, (int64_t)P * P, 0};
+    gc.cs = auxssm_arr{cc, 0, (int64_t)P, 0};
+    const auxssm_arr ysc_dummy{ysc0, (int64_t)P, (int64_t)P, 0};
+    auxssm_dims dc = *dims;
+    dc.dy = P;
+    dc.B = 1;
+    fill_filter_args(f.fa, &dc, &gc, &ysc_dummy, m0p, Ps);
+    const KDims k1{C, 1, 1};
+    f.fa.ys = cm_arr(ysc0, k1, P);
+    f.fa.ms = cm_arr(m0p, k1, D);
+    f.fa.Ps = Arr{Ps, 0, (long long)D * D, 0, 1};
+    f.fa.lay.cm = 1;
+    f.fa.pblk = D;
+    f.fa.aux_on = 1;
+    f.fa.aux_yobs = cv(*yobs);
+    f.fa.aux_shd = sqrt(0.5 * delta);
+    f.fa.dptr = dptr;
+    f.sa.d = kd;
+    f.sa.dx = D;
+    f.sa.Fs = cv(model->Fs); f.sa.Qs = cv(model->Qs); f.sa.bs = cv(model->bs);
+    f.sa.Ps = f.fa.Ps;
+    f.sa.ps_shared = 1;
+    f.sa.elem = nullptr;
+    f.sa.lay = ScanLayout{1, 1, 1, 1, 1, C};
+    SweepLogpdfArgs& la = f.la;
+    la.d = kd;
+    la.dx = D; la.po = PO;
+    la.m0 = cv(model->m0); la.P0 = cv(model->P0); la.Fs = cv(model->Fs); la.Qs = cv(model->Qs); la.bs = cv(model->bs);
+    la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
+    la.x = cm_arr(x, kd, D); la.xp = cm_arr(x_alt, kd, D); la.u = cm_arr(u, kd, D);
+    la.delta = delta; la.nan_policy = nan_policy; la.u_fly = 0; la.shd = sqrt(0.5 * delta); la.dptr = dptr;
+    f.xa = x; f.xb = x_alt; f.sel = sel; f.u = u; f.inc = inc; f.keys = keys; f.eps0s = eps0s; f.u_acc = u_acc; f.accepted = accepted; f.logs = logs;
+    if ((rc = sl->fused(h, f))) return rc;
+    if (!sel) {  // plain state: x' sits in x_alt, the usual select moves the accepted chains
+        if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, cm_arr(x_alt, kd, D), cm_arr(x, kd, D), 1))) return rc;
+    }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
 // ---- stochastic-volatility device factories (examples/stochastic_volatility/auxiliary_kalman.py:22-48, model.py:56-82) ----------
 // potential log g_t(x) = sum_k log N(y_k; 0, exp(x_k)); grad_k = (y_k^2 e^{-x_k} - 1) / 2, hess_kk = -y_k^2 e^{-x_k} / 2.
 //   first order  (:28-35): ys = u + delta/2 grad(x_lin),                      H = I, R = delta/2 I,  c = 0
@@ -1639,6 +1780,62 @@ int auxssm_kalman_sweep_keyed(auxssm_handle h, int dtype, int model_kind, const 
     }
     return kalman_sweep_impl(h, dtype, model_kind, dims, model, yobs, delta_dev ? 1.0 : delta, delta_dev, keys, parallel, nan_policy, layout, x, eps_aux,
                              eps_samp, u_acc, accepted, logs);
+}
+
+int auxssm_kalman_sweep_fused(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs, double delta,
+                              const void* delta_dev, const uint32_t* keys, int parallel, int nan_policy, int layout, void* x, void* x_alt, int32_t* sel, void* u_acc,
+                              int32_t* accepted, void* logs) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, true))) return rc;
+    if (model_kind != AUXSSM_KMODEL_LG_CONCAT) {
+        set_error("auxssm_kalman_sweep_fused runs AUXSSM_KMODEL_LG_CONCAT (model_kind %d: use auxssm_kalman_sweep_keyed)", model_kind);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    if ((rc = check_lgssm(model, dims->T))) return rc;
+    if (dims->B != 1 || !(delta_dev || delta > 0) || !keys || !yobs || !yobs->ptr || !x || !x_alt || !u_acc || !accepted ||
+        (nan_policy != AUXSSM_NAN_REFERENCE && nan_policy != AUXSSM_NAN_MASKED)) {
+        set_error("auxssm_kalman_sweep_fused: B must be 1, delta > 0 (or delta_dev), keys / yobs / x / x_alt / u_acc / accepted non-NULL, nan_policy 0 or 1");
+        return AUXSSM_ERR_ARG;
+    }
+    if (yobs->sc != 0 || model->Hs.sc != 0 || model->Rs.sc != 0 || model->cs.sc != 0) {
+        set_error("yobs and the observation model (Hs, Rs, cs) are shared by the chains of a sweep: their chain strides must be 0");
+        return AUXSSM_ERR_ARG;
+    }
+    if (const char* why = fused_refusal(h, dims, model, parallel, layout)) {  // (nothing has been enqueued: the caller runs auxssm_kalman_sweep_keyed instead)
+        set_error("auxssm_kalman_sweep_fused: %s", why);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    const double* dptr = nullptr;
+    if (delta_dev) {
+        if (!h->dblock) AX_HIP(hipMalloc((void**)&h->dblock, 2 * sizeof(double)));
+        if (dtype == AUXSSM_F32) hipLaunchKernelGGL((k_delta_block<float>), dim3(1), dim3(1), 0, h->stream, (const float*)delta_dev, h->dblock);
+        else hipLaunchKernelGGL((k_delta_block<double>), dim3(1), dim3(1), 0, h->stream, (const double*)delta_dev, h->dblock);
+        dptr = h->dblock;
+    }
+    const double dl = delta_dev ? 1.0 : delta;
+    return dtype == AUXSSM_F32 ? sweep_lg_concat_fused<float>(h, dtype, dims, model, yobs, dl, dptr, keys, nan_policy, x, x_alt, sel, u_acc, accepted, logs)
+                               : sweep_lg_concat_fused<double>(h, dtype, dims, model, yobs, dl, dptr, keys, nan_policy, x, x_alt, sel, u_acc, accepted, logs);
+}
+int auxssm_kalman_state_resolve(auxssm_handle h, int dtype, const auxssm_dims* dims, void* x, const void* x_alt, int32_t* sel) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, false))) return rc;
+    if (!x || !x_alt || !sel) {
+        set_error("x, x_alt and sel must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    const long long rows = (long long)dims->T * dims->dx;
+    const int C = dims->C;
+    if (rows > 0x7fffffffLL || (C + 255) / 256 > 65535) {
+        set_error("state too large for one resolve launch");
+        return AUXSSM_ERR_ARG;
+    }
+    if (dtype == AUXSSM_F32) hipLaunchKernelGGL((k_fs_resolve<float>), dim3((unsigned)rows, (unsigned)((C + 255) / 256)), dim3(256), 0, h->stream, C, (const int32_t*)sel, (const float*)x_alt, (float*)x);
+    else hipLaunchKernelGGL((k_fs_resolve<double>), dim3((unsigned)rows, (unsigned)((C + 255) / 256)), dim3(256), 0, h->stream, C, (const int32_t*)sel, (const double*)x_alt, (double*)x);
+    AX_HIP(hipMemsetAsync(sel, 0, (size_t)C * sizeof(int32_t), h->stream));
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
 }
 
 static int rng_fill(auxssm_handle h, int dtype, bool normal, uint32_t k0, uint32_t k1, uint32_t stream, int64_t n, void* out) {

@@ -160,10 +160,30 @@ struct KalmanEntry {
 };
 typedef int (*sweep_logpdf_fn)(auxssm_ctx*, const SweepLogpdfArgs&, void* out /*[5][C]*/);
 typedef size_t (*sweep_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);
+// host-side description of one fused chain-shared sweep (fused_shared.h::run_fused_shared; built by api.hip)
+struct FusedHost {
+    FilterArgs fa;        // the concatenated model; ys = row 0 of [u_0 ; yobs_0] (chain-minor, one row), ms = the (D, C) slot of the t = 0 mean, Ps shared
+    SampleArgs sa;        // Fs, Qs, bs, Ps (shared)
+    SweepLogpdfArgs la;   // the real observation model, yobs, u (row 0 is read), delta / shd / dptr / nan_policy
+    const void* xa;
+    void* xb;
+    int32_t* sel;         // null: xa is the state, xb receives the proposals
+    void* u;
+    void* inc;
+    const uint32_t* keys;  // {aux0, aux1, samp0, samp1, acc0, acc1}
+    const void* eps0s;     // row 0 of eps_samp
+    const void* u_acc;
+    int32_t* accepted;
+    void* logs;
+};
+typedef int (*fused_fn)(auxssm_ctx*, FusedHost&);
+typedef size_t (*fused_ws_fn)(const auxssm_ctx*, const KDims&);
 struct SweepLogpdfEntry {
     sweep_logpdf_fn run;
     sweep_logpdf_ws_fn ws;
     sweep_logpdf_fn lorenz = nullptr;  // the Lorenz-63 sweep's fused pass (dx = 3 units only); same workspace as `run`
+    fused_fn fused = nullptr;          // the chain-shared LG_CONCAT sweep in three streaming passes (fused_shared.h); null in the wide-state entry
+    fused_ws_fn fused_ws = nullptr;
 };
 typedef int (*sv_logpdf_fn)(auxssm_ctx*, const SvLogpdfArgs&, void* out /*[5][C]*/);
 typedef size_t (*sv_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);

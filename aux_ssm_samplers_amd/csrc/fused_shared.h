@@ -1,0 +1,535 @@
+// fused_shared.h -- the chain-shared LG_CONCAT sweep in three streaming passes (round 3; included at the end of kernels.hip.h).
+//
+// What the chain-shared sweep of affine_shared.h moved per chain and time step (reals of d components; 8.06 GB at C2 / 256 chains, fp64):
+//   filter reduce  r x, w eps_aux | filter down r x, r eps_aux, w ms | sampler reduce r ms, w eps_samp | sampler down r ms, r eps_samp, w x'
+//   log-density r x, r x', r eps_aux | select r x', w x                                                  = 15 d
+// Here (7 d = 3.76 GB):
+//   A  (k_fs_a)  r x            w u      filter fold of the chunk; draws eps_aux, u = x + sqrt(delta/2) eps; the MH terms of the CURRENT state x
+//                                         (prior, observation, auxiliary: kalman/generic.py:88-89, :103-105) where x and eps are in registers
+//   C  (k_fs_c)  r u            w inc    filter walk (means, log-likelihood increments: filtering.py:55-62) AND, in the same ascending walk, the
+//                                         sampler's increments inc_t = M1_t m_t - gb_t + Lc_t eps_t (sampling.py:108-112; draws eps_samp) together with
+//                                         the sampler's chunk aggregate e = sum_t (G_ta ... G_{t-1}) inc_t -- the composition of the reverse affine maps
+//                                         x_t = G_t x_{t+1} + inc_t (sampling.py:51-55) accumulated FORWARD in time against a chain-shared table of the
+//                                         within-chunk prefix products of the gains (k_fs_gpre), so the filtered means never go to memory
+//   E  (k_fs_e)  r inc, r u     w x'     sampler walk (descending), the MH terms of the PROPOSAL x' where it is in registers
+// plus the two aggregate scans (k_aff_aggs, unchanged), one lane per chain for the t = 0 terms (k_fs_head) and the accept step (k_fs_accept).
+// There is no select pass: with a `sel` array the state is LAZY -- chain c lives in buffer sel[c] of a ping-pong pair, reads its x from there, writes
+// its proposal to the other buffer, and acceptance flips sel[c] (auxssm_kalman_sweep_lazy); without one, x' goes to a scratch buffer and the
+// caller runs the usual select.  Same tables as affine_shared.h / kalman_bodies.h (GainRow, SampShared, LogShared), same per-term arithmetic and NaN
+// policy as FilterMeanOp / SampleAffOp / body_sweep_logpdf_shared; the per-chain totals are summed per (chain, chunk) lane and then over chunks, so
+// they agree with the unfused path to rounding, not bitwise (tests/test_gpu_fused.py: 1e-9 relative on x', 1e-7 absolute on log alpha at C2 size).
+#pragma once
+// (included inside namespace ax by kernels.hip.h)
+
+struct FusedArgs {
+    int C, T, E, nchunk;
+    const void* xa;      // (T, D, C) chain-minor; chain c reads its state from xa (sel null or sel[c] == 0) or xb,
+    void* xb;            //                         and writes its proposal to the other one
+    const int32_t* sel;
+    void* u;             // (T, D, C): row 0 written by the caller, rows >= 1 by k_fs_a
+    void* inc;           // (T, D, C)
+    const void* gain;    // n rows GainRow<R, D, P>      (transition i -> i + 1)
+    const void* samp;    // T rows SampShared<R, D>
+    const void* logt;    // n rows LogShared<R, D, PO>
+    const void* gpre;    // T rows D*D: product of the sampler gains of the chunk's earlier steps, G_ta ... G_{t-1} (I at the chunk's first step)
+    const void* m0p;     // (D, C): filtered mean at t = 0
+    void* agg_f; void* pre_f; void* agg_s; void* pre_s;  // chunk aggregates / exclusive prefixes of the two scans (k_aff_aggs layout)
+    Acc* pa;             // (3, C, nchunk): sums over the chunk of [q(x | u) terms, target(x) terms, |x - u|^2 / delta]
+    Acc* pe;             // (3, C, nchunk): the same of x'
+    void* pell;          // (C, nchunk) log-likelihood increments (R)
+    unsigned ka0, ka1, ks0, ks1;  // keys of eps_aux / eps_samp (stream 0 of auxssm_rng_normal at the (T, D, C) flat index)
+    const void* eps0s;   // (D, C): row 0 of eps_samp (fill kernel)
+    double delta, shd;
+    const double* dptr;  // device-resident {delta, sqrt(delta / 2)} or null
+    int nan_policy;
+};
+AX_HD void fs_resolve(FusedArgs& a) {
+    const double* p = a.dptr;
+    a.dptr = nullptr;
+    if (p) a.delta = p[0], a.shd = p[1];
+}
+
+// the chunk [ch E, (ch + 1) E) of time steps and the (chain, chunk) lane: same block-id swizzle as the affine passes
+__device__ __forceinline__ bool fs_decode(const FusedArgs& a, int& ch, int& s) { return decode_aff(a.C, a.nchunk, ch, s); }
+
+// ---- model stage: chunk products of the filter's matrices; within-chunk prefix products + chunk products of the sampler's gains ------------
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_fs_fprod(FusedArgs a, R* __restrict__ cprod) {
+    using TG = GainRow<R, D, P>;
+    const int ch = blockIdx.x * TB_CM + threadIdx.x;
+    if (ch >= a.nchunk) return;
+    const int ta = max(1, ch * a.E), tb = min(a.T, (ch + 1) * a.E);
+    R M[D * D];
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) M[k] = (k / D == k % D) ? (R)1 : (R)0;
+    for (int t = ta; t < tb; ++t) {
+        const R* row = (const R*)a.gain + (long long)(t - 1) * TG::NPAD;
+        R G[D * D], o[D * D];
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) G[k] = row[TG::oM + k];
+        mm<R, D, D, D>(G, M, o);
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) M[k] = o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) cprod[(long long)ch * D * D + k] = M[k];
+}
+template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_gpre(FusedArgs a, R* __restrict__ gpre, R* __restrict__ cprod) {
+    using TS = SampShared<R, D>;
+    const int ch = blockIdx.x * TB_CM + threadIdx.x;
+    if (ch >= a.nchunk) return;
+    const int ta = ch * a.E, tb = min(a.T, (ch + 1) * a.E);
+    R M[D * D];
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) M[k] = (k / D == k % D) ? (R)1 : (R)0;
+    for (int t = ta; t < tb; ++t) {
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) gpre[(long long)t * D * D + k] = M[k];
+        const R* row = (const R*)a.samp + (long long)t * TS::NPAD;
+        R G[D * D], o[D * D];
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) G[k] = row[TS::oG + k];
+        mm<R, D, D, D>(M, G, o);  // (G_ta ... G_{t-1}) G_t
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) M[k] = o[k];
+    }
+    // scan position of the sampler = reversed time: chunk ch is aggregate nchunk - 1 - ch
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) cprod[(long long)(a.nchunk - 1 - ch) * D * D + k] = M[k];
+}
+
+// the MH terms of one state v at time t = i + 1 given the state w at time t - 1 (v, w = x or x'), LogShared row i -- the per-state half of
+// body_sweep_logpdf_shared, same operations: returns [q-term (concatenated likelihood + prior), target term (likelihood + prior), |v - u|^2 / delta]
+template <typename R, int D, int PO>
+__device__ __forceinline__ void fs_terms(const FusedArgs& a, UniformRow<R> row, const R* v, const R* w, const R* u, R inv_delta, R cst, R* out3) {
+    using TL = LogShared<R, D, PO>;
+    R ob;
+    bool badobs = false;
+    {
+        R q = 0;
+#pragma unroll
+        for (int k = 0; k < PO; ++k) {
+            R z = row[TL::oYw + k];
+#pragma unroll
+            for (int j = 0; j < D; ++j) z -= row[TL::oWH + k * D + j] * v[j];
+            badobs = badobs || !finite_(z);
+            q += z * z;
+        }
+        ob = (R)-0.5 * q + row[TL::oCR];
+        if (badobs || isnan_(ob)) ob = 0;
+    }
+    R ax, qa = 0;
+    bool b = false;
+    {
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const R d = u[k] - v[k];
+            b = b || !finite_(d);
+            qa += d * d;
+        }
+        ax = b ? (R)0 : -qa * inv_delta + cst;
+    }
+    const R cc = (a.nan_policy == 0 && (b || badobs)) ? (R)0 : ax + ob;
+    R pr;
+    {
+        R q = 0;
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            R z = -row[TL::oWb + k];
+#pragma unroll
+            for (int l = 0; l <= k; ++l) z += row[TL::oWQ + lidx(k, l)] * v[l];
+#pragma unroll
+            for (int j = 0; j < D; ++j) z -= row[TL::oWF + k * D + j] * w[j];
+            bad = bad || !finite_(z);
+            q += z * z;
+        }
+        pr = (R)-0.5 * q + row[TL::oCQ];
+        if (bad || isnan_(pr)) pr = 0;
+    }
+    out3[0] = cc + pr;
+    out3[1] = ob + pr;
+    out3[2] = qa * inv_delta;
+}
+
+// ---- pass A ---------------------------------------------------------------------------------------------------------------------------
+template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_fs_a(FusedArgs a) {
+    constexpr int P = D + PO;
+    using TG = GainRow<R, D, P>;
+    using TL = LogShared<R, D, PO>;
+    fs_resolve(a);
+    int ch, s;
+    if (!fs_decode(a, ch, s)) return;
+    const long long C = a.C;
+    const int ta = max(1, ch * a.E), tb = min(a.T, (ch + 1) * a.E);
+    const R* xr = (const R*)((a.sel && a.sel[s]) ? (const void*)a.xb : a.xa) + s;
+    R* up = (R*)a.u + s;
+    R h[D], xq[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        h[k] = ch == 0 ? ((const R*)a.m0p)[k * C + s] : (R)0;
+        xq[k] = xr[((long long)(ta - 1) * D + k) * C];
+    }
+    const R shd = (R)a.shd, inv_delta = (R)1 / (R)a.delta;
+    const R cst = (R)-0.5 * (R)D * log_((R)(0.5 * a.delta)) - (R)(0.5 * LOG_2PI) * (R)D;
+    Acc v0 = 0, v1 = 0, v2 = 0;
+#pragma unroll 1
+    for (int t = ta; t < tb; ++t) {
+        const int tu = opaque_uniform(t);
+        R x[D], ev[D], u[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) x[k] = xr[((long long)tu * D + k) * C];
+        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + s, C, ev);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            u[k] = x[k] + shd * ev[k];
+            up[((long long)tu * D + k) * C] = u[k];
+        }
+        {  // filter fold (FilterMeanOp::fold, folded rows): h <- Mb h + kc + K[:, :D] u
+            const UniformRow<R> row = uniform_row<R>((const R*)a.gain + (long long)(tu - 1) * TG::NPAD);
+            R o[D];
+#pragma unroll
+            for (int r = 0; r < D; ++r) {
+                R v = row[TG::oKc + r];
+#pragma unroll
+                for (int k = 0; k < D; ++k) v += row[TG::oM + r * D + k] * h[k];
+#pragma unroll
+                for (int k = 0; k < D; ++k) v += row[TG::oK + r * P + k] * (finite_(u[k]) ? u[k] : (R)0);
+                o[r] = v;
+            }
+#pragma unroll
+            for (int r = 0; r < D; ++r) h[r] = o[r];
+        }
+        {
+            const UniformRow<R> row = uniform_row<R>((const R*)a.logt + (long long)(tu - 1) * TL::NPAD);
+            R w[3];
+            fs_terms<R, D, PO>(a, row, x, xq, u, inv_delta, cst, w);
+            v0 += (Acc)w[0];
+            v1 += (Acc)w[1];
+            v2 += (Acc)w[2];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) xq[k] = x[k];
+    }
+    stv<R, D>((R*)a.agg_f + ((long long)s * a.nchunk + ch) * SampPre<R, D>::NPAD, h);
+    a.pa[((long long)0 * C + s) * a.nchunk + ch] = v0;
+    a.pa[((long long)1 * C + s) * a.nchunk + ch] = v1;
+    a.pa[((long long)2 * C + s) * a.nchunk + ch] = v2;
+}
+
+// ---- pass C ---------------------------------------------------------------------------------------------------------------------------
+template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_fs_c(FusedArgs a) {
+    constexpr int P = D + PO;
+    using TG = GainRow<R, D, P>;
+    using TS = SampShared<R, D>;
+    fs_resolve(a);
+    int ch, s;
+    if (!fs_decode(a, ch, s)) return;
+    const long long C = a.C;
+    const int t0 = ch * a.E, ta = max(1, t0), tb = min(a.T, t0 + a.E);
+    const R* up = (const R*)a.u + s;
+    R* ip = (R*)a.inc + s;
+    R m[D], es[D];
+    if (ch == 0) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) m[k] = ((const R*)a.m0p)[k * C + s];
+    } else {
+        ldv<R, D>((const R*)a.pre_f + ((long long)s * a.nchunk + ch) * SampPre<R, D>::NPAD, m);
+    }
+#pragma unroll
+    for (int k = 0; k < D; ++k) es[k] = 0;
+    // one sampler increment: inc = M1 m - gb + Lc eps (SampleAffOp::step without the G h term), stored, and folded into the chunk aggregate
+    auto emit = [&](int tu, const R* eps) {
+        const UniformRow<R> row = uniform_row<R>((const R*)a.samp + (long long)tu * TS::NPAD);
+        const UniformRow<R> gp = uniform_row<R>((const R*)a.gpre + (long long)tu * D * D);
+        R inc[D];
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R v = -row[TS::oGb + i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += row[TS::oM + i * D + k] * m[k];
+#pragma unroll
+            for (int k = 0; k <= i; ++k) v += row[TS::oL + i * D + k] * eps[k];
+            inc[i] = v;
+            ip[((long long)tu * D + i) * C] = v;
+        }
+#pragma unroll
+        for (int i = 0; i < D; ++i) {
+            R v = es[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += gp[i * D + k] * inc[k];
+            es[i] = v;
+        }
+    };
+    if (ch == 0) {  // t = 0: the mean of k_filter_t0, the noise row of the fill kernel
+        R eps[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) eps[k] = ((const R*)a.eps0s)[k * C + s];
+        emit(0, eps);
+    }
+    R acc = 0;
+#pragma unroll 1
+    for (int t = ta; t < tb; ++t) {
+        const int tu = opaque_uniform(t);
+        R y[D], eps[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) y[k] = up[((long long)tu * D + k) * C];
+        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + s, C, eps);
+        {  // FilterMeanOp::walk_impl<true>: innovation against the incoming mean, then the affine step
+            const UniformRow<R> row = uniform_row<R>((const R*)a.gain + (long long)(tu - 1) * TG::NPAD);
+            R r[P], o[D];
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                R v = row[TG::oYm + k];
+#pragma unroll
+                for (int j = 0; j < D; ++j) v += row[TG::oHF + k * D + j] * m[j];
+                if (k < D) {
+                    const bool fin = finite_(y[k < D ? k : 0]);
+                    y[k < D ? k : 0] = fin ? y[k < D ? k : 0] : (R)0;
+                    r[k] = fin ? y[k < D ? k : 0] - v : (R)0;
+                } else {
+                    r[k] = -v;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                R v = row[TG::oKc + k];
+#pragma unroll
+                for (int j = 0; j < D; ++j) v += row[TG::oM + k * D + j] * m[j];
+#pragma unroll
+                for (int l = 0; l < D; ++l) v += row[TG::oK + k * P + l] * y[l];
+                o[k] = v;
+            }
+            R q = 0;
+#pragma unroll
+            for (int k = 0; k < P; ++k) {
+                R sk = 0;
+#pragma unroll
+                for (int l = 0; l < P; ++l) sk += row[TG::oSi + sidx(P, k, l)] * r[l];
+                q += r[k] * sk;
+            }
+            const R incl = (R)-0.5 * q + row[TG::oC0];
+            acc += isnan_(incl) ? (R)0 : incl;  // nansum (filtering.py:62)
+#pragma unroll
+            for (int k = 0; k < D; ++k) m[k] = o[k];
+        }
+        emit(tu, eps);
+    }
+    stv<R, D>((R*)a.agg_s + ((long long)s * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, es);
+    ((R*)a.pell)[(long long)s * a.nchunk + ch] = acc;
+}
+
+// ---- pass E ---------------------------------------------------------------------------------------------------------------------------
+template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_fs_e(FusedArgs a) {
+    using TS = SampShared<R, D>;
+    using TL = LogShared<R, D, PO>;
+    fs_resolve(a);
+    int ch, s;
+    if (!fs_decode(a, ch, s)) return;
+    const long long C = a.C;
+    const int t0 = ch * a.E, tb = min(a.T, t0 + a.E);
+    R* xw = (R*)((a.sel && a.sel[s]) ? const_cast<void*>(a.xa) : a.xb) + s;
+    const R* up = (const R*)a.u + s;
+    const R* ip = (const R*)a.inc + s;
+    R h[D], uq[D];
+    if (ch == a.nchunk - 1) {
+#pragma unroll
+        for (int k = 0; k < D; ++k) h[k] = 0, uq[k] = 0;  // G_{T-1} = 0: the first position ignores the incoming state
+    } else {
+        ldv<R, D>((const R*)a.pre_s + ((long long)s * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, h);  // x'_{tb}
+#pragma unroll
+        for (int k = 0; k < D; ++k) uq[k] = up[((long long)tb * D + k) * C];
+    }
+    const R inv_delta = (R)1 / (R)a.delta;
+    const R cst = (R)-0.5 * (R)D * log_((R)(0.5 * a.delta)) - (R)(0.5 * LOG_2PI) * (R)D;
+    Acc v0 = 0, v1 = 0, v2 = 0;
+#pragma unroll 1
+    for (int t = tb - 1; t >= t0; --t) {
+        const int tu = opaque_uniform(t);
+        R inc[D], ut[D], xp[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) inc[k] = ip[((long long)tu * D + k) * C], ut[k] = up[((long long)tu * D + k) * C];
+        {
+            const UniformRow<R> row = uniform_row<R>((const R*)a.samp + (long long)tu * TS::NPAD);
+#pragma unroll
+            for (int i = 0; i < D; ++i) {
+                R v = inc[i];
+#pragma unroll
+                for (int k = 0; k < D; ++k) v += row[TS::oG + i * D + k] * h[k];
+                xp[i] = v;
+                xw[((long long)tu * D + i) * C] = v;
+            }
+        }
+        if (tu + 1 < a.T) {  // (wave-uniform) LogShared row tu: x'_{tu+1} = h given x'_tu = xp, observation and auxiliary terms at tu + 1
+            const UniformRow<R> row = uniform_row<R>((const R*)a.logt + (long long)tu * TL::NPAD);
+            R w[3];
+            fs_terms<R, D, PO>(a, row, h, xp, uq, inv_delta, cst, w);
+            v0 += (Acc)w[0];
+            v1 += (Acc)w[1];
+            v2 += (Acc)w[2];
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) h[k] = xp[k], uq[k] = ut[k];
+    }
+    a.pe[((long long)0 * C + s) * a.nchunk + ch] = v0;
+    a.pe[((long long)1 * C + s) * a.nchunk + ch] = v1;
+    a.pe[((long long)2 * C + s) * a.nchunk + ch] = v2;
+}
+
+// ---- t = 0 terms (one lane per chain): body_sweep_logpdf_head on the lane's own pair of buffers -----------------------------------------------
+template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_ELEM) k_fs_head(SweepLogpdfArgs la, const void* xa, const void* xb, const int32_t* sel, R* __restrict__ head5) {
+    resolve_step(la);
+    const int c = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (c >= la.d.C) return;
+    const bool sw = sel && sel[c];
+    la.x.ptr = sw ? xb : xa;
+    la.xp.ptr = sw ? xa : xb;
+    R h5[5];
+    body_sweep_logpdf_head<R, D, PO>(la, c, h5);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) head5[(long long)k * la.d.C + c] = h5[k];
+}
+
+// ---- accept (generic.py:70-73, 98-106): one workgroup per chain sums its chunks' partial totals in a fixed order, forms log alpha in Acc
+// exactly as k_accept does, draws the Bernoulli and -- lazy state -- flips the chain's buffer selector ------------------------------------------
+template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(FusedArgs a, const R* __restrict__ head5, const R* __restrict__ ell0,
+                                                                            const R* __restrict__ u_acc, int32_t* __restrict__ accepted, R* __restrict__ logs,
+                                                                            int32_t* __restrict__ sel) {
+    __shared__ Acc sh[TB_ELEM];
+    const int c = blockIdx.x;
+    const long long C = a.C;
+    Acc tot[7];
+#pragma unroll
+    for (int k = 0; k < 7; ++k) {
+        Acc v = 0;
+        if (k < 6) {
+            const Acc* p = (k < 3 ? a.pa + ((long long)k * C + c) * a.nchunk : a.pe + ((long long)(k - 3) * C + c) * a.nchunk);
+            for (int j = threadIdx.x; j < a.nchunk; j += TB_ELEM) v += p[j];
+        } else {
+            const R* p = (const R*)a.pell + (long long)c * a.nchunk;
+            for (int j = threadIdx.x; j < a.nchunk; j += TB_ELEM) v += (Acc)p[j];
+        }
+        tot[k] = block_sum<Acc, TB_ELEM>(v, sh);
+        __syncthreads();
+    }
+    if (threadIdx.x != 0) return;
+    const Acc ell = (Acc)ell0[c] + tot[6];
+    const Acc jp_prop = tot[3] + (Acc)head5[0 * C + c], jp_rev = tot[0] + (Acc)head5[1 * C + c];
+    const Acc lt_prop = tot[4] + (Acc)head5[2 * C + c], lt_rev = tot[1] + (Acc)head5[3 * C + c];
+    const Acc corr = (tot[5] - tot[2]) + (Acc)head5[4 * C + c];
+    const Acc lp_prop = jp_prop - ell, lp_rev = jp_rev - ell;
+    Acc la = lt_prop - lt_rev;
+    la += lp_rev - lp_prop;
+    la -= corr;
+    const Acc alpha = exp_(min_(la, (Acc)0));
+    const int acc = ((Acc)u_acc[c] < alpha) ? 1 : 0;  // NaN alpha -> reject, as jax.random.bernoulli(key, nan)
+    accepted[c] = acc;
+    if (sel) sel[c] ^= acc;
+    if (logs) {
+        logs[c * 5 + 0] = (R)la;
+        logs[c * 5 + 1] = (R)lp_prop;
+        logs[c * 5 + 2] = (R)lp_rev;
+        logs[c * 5 + 3] = (R)lt_prop;
+        logs[c * 5 + 4] = (R)lt_rev;
+    }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------------------------
+inline int fs_chunk_len(const auxssm_ctx* h, int C, int T) {
+    static const int waves = [] { const char* e = getenv("AUXSSM_FS_WAVES"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
+    static const int fixedE = [] { const char* e = getenv("AUXSSM_FS_E"); return e ? atoi(e) : 0; }();
+    if (fixedE >= 2) return fixedE;
+    const long long stiles = (C + TB_CM - 1) / TB_CM;
+    long long want = (long long)h->num_cu * 4 * waves / stiles;
+    if (want < 1) want = 1;
+    long long E = (T + want - 1) / want;
+    if (E < 16) E = 16;
+    return (int)E;
+}
+template <typename R, int D, int PO> size_t fused_ws(const auxssm_ctx* h, const KDims& d) {
+    constexpr int P = D + PO;
+    const int E = fs_chunk_len(h, d.C, d.T), nchunk = (d.T + E - 1) / E;
+    size_t b = 0;
+    b += (size_t)d.C * nchunk * (4 * SampPre<R, D>::NPAD * sizeof(R) + 6 * sizeof(Acc) + sizeof(R)) + 16 * 256;
+    b += (size_t)d.C * (5 + 1 + D) * sizeof(R) + 4 * 256;
+    // model stage (side slab when the stage overlaps, else this one): matrix filter, gain / sampler / log-density tables, chunk products
+    b += filter_ws<R, D, P>(h, KDims{1, d.T, 1}, 1);
+    b += (size_t)d.T * (SampShared<R, D>::NPAD + LogShared<R, D, PO>::NPAD + (size_t)D * D) * sizeof(R) + (size_t)2 * nchunk * D * D * sizeof(R) + 8 * 256;
+    return b;
+}
+template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHost& f) {
+    constexpr int P = D + PO;
+    const int C = f.fa.d.C, T = f.fa.d.T, n = T - 1;
+    FusedArgs a{};
+    a.C = C; a.T = T;
+    a.E = fs_chunk_len(h, C, T);
+    a.nchunk = (T + a.E - 1) / a.E;
+    a.xa = f.xa; a.xb = f.xb; a.sel = f.sel; a.u = f.u; a.inc = f.inc;
+    a.ka0 = f.keys[0]; a.ka1 = f.keys[1]; a.ks0 = f.keys[2]; a.ks1 = f.keys[3];
+    a.eps0s = f.eps0s;
+    a.delta = f.la.delta; a.shd = f.la.shd; a.dptr = f.la.dptr; a.nan_policy = f.la.nan_policy;
+    R* cprod_f;
+    R* cprod_s;
+    {
+        // MODEL STAGE (ctx.h::SideStage when the sweep opened one): everything that reads the model and the step size only
+        {
+            const int rc = build_gain_table<R, D, P>(h, f.fa);
+            if (rc) return rc;
+        }
+        SideScope side(h);
+        f.sa.tab = ws_take(h, (size_t)T * SampShared<R, D>::NPAD * sizeof(R));
+        f.la.tab = ws_take(h, (size_t)n * LogShared<R, D, PO>::NPAD * sizeof(R));
+        R* gpre = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+        cprod_f = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
+        cprod_s = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
+        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s) return AUXSSM_ERR_NOMEM;
+        a.gain = f.fa.tab; a.samp = f.sa.tab; a.logt = f.la.tab; a.gpre = gpre;
+        {
+            ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
+            hipLaunchKernelGGL((k_sample_shared_tab<R, D>), dim3((T + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.sa);
+            hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.la);
+            hipLaunchKernelGGL((k_fs_fprod<R, D, P>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod_f);
+            hipLaunchKernelGGL((k_fs_gpre<R, D>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, gpre, cprod_s);
+        }
+    }
+    {
+        const int rc = side_close(h);
+        if (rc) return rc;
+    }
+    const size_t npre = (size_t)C * a.nchunk * SampPre<R, D>::NPAD * sizeof(R);
+    a.agg_f = ws_take(h, npre); a.pre_f = ws_take(h, npre); a.agg_s = ws_take(h, npre); a.pre_s = ws_take(h, npre);
+    a.pa = (Acc*)ws_take(h, (size_t)3 * C * a.nchunk * sizeof(Acc));
+    a.pe = (Acc*)ws_take(h, (size_t)3 * C * a.nchunk * sizeof(Acc));
+    a.pell = ws_take(h, (size_t)C * a.nchunk * sizeof(R));
+    R* head5 = (R*)ws_take(h, (size_t)5 * C * sizeof(R));
+    f.fa.ell0 = ws_take(h, (size_t)C * sizeof(R));
+    if (!a.agg_f || !a.pre_f || !a.agg_s || !a.pre_s || !a.pa || !a.pe || !a.pell || !head5 || !f.fa.ell0) return AUXSSM_ERR_NOMEM;
+    a.m0p = f.fa.ms.ptr;
+    // t = 0 update of every chain (reads the concatenated model: after the join)
+    f.fa.t0_keep_ps = 1;
+    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((C + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.fa);
+    const unsigned grid = grid_aff(C, a.nchunk);
+    const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
+    {
+        ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+        hipLaunchKernelGGL((k_fs_a<R, D, PO>), dim3(grid), dim3(TB_CM), 0, h->stream, a);
+        hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_f, a.pre_f}, (const R*)cprod_f, a.nchunk);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
+        hipLaunchKernelGGL((k_fs_c<R, D, PO>), dim3(grid), dim3(TB_CM), 0, h->stream, a);
+        hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_s, a.pre_s}, (const R*)cprod_s, a.nchunk);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_LOGPDF);
+        hipLaunchKernelGGL((k_fs_e<R, D, PO>), dim3(grid), dim3(TB_CM), 0, h->stream, a);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_SELECT);
+        hipLaunchKernelGGL((k_fs_head<R, D, PO>), dim3((C + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.la, f.xa, (const void*)f.xb, (const int32_t*)f.sel, head5);
+        hipLaunchKernelGGL((k_fs_accept<R>), dim3(C), dim3(TB_ELEM), 0, h->stream, a, (const R*)head5, (const R*)f.fa.ell0, (const R*)f.u_acc, f.accepted,
+                           (R*)f.logs, f.sel);
+    }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+

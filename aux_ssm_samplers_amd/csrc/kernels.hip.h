@@ -914,60 +914,70 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     return b;
 }
 
-// Chain-shared model parameters (affine_shared.h): the d x d block-affine scan runs once, on one sequence (the matrix filter), the
-// chains carry an affine recursion with chain-shared matrices.  `a` holds the chain-minor views of ys / ms / Ps; ell0 is filled.
-template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterArgs& a, int parallel, void* ell_out) {
-    const int S = a.d.S(), n = a.d.n(), T = a.d.T;
+// the chain-shared half of the filter: the matrix filter on ONE sequence and the gain table derived from it (a.tab).  Inside a sweep that
+// opened a side stage (ctx.h::SideStage) all of it -- launches, scratch and the table -- goes to the side stream and its slab.
+template <typename R, int D, int P> int build_gain_table(auxssm_ctx* h, FilterArgs& a) {
+    const int n = a.d.n(), T = a.d.T;
     // the covariances are chain-independent: the caller lays them out once, (T, D, D) dense with chain stride 0 (ctx.h::chain_shared_mode),
     // and the matrix filter writes them in place; any other layout gets chain 0's slot filled from a scratch copy
     const bool ps_once = a.Ps.sc == 0 && a.Ps.se == 1 && a.Ps.st == (long long)D * D;
-    if (!(a.tab && a.tab_ready)) {
-        // the matrix filter: the parallel filter on ONE sequence, always the parallel plan (its means are not used: the observation
-        // values are the mask carrier's).  Dense (time-minor) layout.  Inside a sweep that opened a side stage (ctx.h::SideStage) all of this block --
-        // launches, scratch and the gain table -- goes to the side stream and its slab; the caller then put Ps there too.
-        SideScope side(h);
-        if (side.on && !ps_once) {
-            set_error("internal: the side stage needs the shared covariance layout");
-            return AUXSSM_ERR_ARG;
-        }
-        R* ms1 = (R*)ws_take(h, (size_t)T * D * sizeof(R));
-        R* Ps1 = ps_once ? const_cast<R*>((const R*)a.Ps.ptr) : (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
-        R* sc1 = (R*)ws_take(h, 4 * sizeof(R));
-        if (!ms1 || !Ps1 || !sc1) return AUXSSM_ERR_NOMEM;
-        ProfScope ps(h, AUXSSM_K_FILTER_TAB);
-        FilterArgs am = a;
-        am.d = KDims{1, T, 1};
-        am.aux_on = 0;
-        am.tab = nullptr;
-        am.pc = nullptr;
-        am.ms = dense_arr(ms1, am.d, D);
-        am.Ps = dense_arr(Ps1, am.d, (long long)D * D);
-        am.ell0 = sc1;
-        am.ellz = sc1 + 1;
-        if (a.aux_on) {
-            R* ym = (R*)ws_take(h, (size_t)T * P * sizeof(R));
-            if (!ym) return AUXSSM_ERR_NOMEM;
-            const long long tot = (long long)T * P;
-            hipLaunchKernelGGL((k_mask_obs<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, a.aux_yobs, ym);
-            am.ys = dense_arr(ym, am.d, P);
-        } else if (a.mask_ys.ptr) {
-            am.ys = a.mask_ys;  // a chain-independent mask carrier
-        } else {
-            am.ys = Arr{a.ys.ptr, 0, a.ys.st, 0, a.ys.se};  // chain 0's observations
-        }
-        am.lay = make_layout(plan_scan(h, 1, n, 1), 0, 1);
-        am.elem = ws_take(h, (size_t)am.lay.total_reals(n, 1, FiltElem<R, D>::NPAD) * sizeof(R));
-        if (!am.elem) return AUXSSM_ERR_NOMEM;
-        hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3(1), dim3(TB_ELEM), 0, h->stream, am);
-        hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(ntiles(n), 1)), dim3(TB_ELEM), 0, h->stream, am);
-        const int rc = run_scan<FilterOp<R, D>>(h, am, 1, n);
+    if (a.tab && a.tab_ready) return AUXSSM_OK;
+    // the matrix filter: the parallel filter on ONE sequence, always the parallel plan (its means are not used: the observation
+    // values are the mask carrier's).  Dense (time-minor) layout.
+    SideScope side(h);
+    if (side.on && !ps_once) {
+        set_error("internal: the side stage needs the shared covariance layout");
+        return AUXSSM_ERR_ARG;
+    }
+    R* ms1 = (R*)ws_take(h, (size_t)T * D * sizeof(R));
+    R* Ps1 = ps_once ? const_cast<R*>((const R*)a.Ps.ptr) : (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+    R* sc1 = (R*)ws_take(h, 4 * sizeof(R));
+    if (!ms1 || !Ps1 || !sc1) return AUXSSM_ERR_NOMEM;
+    ProfScope ps(h, AUXSSM_K_FILTER_TAB);
+    FilterArgs am = a;
+    am.d = KDims{1, T, 1};
+    am.aux_on = 0;
+    am.tab = nullptr;
+    am.pc = nullptr;
+    am.ms = dense_arr(ms1, am.d, D);
+    am.Ps = dense_arr(Ps1, am.d, (long long)D * D);
+    am.ell0 = sc1;
+    am.ellz = sc1 + 1;
+    if (a.aux_on) {
+        R* ym = (R*)ws_take(h, (size_t)T * P * sizeof(R));
+        if (!ym) return AUXSSM_ERR_NOMEM;
+        const long long tot = (long long)T * P;
+        hipLaunchKernelGGL((k_mask_obs<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, a.aux_yobs, ym);
+        am.ys = dense_arr(ym, am.d, P);
+    } else if (a.mask_ys.ptr) {
+        am.ys = a.mask_ys;  // a chain-independent mask carrier
+    } else {
+        am.ys = Arr{a.ys.ptr, 0, a.ys.st, 0, a.ys.se};  // chain 0's observations
+    }
+    am.lay = make_layout(plan_scan(h, 1, n, 1), 0, 1);
+    am.elem = ws_take(h, (size_t)am.lay.total_reals(n, 1, FiltElem<R, D>::NPAD) * sizeof(R));
+    if (!am.elem) return AUXSSM_ERR_NOMEM;
+    hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3(1), dim3(TB_ELEM), 0, h->stream, am);
+    hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(ntiles(n), 1)), dim3(TB_ELEM), 0, h->stream, am);
+    const int rc = run_scan<FilterOp<R, D>>(h, am, 1, n);
+    if (rc) return rc;
+    a.tab = ws_take(h, (size_t)n * GainRow<R, D, P>::NPAD * sizeof(R));
+    if (!a.tab) return AUXSSM_ERR_NOMEM;
+    hipLaunchKernelGGL((k_gain_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a, (const R*)Ps1);
+    if (side.on) h->side.last_tab = a.tab;
+    if (!ps_once)  // chain 0's slot of the caller's buffer (the sampler's table reads that one)
+        hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
+    return AUXSSM_OK;
+}
+
+// Chain-shared model parameters (affine_shared.h): the d x d block-affine scan runs once, on one sequence (the matrix filter), the
+// chains carry an affine recursion with chain-shared matrices.  `a` holds the chain-minor views of ys / ms / Ps; ell0 is filled.
+template <typename R, int D, int P> int run_filter_shared(auxssm_ctx* h, FilterArgs& a, int parallel, void* ell_out) {
+    const int S = a.d.S(), n = a.d.n();
+    const bool ps_once = a.Ps.sc == 0 && a.Ps.se == 1 && a.Ps.st == (long long)D * D;
+    {
+        const int rc = build_gain_table<R, D, P>(h, a);
         if (rc) return rc;
-        a.tab = ws_take(h, (size_t)n * GainRow<R, D, P>::NPAD * sizeof(R));
-        if (!a.tab) return AUXSSM_ERR_NOMEM;
-        hipLaunchKernelGGL((k_gain_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a, (const R*)Ps1);
-        if (side.on) h->side.last_tab = a.tab;
-        if (!ps_once)  // chain 0's slot of the caller's buffer (the sampler's table reads that one)
-            hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
     }
     {
         const int rc = side_close(h);  // (no-op without a side stage) `stream` waits for the model stage before the first kernel that reads its products
@@ -1204,6 +1214,8 @@ template <typename R, int D, int PO> constexpr sweep_logpdf_fn lorenz_logpdf_ent
     else return nullptr;
 }
 
+#include "fused_shared.h"
+
 // one instantiation unit = one (dtype, D): all P for the filter / logpdf, plus the sampler
 #define AX_KALMAN_ENTRY(R, D, P) \
     { &run_filter<R, D, P>, &filter_ws<R, D, P>, &run_logpdf<R, D, P>, &logpdf_ws<R, D, P> }
@@ -1218,10 +1230,10 @@ template <typename R, int D, int PO> constexpr sweep_logpdf_fn lorenz_logpdf_ent
         return (P >= 1 && P <= MAX_P) ? &tab[P - 1] : nullptr;                                       \
     }                                                                                                \
     const SweepLogpdfEntry* sweep_logpdf_unit_##NAME(int PO) {                                       \
-        static const SweepLogpdfEntry tab[4] = {{&run_sweep_logpdf<R, D, 1>, &sweep_logpdf_ws<R, D, 1>, lorenz_logpdf_entry<R, D, 1>()}, \
-                                                {&run_sweep_logpdf<R, D, 2>, &sweep_logpdf_ws<R, D, 2>, lorenz_logpdf_entry<R, D, 2>()}, \
-                                                {&run_sweep_logpdf<R, D, 3>, &sweep_logpdf_ws<R, D, 3>, lorenz_logpdf_entry<R, D, 3>()}, \
-                                                {&run_sweep_logpdf<R, D, 4>, &sweep_logpdf_ws<R, D, 4>, lorenz_logpdf_entry<R, D, 4>()}}; \
+        static const SweepLogpdfEntry tab[4] = {{&run_sweep_logpdf<R, D, 1>, &sweep_logpdf_ws<R, D, 1>, lorenz_logpdf_entry<R, D, 1>(), &run_fused_shared<R, D, 1>, &fused_ws<R, D, 1>}, \
+                                                {&run_sweep_logpdf<R, D, 2>, &sweep_logpdf_ws<R, D, 2>, lorenz_logpdf_entry<R, D, 2>(), &run_fused_shared<R, D, 2>, &fused_ws<R, D, 2>}, \
+                                                {&run_sweep_logpdf<R, D, 3>, &sweep_logpdf_ws<R, D, 3>, lorenz_logpdf_entry<R, D, 3>(), &run_fused_shared<R, D, 3>, &fused_ws<R, D, 3>}, \
+                                                {&run_sweep_logpdf<R, D, 4>, &sweep_logpdf_ws<R, D, 4>, lorenz_logpdf_entry<R, D, 4>(), &run_fused_shared<R, D, 4>, &fused_ws<R, D, 4>}}; \
         return (PO >= 1 && PO <= 4) ? &tab[PO - 1] : nullptr;                                        \
     }                                                                                                \
     const SampleEntry* sample_unit_##NAME() {                                                        \

@@ -104,7 +104,9 @@ class DeviceChains:
     """C chains' trajectories resident in HBM.  With >= 32 chains (or chain_minor=True) the state and the per-sweep noise
     are stored chain-minor, (T, dx, C): the sweep's lanes then run over chains (AUXSSM_LAYOUT_CHAIN_MINOR, include/auxssm.h)."""
 
-    def __init__(self, handle, x, dtype=None, chain_minor=None):
+    def __init__(self, handle, x, dtype=None, chain_minor=None, fused=None):
+        """fused=False: keyed sweeps never take the fused three-pass path (auxssm_kalman_sweep_fused), e.g. to read the drawn noise back from
+        eps_aux / eps_samp afterwards -- the fused sweep has no such buffers."""
         x = np.asarray(x)
         if x.ndim == 2:
             x = x[None]
@@ -120,9 +122,34 @@ class DeviceChains:
         self.accepted = handle.zeros((self.C,), np.int32)
         self.logs = handle.zeros((self.C, 5), self.dtype)
         # per-sweep noise, allocated once: no hipMalloc / hipFree (and no stream sync) inside the sweep loop
-        self.eps_aux = handle.empty(self.x.shape, self.dtype)
-        self.eps_samp = handle.empty(self.x.shape, self.dtype)
+        self._eps_aux = self._eps_samp = None
         self.u_acc = handle.empty((self.C,), self.dtype)
+        # lazy state of the fused chain-shared sweep (auxssm_kalman_sweep_fused): chain c lives in x_alt where sel[c] != 0; allocated on first use
+        self.x_alt = None
+        self.sel = None
+        self.fused = None if fused is None or fused else False  # None: not tried yet; False: refused (by the library or the caller): keyed sweeps
+
+    # per-sweep noise buffers of the unfused sweeps (allocated once, on first use: the fused sweep draws inside its passes and needs none)
+    @property
+    def eps_aux(self):
+        if self._eps_aux is None:
+            self._eps_aux = self.handle.empty(self.x.shape, self.dtype)
+        return self._eps_aux
+
+    @property
+    def eps_samp(self):
+        if self._eps_samp is None:
+            self._eps_samp = self.handle.empty(self.x.shape, self.dtype)
+        return self._eps_samp
+
+    def resolve(self):
+        """gather the lazy state into x (auxssm_kalman_state_resolve): before anything but a fused sweep reads x"""
+        if self.sel is not None and self._lazy_dirty:
+            dims = _lib.Dims(self.C, self.T, 1, self.dx, 0)
+            _lib.check(self.handle.lib.auxssm_kalman_state_resolve(self.handle.h, _lib.dtype_code(self.dtype), C.byref(dims), self.x.ptr, self.x_alt.ptr, self.sel.ptr))
+            self._lazy_dirty = False
+
+    _lazy_dirty = False
 
     def _to_layout(self, a):
         """(C, T, dx) -> the resident layout"""
@@ -131,6 +158,7 @@ class DeviceChains:
 
     def to_host(self):
         """trajectories as (C, T, dx)"""
+        self.resolve()
         return self.stats_to_host(self.x)
 
     def stats_to_host(self, a):
@@ -154,11 +182,35 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
             if dev and (delta.dtype != np.dtype(chains.dtype) or delta.size < 1):
                 raise ValueError("a device-resident delta must be a DeviceArray of one scalar of the chains' dtype")
             k6 = (C.c_uint32 * 6)(*[int(v) for k in keys for v in np.asarray(k, np.uint32).reshape(2)])
+            # chain-shared linear-Gaussian model on chain-minor resident chains: the sweep in three streaming passes on a LAZY state (no select
+            # pass, no noise buffers).  The library refuses -- before enqueueing anything -- what it cannot run fused; keyed sweeps from then on.
+            if chains.fused is not False and eps_aux is None and model.kmodel == _lib.KMODEL_LG_CONCAT and chains.chain_minor:
+                if chains.x_alt is None:
+                    chains.x_alt = handle.empty(chains.x.shape, chains.dtype)
+                    chains.sel = handle.zeros((chains.C,), np.int32)
+                rc = handle.lib.auxssm_kalman_sweep_fused(
+                    handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
+                    1.0 if dev else float(delta), delta.ptr if dev else None, k6, int(bool(parallel)), pol, chains.layout, chains.x.ptr,
+                    chains.x_alt.ptr, chains.sel.ptr, u_acc.ptr, chains.accepted.ptr, chains.logs.ptr)
+                if rc == _lib.ERR_UNSUPPORTED:  # (nothing was enqueued) e.g. AUXSSM_OPT_SHARE_MODEL switched off, moments attached, odd chain count
+                    chains.resolve()
+                    if chains.fused is None:    # never ran fused: stop trying, drop the partner buffer
+                        chains.fused = False
+                        chains.x_alt = chains.sel = None
+                else:
+                    _lib.check(rc)
+                    chains.fused = True
+                    chains._lazy_dirty = True
+                    return
+            chains.resolve()
+            if eps_aux is None:
+                eps_aux, eps_samp = chains.eps_aux, chains.eps_samp
             _lib.check(handle.lib.auxssm_kalman_sweep_keyed(
                 handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
                 1.0 if dev else float(delta), delta.ptr if dev else None, k6, int(bool(parallel)), pol, chains.layout, chains.x.ptr,
                 eps_aux.ptr, eps_samp.ptr, u_acc.ptr, chains.accepted.ptr, chains.logs.ptr))
             return
+        chains.resolve()
         if isinstance(delta, _lib.DeviceArray):  # device-resident step size (one scalar of the chains' dtype): no host round trip
             if delta.dtype != np.dtype(chains.dtype) or delta.size < 1:
                 raise ValueError("a device-resident delta must be a DeviceArray of one scalar of the chains' dtype")
@@ -183,9 +235,9 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         handle = state.x.handle if resident else _lib.default_handle()  # resident chains carry their device
         chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None)
         keys = None
-        if noise is None:  # the keyed sweep: same values as draw() + sweep(), in one call
+        if noise is None:  # the keyed sweep: same values as draw() + sweep(), in one call (eps buffers: taken on demand, the fused sweep has none)
             keys = _random.split(key, 3)
-            eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc
+            eps_aux, eps_samp, u_acc = None, None, chains.u_acc
         else:
             shape = (chains.C, chains.T, chains.dx)
             eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc

@@ -237,6 +237,21 @@ def kalman_group_reals(mode, d, po):
     sym = lambda n: n * (n + 1) // 2
     par = 2 * d * d + d + po * d + po * po + po  # F, Q, b, Hobs, Robs, cobs of one step
     gain = d * d + d + 2 * d * p + p + sym(p) + 1  # one GainRow (affine_shared.h): Mb, kc, K, HF, ym, Si, c0
+    samp = 3 * d * d + d                                           # one SampShared row: G, M1, gb, Lc
+    logrow = sym(d) + d * d + d + 1 + po * d + po + 1               # one LogShared row: WQ, WF, wb, cQ, WH, yw, cR
+    if mode == "fused":
+        # the chain-shared sweep in three streaming passes on a lazy state (csrc/fused_shared.h, auxssm_kalman_sweep_fused): the library's profiler
+        # files pass A (+ the filter's aggregate scan) under filter_scan, pass C (+ the sampler's aggregate scan) under sample_scan, pass E under
+        # logpdf, the t = 0 terms + accept step under select; no noise buffers, no select pass
+        return {
+            "factory": (0, 0, par),
+            "filter_tab": (0, 0, par + gain + d * d),
+            "sample_init": (0, 0, 2 * d * d + d + samp + logrow + d * d),  # sampler / log-density tables, within-chunk gain products
+            "filter_scan": (d, d, gain + logrow),                     # pass A: x in, u out (eps_aux drawn in registers; MH terms of x)
+            "sample_scan": (d, d, gain + samp + d * d),               # pass C: u in, sampler increments out (eps_samp drawn in registers; ell)
+            "logpdf": (2 * d, d, samp + logrow),                      # pass E: increments and u in, x' out (MH terms of x')
+            "select": (0, 0, 0),                                      # t = 0 terms, accept, selector flip: O(C) work
+        }
     if mode == "shared":
         return {
             # keyed sweep (auxssm_kalman_sweep_keyed): the noise is drawn inside the scans' reduce passes; the fill kernel only draws row t = 0 of
@@ -268,7 +283,12 @@ MODEL_STAGE_GROUPS = ("filter_tab", "factory", "sample_init")
 
 
 def model_stage_overlapped(mode):
-    return mode == "shared" and os.environ.get("AUXSSM_OVERLAP_TAB", "1") != "0"
+    return mode in ("shared", "fused") and os.environ.get("AUXSSM_OVERLAP_TAB", "1") != "0"
+
+
+FUSED_PASS_NAMES = {"filter_scan": "pass A: k_fs_a (x -> u, filter fold, MH terms of x) + k_aff_aggs",
+                    "sample_scan": "pass C: k_fs_c (u -> sampler increments, filter walk, ell) + k_aff_aggs",
+                    "logpdf": "pass E: k_fs_e (increments, u -> x', MH terms of x')"}
 
 
 def kalman_rooflines(groups, mode, C, T, d, po, s, steps):
@@ -295,13 +315,14 @@ def kalman_rooflines(groups, mode, C, T, d, po, s, steps):
 def pmc_traffic(key):
     """HBM bytes per launch group measured with the PMC counters (profiles/r02_traffic.json, written from committed rocprofv3 --pmc
     passes by tools/pmc_traffic.py); None when no pass exists for these kernels."""
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json")))
-        ent = tj.get(key)
-        if ent:
-            return ent.get("hbm_bytes"), ent.get("source")
-    except Exception:
-        pass
+    for name in ("r03_traffic.json", "r02_traffic.json"):
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+            ent = tj.get(key)
+            if ent:
+                return ent.get("hbm_bytes"), ent.get("source")
+        except Exception:
+            pass
     return None, None
 
 
@@ -327,23 +348,32 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
     mode_hint = "shared" if share and chains.chain_minor and C > 1 else "general"
     # the roofline kernel of either path is the filter's scan (the parallel-in-time scan north_star names; on the shared path it and the sampler's
     # scan are within a few per cent of each other, the model stage is off the critical path)
-    focus = lambda ps: "filter_scan" if "filter_scan" in ps else max(ps, key=ps.get)
+    def focus(ps):
+        if getattr(chains, "fused", None):  # three streaming passes: the roofline kernel is the longest of them
+            cand = {g: v for g, v in ps.items() if g in FUSED_PASS_NAMES}
+            if cand:
+                return max(cand, key=cand.get)
+        return "filter_scan" if "filter_scan" in ps else max(ps, key=ps.get)
     el, groups = ctx.timed(lambda k: kernel(keys[k], state, delta), steps, warmup, prof=not args.no_prof, focus=focus)
     handle.set_option(_lib.OPT_SHARE_MODEL, 1)
     s = np.dtype(dtype).itemsize
     mode = "shared" if share and chains.chain_minor and C > 1 else "general"
+    if mode == "shared" and getattr(chains, "fused", None):
+        mode = "fused"
     kernels, dom = kalman_rooflines(groups, mode, C, T, d, d, s, steps)
     out = dict(value=C * ctx.world * steps / el, ms_per_step=el / steps * 1e3, kernels=kernels, mode=mode, chains_obj=chains_obj)
     roof = None
     if dom is not None:
         # the general path's roofline kernel is always the filter's associative scan (the d x d block-affine combine north_star names)
         g = "filter_scan" if "filter_scan" in kernels else dom
+        if mode == "fused":
+            g = max((q for q in FUSED_PASS_NAMES if q in kernels), key=lambda q: kernels[q]["ms_per_step"])
         k = kernels[g]
         if k.get("algorithmic_GBps"):
             key = f"kalman_C2_{args.dtype}_T{T}_d{d}_chains{C}_{mode}_{g}"
             traffic, src = pmc_traffic(key)
             roof = dict(bound="hbm", achieved=k["algorithmic_GBps"], peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(k["algorithmic_GBps"] / HBM_PEAK_GBPS, 4),
-                        traffic=traffic, traffic_source=src, kernel=f"{g} ({mode} path)", avg_launch_ms=k["ms_per_step"],
+                        traffic=traffic, traffic_source=src, kernel=(FUSED_PASS_NAMES[g] if mode == "fused" else f"{g} ({mode} path)"), avg_launch_ms=k["ms_per_step"],
                         launches=int(groups[g][0]), algorithmic_bytes_per_launch=k["algorithmic_bytes_per_step"],
                         share_of_step=round(k["ms_per_step"] / (el / steps * 1e3), 3))
             if mode == "general" and g == "filter_scan":
@@ -604,7 +634,7 @@ def main(argv=None):
     chains, kernel = main_leg["chains_obj"]
 
     general = None
-    if share and not args.no_general_leg and not args.no_prof and main_leg["mode"] == "shared":
+    if share and not args.no_general_leg and not args.no_prof and main_leg["mode"] in ("shared", "fused"):
         general = leg_c2(ctx, args, False, max(3, args.steps // 2), 1, chains_obj=main_leg["chains_obj"])
 
     # the trivial chain-gather (RCCL): acceptance flags + last log-alphas of every chain to rank 0
@@ -649,9 +679,10 @@ def main(argv=None):
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"C2: linear-Gaussian SSM T={T} d={d} p={2 * d}, aux-Kalman sweep, parallel scan",
                        "chains_per_gpu": C, "delta": 0.5, "parallelism": f"chains x{world} (independent, no collective)",
-                       "model_sharing": ("chain-shared model parameters hoisted out of the chain loop (jax.vmap semantics)" if main_leg["mode"] == "shared"
-                                         else "off: general per-chain path"),
-                       "model_stage": ("off: one stream" if os.environ.get("AUXSSM_OVERLAP_TAB", "1") == "0" or main_leg["mode"] != "shared" else
+                       "model_sharing": ("chain-shared model parameters hoisted out of the chain loop (jax.vmap semantics)" + ("; the chain passes fused into three "
+                                         "streaming passes on a lazy ping-pong state (auxssm_kalman_sweep_fused)" if main_leg["mode"] == "fused" else "")
+                                         if main_leg["mode"] in ("shared", "fused") else "off: general per-chain path"),
+                       "model_stage": ("off: one stream" if os.environ.get("AUXSSM_OVERLAP_TAB", "1") == "0" or main_leg["mode"] not in ("shared", "fused") else
                                        "the chain-independent stage of a sweep (matrix filter, gain / sampler / log-density tables: the filter_tab, factory and "
                                        "sample_init groups below) runs on a second stream and overlaps the chain passes of the sweep before -- the groups' "
                                        "times therefore add up to more than ms_per_step")},

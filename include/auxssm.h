@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 106
+#define AUXSSM_VERSION 107
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -212,6 +212,23 @@ int auxssm_kalman_sweep_keyed(auxssm_handle h, int dtype, int model_kind, const 
                               const auxssm_lgssm* model, const auxssm_arr* yobs, double delta, const void* delta_dev,
                               const uint32_t* keys, int parallel, int nan_policy, int layout, void* x, void* eps_aux, void* eps_samp,
                               void* u_acc, int32_t* accepted, void* logs);
+
+/* The keyed LG_CONCAT sweep for chain-shared model parameters in THREE streaming passes over the chains (csrc/fused_shared.h): the draws, the
+ * filter, the pathwise sampler and every log-density of the MH ratio (kalman/generic.py:53-106) are folded into a forward pass over x, a forward
+ * pass over the auxiliary variables and a backward pass that emits x' -- 7 instead of 15 reads / writes of a (C, T, dx) array per sweep, no
+ * eps_aux / eps_samp buffers at all.  Same keys -> same draws as auxssm_kalman_sweep_keyed; x' and the five log terms agree with it to rounding
+ * (the per-chain totals are summed in a different order).
+ *   x, x_alt : two (T, dx, C) chain-minor buffers.
+ *   sel == NULL : x is the state (in / out), x_alt scratch for the proposals (accepted chains are copied back by the usual select pass).
+ *   sel != NULL : LAZY state -- chain c's current trajectory is x_alt[:, :, c] if sel[c] != 0 else x[:, :, c]; the sweep reads it from there,
+ *                 writes the proposal to the other buffer and acceptance flips sel[c]: no select pass.  auxssm_kalman_state_resolve gathers the
+ *                 state into x (and zeroes sel) before anything else reads x.
+ * Returns AUXSSM_ERR_UNSUPPORTED -- before enqueueing anything -- when the sweep cannot run fused (other model kinds, dense layout, per-chain
+ * parameters, odd chain count, T < 64, parallel == 0, running moments attached): the caller then runs auxssm_kalman_sweep_keyed. */
+int auxssm_kalman_sweep_fused(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
+                              const auxssm_arr* yobs, double delta, const void* delta_dev, const uint32_t* keys, int parallel, int nan_policy,
+                              int layout, void* x, void* x_alt, int32_t* sel, void* u_acc, int32_t* accepted, void* logs);
+int auxssm_kalman_state_resolve(auxssm_handle h, int dtype, const auxssm_dims* dims, void* x, const void* x_alt, int32_t* sel);
 
 /* ---- conditional SMC (particle Gibbs) sweep ------------------------------------------------------------
  * == kernel(key, state) of aux_samplers._primitives.csmc.get_kernel (csmc.py:16-66: forward pass _csmc :69-107 with

@@ -74,8 +74,8 @@ def test_keyed_sweep_equals_draw_then_sweep(dtype, C, chain_minor, share):
             rng = np.random.default_rng(11)
             x0 = rng.standard_normal((C, T, d)).astype(dtype) * 0.3
             cm = chain_minor and not getattr(model, "dense_only", False)
-            a = DeviceChains(h, x0, chain_minor=cm)
-            b = DeviceChains(h, x0, chain_minor=cm)
+            a = DeviceChains(h, x0, chain_minor=cm, fused=False)  # (the keyed sweep proper: the fused one keeps no noise buffers, tests/test_gpu_fused.py)
+            b = DeviceChains(h, x0, chain_minor=cm, fused=False)
             key = R.PRNGKey(123)
             kernel(key, KalmanSampler(x=a, updated=None), delta)                     # keyed
             k_aux, k_samp, k_acc = R.split(key, 3)
