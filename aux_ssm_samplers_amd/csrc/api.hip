@@ -54,36 +54,42 @@ int side_open(auxssm_ctx* h, size_t need) {
         set_error("internal: side stage opened inside a side scope");
         return AUXSSM_ERR_ARG;
     }
-    if (!s.stream) {
-        // lowest priority: the stage has a whole sweep of slack, the chain passes it overlaps do not
+    constexpr int NS = auxssm_ctx::SideStage::NS;
+    if (!s.streams[0]) {
+        // lowest priority: the stage has whole sweeps of slack, the chain passes it overlaps do not
         int lo = 0, hi = 0;
-        static const bool prio_on = [] { const char* e = getenv("AUXSSM_SIDE_PRIO"); return e ? atoi(e) != 0 : true; }();
+        static const int prio = [] { const char* e = getenv("AUXSSM_SIDE_PRIO"); return e ? atoi(e) : 1; }();  // 0 default priority, 1 lowest, 2 highest
+        const bool prio_on = prio != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess;
         bool ok = true;
-        if (!prio_on || hipDeviceGetStreamPriorityRange(&lo, &hi) != hipSuccess || hipStreamCreateWithPriority(&s.stream, hipStreamNonBlocking, lo) != hipSuccess)
-            ok = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking) == hipSuccess;
-        for (int p = 0; ok && p < 2; ++p)
-            ok = hipEventCreateWithFlags(&s.done[p], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.sweep_end[p], hipEventDisableTiming) == hipSuccess;
+        for (int p = 0; ok && p < NS; ++p) {
+            if (!prio_on || hipStreamCreateWithPriority(&s.streams[p], hipStreamNonBlocking, prio == 2 ? hi : lo) != hipSuccess)
+                ok = hipStreamCreateWithFlags(&s.streams[p], hipStreamNonBlocking) == hipSuccess;
+            ok = ok && hipEventCreateWithFlags(&s.done[p], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.sweep_end[p], hipEventDisableTiming) == hipSuccess &&
+                 hipEventCreateWithFlags(&s.begun[p], hipEventDisableTiming) == hipSuccess;
+        }
         ok = ok && hipEventCreateWithFlags(&s.fence, hipEventDisableTiming) == hipSuccess;
-        if (!ok) {  // no second stream on this device / runtime: the sweeps stay on the one stream (s.open stays false)
+        if (!ok) {  // no further streams on this device / runtime: the sweeps stay on the one stream (s.open stays false)
             (void)hipGetLastError();
-            if (s.stream) (void)hipStreamDestroy(s.stream);
-            s.stream = nullptr;
+            for (int p = 0; p < NS; ++p) {
+                if (s.streams[p]) (void)hipStreamDestroy(s.streams[p]);
+                s.streams[p] = nullptr;
+            }
             h->overlap_model_stage = 0;
             return AUXSSM_OK;
         }
     }
     if (s.open) AX_HIP(hipStreamSynchronize(h->stream));  // a sweep that failed half way never marked its end: no reader may be left behind
     s.open = false;
-    const int p = s.parity ^ 1;
+    const int p = (s.parity + 1) % NS;
     if (need > s.bytes[p]) {  // (first sweeps of a shape only) nobody may still use the old slab
         AX_HIP(hipStreamSynchronize(h->stream));
-        AX_HIP(hipStreamSynchronize(s.stream));
+        for (int q = 0; q < NS; ++q) AX_HIP(hipStreamSynchronize(s.streams[q]));
         if (s.ws[p]) AX_HIP(hipFree(s.ws[p]));
         s.ws[p] = nullptr;
         s.bytes[p] = 0;
         const size_t want = need + need / 8 + (1u << 20);
         hipError_t e = hipMalloc((void**)&s.ws[p], want);
-        if (e != hipSuccess) {  // no room for the second slab: this sweep stays on the one stream
+        if (e != hipSuccess) {  // no room for another slab: this sweep stays on the one stream
             (void)hipGetLastError();
             s.ws[p] = nullptr;
             return AUXSSM_OK;
@@ -91,13 +97,17 @@ int side_open(auxssm_ctx* h, size_t need) {
         s.bytes[p] = want;
         s.end_valid[p] = false;
     }
-    if (s.end_valid[p]) AX_HIP(hipStreamWaitEvent(s.stream, s.sweep_end[p], 0));
+    if (s.end_valid[p]) AX_HIP(hipStreamWaitEvent(s.streams[p], s.sweep_end[p], 0));
     // something other than a staged sweep went through the handle since -- or the caller holds the raw stream and may have queued work on it the
     // library never saw (auxssm_stream): that work comes first
     if (h->api_calls != s.last_call + 1 || h->stream_exposed) {
         AX_HIP(hipEventRecord(s.fence, h->stream));
-        AX_HIP(hipStreamWaitEvent(s.stream, s.fence, 0));
+        AX_HIP(hipStreamWaitEvent(s.streams[p], s.fence, 0));
     }
+    if (s.begun_valid) AX_HIP(hipStreamWaitEvent(s.streams[p], s.begun[s.parity], 0));  // (s.parity: the previous stage's slab)
+    AX_HIP(hipEventRecord(s.begun[p], s.streams[p]));
+    s.begun_valid = true;
+    s.stream = s.streams[p];
     s.last_call = h->api_calls;
     s.parity = p;
     s.off = 0;
@@ -400,7 +410,7 @@ __global__ void k_accept(int C, const Acc* jp_prop, const Acc* jp_rev, const R* 
     Acc la = lt_prop[c] - lt_rev[c];
     la += lp_rev - lp_prop;
     la -= corr[c];
-    const Acc alpha = exp_(min_(la, (Acc)0));
+    const Acc alpha = exp_(la != la ? la : min_(la, (Acc)0));  // jnp.minimum(0, nan) = nan (generic.py:105): a NaN ratio rejects
     accepted[c] = ((Acc)u_acc[c] < alpha) ? 1 : 0;  // NaN alpha -> reject, as jax.random.bernoulli(key, nan)
     if (logs) {
         logs[c * 5 + 0] = (R)la;
@@ -942,7 +952,7 @@ __global__ void k_sv_accept(int C, const R* j1, const R* j2, const R* ell1, cons
     R la = lt_prop - lt_rev;
     la += lp_rev - lp_prop;
     la -= corr;
-    const R alpha = exp_(min_(la, (R)0));
+    const R alpha = exp_(la != la ? la : min_(la, (R)0));  // jnp.minimum(0, nan) = nan (generic.py:105): a NaN ratio rejects
     accepted[c] = (u_acc[c] < alpha) ? 1 : 0;
     if (logs) {
         logs[c * 5 + 0] = la;
@@ -1415,15 +1425,16 @@ int auxssm_destroy(auxssm_handle h) {
     auxssm_prof_disable(h);
     if (h->ws) (void)hipFree(h->ws);
     if (h->dblock) (void)hipFree(h->dblock);
-    if (h->side.stream) {
-        (void)hipStreamSynchronize(h->side.stream);
-        for (int p = 0; p < 2; ++p) {
+    if (h->side.streams[0]) {
+        for (int p = 0; p < auxssm_ctx::SideStage::NS; ++p) {
+            (void)hipStreamSynchronize(h->side.streams[p]);
             if (h->side.ws[p]) (void)hipFree(h->side.ws[p]);
             (void)hipEventDestroy(h->side.done[p]);
             (void)hipEventDestroy(h->side.sweep_end[p]);
+            (void)hipEventDestroy(h->side.begun[p]);
+            (void)hipStreamDestroy(h->side.streams[p]);
         }
         (void)hipEventDestroy(h->side.fence);
-        (void)hipStreamDestroy(h->side.stream);
     }
     (void)hipStreamDestroy(h->stream);
     delete h;

@@ -58,14 +58,21 @@ struct auxssm_ctx {
     // The MODEL STAGE of a chain-shared sweep -- concatenated observation model, matrix filter on one sequence, gain table: ~0.4 ms of short dependent
     // launches that read the model and the step size only, never a chain -- runs on a second stream with its own double-buffered slab, so that the
     // stage of sweep k + 1 overlaps the chain passes of sweep k (api.hip: side_*).  Joined into `stream` before its first consumer.
+    // Round 3: a RING of NS slabs, each with its own stream -- the stage of sweep k + 2 may start as soon as sweep k - 1 has finished with its slab, so a
+    // stage has two sweeps of slack instead of one (beside full-chip passes its dozen short dependent launches take 1.3 ms, as long as the passes of
+    // the fused sweep themselves) and consecutive stages overlap each other.
     struct SideStage {
-        hipStream_t stream = nullptr;
-        hipEvent_t done[2] = {nullptr, nullptr};       // stage of this parity finished (recorded on the side stream)
-        hipEvent_t sweep_end[2] = {nullptr, nullptr};  // last sweep that read this parity's slab finished enqueueing (recorded on `stream`)
-        bool end_valid[2] = {false, false};
-        char* ws[2] = {nullptr, nullptr};
-        size_t bytes[2] = {0, 0};
-        int parity = 0;
+        static constexpr int NS = 3;
+        hipStream_t streams[NS] = {nullptr, nullptr, nullptr};
+        hipStream_t stream = nullptr;                  // streams[parity] of the open stage (null until the first stage)
+        hipEvent_t done[NS] = {nullptr, nullptr, nullptr};       // stage of this slab finished (recorded on its stream)
+        hipEvent_t sweep_end[NS] = {nullptr, nullptr, nullptr};  // last sweep that read this slab finished enqueueing (recorded on `stream` of the handle)
+        hipEvent_t begun[NS] = {nullptr, nullptr, nullptr};      // this slab's stage got past its waits (recorded on its stream): the NEXT stage starts after it,
+        bool begun_valid = false;                                 // so a fence one stage waited for (new data behind a foreign call) orders every later stage too
+        bool end_valid[NS] = {false, false, false};
+        char* ws[NS] = {nullptr, nullptr, nullptr};
+        size_t bytes[NS] = {0, 0, 0};
+        int parity = 0;                                // slab of the open (or last) stage
         bool open = false, inside = false;
         // A stage runs ahead of whatever `stream` still holds.  That is safe behind another sweep (a sweep writes none of a stage's inputs), not
         // behind anything else the caller may have enqueued through the handle (an upload of new parameters, a memset, another kind of call): every

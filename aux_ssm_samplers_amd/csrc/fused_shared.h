@@ -97,10 +97,105 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_gpre(
     for (int k = 0; k < D * D; ++k) cprod[(long long)(a.nchunk - 1 - ch) * D * D + k] = M[k];
 }
 
-// the MH terms of one state v at time t = i + 1 given the state w at time t - 1 (v, w = x or x'), LogShared row i -- the per-state half of
-// body_sweep_logpdf_shared, same operations: returns [q-term (concatenated likelihood + prior), target term (likelihood + prior), |v - u|^2 / delta]
+// ---- compact per-pass rows (model stage) ----------------------------------------------------------------------------------------------------
+// The passes wait for their chain-shared coefficients more than they compute: read straight from the tables with scalar loads every chunk streams ~1 KB
+// of rows per step through the scalar cache with no reuse, i.e. a dozen dependent L2 round trips per step (measured: pass C 0.92 ms against a VALU
+// floor of 0.28).  So each pass gets its OWN row per time step, holding exactly what it reads, and a workgroup (all its chains x one chunk) copies the
+// chunk's rows into LDS with one burst of coalesced loads; inside the time loop a coefficient is an LDS broadcast read.
+template <typename R, int D, int PO> struct FsRows {
+    static constexpr int P = D + PO;
+    using TL = LogShared<R, D, PO>;
+    static constexpr int VEC = 16 / sizeof(R);
+    static constexpr int pad(int n) { return (n + VEC - 1) / VEC * VEC; }
+    // pass A, row i = t - 1 (t >= 1): [Mb | kc | K[:, :D] | LogShared row i]
+    static constexpr int aM = 0, aKc = D * D, aK = aKc + D, aL = aK + D * D, NA = pad(aL + TL::N);
+    // pass C, row t (t >= 0; the filter part of row 0 is zero): [Mb | kc | K[:, :D] | HF | ym | Si | c0 | M1 | gb | Lc (lower, packed) | gpre]
+    static constexpr int cM = 0, cKc = D * D, cK = cKc + D, cHF = cK + D * D, cYm = cHF + P * D, cSi = cYm + P, cC0 = cSi + symsize(P), cM1 = cC0 + 1,
+                         cGb = cM1 + D * D, cL = cGb + D, cGp = cL + symsize(D), NC = pad(cGp + D * D);
+    // pass E, row t: [G_t | LogShared row t (transition t -> t + 1, observation at t + 1; zero for t = T - 1)]
+    static constexpr int eG = 0, eL = D * D, NE = pad(eL + TL::N);
+};
+// where element k of a compact row comes from: {table (0 gain row t - 1, 1 sampler row t, 2 log-density row t - 1, 3 gpre row t, 4 log-density row t,
+// -1 zero), offset}.  Evaluated per element by one thread, so that consecutive threads write consecutive reals of the destination rows.
+struct FsSrc { int tab, off; };
+template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_a(int k) {
+    constexpr int P = D + PO;
+    using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TL = LogShared<R, D, PO>;
+    if (k < F::aKc) return {0, TG::oM + k};
+    if (k < F::aK) return {0, TG::oKc + (k - F::aKc)};
+    if (k < F::aL) { const int q = k - F::aK; return {0, TG::oK + (q / D) * P + (q % D)}; }
+    if (k < F::aL + TL::N) return {2, k - F::aL};
+    return {-1, 0};
+}
+template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_c(int k) {
+    constexpr int P = D + PO;
+    using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>;
+    if (k < F::cKc) return {0, TG::oM + k};
+    if (k < F::cK) return {0, TG::oKc + (k - F::cKc)};
+    if (k < F::cHF) { const int q = k - F::cK; return {0, TG::oK + (q / D) * P + (q % D)}; }
+    if (k < F::cYm) return {0, TG::oHF + (k - F::cHF)};
+    if (k < F::cSi) return {0, TG::oYm + (k - F::cYm)};
+    if (k < F::cC0) return {0, TG::oSi + (k - F::cSi)};
+    if (k < F::cM1) return {0, TG::oC0};
+    if (k < F::cGb) return {1, TS::oM + (k - F::cM1)};
+    if (k < F::cL) return {1, TS::oGb + (k - F::cGb)};
+    if (k < F::cGp) {  // packed lower index -> (i, j) of the dense D x D factor
+        const int q = k - F::cL;
+        int i = 0;
+        while (lidx(i + 1, 0) <= q) ++i;
+        return {1, TS::oL + i * D + (q - lidx(i, 0))};
+    }
+    if (k < F::cGp + D * D) return {3, k - F::cGp};
+    return {-1, 0};
+}
+template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_e(int k) {
+    using F = FsRows<R, D, PO>; using TS = SampShared<R, D>; using TL = LogShared<R, D, PO>;
+    if (k < F::eL) return {1, TS::oG + k};
+    if (k < F::eL + TL::N) return {4, k - F::eL};
+    return {-1, 0};
+}
+// one thread per destination element: blockIdx.y picks the row family (0 A, 1 C, 2 E), the flat index runs over (t, k)
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_rows(FusedArgs a, R* __restrict__ ra, R* __restrict__ rc, R* __restrict__ re) {
+    constexpr int P = D + PO;
+    using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>; using TL = LogShared<R, D, PO>;
+    const int fam = blockIdx.y;
+    const int N = fam == 0 ? F::NA : fam == 1 ? F::NC : F::NE;
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long rows = fam == 0 ? a.T - 1 : a.T;
+    if (g >= rows * N) return;
+    const int r = (int)(g / N), k = (int)(g % N);
+    const int t = fam == 0 ? r + 1 : r;
+    const FsSrc sc = fam == 0 ? fs_src_a<R, D, PO>(k) : fam == 1 ? fs_src_c<R, D, PO>(k) : fs_src_e<R, D, PO>(k);
+    R v = 0;
+    if (sc.tab == 0) { if (t >= 1) v = ((const R*)a.gain)[(long long)(t - 1) * TG::NPAD + sc.off]; }
+    else if (sc.tab == 1) v = ((const R*)a.samp)[(long long)t * TS::NPAD + sc.off];
+    else if (sc.tab == 2) v = ((const R*)a.logt)[(long long)(t - 1) * TL::NPAD + sc.off];
+    else if (sc.tab == 3) v = ((const R*)a.gpre)[(long long)t * D * D + sc.off];
+    else if (sc.tab == 4) { if (t + 1 < a.T) v = ((const R*)a.logt)[(long long)t * TL::NPAD + sc.off]; }
+    (fam == 0 ? ra : fam == 1 ? rc : re)[g] = v;
+}
+
+// workgroup = all (up to 256) chains of one chunk; consecutive blocks = the chain groups of one chunk
+__device__ __forceinline__ void fs_block(const FusedArgs& a, int& ch, int& c) {
+    const int groups = (a.C + (int)blockDim.x - 1) / (int)blockDim.x;
+    ch = blockIdx.x / groups;
+    c = (blockIdx.x % groups) * blockDim.x + threadIdx.x;
+}
+// copy rows [r0, r1) of a table with rows of N reals into LDS (N a multiple of 16 bytes): one burst of coalesced 16-byte loads
+template <typename R, int N> __device__ __forceinline__ void fs_stage(const R* __restrict__ tab, int r0, int r1, R* __restrict__ lds) {
+    using V = typename Vec16<R>::type;
+    constexpr int W = Vec16<R>::W;
+    const V* src = reinterpret_cast<const V*>(tab + (long long)r0 * N);
+    V* dst = reinterpret_cast<V*>(lds);
+    const int n = (r1 - r0) * (N / W);
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    __syncthreads();
+}
+
+// the MH terms of one state v at time t = i + 1 given the state w at time t - 1 (v, w = x or x'), LogShared row i (`row`, in LDS) -- the per-state
+// half of body_sweep_logpdf_shared, same operations: [q-term (concatenated likelihood + prior), target term (likelihood + prior), |v - u|^2 / delta]
 template <typename R, int D, int PO>
-__device__ __forceinline__ void fs_terms(const FusedArgs& a, UniformRow<R> row, const R* v, const R* w, const R* u, R inv_delta, R cst, R* out3) {
+__device__ __forceinline__ void fs_terms(const FusedArgs& a, const R* row, const R* v, const R* w, const R* u, R inv_delta, R cst, R* out3) {
     using TL = LogShared<R, D, PO>;
     R ob;
     bool badobs = false;
@@ -152,103 +247,111 @@ __device__ __forceinline__ void fs_terms(const FusedArgs& a, UniformRow<R> row, 
 }
 
 // ---- pass A ---------------------------------------------------------------------------------------------------------------------------
-template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_fs_a(FusedArgs a) {
-    constexpr int P = D + PO;
-    using TG = GainRow<R, D, P>;
-    using TL = LogShared<R, D, PO>;
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_a(FusedArgs a, const R* __restrict__ rows) {
+    using F = FsRows<R, D, PO>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lds = (R*)smem;
     fs_resolve(a);
-    int ch, s;
-    if (!fs_decode(a, ch, s)) return;
+    int ch, c;
+    fs_block(a, ch, c);
     const long long C = a.C;
     const int ta = max(1, ch * a.E), tb = min(a.T, (ch + 1) * a.E);
-    const R* xr = (const R*)((a.sel && a.sel[s]) ? (const void*)a.xb : a.xa) + s;
-    R* up = (R*)a.u + s;
+    fs_stage<R, F::NA>(rows, ta - 1, tb - 1, lds);
+    if (c >= a.C) return;
+    const R* xr = (const R*)((a.sel && a.sel[c]) ? (const void*)a.xb : a.xa) + c;
+    R* up = (R*)a.u + c;
     R h[D], xq[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
-        h[k] = ch == 0 ? ((const R*)a.m0p)[k * C + s] : (R)0;
+        h[k] = ch == 0 ? ((const R*)a.m0p)[k * C + c] : (R)0;
         xq[k] = xr[((long long)(ta - 1) * D + k) * C];
     }
     const R shd = (R)a.shd, inv_delta = (R)1 / (R)a.delta;
     const R cst = (R)-0.5 * (R)D * log_((R)(0.5 * a.delta)) - (R)(0.5 * LOG_2PI) * (R)D;
     Acc v0 = 0, v1 = 0, v2 = 0;
+    R xn[D];  // the next step's state, fetched one step ahead
+#pragma unroll
+    for (int k = 0; k < D; ++k) xn[k] = xr[((long long)ta * D + k) * C];
 #pragma unroll 1
     for (int t = ta; t < tb; ++t) {
         const int tu = opaque_uniform(t);
+        const R* row = lds + (tu - ta) * F::NA;
         R x[D], ev[D], u[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = xr[((long long)tu * D + k) * C];
-        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + s, C, ev);
+        for (int k = 0; k < D; ++k) x[k] = xn[k];
+        if (t + 1 < tb) {
+            const int tn = opaque_uniform(t + 1);
+#pragma unroll
+            for (int k = 0; k < D; ++k) xn[k] = xr[((long long)tn * D + k) * C];
+        }
+        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + c, C, ev);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             u[k] = x[k] + shd * ev[k];
             up[((long long)tu * D + k) * C] = u[k];
         }
         {  // filter fold (FilterMeanOp::fold, folded rows): h <- Mb h + kc + K[:, :D] u
-            const UniformRow<R> row = uniform_row<R>((const R*)a.gain + (long long)(tu - 1) * TG::NPAD);
             R o[D];
 #pragma unroll
             for (int r = 0; r < D; ++r) {
-                R v = row[TG::oKc + r];
+                R v = row[F::aKc + r];
 #pragma unroll
-                for (int k = 0; k < D; ++k) v += row[TG::oM + r * D + k] * h[k];
+                for (int k = 0; k < D; ++k) v += row[F::aM + r * D + k] * h[k];
 #pragma unroll
-                for (int k = 0; k < D; ++k) v += row[TG::oK + r * P + k] * (finite_(u[k]) ? u[k] : (R)0);
+                for (int k = 0; k < D; ++k) v += row[F::aK + r * D + k] * (finite_(u[k]) ? u[k] : (R)0);
                 o[r] = v;
             }
 #pragma unroll
             for (int r = 0; r < D; ++r) h[r] = o[r];
         }
-        {
-            const UniformRow<R> row = uniform_row<R>((const R*)a.logt + (long long)(tu - 1) * TL::NPAD);
-            R w[3];
-            fs_terms<R, D, PO>(a, row, x, xq, u, inv_delta, cst, w);
-            v0 += (Acc)w[0];
-            v1 += (Acc)w[1];
-            v2 += (Acc)w[2];
-        }
+        R w[3];
+        fs_terms<R, D, PO>(a, row + F::aL, x, xq, u, inv_delta, cst, w);
+        v0 += (Acc)w[0];
+        v1 += (Acc)w[1];
+        v2 += (Acc)w[2];
 #pragma unroll
         for (int k = 0; k < D; ++k) xq[k] = x[k];
     }
-    stv<R, D>((R*)a.agg_f + ((long long)s * a.nchunk + ch) * SampPre<R, D>::NPAD, h);
-    a.pa[((long long)0 * C + s) * a.nchunk + ch] = v0;
-    a.pa[((long long)1 * C + s) * a.nchunk + ch] = v1;
-    a.pa[((long long)2 * C + s) * a.nchunk + ch] = v2;
+    stv<R, D>((R*)a.agg_f + ((long long)c * a.nchunk + ch) * SampPre<R, D>::NPAD, h);
+    a.pa[((long long)0 * C + c) * a.nchunk + ch] = v0;
+    a.pa[((long long)1 * C + c) * a.nchunk + ch] = v1;
+    a.pa[((long long)2 * C + c) * a.nchunk + ch] = v2;
 }
 
 // ---- pass C ---------------------------------------------------------------------------------------------------------------------------
-template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_fs_c(FusedArgs a) {
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_c(FusedArgs a, const R* __restrict__ rows) {
     constexpr int P = D + PO;
-    using TG = GainRow<R, D, P>;
-    using TS = SampShared<R, D>;
+    using F = FsRows<R, D, PO>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lds = (R*)smem;
     fs_resolve(a);
-    int ch, s;
-    if (!fs_decode(a, ch, s)) return;
+    int ch, c;
+    fs_block(a, ch, c);
     const long long C = a.C;
     const int t0 = ch * a.E, ta = max(1, t0), tb = min(a.T, t0 + a.E);
-    const R* up = (const R*)a.u + s;
-    R* ip = (R*)a.inc + s;
+    fs_stage<R, F::NC>(rows, t0, tb, lds);
+    if (c >= a.C) return;
+    const R* up = (const R*)a.u + c;
+    R* ip = (R*)a.inc + c;
     R m[D], es[D];
     if (ch == 0) {
 #pragma unroll
-        for (int k = 0; k < D; ++k) m[k] = ((const R*)a.m0p)[k * C + s];
+        for (int k = 0; k < D; ++k) m[k] = ((const R*)a.m0p)[k * C + c];
     } else {
-        ldv<R, D>((const R*)a.pre_f + ((long long)s * a.nchunk + ch) * SampPre<R, D>::NPAD, m);
+        ldv<R, D>((const R*)a.pre_f + ((long long)c * a.nchunk + ch) * SampPre<R, D>::NPAD, m);
     }
 #pragma unroll
     for (int k = 0; k < D; ++k) es[k] = 0;
     // one sampler increment: inc = M1 m - gb + Lc eps (SampleAffOp::step without the G h term), stored, and folded into the chunk aggregate
-    auto emit = [&](int tu, const R* eps) {
-        const UniformRow<R> row = uniform_row<R>((const R*)a.samp + (long long)tu * TS::NPAD);
-        const UniformRow<R> gp = uniform_row<R>((const R*)a.gpre + (long long)tu * D * D);
+    auto emit = [&](int tu, const R* row, const R* eps) {
         R inc[D];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
-            R v = -row[TS::oGb + i];
+            R v = -row[F::cGb + i];
 #pragma unroll
-            for (int k = 0; k < D; ++k) v += row[TS::oM + i * D + k] * m[k];
+            for (int k = 0; k < D; ++k) v += row[F::cM1 + i * D + k] * m[k];
 #pragma unroll
-            for (int k = 0; k <= i; ++k) v += row[TS::oL + i * D + k] * eps[k];
+            for (int k = 0; k <= i; ++k) v += row[F::cL + lidx(i, k)] * eps[k];
             inc[i] = v;
             ip[((long long)tu * D + i) * C] = v;
         }
@@ -256,32 +359,40 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_
         for (int i = 0; i < D; ++i) {
             R v = es[i];
 #pragma unroll
-            for (int k = 0; k < D; ++k) v += gp[i * D + k] * inc[k];
+            for (int k = 0; k < D; ++k) v += row[F::cGp + i * D + k] * inc[k];
             es[i] = v;
         }
     };
     if (ch == 0) {  // t = 0: the mean of k_filter_t0, the noise row of the fill kernel
         R eps[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) eps[k] = ((const R*)a.eps0s)[k * C + s];
-        emit(0, eps);
+        for (int k = 0; k < D; ++k) eps[k] = ((const R*)a.eps0s)[k * C + c];
+        emit(0, lds, eps);
     }
     R acc = 0;
+    R yn[D];  // the next step's auxiliary variable, fetched one step ahead
+#pragma unroll
+    for (int k = 0; k < D; ++k) yn[k] = ta < tb ? up[((long long)ta * D + k) * C] : (R)0;
 #pragma unroll 1
     for (int t = ta; t < tb; ++t) {
         const int tu = opaque_uniform(t);
+        const R* row = lds + (tu - t0) * F::NC;
         R y[D], eps[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) y[k] = up[((long long)tu * D + k) * C];
-        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + s, C, eps);
+        for (int k = 0; k < D; ++k) y[k] = yn[k];
+        if (t + 1 < tb) {
+            const int tn = opaque_uniform(t + 1);
+#pragma unroll
+            for (int k = 0; k < D; ++k) yn[k] = up[((long long)tn * D + k) * C];
+        }
+        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + c, C, eps);
         {  // FilterMeanOp::walk_impl<true>: innovation against the incoming mean, then the affine step
-            const UniformRow<R> row = uniform_row<R>((const R*)a.gain + (long long)(tu - 1) * TG::NPAD);
             R r[P], o[D];
 #pragma unroll
             for (int k = 0; k < P; ++k) {
-                R v = row[TG::oYm + k];
+                R v = row[F::cYm + k];
 #pragma unroll
-                for (int j = 0; j < D; ++j) v += row[TG::oHF + k * D + j] * m[j];
+                for (int j = 0; j < D; ++j) v += row[F::cHF + k * D + j] * m[j];
                 if (k < D) {
                     const bool fin = finite_(y[k < D ? k : 0]);
                     y[k < D ? k : 0] = fin ? y[k < D ? k : 0] : (R)0;
@@ -292,11 +403,11 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_
             }
 #pragma unroll
             for (int k = 0; k < D; ++k) {
-                R v = row[TG::oKc + k];
+                R v = row[F::cKc + k];
 #pragma unroll
-                for (int j = 0; j < D; ++j) v += row[TG::oM + k * D + j] * m[j];
+                for (int j = 0; j < D; ++j) v += row[F::cM + k * D + j] * m[j];
 #pragma unroll
-                for (int l = 0; l < D; ++l) v += row[TG::oK + k * P + l] * y[l];
+                for (int l = 0; l < D; ++l) v += row[F::cK + k * D + l] * y[l];
                 o[k] = v;
             }
             R q = 0;
@@ -304,65 +415,73 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_
             for (int k = 0; k < P; ++k) {
                 R sk = 0;
 #pragma unroll
-                for (int l = 0; l < P; ++l) sk += row[TG::oSi + sidx(P, k, l)] * r[l];
+                for (int l = 0; l < P; ++l) sk += row[F::cSi + sidx(P, k, l)] * r[l];
                 q += r[k] * sk;
             }
-            const R incl = (R)-0.5 * q + row[TG::oC0];
+            const R incl = (R)-0.5 * q + row[F::cC0];
             acc += isnan_(incl) ? (R)0 : incl;  // nansum (filtering.py:62)
 #pragma unroll
             for (int k = 0; k < D; ++k) m[k] = o[k];
         }
-        emit(tu, eps);
+        emit(tu, row, eps);
     }
-    stv<R, D>((R*)a.agg_s + ((long long)s * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, es);
-    ((R*)a.pell)[(long long)s * a.nchunk + ch] = acc;
+    stv<R, D>((R*)a.agg_s + ((long long)c * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, es);
+    ((R*)a.pell)[(long long)c * a.nchunk + ch] = acc;
 }
 
 // ---- pass E ---------------------------------------------------------------------------------------------------------------------------
-template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_fs_e(FusedArgs a) {
-    using TS = SampShared<R, D>;
-    using TL = LogShared<R, D, PO>;
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_e(FusedArgs a, const R* __restrict__ rows) {
+    using F = FsRows<R, D, PO>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lds = (R*)smem;
     fs_resolve(a);
-    int ch, s;
-    if (!fs_decode(a, ch, s)) return;
+    int ch, c;
+    fs_block(a, ch, c);
     const long long C = a.C;
     const int t0 = ch * a.E, tb = min(a.T, t0 + a.E);
-    R* xw = (R*)((a.sel && a.sel[s]) ? const_cast<void*>(a.xa) : a.xb) + s;
-    const R* up = (const R*)a.u + s;
-    const R* ip = (const R*)a.inc + s;
+    fs_stage<R, F::NE>(rows, t0, tb, lds);
+    if (c >= a.C) return;
+    R* xw = (R*)((a.sel && a.sel[c]) ? const_cast<void*>(a.xa) : a.xb) + c;
+    const R* up = (const R*)a.u + c;
+    const R* ip = (const R*)a.inc + c;
     R h[D], uq[D];
     if (ch == a.nchunk - 1) {
 #pragma unroll
         for (int k = 0; k < D; ++k) h[k] = 0, uq[k] = 0;  // G_{T-1} = 0: the first position ignores the incoming state
     } else {
-        ldv<R, D>((const R*)a.pre_s + ((long long)s * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, h);  // x'_{tb}
+        ldv<R, D>((const R*)a.pre_s + ((long long)c * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, h);  // x'_{tb}
 #pragma unroll
         for (int k = 0; k < D; ++k) uq[k] = up[((long long)tb * D + k) * C];
     }
     const R inv_delta = (R)1 / (R)a.delta;
     const R cst = (R)-0.5 * (R)D * log_((R)(0.5 * a.delta)) - (R)(0.5 * LOG_2PI) * (R)D;
     Acc v0 = 0, v1 = 0, v2 = 0;
+    R incn[D], utn[D];  // the next (earlier) step's records, fetched one step ahead
+#pragma unroll
+    for (int k = 0; k < D; ++k) incn[k] = ip[((long long)(tb - 1) * D + k) * C], utn[k] = up[((long long)(tb - 1) * D + k) * C];
 #pragma unroll 1
     for (int t = tb - 1; t >= t0; --t) {
         const int tu = opaque_uniform(t);
+        const R* row = lds + (tu - t0) * F::NE;
         R inc[D], ut[D], xp[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) inc[k] = ip[((long long)tu * D + k) * C], ut[k] = up[((long long)tu * D + k) * C];
-        {
-            const UniformRow<R> row = uniform_row<R>((const R*)a.samp + (long long)tu * TS::NPAD);
+        for (int k = 0; k < D; ++k) inc[k] = incn[k], ut[k] = utn[k];
+        if (t > t0) {
+            const int tn = opaque_uniform(t - 1);
 #pragma unroll
-            for (int i = 0; i < D; ++i) {
-                R v = inc[i];
+            for (int k = 0; k < D; ++k) incn[k] = ip[((long long)tn * D + k) * C], utn[k] = up[((long long)tn * D + k) * C];
+        }
 #pragma unroll
-                for (int k = 0; k < D; ++k) v += row[TS::oG + i * D + k] * h[k];
-                xp[i] = v;
-                xw[((long long)tu * D + i) * C] = v;
-            }
+        for (int i = 0; i < D; ++i) {
+            R v = inc[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += row[F::eG + i * D + k] * h[k];
+            xp[i] = v;
+            xw[((long long)tu * D + i) * C] = v;
         }
         if (tu + 1 < a.T) {  // (wave-uniform) LogShared row tu: x'_{tu+1} = h given x'_tu = xp, observation and auxiliary terms at tu + 1
-            const UniformRow<R> row = uniform_row<R>((const R*)a.logt + (long long)tu * TL::NPAD);
             R w[3];
-            fs_terms<R, D, PO>(a, row, h, xp, uq, inv_delta, cst, w);
+            fs_terms<R, D, PO>(a, row + F::eL, h, xp, uq, inv_delta, cst, w);
             v0 += (Acc)w[0];
             v1 += (Acc)w[1];
             v2 += (Acc)w[2];
@@ -370,9 +489,9 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_CM) k_
 #pragma unroll
         for (int k = 0; k < D; ++k) h[k] = xp[k], uq[k] = ut[k];
     }
-    a.pe[((long long)0 * C + s) * a.nchunk + ch] = v0;
-    a.pe[((long long)1 * C + s) * a.nchunk + ch] = v1;
-    a.pe[((long long)2 * C + s) * a.nchunk + ch] = v2;
+    a.pe[((long long)0 * C + c) * a.nchunk + ch] = v0;
+    a.pe[((long long)1 * C + c) * a.nchunk + ch] = v1;
+    a.pe[((long long)2 * C + c) * a.nchunk + ch] = v2;
 }
 
 // ---- t = 0 terms (one lane per chain): body_sweep_logpdf_head on the lane's own pair of buffers -----------------------------------------------
@@ -397,20 +516,15 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
     __shared__ Acc sh[TB_ELEM];
     const int c = blockIdx.x;
     const long long C = a.C;
-    Acc tot[7];
+    Acc tot[7] = {0, 0, 0, 0, 0, 0, 0};
+    const R* pl = (const R*)a.pell + (long long)c * a.nchunk;
+    for (int j = threadIdx.x; j < a.nchunk; j += TB_ELEM) {  // (seven independent loads per trip)
 #pragma unroll
-    for (int k = 0; k < 7; ++k) {
-        Acc v = 0;
-        if (k < 6) {
-            const Acc* p = (k < 3 ? a.pa + ((long long)k * C + c) * a.nchunk : a.pe + ((long long)(k - 3) * C + c) * a.nchunk);
-            for (int j = threadIdx.x; j < a.nchunk; j += TB_ELEM) v += p[j];
-        } else {
-            const R* p = (const R*)a.pell + (long long)c * a.nchunk;
-            for (int j = threadIdx.x; j < a.nchunk; j += TB_ELEM) v += (Acc)p[j];
-        }
-        tot[k] = block_sum<Acc, TB_ELEM>(v, sh);
-        __syncthreads();
+        for (int k = 0; k < 3; ++k) tot[k] += a.pa[((long long)k * C + c) * a.nchunk + j], tot[3 + k] += a.pe[((long long)k * C + c) * a.nchunk + j];
+        tot[6] += (Acc)pl[j];
     }
+#pragma unroll
+    for (int k = 0; k < 7; ++k) tot[k] = block_sum<Acc, TB_ELEM>(tot[k], sh);
     if (threadIdx.x != 0) return;
     const Acc ell = (Acc)ell0[c] + tot[6];
     const Acc jp_prop = tot[3] + (Acc)head5[0 * C + c], jp_rev = tot[0] + (Acc)head5[1 * C + c];
@@ -420,7 +534,7 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
     Acc la = lt_prop - lt_rev;
     la += lp_rev - lp_prop;
     la -= corr;
-    const Acc alpha = exp_(min_(la, (Acc)0));
+    const Acc alpha = exp_(la != la ? la : min_(la, (Acc)0));  // jnp.minimum(0, nan) = nan (generic.py:105): a NaN ratio rejects
     const int acc = ((Acc)u_acc[c] < alpha) ? 1 : 0;  // NaN alpha -> reject, as jax.random.bernoulli(key, nan)
     accepted[c] = acc;
     if (sel) sel[c] ^= acc;
@@ -437,12 +551,13 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
 inline int fs_chunk_len(const auxssm_ctx* h, int C, int T) {
     static const int waves = [] { const char* e = getenv("AUXSSM_FS_WAVES"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
     static const int fixedE = [] { const char* e = getenv("AUXSSM_FS_E"); return e ? atoi(e) : 0; }();
-    if (fixedE >= 2) return fixedE;
+    if (fixedE >= 2 && fixedE <= 32) return fixedE;
     const long long stiles = (C + TB_CM - 1) / TB_CM;
     long long want = (long long)h->num_cu * 4 * waves / stiles;
     if (want < 1) want = 1;
     long long E = (T + want - 1) / want;
     if (E < 16) E = 16;
+    if (E > 32) E = 32;  // the chunk's rows live in LDS: 32 steps x 160 reals (pass C at d = 4, po = 4, fp64) = 40 KB per workgroup
     return (int)E;
 }
 template <typename R, int D, int PO> size_t fused_ws(const auxssm_ctx* h, const KDims& d) {
@@ -454,6 +569,7 @@ template <typename R, int D, int PO> size_t fused_ws(const auxssm_ctx* h, const 
     // model stage (side slab when the stage overlaps, else this one): matrix filter, gain / sampler / log-density tables, chunk products
     b += filter_ws<R, D, P>(h, KDims{1, d.T, 1}, 1);
     b += (size_t)d.T * (SampShared<R, D>::NPAD + LogShared<R, D, PO>::NPAD + (size_t)D * D) * sizeof(R) + (size_t)2 * nchunk * D * D * sizeof(R) + 8 * 256;
+    b += (size_t)d.T * (FsRows<R, D, PO>::NA + FsRows<R, D, PO>::NC + FsRows<R, D, PO>::NE) * sizeof(R) + 4 * 256;
     return b;
 }
 template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHost& f) {
@@ -467,8 +583,7 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     a.ka0 = f.keys[0]; a.ka1 = f.keys[1]; a.ks0 = f.keys[2]; a.ks1 = f.keys[3];
     a.eps0s = f.eps0s;
     a.delta = f.la.delta; a.shd = f.la.shd; a.dptr = f.la.dptr; a.nan_policy = f.la.nan_policy;
-    R* cprod_f;
-    R* cprod_s;
+    R *cprod_f, *cprod_s, *rows_a, *rows_c, *rows_e;
     {
         // MODEL STAGE (ctx.h::SideStage when the sweep opened one): everything that reads the model and the step size only
         {
@@ -481,7 +596,10 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
         R* gpre = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
         cprod_f = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
         cprod_s = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
-        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s) return AUXSSM_ERR_NOMEM;
+        rows_a = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NA * sizeof(R));
+        rows_c = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NC * sizeof(R));
+        rows_e = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NE * sizeof(R));
+        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s || !rows_a || !rows_c || !rows_e) return AUXSSM_ERR_NOMEM;
         a.gain = f.fa.tab; a.samp = f.sa.tab; a.logt = f.la.tab; a.gpre = gpre;
         {
             ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
@@ -489,6 +607,11 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
             hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.la);
             hipLaunchKernelGGL((k_fs_fprod<R, D, P>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod_f);
             hipLaunchKernelGGL((k_fs_gpre<R, D>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, gpre, cprod_s);
+            {
+                using F = FsRows<R, D, PO>;
+                const long long nmax = (long long)T * (F::NC > F::NA ? (F::NC > F::NE ? F::NC : F::NE) : (F::NA > F::NE ? F::NA : F::NE));
+                hipLaunchKernelGGL((k_fs_rows<R, D, PO>), dim3((unsigned)((nmax + 255) / 256), 3), dim3(256), 0, h->stream, a, rows_a, rows_c, rows_e);
+            }
         }
     }
     {
@@ -507,21 +630,23 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     // t = 0 update of every chain (reads the concatenated model: after the join)
     f.fa.t0_keep_ps = 1;
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((C + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.fa);
-    const unsigned grid = grid_aff(C, a.nchunk);
+    using F = FsRows<R, D, PO>;
+    const int TBF = C >= 256 ? 256 : (C + 63) / 64 * 64;
+    const unsigned grid = (unsigned)a.nchunk * (unsigned)((C + TBF - 1) / TBF);
     const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
     {
         ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-        hipLaunchKernelGGL((k_fs_a<R, D, PO>), dim3(grid), dim3(TB_CM), 0, h->stream, a);
+        hipLaunchKernelGGL((k_fs_a<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NA * sizeof(R), h->stream, a, (const R*)rows_a);
         hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_f, a.pre_f}, (const R*)cprod_f, a.nchunk);
     }
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
-        hipLaunchKernelGGL((k_fs_c<R, D, PO>), dim3(grid), dim3(TB_CM), 0, h->stream, a);
+        hipLaunchKernelGGL((k_fs_c<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NC * sizeof(R), h->stream, a, (const R*)rows_c);
         hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_s, a.pre_s}, (const R*)cprod_s, a.nchunk);
     }
     {
         ProfScope ps(h, AUXSSM_K_LOGPDF);
-        hipLaunchKernelGGL((k_fs_e<R, D, PO>), dim3(grid), dim3(TB_CM), 0, h->stream, a);
+        hipLaunchKernelGGL((k_fs_e<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NE * sizeof(R), h->stream, a, (const R*)rows_e);
     }
     {
         ProfScope ps(h, AUXSSM_K_SELECT);

@@ -427,7 +427,8 @@ def get_alpha(lp_prop, lp_rev, lt_prop, lt_rev, sqrt_delta, u, x, x_prop):
     log_alpha += lp_rev - lp_prop
     dp, dc = (x_prop - u) / sqrt_delta, (x - u) / sqrt_delta
     log_alpha -= np.sum(dp ** 2 - dc ** 2)
-    return math.exp(min(0.0, log_alpha)), log_alpha
+    # jnp.minimum(0, nan) = nan (generic.py:105): a NaN ratio gives alpha = nan and bernoulli(key, nan) rejects -- Python's min() would return 0.0
+    return (float("nan") if math.isnan(log_alpha) else math.exp(min(0.0, log_alpha))), log_alpha
 
 
 def kalman_sweep(x, delta, dynamics_factory, observations_factory, log_likelihood_fn, parallel,

@@ -399,7 +399,7 @@ static int sweep_one(const kseq_model* M, double delta, double* x, const double*
     double la = lt_prop - lt_rev; /* _get_alpha :98-106 */
     la += lp_rev - lp_prop;
     la -= corr;
-    const double alpha = exp(la < 0.0 ? la : 0.0);
+    const double alpha = exp(la != la ? la : (la < 0.0 ? la : 0.0)); /* jnp.minimum(0, nan) = nan: a NaN ratio rejects */
     const int acc = u_acc < alpha;
     if (logs) logs[0] = la, logs[1] = lp_prop, logs[2] = lp_rev, logs[3] = lt_prop, logs[4] = lt_rev;
     if (xprop_out) memcpy(xprop_out, xp, sizeof(double) * T * d);
