@@ -212,6 +212,7 @@ __device__ __forceinline__ void fs_terms(const FusedArgs& a, const R* row, const
         ob = (R)-0.5 * q + row[TL::oCR];
         if (badobs || isnan_(ob)) ob = 0;
     }
+    asm volatile("" ::: "memory");  // (the three blocks read disjoint parts of the row: keep their LDS reads apart)
     R ax, qa = 0;
     bool b = false;
     {
@@ -224,6 +225,7 @@ __device__ __forceinline__ void fs_terms(const FusedArgs& a, const R* row, const
         ax = b ? (R)0 : -qa * inv_delta + cst;
     }
     const R cc = (a.nan_policy == 0 && (b || badobs)) ? (R)0 : ax + ob;
+    asm volatile("" ::: "memory");
     R pr;
     {
         R q = 0;
@@ -247,7 +249,10 @@ __device__ __forceinline__ void fs_terms(const FusedArgs& a, const R* row, const
 }
 
 // ---- pass A ---------------------------------------------------------------------------------------------------------------------------
-template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_a(FusedArgs a, const R* __restrict__ rows) {
+#ifndef AUXSSM_FS_WPE_A
+#define AUXSSM_FS_WPE_A 2
+#endif
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUXSSM_FS_WPE_A))) k_fs_a(FusedArgs a, const R* __restrict__ rows) {
     using F = FsRows<R, D, PO>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     R* lds = (R*)smem;
@@ -290,6 +295,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
             u[k] = x[k] + shd * ev[k];
             up[((long long)tu * D + k) * C] = u[k];
         }
+        asm volatile("" ::: "memory");
         {  // filter fold (FilterMeanOp::fold, folded rows): h <- Mb h + kc + K[:, :D] u
             R o[D];
 #pragma unroll
@@ -304,6 +310,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
 #pragma unroll
             for (int r = 0; r < D; ++r) h[r] = o[r];
         }
+        asm volatile("" ::: "memory");  // keep the log-density row's LDS reads behind the fold: hoisted together they cost 200 registers
         R w[3];
         fs_terms<R, D, PO>(a, row + F::aL, x, xq, u, inv_delta, cst, w);
         v0 += (Acc)w[0];
