@@ -28,6 +28,17 @@ GENERAL = {
     "logpdf": [r"^k_sweep_logpdf_cm<"],
     "filter_tab": [r"^k_obs_info_tab<"],
 }
+# round 3: the chain-shared sweep in three streaming passes (csrc/fused_shared.h); k_aff_aggs runs once for the filter's and once for the sampler's aggregates
+FUSED = {
+    "filter_tab": SHARED["filter_tab"],
+    "sample_init": [r"^k_sample_shared_tab<", r"^k_sweep_logpdf_tab<", r"^k_fs_fprod<", r"^k_fs_gpre<", r"^k_fs_rows<"],
+    "filter_scan": [r"^k_fs_a<", (r"^k_aff_aggs<", 0.5)],
+    "sample_scan": [r"^k_fs_c<", (r"^k_aff_aggs<", 0.5)],
+    "logpdf": [r"^k_fs_e<"],
+    "select": [r"^k_fs_head<", r"^k_fs_accept<"],
+    "factory": [r"^k_concat_model<", r"^k_fs_concat0<"],
+    "rng": [r"^k_rng_sweep<"],
+}
 BOTH = {"rng": [r"^k_rng_sweep<"], "select": [r"^k_select(_rows)?<", r"^k_accept<"], "factory": [r"^k_concat_model<", r"^k_concat_obs<"]}
 CSMC = {"csmc_fwd": [r"^k_csmc_fwd<"], "csmc_bwd": [r"^k_csmc_bwd<"], "csmc_ctrans": [r"^k_csmc_ctrans<"]}
 
@@ -49,10 +60,11 @@ def group_bytes(fetch, write, pats, sweeps):
     tot_f = tot_w = 0.0
     kern = {}
     for name in fetch:
-        if any(re.search(p, name) for p in pats):
+        wgt = [p[1] if isinstance(p, tuple) else 1.0 for p in pats if re.search(p[0] if isinstance(p, tuple) else p, name)]
+        if wgt:
             n, fb = fetch[name]
             wb = write.get(name, (0, 0.0))[1]
-            per_sweep = n / sweeps
+            per_sweep = n / sweeps * wgt[0]
             tot_f += 2.0 * fb * per_sweep
             tot_w += wb * per_sweep
             kern[re.sub(r"\(.*$", "", name)] = dict(dispatches_per_sweep=round(per_sweep, 3), fetch_bytes=int(2 * fb), write_bytes=int(wb))
@@ -85,21 +97,31 @@ def mfma_busy(path, key, out_path):
 def main():
     if "--mfma" in sys.argv:  # python tools/pmc_traffic.py --mfma <counter_collection.csv> <key> [--out ...]
         i = sys.argv.index("--mfma")
-        return mfma_busy(sys.argv[i + 1], sys.argv[i + 2], sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r02_traffic.json")
+        return mfma_busy(sys.argv[i + 1], sys.argv[i + 2], sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r03_traffic.json")
     fetch, write, prefix = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "c2"
-    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r02_traffic.json"
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r03_traffic.json"
     src = f"{sys.argv[1]} + {sys.argv[2]} (FETCH_SIZE x2 per the gfx950 rule, + WRITE_SIZE; mean per dispatch x dispatches per sweep)"
     try:
         out = json.load(open(out_path))
     except Exception:
         out = {}
     if cfg == "c2":
-        n_sh = next(n for k, (n, _) in fetch.items() if k.startswith("k_sweep_logpdf_cm_shared<"))
-        n_ge = next(n for k, (n, _) in fetch.items() if re.match(r"k_sweep_logpdf_cm<", k))
+        cnt = lambda pre: next((n for k, (n, _) in fetch.items() if re.match(pre, k)), 0)
+        n_sh, n_ge, n_fu = cnt(r"k_sweep_logpdf_cm_shared<"), cnt(r"k_sweep_logpdf_cm<"), cnt(r"k_fs_e<")
+        if n_fu:  # (a run of fused sweeps only: bench.py --no-general-leg)
+            tot = 0
+            for g, pats in FUSED.items():
+                f, w, kern = group_bytes(fetch, write, pats, n_fu)
+                if kern:
+                    out[f"{prefix}_fused_{g}"] = dict(hbm_bytes=int(f + w), fetch_bytes=int(f), write_bytes=int(w), kernels=kern, source=src)
+                    tot += int(f + w)
+            out[f"{prefix}_fused_sweep"] = dict(hbm_bytes=tot, fetch_bytes=0, write_bytes=0, source=src + "; sum over the launch groups of one sweep")
         for mode, table, sweeps in (("shared", SHARED, n_sh), ("general", GENERAL, n_ge)):
+            if not sweeps or (n_fu and mode == "shared"):
+                continue
             for g, pats in list(table.items()) + list(BOTH.items()):
-                f, w, kern = group_bytes(fetch, write, pats, sweeps if g not in BOTH else n_sh + n_ge)
+                f, w, kern = group_bytes(fetch, write, pats, sweeps if g not in BOTH else n_sh + n_ge + n_fu)
                 if kern:
                     out[f"{prefix}_{mode}_{g}"] = dict(hbm_bytes=int(f + w), fetch_bytes=int(f), write_bytes=int(w), kernels=kern, source=src)
     else:
