@@ -65,3 +65,22 @@ def test_hip_vs_golden(name, parallel):
                         dict(rtol=1e-7, atol=1e-9))
     else:
         _check_filter(lambda ys, lg, par: P.filtering(ys, P.LGSSM(*lg), par), name, parallel, tol)
+
+
+def test_c5_fixture_prefix_reproduces():
+    """tests/golden/c5_T8192_known_answers.npz (the fp64 sequential filter of config C5 at T = 8192) -- the filter at time t depends on the data up
+    to t only, so its first entries are regenerated here from a 600-step prefix (the whole file: python tests/golden/make_c5_fixture.py --check)."""
+    import os
+    from oracle import kalman_np as K
+    from tests.helpers import c5_model
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_T8192_known_answers.npz"))
+    u, lg, _ = c5_model(8192, 64)
+    n = 600
+    cut = lambda a, m: a[:m]
+    lgp = (lg[0], lg[1], cut(lg[2], n - 1), cut(lg[3], n - 1), cut(lg[4], n - 1), cut(lg[5], n), cut(lg[6], n), cut(lg[7], n))
+    ms, Ps, _ = K.filtering(u[:n], lgp, False)
+    sel = ref["idx"] < n
+    assert sel.sum() >= 3
+    npt.assert_allclose(ms[ref["idx"][sel]], ref["ms"][sel], rtol=1e-10, atol=1e-12)
+    npt.assert_allclose(np.einsum("tii->ti", Ps[ref["idx"][sel]]), ref["Ps_diag"][sel], rtol=1e-10, atol=1e-12)
+    npt.assert_allclose(u.sum(), ref["u_checksum"], rtol=1e-12)

@@ -125,6 +125,36 @@ def test_C5_dense_d64(P, dtype, T):
     npt.assert_allclose(P.posterior_logpdf(u.astype(dtype), x.astype(dtype), oell, lg), K.posterior_logpdf(u, x, oell, lg64), rtol=tol["rtol"])
 
 
+def test_C5_benchmarked_horizon_vs_fp64_sequential_fixture(P):
+    """config C5 at the horizon bench.py times (d = p = 64, T = 8192, fp32, one sequence) -- 8191 fp32 combines of
+    unpivoted blocked eliminations -- against the fp64 SEQUENTIAL filter / sampler of the oracle, committed at 32 time points
+    (tests/golden/c5_T8192_known_answers.npz, tests/golden/make_c5_fixture.py).  Stated tolerance: 2e-3 (rtol and atol) on means,
+    covariances and the sampled path, 1e-4 relative on the log-likelihood; the achieved errors are printed."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_T8192_known_answers.npz"))
+    T, d = 8192, 64
+    u, lg64, _ = c5_model(T, d)
+    eps = np.random.default_rng(1).standard_normal((T, d))
+    npt.assert_allclose(u.sum(), ref["u_checksum"], rtol=1e-12)       # the synthetic inputs are the fixture's
+    npt.assert_allclose(eps.sum(), ref["eps_checksum"], rtol=1e-12)
+    lg = P.LGSSM(*[np.ascontiguousarray(a, np.float32) for a in lg64])
+    ms, Ps, ell = P.filtering(u.astype(np.float32), lg, True)
+    idx, full = ref["idx"], ref["full_idx"]
+    e_m = np.max(np.abs(ms[idx] - ref["ms"]))
+    e_p = np.max(np.abs(np.einsum("tii->ti", Ps[idx]) - ref["Ps_diag"]))
+    e_f = np.max(np.abs(Ps[full] - ref["Ps_full"]))
+    e_l = abs(float(ell) - float(ref["ell"])) / abs(float(ref["ell"]))
+    xs = P.sampling(None, ms, Ps, lg, True, eps=eps.astype(np.float32))   # the device's own fp32 moments in, as a sweep would
+    e_x = np.max(np.abs(xs[idx] - ref["xs"]))
+    print(f"C5 T=8192 fp32 vs fp64 sequential: max|dm| {e_m:.2e} max|dP_diag| {e_p:.2e} max|dP| {e_f:.2e} rel|d ell| {e_l:.2e} max|dx| {e_x:.2e}")
+    tol = dict(rtol=2e-3, atol=2e-3)
+    npt.assert_allclose(ms[idx], ref["ms"], **tol)
+    npt.assert_allclose(np.einsum("tii->ti", Ps[idx]), ref["Ps_diag"], **tol)
+    npt.assert_allclose(Ps[full], ref["Ps_full"], **tol)
+    npt.assert_allclose(xs[idx], ref["xs"], **tol)
+    assert e_l < 1e-4
+
+
 def test_too_large_for_lds_fails_loudly(P):
     """fp64 d = 64 exceeds the 160 KB LDS plan: a clear ValueError, never a silent fallback."""
     T, d = 4, 64

@@ -45,7 +45,7 @@ def _worker(rank, world, port, total, q):
     q.put((rank, None if got is None else got.tolist()))
 
 
-@pytest.mark.parametrize("world,total", [(2, 64), (2, 5), (3, 7)])
+@pytest.mark.parametrize("world,total", [(2, 64), (2, 5), (3, 7), (8, 64)])  # (8, 64): the C4 split, 64 chains -> 8 per rank
 def test_gather_chains_gloo(world, total):
     import torch.multiprocessing as mp
     from aux_ssm_samplers_amd.parallel import chain_key
