@@ -29,12 +29,16 @@ template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
 }
 
 // additive constants of time-varying transition densities: ct[t] = -sum_k log LQ_t[k][k] - D/2 log 2 pi
-template <typename R, int D> __global__ void k_csmc_ctrans(int n, const R* __restrict__ LQt, R* __restrict__ ct) {
+template <typename R, int D> __global__ void k_csmc_ctrans(int n, const R* __restrict__ LQt, R* __restrict__ ct, R* __restrict__ idt) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     R c = 0;
 #pragma unroll
-    for (int k = 0; k < D; ++k) c -= det_log(LQt[((long long)t * D + k) * D + k]);
+    for (int k = 0; k < D; ++k) {
+        const R l = LQt[((long long)t * D + k) * D + k];
+        c -= det_log(l);
+        idt[(long long)t * D + k] = (R)1 / l;  // reciprocal diagonal (sweep contract v3)
+    }
     ct[t] = c - (R)D * (R)0.91893853320467274178;
 }
 // gb[t] = sup_x G_t(x): the reduction-free part of the forward weights' shift (sweep contract, csmc_dev.h); +inf where the potential is unbounded
@@ -182,6 +186,7 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     R* red = xbuf + 2 * TB * D;         // [48]
     const int ch = a.c0 + blockIdx.x;
     const bool live = NW > 0 ? true : tid < N;
+    if (tid < 16) red[32 + tid] = 0;  // totals of absent groups: +0 (totals_prefix reads all 16 slots; ordered by the first barrier below)
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
     const R* gaux = GRAD ? (const R*)a.grad + (long long)ch * T * D : uaux;
@@ -239,7 +244,7 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     {
         R g = potential<R, D>(m, x, ycur);
         if (m.proposal == 1) {
-            g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+            g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.iLP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
             if constexpr (GRAD) g = g + grad_correction<R, D>(x, uaux, pm, ((const R*)a.shd)[0]);  // GradientAuxiliaryG0 (:173-190)
         }
         lw = live ? g : ninf;
@@ -290,25 +295,22 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
         R* xprev = xbuf + (t & 1) * TB * D;
 #pragma unroll
         for (int k = 0; k < D; ++k) xprev[tid * D + k] = x[k];
-        R Pg[16];
+        R tot;
         if (CSMC_ABL & 16) {
-#pragma unroll
-            for (int k = 0; k < 16; ++k) Pg[k] = (R)(k + 1);
+            tot = (R)N;
             c[cpad(tid)] = w;
             __syncthreads();
         } else
-            block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, Pg);  // trailing barrier also publishes xprev
-        R tot = NW > 0 ? Pg[NW > 0 ? NW - 1 : 0] : c[cpad(N - 1)];  // full groups: the last total IS c[N - 1], bit for bit
+            block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, tot);  // trailing barrier also publishes xprev; tot = c[N - 1]
         if (used_bound && !(tot > (R)0)) {  // every weight of step t - 1 underflowed under its bound: the exact maximum after all (uniform)
-            if (NW == 0) __syncthreads();   // (c[N - 1] has been read by every lane before it is rewritten)
+            __syncthreads();                // (every lane is past its reads of the step's images before they are rewritten)
             w = block_expmax<R, NW>(lw, red, tid, nw, &mstep);
             if (fmax && tid == 0) fmax[t - 1] = mstep;
-            block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, Pg);
-            tot = NW > 0 ? Pg[NW > 0 ? NW - 1 : 0] : c[cpad(N - 1)];
+            block_cumsum_dpp<R, NW, true>(w, c, red, tid, nw, tot);
         }
         int idx = 0;
         if (CSMC_ABL & 1) idx = (tid * 7) & (N - 1);
-        else if (live && tid > 0) idx = search2<R, NW, true>(c, Pg, N, nw, tot * ((R)1 - un));
+        else if (live && tid > 0) idx = search2<R, NW, true>(c, N, tot * ((R)1 - un));
         R xp[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) xp[k] = xprev[idx * D + k];
@@ -343,7 +345,7 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
             if (m.proposal == 1) {  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
                 R mu[D];
                 trans_mean_t<R, D>(m, tr, xp, mu);
-                g = gauss_chol_logpdf<R, D>(x, mu, tr.LQ, tr.c_trans, tr.ld) + g;
+                g = gauss_chol_logpdf<R, D>(x, mu, tr.LQ, tr.iL, tr.c_trans, tr.ld) + g;
                 // GradientAuxiliaryGt (:252-268): in the reference the correction is summed over all particles, i.e. a constant of the
                 // step (AUXSSM_GRAD_REFERENCE: nothing to add); AUXSSM_GRAD_EXACT applies it per particle
                 if constexpr (GRAD) {
@@ -400,6 +402,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
     int* cnt = (int*)(ubuf + 2);     // [2][16] per-wave counts, by step parity
     const int ch = a.c0 + blockIdx.x;
     const bool live = NW > 0 ? true : tid < N;
+    if (tid < 16) red[32 + tid] = 0;  // totals of absent groups: +0 (csmc_dev.h::totals_prefix)
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
     const R* lws = (const R*)a.lws + (long long)ch * T * N;
     const int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
@@ -418,9 +421,9 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
 #pragma unroll
         for (int k = 0; k < D; ++k) xpub[(TB + tid) * D + k] = xi[k];
     }
-    R Pg[16];
-    block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);
-    int B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[1]), live, tid, nw, cnt + 16, N);
+    R tot;
+    block_cumsum_dpp<R, NW>(w, c, red, tid, nw, tot);
+    int B = block_count_below<R, NW>(c, tot * ((R)1 - ubuf[1]), live, tid, nw, cnt + 16, N);
     R xn[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) xn[k] = xpub[(TB + B) * D + k];
@@ -470,7 +473,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         if (live) {
             R mu[D];
             trans_mean_t<R, D>(m, tr, xi, mu);
-            lw = gauss_chol_logpdf<R, D>(xn, mu, tr.LQ, tr.c_trans, tr.ld) + lwi;
+            lw = gauss_chol_logpdf<R, D>(xn, mu, tr.LQ, tr.iL, tr.c_trans, tr.ld) + lwi;
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) xpub[(par * TB + tid) * D + k] = xi[k];
@@ -482,12 +485,13 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         if (CSMC_ABL & 32) w = lw * (R)0.001 + (R)1;  // (diagnostic build: the backward pass without its exp)
         else w = det_exp(lw - Mb);
         if constexpr (NW > 0) {  // cumulative weight in a register: one barrier (it publishes xpub / ubuf of this parity as well), no c[] image
-            R cv = block_cumsum_reg<R, NW>(w, red, tid, Pg);
-            if (!(Pg[NW - 1] > (R)0)) {  // (uniform: every lane holds the same totals)
+            R cv = block_cumsum_reg<R, NW>(w, red, tid, tot);
+            if (!(tot > (R)0)) {  // (uniform: every lane holds the same total)
+                __syncthreads();  // (every wave has read the totals before they are rewritten)
                 w = block_expmax<R, NW>(lw, red, tid, nw);
-                cv = block_cumsum_reg<R, NW>(w, red, tid, Pg);
+                cv = block_cumsum_reg<R, NW>(w, red, tid, tot);
             }
-            const unsigned long long bal = __ballot(cv < Pg[NW - 1] * ((R)1 - ubuf[par]));
+            const unsigned long long bal = __ballot(cv < tot * ((R)1 - ubuf[par]));
             if ((tid & 63) == 0) cnt[par * 16 + (tid >> 6)] = __popcll(bal);
             __syncthreads();
             B = 0;
@@ -495,13 +499,13 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
             for (int k = 0; k < NW; ++k) B += cnt[par * 16 + k];
             B = B < N - 1 ? B : N - 1;
         } else {
-            block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);    // two barriers: xpub / ubuf of this parity are published as well
-            if (!(c[N - 1] > (R)0)) {
-                __syncthreads();  // (every lane has read c[N - 1] before it is rewritten)
+            block_cumsum_dpp<R, NW>(w, c, red, tid, nw, tot);    // two barriers: xpub / ubuf of this parity are published as well
+            if (!(tot > (R)0)) {
+                __syncthreads();  // (every lane is past its reads of the images before they are rewritten)
                 w = block_expmax<R, NW>(lw, red, tid, nw);
-                block_cumsum_dpp<R, NW>(w, c, red, tid, nw, Pg);
+                block_cumsum_dpp<R, NW>(w, c, red, tid, nw, tot);
             }
-            B = block_count_below<R, NW>(c, c[N - 1] * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
+            B = block_count_below<R, NW>(c, tot * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) xn[k] = xpub[(par * TB + B) * D + k];
@@ -602,7 +606,8 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
         m.bt = (const R*)fk->b_t;
         m.LQt = (const R*)fk->chol_Q_t;
         m.ctt = (const R*)ctt;
-        hipLaunchKernelGGL((k_csmc_ctrans<R, D>), dim3((a.T - 1 + 255) / 256), dim3(256), 0, h->stream, a.T - 1, m.LQt, (R*)ctt);
+        m.idt = (const R*)ctt + (a.T - 1);  // (the caller sizes ctt for (T - 1) (1 + D) reals)
+        hipLaunchKernelGGL((k_csmc_ctrans<R, D>), dim3((a.T - 1 + 255) / 256), dim3(256), 0, h->stream, a.T - 1, m.LQt, (R*)ctt, (R*)ctt + (a.T - 1));
     }
     if (a.gb) hipLaunchKernelGGL((k_csmc_potbound<R, D>), dim3((a.T + 255) / 256), dim3(256), 0, h->stream, a.T, m, (const R*)a.y, (R*)a.gb);
     if (fk->proposal == 1) {
@@ -838,7 +843,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     const size_t big = xs_rec + lws_rec + As_rec;
     int cb = C;
     if (big) {
-        const size_t small = 4096 + 8 * 256 + (size_t)C * N * sR + CT * sR + 2 * (size_t)T * sR + 2 * CT * D * sR;
+        const size_t small = 4096 + 8 * 256 + (size_t)C * N * sR + CT * sR + (size_t)T * (2 + D) * sR + 2 * CT * D * sR;
         size_t fr = 0, tot = 0;
         if (hipMemGetInfo(&fr, &tot) == hipSuccess) {
             const double budget = 0.8 * (double)(fr + h->ws_bytes);  // (ws_reserve adds an eighth)
@@ -865,7 +870,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     need += (size_t)C * N * sR + 256;
     need += CT * sR + 256;  // fmax
     need += (size_t)T * sR + 256;  // gb
-    need += 2 * (CT * D * sR + 256) + (size_t)T * sR + 256;
+    need += 2 * (CT * D * sR + 256) + (size_t)T * (1 + D) * sR + 256;
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     CsmcArgs a;
@@ -875,7 +880,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.x = x;
     a.u = ws_take(h, CT * D * sR);
     a.grad = fk->gradient ? ws_take(h, CT * D * sR) : nullptr;
-    void* ctt = fk->F_t ? ws_take(h, (size_t)T * sR) : nullptr;
+    void* ctt = fk->F_t ? ws_take(h, (size_t)T * (1 + D) * sR) : nullptr;  // constants + reciprocal diagonals of the T - 1 transitions
     a.cb = cb; a.xs_rec = xs_rec; a.lws_rec = lws_rec; a.As_rec = As_rec;
     a.xs = xs_out ? xs_out : ws_take(h, CBT * N * D * sR);
     a.lws = log_ws_out ? log_ws_out : ws_take(h, CBT * N * sR);

@@ -15,11 +15,13 @@ template <typename R> struct FkDev {
     int proposal, potential, D, transition;  // transition: 0 = linear-Gaussian (F, b); 1 = Lorenz-63 Euler-Maruyama (theta = F[0][0..2], dt = b[0])
     R m0[CS_MAXD], LP0[CS_MAXD * CS_MAXD], F[CS_MAXD * CS_MAXD], b[CS_MAXD], LQ[CS_MAXD * CS_MAXD];
     R c_init, c_trans, c_obs, inv_sig_y;  // additive constants: -sum log L_kk - D/2 log 2pi, etc.
+    R iLP0[CS_MAXD], iLQ[CS_MAXD];        // reciprocal diagonals of LP0 / LQ: the log-densities multiply by them (sweep contract v3)
     // time-varying linear transitions (device arrays, row t = transition t -> t+1; null: the invariant F / b / LQ above)
     const R* Ft;   // (T-1, D, D)
     const R* bt;   // (T-1, D)
     const R* LQt;  // (T-1, D, D) lower
     const R* ctt;  // (T-1) additive constants of the transition densities (k_csmc_ctrans)
+    const R* idt;  // (T-1, D) reciprocal diagonals of LQt (k_csmc_ctrans)
     int gradient;  // AUXSSM_GRAD_*
 };
 // the transition t -> t+1 of the model: matrices through pointers (wave-uniform loads when time-varying)
@@ -29,15 +31,16 @@ template <typename R> struct TransT {
     const R* LQ;
     int ld;  // leading dimension of F / LQ: CS_MAXD for the struct arrays, D for the device rows
     R c_trans;
+    const R* iL;  // reciprocal diagonal of LQ
 };
 template <typename R, int D> __device__ __forceinline__ TransT<R> trans_at(const FkDev<R>& m, long long t) {
-    if (m.Ft) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t]};
-    return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans};
+    if (m.Ft) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t], m.idt + t * D};
+    return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans, m.iLQ};
 }
 // the same with the choice made at compile time (the persistent sweep kernels: no branch on the model kind inside the time loop)
 template <typename R, int D, bool TV> __device__ __forceinline__ TransT<R> trans_at_c(const FkDev<R>& m, long long t) {
-    if constexpr (TV) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t]};
-    else return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans};
+    if constexpr (TV) return TransT<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D, D, m.ctt[t], m.idt + t * D};
+    else return TransT<R>{m.F, m.b, m.LQ, CS_MAXD, m.c_trans, m.iLQ};
 }
 
 struct CsmcArgs {
@@ -84,8 +87,9 @@ template <typename R> __device__ __forceinline__ R noise_uniform(const CsmcArgs&
 AXD_HD float fma_(float a, float b, float c) { return fmaf(a, b, c); }
 AXD_HD double fma_(double a, double b, double c) { return fma(a, b, c); }
 
-// log N(x; mean, L L^T) = cst - 0.5 |L^-1 (x - mean)|^2, forward substitution in a fixed order
-template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mean, const R* L, R cst, int ld = CS_MAXD) {
+// log N(x; mean, L L^T) = cst - 0.5 |L^-1 (x - mean)|^2, forward substitution in a fixed order; iL = the reciprocal diagonal of L, computed once
+// per factor (sweep contract v3: a multiplication instead of an IEEE division -- ten instructions -- per particle, component and step)
+template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mean, const R* L, const R* iL, R cst, int ld = CS_MAXD) {
     R z[D];
     R q = 0;
 #pragma unroll
@@ -93,7 +97,7 @@ template <typename R, int D> AXD_HD R gauss_chol_logpdf(const R* x, const R* mea
         R acc = x[k] - mean[k];
 #pragma unroll
         for (int j = 0; j < k; ++j) acc = fma_(-L[k * ld + j], z[j], acc);
-        z[k] = acc / L[k * ld + k];
+        z[k] = acc * iL[k];
         q = fma_(z[k], z[k], q);
     }
     return fma_((R)-0.5, q, cst);
@@ -267,12 +271,12 @@ template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int
 // searchsorted(cumsum(w), c[-1] (1 - u)) (resamplings.py:35-36 -> jax.random.choice), which is invariant to the scale of w, so the
 // normaliser of normalize() (math/utils.py:38-39: one block sum, one log and one more exp per particle and step) is never formed.
 //   cumsum : inside each group of 64 consecutive particles the DPP scan of the hardware -- Kogge-Stone with offsets 1, 2, 4, 8 inside
-//            every row of 16 lanes, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2 and 3 += last of row 1 --
-//            group totals added left to right: c_i = (t_0 + ... + t_{g-1}) + local_i.
-//   search : two levels.  g = #{k < ng - 1 : C_k < r} with C_k = c[64 k + 63] the cumulative total at the end of group k (ng groups),
-//            then the number of entries of group g below r by descent: pos = 64 g; for s = 32, 16, 8, 4, 2, 1: if (pos + s - 1 < end and
-//            c[pos + s - 1] < r) pos += s, end = min(64 g + 64, N); clipped to N - 1.  On a non-decreasing c this IS
-//            searchsorted(c, r, side='left') (the group's last entry is >= r by the choice of g).
+//            every row of 16 lanes, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2 and 3 += last of row 1; the (up to 16)
+//            group totals, padded with +0, prefix-summed by the same Kogge-Stone network on one row of 16 lanes (v3): c_i = P[g - 1] + local_i.
+//   search : branch-free lower bound by descent over the whole array (v3): pos = 0; for s = S0, S0 / 2, ..., 1 (S0 the largest power of two
+//            below N): if (pos + s - 1 < N and c[pos + s - 1] < r) pos += s; clipped to N - 1.  On a non-decreasing c this IS
+//            searchsorted(c, r, side='left').
+//   densities : Gaussian log-densities multiply by the reciprocal diagonal of the Cholesky factor, computed once per factor (v3).
 //   single draw (backward pass): B = #{j < N : c_j < r}, clipped to N - 1 (again searchsorted on a non-decreasing c), counted by ballot.
 //   shifts   : the weights of a step are e_i = exp(lw_i - M) with M an upper bound of max_i lw_i that needs NO reduction where one exists, the
 //            exact maximum otherwise, and the exact maximum after all whenever every e_i underflowed (cumulative total not > 0: detected where
@@ -335,81 +339,69 @@ template <typename R, int NW = 0> __device__ __forceinline__ R block_expmax(R lw
     if (m_out) *m_out = m;
     return det_exp(lw - m);
 }
-// P[wv - 1] (0 for the first wave) by ONE scalar branch on the wave id (readfirstlane tells the compiler it is wave-uniform; a plain
-// switch on tid >> 6 becomes a tree of exec-mask branches, a select chain fifteen compare / select triples)
-template <typename R, int NW> __device__ __forceinline__ R wave_base(const R* P, int wv) {
-    R pre = 0;
-    switch (__builtin_amdgcn_readfirstlane(wv)) {
-#define AX_PRE_CASE(K) \
-    case K + 1:        \
-        if (K + 1 < NW) pre = P[K]; \
-        break;
-        AX_PRE_CASE(0) AX_PRE_CASE(1) AX_PRE_CASE(2) AX_PRE_CASE(3) AX_PRE_CASE(4) AX_PRE_CASE(5) AX_PRE_CASE(6) AX_PRE_CASE(7)
-        AX_PRE_CASE(8) AX_PRE_CASE(9) AX_PRE_CASE(10) AX_PRE_CASE(11) AX_PRE_CASE(12) AX_PRE_CASE(13) AX_PRE_CASE(14)
-#undef AX_PRE_CASE
-        default: break;
-    }
-    return pre;
+// lane `l` (wave-uniform) of v
+__device__ __forceinline__ float readlane_(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+__device__ __forceinline__ double readlane_(double v, int l) {
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
-// inclusive cumsum of w into c[] in the sweep contract's order; P[k] = cumulative total at the end of group k (k < nw), the same
-// numbers as c[64 k + 63]; c[] valid after the trailing barrier.  red slots [32, 48).
-// PAD: c[] is stored with one spare slot per 32 entries (index cpad(i) = i + (i >> 5)): the probes of the search below sit at strides of 64, 32,
-// 16 ... entries, which without the padding all fall into one or two LDS banks (a 16- to 32-way conflict on the first probes of every lane).
+// Sweep contract v3 (round 3), the prefix over the (up to 16) group totals: every wave reads the totals into lanes 0..15 (all four rows alike; slots of
+// absent groups hold +0 -- the kernels zero red[32 .. 48) once) and scans them with the Kogge-Stone network of one DPP row (offsets 1, 2, 4, 8).  Lane k then
+// holds P[k]; a wave's own base is ONE readlane -- no dependent left-to-right adds, no branch on the wave id (31 branches per wave and step before).
+//   base = P[wv - 1] (0 for the first wave);   tot = P[last - 1] + t[last] = c[N - 1] bit for bit (the last live particle's cumulative weight)
+template <typename R> __device__ __forceinline__ void totals_prefix(const R* red, int lane, int wv, int last, R& pre, R& tot) {
+    const R tv = red[32 + (lane & 15)];
+    R v = tv;
+    v = v + dpp_mov<DPP_ROW_SHR1, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_SHR2, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_SHR4, 0xf>((R)0, v);
+    v = v + dpp_mov<DPP_ROW_SHR8, 0xf>((R)0, v);
+    const int wvu = __builtin_amdgcn_readfirstlane(wv);
+    pre = wvu > 0 ? readlane_(v, wvu > 0 ? wvu - 1 : 0) : (R)0;
+    tot = last > 0 ? readlane_(v, last > 0 ? last - 1 : 0) + readlane_(tv, last) : readlane_(tv, 0);
+}
+// inclusive cumsum of w into c[] in the sweep contract's order; tot = c[N - 1]; c[] valid after the trailing barrier.  red slots [32, 48).
+// PAD: c[] is stored with one spare slot per 32 entries (index cpad(i) = i + (i >> 5)): the probes of the search below sit at strides of 512 .. 1
+// entries, which without the padding fall into one or two LDS banks (a 16- to 32-way conflict on the later probes of every lane).
 __host__ __device__ __forceinline__ constexpr int cpad(int i) { return i + (i >> 5); }
-template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R* P) {
+template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ void block_cumsum_dpp(R w, R* c, R* red, int tid, int nw, R& tot) {
     const int lane = tid & 63, wv = tid >> 6;
     const R v = wave_scan_dpp(w);
     if (lane == 63) red[32 + wv] = v;
     __syncthreads();
-    R t[16];
-    load16<R>(red + 32, t);
-    P[0] = t[0];
-    R pre = 0;
-    if constexpr (NW > 0) {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) P[k] = k < NW ? P[k - 1] + t[k] : P[k - 1];  // (k < NW: compile time)
-        pre = wave_base<R, NW>(P, wv);
-    } else {
-#pragma unroll
-        for (int k = 1; k < 16; ++k) P[k] = k < nw ? P[k - 1] + t[k] : P[k - 1];
-#pragma unroll
-        for (int k = 0; k < 15; ++k) pre = (k + 1 == wv) ? P[k] : pre;
-    }
+    R pre;
+    totals_prefix<R>(red, lane, wv, (NW > 0 ? NW : nw) - 1, pre, tot);
     c[PAD ? cpad(tid) : tid] = wv > 0 ? pre + v : v;
     __syncthreads();
 }
-// NW full waves, the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two
-// and no c[] image -- for the backward pass, whose single draw only counts {c_j < r}.  P[NW - 1] = c[N - 1] bit for bit (full groups).
-template <typename R, int NW> __device__ __forceinline__ R block_cumsum_reg(R w, R* red, int tid, R* P) {
+// the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two and no c[] image --
+// for the backward pass, whose single draw only counts {c_j < r}.
+template <typename R, int NW> __device__ __forceinline__ R block_cumsum_reg(R w, R* red, int tid, R& tot) {
     const int lane = tid & 63, wv = tid >> 6;
     const R v = wave_scan_dpp(w);
     if (lane == 63) red[32 + wv] = v;
     __syncthreads();
-    R t[16];
-    load16<R>(red + 32, t);
-    P[0] = t[0];
-#pragma unroll
-    for (int k = 1; k < 16; ++k) P[k] = k < NW ? P[k - 1] + t[k] : P[k - 1];
-    const R pre = wave_base<R, NW>(P, wv);
+    R pre;
+    totals_prefix<R>(red, lane, wv, NW - 1, pre, tot);
     return wv > 0 ? pre + v : v;
 }
-// the two-level search of the sweep contract; P from block_cumsum_dpp, ng = number of groups of 64 covering [0, N)
-template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ int search2(const R* c, const R* P, int N, int ng, R r) {
-    int g = 0;
-    if constexpr (NW > 0) {
+// the ancestor search of the sweep contract (v3): branch-free lower bound by descent over the whole cumulative-weight array.  On the padded image of a full
+// workgroup every probe is one LDS read at (running padded position + constant): while pos stays a multiple of 2 s, cpad(pos + s - 1) =
+// cpad(pos) + (s - 1) + ((s - 1) >> 5), and taking the step adds s + (s >> 5).
+template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ int search2(const R* c, int N, R r) {
+    if constexpr (NW > 0 && PAD) {
+        int ppos = 0;
 #pragma unroll
-        for (int k = 0; k < NW - 1; ++k) g += P[k] < r ? 1 : 0;
-        int pos = g << 6;
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) pos += c[PAD ? cpad(pos + s - 1) : pos + s - 1] < r ? s : 0;
+        for (int s = NW * 32; s > 0; s >>= 1) ppos += c[ppos + (s - 1) + ((s - 1) >> 5)] < r ? s + (s >> 5) : 0;
+        const int pos = ppos - ((ppos * 1986) >> 16);  // ppos = 33 (pos >> 5) + (pos & 31)
         return pos < N - 1 ? pos : N - 1;
     } else {
-#pragma unroll
-        for (int k = 0; k < 15; ++k) g += (k < ng - 1 && P[k] < r) ? 1 : 0;
-        int pos = g << 6;
-        const int end = min(pos + 64, N);
-#pragma unroll
-        for (int s = 32; s > 0; s >>= 1) pos += (pos + s - 1 < end && c[PAD ? cpad(min(pos + s - 1, N - 1)) : min(pos + s - 1, N - 1)] < r) ? s : 0;
+        int s0 = 1;
+        while (s0 * 2 < N) s0 *= 2;
+        int pos = 0;
+        for (int s = s0; s > 0; s >>= 1) {
+            const int q = pos + s - 1;
+            pos += (q < N && c[PAD ? cpad(q < N ? q : N - 1) : (q < N ? q : N - 1)] < r) ? s : 0;
+        }
         return pos < N - 1 ? pos : N - 1;
     }
 }
@@ -440,6 +432,10 @@ template <typename R> static void fill_model(FkDev<R>& m, const auxssm_fk_model*
     for (int k = 0; k < D; ++k) {
         ci -= det_log(m.LP0[k * CS_MAXD + k]);
         ct -= det_log(m.LQ[k * CS_MAXD + k]);
+    }
+    for (int k = 0; k < D; ++k) {
+        m.iLP0[k] = (R)1 / m.LP0[k * CS_MAXD + k];
+        m.iLQ[k] = (R)1 / m.LQ[k * CS_MAXD + k];
     }
     const R half_log_2pi = (R)0.91893853320467274178;
     m.c_init = ci - (R)D * half_log_2pi;

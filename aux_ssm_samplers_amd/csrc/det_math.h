@@ -44,9 +44,15 @@ AXD_HD float det_exp(float x) {
     p = fmaf(p, r, 1.0f);
     p = fmaf(p, r, 1.0f);
     const int k = (int)kf;                              // in [-126, 128]
+#if defined(__HIP_DEVICE_COMPILE__)
+    // p in [0.7, 1.5] and the result is a normal number (or overflows to +inf exactly as the two-step product does): ldexp is the same exact scaling,
+    // one instruction (v_ldexp_f32) instead of seven
+    float res = __builtin_ldexpf(p, k);
+#else
     // scale by 2^k in two exact steps (k may be 128)
     const int k1 = k / 2, k2 = k - k1;
     float res = p * u2f((uint32_t)(k1 + 127) << 23) * u2f((uint32_t)(k2 + 127) << 23);
+#endif
     res = small ? 0.0f : res;
     res = big ? INFINITY : res;
     return isnan ? x : res;

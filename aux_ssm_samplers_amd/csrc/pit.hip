@@ -108,7 +108,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_leave
 #pragma unroll
     for (int k = 0; k < D; ++k) y0[k] = a.y ? ((const R*)a.y)[k] : (R)0;
     R g = potential<R, D>(m, x, y0);
-    g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+    g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.iLP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
     const R lw = block_lognormalize<R>(live ? g : (R)-INFINITY, red, tid, (N + 63) >> 6);
     if (live) ((R*)a.lw0)[(long long)c * N + tid] = lw;
 }

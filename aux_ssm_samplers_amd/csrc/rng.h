@@ -101,7 +101,14 @@ template <> AX_HD void bits_to_normal2<float>(uint32_t b0, uint32_t b1, float& z
     const float r = sqrtf(-2.0f * logf(u1));
 #endif
     float c, s;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_cos_f32 / v_sin_f32 take their argument in REVOLUTIONS (cos(2 pi u), sin(2 pi u)), u in [0, 1): two instructions instead of the quadrant split
+    // and two polynomials (device fp32 normals are reproducible on the device only, see the contract above)
+    c = __builtin_amdgcn_cosf(u2);
+    s = __builtin_amdgcn_sinf(u2);
+#else
     sincos_2pi<float>(u2, c, s);
+#endif
     z0 = r * c;
     z1 = r * s;
 }

@@ -23,10 +23,14 @@
  *     exp(lw - max lw), NOT divided by their sum -- resampling is searchsorted(cumsum(w), c[-1] (1 - u)) (resamplings.py:35-36 ->
  *     jax.random.choice), invariant to the scale of w, so normalize()'s logsumexp (math/utils.py:38-39) is never formed;
  *       cumsum : inside each group of 64 the scan order of the GPU's DPP network: Kogge-Stone with offsets 1, 2, 4, 8 inside each
- *                row of 16, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2, 3 += last of row 1; group totals
- *                left to right as above;
- *       search : g = #{k < ng - 1 : c[64 k + 63] < r}, then lower_bound inside group g; clipped to N - 1 (== searchsorted on a
+ *                row of 16, then row 1 += last of row 0 and row 3 += last of row 2, then rows 2, 3 += last of row 1; the (up to 16) group
+ *                totals, padded with +0, are prefix-summed by the same Kogge-Stone network on ONE row of 16 lanes (contract v3, round 3:
+ *                every wave reads the totals into lanes 0..15 and scans them with four DPP adds; its own base is one readlane);
+ *       search : branch-free lower bound by descent over the whole array (contract v3): pos = 0; for s = S0, S0/2, .., 1 (S0 the largest
+ *                power of two below N): if (pos + s - 1 < N and c[pos + s - 1] < r) pos += s; clipped to N - 1 (== searchsorted on a
  *                non-decreasing c);   single draw of the backward pass: B = #{j : c_j < r}, clipped to N - 1;
+ *       densities : Gaussian log-densities multiply by the RECIPROCAL diagonal of the Cholesky factor, computed once per factor in the
+ *                working precision (contract v3: no division per particle and step);
  *   - every multiply-add that is fused is written as fma(); compile with -ffp-contract=off.
  * What IS pinned: the statistical known answers of the reference's tests (test_csmc.py::test_flat_potential :18-69,
  * test_resamplings.py::test_multinomial_resampling :11-24) -- see tests/test_oracle_csmc.py -- and, since round 3, the LITERAL
@@ -186,6 +190,7 @@ typedef struct {
     int proposal, potential, D, transition;
     REAL m0[MAXD], LP0[MAXD * MAXD], F[MAXD * MAXD], b[MAXD], LQ[MAXD * MAXD];
     REAL c_init, c_trans, c_obs, inv_sig_y;
+    REAL iLP0[MAXD], iLQ[MAXD]; /* reciprocal diagonals of the two Cholesky factors: the log-densities multiply by them (contract v3: no division per particle) */
 } SUF(fk);
 
 static void SUF(fk_fill)(SUF(fk) * m, const fk_model* g) {
@@ -201,6 +206,7 @@ static void SUF(fk_fill)(SUF(fk) * m, const fk_model* g) {
         }
     REAL ci = 0, ct = 0;
     for (int k = 0; k < D; ++k) { ci -= LOG(m->LP0[k * MAXD + k]); ct -= LOG(m->LQ[k * MAXD + k]); }
+    for (int k = 0; k < D; ++k) { m->iLP0[k] = (REAL)1 / m->LP0[k * MAXD + k]; m->iLQ[k] = (REAL)1 / m->LQ[k * MAXD + k]; }
     const REAL hl2pi = (REAL)0.91893853320467274178;
     m->c_init = ci - (REAL)D * hl2pi;
     m->c_trans = ct - (REAL)D * hl2pi;
@@ -216,13 +222,13 @@ static void SUF(fk_fill)(SUF(fk) * m, const fk_model* g) {
     }
 }
 
-/* log N(x; mean, L L^T) with the additive constant precomputed */
-static REAL SUF(gauss)(int D, const REAL* x, const REAL* mean, const REAL* L, REAL cst) {
+/* log N(x; mean, L L^T) with the additive constant precomputed; iL = the reciprocal diagonal of L (contract v3) */
+static REAL SUF(gauss)(int D, const REAL* x, const REAL* mean, const REAL* L, const REAL* iL, REAL cst) {
     REAL z[MAXD], q = 0;
     for (int k = 0; k < D; ++k) {
         REAL acc = x[k] - mean[k];
         for (int j = 0; j < k; ++j) acc = FMA(-L[k * MAXD + j], z[j], acc);
-        z[k] = acc / L[k * MAXD + k];
+        z[k] = acc * iL[k];
         q = FMA(z[k], z[k], q);
     }
     return FMA((REAL)-0.5, q, cst);
@@ -350,8 +356,12 @@ static REAL SUF(expmax)(const REAL* lw, int N, REAL* w) {
     return m;
 }
 static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) {
-    REAL pre = 0;
-    for (int g = 0; g * 64 < N; ++g) {
+    /* sweep contract v3: inside each group of 64 the DPP scan order of the wave; the (up to 16) group totals, padded with +0, are prefix-summed by
+     * the same Kogge-Stone network on one row of 16 lanes (offsets 1, 2, 4, 8; lanes without a source add +0); c_i = P[g - 1] + local_i (g > 0) */
+    REAL loc[1024], tot[16], o16[16];
+    const int ng = (N + 63) / 64;
+    for (int k = 0; k < 16; ++k) tot[k] = 0;
+    for (int g = 0; g < ng; ++g) {
         REAL t[64], o[64];
         const int n = N - g * 64 < 64 ? N - g * 64 : 64;
         for (int i = 0; i < 64; ++i) t[i] = i < n ? w[g * 64 + i] : (REAL)0;
@@ -363,20 +373,25 @@ static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) {
         memcpy(t, o, sizeof t);
         for (int i = 0; i < 64; ++i) o[i] = t[i] + (i >= 32 ? t[31] : (REAL)0);                   /* row_bcast:31, rows 2 and 3 */
         memcpy(t, o, sizeof t);
-        for (int i = 0; i < n; ++i) c[g * 64 + i] = g == 0 ? t[i] : pre + t[i];
-        pre = g == 0 ? t[63] : pre + t[63];
+        for (int i = 0; i < n; ++i) loc[g * 64 + i] = t[i];
+        tot[g] = t[63];
     }
+    for (int off = 1; off < 16; off <<= 1) {
+        for (int k = 0; k < 16; ++k) o16[k] = tot[k] + (k >= off ? tot[k - off] : (REAL)0);
+        memcpy(tot, o16, sizeof tot);
+    }
+    for (int i = 0; i < N; ++i) c[i] = i < 64 ? loc[i] : tot[i / 64 - 1] + loc[i];
 }
-/* conditional-multinomial ancestor of one particle: two-level search */
+/* conditional-multinomial ancestor of one particle: branch-free lower bound by descent over the whole cumulative-weight array (contract v3) --
+ * pos = 0; for s = S0, S0/2, ..., 1 (S0 = the largest power of two below N): if (pos + s - 1 < N and c[pos + s - 1] < r) pos += s; clipped to N - 1.
+ * On a non-decreasing c this IS searchsorted(c, r, side='left') of resamplings.py:35-36 -> jax.random.choice. */
 static int SUF(choice2)(const REAL* c, int N, REAL un) {
     const REAL r = c[N - 1] * ((REAL)1 - un);
-    const int ng = (N + 63) / 64;
-    int g = 0;
-    for (int k = 0; k < ng - 1; ++k) g += c[64 * k + 63] < r;
-    const int end = 64 * g + 64 < N ? 64 * g + 64 : N;
-    int pos = 64 * g; /* number of entries of the group below r, by descent: six probes, no data-dependent branch on the device */
-    for (int s = 32; s > 0; s >>= 1)
-        if (pos + s - 1 < end && c[pos + s - 1] < r) pos += s;
+    int s0 = 1;
+    while (s0 * 2 < N) s0 *= 2;
+    int pos = 0;
+    for (int s = s0; s > 0; s >>= 1)
+        if (pos + s - 1 < N && c[pos + s - 1] < r) pos += s;
     return pos < N - 1 ? pos : N - 1;
 }
 /* the single draw of the backward pass: count of the cumulative weights below r */
@@ -388,11 +403,12 @@ static int SUF(choice_count)(const REAL* c, int N, REAL un) {
 }
 
 /* ---- time-varying transitions and gradient-informed proposals (csmc/independent.py:57-75 gradient=True, :121-134, :173-190, :252-268) ---- */
-typedef struct { REAL F[MAXD * MAXD], b[MAXD], LQ[MAXD * MAXD], c_trans; } SUF(trans);
+typedef struct { REAL F[MAXD * MAXD], b[MAXD], LQ[MAXD * MAXD], iLQ[MAXD], c_trans; } SUF(trans);
 static void SUF(trans_at)(const SUF(fk) * m, const fk_model* g, long t, SUF(trans) * tr) {
     const int D = m->D;
     if (!g->F_t) {
         memcpy(tr->F, m->F, sizeof tr->F); memcpy(tr->b, m->b, sizeof tr->b); memcpy(tr->LQ, m->LQ, sizeof tr->LQ);
+        memcpy(tr->iLQ, m->iLQ, sizeof tr->iLQ);
         tr->c_trans = m->c_trans;
         return;
     }
@@ -405,7 +421,7 @@ static void SUF(trans_at)(const SUF(fk) * m, const fk_model* g, long t, SUF(tran
             tr->LQ[i * MAXD + j] = (REAL)g->LQ_t[(t * D + i) * D + j];
         }
     }
-    for (int k = 0; k < D; ++k) c -= LOG(tr->LQ[k * MAXD + k]);
+    for (int k = 0; k < D; ++k) { c -= LOG(tr->LQ[k * MAXD + k]); tr->iLQ[k] = (REAL)1 / tr->LQ[k * MAXD + k]; }
     tr->c_trans = c - (REAL)D * (REAL)0.91893853320467274178;
 }
 static void SUF(tmean_t)(const SUF(fk) * m, const SUF(trans) * tr, const REAL* xp, REAL* mu) {
@@ -531,7 +547,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
         if (i == 0) for (int k = 0; k < D; ++k) xi[k] = x[k];
         REAL gq = SUF(pot)(&m, xi, y ? y : zero);
         if (m.proposal == 1) {
-            gq = gq + SUF(gauss)(D, xi, m.m0, m.LP0, m.c_init);
+            gq = gq + SUF(gauss)(D, xi, m.m0, m.LP0, m.iLP0, m.c_init);
             if (g->gradient) gq = gq + SUF(grad_corr)(D, xi, u, pm, shd[0]);
         }
         lws[i] = gq;
@@ -579,7 +595,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             if (m.proposal == 1) {
                 REAL mu[MAXD];
                 SUF(tmean_t)(&m, &tr, xp, mu);
-                gq = SUF(gauss)(D, xi, mu, tr.LQ, tr.c_trans) + gq;
+                gq = SUF(gauss)(D, xi, mu, tr.LQ, tr.iLQ, tr.c_trans) + gq;
                 if (g->gradient == 2) gq = gq + SUF(grad_corr)(D, xi, u + t * D, pm, shd[t]);
             }
             lw[i] = gq;
@@ -611,7 +627,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             for (int i = 0; i < N; ++i) {
                 REAL mu[MAXD];
                 SUF(tmean_t)(&m, &tr, xs + ((size_t)t * N + i) * D, mu);
-                lw[i] = SUF(gauss)(D, xn, mu, tr.LQ, tr.c_trans) + lws[(size_t)t * N + i];
+                lw[i] = SUF(gauss)(D, xn, mu, tr.LQ, tr.iLQ, tr.c_trans) + lws[(size_t)t * N + i];
             }
             /* sweep contract: weights shifted by a bound of their maximum (forward block maximum + log-normaliser of the transition density);
                the exact maximum only when every weight underflowed */
@@ -681,7 +697,7 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
         REAL mx;
         for (int n = 0; n < N; ++n) {
             REAL gq = SUF(pot)(&m, xs + (size_t)n * D, y ? y : zero);
-            g0[n] = gq + SUF(gauss)(D, xs + (size_t)n * D, m.m0, m.LP0, m.c_init);
+            g0[n] = gq + SUF(gauss)(D, xs + (size_t)n * D, m.m0, m.LP0, m.iLP0, m.c_init);
         }
         mx = g0[0];
         for (int n = 1; n < N; ++n) mx = mx > g0[n] ? mx : g0[n];

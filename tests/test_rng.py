@@ -37,5 +37,5 @@ def test_device_fill_vs_oracle(dtype):
     n = 100_000
     npt.assert_array_equal(h.rng_uniform(key, 5, (n,), dtype).to_host(), O.uniform(key, 5, n, dtype))
     z = h.rng_normal(key, 9, (n,), dtype).to_host()
-    npt.assert_allclose(z, O.normal(key, 9, n, dtype), rtol=2e-5 if dtype == np.float32 else 1e-12, atol=2e-6 if dtype == np.float32 else 1e-13)
+    npt.assert_allclose(z, O.normal(key, 9, n, dtype), rtol=2e-5 if dtype == np.float32 else 1e-12, atol=4e-6 if dtype == np.float32 else 1e-13)
     assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02
