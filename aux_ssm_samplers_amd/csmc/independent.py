@@ -6,6 +6,8 @@ parallel=False: the classical sequential sweep (independent.py:57-75, auxssm_csm
 (conditional dSMC, independent.py:78-118 on _primitives/csmc/pit, auxssm_csmc_pit_sweep: log2(T) stitching launches instead of T
 sequential steps; `backward` / `Pt` are unused there, as in the reference).
 
+gradient=True with parallel=True: the proposals are shifted the same way and every leaf carries the importance weight qt.logpdf - mt.logpdf
+(independent.py:81-84, pit/csmc.py:83-88), per particle; time-varying dynamics are read row by row in both sweeps.
 gradient=True (classical sweep): proposals N(u_t + delta_t/2 grad_t, delta_t/2 I) with grad the gradient at u of the model's joint
 log-density (independent.py:121-134), which the reference gets from jax.grad and the device kernel evaluates in closed form for the
 model family (csrc/csmc.hip::k_csmc_grad).  gradient=True follows the reference to the letter: the importance correction of the shifted
@@ -19,8 +21,8 @@ from . import _device
 from .generic import get_kernel as get_base_kernel, IndependentFactory
 
 
-def _get_parallel_kernel(M0, G0, Mt, Gt, N):
-    fk = _device.describe_independent(M0, G0, Mt, Gt, None)
+def _get_parallel_kernel(M0, G0, Mt, Gt, N, gmode=0):
+    fk = _device.describe_independent(M0, G0, Mt, Gt, None, gmode)
 
     def kernel(key, state, delta, noise=None):
         if isinstance(state.x, _device.CsmcChains):  # resident chains: in place, asynchronous; delta None = the chains' device delta
@@ -46,9 +48,9 @@ def get_kernel(M0, G0, Mt, Gt, N, backward=False, Pt=None, gradient=False, paral
         raise ValueError("gradient must be False, True (the reference's weights) or 'exact'")
     gmode = _lib.GRAD_NONE if not gradient else (_lib.GRAD_EXACT if gradient == "exact" else _lib.GRAD_REFERENCE)
     if parallel:
-        if gmode:
-            raise NotImplementedError("gradient-informed proposals are built for the sequential sweep (parallel=False)")
-        return _get_parallel_kernel(M0, G0, Mt, Gt, N)
+        # gradient=True here is independent.py:81-84: proposals mt = N(u + delta/2 grad, delta/2 I) weighted by qt.logpdf - mt.logpdf PER PARTICLE
+        # (pit/csmc.py:83-88) -- the parallel kernel has no summed variant, so True and "exact" are the same sampler
+        return _get_parallel_kernel(M0, G0, Mt, Gt, N, gmode)
     if backward and Pt is None:
         Pt = Mt
     return get_base_kernel(IndependentFactory(M0, G0, Mt, Gt, Pt, gmode), N, backward, Pt)

@@ -18,29 +18,6 @@
 
 namespace ax {
 
-// ---- prologue: u = x + sqrt(delta_t/2) eps   (csmc/generic.py:67) ------------------------------------------------------
-template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long total = (long long)a.C * a.T * D;
-    if (g >= total) return;
-    const long long t = (g / D) % a.T;
-    const R e = noise_normal<R>(a, a.eps_aux, STREAM_EPS_AUX, g);
-    ((R*)a.u)[g] = fma_(((const R*)a.shd)[t], e, ((const R*)a.x)[g]);
-}
-
-// additive constants of time-varying transition densities: ct[t] = -sum_k log LQ_t[k][k] - D/2 log 2 pi
-template <typename R, int D> __global__ void k_csmc_ctrans(int n, const R* __restrict__ LQt, R* __restrict__ ct, R* __restrict__ idt) {
-    const int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n) return;
-    R c = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const R l = LQt[((long long)t * D + k) * D + k];
-        c -= det_log(l);
-        idt[(long long)t * D + k] = (R)1 / l;  // reciprocal diagonal (sweep contract v3)
-    }
-    ct[t] = c - (R)D * (R)0.91893853320467274178;
-}
 // gb[t] = sup_x G_t(x): the reduction-free part of the forward weights' shift (sweep contract, csmc_dev.h); +inf where the potential is unbounded
 template <typename R, int D> __global__ void k_csmc_potbound(int T, FkDev<R> m, const R* __restrict__ y, R* __restrict__ gb) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -63,108 +40,6 @@ template <typename R, int D> __global__ void k_csmc_potbound(int T, FkDev<R> m, 
     }
     gb[t] = b;
 }
-// w <- (L L^T)^-1 r, L lower with leading dimension ld; fixed operation order (restated by oracle/csmc_ref.c::cho_solve_)
-template <typename R, int D> __device__ __forceinline__ void cho_solve_fixed(const R* L, int ld, const R* r, R* w) {
-    R z[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        R acc = r[k];
-#pragma unroll
-        for (int j = 0; j < k; ++j) acc = fma_(-L[k * ld + j], z[j], acc);
-        z[k] = acc / L[k * ld + k];
-    }
-#pragma unroll
-    for (int k = D - 1; k >= 0; --k) {
-        R acc = z[k];
-#pragma unroll
-        for (int j = k + 1; j < D; ++j) acc = fma_(-L[j * ld + k], w[j], acc);
-        w[k] = acc / L[k * ld + k];
-    }
-}
-// gradient at u of  log M0(u_0) + G0(u_0) + sum_t [log Mt(u_{t+1} | u_t) + Gt(u_{t+1})]  (csmc/independent.py:121-134, jax.grad there),
-// closed form for the model family: one thread per (chain, time step)
-template <typename R, int D> __global__ void k_csmc_grad(CsmcArgs a, FkDev<R> m) {
-    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= (long long)a.C * a.T) return;
-    const long long t = g % a.T;
-    const R* u = (const R*)a.u + g * D;
-    R ut[D], gr[D], r[D], w[D], mu[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) ut[k] = u[k];
-    const R* yv = (const R*)a.y;
-    // potential
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const R y = yv ? yv[t * D + k] : (R)0;
-        R v = 0;
-        if (m.potential == 1 || (m.potential == 3 && y - y == 0)) v = ((y - ut[k]) * m.inv_sig_y) * m.inv_sig_y;
-        else if (m.potential == 2) {
-            const R e = det_exp(-ut[k]);
-            v = (R)0.5 * fma_(y * y, e, (R)-1);
-            v = (v == v) ? v : (R)0;
-        }
-        gr[k] = v;
-    }
-    // density of u_t given the past
-    if (t == 0) {
-#pragma unroll
-        for (int k = 0; k < D; ++k) r[k] = ut[k] - m.m0[k];
-        cho_solve_fixed<R, D>(m.LP0, CS_MAXD, r, w);
-    } else {
-        const TransT<R> tr = trans_at<R, D>(m, t - 1);
-        trans_mean_t<R, D>(m, tr, u - D, mu);
-#pragma unroll
-        for (int k = 0; k < D; ++k) r[k] = ut[k] - mu[k];
-        cho_solve_fixed<R, D>(tr.LQ, tr.ld, r, w);
-    }
-#pragma unroll
-    for (int k = 0; k < D; ++k) gr[k] = gr[k] - w[k];
-    // density of u_{t+1} given u_t:  J(u_t)^T Q^-1 (u_{t+1} - mean(u_t))
-    if (t + 1 < a.T) {
-        const TransT<R> tr = trans_at<R, D>(m, t);
-        trans_mean_t<R, D>(m, tr, ut, mu);
-#pragma unroll
-        for (int k = 0; k < D; ++k) r[k] = u[D + k] - mu[k];
-        cho_solve_fixed<R, D>(tr.LQ, tr.ld, r, w);
-        if constexpr (D == 3) {
-            if (m.transition == 1) {  // Lorenz-63: J = I + dt dphi/dx (examples/lorenz/model.py:10-25)
-                const R th1 = m.F[0], th2 = m.F[1], th3 = m.F[2], dt = m.b[0];
-                const R J[9] = {-th1, th1, (R)0, th2 - ut[2], (R)-1, -ut[0], ut[1], ut[0], -th3};
-#pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    R acc = 0;
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc = fma_(J[j * 3 + k], w[j], acc);
-                    gr[k] = gr[k] + fma_(dt, acc, w[k]);
-                }
-                goto done;
-            }
-        }
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            R acc = 0;
-#pragma unroll
-            for (int j = 0; j < D; ++j) acc = fma_(tr.F[j * tr.ld + k], w[j], acc);
-            gr[k] = gr[k] + acc;
-        }
-    }
-done:
-#pragma unroll
-    for (int k = 0; k < D; ++k) ((R*)a.grad)[g * D + k] = gr[k];
-}
-
-// sum_k [log N(x_k; u_k, s) - log N(x_k; pm_k, s)] = sum_k ((x_k - pm_k)^2 - (x_k - u_k)^2) / (2 s^2)   (independent.py:184-189)
-template <typename R, int D> __device__ __forceinline__ R grad_correction(const R* x, const R* u, const R* pm, R s) {
-    R acc = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        const R d1 = x[k] - u[k], d2 = x[k] - pm[k];
-        acc = fma_(d2, d2, acc);
-        acc = fma_(-d1, d1, acc);
-    }
-    return acc * ((R)0.5 / (s * s));
-}
-
 // Diagnostic builds only (tools/csmc_ablate.sh): -DAUXSSM_CSMC_ABLATE=<mask> removes one phase of the forward step at a time (wrong results, right
 // shape) to attribute its time: 1 search, 2 in-kernel draws, 4 potential / transition log-density, 8 max + exp, 16 cumsum; 32: max + exp of the
 // BACKWARD pass.  0 in the product.

@@ -36,6 +36,11 @@ struct PitArgs {
     void* x;          // (C, T, D) reference trajectory in, new trajectory out
     void* xs;         // (C, T, N, D) leaf particles
     void* lw0;        // (C, N) normalised log-weights of the leaf at t = 0
+    // gradient-informed proposals (csmc/independent.py:81-84: mt = N(u + delta/2 grad, delta/2 I), qt = N(u, delta/2 I); pit/csmc.py:83-88: the leaf
+    // weights are qt.logpdf - mt.logpdf, per particle): u, grad (C, T, D) and the normalised leaf log-weights of EVERY time step, lwt (C, T, N); null otherwise
+    const void* u;
+    const void* grad;
+    void* lwt;
     uint16_t* Ls;     // (C, tot, N) left slot of each stitched pair, nodes of all levels back to back (off[k] = first node of level k)
     uint16_t* Rs;     // (C, tot, N) right slot
     uint16_t* Fi;     // (C, tot, N) leaf particle index at the node's first time step
@@ -85,49 +90,49 @@ template <typename R> __device__ __forceinline__ R block_lognormalize(R lw, R* r
 
 // leaves: u = x + sqrt(delta/2) eps_aux (csmc/independent.py:101-102); particles ~ N(u_t, delta_t/2 I), slot 0 = x (pit/csmc.py:77-80);
 // weights 0 except G0 at t = 0, normalised per time step (:85-91).  One workgroup per (t, chain), one lane per particle.
-template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_leaves(PitArgs a, FkDev<R> m) {
+template <typename R, int D, bool GRAD> __global__ void __launch_bounds__(1024) k_pit_leaves(PitArgs a, FkDev<R> m) {
     __shared__ R red[48];
     const int t = blockIdx.x, c = blockIdx.y, tid = threadIdx.x, N = a.N, T = a.T;
     const bool live = tid < N;
     const long long ct = (long long)c * T + t;
     const R sh = ((const R*)a.shd)[t];
-    R x[D];
+    R x[D], uu[D], pm[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const R xr = ((const R*)a.x)[ct * D + k];
-        const R uu = fma_(sh, pit_normal<R>(a, a.eps_aux, STREAM_EPS_AUX, ct * D + k), xr);
+        if constexpr (GRAD) {  // u was formed by k_csmc_aux (the gradient kernel reads it), the proposal mean is shifted by delta_t / 2 grad_t
+            uu[k] = ((const R*)a.u)[ct * D + k];
+            pm[k] = fma_(sh * sh, ((const R*)a.grad)[ct * D + k], uu[k]);
+        } else {
+            uu[k] = fma_(sh, pit_normal<R>(a, a.eps_aux, STREAM_EPS_AUX, ct * D + k), xr);
+            pm[k] = uu[k];
+        }
         const R e = live ? pit_normal<R>(a, a.eps_prop, STREAM_EPS_PROP, (ct * N + tid) * D + k) : (R)0;
-        x[k] = tid == 0 ? xr : fma_(sh, e, uu);
+        x[k] = tid == 0 ? xr : fma_(sh, e, pm[k]);
     }
     if (live) {
 #pragma unroll
         for (int k = 0; k < D; ++k) ((R*)a.xs)[(ct * N + tid) * D + k] = x[k];
     }
-    if (t != 0) return;
-    R y0[D];
+    if (!GRAD && t != 0) return;
+    R g = 0;
+    if constexpr (GRAD) g = grad_correction<R, D>(x, uu, pm, sh);  // qt.logpdf(x) - mt.logpdf(x) (pit/csmc.py:84-85), slot 0 included
+    if (t == 0) {
+        R y0[D];
 #pragma unroll
-    for (int k = 0; k < D; ++k) y0[k] = a.y ? ((const R*)a.y)[k] : (R)0;
-    R g = potential<R, D>(m, x, y0);
-    g = g + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.iLP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+        for (int k = 0; k < D; ++k) y0[k] = a.y ? ((const R*)a.y)[k] : (R)0;
+        R g0 = potential<R, D>(m, x, y0);
+        g0 = g0 + gauss_chol_logpdf<R, D>(x, m.m0, m.LP0, m.iLP0, m.c_init);  // AuxiliaryG0 (independent.py:163-169)
+        g = GRAD ? g + g0 : g0;                                               // log_wts.at[0].add(log_w0) (pit/csmc.py:90-91)
+    }
     const R lw = block_lognormalize<R>(live ? g : (R)-INFINITY, red, tid, (N + 63) >> 6);
-    if (live) ((R*)a.lw0)[(long long)c * N + tid] = lw;
+    if (live) {
+        if constexpr (GRAD) ((R*)a.lwt)[ct * N + tid] = lw;
+        else ((R*)a.lw0)[(long long)c * N + tid] = lw;
+    }
 }
 
 constexpr int PIT_SC = 8;  // sub-chunks per chunk (arithmetic contract, see the header)
-
-template <typename R, int D> __device__ __forceinline__ R gauss_r(const R* x, const R* mean, const R* L, const R* iL, R cst) {
-    R z[D];
-    R q = 0;
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        R acc = x[k] - mean[k];
-#pragma unroll
-        for (int j = 0; j < k; ++j) acc = fma_(-L[k * CS_MAXD + j], z[j], acc);
-        z[k] = acc * iL[k];
-        q = fma_(z[k], z[k], q);
-    }
-    return fma_((R)-0.5, q, cst);
-}
 
 // the stitch of node j at level k (see the header); grid (nodes of the level, chains), NCH lanes
 template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitch(PitArgs a, FkDev<R> m, int k) {
@@ -157,9 +162,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitc
     const uint16_t* fi_right = kb >= 0 ? a.Fi + (chain_nodes + a.off[kb] + jb) * N : nullptr;
     const uint16_t* la_right = kb >= 0 ? a.La + (chain_nodes + a.off[kb] + jb) * N : nullptr;
     const R nln = (R)a.neg_log_n;
-    R iL[D];
-#pragma unroll
-    for (int q = 0; q < D; ++q) iL[q] = (R)1 / m.LQ[q * CS_MAXD + q];
+    const TransT<R> tr = trans_at<R, D>(m, mid - 1);  // the transition across the boundary (time-varying: row mid - 1 of the device arrays)
     if (tid < N) {
         const int ia = la_left ? la_left[tid] : tid;
         const int ib = fi_right ? fi_right[tid] : tid;
@@ -172,14 +175,23 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitc
             xr[q] = xv[q];
             yv[q] = a.y ? ((const R*)a.y)[mid * D + q] : (R)0;
         }
-        trans_mean<R, D>(m, xl, mm);
+        trans_mean_t<R, D>(m, tr, xl, mm);
 #pragma unroll
         for (int q = 0; q < D; ++q) {
             mu[tid * D + q] = mm[q];
             xb[tid * D + q] = xr[q];
         }
-        pg[tid] = potential<R, D>(m, xr, yv) + nln;
-        hh[tid] = mid == 1 ? ((const R*)a.lw0)[(long long)c * N + ia] : nln;
+        // the log-weights the two blocks bring: -log N once a block has been stitched (operator.py:106-108), the LEAF's own while it is a single time step --
+        // the left block at level 0, the right one when no level below stitched it (kb < 0)
+        R wl = nln, wr = nln;
+        if (a.lwt) {
+            if (k == 0) wl = ((const R*)a.lwt)[((long long)c * T + mid - 1) * N + ia];
+            if (kb < 0) wr = ((const R*)a.lwt)[((long long)c * T + mid) * N + ib];
+        } else if (mid == 1) {
+            wl = ((const R*)a.lw0)[(long long)c * N + ia];
+        }
+        pg[tid] = potential<R, D>(m, xr, yv) + wr;
+        hh[tid] = wl;
     }
     __syncthreads();
     const long long NN = (long long)N * N;
@@ -193,7 +205,7 @@ template <typename R, int D> __global__ void __launch_bounds__(1024) k_pit_stitc
             xj[q] = xb[jj * D + q];
             mi[q] = mu[i * D + q];
         }
-        return (gauss_r<R, D>(xj, mi, m.LQ, iL, m.c_trans) + pg[jj]) + hh[i];
+        return (gauss_chol_logpdf<R, D>(xj, mi, tr.LQ, tr.iL, tr.c_trans, tr.ld) + pg[jj]) + hh[i];
     };
     // pass 1: max
     R vmax = -INFINITY;
@@ -305,11 +317,31 @@ template <typename R> __global__ void k_pit_trace(PitArgs a, int D) {
     for (int kk = 0; kk < D; ++kk) ((R*)a.x)[g * D + kk] = ((const R*)a.xs)[(g * a.N + q) * D + kk];
 }
 
-template <typename R, int D> static int run_pit(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host_model, PitArgs& a) {
+template <typename R, int D> static int run_pit(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host_model, PitArgs& a, void* ctt) {
     FkDev<R> m;
     fill_model<R>(m, fk, host_model);
+    m.gradient = fk->gradient;
     const int TB = (a.N + 63) / 64 * 64;
-    hipLaunchKernelGGL((k_pit_leaves<R, D>), dim3(a.T, a.C), dim3(TB), 0, h->stream, a, m);
+    if (fk->F_t) {  // time-varying transitions (csmc.py:103 scans Mt.params; here AuxiliaryGt's Mt, independent.py:238-248)
+        m.Ft = (const R*)fk->F_t;
+        m.bt = (const R*)fk->b_t;
+        m.LQt = (const R*)fk->chol_Q_t;
+        m.ctt = (const R*)ctt;
+        m.idt = (const R*)ctt + (a.T - 1);
+        hipLaunchKernelGGL((k_csmc_ctrans<R, D>), dim3((a.T - 1 + 255) / 256), dim3(256), 0, h->stream, a.T - 1, m.LQt, (R*)ctt, (R*)ctt + (a.T - 1));
+    }
+    if (fk->gradient) {  // u and the gradient of the model's joint log-density at u (independent.py:82, :121-134): the sequential sweep's kernels
+        CsmcArgs ca{};
+        ca.C = a.C; ca.T = a.T; ca.N = a.N;
+        ca.y = a.y; ca.shd = a.shd; ca.x = a.x; ca.u = const_cast<void*>(a.u); ca.grad = const_cast<void*>(a.grad);
+        ca.noise_mode = a.noise_mode; ca.key0 = a.key0; ca.key1 = a.key1; ca.eps_aux = a.eps_aux;
+        const long long total = (long long)a.C * a.T * D, tot = (long long)a.C * a.T;
+        hipLaunchKernelGGL((k_csmc_aux<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, ca, D);
+        hipLaunchKernelGGL((k_csmc_grad<R, D>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, ca, m);
+        hipLaunchKernelGGL((k_pit_leaves<R, D, true>), dim3(a.T, a.C), dim3(TB), 0, h->stream, a, m);
+    } else {
+        hipLaunchKernelGGL((k_pit_leaves<R, D, false>), dim3(a.T, a.C), dim3(TB), 0, h->stream, a, m);
+    }
     const int NCH = a.N <= 32 ? 64 : (a.N <= 128 ? 256 : 1024);  // part of the arithmetic contract (header)
     const size_t lds = ((size_t)a.N * (2 * D + 2) + NCH + 48 + (size_t)PIT_SC * NCH) * sizeof(R) + 64;
     if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_pit_stitch<R, D>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -359,9 +391,17 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
         set_error("the parallel-in-time sweep needs proposals that are independent across time: AUXSSM_PROP_AUX_INDEPENDENT");
         return AUXSSM_ERR_ARG;
     }
-    if (fk->F_t || fk->b_t || fk->chol_Q_t || fk->gradient) {
-        set_error("time-varying transitions and gradient-informed proposals are built for the sequential sweep (auxssm_csmc_sweep) only");
-        return AUXSSM_ERR_UNSUPPORTED;
+    if ((fk->F_t || fk->b_t || fk->chol_Q_t) && !(fk->F_t && fk->b_t && fk->chol_Q_t)) {
+        set_error("time-varying transitions need all of F_t, b_t, chol_Q_t (device arrays with T - 1 rows)");
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->F_t && fk->transition != AUXSSM_TRANS_LINEAR) {
+        set_error("time-varying transitions are linear-Gaussian");
+        return AUXSSM_ERR_ARG;
+    }
+    if (fk->gradient != AUXSSM_GRAD_NONE && fk->gradient != AUXSSM_GRAD_REFERENCE && fk->gradient != AUXSSM_GRAD_EXACT) {
+        set_error("unknown gradient mode %d", fk->gradient);
+        return AUXSSM_ERR_ARG;
     }
     if (fk->potential < AUXSSM_POT_FLAT || fk->potential > AUXSSM_POT_GAUSS_OBS_MASKED) {
         set_error("unknown potential kind %d", fk->potential);
@@ -414,6 +454,8 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
     const size_t CT = (size_t)C * T;
     const size_t tree = (size_t)C * tot * N * sizeof(uint16_t);
     size_t need = 8192 + CT * N * D * sR + (size_t)C * N * sR + 4 * (tree + 256);
+    if (fk->gradient) need += 2 * (CT * D * sR + 256) + CT * N * sR + 256;  // u, grad, the leaf log-weights of every time step
+    if (fk->F_t) need += (size_t)T * (1 + D) * sR + 256;
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     a.y = fk->y;
@@ -421,6 +463,14 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
     a.x = x;
     a.xs = ws_take(h, CT * N * D * sR);
     a.lw0 = ws_take(h, (size_t)C * N * sR);
+    if (fk->gradient) {  // (in the parallel kernel the correction is per particle in either mode: pit/csmc.py:83-88 has no summed variant)
+        a.u = ws_take(h, CT * D * sR);
+        a.grad = ws_take(h, CT * D * sR);
+        a.lwt = ws_take(h, CT * N * sR);
+        if (!a.u || !a.grad || !a.lwt) return AUXSSM_ERR_NOMEM;
+    }
+    void* ctt = fk->F_t ? ws_take(h, (size_t)T * (1 + D) * sR) : nullptr;
+    if (fk->F_t && !ctt) return AUXSSM_ERR_NOMEM;
     a.Ls = (uint16_t*)ws_take(h, tree);
     a.Rs = (uint16_t*)ws_take(h, tree);
     a.Fi = (uint16_t*)ws_take(h, tree);
@@ -432,10 +482,10 @@ extern "C" int auxssm_csmc_pit_sweep(auxssm_handle h, int dtype, const auxssm_fk
     if (!a.xs || !a.lw0 || !a.Ls || !a.Rs || !a.Fi || !a.La) return AUXSSM_ERR_NOMEM;
 #define AX_PIT_D(R)                                                    \
     switch (D) {                                                       \
-        case 1: return run_pit<R, 1>(h, fk, hm.data(), a);             \
-        case 2: return run_pit<R, 2>(h, fk, hm.data(), a);             \
-        case 3: return run_pit<R, 3>(h, fk, hm.data(), a);             \
-        default: return run_pit<R, 4>(h, fk, hm.data(), a);            \
+        case 1: return run_pit<R, 1>(h, fk, hm.data(), a, ctt);             \
+        case 2: return run_pit<R, 2>(h, fk, hm.data(), a, ctt);             \
+        case 3: return run_pit<R, 3>(h, fk, hm.data(), a, ctt);             \
+        default: return run_pit<R, 4>(h, fk, hm.data(), a, ctt);            \
     }
     if (dtype == AUXSSM_F32) { AX_PIT_D(float) } else { AX_PIT_D(double) }
 #undef AX_PIT_D

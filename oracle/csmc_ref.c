@@ -653,16 +653,6 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
  * evaluated node by node with FULL block gathers, exactly as the reference's operator does (trajectories, origins and weights of a
  * whole block are re-indexed at every stitch); the HIP kernels (csrc/pit.hip) keep only boundary indices and must give the same
  * trajectory and origins.  Arithmetic contract: see the header of csrc/pit.hip. */
-static REAL SUF(gauss_r)(int D, const REAL* x, const REAL* mean, const REAL* L, const REAL* iL, REAL cst) {
-    REAL z[MAXD], q = 0;
-    for (int k = 0; k < D; ++k) {
-        REAL acc = x[k] - mean[k];
-        for (int j = 0; j < k; ++j) acc = FMA(-L[k * MAXD + j], z[j], acc);
-        z[k] = acc * iL[k];
-        q = FMA(z[k], z[k], q);
-    }
-    return FMA((REAL)-0.5, q, cst);
-}
 /* x (T,D) in/out; y (T,D) or NULL; shd (T); eps_aux (T,D); eps_prop (T,N,D); u_res (T,N); outputs anc (T) and, if non-NULL,
  * xs (T,N,D) the leaf particles.  T >= 2. */
 int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y, const REAL* shd, const REAL* eps_aux,
@@ -678,35 +668,47 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
     int32_t* ot = (int32_t*)malloc(sizeof(int32_t) * TN);
     REAL zero[MAXD] = {0, 0, 0, 0};
     const REAL nln = -LOG((REAL)N);
-    REAL iL[MAXD];
-    for (int q = 0; q < D; ++q) iL[q] = (REAL)1 / m.LQ[q * MAXD + q];
-    /* leaves (pit/csmc.py:77-96) */
+    /* leaves (pit/csmc.py:77-96).  Gradient-informed proposals (csmc/independent.py:81-84): mt = N(u + delta/2 grad, delta/2 I) proposes, qt = N(u, delta/2 I)
+     * is the target's factor, so every leaf carries log_wts = qt.logpdf - mt.logpdf (pit/csmc.py:83-88) -- per particle, slot 0 included. */
+    REAL* uall = (REAL*)malloc(sizeof(REAL) * (size_t)T * D);
+    REAL* grad = (REAL*)malloc(sizeof(REAL) * (size_t)T * D);
+    for (int t = 0; t < T; ++t)
+        for (int k = 0; k < D; ++k) uall[t * D + k] = FMA(shd[t], eps_aux[t * D + k], x[t * D + k]);
+    if (g->gradient) SUF(grad_logpi)(&m, g, T, uall, y, grad);
     for (int t = 0; t < T; ++t)
         for (int n = 0; n < N; ++n) {
+            REAL pm[MAXD];
             for (int k = 0; k < D; ++k) {
-                const REAL uu = FMA(shd[t], eps_aux[t * D + k], x[t * D + k]);
-                xs[((size_t)t * N + n) * D + k] = n == 0 ? x[t * D + k] : FMA(shd[t], eps_prop[((size_t)t * N + n) * D + k], uu);
+                pm[k] = g->gradient ? FMA(shd[t] * shd[t], grad[t * D + k], uall[t * D + k]) : uall[t * D + k];
+                xs[((size_t)t * N + n) * D + k] = n == 0 ? x[t * D + k] : FMA(shd[t], eps_prop[((size_t)t * N + n) * D + k], pm[k]);
             }
             org[(size_t)t * N + n] = n;
-            lw[(size_t)t * N + n] = nln;
+            lw[(size_t)t * N + n] = g->gradient ? SUF(grad_corr)(D, xs + ((size_t)t * N + n) * D, uall + t * D, pm, shd[t]) : nln;
         }
     if (xs_out) memcpy(xs_out, xs, sizeof(REAL) * TN * D);
     {
         REAL* g0 = (REAL*)malloc(sizeof(REAL) * N);
         REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
-        REAL mx;
-        for (int n = 0; n < N; ++n) {
-            REAL gq = SUF(pot)(&m, xs + (size_t)n * D, y ? y : zero);
-            g0[n] = gq + SUF(gauss)(D, xs + (size_t)n * D, m.m0, m.LP0, m.iLP0, m.c_init);
+        for (int t = 0; t < (g->gradient ? T : 1); ++t) { /* normalise per time step (:91); without gradients the rows t >= 1 are -log N already */
+            REAL mx;
+            for (int n = 0; n < N; ++n) {
+                g0[n] = g->gradient ? lw[(size_t)t * N + n] : (REAL)0;
+                if (t == 0) {
+                    REAL gq = SUF(pot)(&m, xs + (size_t)n * D, y ? y : zero);
+                    gq = gq + SUF(gauss)(D, xs + (size_t)n * D, m.m0, m.LP0, m.iLP0, m.c_init);
+                    g0[n] = g->gradient ? g0[n] + gq : gq;
+                }
+            }
+            mx = g0[0];
+            for (int n = 1; n < N; ++n) mx = mx > g0[n] ? mx : g0[n];
+            if (!(mx - mx == 0)) mx = 0;
+            for (int n = 0; n < N; ++n) tmp[n] = EXP(g0[n] - mx);
+            const REAL lse = LOG(SUF(sum)(tmp, N)) + mx;
+            for (int n = 0; n < N; ++n) lw[(size_t)t * N + n] = g0[n] - lse;
         }
-        mx = g0[0];
-        for (int n = 1; n < N; ++n) mx = mx > g0[n] ? mx : g0[n];
-        if (!(mx - mx == 0)) mx = 0;
-        for (int n = 0; n < N; ++n) tmp[n] = EXP(g0[n] - mx);
-        const REAL lse = LOG(SUF(sum)(tmp, N)) + mx;
-        for (int n = 0; n < N; ++n) lw[n] = g0[n] - lse;
         free(g0); free(tmp);
     }
+    free(uall); free(grad);
     int K = 0;
     while ((1 << K) < T) ++K;
     const long long NN = (long long)N * N;
@@ -730,12 +732,14 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
             const REAL* xa = xs + (size_t)(mid - 1) * N * D;
             const REAL* xb = xs + (size_t)mid * N * D;
             const REAL* yv = y ? y + (size_t)mid * D : zero;
+            SUF(trans) tr;
+            SUF(trans_at)(&m, g, mid - 1, &tr); /* the transition across the boundary (time-varying: row mid - 1) */
             for (int n = 0; n < N; ++n) {
-                SUF(tmean)(&m, xa + (size_t)n * D, mu + (size_t)n * D);
+                SUF(tmean_t)(&m, &tr, xa + (size_t)n * D, mu + (size_t)n * D);
                 pg[n] = SUF(pot)(&m, xb + (size_t)n * D, yv) + lw[(size_t)mid * N + n];
             }
             const REAL* ha = lw + (size_t)(mid - 1) * N;
-#define PIT_V(i, j) ((SUF(gauss_r)(D, xb + (size_t)(j) * D, mu + (size_t)(i) * D, m.LQ, iL, m.c_trans) + pg[j]) + ha[i])
+#define PIT_V(i, j) ((SUF(gauss)(D, xb + (size_t)(j) * D, mu + (size_t)(i) * D, tr.LQ, tr.iLQ, tr.c_trans) + pg[j]) + ha[i])
             REAL vmax = -INFINITY;
             for (long long p = 0; p < NN; ++p) { const REAL v = PIT_V(p / N, p % N); vmax = v > vmax ? v : vmax; }
             if (!(vmax - vmax == 0)) vmax = 0;

@@ -220,7 +220,78 @@ def test_time_varying_and_gradient_argument_checks():
     fk = _device.describe_bootstrap(M0, FlatPotential(), Mt, FlatPotential(), Mt)
     with pytest.raises(ValueError):  # 3 transition rows need T = 4
         _device.sweep(fk, np.zeros((6, 1), np.float32), 8, False, key=0)
-    with pytest.raises(NotImplementedError):
-        get_independent_kernel(M0, FlatPotential(), Mt, FlatPotential(), N=8, gradient=True, parallel=True)
+    init, kern = get_independent_kernel(M0, FlatPotential(), Mt, FlatPotential(), N=8, gradient=True, parallel=True)  # (round 3: built)
+    assert callable(kern)
     with pytest.raises(ValueError):
         get_independent_kernel(M0, FlatPotential(), Mt, FlatPotential(), N=8, gradient="maybe")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d,N,T", [(1, 32, 9), (1, 64, 37), (2, 100, 33), (3, 256, 20), (4, 33, 16)])
+@pytest.mark.parametrize("potential", [O.POT_FLAT, O.POT_GAUSS_OBS, O.POT_SV])
+@pytest.mark.parametrize("gradient", [False, True])
+@pytest.mark.parametrize("tv", [False, True])
+def test_parallel_in_time_sweep_with_gradient_proposals_and_time_varying_transitions(dtype, d, N, T, potential, gradient, tv):
+    """csmc/independent.py:78-118 with gradient=True (proposals mt = N(u + delta/2 grad, delta/2 I), leaf weights qt.logpdf - mt.logpdf:
+    pit/csmc.py:83-91) and / or transitions read row by row: the tree kernels of csrc/pit.hip against the block-gathering oracle, bit for bit."""
+    if not gradient and not tv:
+        pytest.skip("covered by tests/test_gpu_pit.py")
+    from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics
+    from aux_ssm_samplers_amd import _lib
+    rng = np.random.default_rng(11 * d + N + T + potential)
+    M0 = GaussianInit(m0=0.1 * rng.standard_normal(d), P0=2.0 * np.eye(d))
+    if tv:
+        F, b, Q = _tv_model(T, d, rng)
+        ext = dict(F=F[0], b=b[0], chol_Q=np.linalg.cholesky(Q[0]), F_t=F, b_t=b, chol_Q_t=np.linalg.cholesky(Q))
+    else:
+        A = rng.standard_normal((d, d))
+        F, b, Q = 0.9 * np.eye(d) + 0.05 * rng.standard_normal((d, d)), 0.1 * rng.standard_normal(d), A @ A.T / d + 0.5 * np.eye(d)
+        ext = dict(F=F, b=b, chol_Q=np.linalg.cholesky(Q))
+    Mt = LinearGaussianDynamics(F=F, b=b, Q=Q)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(potential, y)
+    gmode = _lib.GRAD_EXACT if gradient else _lib.GRAD_NONE
+    fk = _device.describe_independent(M0, G0, Mt, Gt, None, gmode)
+    x0 = rng.standard_normal((T, d)).astype(dtype)
+    delta = 0.05 + 0.1 * rng.random(T)
+    noise = dict(eps_aux=rng.standard_normal((T, d)), eps_prop=rng.standard_normal((T, N, d)), u_res=rng.random((T, N)))
+    noise = {k: np.asarray(v, dtype) for k, v in noise.items()}
+    x, anc = _device.pit_sweep(fk, x0, N, noise={k: v[None] for k, v in noise.items()}, delta=delta)
+    od = dict(proposal=O.AUX_INDEPENDENT, potential=potential, m0=M0.m0, chol_P0=M0.chol(), sig_y=0.7, gradient=gmode, **ext)
+    ref = O.pit_sweep(od, x0, N, y=y if potential else None, sqrt_half_delta=np.sqrt(0.5 * delta), dtype=dtype, **noise)
+    npt.assert_array_equal(anc, ref["ancestors"])
+    npt.assert_array_equal(x, ref["x"])
+    assert anc.any()
+    if gradient:  # the shifted proposals really are different particles
+        fk0 = _device.describe_independent(M0, G0, Mt, Gt, None)
+        x_ng, _ = _device.pit_sweep(fk0, x0, N, noise={k: v[None] for k, v in noise.items()}, delta=delta)
+        assert np.max(np.abs(x_ng - x)) > 0
+
+
+def test_oracle_parallel_in_time_gradient_kernel_targets_the_smoother():
+    """CPU: the parallel-in-time sweep with gradient-informed proposals (oracle restatement of independent.py:81-84 + pit/csmc.py:83-91) leaves the
+    smoothing distribution of a linear-Gaussian model invariant -- the importance weights qt / mt per particle make up for the shifted proposals."""
+    from tests.test_oracle_pit import _lg, smoother
+    T, N, rho, sig_y, M, B = 6, 8, 0.9, 0.5, 30000, 1000
+    model, xtrue, y = _lg(T, rho, sig_y, seed=3)
+    model = dict(model, gradient=O.GRAD_EXACT)
+    mean, var = smoother(T, rho, sig_y, y[:, 0])
+    rng = np.random.default_rng(0)
+    x = np.zeros((T, 1))
+    acc, acc2, upd = np.zeros(T), np.zeros(T), np.zeros(T)
+    shd = np.full(T, np.sqrt(0.5 * 0.15))  # (a gradient step this model's sharp likelihood, sig_y = 0.5, does not overshoot)
+    for it in range(M):
+        out = O.pit_sweep(model, x, N, y=y, sqrt_half_delta=shd, eps_aux=rng.standard_normal((T, 1)), eps_prop=rng.standard_normal((T, N, 1)),
+                          u_res=rng.random((T, N)), dtype=np.float64)
+        x = out["x"]
+        if it >= B:
+            acc += x[:, 0]
+            acc2 += x[:, 0] ** 2
+            upd += out["ancestors"] != 0
+    n = M - B
+    m_hat = acc / n
+    v_hat = acc2 / n - m_hat ** 2
+    assert upd.min() / n > 0.2
+    npt.assert_allclose(m_hat, mean, atol=0.03)
+    npt.assert_allclose(v_hat, var, rtol=0.08)

@@ -218,8 +218,8 @@ def test_unsupported_python_models_fail_loudly():
     Mt = LinearGaussianDynamics(F=[[0.5]], b=[0.0], Q=[[1.0]])
     with pytest.raises(NotImplementedError):
         get_kernel(M0, FlatPotential(), MyDyn(), FlatPotential(), N=8)
-    with pytest.raises(NotImplementedError):  # gradient proposals exist for the sequential sweep (tests/test_csmc_gradient_timevarying.py)
-        get_independent_kernel(M0, FlatPotential(), Mt, FlatPotential(), 8, gradient=True, parallel=True)
+    # (gradient proposals in the parallel-in-time sweep: built in round 3, tests/test_csmc_gradient_timevarying.py)
+    assert callable(get_independent_kernel(M0, FlatPotential(), Mt, FlatPotential(), 8, gradient=True, parallel=True)[1])
     with pytest.raises(NotImplementedError):
         get_generic_kernel(lambda u, s: None, 8)
     with pytest.raises(ValueError):
