@@ -136,9 +136,16 @@ def describe_independent(M0, G0, Mt, Gt, Pt, gradient=_lib.GRAD_NONE):
     return FkDesc(_lib.PROP_AUX_INDEPENDENT, pot, M0.m0, M0.chol(), F, b, Mt.chol(), y, sig, tk, gradient)
 
 
-def key_noise(handle, key, Cn, T, N, d, dtype):
+def key_noise(handle, key, Cn, T, N, d, dtype, wide=None):
     """The explicit noise arrays a THREEFRY sweep with `key` draws in-kernel (index map: csrc/csmc.hip::k_csmc_fwd): an
-    EXPLICIT sweep on these arrays is bit-identical to the keyed one.  Debug / test utility."""
+    EXPLICIT sweep on these arrays is bit-identical to the keyed one.  Debug / test utility.  wide (default: d > 4): the wide-state kernels
+    (csrc/csmc_wide.hip) index their draws by the natural flat position in the explicit arrays."""
+    if wide is None:
+        wide = d > 4
+    if wide:
+        return dict(eps_aux=handle.rng_normal(key, 1, (Cn, T, d), dtype).to_host(), eps_prop=handle.rng_normal(key, 2, (Cn, T, N, d), dtype).to_host(),
+                    u_res=handle.rng_uniform(key, 3, (Cn, max(T - 1, 0), N), dtype).to_host() if T > 1 else np.zeros((Cn, 0, N), dtype),
+                    u_bwd=handle.rng_uniform(key, 4, (Cn, T), dtype).to_host())
     T2 = (T + 1) // 2
     ep = handle.rng_normal(key, 2, (Cn, T2, N, d, 2), dtype).to_host()
     ur = handle.rng_uniform(key, 3, (Cn, T2, N, 2), dtype).to_host()

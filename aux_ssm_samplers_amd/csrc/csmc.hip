@@ -552,6 +552,9 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
 
 }  // namespace ax
 
+namespace ax {
+int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a, void* dev_block);  // csmc_wide.hip
+}
 using namespace ax;
 
 extern "C" int auxssm_normalize_resample(auxssm_handle h, int dtype, int32_t rows, int32_t N, const void* log_weights,
@@ -642,8 +645,13 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         return AUXSSM_ERR_ARG;
     }
     const int D = fk->dx;
-    if (D < 1 || D > CS_MAXD) {
-        set_error("dx=%d not instantiated (1..%d)", D, CS_MAXD);
+    const bool wide = D > CS_MAXD;  // csmc_wide.hip: one wave per chain, particles' components in LDS rows
+    if (D < 1 || D > 32) {
+        set_error("dx=%d: the cSMC kernels cover 1 <= dx <= 32", D);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    if (wide && (N > 64 || fk->F_t || fk->b_t || fk->chol_Q_t || fk->gradient || fk->transition != AUXSSM_TRANS_LINEAR)) {
+        set_error("dx=%d runs the wide-state cSMC kernels: N <= 64 particles, time-invariant linear-Gaussian transitions, no gradient proposals", D);
         return AUXSSM_ERR_UNSUPPORTED;
     }
     if (fk->proposal != AUXSSM_PROP_BOOTSTRAP_LG && fk->proposal != AUXSSM_PROP_AUX_INDEPENDENT) {
@@ -738,7 +746,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         }
     }
     const size_t CBT = (size_t)cb * T;
-    size_t need = 4096;
+    size_t need = 4096 + ((size_t)3 * D * D + 4 * D + 8) * sR + 256;  // (+ the wide kernels' model block)
     if (!xs_out) need += CBT * N * D * sR + 256;
     if (!log_ws_out) need += CBT * N * sR + 256;
     if (!backward && !As_out) need += (size_t)cb * (T > 1 ? T - 1 : 1) * N * 4 + 256;
@@ -769,6 +777,11 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.key0 = noise->key0; a.key1 = noise->key1;
     a.eps_aux = noise->eps_aux; a.eps_prop = noise->eps_prop; a.u_res = noise->u_res; a.u_bwd = noise->u_bwd;
     if (!a.u || !a.xs || !a.lws || !a.wT || !a.fmax || (!backward && !a.As) || (fk->gradient && !a.grad) || (fk->F_t && !ctt)) return AUXSSM_ERR_NOMEM;
+    if (wide) {
+        void* blk = ws_take(h, ((size_t)3 * D * D + 4 * D + 8) * sR);
+        if (!blk) return AUXSSM_ERR_NOMEM;
+        return run_csmc_wide(h, dtype, fk, a, blk);
+    }
 #define AX_CSMC_D(R)                                                        \
     switch (D) {                                                            \
         case 1: return run_csmc<R, 1>(h, fk, hm.data(), a, ctt);                 \

@@ -46,7 +46,7 @@
 #include <stdlib.h>
 #include <string.h>
 
-#define MAXD 4
+#define MAXD 32 /* the register kernels cover dx <= 4, csrc/csmc_wide.hip dx <= 32 */
 #define PIT_SC 8 /* sub-chunks per chunk in the stitch of the parallel-in-time sweep (csrc/pit.hip) */
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -520,7 +520,7 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
     REAL* c = (REAL*)malloc(sizeof(REAL) * N);
     REAL* tmp = (REAL*)malloc(sizeof(REAL) * N);
     REAL* lw = (REAL*)malloc(sizeof(REAL) * N);
-    REAL zero[MAXD] = {0, 0, 0, 0};
+    REAL zero[MAXD] = {0};
     REAL* grad = (REAL*)malloc(sizeof(REAL) * (size_t)T * D);
     if (m.proposal == 1) /* csmc/generic.py:67 */
         for (int t = 0; t < T; ++t)
@@ -666,7 +666,7 @@ int SUF(csmc_ref_pit_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL
     REAL* lw = (REAL*)malloc(sizeof(REAL) * TN);       /* per (t, slot) log-weights */
     int32_t* org = (int32_t*)malloc(sizeof(int32_t) * TN);
     int32_t* ot = (int32_t*)malloc(sizeof(int32_t) * TN);
-    REAL zero[MAXD] = {0, 0, 0, 0};
+    REAL zero[MAXD] = {0};
     const REAL nln = -LOG((REAL)N);
     /* leaves (pit/csmc.py:77-96).  Gradient-informed proposals (csmc/independent.py:81-84): mt = N(u + delta/2 grad, delta/2 I) proposes, qt = N(u, delta/2 I)
      * is the target's factor, so every leaf carries log_wts = qt.logpdf - mt.logpdf (pit/csmc.py:83-88) -- per particle, slot 0 included. */

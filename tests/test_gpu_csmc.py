@@ -403,3 +403,65 @@ def test_forward_weights_bound_and_its_fallbacks(dtype, N, case):
         c_obs = -np.log(sig) - 0.5 * np.log(2 * np.pi)
         under = (lw[1:-1] - c_obs).max(axis=1) < (-104 if dtype == np.float32 else -746)
         assert under.sum() >= 3, under
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d,N,T", [(5, 25, 12), (8, 64, 20), (30, 25, 16), (32, 33, 9), (16, 2, 7)])
+@pytest.mark.parametrize("proposal", [O.BOOTSTRAP_LG, O.AUX_INDEPENDENT])
+@pytest.mark.parametrize("potential", [O.POT_FLAT, O.POT_GAUSS_OBS, O.POT_SV])
+@pytest.mark.parametrize("backward", [True, False])
+def test_wide_state_sweep_bit_exact_vs_oracle(dtype, d, N, T, proposal, potential, backward):
+    """4 < dx <= 32 with few particles (csrc/csmc_wide.hip: one wave per chain, components in LDS rows) -- the reference's own stochastic-volatility
+    protocol is D = 30, N = 25 (examples/stochastic_volatility/experiment.sh:1-10): particles, log-weights, ancestors and the trajectory bit-exact
+    against the same oracle as the register kernels."""
+    from aux_ssm_samplers_amd.csmc import _device
+    rng = np.random.default_rng(100 * d + N + T)
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(potential, y)
+    x0 = rng.standard_normal((T, d)).astype(dtype)
+    noise = dict(eps_prop=rng.standard_normal((T, N, d)), u_res=rng.random((T - 1, N)), u_bwd=rng.random(T))
+    delta, okw = None, {}
+    if proposal == O.AUX_INDEPENDENT:
+        delta = 0.5 + rng.random(T)
+        noise["eps_aux"] = rng.standard_normal((T, d))
+        fk = _device.describe_independent(M0, G0, Mt, Gt, Mt)
+        okw = dict(sqrt_half_delta=np.sqrt(0.5 * delta), eps_aux=noise["eps_aux"])
+    else:
+        fk = _device.describe_bootstrap(M0, G0, Mt, Gt, Mt)
+    nz = {k: np.asarray(v, dtype) for k, v in noise.items()}
+    x, anc, hist = _device.sweep(fk, x0, N, backward, noise={k: v[None] for k, v in nz.items()}, delta=delta, want_history=True)
+    ref = O.sweep(_odesc(proposal, potential, M0, Mt, 0.7), x0, N, backward, y=y if potential else None, eps_prop=noise["eps_prop"],
+                  u_res=noise["u_res"], u_bwd=noise["u_bwd"], dtype=dtype, **okw)
+    npt.assert_array_equal(hist["xs"], ref["xs"])
+    npt.assert_array_equal(hist["log_ws"], ref["log_ws"])
+    npt.assert_array_equal(hist["As"], ref["As"])
+    npt.assert_array_equal(anc, ref["ancestors"])
+    npt.assert_array_equal(x, ref["x"])
+    assert np.all(hist["As"][:, 0] == 0) and np.all(hist["xs"][:, 0] == x0)
+
+
+def test_wide_state_threefry_equals_explicit_and_chains_are_independent():
+    """the SV protocol's shape (D = 30, N = 25, T = 250) for several chains: the keyed sweep equals the explicit sweep on key_noise(wide=True),
+    a multi-chain launch equals single launches, refusals are loud"""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics, SVPotential
+    from tests.helpers import sv_setup
+    h = _lib.default_handle()
+    T, d, N, C = 250, 30, 25, 3
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, d)
+    M0, Mt = GaussianInit(m0=m0, P0=P0), LinearGaussianDynamics(F=F, b=b, Q=Q)
+    fk = _device.describe_independent(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), Mt)
+    x0 = (xtrue[None] + 0.1 * np.random.default_rng(0).standard_normal((C, T, d))).astype(np.float32)
+    key = R.PRNGKey(77)
+    xa, anca, _ = _device.sweep(fk, x0, N, True, key=key, delta=0.05)
+    nz = _device.key_noise(h, key, C, T, N, d, np.float32)
+    xb, ancb, _ = _device.sweep(fk, x0, N, True, noise=nz, delta=0.05)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    for c in range(C):
+        xc, ancc, _ = _device.sweep(fk, x0[c], N, True, noise={k: v[c:c + 1] for k, v in nz.items()}, delta=0.05)
+        npt.assert_array_equal(xc, xa[c])
+    assert (anca != 0).mean() > 0.3
+    with pytest.raises(ValueError):  # more than one wave of particles at dx > 4
+        _device.sweep(fk, x0[0], 128, True, key=key, delta=0.05)

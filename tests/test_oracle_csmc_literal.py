@@ -84,7 +84,7 @@ def _run_both(od, objs, y, x0, N, backward, proposal, nz, delta=None, gradient=0
 @pytest.mark.parametrize("backward", [True, False])
 @pytest.mark.parametrize("proposal", [O.BOOTSTRAP_LG, O.AUX_INDEPENDENT])
 @pytest.mark.parametrize("potential", [O.POT_FLAT, O.POT_GAUSS_OBS, O.POT_SV, O.POT_GAUSS_OBS_MASKED])
-@pytest.mark.parametrize("d,N,T", [(1, 32, 25), (1, 1024, 40), (2, 100, 30), (3, 512, 12), (4, 65, 33)])
+@pytest.mark.parametrize("d,N,T", [(1, 32, 25), (1, 1024, 40), (2, 100, 30), (3, 512, 12), (4, 65, 33), (8, 25, 20), (30, 25, 12)])  # (d > 4: csrc/csmc_wide.hip)
 def test_contract_oracle_equals_literal_restatement_fp64(d, N, T, potential, proposal, backward):
     """identical explicit noise -> identical As, B and trajectory; particles / log-weights to rounding"""
     rng = np.random.default_rng(7919 * d + 13 * N + T + 101 * potential + proposal)
