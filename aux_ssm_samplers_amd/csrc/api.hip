@@ -726,6 +726,22 @@ template <typename R> __global__ void __launch_bounds__(256) k_fs_resolve(int C,
     const long long off = (long long)blockIdx.x * C + c;
     if (sel[c]) xa[off] = xb[off];
 }
+// running moments of a LAZY state (auxssm_stats_attach; the fold launch_select does for a plain state): after the accept step chain c's new trajectory
+// lives in buffer sel[c], its previous one in the other buffer if the proposal was accepted (else they coincide: no jump).  Rows of C chains.
+template <typename R>
+__global__ void __launch_bounds__(256) k_fs_stats(int C, const int32_t* __restrict__ accepted, const int32_t* __restrict__ sel, const R* __restrict__ xa, const R* __restrict__ xb,
+                                                   R* __restrict__ sq_jump, R* __restrict__ mean, R* __restrict__ sq_mean, long long iter) {
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= C) return;
+    const long long off = (long long)blockIdx.x * C + c;
+    const int s = sel[c], acc = accepted[c];
+    const R xn = (s ? xb : xa)[off];
+    const R xo = acc ? (s ? xa : xb)[off] : xn;
+    const R it = (R)iter, dj = xn - xo;
+    sq_jump[off] = fold_mean<R>(it, sq_jump[off], dj * dj);
+    mean[off] = fold_mean<R>(it, mean[off], xn);
+    sq_mean[off] = fold_mean<R>(it, sq_mean[off], xn * xn);
+}
 // whether (and why not) a sweep can run the fused passes
 static const char* fused_refusal(const auxssm_ctx* h, const auxssm_dims* dims, const auxssm_lgssm* model, int parallel, int layout) {
     const int C = dims->C, T = dims->T, D = dims->dx, PO = dims->dy;
@@ -739,7 +755,6 @@ static const char* fused_refusal(const auxssm_ctx* h, const auxssm_dims* dims, c
         return "the fused sweep needs chain-shared model parameters (chain stride 0)";
     if (C < 2 || (C % 2) != 0) return "the fused sweep pairs chains for its in-kernel draws: the chain count must be even";
     if (T < 64) return "the fused sweep needs T >= 64";
-    if (h->st_mean) return "running moments are attached (auxssm_stats_attach): their fold lives in the select pass";
     return nullptr;
 }
 template <typename R>
@@ -832,9 +847,20 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
     la.x = cm_arr(x, kd, D); la.xp = cm_arr(x_alt, kd, D); la.u = cm_arr(u, kd, D);
     la.delta = delta; la.nan_policy = nan_policy; la.u_fly = 0; la.shd = sqrt(0.5 * delta); la.dptr = dptr;
     f.xa = x; f.xb = x_alt; f.sel = sel; f.u = u; f.inc = inc; f.keys = keys; f.eps0s = eps0s; f.u_acc = u_acc; f.accepted = accepted; f.logs = logs;
+    if (h->st_mean && (h->st_x != x || h->st_n != (long long)C * T * D || h->st_dtype != (sizeof(R) == 4 ? AUXSSM_F32 : AUXSSM_F64))) {
+        set_error("running moments are attached to another state (x=%p, n=%lld, dtype=%d): detach them (auxssm_stats_attach with NULLs) "
+                  "before sweeping a different state on this handle", h->st_x, h->st_n, h->st_dtype);
+        return AUXSSM_ERR_ARG;
+    }
     if ((rc = sl->fused(h, f))) return rc;
-    if (!sel) {  // plain state: x' sits in x_alt, the usual select moves the accepted chains
+    if (!sel) {  // plain state: x' sits in x_alt, the usual select moves the accepted chains (and folds attached moments)
         if ((rc = launch_select<R>(h, C, T, D, (const int32_t*)accepted, cm_arr(x_alt, kd, D), cm_arr(x, kd, D), 1))) return rc;
+    } else if (h->st_mean) {  // lazy state: the moments' fold as its own pass over the pair of buffers
+        ProfScope ps(h, AUXSSM_K_SELECT);
+        const long long rows = (long long)T * D;
+        hipLaunchKernelGGL((k_fs_stats<R>), dim3((unsigned)rows, (unsigned)((C + 255) / 256)), dim3(256), 0, h->stream, C, (const int32_t*)accepted, (const int32_t*)sel,
+                           (const R*)x, (const R*)x_alt, (R*)h->st_sq_jump, (R*)h->st_mean, (R*)h->st_sq_mean, h->st_iter);
+        ++h->st_iter;
     }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
