@@ -257,27 +257,16 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
 // One draw per step: B = #{j : c_j < r} by ballot + per-wave counts (no serial search), the candidate particles of the step are
 // published to LDS before the first barrier so that x_t^B is an LDS read, and the next step's rows (xs, log_ws) and uniform are
 // fetched one step ahead: no global-memory latency on the dependent chain.  4 barriers per step (max, wave totals, publish, counts).
-template <typename R, int NW = 0> __device__ __forceinline__ int block_count_below(const R* c, R r, bool live, int tid, int nw, int* cnt, int N) {
-    const int lane = tid & 63, wv = tid >> 6;
-    const unsigned long long bal = __ballot(live && c[tid] < r);
-    if (lane == 0) cnt[wv] = __popcll(bal);
-    __syncthreads();
-    int B = 0;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) B += (NW > 0 ? k < NW : k < nw) ? cnt[k] : 0;
-    return B < N - 1 ? B : N - 1;
-}
 template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(1024) k_csmc_bwd(CsmcArgs a, FkDev<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
-    R* c = (R*)smem;                 // [TB]
-    R* red = c + TB;                 // [48]
-    R* xpub = red + 48;              // [2][TB][D] candidate particles of the step, by step parity
+    R* c = (R*)smem;                 // [2][TB] the step's cumulative weights (generic) / local scan values (full workgroups), by step parity
+    R* red = c + 2 * TB;             // [48] + [16]: a second set of wave totals (slots [48, 64)) for the odd steps of the one-barrier loop
+    R* xpub = red + 64;              // [2][TB][D] candidate particles of the step, by step parity
     R* ubuf = xpub + 2 * TB * D;     // [2] the step's uniform, by step parity
-    int* cnt = (int*)(ubuf + 2);     // [2][16] per-wave counts, by step parity
     const int ch = a.c0 + blockIdx.x;
     const bool live = NW > 0 ? true : tid < N;
-    if (tid < 16) red[32 + tid] = 0;  // totals of absent groups: +0 (csmc_dev.h::totals_prefix)
+    if (tid < 16) red[32 + tid] = 0, red[48 + tid] = 0;  // totals of absent groups: +0 (csmc_dev.h::totals_prefix)
     const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
     const R* lws = (const R*)a.lws + (long long)ch * T * N;
     const int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
@@ -288,7 +277,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
 
     // B_T ~ choice(w_T)   (csmc.py:111 / :131); w_T are the forward pass's unnormalised weights
     R w = live ? ((const R*)a.wT)[(long long)ch * N + tid] : (R)0;
-    if (tid == 0) ubuf[1] = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 1));
+    if (tid == 0) ubuf[1] = ((const R*)a.u_bwd)[ub_base + (T - 1)];
     {
         R xi[D];
 #pragma unroll
@@ -297,8 +286,17 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         for (int k = 0; k < D; ++k) xpub[(TB + tid) * D + k] = xi[k];
     }
     R tot;
-    block_cumsum_dpp<R, NW>(w, c, red, tid, nw, tot);
-    int B = block_count_below<R, NW>(c, tot * ((R)1 - ubuf[1]), live, tid, nw, cnt + 16, N);
+    int B;
+    {   // (sweep contract: the two-level single draw; the generic cumsum image c[] holds base + local, so the local values are recovered per group)
+        const int lane = tid & 63, wv = tid >> 6;
+        const R v = wave_scan_dpp(w);
+        c[TB + tid] = v;
+        if (lane == 63) red[32 + wv] = v;
+        __syncthreads();
+        R pre, Pv;
+        totals_prefix<R>(red, lane, wv, nw - 1, pre, tot, &Pv);
+        B = draw_two_level<R>(c + TB, Pv, lane, nw, N, tot * ((R)1 - ubuf[1]));
+    }
     R xn[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) xn[k] = xpub[(TB + B) * D + k];
@@ -328,7 +326,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         for (int k = 0; k < D; ++k) xi_nx[k] = live ? xs[((long long)(T - 2) * N + tid) * D + k] : (R)0;
         lw_nx = live ? lws[(long long)(T - 2) * N + tid] : ninf;
         fm_nx = fmax[T - 2];
-        if (tid == 0) un_nx = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (T - 2));
+        if (tid == 0) un_nx = ((const R*)a.u_bwd)[ub_base + (T - 2)];
     }
     for (int t = T - 2; t >= 0; --t) {
         const int par = t & 1;
@@ -341,7 +339,7 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
             for (int k = 0; k < D; ++k) xi_nx[k] = live ? xs[((long long)(t - 1) * N + tid) * D + k] : (R)0;
             lw_nx = live ? lws[(long long)(t - 1) * N + tid] : ninf;
             fm_nx = fmax[t - 1];
-            if (tid == 0) un_nx = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, ub_base + (t - 1));
+            if (tid == 0) un_nx = ((const R*)a.u_bwd)[ub_base + (t - 1)];
         }
         R lw = ninf;
         const TransT<R> tr = trans_at_c<R, D, TV>(m, t);  // Pt.logpdf(x_{t+1}, xs_t, params_t) (csmc.py:136)
@@ -359,28 +357,27 @@ template <typename R, int D, bool TV, int NW> __global__ void __launch_bounds__(
         if (!(Mb - Mb == 0)) Mb = 0;
         if (CSMC_ABL & 32) w = lw * (R)0.001 + (R)1;  // (diagnostic build: the backward pass without its exp)
         else w = det_exp(lw - Mb);
-        if constexpr (NW > 0) {  // cumulative weight in a register: one barrier (it publishes xpub / ubuf of this parity as well), no c[] image
-            R cv = block_cumsum_reg<R, NW>(w, red, tid, tot);
-            if (!(tot > (R)0)) {  // (uniform: every lane holds the same total)
-                __syncthreads();  // (every wave has read the totals before they are rewritten)
-                w = block_expmax<R, NW>(lw, red, tid, nw);
-                cv = block_cumsum_reg<R, NW>(w, red, tid, tot);
-            }
-            const unsigned long long bal = __ballot(cv < tot * ((R)1 - ubuf[par]));
-            if ((tid & 63) == 0) cnt[par * 16 + (tid >> 6)] = __popcll(bal);
+        {   // ONE barrier per step: local scan values and wave totals of this parity are published together with xpub / ubuf; every wave then finds the
+            // group and counts inside it on its own (csmc_dev.h::draw_two_level)
+            const int lane = tid & 63, wv = tid >> 6;
+            R* vloc = c + par * TB;
+            R* tl = red + 32 + par * 16;
+            R v = wave_scan_dpp(w);
+            vloc[tid] = v;
+            if (lane == 63) tl[wv] = v;
             __syncthreads();
-            B = 0;
-#pragma unroll
-            for (int k = 0; k < NW; ++k) B += cnt[par * 16 + k];
-            B = B < N - 1 ? B : N - 1;
-        } else {
-            block_cumsum_dpp<R, NW>(w, c, red, tid, nw, tot);    // two barriers: xpub / ubuf of this parity are published as well
-            if (!(tot > (R)0)) {
-                __syncthreads();  // (every lane is past its reads of the images before they are rewritten)
+            R pre, Pv;
+            totals_prefix<R>(tl - 32, lane, wv, nw - 1, pre, tot, &Pv);
+            if (!(tot > (R)0)) {  // (uniform) every weight underflowed under its bound: the exact maximum after all
+                __syncthreads();  // (every wave has read this parity's totals before they are rewritten)
                 w = block_expmax<R, NW>(lw, red, tid, nw);
-                block_cumsum_dpp<R, NW>(w, c, red, tid, nw, tot);
+                v = wave_scan_dpp(w);
+                vloc[tid] = v;
+                if (lane == 63) tl[wv] = v;
+                __syncthreads();
+                totals_prefix<R>(tl - 32, lane, wv, nw - 1, pre, tot, &Pv);
             }
-            B = block_count_below<R, NW>(c, tot * ((R)1 - ubuf[par]), live, tid, nw, cnt + par * 16, N);  // one barrier
+            B = draw_two_level<R>(vloc, Pv, lane, nw, N, tot * ((R)1 - ubuf[par]));
         }
 #pragma unroll
         for (int k = 0; k < D; ++k) xn[k] = xpub[(par * TB + B) * D + k];
@@ -527,7 +524,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
     }
     {
         ProfScope ps(h, AUXSSM_K_CSMC_BWD);
-        const size_t lds = (size_t)TB * sizeof(R) + 48 * sizeof(R) + (size_t)2 * TB * D * sizeof(R) + 2 * sizeof(R) + 32 * sizeof(int) + 64;
+        const size_t lds = (size_t)2 * TB * sizeof(R) + 64 * sizeof(R) + (size_t)2 * TB * D * sizeof(R) + 2 * sizeof(R) + 64;
         const int fullw = (TB == a.N && (a.N == 1024 || a.N == 512)) ? a.N / 64 : 0;
 #define AX_BWD(TVv, NWv)                                                                                                                                 \
     do {                                                                                                                                                 \
@@ -751,7 +748,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     if (!log_ws_out) need += CBT * N * sR + 256;
     if (!backward && !As_out) need += (size_t)cb * (T > 1 ? T - 1 : 1) * N * 4 + 256;
     need += (size_t)C * N * sR + 256;
-    need += CT * sR + 256;  // fmax
+    need += 2 * (CT * sR + 256);  // fmax, the backward pass's uniforms
     need += (size_t)T * sR + 256;  // gb
     need += 2 * (CT * D * sR + 256) + (size_t)T * (1 + D) * sR + 256;
     int rc = ws_reserve(h, need);
@@ -776,6 +773,14 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     a.noise_mode = noise->mode;
     a.key0 = noise->key0; a.key1 = noise->key1;
     a.eps_aux = noise->eps_aux; a.eps_prop = noise->eps_prop; a.u_res = noise->u_res; a.u_bwd = noise->u_bwd;
+    if (noise->mode == AUXSSM_NOISE_THREEFRY) {  // the backward pass's uniforms, drawn once (csmc_dev.h::k_csmc_ubwd)
+        void* ub = ws_take(h, CT * sR);
+        if (!ub) return AUXSSM_ERR_NOMEM;
+        const long long n = (long long)CT;
+        if (dtype == AUXSSM_F32) hipLaunchKernelGGL((k_csmc_ubwd<float>), dim3((unsigned)(((n + 1) / 2 + 255) / 256)), dim3(256), 0, h->stream, n, noise->key0, noise->key1, (float*)ub);
+        else hipLaunchKernelGGL((k_csmc_ubwd<double>), dim3((unsigned)(((n + 1) / 2 + 255) / 256)), dim3(256), 0, h->stream, n, noise->key0, noise->key1, (double*)ub);
+        a.u_bwd = ub;
+    }
     if (!a.u || !a.xs || !a.lws || !a.wT || !a.fmax || (!backward && !a.As) || (fk->gradient && !a.grad) || (fk->F_t && !ctt)) return AUXSSM_ERR_NOMEM;
     if (wide) {
         void* blk = ws_take(h, ((size_t)3 * D * D + 4 * D + 8) * sR);

@@ -63,7 +63,7 @@ struct CsmcArgs {
     const void* eps_aux;   // (C, T, D)
     const void* eps_prop;  // (C, T, N, D)
     const void* u_res;     // (C, T-1, N)
-    const void* u_bwd;     // (C, T)
+    const void* u_bwd;     // (C, T); with in-kernel draws the sweep fills its own array first (k_csmc_ubwd): the backward kernels always read it
     // chain batching (csmc.hip::auxssm_csmc_sweep): the particle system of one chain is T N (D + 1) reals -- 537 MB at C3 -- so a sweep over more chains
     // than the device holds runs the forward + backward pair batch by batch, [c0, c0 + C) per launch.  Every array above is indexed by the GLOBAL
     // chain c0 + blockIdx.x (so are the random streams: a batched sweep is bit for bit the unbatched one); the workspace-owned xs / lws / As of a
@@ -277,7 +277,8 @@ template <typename R> __device__ __forceinline__ int lower_bound(const R* c, int
 //            below N): if (pos + s - 1 < N and c[pos + s - 1] < r) pos += s; clipped to N - 1.  On a non-decreasing c this IS
 //            searchsorted(c, r, side='left').
 //   densities : Gaussian log-densities multiply by the reciprocal diagonal of the Cholesky factor, computed once per factor (v3).
-//   single draw (backward pass): B = #{j < N : c_j < r}, clipped to N - 1 (again searchsorted on a non-decreasing c), counted by ballot.
+//   single draw (backward pass): B = 64 g + #{l < 64 : c_{64 g + l} < r}, g = #{k < ng - 1 : P[k] < r}, clipped to N - 1 (v3; again searchsorted
+//            on a non-decreasing c): every wave finds g and counts inside the group by ballot -- one barrier per backward step.
 //   shifts   : the weights of a step are e_i = exp(lw_i - M) with M an upper bound of max_i lw_i that needs NO reduction where one exists, the
 //            exact maximum otherwise, and the exact maximum after all whenever every e_i underflowed (cumulative total not > 0: detected where
 //            the total is formed -- one step later in the forward pass, in the same step in the backward pass).  Scale-invariant as above.
@@ -348,7 +349,7 @@ __device__ __forceinline__ double readlane_(double v, int l) {
 // absent groups hold +0 -- the kernels zero red[32 .. 48) once) and scans them with the Kogge-Stone network of one DPP row (offsets 1, 2, 4, 8).  Lane k then
 // holds P[k]; a wave's own base is ONE readlane -- no dependent left-to-right adds, no branch on the wave id (31 branches per wave and step before).
 //   base = P[wv - 1] (0 for the first wave);   tot = P[last - 1] + t[last] = c[N - 1] bit for bit (the last live particle's cumulative weight)
-template <typename R> __device__ __forceinline__ void totals_prefix(const R* red, int lane, int wv, int last, R& pre, R& tot) {
+template <typename R> __device__ __forceinline__ void totals_prefix(const R* red, int lane, int wv, int last, R& pre, R& tot, R* Pv = nullptr) {
     const R tv = red[32 + (lane & 15)];
     R v = tv;
     v = v + dpp_mov<DPP_ROW_SHR1, 0xf>((R)0, v);
@@ -358,6 +359,24 @@ template <typename R> __device__ __forceinline__ void totals_prefix(const R* red
     const int wvu = __builtin_amdgcn_readfirstlane(wv);
     pre = wvu > 0 ? readlane_(v, wvu > 0 ? wvu - 1 : 0) : (R)0;
     tot = last > 0 ? readlane_(v, last > 0 ? last - 1 : 0) + readlane_(tv, last) : readlane_(tv, 0);
+    if (Pv) *Pv = v;
+}
+// The single draw of the backward pass (sweep contract v3): B = 64 g + #{l < 64 : c_{64 g + l} < r}, g = #{k < ng - 1 : P[k] < r} -- on a non-decreasing c
+// exactly #{j : c_j < r} = searchsorted(c, r).  Every wave finds g from the totals' prefix it holds in lanes 0..15 (one ballot) and counts inside group g from
+// the group's LOCAL scan values, which each wave left in LDS before the one barrier of the step: no second barrier, no exchange of per-wave counts.
+//   vloc: this step's image of the local scan values (64 per group); Pv: totals_prefix's lane vector; ng groups; returns B clipped to N - 1
+template <typename R> __device__ __forceinline__ int draw_two_level(const R* vloc, R Pv, int lane, int ng, int N, R r) {
+    const unsigned long long below = __ballot(Pv < r);
+    const unsigned long long mask = ng > 1 ? ((1ull << (ng - 1)) - 1ull) : 0ull;
+    const int g = __popcll(below & mask);  // (wave-uniform)
+    const int gu = __builtin_amdgcn_readfirstlane(g);
+    const R base = gu > 0 ? readlane_(Pv, gu > 0 ? gu - 1 : 0) : (R)0;
+    const int j = 64 * gu + lane;
+    const R vl = vloc[j];
+    const R cg = gu > 0 ? base + vl : vl;
+    const int cntg = __popcll(__ballot(j < N && cg < r));
+    const int B = 64 * gu + cntg;
+    return B < N - 1 ? B : N - 1;
 }
 // inclusive cumsum of w into c[] in the sweep contract's order; tot = c[N - 1]; c[] valid after the trailing barrier.  red slots [32, 48).
 // PAD: c[] is stored with one spare slot per 32 entries (index cpad(i) = i + (i >> 5)): the probes of the search below sit at strides of 512 .. 1
@@ -372,17 +391,6 @@ template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ v
     totals_prefix<R>(red, lane, wv, (NW > 0 ? NW : nw) - 1, pre, tot);
     c[PAD ? cpad(tid) : tid] = wv > 0 ? pre + v : v;
     __syncthreads();
-}
-// the inclusive cumsum of the lane kept in a REGISTER (same numbers as block_cumsum_dpp's c[tid]): one barrier instead of two and no c[] image --
-// for the backward pass, whose single draw only counts {c_j < r}.
-template <typename R, int NW> __device__ __forceinline__ R block_cumsum_reg(R w, R* red, int tid, R& tot) {
-    const int lane = tid & 63, wv = tid >> 6;
-    const R v = wave_scan_dpp(w);
-    if (lane == 63) red[32 + wv] = v;
-    __syncthreads();
-    R pre;
-    totals_prefix<R>(red, lane, wv, NW - 1, pre, tot);
-    return wv > 0 ? pre + v : v;
 }
 // the ancestor search of the sweep contract (v3): branch-free lower bound by descent over the whole cumulative-weight array.  On the padded image of a full
 // workgroup every probe is one LDS read at (running padded position + constant): while pos stays a multiple of 2 s, cpad(pos + s - 1) =
@@ -407,6 +415,16 @@ template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ i
 }
 
 // ---- kernels both sweeps launch (csmc.hip: sequential; pit.hip: parallel in time) ------------------------------------------------------------
+// the backward pass's uniforms, one per (chain, time step), drawn ONCE into an array (uniform c T + t of stream 4): inside the pass a single lane
+// needed a single number per step, and the whole wave ran a Threefry block for it -- three quarters of the pass's vector instructions
+template <typename R> __global__ void k_csmc_ubwd(long long n, uint32_t key0, uint32_t key1, R* __restrict__ out) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (2 * i >= n) return;
+    R u0, u1;
+    stream_uniform2<R>(key0, key1, STREAM_U_BWD, (unsigned long long)i, u0, u1);
+    out[2 * i] = u0;
+    if (2 * i + 1 < n) out[2 * i + 1] = u1;
+}
 // ---- prologue: u = x + sqrt(delta_t/2) eps   (csmc/generic.py:67) ------------------------------------------------------
 template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;

@@ -294,7 +294,7 @@ template <typename R> __global__ void __launch_bounds__(64) k_cw_bwd(CsmcArgs a,
         const R w = live ? ((const R*)a.wT)[(long long)ch * N + tid] : (R)0;
         const R cv = wave_scan_dpp(w);
         const R tot = readlane_(cv, 63);
-        const R un = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, (long long)ch * T + (T - 1));
+        const R un = ((const R*)a.u_bwd)[(long long)ch * T + (T - 1)];
         B = count_below(cv, tot * ((R)1 - un));
     }
     for (int k = tid; k < D; k += 64) {
@@ -331,7 +331,7 @@ template <typename R> __global__ void __launch_bounds__(64) k_cw_bwd(CsmcArgs a,
             cv = wave_scan_dpp(w);
             tot = readlane_(cv, 63);
         }
-        const R un = noise_uniform<R>(a, a.u_bwd, STREAM_U_BWD, (long long)ch * T + t);
+        const R un = ((const R*)a.u_bwd)[(long long)ch * T + t];
         B = count_below(cv, tot * ((R)1 - un));
         __syncthreads();  // (every lane has read x_{t+1} before it is replaced)
         for (int k = tid; k < D; k += 64) {

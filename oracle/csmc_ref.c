@@ -28,7 +28,8 @@
  *                every wave reads the totals into lanes 0..15 and scans them with four DPP adds; its own base is one readlane);
  *       search : branch-free lower bound by descent over the whole array (contract v3): pos = 0; for s = S0, S0/2, .., 1 (S0 the largest
  *                power of two below N): if (pos + s - 1 < N and c[pos + s - 1] < r) pos += s; clipped to N - 1 (== searchsorted on a
- *                non-decreasing c);   single draw of the backward pass: B = #{j : c_j < r}, clipped to N - 1;
+ *                non-decreasing c);   single draw of the backward pass: B = 64 g + #{l < 64 : c_{64 g + l} < r}, g = #{k < ng - 1 : P[k] < r},
+ *                clipped to N - 1 (every wave finds the group and counts inside it: one barrier per backward step);
  *       densities : Gaussian log-densities multiply by the RECIPROCAL diagonal of the Cholesky factor, computed once per factor in the
  *                working precision (contract v3: no division per particle and step);
  *   - every multiply-add that is fused is written as fma(); compile with -ffp-contract=off.
@@ -355,7 +356,7 @@ static REAL SUF(expmax)(const REAL* lw, int N, REAL* w) {
     for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - m);
     return m;
 }
-static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) {
+static void SUF(cumsum_dpp_p)(const REAL* w, int N, REAL* c, REAL* Pout) {
     /* sweep contract v3: inside each group of 64 the DPP scan order of the wave; the (up to 16) group totals, padded with +0, are prefix-summed by
      * the same Kogge-Stone network on one row of 16 lanes (offsets 1, 2, 4, 8; lanes without a source add +0); c_i = P[g - 1] + local_i (g > 0) */
     REAL loc[1024], tot[16], o16[16];
@@ -381,7 +382,9 @@ static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) {
         memcpy(tot, o16, sizeof tot);
     }
     for (int i = 0; i < N; ++i) c[i] = i < 64 ? loc[i] : tot[i / 64 - 1] + loc[i];
+    if (Pout) memcpy(Pout, tot, sizeof tot);
 }
+static void SUF(cumsum_dpp)(const REAL* w, int N, REAL* c) { SUF(cumsum_dpp_p)(w, N, c, NULL); }
 /* conditional-multinomial ancestor of one particle: branch-free lower bound by descent over the whole cumulative-weight array (contract v3) --
  * pos = 0; for s = S0, S0/2, ..., 1 (S0 = the largest power of two below N): if (pos + s - 1 < N and c[pos + s - 1] < r) pos += s; clipped to N - 1.
  * On a non-decreasing c this IS searchsorted(c, r, side='left') of resamplings.py:35-36 -> jax.random.choice. */
@@ -394,11 +397,15 @@ static int SUF(choice2)(const REAL* c, int N, REAL un) {
         if (pos + s - 1 < N && c[pos + s - 1] < r) pos += s;
     return pos < N - 1 ? pos : N - 1;
 }
-/* the single draw of the backward pass: count of the cumulative weights below r */
-static int SUF(choice_count)(const REAL* c, int N, REAL un) {
+/* the single draw of the backward pass (contract v3): B = 64 g + #{l < 64 : c_{64 g + l} < r} with g = #{k < ng - 1 : P[k] < r} (P the prefix of the
+ * group totals); on a non-decreasing c this is #{j : c_j < r} = searchsorted(c, r) */
+static int SUF(choice_count)(const REAL* c, const REAL* P, int N, REAL un) {
     const REAL r = c[N - 1] * ((REAL)1 - un);
-    int B = 0;
-    for (int j = 0; j < N; ++j) B += c[j] < r;
+    const int ng = (N + 63) / 64;
+    int g = 0;
+    for (int k = 0; k < ng - 1; ++k) g += P[k] < r;
+    int B = 64 * g;
+    for (int j = 64 * g; j < 64 * g + 64 && j < N; ++j) B += c[j] < r;
     return B < N - 1 ? B : N - 1;
 }
 
@@ -614,8 +621,9 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
     }
     free(gb);
     /* backward (csmc.py:110-149) */
-    SUF(cumsum_dpp)(w, N, c);
-    int B = SUF(choice_count)(c, N, u_bwd[T - 1]);
+    REAL Pt[16];
+    SUF(cumsum_dpp_p)(w, N, c, Pt);
+    int B = SUF(choice_count)(c, Pt, N, u_bwd[T - 1]);
     anc[T - 1] = B;
     REAL xn[MAXD];
     for (int k = 0; k < D; ++k) xn[k] = x[(T - 1) * D + k] = xs[((size_t)(T - 1) * N + B) * D + k];
@@ -634,12 +642,12 @@ int SUF(csmc_ref_sweep)(const fk_model* g, int T, int N, REAL* x, const REAL* y,
             REAL Mb = fmax[t] + tr.c_trans;
             if (!(Mb - Mb == 0)) Mb = 0;
             for (int i = 0; i < N; ++i) w[i] = EXP(lw[i] - Mb);
-            SUF(cumsum_dpp)(w, N, c);
+            SUF(cumsum_dpp_p)(w, N, c, Pt);
             if (!(c[N - 1] > 0)) {
                 SUF(expmax)(lw, N, w);
-                SUF(cumsum_dpp)(w, N, c);
+                SUF(cumsum_dpp_p)(w, N, c, Pt);
             }
-            B = SUF(choice_count)(c, N, u_bwd[t]);
+            B = SUF(choice_count)(c, Pt, N, u_bwd[t]);
         }
         anc[t] = B;
         for (int k = 0; k < D; ++k) xn[k] = x[t * D + k] = xs[((size_t)t * N + B) * D + k];
