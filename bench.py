@@ -431,6 +431,18 @@ def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
         out["roofline"] = dict(bound="hbm", achieved=ach, peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(ach / HBM_PEAK_GBPS, 4), traffic=traffic,
                                traffic_source=src, kernel=f"k_{g} (persistent, one workgroup per chain)", avg_launch_ms=kern[g]["ms_per_step"],
                                algorithmic_bytes_per_launch=alg[g])
+        # these kernels are VALU-issue / latency bound, not HBM bound: the committed SQ counter passes (tools/pmc_sq_c3.sh -> tools/sq_summary.py) say how busy
+        # the vector ALUs are -- SQ_INSTS_VALU x 4 cycles over SQ_BUSY_CU_CYCLES x 4 SIMDs -- and how many instructions a wave issues per time step
+        sq = {}
+        for kk in ("csmc_fwd", "csmc_bwd"):
+            try:
+                ent = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json"))).get(f"csmc_C3_sq_k_{kk}")
+            except Exception:
+                ent = None
+            if ent:
+                sq[kk] = {q: ent.get(q) for q in ("valu_issue_frac", "valu_per_wave_step", "salu_per_wave_step", "lds_per_wave_step", "branch_per_wave_step", "source")}
+        if sq:
+            out["valu_issue"] = sq
     if cpu:
         from oracle import csmc as O
         Tb = min(T, 4096)
@@ -463,38 +475,53 @@ def leg_c4(ctx, total_chains=64, T=16384, N=512, steps=20, warmup=3):
                chains_this_rank=Cn, scaling="strong", parallelism=f"{total_chains} chains block-partitioned over {ctx.world} rank(s), no collective")
     model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
-    ch = DeviceChains(handle, np.repeat(xtrue[None], Cn, axis=0).astype(np.float32))
-    st = KalmanSampler(x=ch, updated=None)
-    keys = R.split(chain_key(R.PRNGKey(4), lo), steps + warmup + 1)  # the rank's stream is folded from its first global chain id
-    el, groups = ctx.timed(lambda k: kernel(keys[k], st, 1e-4), steps, warmup)
-    acc = ctx.sum_over_ranks(float(ch.accepted.to_host().sum())) / total_chains
-    s = 4
-    d, po = 3, 2
-    # fused-sweep lower bound of SURVEY 8(d): x, eps_aux, eps_samp read, x' written per chain-step (the linearised F_t, b_t are functions of x)
-    alg = Cn * T * 4 * d * s
-    out["kalman"] = dict(value=round(total_chains * steps / el, 1), unit="sweeps/s", ms_per_step=round(el / steps * 1e3, 4), steps=steps,
-                         accept_rate=round(acc, 3), layout="chain-minor" if ch.chain_minor else "dense",
-                         kernels={g: round(ms / steps, 4) for g, (n, ms) in groups.items()},
-                         roofline=dict(bound="hbm", achieved=round(alg / (el / steps) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                                       frac=round(alg / (el / steps) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None,
-                                       kernel="whole sweep (about 40 dependent launches; latency-bound at 8 chains per GPU)",
-                                       algorithmic_bytes_per_launch=alg))
-    del ch
     M0, Mt, G0, Gt, xt, y, sig_y = lorenz_setup(T, every=80, dt=1.25e-4)
-    init, ck = get_csmc_kernel(M0, G0, Mt, Gt, N, backward=True, Pt=Mt)
-    cc = CsmcChains(handle, np.repeat(xt[None], Cn, axis=0).astype(np.float32))
-    cst = CSMCState(x=cc, updated=None)
-    ckeys = R.split(chain_key(R.PRNGKey(5), lo), 8)
-    csteps = 3
-    el, groups = ctx.timed(lambda k: ck(ckeys[k], cst), csteps, 1)
-    alg = Cn * T * N * (d * s + s)
-    fwd = groups.get("csmc_fwd", (0, 0.0))[1] / csteps
-    out["csmc"] = dict(value=round(total_chains * csteps / el, 2), unit="sweeps/s", ms_per_step=round(el / csteps * 1e3, 3), steps=csteps, particles=N,
-                       updated_fraction=float((cc.ancestors.to_host() != 0).mean()),
-                       kernels={g: round(ms / csteps, 3) for g, (n, ms) in groups.items()},
-                       roofline=None if not fwd else dict(bound="hbm", achieved=round(alg / (fwd * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                                                          frac=round(alg / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None,
-                                                          kernel="k_csmc_fwd<float,3>", avg_launch_ms=round(fwd, 3), algorithmic_bytes_per_launch=alg))
+    cinit, ck = get_csmc_kernel(M0, G0, Mt, Gt, N, backward=True, Pt=Mt)
+    s, d, po = 4, 3, 2
+
+    def measure(Cn, lo, total, ksteps, kwarm, csteps):
+        """both samplers on Cn resident chains; `total` chains are what the rate is scaled to (all ranks run the same number of chains)"""
+        ch = DeviceChains(handle, np.repeat(xtrue[None], Cn, axis=0).astype(np.float32))
+        st = KalmanSampler(x=ch, updated=None)
+        keys = R.split(chain_key(R.PRNGKey(4), lo), ksteps + kwarm + 1)  # the rank's stream is folded from its first global chain id
+        el, groups = ctx.timed(lambda k: kernel(keys[k], st, 1e-4), ksteps, kwarm)
+        acc = ctx.sum_over_ranks(float(ch.accepted.to_host().sum())) / total
+        # fused-sweep lower bound of SURVEY 8(d): x, eps_aux, eps_samp read, x' written per chain-step (the linearised F_t, b_t are functions of x)
+        alg = Cn * T * 4 * d * s
+        kal = dict(value=round(total * ksteps / el, 1), unit="sweeps/s", ms_per_step=round(el / ksteps * 1e3, 4), steps=ksteps,
+                   accept_rate=round(acc, 3), layout="chain-minor" if ch.chain_minor else "dense",
+                   kernels={g: round(ms / ksteps, 4) for g, (n, ms) in groups.items()},
+                   roofline=dict(bound="hbm", achieved=round(alg / (el / ksteps) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                 frac=round(alg / (el / ksteps) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None,
+                                 kernel="whole sweep (about 40 dependent launches; latency-bound at 8 chains per GPU)",
+                                 algorithmic_bytes_per_launch=alg))
+        del ch, st
+        cc = CsmcChains(handle, np.repeat(xt[None], Cn, axis=0).astype(np.float32))
+        cst = CSMCState(x=cc, updated=None)
+        ckeys = R.split(chain_key(R.PRNGKey(5), lo), 8)
+        el, groups = ctx.timed(lambda k: ck(ckeys[k], cst), csteps, 1)
+        alg = Cn * T * N * (d * s + s)
+        fwd = groups.get("csmc_fwd", (0, 0.0))[1] / csteps
+        csm = dict(value=round(total * csteps / el, 2), unit="sweeps/s", ms_per_step=round(el / csteps * 1e3, 3), steps=csteps, particles=N,
+                   updated_fraction=float((cc.ancestors.to_host() != 0).mean()),
+                   kernels={g: round(ms / csteps, 3) for g, (n, ms) in groups.items()},
+                   roofline=None if not fwd else dict(bound="hbm", achieved=round(alg / (fwd * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                                      frac=round(alg / (fwd * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None,
+                                                      kernel="k_csmc_fwd<float,3>", avg_launch_ms=round(fwd, 3), algorithmic_bytes_per_launch=alg))
+        return kal, csm
+
+    out["kalman"], out["csmc"] = measure(Cn, lo, total_chains, steps, warmup, 3)
+    if ctx.world == 1 and total_chains >= 16:
+        # What the 8-GPU run of this leg will look like, from THIS GPU: the shard of one rank (total / 8 chains) measured alone.  Eight ranks run eight such
+        # shards side by side with no exchange, so the 8-GPU rate is 8 x the shard's rate -- and because one shard leaves most of the chip idle (one
+        # workgroup per chain in the cSMC kernels, short dependent launches in the Kalman sweep), that is NOT 8 x the single-GPU figure above.
+        k8, c8 = measure(total_chains // 8, 0, total_chains // 8, max(5, steps // 2), 2, 2)
+        out["prediction_8_gpus"] = dict(
+            shard_chains=total_chains // 8,
+            kalman=dict(shard_sweeps_per_s=k8["value"], predicted_sweeps_per_s=round(8 * k8["value"], 1), vs_one_gpu=round(8 * k8["value"] / out["kalman"]["value"], 2)),
+            csmc=dict(shard_sweeps_per_s=c8["value"], predicted_sweeps_per_s=round(8 * c8["value"], 2), vs_one_gpu=round(8 * c8["value"] / out["csmc"]["value"], 2)),
+            note="strong scaling of a FIXED 64 chains: the leg that carries north_star's >= 6x at 8 GPUs is the C2 headline (weak scaling, 256 chains per GPU, "
+                 "no exchange between ranks), not this one")
     return out
 
 
