@@ -127,6 +127,8 @@ class DeviceChains:
         # lazy state of the fused chain-shared sweep (auxssm_kalman_sweep_fused): chain c lives in x_alt where sel[c] != 0; allocated on first use
         self.x_alt = None
         self.sel = None
+        if fused is None and os.environ.get("AUXSSM_FUSED") == "0":   # measurement switch: the keyed sweep of rounds 1-2
+            fused = False
         self.fused = None if fused is None or fused else False  # None: not tried yet; False: refused (by the library or the caller): keyed sweeps
 
     # per-sweep noise buffers of the unfused sweeps (allocated once, on first use: the fused sweep draws inside its passes and needs none)
