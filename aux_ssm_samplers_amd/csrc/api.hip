@@ -546,7 +546,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     add(CT * D * D * sR);                              // Ps
     add(CT * D * sR);                                  // x_prop
     add((size_t)C * sR + (size_t)5 * C * sizeof(Acc) + 2048);  // ell, the five totals
-    add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
+    add(wide ? wide_filter_ws(h, dtype, kd, parallel, D, P) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : sl->ws(h, kd));
     int rc = ws_reserve(h, need);
@@ -1016,7 +1016,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     add(CT * D * sR);                                        // ms
     add(CT * D * D * sR);                                    // Ps
     add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + (size_t)5 * C * sizeof(Acc) + 4096);
-    add(wide ? wide_filter_ws(h, dtype, kd, parallel, D) : ke->filter_ws(h, kd, parallel));
+    add(wide ? wide_filter_ws(h, dtype, kd, parallel, D, D) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : std::max(ke->logpdf_ws(h, kd), se->sv_logpdf_ws(h, kd)));
     int rc = ws_reserve(h, need);
@@ -1642,7 +1642,7 @@ int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, co
     const KalmanEntry* e = need_kalman(dtype, dims->dx, dims->dy);
     if (!e) return AUXSSM_ERR_UNSUPPORTED;
     const KDims kd{dims->C, dims->T, dims->B};
-    const size_t wsb = is_wide(dims->dx, dims->dy) ? wide_filter_ws(h, dtype, kd, parallel, dims->dx) : e->filter_ws(h, kd, parallel);
+    const size_t wsb = is_wide(dims->dx, dims->dy) ? wide_filter_ws(h, dtype, kd, parallel, dims->dx, dims->dy) : e->filter_ws(h, kd, parallel);
     if ((rc = ws_reserve(h, wsb + 4096))) return rc;
     FilterArgs a;
     fill_filter_args(a, dims, lgssm, ys, ms, Ps);

@@ -216,7 +216,7 @@ const SampleEntry* wide_sample_entry(int dtype);
 const SweepLogpdfEntry* wide_sweep_logpdf_entry(int dtype);
 bool wide_fits(int dtype, int dx, int dy, std::string* why);
 // the wide entries' *_ws members return 0 (the table signatures carry no sizes): api.hip asks through these instead
-size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d);
+size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d, int p);
 size_t wide_sample_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d);
 size_t wide_logpdf_ws(int dtype, const KDims& kd);
 

@@ -2214,6 +2214,8 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sweep_logpdf(Swee
     }
 }
 
+#include "wide_shared.h"
+
 // ---- host side -----------------------------------------------------------------------------------------------------------------
 constexpr int WMAXLEV = 4;
 struct WPlan {
@@ -2270,17 +2272,52 @@ static bool fold_enabled() {
     return on;
 }
 template <typename R> static bool use_fold(int d, int p) { return fold_enabled() && fold_fits(sizeof(R), d) && lds_obs_info(sizeof(R), d, p) <= LDS_BUDGET; }
-template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims& kd, int parallel, int d) {
-    const int S = kd.S(), n = kd.n();
+template <typename R> static size_t filter_ws_one(const auxssm_ctx* h, int S, int n, int parallel, int d) {
     const WPlan p = plan(h, S, n, parallel);
     const size_t ne = (size_t)fe_size(d);
     size_t nagg = 0;
     for (int l = 0; l <= p.nlev; ++l) nagg += p.cnt[l];
     return ((size_t)S * std::max(n, 1) * ne + (size_t)S * nagg * (ne + (size_t)pre_size(d)) + (size_t)S * (std::max(n, 1) + 2)) * sizeof(R) + 8192 + 256 * (2 * (WMAXLEV + 1) + 4);
 }
+// the chain-shared filter (wide_shared.h): blocks of CB sequences ride as matrix columns; chunks of E transitions
+struct SPlan {
+    int CB, ncb, E, nchunk;
+};
+static SPlan shared_plan(const auxssm_ctx* h, int S, int n, int d, int p, size_t sR) {
+    SPlan sp{};
+    sp.CB = 64;
+    while (sp.CB > 16 && (sp.CB / 2 >= S || (long long)p * sp.CB > (long long)SH_NY * NT || std::max(lds_mean_down(sR, d, p, sp.CB), lds_mean_reduce(sR, d, p, sp.CB)) > LDS_BUDGET))
+        sp.CB /= 2;
+    sp.ncb = (S + sp.CB - 1) / sp.CB;
+    long long nchunk = std::max(1, std::min(n, std::max(h->num_cu / sp.ncb, 32)));
+    if (const char* ev = getenv("AUXSSM_WIDE_SHARED_NCHUNK")) {
+        const long long v = atoll(ev);
+        if (v >= 1 && v <= n) nchunk = v;
+    }
+    sp.E = (int)((n + nchunk - 1) / nchunk);
+    sp.nchunk = (n + sp.E - 1) / sp.E;
+    return sp;
+}
+template <typename R> static size_t shared_ws(const auxssm_ctx* h, int S, int n, int d, int p) {
+    const SPlan sp = shared_plan(h, S, n, d, p, sizeof(R));
+    const GRow g(d, p);
+    const size_t Spad = (size_t)sp.ncb * sp.CB;
+    return ((size_t)n * g.size + (size_t)sp.nchunk * d * ldp_(d) + 2 * (size_t)sp.nchunk * d * Spad + (size_t)S * sp.nchunk + 2 * (size_t)S + 64) * sizeof(R) + 16 * 256;
+}
+template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims& kd, int parallel, int d, int p) {
+    const int S = kd.S(), n = kd.n();
+    size_t need = filter_ws_one<R>(h, S, n, parallel, d);
+    if (S >= 2 && parallel && n >= 4 && p > 0) need = std::max(need, filter_ws_one<R>(h, 1, n, parallel, d) + shared_ws<R>(h, S, n, d, p));
+    return need;
+}
+template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterArgs& a, void* ell_out);
 
 template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int parallel, void* ell_out) {
     const int S = a.d.S(), n = a.d.n(), d = a.dx, p = a.dy;
+    if (S >= 2 && parallel && n >= 4) {  // sequences that share every model parameter: one matrix recursion, the means as columns (wide_shared.h)
+        const int rc = run_filter_shared<R>(h, a, ell_out);
+        if (rc != 1) return rc;  // 1: not applicable (strides, option, observation patterns, LDS), nothing written -- the per-sequence path below
+    }
     const WPlan pl = plan(h, S, n, parallel);
     const bool fold = use_fold<R>(d, p);
     const size_t ne = (size_t)fe_size(d), np = (size_t)pre_size(d);
@@ -2325,6 +2362,70 @@ template <typename R> int run_filter(auxssm_ctx* h, const FilterArgs& a, int par
     }
     // ell = t = 0 term + the scan's log-scale (the reference's second pass, filtering.py:60-62, is not needed)
     hipLaunchKernelGGL((wk_reduce<R>), dim3(a.d.C), dim3(NT), 0, h->stream, (const R*)ellz, (const R*)ell0, a.d.B, (long long)(n > 0 ? 1 : 0), (R*)ell_out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+// returns 1 when the shared form does not apply (the caller runs the per-sequence path), else a status
+template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterArgs& a, void* ell_out) {
+    const int S = a.d.S(), n = a.d.n(), d = a.dx, p = a.dy;
+    static const bool off = getenv("AUXSSM_WIDE_SHARED") && atoi(getenv("AUXSSM_WIDE_SHARED")) == 0;
+    if (off || !h->share_model || a.aux_on || a.tab || p < 1) return 1;
+    for (const Arr* q : {&a.P0, &a.Fs, &a.Qs, &a.bs, &a.Hs, &a.Rs, &a.cs})
+        if (q->sc != 0 || q->sb != 0) return 1;
+    const SPlan sp = shared_plan(h, S, n, d, p, sizeof(R));
+    if ((long long)p * sp.CB > (long long)SH_NY * NT || (long long)d * sp.CB > 6ll * NT || (long long)std::max(d, p) * ldp_(std::max(d, p)) > (long long)SH_NR * NT ||
+        d + 2 * p + 2 > 3 * NT || !spd_fits(p, 2 * p + d))
+        return 1;
+    const size_t l_tab = lds_gain_tab(sizeof(R), d, p), l_red = lds_mean_reduce(sizeof(R), d, p, sp.CB), l_agg = lds_mean_aggs(sizeof(R), d, sp.CB),
+                 l_down = lds_mean_down(sizeof(R), d, p, sp.CB);
+    if (std::max({l_tab, l_red, l_agg, l_down}) > LDS_BUDGET) return 1;
+    const GRow g(d, p);
+    const size_t Spad = (size_t)sp.ncb * sp.CB;
+    const size_t mark = h->ws_off;
+    int* flag = (int*)ws_take(h, 256);
+    R* tab = (R*)ws_take(h, (size_t)n * g.size * sizeof(R));
+    R* aggA = (R*)ws_take(h, (size_t)sp.nchunk * d * ldp_(d) * sizeof(R));
+    R* aggG = (R*)ws_take(h, (size_t)sp.nchunk * d * Spad * sizeof(R));
+    R* pre = (R*)ws_take(h, (size_t)sp.nchunk * d * Spad * sizeof(R));
+    R* ellpart = (R*)ws_take(h, (size_t)S * sp.nchunk * sizeof(R));
+    R* ell0 = (R*)ws_take(h, (size_t)S * sizeof(R));
+    R* ell_seq0 = (R*)ws_take(h, 256);
+    if (!flag || !tab || !aggA || !aggG || !pre || !ellpart || !ell0 || !ell_seq0) return AUXSSM_ERR_NOMEM;
+    // the one decision that needs the data: do all sequences miss the same observations?  (4 bytes back to the host; the filter call is not inside a sweep loop)
+    AX_HIP(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+    hipLaunchKernelGGL((wk_mask_check<R>), dim3(std::min<long long>(1024, ((long long)a.d.T * p + 255) / 256)), dim3(256), 0, h->stream, a, flag);
+    int differ = 0;
+    AX_HIP(hipMemcpyAsync(&differ, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    AX_HIP(hipStreamSynchronize(h->stream));
+    if (differ) {
+        h->ws_off = mark;
+        return 1;
+    }
+    FilterArgs fa = a;
+    fa.ell0 = ell0;
+    {
+        ProfScope ps(h, AUXSSM_K_FILTER_INIT);
+        WK_LAUNCH((wk_filter_t0<R>), S, lds_filter_t0(sizeof(R), d, p), fa);  // every sequence's own t = 0 update: ms[., 0], Ps[., 0], its ell term
+    }
+    {   // the matrix filter: sequence 0 through the per-sequence path (its ms / Ps rows are final, its ell is recomputed below with the others')
+        FilterArgs a1 = a;
+        a1.d = KDims{1, a.d.T, 1};
+        const int rc = run_filter<R>(h, a1, 1, ell_seq0);
+        if (rc) return rc;
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_FILTER_TAB);
+        WK_LAUNCH((wk_gain_tab<R>), n, l_tab, fa, tab);
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_FILTER_ELL);
+        if (sp.nchunk > 1) WK_LAUNCH((wk_mean_reduce<R>), (long long)sp.nchunk * sp.ncb, l_red, fa, (const R*)tab, aggA, aggG, sp.E, sp.ncb, sp.CB);
+        WK_LAUNCH((wk_mean_aggs<R>), sp.ncb, l_agg, fa, (const R*)aggA, (const R*)aggG, pre, sp.nchunk, sp.ncb, sp.CB);
+        WK_LAUNCH((wk_mean_down<R>), (long long)sp.nchunk * sp.ncb, l_down, fa, (const R*)tab, (const R*)pre, ellpart, sp.E, sp.nchunk, sp.ncb, sp.CB);
+        hipLaunchKernelGGL((wk_ps_bcast<R>), dim3(n), dim3(NT), 0, h->stream, fa);
+    }
+    hipLaunchKernelGGL((wk_reduce<R>), dim3(a.d.C), dim3(NT), 0, h->stream, (const R*)ellpart, (const R*)ell0, a.d.B, (long long)sp.nchunk, (R*)ell_out);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
@@ -2376,8 +2477,8 @@ template <typename R> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs&
 }  // namespace wide
 
 // ---- workspace sizes: the entry-table signatures carry no (dx, dy), so api.hip asks through these ---------------------------
-size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d) {
-    return dtype == AUXSSM_F32 ? wide::filter_ws_d<float>(h, kd, parallel, d) : wide::filter_ws_d<double>(h, kd, parallel, d);
+size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d, int p) {
+    return dtype == AUXSSM_F32 ? wide::filter_ws_d<float>(h, kd, parallel, d, p) : wide::filter_ws_d<double>(h, kd, parallel, d, p);
 }
 size_t wide_sample_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d) {
     const size_t s = dtype == AUXSSM_F32 ? 4 : 8;

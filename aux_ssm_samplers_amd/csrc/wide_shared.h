@@ -1,0 +1,455 @@
+// wide_shared.h -- included inside namespace ax::wide of wide.hip (after the filter kernels, before the host side).
+//
+// The wide-state FILTER for S >= 2 sequences that share EVERY model parameter (P0, Fs, Qs, bs, Hs, Rs, cs with chain and batch stride 0 -- what
+// jax.vmap leaves unbatched when only ys is mapped over, filtering.py:18-46) and the same missing-observation pattern.  The covariance recursion, the
+// gains and the innovation covariances then do not depend on the sequence (filtering.py:89-130: P_t, K_t, S_t are functions of the parameters and
+// of WHICH components of y_t are observed, never of their values), so they are computed ONCE -- by the one-sequence matrix filter of this file
+// (the parallel scan of filtering.py:163-183) on sequence 0 -- and every sequence is left with the affine mean recursion of the gain form
+//
+//      m_t = A_t m_{t-1} + K_t y_t + g_t,     A_t = (I - K_t H_t) F_{t-1},   g_t = b_{t-1} - K_t (H_t b_{t-1} + c_t)
+//      v_t = y_t - H_t F_{t-1} m_{t-1} - (H_t b_{t-1} + c_t),   ell_t = -1/2 v_t^T S_t^-1 v_t - 1/2 log|S_t| - (#observed / 2) log 2 pi
+//
+// which is a parallel scan over time of d x d times d x S products: the S means ride as the COLUMNS of one matrix (a 64 x 64 x 16 MFMA product per
+// step at C5's sizes instead of sixteen 64^3 combines with a pivoted LU each).  Three launches, chunked like every scan here: chunk composites
+// (A-products shared, one d x S offset block per chunk), a short sequential pass over the chunk composites, and the down pass that re-walks each chunk
+// from its true start, writes the means and accumulates the log-likelihood.  Same C2-style hoist as affine_shared.h, for d up to the wide path's limit.
+//
+// Table row of transition i -> i + 1 (GRow; every matrix is stored as its padded LDS image, leading dimension ldp_(.), so a row is staged with
+// straight linear copies):   [ H F (p x d) | A (d x d) | X = S^-1 H P^- = K^T (p x d) | S^-1 (p x p) | g (d) | hb (p) | mask (p) | ellc | ok ].
+
+struct GRow {
+    int d, p, ldd, ldp;
+    long long oHF, oA, oX, oS, oV, size;
+    __host__ __device__ GRow(int d_, int p_) : d(d_), p(p_), ldd(ldp_(d_)), ldp(ldp_(p_)) {
+        oHF = 0;
+        oA = oHF + (long long)p * ldd;
+        oX = oA + (long long)d * ldd;
+        oS = oX + (long long)p * ldd;
+        oV = oS + (long long)p * ldp;
+        size = (oV + d + 2 * p + 2 + 3) & ~3ll;
+    }
+};
+
+// one padded matrix image (<= 85 x 85 reals) in flight: fetched a step ahead into registers, dropped into LDS at the top of its step
+constexpr int SH_NR = 8;
+template <typename R> struct Img {
+    R v[SH_NR];
+};
+template <typename R> __device__ __forceinline__ void img_fetch(Img<R>& g, const R* __restrict__ src, int count, int tid) {
+#pragma unroll
+    for (int u = 0; u < SH_NR; ++u) {
+        const int e = tid + u * NT;
+        g.v[u] = e < count ? src[e] : (R)0;
+    }
+}
+template <typename R> __device__ __forceinline__ void img_drop(const Img<R>& g, R* dst, int count, int tid) {
+#pragma unroll
+    for (int u = 0; u < SH_NR; ++u) {
+        const int e = tid + u * NT;
+        if (e < count) dst[e] = g.v[u];
+    }
+}
+// the observations of one time step of a block of CB sequences: y[k][sl] (p x CB, ld ldc), missing entries as 0 (the mask row deletes them)
+constexpr int SH_NY = 4;  // p * CB <= 4 NT (the host picks CB accordingly)
+template <typename R> struct YTile {
+    const R* base[SH_NY];  // &ys[sequence, t = 0, k], null outside the block / beyond S
+    int off[SH_NY];        // k * ldc + sl
+    R v[SH_NY];
+};
+template <typename R> __device__ __forceinline__ void ytile_init(YTile<R>& y, const FilterArgs& a, int s0, int CB, int S, int p, int ldc, int tid) {
+#pragma unroll
+    for (int u = 0; u < SH_NY; ++u) {
+        const int e = tid + u * NT;
+        const int sl = e / p, k = e - sl * p, s = s0 + sl;
+        const bool v = sl < CB && s < S;
+        y.base[u] = v ? at<R>(a.ys, s / a.d.B, 0, s % a.d.B) + (long long)k * a.ys.se : nullptr;
+        y.off[u] = v ? k * ldc + sl : -1;
+        y.v[u] = 0;
+    }
+}
+template <typename R> __device__ __forceinline__ void ytile_fetch(YTile<R>& y, long long tst) {
+#pragma unroll
+    for (int u = 0; u < SH_NY; ++u) y.v[u] = y.base[u] ? y.base[u][tst] : (R)0;
+}
+template <typename R> __device__ __forceinline__ void ytile_drop(const YTile<R>& y, R* Y) {
+#pragma unroll
+    for (int u = 0; u < SH_NY; ++u)
+        if (y.off[u] >= 0) Y[y.off[u]] = finite_(y.v[u]) ? y.v[u] : (R)0;
+}
+
+// ---- every sequence has the missing-observation pattern of sequence 0? (flag |= 1 otherwise) ------------------------------------------------
+template <typename R> __global__ void __launch_bounds__(256) wk_mask_check(FilterArgs a, int* __restrict__ flag) {
+    const int p = a.dy, S = a.d.S();
+    const long long total = (long long)a.d.T * p;
+    int bad = 0;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long t = e / p;
+        const int k = (int)(e - t * p);
+        const bool f0 = finite_(at<R>(a.ys, 0, t, 0)[(long long)k * a.ys.se]);
+        for (int s = 1; s < S; ++s) bad |= finite_(at<R>(a.ys, s / a.d.B, t, s % a.d.B)[(long long)k * a.ys.se]) != f0;
+    }
+    if (bad) atomicOr(flag, 1);
+}
+
+// ---- the gain-form row of transition i -> i + 1 from the filtered covariance P_i of the matrix filter; one workgroup per transition -------------
+static size_t lds_gain_tab(size_t s, int d, int p) {
+    const size_t ldd = ldp_(d), nct = 2 * (size_t)p + d, ldz = ldp_((int)nct);
+    return 3 * al16(d * ldd * s) + 3 * al16(p * ldd * s) + al16(p * ldz * s) + 2 * al16(d * s) + 4 * al16(p * s) + al16((2 * (nct + 1) + NWV) * s) + al16(p) + 128;
+}
+template <typename R> __global__ void __launch_bounds__(NT) wk_gain_tab(FilterArgs a, R* __restrict__ tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, p = a.dy, i = blockIdx.x;
+    const long long t = (long long)i + 1;
+    const int ldd = ldp_(d), ldpp = ldp_(p), nct = 2 * p + d, ldz = ldp_(nct);
+    const GRow g(d, p);
+    R* row = tab + (long long)i * g.size;
+    Bump L{smem};
+    R* F = L.take<R>(d * ldd);
+    R* P = L.take<R>(d * ldd);
+    R* T1 = L.take<R>(d * ldd);
+    Obs<R> o;
+    o.H_ = L.take<R>(p * ldd);
+    R* HP = L.take<R>(p * ldd);
+    R* HF = L.take<R>(p * ldd);
+    R* Z = L.take<R>(p * ldz);  // [S | H_ P^- | I] -> [. | X | S^-1]
+    R* bd = L.take<R>(d);
+    R* g0 = L.take<R>(d);
+    o.c_ = L.take<R>(p);
+    o.y = L.take<R>(p);
+    R* hb = L.take<R>(p);
+    R* piv = L.take<R>(p);
+    R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
+    o.nan = L.take<unsigned char>(p);
+    o.cnt = L.take<int>(1);
+    load_mat<R>(F, ldd, at<R>(a.Fs, 0, i, 0), d, d, tid);
+    load_mat<R>(P, ldd, at<R>(a.Ps, 0, i, 0), d, d, tid);
+    load_vec<R>(bd, at<R>(a.bs, 0, i, 0), d, tid);
+    load_obs<R>(o, at<R>(a.Hs, 0, t, 0), at<R>(a.cs, 0, t, 0), at<R>(a.ys, 0, t, 0), p, d, ldd, tid);
+    // P^- = F P F^T + Q (not symmetrised, filtering.py:200-201 / predict)
+    gemm<false, false>(d, d, d, F, ldd, P, ldd, T1, ldd, (R)1, (R)0, tid);
+    gemm<false, true>(d, d, d, T1, ldd, F, ldd, P, ldd, (R)1, (R)0, tid);
+    {
+        const R* Qg = at<R>(a.Qs, 0, i, 0);
+        for (int r = tid / 64; r < d; r += NWV)
+            for (int q = tid & 63; q < d; q += 64) P[r * ldd + q] += Qg[(long long)r * d + q];
+    }
+    __syncthreads();
+    // S = H_ P^- H_^T + R_ ; right-hand sides H_ P^- and the identity.  A step with nothing observed needs no special case: H_ = 0, every row deleted -> X = 0, S^-1
+    // rows 0, half log-determinant 0, i.e. A = F, g = b, ell_t = 0 (_passthrough, filtering.py:239-248)
+    gemm<false, false>(p, d, d, o.H_, ldd, P, ldd, HP, ldd, (R)1, (R)0, tid);
+    gemm<false, true>(p, p, d, HP, ldd, o.H_, ldd, Z, ldz, (R)1, (R)0, tid);
+    {
+        const R* Rg = at<R>(a.Rs, 0, t, 0);
+        for (int r = tid / 64; r < p; r += NWV)
+            for (int q = tid & 63; q <= r; q += 64) {
+                const R v = Z[r * ldz + q] + ((o.nan[r] || o.nan[q]) ? (R)0 : Rg[(long long)q * p + r]);
+                Z[r * ldz + q] = v;
+                Z[q * ldz + r] = v;
+            }
+        for (int r = tid / 64; r < p; r += NWV) {
+            for (int q = tid & 63; q < d; q += 64) Z[r * ldz + p + q] = HP[r * ldd + q];
+            for (int q = tid & 63; q < p; q += 64) Z[r * ldz + p + d + q] = r == q ? (R)1 : (R)0;
+        }
+    }
+    __syncthreads();
+    R hl;
+    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
+    // H F;  A = F - X^T (H F);  hb = H_ b + c_;  g = b - X^T hb
+    gemm<false, false>(p, d, d, o.H_, ldd, F, ldd, HF, ldd, (R)1, (R)0, tid);
+    gemm<true, false>(d, d, p, Z + p, ldz, HF, ldd, T1, ldd, (R)-1, (R)1, tid, F, ldd);
+    gemv<R, false>(p, d, o.H_, ldd, bd, hb, (R)1, (R)0, tid);
+    for (int k = tid; k < p; k += NT) hb[k] = o.nan[k] ? (R)0 : hb[k] + o.c_[k];
+    __syncthreads();
+    gemv<R, true>(d, p, Z + p, ldz, hb, g0, (R)1, (R)0, tid);
+    const R bad = r_nan<R>();
+    for (int e = tid; e < p * ldd; e += NT) {
+        const int r = e / ldd, q = e - r * ldd;
+        row[g.oHF + e] = q < d ? HF[e] : (R)0;
+        row[g.oX + e] = q < d ? Z[r * ldz + p + q] : (R)0;
+    }
+    for (int e = tid; e < d * ldd; e += NT) {
+        const int r = e / ldd, q = e - r * ldd;
+        row[g.oA + e] = q < d ? (ok ? T1[e] : bad) : (R)0;  // a failed factorisation poisons the means from here on, as the reference's NaN gain does
+    }
+    for (int e = tid; e < p * ldpp; e += NT) {
+        const int r = e / ldpp, q = e - r * ldpp;
+        row[g.oS + e] = q < p ? Z[r * ldz + p + d + q] : (R)0;
+    }
+    R* vec = row + g.oV;
+    for (int k = tid; k < d; k += NT) vec[k] = bd[k] - g0[k];
+    for (int k = tid; k < p; k += NT) {
+        vec[d + k] = hb[k];
+        vec[d + p + k] = o.nan[k] ? (R)0 : (R)1;
+    }
+    if (tid == 0) {
+        vec[d + 2 * p] = ok ? -hl - (R)(0.5 * LOG_2PI) * (R)*o.cnt : bad;
+        vec[d + 2 * p + 1] = ok ? (R)1 : (R)0;
+    }
+}
+
+// ---- chunk composites: G_j (d x S) = the chunk's recursion started from 0, Abar_j = the product of its A's (block 0 of the sequences computes it) ----
+static size_t lds_mean_reduce(size_t s, int d, int p, int CB) {
+    const size_t ldd = ldp_(d), ldg = ldp_(CB + d), ldc = ldp_(CB);
+    return al16(d * ldd * s) + al16(p * ldd * s) + 2 * al16(d * ldg * s) + al16(p * ldc * s) + al16(d * s) + 64;
+}
+template <typename R>
+__global__ void __launch_bounds__(NT) wk_mean_reduce(FilterArgs a, const R* __restrict__ tab, R* __restrict__ aggA, R* __restrict__ aggG, int E, int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1, S = a.d.S();
+    const int j = blockIdx.x / ncb, cb = blockIdx.x - j * ncb, s0 = cb * CB;
+    const int i0 = j * E, i1 = i0 + E < n ? i0 + E : n;
+    const int ldd = ldp_(d), ldg = ldp_(CB + d), ldc = ldp_(CB), Spad = ncb * CB;
+    const bool doA = cb == 0;
+    const GRow g(d, p);
+    Bump L{smem};
+    R* Al = L.take<R>(d * ldd);
+    R* Xl = L.take<R>(p * ldd);
+    R* GA[2] = {L.take<R>(d * ldg), L.take<R>(d * ldg)};  // [G (d x CB) | Abar (d x d)]
+    R* Yl = L.take<R>(p * ldc);
+    R* gl = L.take<R>(d);
+    for (int e = tid; e < d * ldg; e += NT) {
+        const int r = e / ldg, q = e - r * ldg;
+        GA[0][e] = (q >= CB && q - CB == r) ? (R)1 : (R)0;
+        GA[1][e] = 0;
+    }
+    YTile<R> yt;
+    ytile_init<R>(yt, a, s0, CB, S, p, ldc, tid);
+    Img<R> ia, ix;
+    R gv = 0;
+    {
+        const R* row = tab + (long long)i0 * g.size;
+        img_fetch<R>(ia, row + g.oA, d * ldd, tid);
+        img_fetch<R>(ix, row + g.oX, p * ldd, tid);
+        if (tid < d) gv = row[g.oV + tid];
+        ytile_fetch<R>(yt, (long long)(i0 + 1) * a.ys.st);
+    }
+    int cur = 0;
+    for (int i = i0; i < i1; ++i) {
+        __syncthreads();  // the previous step's products have read Al / Xl / Yl / gl; its offsets are complete
+        img_drop<R>(ia, Al, d * ldd, tid);
+        img_drop<R>(ix, Xl, p * ldd, tid);
+        ytile_drop<R>(yt, Yl);
+        if (tid < d) gl[tid] = gv;
+        __syncthreads();
+        if (i + 1 < i1) {
+            const R* row = tab + (long long)(i + 1) * g.size;
+            img_fetch<R>(ia, row + g.oA, d * ldd, tid);
+            img_fetch<R>(ix, row + g.oX, p * ldd, tid);
+            if (tid < d) gv = row[g.oV + tid];
+            ytile_fetch<R>(yt, (long long)(i + 2) * a.ys.st);
+        }
+        R* c0 = GA[cur];
+        R* c1 = GA[cur ^ 1];
+        gemm<false, false>(d, doA ? CB + d : CB, d, Al, ldd, c0, ldg, c1, ldg, (R)1, (R)0, tid);
+        gemm<true, false>(d, CB, p, Xl, ldd, Yl, ldc, c1, ldg, (R)1, (R)1, tid);
+        for (int e = tid; e < d * CB; e += NT) {
+            const int r = e / CB, q = e - r * CB;
+            c1[r * ldg + q] += gl[r];
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    const R* fin = GA[cur];
+    for (int e = tid; e < d * CB; e += NT) {
+        const int r = e / CB, q = e - r * CB;
+        aggG[((long long)j * d + r) * Spad + s0 + q] = fin[r * ldg + q];
+    }
+    if (doA)
+        for (int e = tid; e < d * ldd; e += NT) {
+            const int r = e / ldd, q = e - r * ldd;
+            aggA[(long long)j * d * ldd + e] = q < d ? fin[r * ldg + CB + q] : (R)0;
+        }
+}
+
+// ---- the means at the chunk starts: M_0 = the t = 0 update (wk_filter_t0), M_{j+1} = Abar_j M_j + G_j; one workgroup per block of sequences ----
+static size_t lds_mean_aggs(size_t s, int d, int CB) {
+    const size_t ldd = ldp_(d), ldc = ldp_(CB);
+    return al16(d * ldd * s) + 3 * al16(d * ldc * s) + 64;
+}
+template <typename R>
+__global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __restrict__ aggA, const R* __restrict__ aggG, R* __restrict__ pre, int nchunk, int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, S = a.d.S(), cb = blockIdx.x, s0 = cb * CB;
+    const int ldd = ldp_(d), ldc = ldp_(CB), Spad = ncb * CB;
+    Bump L{smem};
+    R* Ab = L.take<R>(d * ldd);
+    R* M[2] = {L.take<R>(d * ldc), L.take<R>(d * ldc)};
+    R* Gl = L.take<R>(d * ldc);
+    for (int e = tid; e < d * CB; e += NT) {
+        const int sl = e / d, r = e - sl * d, s = s0 + sl;
+        M[0][r * ldc + sl] = s < S ? at<R>(a.ms, s / a.d.B, 0, s % a.d.B)[(long long)r * a.ms.se] : (R)0;
+    }
+    Img<R> ia, ig;  // d * CB <= 85 * 64 < 8 NT
+    if (nchunk > 1) {
+        img_fetch<R>(ia, aggA, d * ldd, tid);
+#pragma unroll
+        for (int u = 0; u < SH_NR; ++u) {
+            const int e = tid + u * NT, r = e / CB, q = e - r * CB;
+            ig.v[u] = e < d * CB ? aggG[(long long)r * Spad + s0 + q] : (R)0;
+        }
+    }
+    int cur = 0;
+    for (int j = 0; j < nchunk; ++j) {
+        __syncthreads();
+        const R* m = M[cur];
+        for (int e = tid; e < d * CB; e += NT) {
+            const int r = e / CB, q = e - r * CB;
+            pre[((long long)j * d + r) * Spad + s0 + q] = m[r * ldc + q];
+        }
+        if (j + 1 == nchunk) break;
+        img_drop<R>(ia, Ab, d * ldd, tid);
+#pragma unroll
+        for (int u = 0; u < SH_NR; ++u) {
+            const int e = tid + u * NT, r = e / CB, q = e - r * CB;
+            if (e < d * CB) Gl[r * ldc + q] = ig.v[u];
+        }
+        __syncthreads();
+        if (j + 2 < nchunk) {
+            img_fetch<R>(ia, aggA + (long long)(j + 1) * d * ldd, d * ldd, tid);
+#pragma unroll
+            for (int u = 0; u < SH_NR; ++u) {
+                const int e = tid + u * NT, r = e / CB, q = e - r * CB;
+                ig.v[u] = e < d * CB ? aggG[((long long)(j + 1) * d + r) * Spad + s0 + q] : (R)0;
+            }
+        }
+        gemm<false, false>(d, CB, d, Ab, ldd, m, ldc, M[cur ^ 1], ldc, (R)1, (R)1, tid, Gl, ldc);
+        cur ^= 1;
+    }
+}
+
+// ---- down pass: each chunk re-walked from its true start; means written, log-likelihood increments accumulated per sequence -------------------
+static size_t lds_mean_down(size_t s, int d, int p, int CB) {
+    const size_t ldd = ldp_(d), ldpp = ldp_(p), ldc = ldp_(CB);
+    return al16((p + d) * ldd * s) + al16(p * ldd * s) + al16(p * ldpp * s) + 2 * al16(d * ldc * s) + al16((p + d) * ldc * s) + 2 * al16(p * ldc * s) +
+           al16((d + 2 * p + 2) * s) + al16(NWV * CB * s) + 64;
+}
+template <typename R>
+__global__ void __launch_bounds__(NT) wk_mean_down(FilterArgs a, const R* __restrict__ tab, const R* __restrict__ pre, R* __restrict__ ellpart, int E, int nchunk, int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = a.dx, p = a.dy, n = a.d.T - 1, S = a.d.S();
+    const int j = blockIdx.x / ncb, cb = blockIdx.x - j * ncb, s0 = cb * CB;
+    const int i0 = j * E, i1 = i0 + E < n ? i0 + E : n;
+    const int ldd = ldp_(d), ldpp = ldp_(p), ldc = ldp_(CB), Spad = ncb * CB;
+    const GRow g(d, p);
+    Bump L{smem};
+    R* HA = L.take<R>((p + d) * ldd);  // [H F ; A]
+    R* Xl = L.take<R>(p * ldd);
+    R* Sl = L.take<R>(p * ldpp);
+    R* M[2] = {L.take<R>(d * ldc), L.take<R>(d * ldc)};
+    R* VM = L.take<R>((p + d) * ldc);  // [H F m ; A m] -> rows < p become the innovations v
+    R* Yl = L.take<R>(p * ldc);
+    R* Ul = L.take<R>(p * ldc);
+    R* vec = L.take<R>(d + 2 * p + 2);
+    R* qpart = L.take<R>(NWV * CB);
+    for (int e = tid; e < d * CB; e += NT) {
+        const int r = e / CB, q = e - r * CB;
+        M[0][r * ldc + q] = pre[((long long)j * d + r) * Spad + s0 + q];
+    }
+    YTile<R> yt;
+    ytile_init<R>(yt, a, s0, CB, S, p, ldc, tid);
+    // the means of time t: element (sequence sl, component r) -> ms[s, t, r]
+    constexpr int NM = 6;  // d * CB <= 85 * 64 < 6 NT
+    R* mbase[NM];
+    int moff[NM], mrow[NM];
+#pragma unroll
+    for (int u = 0; u < NM; ++u) {
+        const int e = tid + u * NT, sl = e / d, r = e - sl * d, s = s0 + sl;
+        const bool v = sl < CB && s < S;
+        mbase[u] = v ? const_cast<R*>(at<R>(a.ms, s / a.d.B, 0, s % a.d.B)) + (long long)r * a.ms.se : nullptr;
+        moff[u] = sl < CB ? r * ldc + sl : -1;
+        mrow[u] = r;
+    }
+    Img<R> ih, ia, ix, is;
+    R vv[3] = {0, 0, 0};  // d + 2 p + 2 <= 3 NT
+    auto fetch = [&](int i) {
+        const R* row = tab + (long long)i * g.size;
+        img_fetch<R>(ih, row + g.oHF, p * ldd, tid);
+        img_fetch<R>(ia, row + g.oA, d * ldd, tid);
+        img_fetch<R>(ix, row + g.oX, p * ldd, tid);
+        img_fetch<R>(is, row + g.oS, p * ldpp, tid);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = tid + u * NT;
+            vv[u] = e < d + 2 * p + 2 ? row[g.oV + e] : (R)0;
+        }
+        ytile_fetch<R>(yt, (long long)(i + 1) * a.ys.st);
+    };
+    fetch(i0);
+    R ellacc = 0;
+    int cur = 0;
+    for (int i = i0; i < i1; ++i) {
+        __syncthreads();
+        img_drop<R>(ih, HA, p * ldd, tid);
+        img_drop<R>(ia, HA + p * ldd, d * ldd, tid);
+        img_drop<R>(ix, Xl, p * ldd, tid);
+        img_drop<R>(is, Sl, p * ldpp, tid);
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+            const int e = tid + u * NT;
+            if (e < d + 2 * p + 2) vec[e] = vv[u];
+        }
+        ytile_drop<R>(yt, Yl);
+        __syncthreads();
+        if (i + 1 < i1) fetch(i + 1);
+        const R* m = M[cur];
+        R* mn = M[cur ^ 1];
+        gemm<false, false>(p + d, CB, d, HA, ldd, m, ldc, VM, ldc, (R)1, (R)0, tid);
+        // v = mask (y - H F m - hb)
+        for (int e = tid; e < p * CB; e += NT) {
+            const int k = e / CB, q = e - k * CB;
+            VM[k * ldc + q] = vec[d + p + k] != (R)0 ? Yl[k * ldc + q] - VM[k * ldc + q] - vec[d + k] : (R)0;
+        }
+        __syncthreads();
+        gemm<false, false>(p, CB, p, Sl, ldpp, VM, ldc, Ul, ldc, (R)1, (R)0, tid, nullptr, 0, false);
+        gemm<true, false>(d, CB, p, Xl, ldd, Yl, ldc, mn, ldc, (R)1, (R)1, tid, VM + p * ldc, ldc);  // A m + K y  (trailing barrier: Ul complete too)
+        // q_s = v_s^T S^-1 v_s: lane's sequence is tid % CB (NT % CB == 0), partial over its rows, then over the lanes / waves of that sequence
+        {
+            R acc = 0;
+            for (int e = tid; e < p * CB; e += NT) {
+                const int k = e / CB, q = e - k * CB;
+                acc += VM[k * ldc + q] * Ul[k * ldc + q];
+            }
+            for (int off = CB; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
+            if (lane < CB) qpart[wv * CB + lane] = acc;
+        }
+        // m_t = A m + K y + g: finished in place and written out
+        const long long tst = (long long)(i + 1) * a.ms.st;
+#pragma unroll
+        for (int u = 0; u < NM; ++u)
+            if (moff[u] >= 0) {
+                const R val = mn[moff[u]] + vec[mrow[u]];
+                mn[moff[u]] = val;
+                if (mbase[u]) mbase[u][tst] = val;
+            }
+        __syncthreads();
+        if (tid < CB) {
+            R q = 0;
+            for (int w = 0; w < NWV; ++w) q += qpart[w * CB + tid];
+            const R e = (R)-0.5 * q + vec[d + 2 * p];
+            ellacc += isnan_(e) ? (R)0 : e;  // the reference's nansum (filtering.py:62)
+        }
+        cur ^= 1;
+    }
+    if (tid < CB && s0 + tid < S) ellpart[(long long)(s0 + tid) * nchunk + j] = ellacc;
+}
+
+// ---- the covariances of sequence 0 (the matrix filter's) copied to the other sequences' output slots, t >= 1; one workgroup per time step ------
+template <typename R> __global__ void __launch_bounds__(NT) wk_ps_bcast(FilterArgs a) {
+    const int tid = threadIdx.x, d = a.dx, S = a.d.S();
+    const long long t = (long long)blockIdx.x + 1;
+    const R* src = at<R>(a.Ps, 0, t, 0);
+    R v[SH_NR];
+#pragma unroll
+    for (int u = 0; u < SH_NR; ++u) {
+        const int e = tid + u * NT;
+        v[u] = e < d * d ? src[e] : (R)0;
+    }
+    for (int s = 1; s < S; ++s) {
+        R* dst = const_cast<R*>(at<R>(a.Ps, s / a.d.B, t, s % a.d.B));
+#pragma unroll
+        for (int u = 0; u < SH_NR; ++u) {
+            const int e = tid + u * NT;
+            if (e < d * d) dst[e] = v[u];
+        }
+    }
+}

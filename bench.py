@@ -537,7 +537,7 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
     out = dict(workload=f"C5: dense LG-SSM d=p={d} T={T} fp32, first-order auxiliary observations, wide-state filter (parallel scan)", runs=[])
     for S in seqs:
         dl = DeviceLGSSM(handle, tuple(lg64), 1, T, 1, d, d, False, f32)  # chain-shared parameters (stride 0), S sequences of observations
-        ys = np.ascontiguousarray(np.broadcast_to(u.astype(f32)[None], (S, T, d)))
+        ys = (u[None] + np.concatenate([np.zeros((1, T, d)), 0.3 * np.random.default_rng(4).standard_normal((S - 1, T, d))])).astype(f32)  # S different sequences
         yd = handle.to_device(ys)
         yarr = yd.arr(T * d, d, 0)
         ms = handle.empty((S, T, 1, d), f32)
@@ -550,8 +550,10 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
 
         el, groups = ctx.timed(step, steps, 1)
         scan = groups.get("filter_scan", (0, 0.0))[1] / steps
-        flops = S * 2 * (T - 1) * 19.3 * d ** 3
-        ent = dict(sequences_per_launch=S, filters_per_s=round(S * ctx.world * steps / el, 2), ms_per_filter_call=round(el / steps * 1e3, 3),
+        shared = "filter_tab" in groups  # chain-shared parameters: ONE matrix recursion (sequence 0), the other sequences ride as columns of the mean scan
+        flops = (1 if shared else S) * 2 * (T - 1) * 19.3 * d ** 3
+        ent = dict(sequences_per_launch=S, path=("shared: one matrix filter + gain table (filter_tab) + mean / log-likelihood scan of all sequences (filter_ell)"
+                                                 if shared else "per sequence"), filters_per_s=round(S * ctx.world * steps / el, 2), ms_per_filter_call=round(el / steps * 1e3, 3),
                    kernels={g: round(t / steps, 3) for g, (n, t) in groups.items()})
         if scan:
             tf = flops / (scan * 1e-3) / 1e12

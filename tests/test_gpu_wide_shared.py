@@ -1,0 +1,135 @@
+"""The wide-state filter for SEVERAL sequences that share every model parameter (csrc/wide_shared.h: one matrix recursion on sequence 0, the
+gain-form affine mean recursion of all sequences as the columns of one matrix) against
+  (1) the per-sequence path of the same library (AUXSSM_OPT_SHARE_MODEL = 0: every sequence runs the full associative scan of filtering.py:163-183),
+  (2) the NumPy oracle (oracle/kalman_np.py::filtering, filtering.py:18-250 line by line) sequence by sequence,
+including time-varying parameters, missing observations (one pattern for all sequences: the shared form; differing patterns: the library must
+notice and run the per-sequence path), steps with nothing observed, more sequences than one column block, and C5's sizes.
+Tolerances: fp64 rtol 1e-8 / atol 1e-10; fp32 5e-4 (as tests/test_gpu_wide.py)."""
+import ctypes as C
+
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+from oracle import kalman_np as K
+from tests.helpers import c5_model
+from tests.test_gpu_wide import stable_model
+
+pytestmark = pytest.mark.gpu
+
+
+def device_filter(lg, ys, dtype, share=True):
+    """auxssm_kalman_filter on S sequences ys (S, T, p) with ONE parameter set (chain stride 0); returns ms, Ps, ell and the launch groups that ran"""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    h = _lib.default_handle()
+    S, T, p = ys.shape
+    d = lg[0].shape[-1]
+    dl = DeviceLGSSM(h, tuple(lg), 1, T, 1, d, p, False, dtype)
+    yd = h.to_device(np.ascontiguousarray(ys, dtype))
+    yarr = yd.arr(T * p, p, 0)
+    ms, Ps, ell = h.empty((S, T, d), dtype), h.empty((S, T, d, d), dtype), h.empty((S,), dtype)
+    dims = _lib.Dims(S, T, 1, d, p)
+    h.set_option(_lib.OPT_SHARE_MODEL, 1 if share else 0)
+    try:
+        h.prof_enable(_lib.K_ALL, 64)
+        _lib.check(h.lib.auxssm_kalman_filter(h.h, _lib.dtype_code(dtype), C.byref(dims), C.byref(dl.c), C.byref(yarr), 1, ms.ptr, Ps.ptr, ell.ptr))
+        groups = h.prof_read_groups()
+    finally:
+        h.prof_disable()
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    return ms.to_host(), Ps.to_host(), ell.to_host(), groups
+
+
+def check(lg, ys, dtype, expect_shared=True, tol=None):
+    tol = tol or (dict(rtol=1e-8, atol=1e-10) if dtype == np.float64 else dict(rtol=5e-4, atol=5e-4))
+    ms, Ps, ell, groups = device_filter(lg, ys, dtype, True)
+    assert ("filter_tab" in groups) == expect_shared, groups
+    ms1, Ps1, ell1, g1 = device_filter(lg, ys, dtype, False)
+    assert "filter_tab" not in g1
+    npt.assert_allclose(ms, ms1, **tol)
+    npt.assert_allclose(Ps, Ps1, **tol)
+    npt.assert_allclose(ell, ell1, rtol=tol["rtol"], atol=tol["atol"])
+    for s in range(ys.shape[0]):
+        oms, oPs, oell = K.filtering(ys[s], lg, True)
+        npt.assert_allclose(ms[s], oms, **tol)
+        npt.assert_allclose(Ps[s], oPs, **tol)
+        npt.assert_allclose(ell[s], oell, rtol=tol["rtol"], atol=tol["atol"])
+
+
+@pytest.mark.parametrize("d,p,T,S", [(8, 8, 50, 3), (16, 5, 130, 16), (12, 20, 257, 5), (6, 11, 300, 70), (33, 40, 60, 20), (5, 3, 9, 2)])
+def test_shared_vs_per_sequence_and_oracle_fp64(d, p, T, S):
+    rng = np.random.default_rng(d * 1000 + T)
+    y0, lg = stable_model(rng, T, d, p, nan=False)
+    ys = y0[None] + rng.standard_normal((S, T, p))
+    check(lg, ys, np.float64)
+
+
+@pytest.mark.parametrize("d,p,T,S", [(8, 8, 64, 4), (12, 7, 257, 17), (16, 16, 40, 3)])
+def test_missing_observations_one_pattern(d, p, T, S):
+    """NaN rows (nothing observed at that step), scattered NaN components: the pattern of sequence 0 for all -> still the shared form"""
+    rng = np.random.default_rng(T + S)
+    y0, lg = stable_model(rng, T, d, p, nan=True)
+    ys = y0[None] + rng.standard_normal((S, T, p))  # NaN + x = NaN: same pattern everywhere
+    assert np.isnan(ys).any() and np.isnan(ys[0]).all(1).any()
+    check(lg, ys, np.float64)
+
+
+def test_differing_patterns_fall_back_to_the_per_sequence_path():
+    rng = np.random.default_rng(3)
+    d, p, T, S = 8, 6, 40, 3
+    y0, lg = stable_model(rng, T, d, p, nan=True)
+    ys = y0[None] + rng.standard_normal((S, T, p))
+    ys[1, 7, 2] = np.nan if np.isfinite(ys[0, 7, 2]) else 0.3
+    check(lg, ys, np.float64, expect_shared=False)
+
+
+def test_sequence_dependent_parameters_are_not_shared():
+    """a per-sequence parameter array (chain stride != 0) must never take the shared form"""
+    from aux_ssm_samplers_amd import _lib
+    import aux_ssm_samplers_amd._primitives.kalman as P
+    rng = np.random.default_rng(5)
+    d, p, T = 6, 9, 30
+    y0, lg = stable_model(rng, T, d, p, nan=False)
+    h = _lib.default_handle()
+    h.prof_enable(_lib.K_ALL, 64)
+    try:
+        P.filtering(y0, P.LGSSM(*lg), True)
+        assert "filter_tab" not in h.prof_read_groups()
+    finally:
+        h.prof_disable()
+
+
+@pytest.mark.parametrize("dtype,d,T,S", [(np.float32, 64, 96, 16), (np.float64, 40, 40, 4), (np.float32, 64, 40, 70)])
+def test_C5_sizes(dtype, d, T, S):
+    u, lg64, x = c5_model(T, d)
+    rng = np.random.default_rng(2)
+    ys = u[None] + 0.3 * rng.standard_normal((S, T, d))
+    check([np.ascontiguousarray(a) for a in lg64], ys, dtype)
+
+
+def test_C5_benchmarked_horizon_16_sequences():
+    """T = 8192, d = p = 64, fp32, 16 sequences (what bench.py's C5 leg times): sequence 0 carries the fixture's observations and is checked against the
+    committed fp64 sequential answers (tests/golden/c5_T8192_known_answers.npz, tolerance 2e-3 as in tests/test_gpu_wide.py); the other sequences
+    against the per-sequence path of the library at a few time points."""
+    import os
+    ref = np.load(os.path.join(os.path.dirname(__file__), "golden", "c5_T8192_known_answers.npz"))
+    T, d, S = 8192, 64, 16
+    u, lg64, _ = c5_model(T, d)
+    rng = np.random.default_rng(4)
+    ys = u[None] + np.concatenate([np.zeros((1, T, d)), 0.3 * rng.standard_normal((S - 1, T, d))])
+    lg = [np.ascontiguousarray(a) for a in lg64]
+    ms, Ps, ell, groups = device_filter(lg, ys, np.float32, True)
+    assert "filter_tab" in groups
+    idx = ref["idx"]
+    tol = dict(rtol=2e-3, atol=2e-3)
+    npt.assert_allclose(ms[0][idx], ref["ms"], **tol)
+    npt.assert_allclose(np.einsum("tii->ti", Ps[0][idx]), ref["Ps_diag"], **tol)
+    assert abs(float(ell[0]) - float(ref["ell"])) / abs(float(ref["ell"])) < 1e-4
+    e_m = np.max(np.abs(ms[0][idx] - ref["ms"]))
+    ms1, Ps1, ell1, _ = device_filter(lg, ys[[0, 5, 15]], np.float32, False)
+    for k, s in enumerate([0, 5, 15]):
+        npt.assert_allclose(ms[s][idx], ms1[k][idx], **tol)
+        npt.assert_allclose(Ps[s][idx], Ps1[k][idx], **tol)
+        assert abs(float(ell[s]) - float(ell1[k])) / abs(float(ell1[k])) < 1e-4
+    print(f"shared wide filter, T=8192 x 16: max|dm| vs fp64 fixture {e_m:.2e}; groups {groups}")

@@ -44,7 +44,7 @@ def table(unit):
 
 
 if __name__ == "__main__":
-    if sys.argv[1] == "--json":  # python tools/kernel_resources.py --json wide.hip > profiles/r02_wide_resources.json
+    if sys.argv[1] == "--json":  # python tools/kernel_resources.py --json wide.hip > profiles/r03_wide_resources.json
         import json
         print(json.dumps(table(sys.argv[2]), indent=1, sort_keys=True))
         sys.exit(0)
