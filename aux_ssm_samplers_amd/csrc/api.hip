@@ -1462,6 +1462,11 @@ int auxssm_destroy(auxssm_handle h) {
         }
         (void)hipEventDestroy(h->side.fence);
     }
+    if (h->fork_stream) {
+        (void)hipEventDestroy(h->fork_ev);
+        (void)hipEventDestroy(h->join_ev);
+        (void)hipStreamDestroy(h->fork_stream);
+    }
     (void)hipStreamDestroy(h->stream);
     delete h;
     return AUXSSM_OK;

@@ -54,6 +54,10 @@ struct auxssm_ctx {
     int overlap_model_stage = 0;       // AUXSSM_OPT_OVERLAP_MODEL_STAGE (off unless the caller opts in: include/auxssm.h)
     bool stream_exposed = false;       // auxssm_stream() has handed out `stream`: work the library cannot see may be queued on it, so a model stage
                                        // always waits for the tail of `stream` from then on (side_open)
+    // a helper stream for memory-bound side work of ONE call that needs none of the call's later results (the covariance broadcast of the chain-shared wide
+    // filter): forked from `stream` by an event, joined back before the call returns -- never visible to the caller (lazily created)
+    hipStream_t fork_stream = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     double* dblock = nullptr;  // {delta, sqrt(delta / 2)} of a sweep whose step size is device-resident (auxssm_kalman_sweep_dd); lazily allocated
     // The MODEL STAGE of a chain-shared sweep -- concatenated observation model, matrix filter on one sequence, gain table: ~0.4 ms of short dependent
     // launches that read the model and the step size only, never a chain -- runs on a second stream with its own double-buffered slab, so that the

@@ -2414,18 +2414,43 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
         const int rc = run_filter<R>(h, a1, 1, ell_seq0);
         if (rc) return rc;
     }
+    // the other sequences' covariance slots are copies of sequence 0's: pure memory traffic that only needs the matrix filter -- on the fork stream,
+    // beside the gain table (matrix cores / latency) and the one-workgroup pass over the chunk composites
+    bool forked = false;
+    const bool prof_all = h->prof.kernel_id == AUXSSM_K_ALL && h->prof.max_launches > 0;
+    if (!prof_all && !getenv("AUXSSM_WIDE_NO_FORK")) {
+        if (!h->fork_stream) {
+            AX_HIP(hipStreamCreateWithFlags(&h->fork_stream, hipStreamNonBlocking));
+            AX_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
+            AX_HIP(hipEventCreateWithFlags(&h->join_ev, hipEventDisableTiming));
+        }
+        AX_HIP(hipEventRecord(h->fork_ev, h->stream));
+        AX_HIP(hipStreamWaitEvent(h->fork_stream, h->fork_ev, 0));
+        hipLaunchKernelGGL((wk_ps_bcast<R>), dim3(n), dim3(NT), 0, h->fork_stream, fa);
+        AX_HIP(hipEventRecord(h->join_ev, h->fork_stream));
+        forked = true;
+    } else {
+        ProfScope ps(h, AUXSSM_K_SELECT);  // (profiled runs keep everything on the one stream: the group times then add up)
+        hipLaunchKernelGGL((wk_ps_bcast<R>), dim3(n), dim3(NT), 0, h->stream, fa);
+    }
     {
         ProfScope ps(h, AUXSSM_K_FILTER_TAB);
         WK_LAUNCH((wk_gain_tab<R>), n, l_tab, fa, tab);
     }
     {
         ProfScope ps(h, AUXSSM_K_FILTER_ELL);
-        if (sp.nchunk > 1) WK_LAUNCH((wk_mean_reduce<R>), (long long)sp.nchunk * sp.ncb, l_red, fa, (const R*)tab, aggA, aggG, sp.E, sp.ncb, sp.CB);
-        WK_LAUNCH((wk_mean_aggs<R>), sp.ncb, l_agg, fa, (const R*)aggA, (const R*)aggG, pre, sp.nchunk, sp.ncb, sp.CB);
-        WK_LAUNCH((wk_mean_down<R>), (long long)sp.nchunk * sp.ncb, l_down, fa, (const R*)tab, (const R*)pre, ellpart, sp.E, sp.nchunk, sp.ncb, sp.CB);
-        hipLaunchKernelGGL((wk_ps_bcast<R>), dim3(n), dim3(NT), 0, h->stream, fa);
+#define AX_MEAN(NRI)                                                                                                                                                         \
+    do {                                                                                                                                                                  \
+        if (sp.nchunk > 1) WK_LAUNCH((wk_mean_reduce<R, NRI>), (long long)sp.nchunk * sp.ncb, l_red, fa, (const R*)tab, aggA, aggG, sp.E, sp.ncb, sp.CB);                  \
+        WK_LAUNCH((wk_mean_aggs<R, NRI>), sp.ncb, l_agg, fa, (const R*)aggA, (const R*)aggG, pre, sp.nchunk, sp.ncb, sp.CB);                                               \
+        WK_LAUNCH((wk_mean_down<R, NRI>), (long long)sp.nchunk * sp.ncb, l_down, fa, (const R*)tab, (const R*)pre, ellpart, sp.E, sp.nchunk, sp.ncb, sp.CB);              \
+    } while (0)
+        if ((long long)std::max(d, p) * ldp_(std::max(d, p)) <= 5ll * NT) AX_MEAN(5);
+        else AX_MEAN(SH_NR);
+#undef AX_MEAN
     }
     hipLaunchKernelGGL((wk_reduce<R>), dim3(a.d.C), dim3(NT), 0, h->stream, (const R*)ellpart, (const R*)ell0, a.d.B, (long long)sp.nchunk, (R*)ell_out);
+    if (forked) AX_HIP(hipStreamWaitEvent(h->stream, h->join_ev, 0));
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -32,19 +32,19 @@ struct GRow {
 
 // one padded matrix image (<= 85 x 85 reals) in flight: fetched a step ahead into registers, dropped into LDS at the top of its step
 constexpr int SH_NR = 8;
-template <typename R> struct Img {
-    R v[SH_NR];
+template <typename R, int NRI = SH_NR> struct Img {  // NRI = 5 holds 71 x 71 (C5's 64 x 65 images): three registers per image less than the general 8
+    R v[NRI];
 };
-template <typename R> __device__ __forceinline__ void img_fetch(Img<R>& g, const R* __restrict__ src, int count, int tid) {
+template <typename R, int NRI> __device__ __forceinline__ void img_fetch(Img<R, NRI>& g, const R* __restrict__ src, int count, int tid) {
 #pragma unroll
-    for (int u = 0; u < SH_NR; ++u) {
+    for (int u = 0; u < NRI; ++u) {
         const int e = tid + u * NT;
         g.v[u] = e < count ? src[e] : (R)0;
     }
 }
-template <typename R> __device__ __forceinline__ void img_drop(const Img<R>& g, R* dst, int count, int tid) {
+template <typename R, int NRI> __device__ __forceinline__ void img_drop(const Img<R, NRI>& g, R* dst, int count, int tid) {
 #pragma unroll
-    for (int u = 0; u < SH_NR; ++u) {
+    for (int u = 0; u < NRI; ++u) {
         const int e = tid + u * NT;
         if (e < count) dst[e] = g.v[u];
     }
@@ -121,39 +121,94 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_gain_tab(FilterAr
     R* rowbuf = L.take<R>(2 * (nct + 1) + NWV);
     o.nan = L.take<unsigned char>(p);
     o.cnt = L.take<int>(1);
-    load_mat<R>(F, ldd, at<R>(a.Fs, 0, i, 0), d, d, tid);
-    load_mat<R>(P, ldd, at<R>(a.Ps, 0, i, 0), d, d, tid);
-    load_vec<R>(bd, at<R>(a.bs, 0, i, 0), d, tid);
-    load_obs<R>(o, at<R>(a.Hs, 0, t, 0), at<R>(a.cs, 0, t, 0), at<R>(a.ys, 0, t, 0), p, d, ldd, tid);
+    // every global operand of the step is requested before anything waits: one 1024-lane workgroup fills a CU, so nothing else hides the latency
+    Img<R> rF, rP, rQ, rH, rR;
+    img_fetch(rF, at<R>(a.Fs, 0, i, 0), d * d, tid);
+    img_fetch(rP, at<R>(a.Ps, 0, i, 0), d * d, tid);
+    img_fetch(rH, at<R>(a.Hs, 0, t, 0), p * d, tid);
+    img_fetch(rQ, at<R>(a.Qs, 0, i, 0), d * d, tid);
+    img_fetch(rR, at<R>(a.Rs, 0, t, 0), p * p, tid);
+    const R vb_ = tid < d ? at<R>(a.bs, 0, i, 0)[tid] : (R)0;
+    const R vy_ = tid < p ? at<R>(a.ys, 0, t, 0)[(long long)tid * a.ys.se] : (R)0;
+    const R vc_ = tid < p ? at<R>(a.cs, 0, t, 0)[tid] : (R)0;
+    if (tid == 0) *o.cnt = 0;
+    __syncthreads();
+    if (tid < d) bd[tid] = vb_;
+    if (tid < p) {  // load_obs (filtering.py:89-100): a missing component deletes its row of H and its offset
+        const bool nn = !finite_(vy_);
+        o.nan[tid] = nn;
+        o.y[tid] = vy_;
+        o.c_[tid] = nn ? (R)0 : vc_;
+        if (!nn) atomicAdd(o.cnt, 1);
+    }
+#pragma unroll
+    for (int u = 0; u < SH_NR; ++u) {
+        const int e = tid + u * NT;
+        if (e < d * d) {
+            const int r = e / d, q = e - r * d;
+            F[r * ldd + q] = rF.v[u];
+            P[r * ldd + q] = rP.v[u];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < SH_NR; ++u) {
+        const int e = tid + u * NT;
+        if (e < p * d) {
+            const int r = e / d, q = e - r * d;
+            o.H_[r * ldd + q] = o.nan[r] ? (R)0 : rH.v[u];
+        }
+    }
+#if defined(AUXSSM_GT_PHASE)
+    if (AUXSSM_GT_PHASE == 1) return;
+#endif
     // P^- = F P F^T + Q (not symmetrised, filtering.py:200-201 / predict)
     gemm<false, false>(d, d, d, F, ldd, P, ldd, T1, ldd, (R)1, (R)0, tid);
     gemm<false, true>(d, d, d, T1, ldd, F, ldd, P, ldd, (R)1, (R)0, tid);
-    {
-        const R* Qg = at<R>(a.Qs, 0, i, 0);
-        for (int r = tid / 64; r < d; r += NWV)
-            for (int q = tid & 63; q < d; q += 64) P[r * ldd + q] += Qg[(long long)r * d + q];
+#pragma unroll
+    for (int u = 0; u < SH_NR; ++u) {
+        const int e = tid + u * NT;
+        if (e < d * d) {
+            const int r = e / d, q = e - r * d;
+            P[r * ldd + q] += rQ.v[u];
+        }
     }
     __syncthreads();
+#if defined(AUXSSM_GT_PHASE)
+    if (AUXSSM_GT_PHASE == 2) return;
+#endif
     // S = H_ P^- H_^T + R_ ; right-hand sides H_ P^- and the identity.  A step with nothing observed needs no special case: H_ = 0, every row deleted -> X = 0, S^-1
     // rows 0, half log-determinant 0, i.e. A = F, g = b, ell_t = 0 (_passthrough, filtering.py:239-248)
     gemm<false, false>(p, d, d, o.H_, ldd, P, ldd, HP, ldd, (R)1, (R)0, tid);
     gemm<false, true>(p, p, d, HP, ldd, o.H_, ldd, Z, ldz, (R)1, (R)0, tid);
     {
-        const R* Rg = at<R>(a.Rs, 0, t, 0);
-        for (int r = tid / 64; r < p; r += NWV)
-            for (int q = tid & 63; q <= r; q += 64) {
-                const R v = Z[r * ldz + q] + ((o.nan[r] || o.nan[q]) ? (R)0 : Rg[(long long)q * p + r]);
-                Z[r * ldz + q] = v;
-                Z[q * ldz + r] = v;
+        // the value the reference computes for the upper entry (q, r), q <= r: (H_ P^- H_^T)[r][q] + R[q][r], mirrored (as wk_filter_t0)
+#pragma unroll
+        for (int u = 0; u < SH_NR; ++u) {
+            const int e = tid + u * NT;
+            if (e < p * p) {
+                const int q = e / p, r = e - q * p;
+                if (q <= r) {
+                    const R v = Z[r * ldz + q] + ((o.nan[r] || o.nan[q]) ? (R)0 : rR.v[u]);
+                    Z[r * ldz + q] = v;
+                    Z[q * ldz + r] = v;
+                }
             }
+        }
         for (int r = tid / 64; r < p; r += NWV) {
             for (int q = tid & 63; q < d; q += 64) Z[r * ldz + p + q] = HP[r * ldd + q];
             for (int q = tid & 63; q < p; q += 64) Z[r * ldz + p + d + q] = r == q ? (R)1 : (R)0;
         }
     }
     __syncthreads();
+#if defined(AUXSSM_GT_PHASE)
+    if (AUXSSM_GT_PHASE == 3) return;
+#endif
     R hl;
     const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
+#if defined(AUXSSM_GT_PHASE)
+    if (AUXSSM_GT_PHASE == 4) return;
+#endif
     // H F;  A = F - X^T (H F);  hb = H_ b + c_;  g = b - X^T hb
     gemm<false, false>(p, d, d, o.H_, ldd, F, ldd, HF, ldd, (R)1, (R)0, tid);
     gemm<true, false>(d, d, p, Z + p, ldz, HF, ldd, T1, ldd, (R)-1, (R)1, tid, F, ldd);
@@ -161,6 +216,9 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_gain_tab(FilterAr
     for (int k = tid; k < p; k += NT) hb[k] = o.nan[k] ? (R)0 : hb[k] + o.c_[k];
     __syncthreads();
     gemv<R, true>(d, p, Z + p, ldz, hb, g0, (R)1, (R)0, tid);
+#if defined(AUXSSM_GT_PHASE)
+    if (AUXSSM_GT_PHASE == 5) return;
+#endif
     const R bad = r_nan<R>();
     for (int e = tid; e < p * ldd; e += NT) {
         const int r = e / ldd, q = e - r * ldd;
@@ -192,7 +250,7 @@ static size_t lds_mean_reduce(size_t s, int d, int p, int CB) {
     const size_t ldd = ldp_(d), ldg = ldp_(CB + d), ldc = ldp_(CB);
     return al16(d * ldd * s) + al16(p * ldd * s) + 2 * al16(d * ldg * s) + al16(p * ldc * s) + al16(d * s) + 64;
 }
-template <typename R>
+template <typename R, int NRI>
 __global__ void __launch_bounds__(NT) wk_mean_reduce(FilterArgs a, const R* __restrict__ tab, R* __restrict__ aggA, R* __restrict__ aggG, int E, int ncb, int CB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, p = a.dy, n = a.d.T - 1, S = a.d.S();
@@ -214,27 +272,27 @@ __global__ void __launch_bounds__(NT) wk_mean_reduce(FilterArgs a, const R* __re
     }
     YTile<R> yt;
     ytile_init<R>(yt, a, s0, CB, S, p, ldc, tid);
-    Img<R> ia, ix;
+    Img<R, NRI> ia, ix;
     R gv = 0;
     {
         const R* row = tab + (long long)i0 * g.size;
-        img_fetch<R>(ia, row + g.oA, d * ldd, tid);
-        img_fetch<R>(ix, row + g.oX, p * ldd, tid);
+        img_fetch(ia, row + g.oA, d * ldd, tid);
+        img_fetch(ix, row + g.oX, p * ldd, tid);
         if (tid < d) gv = row[g.oV + tid];
         ytile_fetch<R>(yt, (long long)(i0 + 1) * a.ys.st);
     }
     int cur = 0;
     for (int i = i0; i < i1; ++i) {
         __syncthreads();  // the previous step's products have read Al / Xl / Yl / gl; its offsets are complete
-        img_drop<R>(ia, Al, d * ldd, tid);
-        img_drop<R>(ix, Xl, p * ldd, tid);
+        img_drop(ia, Al, d * ldd, tid);
+        img_drop(ix, Xl, p * ldd, tid);
         ytile_drop<R>(yt, Yl);
         if (tid < d) gl[tid] = gv;
         __syncthreads();
         if (i + 1 < i1) {
             const R* row = tab + (long long)(i + 1) * g.size;
-            img_fetch<R>(ia, row + g.oA, d * ldd, tid);
-            img_fetch<R>(ix, row + g.oX, p * ldd, tid);
+            img_fetch(ia, row + g.oA, d * ldd, tid);
+            img_fetch(ix, row + g.oX, p * ldd, tid);
             if (tid < d) gv = row[g.oV + tid];
             ytile_fetch<R>(yt, (long long)(i + 2) * a.ys.st);
         }
@@ -266,7 +324,7 @@ static size_t lds_mean_aggs(size_t s, int d, int CB) {
     const size_t ldd = ldp_(d), ldc = ldp_(CB);
     return al16(d * ldd * s) + 3 * al16(d * ldc * s) + 64;
 }
-template <typename R>
+template <typename R, int NRI>
 __global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __restrict__ aggA, const R* __restrict__ aggG, R* __restrict__ pre, int nchunk, int ncb, int CB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, S = a.d.S(), cb = blockIdx.x, s0 = cb * CB;
@@ -279,9 +337,10 @@ __global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __rest
         const int sl = e / d, r = e - sl * d, s = s0 + sl;
         M[0][r * ldc + sl] = s < S ? at<R>(a.ms, s / a.d.B, 0, s % a.d.B)[(long long)r * a.ms.se] : (R)0;
     }
-    Img<R> ia, ig;  // d * CB <= 85 * 64 < 8 NT
+    Img<R, NRI> ia;
+    Img<R> ig;  // d * CB <= 85 * 64 < 8 NT
     if (nchunk > 1) {
-        img_fetch<R>(ia, aggA, d * ldd, tid);
+        img_fetch(ia, aggA, d * ldd, tid);
 #pragma unroll
         for (int u = 0; u < SH_NR; ++u) {
             const int e = tid + u * NT, r = e / CB, q = e - r * CB;
@@ -297,7 +356,7 @@ __global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __rest
             pre[((long long)j * d + r) * Spad + s0 + q] = m[r * ldc + q];
         }
         if (j + 1 == nchunk) break;
-        img_drop<R>(ia, Ab, d * ldd, tid);
+        img_drop(ia, Ab, d * ldd, tid);
 #pragma unroll
         for (int u = 0; u < SH_NR; ++u) {
             const int e = tid + u * NT, r = e / CB, q = e - r * CB;
@@ -305,7 +364,7 @@ __global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __rest
         }
         __syncthreads();
         if (j + 2 < nchunk) {
-            img_fetch<R>(ia, aggA + (long long)(j + 1) * d * ldd, d * ldd, tid);
+            img_fetch(ia, aggA + (long long)(j + 1) * d * ldd, d * ldd, tid);
 #pragma unroll
             for (int u = 0; u < SH_NR; ++u) {
                 const int e = tid + u * NT, r = e / CB, q = e - r * CB;
@@ -323,7 +382,7 @@ static size_t lds_mean_down(size_t s, int d, int p, int CB) {
     return al16((p + d) * ldd * s) + al16(p * ldd * s) + al16(p * ldpp * s) + 2 * al16(d * ldc * s) + al16((p + d) * ldc * s) + 2 * al16(p * ldc * s) +
            al16((d + 2 * p + 2) * s) + al16(NWV * CB * s) + 64;
 }
-template <typename R>
+template <typename R, int NRI>
 __global__ void __launch_bounds__(NT) wk_mean_down(FilterArgs a, const R* __restrict__ tab, const R* __restrict__ pre, R* __restrict__ ellpart, int E, int nchunk, int ncb, int CB) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, d = a.dx, p = a.dy, n = a.d.T - 1, S = a.d.S();
@@ -347,26 +406,14 @@ __global__ void __launch_bounds__(NT) wk_mean_down(FilterArgs a, const R* __rest
     }
     YTile<R> yt;
     ytile_init<R>(yt, a, s0, CB, S, p, ldc, tid);
-    // the means of time t: element (sequence sl, component r) -> ms[s, t, r]
-    constexpr int NM = 6;  // d * CB <= 85 * 64 < 6 NT
-    R* mbase[NM];
-    int moff[NM], mrow[NM];
-#pragma unroll
-    for (int u = 0; u < NM; ++u) {
-        const int e = tid + u * NT, sl = e / d, r = e - sl * d, s = s0 + sl;
-        const bool v = sl < CB && s < S;
-        mbase[u] = v ? const_cast<R*>(at<R>(a.ms, s / a.d.B, 0, s % a.d.B)) + (long long)r * a.ms.se : nullptr;
-        moff[u] = sl < CB ? r * ldc + sl : -1;
-        mrow[u] = r;
-    }
-    Img<R> ih, ia, ix, is;
+    Img<R, NRI> ih, ia, ix, is;
     R vv[3] = {0, 0, 0};  // d + 2 p + 2 <= 3 NT
     auto fetch = [&](int i) {
         const R* row = tab + (long long)i * g.size;
-        img_fetch<R>(ih, row + g.oHF, p * ldd, tid);
-        img_fetch<R>(ia, row + g.oA, d * ldd, tid);
-        img_fetch<R>(ix, row + g.oX, p * ldd, tid);
-        img_fetch<R>(is, row + g.oS, p * ldpp, tid);
+        img_fetch(ih, row + g.oHF, p * ldd, tid);
+        img_fetch(ia, row + g.oA, d * ldd, tid);
+        img_fetch(ix, row + g.oX, p * ldd, tid);
+        img_fetch(is, row + g.oS, p * ldpp, tid);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int e = tid + u * NT;
@@ -379,10 +426,10 @@ __global__ void __launch_bounds__(NT) wk_mean_down(FilterArgs a, const R* __rest
     int cur = 0;
     for (int i = i0; i < i1; ++i) {
         __syncthreads();
-        img_drop<R>(ih, HA, p * ldd, tid);
-        img_drop<R>(ia, HA + p * ldd, d * ldd, tid);
-        img_drop<R>(ix, Xl, p * ldd, tid);
-        img_drop<R>(is, Sl, p * ldpp, tid);
+        img_drop(ih, HA, p * ldd, tid);
+        img_drop(ia, HA + p * ldd, d * ldd, tid);
+        img_drop(ix, Xl, p * ldd, tid);
+        img_drop(is, Sl, p * ldpp, tid);
 #pragma unroll
         for (int u = 0; u < 3; ++u) {
             const int e = tid + u * NT;
@@ -412,15 +459,14 @@ __global__ void __launch_bounds__(NT) wk_mean_down(FilterArgs a, const R* __rest
             for (int off = CB; off < 64; off <<= 1) acc += __shfl_xor(acc, off, 64);
             if (lane < CB) qpart[wv * CB + lane] = acc;
         }
-        // m_t = A m + K y + g: finished in place and written out
-        const long long tst = (long long)(i + 1) * a.ms.st;
-#pragma unroll
-        for (int u = 0; u < NM; ++u)
-            if (moff[u] >= 0) {
-                const R val = mn[moff[u]] + vec[mrow[u]];
-                mn[moff[u]] = val;
-                if (mbase[u]) mbase[u][tst] = val;
-            }
+        // m_t = A m + K y + g: finished in place and written out, element (sequence sl, component r) -> ms[s, t, r] (indices on the fly: registers are what
+        // this kernel is short of)
+        for (int e = tid; e < d * CB; e += NT) {
+            const int sl = e / d, r = e - sl * d, s = s0 + sl;
+            const R val = mn[r * ldc + sl] + vec[r];
+            mn[r * ldc + sl] = val;
+            if (s < S) const_cast<R*>(at<R>(a.ms, s / a.d.B, (long long)i + 1, s % a.d.B))[(long long)r * a.ms.se] = val;
+        }
         __syncthreads();
         if (tid < CB) {
             R q = 0;
