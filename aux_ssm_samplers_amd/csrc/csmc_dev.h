@@ -397,9 +397,22 @@ template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ v
 // cpad(pos) + (s - 1) + ((s - 1) >> 5), and taking the step adds s + (s >> 5).
 template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ int search2(const R* c, int N, R r) {
     if constexpr (NW > 0 && PAD) {
+        // TWO levels of the descent per LDS round trip: the probe of step s and BOTH candidate probes of step s / 2 (after a step not taken / taken) are three
+        // reads at constant offsets from the same position, issued together; the comparisons are exactly those of the one-level descent, in its order
+        // (ten dependent LDS latencies per search were the longest chain of the forward step)
         int ppos = 0;
+        constexpr int S0 = NW * 32;
+        constexpr bool ODD = (NW == 8);  // 9 levels at N = 512: the first one alone
+        if constexpr (ODD) ppos += c[ppos + (S0 - 1) + ((S0 - 1) >> 5)] < r ? S0 + (S0 >> 5) : 0;
 #pragma unroll
-        for (int s = NW * 32; s > 0; s >>= 1) ppos += c[ppos + (s - 1) + ((s - 1) >> 5)] < r ? s + (s >> 5) : 0;
+        for (int s = ODD ? S0 / 2 : S0; s >= 2; s >>= 2) {
+            const int h = s >> 1;
+            const int ks = (s - 1) + ((s - 1) >> 5), kh = (h - 1) + ((h - 1) >> 5), ps = s + (s >> 5), ph = h + (h >> 5);
+            const R A = c[ppos + ks], B0 = c[ppos + kh], B1 = c[ppos + ps + kh];
+            const bool a = A < r;
+            const bool b = (a ? B1 : B0) < r;
+            ppos += (a ? ps : 0) + (b ? ph : 0);
+        }
         const int pos = ppos - ((ppos * 1986) >> 16);  // ppos = 33 (pos >> 5) + (pos & 31)
         return pos < N - 1 ? pos : N - 1;
     } else {
