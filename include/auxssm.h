@@ -111,7 +111,7 @@ typedef enum {
     AUXSSM_K_NONE = 0,
     AUXSSM_K_FILTER_INIT = 1,
     AUXSSM_K_FILTER_SCAN = 2, /* the three launches of the filter's associative scan, timed as one unit */
-    AUXSSM_K_FILTER_ELL = 3,  /* reserved: the log-likelihood is carried by the scan elements, no such pass exists */
+    AUXSSM_K_FILTER_ELL = 3,  /* chain-shared wide filter: the mean / log-likelihood scan of all sequences (else unused: the scan elements carry the log-likelihood) */
     AUXSSM_K_SAMPLE_INIT = 4,
     AUXSSM_K_SAMPLE_SCAN = 5,
     AUXSSM_K_LOGPDF = 6,
@@ -134,6 +134,11 @@ int auxssm_prof_disable(auxssm_handle h);
  *   ys (C,T,B,dy) -> ms (C,T,B,dx), Ps (C,T,B,dx,dx) dense outputs, ell (C) [summed over B, :43-45].
  *   parallel != 0: associative scan over T (filtering.py:49-63); 0: the same kernels run the scan with one
  *   chunk per sequence, i.e. the sequential recursion (filtering.py:66-79).  NaN observations = missing.
+ *   Wide states (dx > 4 or dy > 8), parallel != 0, C * B >= 2 sequences whose parameter arrays (P0, Fs, Qs, bs, Hs, Rs, cs) all have chain
+ *   and batch stride 0, AUXSSM_OPT_SHARE_MODEL on: the covariance recursion runs ONCE (sequence 0) and every sequence keeps the affine mean /
+ *   log-likelihood recursion of the gain form (csrc/wide_shared.h).  That form needs all sequences to miss the same observations; the call
+ *   checks it on the device and reads the 4-byte answer back (one stream synchronisation per call), falling back to the per-sequence scan
+ *   when they differ.  Same results to rounding.
  */
 int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
                          const auxssm_arr* ys, int parallel, void* ms, void* Ps, void* ell);
