@@ -79,7 +79,7 @@ template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launc
     //   eps_prop[ch][t][n][k] = normal  2 * (((ch T2 + (t >> 1)) N + n) D + k) + (t & 1)  of stream 2
     //   u_res[ch][s][n]       = uniform 2 * ((ch T2 + (s >> 1)) N + n) + (s & 1)          of stream 3
     // (flat auxssm_rng_* indices; csmc/_device.py::key_noise builds the equivalent explicit arrays).
-    const bool gen = a.noise_mode != 0;
+    const bool gen = a.noise_mode != 0 && !a.pregen;
     const long long T2 = (T + 1) >> 1;
     R x[D], eps[D], eps_nx[D], ycur[D], pm[D], un_nx = 0;
 #pragma unroll
@@ -751,6 +751,14 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
     need += 2 * (CT * sR + 256);  // fmax, the backward pass's uniforms
     need += (size_t)T * sR + 256;  // gb
     need += 2 * (CT * D * sR + 256) + (size_t)T * (1 + D) * sR + 256;
+    // fewer chains than CUs: the forward pass's draws are generated up front by the whole chip (csmc_dev.h::k_csmc_pregen) when the two arrays fit
+    const size_t pre_eps = CT * N * D * sR + 256, pre_u = (size_t)C * (T > 1 ? T - 1 : 1) * N * sR + 256;
+    bool pregen = noise->mode == AUXSSM_NOISE_THREEFRY && !wide && T > 1 && C < h->num_cu && cb == C && !getenv("AUXSSM_CSMC_NO_PREGEN");
+    if (pregen) {
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || (double)(need + pre_eps + pre_u) > 0.7 * (double)(fr + h->ws_bytes)) pregen = false;
+    }
+    if (pregen) need += pre_eps + pre_u;
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     CsmcArgs a;
@@ -782,6 +790,19 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         a.u_bwd = ub;
     }
     if (!a.u || !a.xs || !a.lws || !a.wT || !a.fmax || (!backward && !a.As) || (fk->gradient && !a.grad) || (fk->F_t && !ctt)) return AUXSSM_ERR_NOMEM;
+    if (pregen) {
+        void* pe = ws_take(h, pre_eps - 256);
+        void* pu = ws_take(h, pre_u - 256);
+        if (!pe || !pu) return AUXSSM_ERR_NOMEM;
+        const int T2 = (T + 1) >> 1;
+        const dim3 grid((unsigned)C * T2, (unsigned)((N * D + 255) / 256));
+        ProfScope ps(h, AUXSSM_K_RNG);
+        if (dtype == AUXSSM_F32) hipLaunchKernelGGL((k_csmc_pregen<float>), grid, dim3(256), 0, h->stream, T, N, D, noise->key0, noise->key1, (float*)pe, (float*)pu);
+        else hipLaunchKernelGGL((k_csmc_pregen<double>), grid, dim3(256), 0, h->stream, T, N, D, noise->key0, noise->key1, (double*)pe, (double*)pu);
+        a.pregen = 1;
+        a.eps_prop = pe;
+        a.u_res = pu;
+    }
     if (wide) {
         void* blk = ws_take(h, ((size_t)3 * D * D + 4 * D + 8) * sR);
         if (!blk) return AUXSSM_ERR_NOMEM;

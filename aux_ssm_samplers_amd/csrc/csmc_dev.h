@@ -59,6 +59,8 @@ struct CsmcArgs {
     const void* gb;      // (T) upper bound of the potential G_t over x (a function of y_t only; +inf where there is none); null: exact maxima only
     int32_t* anc;        // (C, T)
     int noise_mode;      // 0 explicit arrays, 1 Threefry
+    int pregen = 0;      // Threefry mode with the forward pass's draws generated into eps_prop / u_res BEFORE the pass (k_csmc_pregen: a sweep with fewer chains than
+                         // CUs leaves most of the chip idle while every step of its few workgroups waits for a Threefry block and a Box-Muller pair)
     uint32_t key0, key1;
     const void* eps_aux;   // (C, T, D)
     const void* eps_prop;  // (C, T, N, D)
@@ -437,6 +439,28 @@ template <typename R> __global__ void k_csmc_ubwd(long long n, uint32_t key0, ui
     stream_uniform2<R>(key0, key1, STREAM_U_BWD, (unsigned long long)i, u0, u1);
     out[2 * i] = u0;
     if (2 * i + 1 < n) out[2 * i + 1] = u1;
+}
+// The forward pass's in-kernel draws (csmc.hip::k_csmc_fwd: one Threefry block serves two consecutive time steps of a particle), written out as the explicit
+// arrays the same kernel reads in explicit-noise mode -- value for value what it would have drawn itself:
+//   eps_prop[ch][t][n][k] = normal  2 (((ch T2 + (t >> 1)) N + n) D + k) + (t & 1) of stream 2,   u_res[ch][s][n] = uniform 2 ((ch T2 + (s >> 1)) N + n) + (s & 1) of stream 3
+// grid (C T2, ceil(N D / 256)): blockIdx.x = ch T2 + h is the pair of time steps (2 h, 2 h + 1) of chain ch -- no 64-bit division per thread
+template <typename R> __global__ void __launch_bounds__(256) k_csmc_pregen(int T, int N, int D, uint32_t key0, uint32_t key1, R* __restrict__ eps, R* __restrict__ ures) {
+    const int T2 = (T + 1) >> 1, row = blockIdx.x, ch = row / T2, h = row - ch * T2;
+    const int j = blockIdx.y * 256 + threadIdx.x, ND = N * D;
+    if (j < ND) {
+        R z0, z1;
+        stream_normal2<R>(key0, key1, STREAM_EPS_PROP, (unsigned long long)row * ND + j, z0, z1);
+        R* e = eps + ((long long)ch * T + 2 * h) * ND + j;
+        e[0] = z0;
+        if (2 * h + 1 < T) e[ND] = z1;
+    }
+    if (j < N) {
+        R u0, u1;
+        stream_uniform2<R>(key0, key1, STREAM_U_RES, (unsigned long long)row * N + j, u0, u1);
+        R* u = ures + ((long long)ch * (T - 1) + 2 * h) * N + j;
+        if (2 * h < T - 1) u[0] = u0;
+        if (2 * h + 1 < T - 1) u[N] = u1;
+    }
 }
 // ---- prologue: u = x + sqrt(delta_t/2) eps   (csmc/generic.py:67) ------------------------------------------------------
 template <typename R> __global__ void k_csmc_aux(CsmcArgs a, int D) {

@@ -99,6 +99,33 @@ def test_multichain_equals_single_chain_and_threefry_equals_explicit(T):
         npt.assert_array_equal(ancc, ancb[c])
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d,N,T,C", [(1, 64, 2, 3), (1, 100, 7, 2), (3, 512, 8, 4), (2, 33, 65, 5), (4, 1024, 5, 2)])
+@pytest.mark.parametrize("proposal", ["independent", "bootstrap"])
+def test_draws_generated_ahead_of_the_forward_pass_equal_in_kernel_draws(dtype, d, N, T, C, proposal, monkeypatch):
+    """Fewer chains than CUs: the forward pass's Threefry draws are written out by a separate full-chip kernel first (csmc_dev.h::k_csmc_pregen) and read back
+    as explicit arrays.  Same trajectories, ancestors, particle systems and log-weights bit for bit as with the draws made inside the pass
+    (AUXSSM_CSMC_NO_PREGEN=1), for odd and even T, partial last waves and every state dimension of the register kernels."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.csmc import _device
+    rng = np.random.default_rng(d * 100 + T)
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(O.POT_SV, y)
+    fk = (_device.describe_independent if proposal == "independent" else _device.describe_bootstrap)(M0, G0, Mt, Gt, Mt)
+    x0 = rng.standard_normal((C, T, d)).astype(dtype)
+    kw = dict(key=R.PRNGKey(31), delta=0.5) if proposal == "independent" else dict(key=R.PRNGKey(31))
+    monkeypatch.delenv("AUXSSM_CSMC_NO_PREGEN", raising=False)
+    xa, anca, exa = _device.sweep(fk, x0, N, True, want_history=True, **kw)
+    monkeypatch.setenv("AUXSSM_CSMC_NO_PREGEN", "1")
+    xb, ancb, exb = _device.sweep(fk, x0, N, True, want_history=True, **kw)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    for k in exa:
+        npt.assert_array_equal(exa[k], exb[k])
+    assert len({xa[c].tobytes() for c in range(C)}) == C
+
+
 @pytest.mark.parametrize("backward", [True, False])
 @pytest.mark.parametrize("mode", ["threefry", "explicit"])
 def test_chain_batched_sweep_equals_one_launch(backward, mode, monkeypatch):
