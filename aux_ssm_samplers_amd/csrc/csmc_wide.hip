@@ -344,6 +344,346 @@ template <typename R> __global__ void __launch_bounds__(64) k_cw_bwd(CsmcArgs a,
     }
 }
 
+// =================================================================================================================================================
+// Version 2 of both passes (round 3): NW2 waves per chain, a particle's dx components ACROSS the 32 lanes of a half-wave (two particles per wave,
+// particle i = 2 NW2 s + 2 wave + half in pass s of ceil(N / (2 NW2))).  The first version walked a particle's dx x dx products in ONE lane (25 of 64
+// lanes busy, 30 x 30 dependent multiply-adds each: 122 us per time step of the SV protocol).  Everything the contract orders is kept in its order:
+//   * a mean component is one dot product, accumulated over j = 0 .. dx - 1 by the lane that owns the component;
+//   * the forward substitution runs COLUMN by column -- z_j = acc_j / L_jj is final once columns < j have been applied, it is broadcast inside the
+//     half-wave by v_readlane and every lane k > j applies acc_k = fma(-L_kj, z_j, acc_k): each acc_k receives the same updates in the same order
+//     as the row-oriented loop of gauss_w above, so z, q = sum z_k^2 (accumulated in k order by every lane alike) and the densities are bit-identical;
+//   * the potential's sum over components is accumulated in component order from readlane broadcasts of the per-component terms;
+//   * weights, cumulative sums, searches and the single draw of the backward pass are done by wave 0 with one lane per particle, exactly as before.
+// Two workgroup barriers per time step in either pass.  In-kernel draws keep the natural flat indices (and use both normals of a Threefry block).
+constexpr int NW2 = 8;  // waves per chain
+
+template <typename R> struct Cw2Lds {
+    int D, S;
+    R *F, *LQ, *b, *iL, *c, *lwv, *xa, *xb, *eps;
+    int* idx;
+    __device__ Cw2Lds(char* smem, int D_) : D(D_), S(D_ | 1) {
+        F = (R*)smem;           // [D][S]
+        LQ = F + D * S;         // [D][S]
+        b = LQ + D * S;
+        iL = b + D;
+        c = iL + D;             // [64]
+        lwv = c + 64;           // [64]
+        xa = lwv + 64;          // [64][S]
+        xb = xa + 64 * S;       // [64][S]
+        eps = xb + 64 * S;      // [64][S]
+        idx = (int*)(eps + 64 * S);  // [64]
+    }
+    static size_t bytes(int D) { return ((size_t)2 * D * (D | 1) + 2 * D + 128 + (size_t)3 * 64 * (D | 1)) * sizeof(R) + 64 * sizeof(int) + 64; }
+};
+template <typename R> __device__ __forceinline__ void cw2_stage(const FkW<R>& m, Cw2Lds<R>& L, int tid, int nt) {
+    const int D = m.D, S = L.S;
+    for (int i = tid; i < D * D; i += nt) {
+        const int r = i / D, q = i - r * D;
+        L.F[r * S + q] = m.F[i];
+        L.LQ[r * S + q] = m.LQ[i];
+    }
+    for (int i = tid; i < D; i += nt) L.b[i] = m.b[i], L.iL[i] = m.iLQ[i];
+    __syncthreads();
+}
+// value of lane j of MY half-wave (j wave-uniform)
+template <typename R> __device__ __forceinline__ R half_bcast(R v, int j, bool hi) {
+    const R lo_ = readlane_(v, j), hi_ = readlane_(v, 32 + j);
+    return hi ? hi_ : lo_;
+}
+// log N(x; mean, L L^T) of the particle whose component k this lane holds (x - mean in `acc`), column-oriented substitution; L: lane k's row pointer with
+// element stride 1 (L[j] = L_kj), iLk = 1 / L_kk.  Every lane of the half-wave returns the same value.
+template <typename R> __device__ __forceinline__ R gauss_half(int D, int k, bool hi, R acc, const R* Lrow, R iLk, R cst) {
+    R q = 0;
+    for (int j = 0; j < D; ++j) {
+        const R zj = half_bcast<R>(acc * iLk, j, hi);
+        q = fma_(zj, zj, q);
+        if (k > j && k < D) acc = fma_(-Lrow[j], zj, acc);
+    }
+    return fma_((R)-0.5, q, cst);
+}
+// g_t(x) of that particle: per-component terms in the lanes, summed in component order (potential_w above, same operations)
+template <typename R> __device__ __forceinline__ R potential_half(const FkW<R>& m, int k, bool hi, R xk, R yk) {
+    const int D = m.D;
+    if (m.potential == 0) return (R)0;
+    if (m.potential == 1 || m.potential == 3) {
+        const bool obs = m.potential == 1 || (yk - yk == 0);
+        const R z = (k < D && obs) ? (yk - xk) * m.inv_sig_y : (R)0;
+        R q = 0;
+        for (int j = 0; j < D; ++j) {
+            const R zj = half_bcast<R>(z, j, hi);
+            q = fma_(zj, zj, q);  // (a missing component contributes fma(0, 0, q) = q: the reference skips it)
+        }
+        if (m.potential == 1) return fma_((R)-0.5, q, m.c_obs);
+        const unsigned long long bal = __ballot(k < D && obs);
+        const int nobs = __popc((unsigned int)(hi ? bal >> 32 : bal & 0xffffffffull));
+        return fma_((R)-0.5, q, (R)nobs * m.c_obs);
+    }
+    const R e = det_exp(-xk);
+    const R sv = fma_(yk * yk, e, xk);
+    R v = fma_((R)-0.5, sv, m.c_obs);
+    v = (k < D && v == v) ? v : (R)0;
+    R acc = 0;
+    for (int j = 0; j < D; ++j) acc += half_bcast<R>(v, j, hi);
+    return acc;
+}
+// this step's proposal noise into the LDS rows eps[n][k]: natural flat index ((ch T + t) N + n) D + k of stream 2, both normals of every Threefry block used
+template <typename R> __device__ __forceinline__ void cw2_draw(const CsmcArgs& a, Cw2Lds<R>& L, int ch, int t, int r, int nr) {
+    const int N = a.N, D = L.D, S = L.S, ND = N * D;
+    const long long base = (((long long)ch * a.T + t) * N) * D;
+    if (a.noise_mode == 0) {
+        for (int e = r; e < ND; e += nr) {
+            const int n = e / D, k = e - n * D;
+            L.eps[n * S + k] = ((const R*)a.eps_prop)[base + e];
+        }
+        return;
+    }
+    const long long b0 = base >> 1, b1 = (base + ND - 1) >> 1;
+    for (long long blk = b0 + r; blk <= b1; blk += nr) {
+        R z0, z1;
+        stream_normal2<R>(a.key0, a.key1, STREAM_EPS_PROP, (unsigned long long)blk, z0, z1);
+        const long long e0 = 2 * blk - base, e1 = e0 + 1;
+        if (e0 >= 0 && e0 < ND) {
+            const int n = (int)e0 / D, k = (int)e0 - n * D;
+            L.eps[n * S + k] = z0;
+        }
+        if (e1 >= 0 && e1 < ND) {
+            const int n = (int)e1 / D, k = (int)e1 - n * D;
+            L.eps[n * S + k] = z1;
+        }
+    }
+}
+
+template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(CsmcArgs a, FkW<R> m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT_ = 64 * NW2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N, T = a.T, D = m.D;
+    const bool hi = lane >= 32;
+    const int k = lane & 31;
+    Cw2Lds<R> L(smem, D);
+    cw2_stage<R>(m, L, tid, NT_);
+    const int S = L.S, nslot = (N + 2 * NW2 - 1) / (2 * NW2);
+    const int ch = a.c0 + blockIdx.x;
+    const R* xstar = (const R*)a.x + (long long)ch * T * D;
+    const R* uaux = (const R*)a.u + (long long)ch * T * D;
+    const R* yv = (const R*)a.y;
+    R* xs = (R*)a.xs + (long long)ch * T * N * D;
+    R* lws = (R*)a.lws + (long long)ch * T * N;
+    int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
+    R* fmax = a.fmax ? (R*)a.fmax + (long long)ch * T : nullptr;
+    const R* gbp = (const R*)a.gb;
+    const bool bmode = gbp != nullptr;
+    const R ninf = -INFINITY;
+    const R iLk = k < D ? L.iL[k] : (R)0, bk = k < D ? L.b[k] : (R)0;
+    const R* Frow = L.F + (k < D ? k : 0) * S;
+    const R* Lrow = L.LQ + (k < D ? k : 0) * S;
+
+    // ---- t = 0 (csmc.py:74-80)
+    cw2_draw<R>(a, L, ch, 0, tid, NT_);
+    __syncthreads();
+    for (int s = 0; s < nslot; ++s) {
+        const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
+        const bool pl = i < N;  // (uniform per half-wave)
+        const int ir = pl ? i : 0;
+        R xk = 0, acc0 = 0;
+        if (k < D) {
+            if (m.proposal == 0) {
+                R acc = m.m0[k];
+                for (int j = 0; j <= k; ++j) acc = fma_(m.LP0[k * D + j], L.eps[ir * S + j], acc);
+                xk = acc;
+            } else {
+                xk = fma_(((const R*)a.shd)[0], L.eps[ir * S + k], uaux[k]);
+            }
+            if (i == 0) xk = xstar[k];
+            acc0 = xk - m.m0[k];
+        }
+        const R yk = (yv && k < D) ? yv[k] : (R)0;
+        R g = potential_half<R>(m, k, hi, xk, yk);
+        if (m.proposal == 1) g = g + gauss_half<R>(D, k, hi, acc0, m.LP0 + (long long)(k < D ? k : 0) * D, k < D ? m.iLP0[k] : (R)0, m.c_init);  // AuxiliaryG0
+        if (pl && k < D) {
+            L.xa[i * S + k] = xk;
+            xs[(long long)i * D + k] = xk;
+        }
+        if (pl && k == 0) {
+            L.lwv[i] = g;
+            lws[i] = g;
+        }
+    }
+    __syncthreads();
+    R* xprev = L.xa;
+    R* xcur = L.xb;
+    for (int t = 1; t < T; ++t) {
+        if (wv == 0) {
+            // weights of step t - 1 and the conditional multinomial resampling (resamplings.py:14-37), one lane per particle
+            const bool live = lane < N;
+            const R lw = live ? L.lwv[lane] : ninf;
+            const int tp = t - 1;
+            R Mb = (bmode ? gbp[tp] : (R)0) + (m.proposal == 1 ? m.c_trans : (R)0);
+            const bool used_bound = bmode && tp >= 1 && tp < T - 1 && (Mb - Mb == 0);
+            R mstep, w;
+            if (used_bound) {
+                w = det_exp(lw - Mb);
+                mstep = Mb;
+            } else {
+                w = wave_expmax<R>(lw, &mstep);
+            }
+            R cv = wave_scan_dpp(w);
+            R tot = readlane_(cv, 63);
+            if (used_bound && !(tot > (R)0)) {  // every weight underflowed under its bound: the exact maximum after all
+                w = wave_expmax<R>(lw, &mstep);
+                cv = wave_scan_dpp(w);
+                tot = readlane_(cv, 63);
+            }
+            if (fmax && lane == 0) fmax[tp] = mstep;
+            L.c[lane] = cv;
+            __builtin_amdgcn_wave_barrier();
+            const R un = (live && lane > 0) ? noise_uniform<R>(a, a.u_res, STREAM_U_RES, ((long long)ch * (T - 1) + (t - 1)) * N + lane) : (R)0;
+            int idx = 0;
+            if (live && lane > 0) idx = search_w<R>(L.c, N, tot * ((R)1 - un));
+            L.idx[lane] = idx;
+            if (live && As) As[(long long)(t - 1) * N + lane] = idx;
+            cw2_draw<R>(a, L, ch, t, lane, NT_);  // (its share of the draws: the other waves start with theirs)
+        } else {
+            cw2_draw<R>(a, L, ch, t, tid, NT_);
+        }
+        __syncthreads();
+        const R yk = (yv && k < D) ? yv[(long long)t * D + k] : (R)0;
+        const R st = m.proposal != 0 ? ((const R*)a.shd)[t] : (R)0;
+        const R uk = (m.proposal != 0 && k < D) ? uaux[(long long)t * D + k] : (R)0;
+        const R xsk = k < D ? xstar[(long long)t * D + k] : (R)0;
+        for (int s = 0; s < nslot; ++s) {
+            const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
+            const bool pl = i < N;
+            const int ir = pl ? i : 0;
+            const R* xp = xprev + L.idx[ir] * S;
+            // the parent's transition mean, component k (csmc.py:91-92)
+            R mu = bk;
+            if (m.proposal == 0 || true) {
+                for (int j = 0; j < D; ++j) mu = fma_(Frow[j], xp[j], mu);
+            }
+            R xk = 0;
+            if (k < D) {
+                if (m.proposal == 0) {
+                    R acc = mu;
+                    for (int j = 0; j <= k; ++j) acc = fma_(Lrow[j], L.eps[ir * S + j], acc);
+                    xk = acc;
+                } else {
+                    xk = fma_(st, L.eps[ir * S + k], uk);
+                }
+                if (i == 0) xk = xsk;
+            }
+            // weights (csmc.py:95-96)
+            R g = potential_half<R>(m, k, hi, xk, yk);
+            if (m.proposal == 1) g = gauss_half<R>(D, k, hi, xk - mu, Lrow, iLk, m.c_trans) + g;  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
+            if (pl && k < D) {
+                xcur[i * S + k] = xk;
+                xs[((long long)t * N + i) * D + k] = xk;
+            }
+            if (pl && k == 0) {
+                L.lwv[i] = g;
+                lws[(long long)t * N + i] = g;
+            }
+        }
+        __syncthreads();
+        R* tmp = xprev;
+        xprev = xcur;
+        xcur = tmp;
+    }
+    if (wv == 0) {  // the weights of the last step: exact maximum
+        const bool live = lane < N;
+        const R lw = live ? L.lwv[lane] : ninf;
+        R mstep;
+        const R w = wave_expmax<R>(lw, &mstep);
+        if (fmax && lane == 0) fmax[T - 1] = mstep;
+        if (live) ((R*)a.wT)[(long long)ch * N + lane] = w;
+    }
+}
+
+template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_bwd(CsmcArgs a, FkW<R> m) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NT_ = 64 * NW2;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N, T = a.T, D = m.D;
+    const bool hi = lane >= 32;
+    const int k = lane & 31;
+    Cw2Lds<R> L(smem, D);
+    cw2_stage<R>(m, L, tid, NT_);
+    const int S = L.S, nslot = (N + 2 * NW2 - 1) / (2 * NW2);
+    const int ch = a.c0 + blockIdx.x;
+    const R* xs = (const R*)a.xs + (long long)ch * T * N * D;
+    const R* lws = (const R*)a.lws + (long long)ch * T * N;
+    const int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
+    R* xout = (R*)a.x + (long long)ch * T * D;
+    int32_t* anc = a.anc + (long long)ch * T;
+    const R* fmax = (const R*)a.fmax + (long long)ch * T;
+    const R ninf = -INFINITY;
+    const R iLk = k < D ? L.iL[k] : (R)0, bk = k < D ? L.b[k] : (R)0;
+    const R* Frow = L.F + (k < D ? k : 0) * S;
+    const R* Lrow = L.LQ + (k < D ? k : 0) * S;
+    // B_T ~ choice(w_T) by wave 0
+    if (wv == 0) {
+        const bool live = lane < N;
+        const R w = live ? ((const R*)a.wT)[(long long)ch * N + lane] : (R)0;
+        const R cv = wave_scan_dpp(w);
+        const R tot = readlane_(cv, 63);
+        const R un = ((const R*)a.u_bwd)[(long long)ch * T + (T - 1)];
+        int B = __popcll(__ballot(live && cv < tot * ((R)1 - un)));
+        B = B < N - 1 ? B : N - 1;
+        if (lane == 0) L.idx[0] = B, anc[T - 1] = B;
+    }
+    __syncthreads();
+    int B = L.idx[0];
+    R xn = k < D ? xs[((long long)(T - 1) * N + B) * D + k] : (R)0;  // x_{t+1}, component k (every half-wave holds a copy)
+    if (wv == 0 && !hi && k < D) xout[(long long)(T - 1) * D + k] = xn;
+    if (!a.backward) {
+        if (tid == 0) {
+            for (int t = T - 1; t >= 1; --t) {
+                B = As[(long long)(t - 1) * N + B];
+                for (int q = 0; q < D; ++q) xout[(long long)(t - 1) * D + q] = xs[((long long)(t - 1) * N + B) * D + q];
+                anc[t - 1] = B;
+            }
+        }
+        return;
+    }
+    for (int t = T - 2; t >= 0; --t) {
+        __syncthreads();  // (the draw of the step before has been read by everybody)
+        for (int s = 0; s < nslot; ++s) {
+            const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
+            const bool pl = i < N;
+            const int ir = pl ? i : 0;
+            const R xik = k < D ? xs[((long long)t * N + ir) * D + k] : (R)0;
+            if (k < D) L.xa[ir * S + k] = xik;  // (a half-wave reads back only its own row: ordered inside the wave)
+            __builtin_amdgcn_wave_barrier();
+            const R* xi = L.xa + ir * S;
+            R mu = bk;
+            for (int j = 0; j < D; ++j) mu = fma_(Frow[j], xi[j], mu);
+            const R lwt = gauss_half<R>(D, k, hi, xn - mu, Lrow, iLk, m.c_trans) + lws[(long long)t * N + ir];  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
+            if (pl && k == 0) L.lwv[i] = lwt;
+        }
+        __syncthreads();
+        if (wv == 0) {
+            const bool live = lane < N;
+            const R lw = live ? L.lwv[lane] : ninf;
+            R Mb = fmax[t] + m.c_trans;
+            if (!(Mb - Mb == 0)) Mb = 0;
+            R w = det_exp(lw - Mb);
+            R cv = wave_scan_dpp(w);
+            R tot = readlane_(cv, 63);
+            if (!(tot > (R)0)) {
+                w = wave_expmax<R>(lw, nullptr);
+                cv = wave_scan_dpp(w);
+                tot = readlane_(cv, 63);
+            }
+            const R un = ((const R*)a.u_bwd)[(long long)ch * T + t];
+            int Bn = __popcll(__ballot(live && cv < tot * ((R)1 - un)));
+            Bn = Bn < N - 1 ? Bn : N - 1;
+            if (lane == 0) L.idx[0] = Bn, anc[t] = Bn;
+        }
+        __syncthreads();
+        B = L.idx[0];
+        xn = k < D ? L.xa[B * S + k] : (R)0;
+        if (wv == 0 && !hi && k < D) xout[(long long)t * D + k] = xn;
+    }
+}
+
 // host: the model as one device block [m0 | LP0 | iLP0 | F | b | LQ | iLQ], constants as csmc_dev.h::fill_model computes them
 template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk, CsmcArgs& a, void* dev_block, R* host_block) {
     const int D = fk->dx;
@@ -396,10 +736,13 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
         const long long total = (long long)a.C * a.T * D;
         hipLaunchKernelGGL((k_csmc_aux<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a, D);
     }
-    const size_t lds = CwLds<R>::bytes(D);
+    static const bool v1 = getenv("AUXSSM_CW_V1") != nullptr;  // (measurement switch: the one-lane-per-particle kernels of the first version)
+    const size_t lds = v1 ? CwLds<R>::bytes(D) : Cw2Lds<R>::bytes(D);
     if (lds > 48 * 1024) {
         AX_HIP(hipFuncSetAttribute((const void*)k_cw_fwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AX_HIP(hipFuncSetAttribute((const void*)k_cw_bwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_fwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_bwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int cb = a.cb > 0 ? a.cb : a.C;
     for (int c0 = 0; c0 < a.C; c0 += cb) {
@@ -411,11 +754,13 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
         if (a.As) ab.As = (int32_t*)((char*)a.As - (size_t)c0 * a.As_rec);
         {
             ProfScope ps(h, AUXSSM_K_CSMC_FWD);
-            hipLaunchKernelGGL((k_cw_fwd<R>), dim3(ab.C), dim3(64), lds, h->stream, ab, m);
+            if (v1) hipLaunchKernelGGL((k_cw_fwd<R>), dim3(ab.C), dim3(64), lds, h->stream, ab, m);
+            else hipLaunchKernelGGL((k_cw2_fwd<R>), dim3(ab.C), dim3(64 * NW2), lds, h->stream, ab, m);
         }
         {
             ProfScope ps(h, AUXSSM_K_CSMC_BWD);
-            hipLaunchKernelGGL((k_cw_bwd<R>), dim3(ab.C), dim3(64), lds, h->stream, ab, m);
+            if (v1) hipLaunchKernelGGL((k_cw_bwd<R>), dim3(ab.C), dim3(64), lds, h->stream, ab, m);
+            else hipLaunchKernelGGL((k_cw2_bwd<R>), dim3(ab.C), dim3(64 * NW2), lds, h->stream, ab, m);
         }
     }
     AX_HIP(hipGetLastError());
