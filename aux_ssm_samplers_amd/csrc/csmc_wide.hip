@@ -14,6 +14,9 @@
 // In-kernel draws (AUXSSM_NOISE_THREEFRY) use the NATURAL flat indices of the explicit arrays -- eps_prop[c][t][n][k] = normal ((c T + t) N + n) dx + k of
 // stream 2, u_res[c][s][n] = uniform (c (T-1) + s) N + n of stream 3, u_bwd[c][t] = uniform c T + t of stream 4 -- not the two-steps-per-block packing
 // of the register kernels (csmc/_device.py::key_noise(wide=True) builds the equivalent arrays).
+#include <type_traits>
+#include <utility>
+
 #include "csmc_dev.h"
 
 namespace ax {
@@ -355,13 +358,15 @@ template <typename R> __global__ void __launch_bounds__(64) k_cw_bwd(CsmcArgs a,
 //   * the potential's sum over components is accumulated in component order from readlane broadcasts of the per-component terms;
 //   * weights, cumulative sums, searches and the single draw of the backward pass are done by wave 0 with one lane per particle, exactly as before.
 // Two workgroup barriers per time step in either pass.  In-kernel draws keep the natural flat indices (and use both normals of a Threefry block).
-constexpr int NW2 = 8;  // waves per chain
+#ifndef CW2_ABL
+#define CW2_ABL 0  // diagnostic builds: 1 no search, 2 no draws, 4 no substitution, 8 no potential sums, 16 no mean products (tools/cw2_ablate.sh)
+#endif
 
 template <typename R> struct Cw2Lds {
     int D, S;
     R *F, *LQ, *b, *iL, *c, *lwv, *xa, *xb, *eps;
     int* idx;
-    __device__ Cw2Lds(char* smem, int D_) : D(D_), S(D_ | 1) {
+    __device__ Cw2Lds(char* smem, int D_) : D(D_), S(CSW_MAXD + 1) {  // rows padded with zeros to 32 columns (+ 1: odd stride): every component loop runs 32 steps, unrolled
         F = (R*)smem;           // [D][S]
         LQ = F + D * S;         // [D][S]
         b = LQ + D * S;
@@ -373,46 +378,66 @@ template <typename R> struct Cw2Lds {
         eps = xb + 64 * S;      // [64][S]
         idx = (int*)(eps + 64 * S);  // [64]
     }
-    static size_t bytes(int D) { return ((size_t)2 * D * (D | 1) + 2 * D + 128 + (size_t)3 * 64 * (D | 1)) * sizeof(R) + 64 * sizeof(int) + 64; }
+    static size_t bytes(int D) { return ((size_t)2 * D * (CSW_MAXD + 1) + 2 * D + 128 + (size_t)3 * 64 * (CSW_MAXD + 1)) * sizeof(R) + 64 * sizeof(int) + 64; }
 };
 template <typename R> __device__ __forceinline__ void cw2_stage(const FkW<R>& m, Cw2Lds<R>& L, int tid, int nt) {
     const int D = m.D, S = L.S;
-    for (int i = tid; i < D * D; i += nt) {
-        const int r = i / D, q = i - r * D;
-        L.F[r * S + q] = m.F[i];
-        L.LQ[r * S + q] = m.LQ[i];
+    for (int i = tid; i < D * S; i += nt) {
+        const int r = i / S, q = i - r * S;
+        L.F[i] = q < D ? m.F[r * D + q] : (R)0;
+        L.LQ[i] = q < D ? m.LQ[r * D + q] : (R)0;
     }
     for (int i = tid; i < D; i += nt) L.b[i] = m.b[i], L.iL[i] = m.iLQ[i];
+    for (int i = tid; i < 64 * S; i += nt) L.xa[i] = 0, L.xb[i] = 0, L.eps[i] = 0;
     __syncthreads();
 }
-// value of lane j of MY half-wave (j wave-uniform)
-template <typename R> __device__ __forceinline__ R half_bcast(R v, int j, bool hi) {
-    const R lo_ = readlane_(v, j), hi_ = readlane_(v, 32 + j);
-    return hi ? hi_ : lo_;
+// value of lane J of MY half-wave: ds_swizzle in bit mode (lane' = (lane & and) | or inside each group of 32 lanes, and = 0, or = J) -- one LDS-crossbar
+// instruction, no memory, no scalar round trip (two v_readlane + two v_mov + a select before: the component loops are bound by the CU's instruction issue,
+// thirteen waves of one chain walk them together)
+template <typename R, int J> __device__ __forceinline__ R half_bcast(R v) {
+    if constexpr (sizeof(R) == 4) {
+        return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), J << 5));
+    } else {
+        const int lo_ = __builtin_amdgcn_ds_swizzle(__double2loint(v), J << 5), hi_ = __builtin_amdgcn_ds_swizzle(__double2hiint(v), J << 5);
+        return __hiloint2double(hi_, lo_);
+    }
+}
+template <int J, int N, typename F> __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (J < N) {
+        f(std::integral_constant<int, J>{});
+        static_for<J + 1, N>(f);
+    }
 }
 // log N(x; mean, L L^T) of the particle whose component k this lane holds (x - mean in `acc`), column-oriented substitution; L: lane k's row pointer with
 // element stride 1 (L[j] = L_kj), iLk = 1 / L_kk.  Every lane of the half-wave returns the same value.
 template <typename R> __device__ __forceinline__ R gauss_half(int D, int k, bool hi, R acc, const R* Lrow, R iLk, R cst) {
     R q = 0;
-    for (int j = 0; j < D; ++j) {
-        const R zj = half_bcast<R>(acc * iLk, j, hi);
+    if (CW2_ABL & 4) return acc * cst;
+    acc = k < D ? acc : (R)0;  // (components beyond D: z = 0, fma(0, 0, q) = q -- the 32 steps below are the D steps of the contract)
+    R l[CSW_MAXD];
+#pragma unroll
+    for (int j = 0; j < CSW_MAXD; ++j) l[j] = j < D ? Lrow[j] : (R)0;
+    static_for<0, CSW_MAXD>([&](auto jc) {  // (straight-line: the row of L requested up front, only the broadcast / multiply-add chain is serial)
+        constexpr int j = decltype(jc)::value;
+        const R zj = half_bcast<R, j>(acc * iLk);
         q = fma_(zj, zj, q);
-        if (k > j && k < D) acc = fma_(-Lrow[j], zj, acc);
-    }
+        acc = (k > j && k < D) ? fma_(-l[j], zj, acc) : acc;
+    });
     return fma_((R)-0.5, q, cst);
 }
 // g_t(x) of that particle: per-component terms in the lanes, summed in component order (potential_w above, same operations)
 template <typename R> __device__ __forceinline__ R potential_half(const FkW<R>& m, int k, bool hi, R xk, R yk) {
     const int D = m.D;
     if (m.potential == 0) return (R)0;
+    if (CW2_ABL & 8) return xk * yk;
     if (m.potential == 1 || m.potential == 3) {
         const bool obs = m.potential == 1 || (yk - yk == 0);
         const R z = (k < D && obs) ? (yk - xk) * m.inv_sig_y : (R)0;
         R q = 0;
-        for (int j = 0; j < D; ++j) {
-            const R zj = half_bcast<R>(z, j, hi);
-            q = fma_(zj, zj, q);  // (a missing component contributes fma(0, 0, q) = q: the reference skips it)
-        }
+        static_for<0, CSW_MAXD>([&](auto jc) {
+            const R zj = half_bcast<R, decltype(jc)::value>(z);
+            q = fma_(zj, zj, q);  // (a missing component, or one beyond D, contributes fma(0, 0, q) = q: the reference skips it)
+        });
         if (m.potential == 1) return fma_((R)-0.5, q, m.c_obs);
         const unsigned long long bal = __ballot(k < D && obs);
         const int nobs = __popc((unsigned int)(hi ? bal >> 32 : bal & 0xffffffffull));
@@ -423,12 +448,16 @@ template <typename R> __device__ __forceinline__ R potential_half(const FkW<R>& 
     R v = fma_((R)-0.5, sv, m.c_obs);
     v = (k < D && v == v) ? v : (R)0;
     R acc = 0;
-    for (int j = 0; j < D; ++j) acc += half_bcast<R>(v, j, hi);
+    static_for<0, CSW_MAXD>([&](auto jc) { acc += half_bcast<R, decltype(jc)::value>(v); });
     return acc;
 }
 // this step's proposal noise into the LDS rows eps[n][k]: natural flat index ((ch T + t) N + n) D + k of stream 2, both normals of every Threefry block used
 template <typename R> __device__ __forceinline__ void cw2_draw(const CsmcArgs& a, Cw2Lds<R>& L, int ch, int t, int r, int nr) {
     const int N = a.N, D = L.D, S = L.S, ND = N * D;
+    if (CW2_ABL & 2) {
+        for (int e = r; e < N * S; e += nr) L.eps[e] = (R)0.25;
+        return;
+    }
     const long long base = (((long long)ch * a.T + t) * N) * D;
     if (a.noise_mode == 0) {
         for (int e = r; e < ND; e += nr) {
@@ -453,7 +482,7 @@ template <typename R> __device__ __forceinline__ void cw2_draw(const CsmcArgs& a
     }
 }
 
-template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(CsmcArgs a, FkW<R> m) {
+template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(CsmcArgs a, FkW<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT_ = 64 * NW2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N, T = a.T, D = m.D;
@@ -512,6 +541,11 @@ template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(Csmc
     R* xprev = L.xa;
     R* xcur = L.xb;
     for (int t = 1; t < T; ++t) {
+        // the step's rows from global memory, requested before the resampling section and its barrier
+        const R yk = (yv && k < D) ? yv[(long long)t * D + k] : (R)0;
+        const R st = m.proposal != 0 ? ((const R*)a.shd)[t] : (R)0;
+        const R uk = (m.proposal != 0 && k < D) ? uaux[(long long)t * D + k] : (R)0;
+        const R xsk = k < D ? xstar[(long long)t * D + k] : (R)0;
         if (wv == 0) {
             // weights of step t - 1 and the conditional multinomial resampling (resamplings.py:14-37), one lane per particle
             const bool live = lane < N;
@@ -538,7 +572,8 @@ template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(Csmc
             __builtin_amdgcn_wave_barrier();
             const R un = (live && lane > 0) ? noise_uniform<R>(a, a.u_res, STREAM_U_RES, ((long long)ch * (T - 1) + (t - 1)) * N + lane) : (R)0;
             int idx = 0;
-            if (live && lane > 0) idx = search_w<R>(L.c, N, tot * ((R)1 - un));
+            if (CW2_ABL & 1) idx = (lane * 7) % N;
+            else if (live && lane > 0) idx = search_w<R>(L.c, N, tot * ((R)1 - un));
             L.idx[lane] = idx;
             if (live && As) As[(long long)(t - 1) * N + lane] = idx;
             cw2_draw<R>(a, L, ch, t, lane, NT_);  // (its share of the draws: the other waves start with theirs)
@@ -546,10 +581,6 @@ template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(Csmc
             cw2_draw<R>(a, L, ch, t, tid, NT_);
         }
         __syncthreads();
-        const R yk = (yv && k < D) ? yv[(long long)t * D + k] : (R)0;
-        const R st = m.proposal != 0 ? ((const R*)a.shd)[t] : (R)0;
-        const R uk = (m.proposal != 0 && k < D) ? uaux[(long long)t * D + k] : (R)0;
-        const R xsk = k < D ? xstar[(long long)t * D + k] : (R)0;
         for (int s = 0; s < nslot; ++s) {
             const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
             const bool pl = i < N;
@@ -557,14 +588,16 @@ template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(Csmc
             const R* xp = xprev + L.idx[ir] * S;
             // the parent's transition mean, component k (csmc.py:91-92)
             R mu = bk;
-            if (m.proposal == 0 || true) {
-                for (int j = 0; j < D; ++j) mu = fma_(Frow[j], xp[j], mu);
+            if (!(CW2_ABL & 16)) {
+#pragma unroll
+                for (int j = 0; j < CSW_MAXD; ++j) mu = fma_(Frow[j], xp[j], mu);  // (columns beyond D are zeros on both sides: fma(0, 0, mu) = mu)
             }
             R xk = 0;
             if (k < D) {
                 if (m.proposal == 0) {
                     R acc = mu;
-                    for (int j = 0; j <= k; ++j) acc = fma_(Lrow[j], L.eps[ir * S + j], acc);
+#pragma unroll
+                    for (int j = 0; j < CSW_MAXD; ++j) acc = j <= k ? fma_(Lrow[j], L.eps[ir * S + j], acc) : acc;
                     xk = acc;
                 } else {
                     xk = fma_(st, L.eps[ir * S + k], uk);
@@ -598,7 +631,7 @@ template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_fwd(Csmc
     }
 }
 
-template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_bwd(CsmcArgs a, FkW<R> m) {
+template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2_bwd(CsmcArgs a, FkW<R> m) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NT_ = 64 * NW2;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, N = a.N, T = a.T, D = m.D;
@@ -643,19 +676,36 @@ template <typename R> __global__ void __launch_bounds__(64 * NW2) k_cw2_bwd(Csmc
         }
         return;
     }
+    constexpr int NSL = 64 / (2 * NW2);  // passes at N = 64
+    R xi_nx[NSL], lw_nx[NSL];  // the rows of step t, requested one step ahead (they do not depend on the draws)
+#pragma unroll
+    for (int s = 0; s < NSL; ++s) {
+        const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0), ir = i < N ? i : 0;
+        xi_nx[s] = (T >= 2 && k < D) ? xs[((long long)(T - 2) * N + ir) * D + k] : (R)0;
+        lw_nx[s] = T >= 2 ? lws[(long long)(T - 2) * N + ir] : (R)0;
+    }
     for (int t = T - 2; t >= 0; --t) {
         __syncthreads();  // (the draw of the step before has been read by everybody)
-        for (int s = 0; s < nslot; ++s) {
+#pragma unroll
+        for (int s = 0; s < NSL; ++s) {
+            if (s >= nslot) break;
             const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
             const bool pl = i < N;
             const int ir = pl ? i : 0;
-            const R xik = k < D ? xs[((long long)t * N + ir) * D + k] : (R)0;
+            const R xik = xi_nx[s], lwik = lw_nx[s];
+            if (t > 0) {
+                xi_nx[s] = k < D ? xs[((long long)(t - 1) * N + ir) * D + k] : (R)0;
+                lw_nx[s] = lws[(long long)(t - 1) * N + ir];
+            }
             if (k < D) L.xa[ir * S + k] = xik;  // (a half-wave reads back only its own row: ordered inside the wave)
             __builtin_amdgcn_wave_barrier();
             const R* xi = L.xa + ir * S;
             R mu = bk;
-            for (int j = 0; j < D; ++j) mu = fma_(Frow[j], xi[j], mu);
-            const R lwt = gauss_half<R>(D, k, hi, xn - mu, Lrow, iLk, m.c_trans) + lws[(long long)t * N + ir];  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
+            if (!(CW2_ABL & 16)) {
+#pragma unroll
+                for (int j = 0; j < CSW_MAXD; ++j) mu = fma_(Frow[j], xi[j], mu);
+            }
+            const R lwt = gauss_half<R>(D, k, hi, xn - mu, Lrow, iLk, m.c_trans) + lwik;  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
             if (pl && k == 0) L.lwv[i] = lwt;
         }
         __syncthreads();
@@ -741,10 +791,15 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
     if (lds > 48 * 1024) {
         AX_HIP(hipFuncSetAttribute((const void*)k_cw_fwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         AX_HIP(hipFuncSetAttribute((const void*)k_cw_bwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_fwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_bwd<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_fwd<R, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_bwd<R, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_fwd<R, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        AX_HIP(hipFuncSetAttribute((const void*)k_cw2_bwd<R, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     }
     const int cb = a.cb > 0 ? a.cb : a.C;
+    // sixteen waves per chain (every particle of N <= 32 in its own half-wave at once: the shortest step) while the chains leave CUs to spare, eight (no idle
+    // waves at N = 25, two passes) once there are more chains than CUs
+    const bool wide16 = sizeof(R) == 4 && (getenv("AUXSSM_CW_WAVES") ? atoi(getenv("AUXSSM_CW_WAVES")) == 16 : a.C <= h->num_cu);  // (fp64: the unrolled loops need more than the 128 registers of a 1024-lane workgroup)
     for (int c0 = 0; c0 < a.C; c0 += cb) {
         CsmcArgs ab = a;
         ab.c0 = c0;
@@ -755,12 +810,14 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
         {
             ProfScope ps(h, AUXSSM_K_CSMC_FWD);
             if (v1) hipLaunchKernelGGL((k_cw_fwd<R>), dim3(ab.C), dim3(64), lds, h->stream, ab, m);
-            else hipLaunchKernelGGL((k_cw2_fwd<R>), dim3(ab.C), dim3(64 * NW2), lds, h->stream, ab, m);
+            else if (wide16) hipLaunchKernelGGL((k_cw2_fwd<R, 16>), dim3(ab.C), dim3(1024), lds, h->stream, ab, m);
+            else hipLaunchKernelGGL((k_cw2_fwd<R, 8>), dim3(ab.C), dim3(512), lds, h->stream, ab, m);
         }
         {
             ProfScope ps(h, AUXSSM_K_CSMC_BWD);
             if (v1) hipLaunchKernelGGL((k_cw_bwd<R>), dim3(ab.C), dim3(64), lds, h->stream, ab, m);
-            else hipLaunchKernelGGL((k_cw2_bwd<R>), dim3(ab.C), dim3(64 * NW2), lds, h->stream, ab, m);
+            else if (wide16) hipLaunchKernelGGL((k_cw2_bwd<R, 16>), dim3(ab.C), dim3(1024), lds, h->stream, ab, m);
+            else hipLaunchKernelGGL((k_cw2_bwd<R, 8>), dim3(ab.C), dim3(512), lds, h->stream, ab, m);
         }
     }
     AX_HIP(hipGetLastError());
