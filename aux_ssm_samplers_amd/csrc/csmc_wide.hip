@@ -364,7 +364,7 @@ template <typename R> __global__ void __launch_bounds__(64) k_cw_bwd(CsmcArgs a,
 
 template <typename R> struct Cw2Lds {
     int D, S;
-    R *F, *LQ, *b, *iL, *c, *lwv, *xa, *xb, *eps;
+    R *F, *LQ, *b, *iL, *c, *lwv, *xa, *xb, *eps, *blk;
     int* idx;
     __device__ Cw2Lds(char* smem, int D_) : D(D_), S(CSW_MAXD + 1) {  // rows padded with zeros to 32 columns (+ 1: odd stride): every component loop runs 32 steps, unrolled
         F = (R*)smem;           // [D][S]
@@ -376,9 +376,10 @@ template <typename R> struct Cw2Lds {
         xa = lwv + 64;          // [64][S]
         xb = xa + 64 * S;       // [64][S]
         eps = xb + 64 * S;      // [64][S]
-        idx = (int*)(eps + 64 * S);  // [64]
+        blk = eps + 64 * S;     // [8][12] the 4 x 4 diagonal blocks of chol Q and the reciprocal diagonal, in the order gauss_half_blk reads them
+        idx = (int*)(blk + 96);  // [64]
     }
-    static size_t bytes(int D) { return ((size_t)2 * D * (CSW_MAXD + 1) + 2 * D + 128 + (size_t)3 * 64 * (CSW_MAXD + 1)) * sizeof(R) + 64 * sizeof(int) + 64; }
+    static size_t bytes(int D) { return ((size_t)2 * D * (CSW_MAXD + 1) + 2 * D + 128 + (size_t)3 * 64 * (CSW_MAXD + 1) + 96) * sizeof(R) + 64 * sizeof(int) + 64; }
 };
 template <typename R> __device__ __forceinline__ void cw2_stage(const FkW<R>& m, Cw2Lds<R>& L, int tid, int nt) {
     const int D = m.D, S = L.S;
@@ -389,6 +390,18 @@ template <typename R> __device__ __forceinline__ void cw2_stage(const FkW<R>& m,
     }
     for (int i = tid; i < D; i += nt) L.b[i] = m.b[i], L.iL[i] = m.iLQ[i];
     for (int i = tid; i < 64 * S; i += nt) L.xa[i] = 0, L.xb[i] = 0, L.eps[i] = 0;
+    if (tid < 96) {  // block jb = 4 (tid / 12): [L10 L20 L21 L30 L31 L32 | i0 i1 i2 i3 | 0 0], zeros beyond D
+        const int bq = tid / 12, e = tid - 12 * bq, jb = 4 * bq;
+        const int rr[6] = {1, 2, 2, 3, 3, 3}, cc[6] = {0, 0, 1, 0, 1, 2};
+        R v = 0;
+        if (e < 6) {
+            const int r = jb + rr[e], q = jb + cc[e];
+            v = r < D ? m.LQ[r * D + q] : (R)0;
+        } else if (e < 10) {
+            v = jb + e - 6 < D ? m.iLQ[jb + e - 6] : (R)0;
+        }
+        L.blk[tid] = v;
+    }
     __syncthreads();
 }
 // value of lane J of MY half-wave: ds_swizzle in bit mode (lane' = (lane & and) | or inside each group of 32 lanes, and = 0, or = J) -- one LDS-crossbar
@@ -422,6 +435,42 @@ template <typename R> __device__ __forceinline__ R gauss_half(int D, int k, bool
         const R zj = half_bcast<R, j>(acc * iLk);
         q = fma_(zj, zj, q);
         acc = (k > j && k < D) ? fma_(-l[j], zj, acc) : acc;
+    });
+    return fma_((R)-0.5, q, cst);
+}
+// The same density with the substitution in BLOCKS OF FOUR columns: one round of four broadcasts hands every lane the accumulators of lanes jb .. jb + 3 (final with
+// respect to the columns before jb); every lane then solves the 4 x 4 triangular block for z_jb .. z_jb+3 itself -- the multiply-adds lane jb + a would apply to its own
+// accumulator, in the same order, so the same bits -- and applies the four columns to its own accumulator in order.  Eight broadcast latencies per density instead of
+// thirty-two (profiles/r03_d_cw2_ablation.txt: the dependent broadcast chain was half of the sweep).  blk: Cw2Lds::blk (uniform reads).
+template <typename R> __device__ __forceinline__ R gauss_half_blk(int D, int k, R acc, const R* Lrow, const R* blk, R cst) {
+    if (CW2_ABL & 4) return acc * cst;
+    R q = 0;
+    acc = k < D ? acc : (R)0;
+    R l[CSW_MAXD];
+#pragma unroll
+    for (int j = 0; j < CSW_MAXD; ++j) l[j] = Lrow[j];  // (rows are zero-padded to 32 columns)
+    static_for<0, CSW_MAXD / 4>([&](auto bc) {
+        constexpr int jb = 4 * decltype(bc)::value;
+        const R* e = blk + 12 * decltype(bc)::value;
+        R a0 = half_bcast<R, jb>(acc), a1 = half_bcast<R, jb + 1>(acc), a2 = half_bcast<R, jb + 2>(acc), a3 = half_bcast<R, jb + 3>(acc);
+        const R z0 = a0 * e[6];
+        a1 = fma_(-e[0], z0, a1);
+        const R z1 = a1 * e[7];
+        a2 = fma_(-e[1], z0, a2);
+        a2 = fma_(-e[2], z1, a2);
+        const R z2 = a2 * e[8];
+        a3 = fma_(-e[3], z0, a3);
+        a3 = fma_(-e[4], z1, a3);
+        a3 = fma_(-e[5], z2, a3);
+        const R z3 = a3 * e[9];
+        q = fma_(z0, z0, q);
+        q = fma_(z1, z1, q);
+        q = fma_(z2, z2, q);
+        q = fma_(z3, z3, q);
+        acc = (k > jb && k < D) ? fma_(-l[jb], z0, acc) : acc;
+        acc = (k > jb + 1 && k < D) ? fma_(-l[jb + 1], z1, acc) : acc;
+        acc = (k > jb + 2 && k < D) ? fma_(-l[jb + 2], z2, acc) : acc;
+        acc = (k > jb + 3 && k < D) ? fma_(-l[jb + 3], z3, acc) : acc;
     });
     return fma_((R)-0.5, q, cst);
 }
@@ -606,7 +655,7 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
             }
             // weights (csmc.py:95-96)
             R g = potential_half<R>(m, k, hi, xk, yk);
-            if (m.proposal == 1) g = gauss_half<R>(D, k, hi, xk - mu, Lrow, iLk, m.c_trans) + g;  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
+            if (m.proposal == 1) g = gauss_half_blk<R>(D, k, xk - mu, Lrow, L.blk, m.c_trans) + g;  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
             if (pl && k < D) {
                 xcur[i * S + k] = xk;
                 xs[((long long)t * N + i) * D + k] = xk;
@@ -705,7 +754,7 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
 #pragma unroll
                 for (int j = 0; j < CSW_MAXD; ++j) mu = fma_(Frow[j], xi[j], mu);
             }
-            const R lwt = gauss_half<R>(D, k, hi, xn - mu, Lrow, iLk, m.c_trans) + lwik;  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
+            const R lwt = gauss_half_blk<R>(D, k, xn - mu, Lrow, L.blk, m.c_trans) + lwik;  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
             if (pl && k == 0) L.lwv[i] = lwt;
         }
         __syncthreads();
