@@ -261,10 +261,31 @@ def sv30(T=250, D=30, N=25):
                               updated=float((cc.ancestors.to_host() != 0).mean()))))
 
 
+def sv30_kalman(T=250, D=30, chains=(1, 16, 64)):
+    """the other sampler of the same protocol: the auxiliary Kalman sampler with first / second order linearisation of the SV observation model at D = 30
+    (examples/stochastic_volatility/auxiliary_kalman.py:22-48), fp64 as the reference runs it, parallel scan; wide-state kernels (dx = 30)"""
+    from tests.helpers import sv_setup
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, D)
+    h = _lib.default_handle()
+    for order in (1, 2):
+        model = SVModel(y, m0, P0, F, Q, b, order=order)
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        for C_ in chains:
+            try:
+                ch = DeviceChains(h, np.repeat(xtrue[None], C_, axis=0), chain_minor=False)
+                v, ms, acc = timed_sweeps(kernel, ch, 0.01, steps=3, warmup=1)
+                print(json.dumps(dict(config=f"SV protocol D={D} T={T}, aux-Kalman order {order}, fp64, parallel scan, wide-state kernels", chains=C_,
+                                      sweeps_per_s=round(v, 1), ms_per_step=round(ms, 2), accept=acc)), flush=True)
+            except Exception as e:  # noqa: BLE001
+                print(json.dumps(dict(config=f"SV protocol D={D} T={T}, aux-Kalman order {order}", chains=C_, error=f"{type(e).__name__}: {e}")), flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["c3k", "c4", "c5"]
     if "sv30" in which:
         sv30()
+    if "sv30k" in which:
+        sv30_kalman()
     if "pit" in which:
         pit()
     if "loop" in which:
