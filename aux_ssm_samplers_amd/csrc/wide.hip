@@ -2302,7 +2302,7 @@ template <typename R> static size_t shared_ws(const auxssm_ctx* h, int S, int n,
     const SPlan sp = shared_plan(h, S, n, d, p, sizeof(R));
     const GRow g(d, p);
     const size_t Spad = (size_t)sp.ncb * sp.CB;
-    return ((size_t)n * g.size + (size_t)sp.nchunk * d * ldp_(d) + 2 * (size_t)sp.nchunk * d * Spad + (size_t)S * sp.nchunk + 2 * (size_t)S + 64) * sizeof(R) + 16 * 256;
+    return ((size_t)n * g.size + 2 * (size_t)sp.nchunk * d * ldp_(d) + 4 * (size_t)sp.nchunk * d * Spad + (size_t)S * sp.nchunk + 2 * (size_t)S + 64) * sizeof(R) + 20 * 256;
 }
 template <typename R> static size_t filter_ws_d(const auxssm_ctx* h, const KDims& kd, int parallel, int d, int p) {
     const int S = kd.S(), n = kd.n();
@@ -2388,6 +2388,21 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     R* aggA = (R*)ws_take(h, (size_t)sp.nchunk * d * ldp_(d) * sizeof(R));
     R* aggG = (R*)ws_take(h, (size_t)sp.nchunk * d * Spad * sizeof(R));
     R* pre = (R*)ws_take(h, (size_t)sp.nchunk * d * Spad * sizeof(R));
+    // second level of the chunk-composite scan: groups of GRP composites (none below 2 GRP chunks)
+    static const int GRP = getenv("AUXSSM_WIDE_SHARED_GROUP") ? std::max(2, atoi(getenv("AUXSSM_WIDE_SHARED_GROUP"))) : 16;
+    const int nsup = sp.nchunk >= 2 * GRP ? (sp.nchunk + GRP - 1) / GRP : 1;
+    const size_t l_grp = lds_mean_group(sizeof(R), d, sp.CB);
+    R *supA = nullptr, *supG = nullptr, *presup = nullptr;
+    if (nsup > 1) {
+        if (l_grp > LDS_BUDGET) {
+            h->ws_off = mark;
+            return 1;
+        }
+        supA = (R*)ws_take(h, (size_t)nsup * d * ldp_(d) * sizeof(R));
+        supG = (R*)ws_take(h, (size_t)nsup * d * Spad * sizeof(R));
+        presup = (R*)ws_take(h, (size_t)nsup * d * Spad * sizeof(R));
+        if (!supA || !supG || !presup) return AUXSSM_ERR_NOMEM;
+    }
     R* ellpart = (R*)ws_take(h, (size_t)S * sp.nchunk * sizeof(R));
     R* ell0 = (R*)ws_take(h, (size_t)S * sizeof(R));
     R* ell_seq0 = (R*)ws_take(h, 256);
@@ -2442,7 +2457,13 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
 #define AX_MEAN(NRI)                                                                                                                                                         \
     do {                                                                                                                                                                  \
         if (sp.nchunk > 1) WK_LAUNCH((wk_mean_reduce<R, NRI>), (long long)sp.nchunk * sp.ncb, l_red, fa, (const R*)tab, aggA, aggG, sp.E, sp.ncb, sp.CB);                  \
-        WK_LAUNCH((wk_mean_aggs<R, NRI>), sp.ncb, l_agg, fa, (const R*)aggA, (const R*)aggG, pre, sp.nchunk, sp.ncb, sp.CB);                                               \
+        if (nsup > 1) {  /* two levels: group composites, their sequential pass, then every group's chunk starts in parallel */                                         \
+            WK_LAUNCH((wk_mean_group<R, NRI>), (long long)nsup * sp.ncb, l_grp, fa, (const R*)aggA, (const R*)aggG, supA, supG, sp.nchunk, sp.ncb, sp.CB, GRP);            \
+            WK_LAUNCH((wk_mean_aggs<R, NRI>), sp.ncb, l_agg, fa, (const R*)supA, (const R*)supG, presup, nsup, sp.ncb, sp.CB, nsup, (const R*)nullptr);                    \
+            WK_LAUNCH((wk_mean_aggs<R, NRI>), (long long)nsup * sp.ncb, l_agg, fa, (const R*)aggA, (const R*)aggG, pre, sp.nchunk, sp.ncb, sp.CB, GRP, (const R*)presup);  \
+        } else {                                                                                                                                                          \
+            WK_LAUNCH((wk_mean_aggs<R, NRI>), sp.ncb, l_agg, fa, (const R*)aggA, (const R*)aggG, pre, sp.nchunk, sp.ncb, sp.CB, sp.nchunk, (const R*)nullptr);            \
+        }                                                                                                                                                                 \
         WK_LAUNCH((wk_mean_down<R, NRI>), (long long)sp.nchunk * sp.ncb, l_down, fa, (const R*)tab, (const R*)pre, ellpart, sp.E, sp.nchunk, sp.ncb, sp.CB);              \
     } while (0)
         if ((long long)std::max(d, p) * ldp_(std::max(d, p)) <= 5ll * NT) AX_MEAN(5);

@@ -319,23 +319,105 @@ __global__ void __launch_bounds__(NT) wk_mean_reduce(FilterArgs a, const R* __re
         }
 }
 
+// ---- composites of GROUPS of G consecutive chunk composites (the second level of the scan: with 256 chunks the plain sequential pass below is 256 dependent
+// products on ONE workgroup, 0.46 ms at C5; groups of 16 make it 16 + 16 + 16) ----------------------------------------------------------------------
+static size_t lds_mean_group(size_t s, int d, int CB) {
+    const size_t ldd = ldp_(d), ldg = ldp_(CB + d), ldc = ldp_(CB);
+    return al16(d * ldd * s) + 2 * al16(d * ldg * s) + al16(d * ldc * s) + 64;
+}
+template <typename R, int NRI>
+__global__ void __launch_bounds__(NT) wk_mean_group(FilterArgs a, const R* __restrict__ aggA, const R* __restrict__ aggG, R* __restrict__ supA, R* __restrict__ supG, int nchunk_all,
+                                                    int ncb, int CB, int G) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, g = blockIdx.x / ncb, cb = blockIdx.x - g * ncb, s0 = cb * CB;
+    const int ldd = ldp_(d), ldg = ldp_(CB + d), ldc = ldp_(CB), Spad = ncb * CB;
+    const int j0 = g * G, j1 = j0 + G < nchunk_all ? j0 + G : nchunk_all;
+    const bool doA = cb == 0;
+    Bump L{smem};
+    R* Ab = L.take<R>(d * ldd);
+    R* GA[2] = {L.take<R>(d * ldg), L.take<R>(d * ldg)};  // [offset block (d x CB) | product of the A-composites (d x d)]
+    R* Gl = L.take<R>(d * ldc);
+    for (int e = tid; e < d * ldg; e += NT) {
+        const int r = e / ldg, q = e - r * ldg;
+        GA[0][e] = (q >= CB && q - CB == r) ? (R)1 : (R)0;
+        GA[1][e] = 0;
+    }
+    Img<R, NRI> ia;
+    Img<R> ig;
+    auto fetch = [&](int j) {
+        img_fetch(ia, aggA + (long long)j * d * ldd, d * ldd, tid);
+#pragma unroll
+        for (int u = 0; u < SH_NR; ++u) {
+            const int e = tid + u * NT, r = e / CB, q = e - r * CB;
+            ig.v[u] = e < d * CB ? aggG[((long long)j * d + r) * Spad + s0 + q] : (R)0;
+        }
+    };
+    fetch(j0);
+    int cur = 0;
+    for (int j = j0; j < j1; ++j) {
+        __syncthreads();
+        img_drop(ia, Ab, d * ldd, tid);
+#pragma unroll
+        for (int u = 0; u < SH_NR; ++u) {
+            const int e = tid + u * NT, r = e / CB, q = e - r * CB;
+            if (e < d * CB) Gl[r * ldc + q] = ig.v[u];
+        }
+        __syncthreads();
+        if (j + 1 < j1) fetch(j + 1);
+        R* c0 = GA[cur];
+        R* c1 = GA[cur ^ 1];
+        gemm<false, false>(d, doA ? CB + d : CB, d, Ab, ldd, c0, ldg, c1, ldg, (R)1, (R)0, tid);
+        for (int e = tid; e < d * CB; e += NT) {
+            const int r = e / CB, q = e - r * CB;
+            c1[r * ldg + q] += Gl[r * ldc + q];
+        }
+        cur ^= 1;
+    }
+    __syncthreads();
+    const R* fin = GA[cur];
+    for (int e = tid; e < d * CB; e += NT) {
+        const int r = e / CB, q = e - r * CB;
+        supG[((long long)g * d + r) * Spad + s0 + q] = fin[r * ldg + q];
+    }
+    if (doA)
+        for (int e = tid; e < d * ldd; e += NT) {
+            const int r = e / ldd, q = e - r * ldd;
+            supA[(long long)g * d * ldd + e] = q < d ? fin[r * ldg + CB + q] : (R)0;
+        }
+}
+
 // ---- the means at the chunk starts: M_0 = the t = 0 update (wk_filter_t0), M_{j+1} = Abar_j M_j + G_j; one workgroup per block of sequences ----
 static size_t lds_mean_aggs(size_t s, int d, int CB) {
     const size_t ldd = ldp_(d), ldc = ldp_(CB);
     return al16(d * ldd * s) + 3 * al16(d * ldc * s) + 64;
 }
 template <typename R, int NRI>
-__global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __restrict__ aggA, const R* __restrict__ aggG, R* __restrict__ pre, int nchunk, int ncb, int CB) {
+__global__ void __launch_bounds__(NT) wk_mean_aggs(FilterArgs a, const R* __restrict__ aggA, const R* __restrict__ aggG, R* __restrict__ pre, int nchunk_all, int ncb, int CB,
+                                                   int G, const R* __restrict__ start) {
+    // workgroup (g, cb): the composites j0 = g G .. j1 - 1 of column block cb, started from start[g] (the means at the start of group g) or, start == null, from the
+    // t = 0 update.  One group of all composites = the plain sequential pass; groups of G run in parallel once a pass over the GROUP composites (wk_mean_group)
+    // has produced their starts.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, d = a.dx, S = a.d.S(), cb = blockIdx.x, s0 = cb * CB;
+    const int tid = threadIdx.x, d = a.dx, S = a.d.S(), g = blockIdx.x / ncb, cb = blockIdx.x - g * ncb, s0 = cb * CB;
     const int ldd = ldp_(d), ldc = ldp_(CB), Spad = ncb * CB;
+    const int j0 = g * G, nchunk = (j0 + G < nchunk_all ? j0 + G : nchunk_all) - j0;
+    aggA += (long long)j0 * d * ldd;
+    aggG += (long long)j0 * d * Spad;
+    pre += (long long)j0 * d * Spad;
     Bump L{smem};
     R* Ab = L.take<R>(d * ldd);
     R* M[2] = {L.take<R>(d * ldc), L.take<R>(d * ldc)};
     R* Gl = L.take<R>(d * ldc);
-    for (int e = tid; e < d * CB; e += NT) {
-        const int sl = e / d, r = e - sl * d, s = s0 + sl;
-        M[0][r * ldc + sl] = s < S ? at<R>(a.ms, s / a.d.B, 0, s % a.d.B)[(long long)r * a.ms.se] : (R)0;
+    if (start) {
+        for (int e = tid; e < d * CB; e += NT) {
+            const int r = e / CB, q = e - r * CB;
+            M[0][r * ldc + q] = start[((long long)g * d + r) * Spad + s0 + q];
+        }
+    } else {
+        for (int e = tid; e < d * CB; e += NT) {
+            const int sl = e / d, r = e - sl * d, s = s0 + sl;
+            M[0][r * ldc + sl] = s < S ? at<R>(a.ms, s / a.d.B, 0, s % a.d.B)[(long long)r * a.ms.se] : (R)0;
+        }
     }
     Img<R, NRI> ia;
     Img<R> ig;  // d * CB <= 85 * 64 < 8 NT

@@ -21,7 +21,7 @@ def oracle_target(model):
 
 
 @pytest.mark.parametrize("order", [1, 2])
-@pytest.mark.parametrize("d,T", [(1, 400), (2, 257), (4, 150), (6, 60)])
+@pytest.mark.parametrize("d,T", [(1, 400), (2, 257), (4, 150), (6, 60), (30, 24)])
 @pytest.mark.parametrize("parallel", [True, False])
 def test_sv_device_sweep_vs_oracle(order, d, T, parallel):
     from aux_ssm_samplers_amd.kalman import get_kernel, SVModel
