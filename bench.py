@@ -376,6 +376,16 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
                         traffic=traffic, traffic_source=src, kernel=(FUSED_PASS_NAMES[g] if mode == "fused" else f"{g} ({mode} path)"), avg_launch_ms=k["ms_per_step"],
                         launches=int(groups[g][0]), algorithmic_bytes_per_launch=k["algorithmic_bytes_per_step"],
                         share_of_step=round(k["ms_per_step"] / (el / steps * 1e3), 3))
+            if mode == "fused":  # the three passes' VALU-issue fractions from the committed SQ counter passes of this command (tools/pmc_sq.sh): passes A and C
+                # are bound by instruction issue (fp64 Threefry + Box-Muller inside the pass), pass E by HBM -- the HBM fraction alone does not say that
+                try:
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
+                    vi = {q: {kk: tj[f"fused_C2_sq_{q}"][kk] for kk in ("valu_issue_frac", "valu_per_chain_step", "us_per_launch")}
+                          for q in ("pass_A", "pass_C", "pass_E") if f"fused_C2_sq_{q}" in tj}
+                    if vi and args.dtype == "f64" and (T, d, C) == (65536, 4, 256):
+                        roof["valu_issue"] = dict(vi, source=tj["fused_C2_sq_pass_A"]["source"])
+                except Exception:
+                    pass
             if mode == "general" and g == "filter_scan":
                 n = T - 1
                 k3 = C * n * ((3 * d * d + 2 * d) + (d * d + d)) * s  # the reference's unpacked (A, b, C, eta, J) elements
