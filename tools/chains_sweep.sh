@@ -1,4 +1,4 @@
-for c in 1 8 64; do
+for c in ${CHAINS:-1 8 64}; do
   timeout -k 10 300 python bench.py --chains $c --no-secondary --no-cpu-baseline --steps 8 --warmup 2 > gpurun_out/ch_$c.log 2>&1 || { tail -3 gpurun_out/ch_$c.log; exit 1; }
   python - <<PY
 import json
