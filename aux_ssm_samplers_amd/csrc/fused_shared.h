@@ -6,7 +6,7 @@
 // Here (7 d = 3.76 GB):
 //   A  (k_fs_a)  r x            w u      filter fold of the chunk; draws eps_aux, u = x + sqrt(delta/2) eps; the MH terms of the CURRENT state x
 //                                         (prior, observation, auxiliary: kalman/generic.py:88-89, :103-105) where x and eps are in registers
-//   C  (k_fs_c)  r u            w inc    filter walk (means, log-likelihood increments: filtering.py:55-62) AND, in the same ascending walk, the
+//   C  (k_fs_c)  r u            w inc    filter walk (means; the marginal log-likelihood comes from an identity, see k_fs_accept) AND, in the same ascending walk, the
 //                                         sampler's increments inc_t = M1_t m_t - gb_t + Lc_t eps_t (sampling.py:108-112; draws eps_samp) together with
 //                                         the sampler's chunk aggregate e = sum_t (G_ta ... G_{t-1}) inc_t -- the composition of the reverse affine maps
 //                                         x_t = G_t x_{t+1} + inc_t (sampling.py:51-55) accumulated FORWARD in time against a chain-shared table of the
@@ -36,7 +36,8 @@ struct FusedArgs {
     void* agg_f; void* pre_f; void* agg_s; void* pre_s;  // chunk aggregates / exclusive prefixes of the two scans (k_aff_aggs layout)
     Acc* pa;             // (3, C, nchunk): sums over the chunk of [q(x | u) terms, target(x) terms, |x - u|^2 / delta]
     Acc* pe;             // (3, C, nchunk): the same of x'
-    void* pell;          // (C, nchunk) log-likelihood increments (R)
+    void* pell;          // (C, nchunk) -1/2 sum |eps_samp|^2 of the chunk: the data part of log q(x' | u) (R)
+    const Acc* clog;     // sum_t (sum_i log Lc_t[i][i] + D/2 log 2 pi): the chain-shared part of log q(x' | u) (k_fs_clog, model stage)
     unsigned ka0, ka1, ks0, ks1;  // keys of eps_aux / eps_samp (stream 0 of auxssm_rng_normal at the (T, D, C) flat index)
     const void* eps0s;   // (D, C): row 0 of eps_samp (fill kernel)
     double delta, shd;
@@ -109,9 +110,9 @@ template <typename R, int D, int PO> struct FsRows {
     static constexpr int pad(int n) { return (n + VEC - 1) / VEC * VEC; }
     // pass A, row i = t - 1 (t >= 1): [Mb | kc | K[:, :D] | LogShared row i]
     static constexpr int aM = 0, aKc = D * D, aK = aKc + D, aL = aK + D * D, NA = pad(aL + TL::N);
-    // pass C, row t (t >= 0; the filter part of row 0 is zero): [Mb | kc | K[:, :D] | HF | ym | Si | c0 | M1 | gb | Lc (lower, packed) | gpre]
-    static constexpr int cM = 0, cKc = D * D, cK = cKc + D, cHF = cK + D * D, cYm = cHF + P * D, cSi = cYm + P, cC0 = cSi + symsize(P), cM1 = cC0 + 1,
-                         cGb = cM1 + D * D, cL = cGb + D, cGp = cL + symsize(D), NC = pad(cGp + D * D);
+    // pass C, row t (t >= 0; the filter part of row 0 is zero): [Mb | kc | K[:, :D] | M1 | gb | Lc (lower, packed) | gpre]   (no innovation coefficients: the
+    // log-likelihood is not walked, k_fs_accept)
+    static constexpr int cM = 0, cKc = D * D, cK = cKc + D, cM1 = cK + D * D, cGb = cM1 + D * D, cL = cGb + D, cGp = cL + symsize(D), NC = pad(cGp + D * D);
     // pass E, row t: [G_t | LogShared row t (transition t -> t + 1, observation at t + 1; zero for t = T - 1)]
     static constexpr int eG = 0, eL = D * D, NE = pad(eL + TL::N);
 };
@@ -132,11 +133,7 @@ template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_c(i
     using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>;
     if (k < F::cKc) return {0, TG::oM + k};
     if (k < F::cK) return {0, TG::oKc + (k - F::cKc)};
-    if (k < F::cHF) { const int q = k - F::cK; return {0, TG::oK + (q / D) * P + (q % D)}; }
-    if (k < F::cYm) return {0, TG::oHF + (k - F::cHF)};
-    if (k < F::cSi) return {0, TG::oYm + (k - F::cYm)};
-    if (k < F::cC0) return {0, TG::oSi + (k - F::cSi)};
-    if (k < F::cM1) return {0, TG::oC0};
+    if (k < F::cM1) { const int q = k - F::cK; return {0, TG::oK + (q / D) * P + (q % D)}; }
     if (k < F::cGb) return {1, TS::oM + (k - F::cM1)};
     if (k < F::cL) return {1, TS::oGb + (k - F::cGb)};
     if (k < F::cGp) {  // packed lower index -> (i, j) of the dense D x D factor
@@ -173,6 +170,40 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
     else if (sc.tab == 3) v = ((const R*)a.gpre)[(long long)t * D * D + sc.off];
     else if (sc.tab == 4) { if (t + 1 < a.T) v = ((const R*)a.logt)[(long long)t * TL::NPAD + sc.off]; }
     (fam == 0 ? ra : fam == 1 ? rc : re)[g] = v;
+}
+
+// the chain-shared part of log q(x' | u): x'_t | x'_{t+1} = G_t x'_{t+1} + M1_t m_t - gb_t + Lc_t eps_t, so log q = sum_t (-1/2 |eps_t|^2 - sum_i log Lc_t[i][i] - D/2 log 2 pi).
+// Two launches with a fixed shape (one lane per time step, a tree per workgroup, then one workgroup over the partial sums): deterministic, and a few microseconds
+// on the model stage's chain of dependent launches (one workgroup walking all T steps took 0.6 ms there and made the stage the critical path).
+template <typename R, int D> __global__ void __launch_bounds__(256) k_fs_clog_part(int T, const R* __restrict__ samp, Acc* __restrict__ part) {
+    using TS = SampShared<R, D>;
+    __shared__ Acc sh[256];
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    R s = 0;
+    if (t < T) {
+        const R* row = samp + (long long)t * TS::NPAD;
+#pragma unroll
+        for (int i = 0; i < D; ++i) s += log_(row[TS::oL + i * D + i]);
+    }
+    sh[threadIdx.x] = (Acc)s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
+}
+template <int D> __global__ void __launch_bounds__(256) k_fs_clog_sum(int T, int nb, const Acc* __restrict__ part, Acc* __restrict__ out) {
+    __shared__ Acc sh[256];
+    Acc acc = 0;
+    for (int b = threadIdx.x; b < nb; b += 256) acc += part[b];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] += sh[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *out = sh[0] + (Acc)T * (Acc)D * (Acc)(0.5 * LOG_2PI);
 }
 
 // workgroup = all (up to 256) chains of one chunk; consecutive blocks = the chain groups of one chunk
@@ -350,8 +381,11 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
 #pragma unroll
     for (int k = 0; k < D; ++k) es[k] = 0;
     // one sampler increment: inc = M1 m - gb + Lc eps (SampleAffOp::step without the G h term), stored, and folded into the chunk aggregate
+    R se = 0;  // sum |eps|^2 over the chunk's steps: the data part of log q(x' | u)
     auto emit = [&](int tu, const R* row, const R* eps) {
         R inc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) se += eps[k] * eps[k];
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             R v = -row[F::cGb + i];
@@ -376,7 +410,6 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
         for (int k = 0; k < D; ++k) eps[k] = ((const R*)a.eps0s)[k * C + c];
         emit(0, lds, eps);
     }
-    R acc = 0;
     R yn[D];  // the next step's auxiliary variable, fetched one step ahead
 #pragma unroll
     for (int k = 0; k < D; ++k) yn[k] = ta < tb ? up[((long long)ta * D + k) * C] : (R)0;
@@ -393,21 +426,10 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
             for (int k = 0; k < D; ++k) yn[k] = up[((long long)tn * D + k) * C];
         }
         normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + c, C, eps);
-        {  // FilterMeanOp::walk_impl<true>: innovation against the incoming mean, then the affine step
-            R r[P], o[D];
+        {  // the affine step of the filtered mean (FilterMeanOp::walk_impl without its innovation / log-likelihood half; a missing auxiliary value counts as 0, as there)
+            R o[D];
 #pragma unroll
-            for (int k = 0; k < P; ++k) {
-                R v = row[F::cYm + k];
-#pragma unroll
-                for (int j = 0; j < D; ++j) v += row[F::cHF + k * D + j] * m[j];
-                if (k < D) {
-                    const bool fin = finite_(y[k < D ? k : 0]);
-                    y[k < D ? k : 0] = fin ? y[k < D ? k : 0] : (R)0;
-                    r[k] = fin ? y[k < D ? k : 0] - v : (R)0;
-                } else {
-                    r[k] = -v;
-                }
-            }
+            for (int k = 0; k < D; ++k) y[k] = finite_(y[k]) ? y[k] : (R)0;
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 R v = row[F::cKc + k];
@@ -417,23 +439,13 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
                 for (int l = 0; l < D; ++l) v += row[F::cK + k * D + l] * y[l];
                 o[k] = v;
             }
-            R q = 0;
-#pragma unroll
-            for (int k = 0; k < P; ++k) {
-                R sk = 0;
-#pragma unroll
-                for (int l = 0; l < P; ++l) sk += row[F::cSi + sidx(P, k, l)] * r[l];
-                q += r[k] * sk;
-            }
-            const R incl = (R)-0.5 * q + row[F::cC0];
-            acc += isnan_(incl) ? (R)0 : incl;  // nansum (filtering.py:62)
 #pragma unroll
             for (int k = 0; k < D; ++k) m[k] = o[k];
         }
         emit(tu, row, eps);
     }
     stv<R, D>((R*)a.agg_s + ((long long)c * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, es);
-    ((R*)a.pell)[(long long)c * a.nchunk + ch] = acc;
+    ((R*)a.pell)[(long long)c * a.nchunk + ch] = (R)-0.5 * se;
 }
 
 // ---- pass E ---------------------------------------------------------------------------------------------------------------------------
@@ -533,8 +545,13 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
 #pragma unroll
     for (int k = 0; k < 7; ++k) tot[k] = block_sum<Acc, TB_ELEM>(tot[k], sh);
     if (threadIdx.x != 0) return;
-    const Acc ell = (Acc)ell0[c] + tot[6];
+    // The marginal log-likelihood of the auxiliary model WITHOUT walking its innovations: for any path z, ell = log p(z, u, y) - log p(z | u, y), and for the sampled
+    // proposal x' both are at hand -- the joint is the sum pass E forms anyway (jp_prop), the conditional is the density of the pathwise draw,
+    // log q(x' | u) = sum_t (-1/2 |eps_t|^2 - log|Lc_t| - D/2 log 2 pi) (pass C accumulates the first term, k_fs_clog the rest).  Same quantity as filtering.py:55-62
+    // to rounding; log alpha does not depend on it at all (it enters lp_prop and lp_rev alike), only the reported lp_prop / lp_rev do.
+    (void)ell0;
     const Acc jp_prop = tot[3] + (Acc)head5[0 * C + c], jp_rev = tot[0] + (Acc)head5[1 * C + c];
+    const Acc ell = jp_prop - (tot[6] - *a.clog);
     const Acc lt_prop = tot[4] + (Acc)head5[2 * C + c], lt_rev = tot[1] + (Acc)head5[3 * C + c];
     const Acc corr = (tot[5] - tot[2]) + (Acc)head5[4 * C + c];
     const Acc lp_prop = jp_prop - ell, lp_rev = jp_rev - ell;
@@ -575,7 +592,7 @@ template <typename R, int D, int PO> size_t fused_ws(const auxssm_ctx* h, const 
     b += (size_t)d.C * (5 + 1 + D) * sizeof(R) + 4 * 256;
     // model stage (side slab when the stage overlaps, else this one): matrix filter, gain / sampler / log-density tables, chunk products
     b += filter_ws<R, D, P>(h, KDims{1, d.T, 1}, 1);
-    b += (size_t)d.T * (SampShared<R, D>::NPAD + LogShared<R, D, PO>::NPAD + (size_t)D * D) * sizeof(R) + (size_t)2 * nchunk * D * D * sizeof(R) + 8 * 256;
+    b += (size_t)d.T * (SampShared<R, D>::NPAD + LogShared<R, D, PO>::NPAD + (size_t)D * D) * sizeof(R) + (size_t)2 * nchunk * D * D * sizeof(R) + 10 * 256 + ((size_t)d.T / 256 + 2) * sizeof(Acc);
     b += (size_t)d.T * (FsRows<R, D, PO>::NA + FsRows<R, D, PO>::NC + FsRows<R, D, PO>::NE) * sizeof(R) + 4 * 256;
     return b;
 }
@@ -606,11 +623,16 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
         rows_a = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NA * sizeof(R));
         rows_c = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NC * sizeof(R));
         rows_e = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NE * sizeof(R));
-        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s || !rows_a || !rows_c || !rows_e) return AUXSSM_ERR_NOMEM;
+        const int nclb = (T + 255) / 256;
+        Acc* clog = (Acc*)ws_take(h, 256 + (size_t)nclb * sizeof(Acc));  // [0] the sum, [32 ...) the partial sums
+        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s || !rows_a || !rows_c || !rows_e || !clog) return AUXSSM_ERR_NOMEM;
+        a.clog = clog;
         a.gain = f.fa.tab; a.samp = f.sa.tab; a.logt = f.la.tab; a.gpre = gpre;
         {
             ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
             hipLaunchKernelGGL((k_sample_shared_tab<R, D>), dim3((T + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.sa);
+            hipLaunchKernelGGL((k_fs_clog_part<R, D>), dim3(nclb), dim3(256), 0, h->stream, T, (const R*)f.sa.tab, clog + 32);
+            hipLaunchKernelGGL((k_fs_clog_sum<D>), dim3(1), dim3(256), 0, h->stream, T, nclb, (const Acc*)(clog + 32), clog);
             hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.la);
             hipLaunchKernelGGL((k_fs_fprod<R, D, P>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod_f);
             hipLaunchKernelGGL((k_fs_gpre<R, D>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, gpre, cprod_s);
