@@ -84,6 +84,45 @@ def test_differing_patterns_fall_back_to_the_per_sequence_path():
     check(lg, ys, np.float64, expect_shared=False)
 
 
+def test_batch_axis_sequences_share_the_recursion_too():
+    """C chains x B batch members (base.py:40-49: the log-likelihood of a chain is the SUM over its batch members) with one parameter set: all C B sequences ride in
+    the shared form; ms, Ps per (chain, batch member) and ell per chain equal the per-sequence path and the oracle."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    rng = np.random.default_rng(21)
+    d, p, T, Cn, B = 7, 9, 60, 3, 2
+    y0, lg = stable_model(rng, T, d, p, nan=False)
+    ys = y0[None, :, None, :] + rng.standard_normal((Cn, T, B, p))
+    h = _lib.default_handle()
+    out = {}
+    for share in (1, 0):
+        dl = DeviceLGSSM(h, tuple(lg), 1, T, 1, d, p, False, np.float64)
+        yd = h.to_device(np.ascontiguousarray(ys))
+        yarr = yd.arr(T * B * p, B * p, p)
+        ms, Ps, ell = h.empty((Cn, T, B, d), np.float64), h.empty((Cn, T, B, d, d), np.float64), h.empty((Cn,), np.float64)
+        dims = _lib.Dims(Cn, T, B, d, p)
+        h.set_option(_lib.OPT_SHARE_MODEL, share)
+        try:
+            h.prof_enable(_lib.K_ALL, 64)
+            _lib.check(h.lib.auxssm_kalman_filter(h.h, _lib.F64, C.byref(dims), C.byref(dl.c), C.byref(yarr), 1, ms.ptr, Ps.ptr, ell.ptr))
+            groups = h.prof_read_groups()
+        finally:
+            h.prof_disable()
+            h.set_option(_lib.OPT_SHARE_MODEL, 1)
+        assert ("filter_tab" in groups) == bool(share)
+        out[share] = (ms.to_host(), Ps.to_host(), ell.to_host())
+    for a, b in zip(out[1], out[0]):
+        npt.assert_allclose(a, b, rtol=1e-8, atol=1e-10)
+    for c in range(Cn):
+        tot = 0.0
+        for b in range(B):
+            oms, oPs, oell = K.filtering(ys[c, :, b], lg, True)
+            npt.assert_allclose(out[1][0][c, :, b], oms, rtol=1e-8, atol=1e-10)
+            npt.assert_allclose(out[1][1][c, :, b], oPs, rtol=1e-8, atol=1e-10)
+            tot += oell
+        npt.assert_allclose(out[1][2][c], tot, rtol=1e-8)
+
+
 def test_sequence_dependent_parameters_are_not_shared():
     """a per-sequence parameter array (chain stride != 0) must never take the shared form"""
     from aux_ssm_samplers_amd import _lib
