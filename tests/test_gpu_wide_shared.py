@@ -123,6 +123,41 @@ def test_batch_axis_sequences_share_the_recursion_too():
         npt.assert_allclose(out[1][2][c], tot, rtol=1e-8)
 
 
+@pytest.mark.parametrize("order", [1, 2])
+def test_wide_sv_sweep_with_several_chains_shared_equals_per_chain(order):
+    """Inside a sweep: the stochastic-volatility sampler at D = 6 (wide path) with 4 dense chains.  First order: H = I, R = delta/2 I and the dynamics are the same for
+    every chain, so both filters of the sweep take the shared form; second order: R depends on the chain's state, so they must not.  Either way the keyed sweep equals
+    the one with AUXSSM_OPT_SHARE_MODEL off (same keys, same draws) to rounding."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.kalman import get_kernel, SVModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    from tests.helpers import sv_setup
+    T, D, Cn = 40, 6, 4
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, D)
+    model = SVModel(y, m0, P0, F, Q, b, order=order)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    h = _lib.default_handle()
+    x0 = xtrue[None] + 0.2 * np.random.default_rng(9).standard_normal((Cn, T, D))
+    res = {}
+    for share in (1, 0):
+        chains = DeviceChains(h, x0, chain_minor=False)
+        h.set_option(_lib.OPT_SHARE_MODEL, share)
+        try:
+            h.prof_enable(_lib.K_ALL, 256)
+            for i in range(3):
+                kernel(R.PRNGKey(60 + i), KalmanSampler(x=chains, updated=None), 0.3)
+            groups = h.prof_read_groups()
+        finally:
+            h.prof_disable()
+            h.set_option(_lib.OPT_SHARE_MODEL, 1)
+        assert ("filter_tab" in groups) == (share == 1 and order == 1), groups
+        res[share] = (chains.to_host(), chains.logs.to_host(), chains.accepted.to_host())
+    npt.assert_allclose(res[1][0], res[0][0], rtol=1e-8, atol=1e-9)
+    npt.assert_allclose(res[1][1][:, 1:], res[0][1][:, 1:], rtol=1e-9)
+    npt.assert_allclose(res[1][1][:, 0], res[0][1][:, 0], atol=1e-6)
+    npt.assert_array_equal(res[1][2], res[0][2])
+
+
 def test_sequence_dependent_parameters_are_not_shared():
     """a per-sequence parameter array (chain stride != 0) must never take the shared form"""
     from aux_ssm_samplers_amd import _lib
