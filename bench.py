@@ -391,6 +391,15 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
                 k3 = C * n * ((3 * d * d + 2 * d) + (d * d + d)) * s  # the reference's unpacked (A, b, C, eta, J) elements
                 roof["k3_equivalent_GBps"] = round(k3 / (k["ms_per_step"] * 1e-3) / 1e9, 1)
                 roof["k3_equivalent_frac"] = round(roof["k3_equivalent_GBps"] / HBM_PEAK_GBPS, 4)
+    if roof is not None and mode == "fused":
+        # the whole sweep against the same peak: the algorithmic bytes of all launch groups on the chains' stream (the three passes) over the step time -- beside the
+        # dominant pass's own fraction, which says little while that pass is bound by instruction issue (valu_issue above)
+        chain_groups = [q for q in FUSED_PASS_NAMES if q in kernels]
+        tot = sum(kernels[q].get("algorithmic_bytes_per_step", 0) for q in chain_groups)
+        if tot:
+            gbps = tot / (el / steps) / 1e9
+            roof["whole_sweep"] = dict(algorithmic_bytes_per_step=int(tot), achieved=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBPS, 4), unit="GB/s",
+                                       note="three chain passes' algorithmic bytes / wall time of a step")
     out["roofline"] = roof
     return out
 
