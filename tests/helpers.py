@@ -157,3 +157,22 @@ def c5_model(T, d=64, delta=0.1, seed=0):
     lg = (np.zeros(d), np.eye(d), bt(F, (T - 1, d, d)), bt(np.eye(d), (T - 1, d, d)), bt(np.zeros(d), (T - 1, d)),
           bt(np.eye(d), (T, d, d)), bt(delta / 2 * np.eye(d), (T, d, d)), bt(np.zeros(d), (T, d)))
     return u, lg, x
+
+
+def sv_posterior_by_quadrature(y, m0, P0, F, Q, b, n=151, width=7.0):
+    """posterior mean / variance of each x_t of the scalar stochastic-volatility model with T = 3 by a tensor-product grid over (x_0, x_1, x_2):
+    pi(x) ~ N(x_0; m0, P0) prod_t N(x_t; F x_{t-1} + b, Q) prod_t N(y_t; 0, exp(x_t)).  Independent of every sampler and of the oracle."""
+    s0 = np.sqrt(P0)
+    g = np.linspace(-width * s0, width * s0, n)
+    x0, x1, x2 = np.meshgrid(g, g, g, indexing="ij", sparse=True)
+    lp = -0.5 * (x0 - m0) ** 2 / P0 - 0.5 * (x1 - F * x0 - b) ** 2 / Q - 0.5 * (x2 - F * x1 - b) ** 2 / Q
+    for xt, yt in ((x0, y[0]), (x1, y[1]), (x2, y[2])):
+        lp = lp - 0.5 * xt - 0.5 * yt ** 2 * np.exp(-xt)
+    w = np.exp(lp - lp.max())
+    w /= w.sum()
+    out = []
+    for ax, gx in enumerate((g, g, g)):
+        m = w.sum(tuple(a for a in range(3) if a != ax))
+        mean = float((m * gx).sum())
+        out.append((mean, float((m * (gx - mean) ** 2).sum())))
+    return np.array(out)

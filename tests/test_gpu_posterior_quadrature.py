@@ -1,6 +1,6 @@
 """Particle-Gibbs kernels against GROUND TRUTH with no restatement of the reference in the loop (csmc/generic.py and independent.py were
 pinned only through the oracles): on a scalar stochastic-volatility model with T = 3 the posterior means and variances of x_0, x_1, x_2 are computed by quadrature on a
-151^3 grid (tests/test_gpu_nonlinear_kalman.py::sv_posterior_by_quadrature, converged to 1e-12); every cSMC kernel of the family -- auxiliary independent proposals with
+151^3 grid (tests/helpers.py::sv_posterior_by_quadrature, converged to 1e-12); every cSMC kernel of the family -- auxiliary independent proposals with
 ancestor tracing / backward sampling (csmc/independent.py:57-75 on csmc/generic.py:56-72), gradient-informed proposals in the reference's and the exact weighting
 (:121-134, :173-190, :252-268), the bootstrap sweep (_primitives/csmc/csmc.py:52-59) and the parallel-in-time sweep with and without gradient proposals (:78-118) --
 must reproduce them from 1024 resident device chains within 5 standard errors (integrated autocorrelation time taken as 10)."""
@@ -9,7 +9,7 @@ import numpy.testing as npt
 import pytest
 
 from tests.helpers import sv_setup
-from tests.test_gpu_nonlinear_kalman import sv_posterior_by_quadrature
+from tests.helpers import sv_posterior_by_quadrature
 
 pytestmark = pytest.mark.gpu
 

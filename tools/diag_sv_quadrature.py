@@ -10,7 +10,7 @@ from aux_ssm_samplers_amd import _lib, random as R  # noqa: E402
 from aux_ssm_samplers_amd.kalman import get_kernel, SVModel  # noqa: E402
 from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler  # noqa: E402
 from tests.helpers import sv_setup  # noqa: E402
-from tests.test_gpu_nonlinear_kalman import sv_posterior_by_quadrature  # noqa: E402
+from tests.helpers import sv_posterior_by_quadrature  # noqa: E402
 
 T, d, C = 3, 1, 1024
 y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, d, seed=4, rho=0.0)
