@@ -575,13 +575,18 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
 inline int fs_chunk_len(const auxssm_ctx* h, int C, int T) {
     static const int waves = [] { const char* e = getenv("AUXSSM_FS_WAVES"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
     static const int fixedE = [] { const char* e = getenv("AUXSSM_FS_E"); return e ? atoi(e) : 0; }();
-    if (fixedE >= 2 && fixedE <= 32) return fixedE;
+    if (fixedE >= 2 && fixedE <= 64) return fixedE;
     const long long stiles = (C + TB_CM - 1) / TB_CM;
     long long want = (long long)h->num_cu * 4 * waves / stiles;
     if (want < 1) want = 1;
     long long E = (T + want - 1) / want;
     if (E < 16) E = 16;
-    if (E > 32) E = 32;  // the chunk's rows live in LDS: 32 steps x 160 reals (pass C at d = 4, po = 4, fp64) = 40 KB per workgroup
+    if (E > 32) E = 32;
+    // measured at T = 65536, d = 4, fp64 once pass C stopped walking the innovations (rows of 88 / 84 / 68 reals: 64 steps = 45 KB of LDS at most): 64 chains 16 (81k
+    // sweeps/s; 32: 76k), 96 chains 32 (100k; 16: 96k), 128 chains 32 (125k; 16: 118k), 256 chains 32 or 64 (175k; 24: 172k), 1024 chains 64 (228k; 32: 220k)
+    if (C >= 1024) E = 64;
+    else if (C >= 96) E = 32;
+    if (E > T) E = T > 2 ? T : 2;
     return (int)E;
 }
 template <typename R, int D, int PO> size_t fused_ws(const auxssm_ctx* h, const KDims& d) {
