@@ -237,4 +237,5 @@ def test_c_abi_default_is_the_single_stream_sweep():
         assert lib.auxssm_get_option(h, _lib.OPT_OVERLAP_MODEL_STAGE, ctypes.byref(v)) == 0 and v.value == 0
     finally:
         lib.auxssm_destroy(h)
-    assert _lib.Handle().get_option(_lib.OPT_OVERLAP_MODEL_STAGE) == 1
+    import os
+    assert _lib.Handle().get_option(_lib.OPT_OVERLAP_MODEL_STAGE) == (0 if os.environ.get("AUXSSM_OVERLAP_TAB") == "0" else 1)  # (the measurement switch keeps it off)
