@@ -665,7 +665,8 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     f.fa.t0_keep_ps = 1;
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((C + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.fa);
     using F = FsRows<R, D, PO>;
-    const int TBF = C >= 256 ? 256 : (C + 63) / 64 * 64;
+    static const int tbf_env = getenv("AUXSSM_FS_TBF") ? atoi(getenv("AUXSSM_FS_TBF")) : 0;
+    const int TBF = (tbf_env == 64 || tbf_env == 128 || tbf_env == 256) && C >= tbf_env ? tbf_env : (C >= 256 ? 256 : (C + 63) / 64 * 64);
     const unsigned grid = (unsigned)a.nchunk * (unsigned)((C + TBF - 1) / TBF);
     const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
     {
