@@ -223,6 +223,20 @@ template <typename R, int N> __device__ __forceinline__ void fs_stage(const R* _
     __syncthreads();
 }
 
+// the tables of the fp64 normal transform (rng.h) in the workgroup's LDS, behind the pass's coefficient rows; the barrier of fs_stage publishes them.
+// fp32 draws use the hardware functions: no table, no LDS.
+template <typename R> struct FsNormTabSel { using type = NormTabGlobal; static constexpr size_t BYTES = 0; };
+template <> struct FsNormTabSel<double> { using type = NormTabLds; static constexpr size_t BYTES = (size_t)RNG_TAB_DOUBLES * sizeof(double); };
+template <typename R> using FsNormTab = typename FsNormTabSel<R>::type;
+template <typename R> __device__ __forceinline__ FsNormTab<R> fs_stage_normtab(R* behind_rows) {
+    if constexpr (sizeof(R) == 8) {
+        NormTabLds::stage((double*)behind_rows, false);
+        return NormTabLds{(const double*)behind_rows};
+    } else {
+        return NormTabGlobal{};
+    }
+}
+
 // the MH terms of one state v at time t = i + 1 given the state w at time t - 1 (v, w = x or x'), LogShared row i (`row`, in LDS) -- the per-state
 // half of body_sweep_logpdf_shared, same operations: [q-term (concatenated likelihood + prior), target term (likelihood + prior), |v - u|^2 / delta]
 template <typename R, int D, int PO>
@@ -279,6 +293,50 @@ __device__ __forceinline__ void fs_terms(const FusedArgs& a, const R* row, const
     out3[2] = qa * inv_delta;
 }
 
+// The same three sums with NO per-term policy: every residual kept, nothing tested.  Returns true when the lane's result is not finite -- a non-finite
+// residual, difference or row constant makes the sum of the three terms non-finite -- in which case fs_terms (the per-term NaN policy: masked rows are
+// zeros, a non-finite kept residual drops its term) has to redo the step; when everything is finite the two agree term by term.  The passes branch on the
+// WAVE's ballot of that flag: the policy's fourteen class tests, their boolean algebra and the selects on doubles were a tenth of pass A's instructions,
+// spent on a case (a NaN in the state or the data row) that almost no wave ever sees.
+template <typename R, int D, int PO>
+__device__ __forceinline__ bool fs_terms_fast(const R* row, const R* v, const R* w, const R* u, R inv_delta, R cst, R* out3) {
+    using TL = LogShared<R, D, PO>;
+    R qo = 0;
+#pragma unroll
+    for (int k = 0; k < PO; ++k) {
+        R z = row[TL::oYw + k];
+#pragma unroll
+        for (int j = 0; j < D; ++j) z -= row[TL::oWH + k * D + j] * v[j];
+        qo += z * z;
+    }
+    const R ob = (R)-0.5 * qo + row[TL::oCR];
+    asm volatile("" ::: "memory");  // (the blocks read disjoint parts of the row: keep their LDS reads apart)
+    R qa = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R d = u[k] - v[k];
+        qa += d * d;
+    }
+    const R ax = -qa * inv_delta + cst;
+    asm volatile("" ::: "memory");
+    R qp = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        R z = -row[TL::oWb + k];
+#pragma unroll
+        for (int l = 0; l <= k; ++l) z += row[TL::oWQ + lidx(k, l)] * v[l];
+#pragma unroll
+        for (int j = 0; j < D; ++j) z -= row[TL::oWF + k * D + j] * w[j];
+        qp += z * z;
+    }
+    const R pr = (R)-0.5 * qp + row[TL::oCQ];
+    out3[0] = (ax + ob) + pr;
+    out3[1] = ob + pr;
+    out3[2] = qa * inv_delta;
+    return !finite_(out3[0]);
+}
+__device__ __forceinline__ bool fs_wave_any(bool flag) { return __builtin_amdgcn_ballot_w64(flag) != 0; }
+
 // ---- pass A ---------------------------------------------------------------------------------------------------------------------------
 #ifndef AUXSSM_FS_WPE_A
 #define AUXSSM_FS_WPE_A 2
@@ -292,6 +350,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __at
     fs_block(a, ch, c);
     const long long C = a.C;
     const int ta = max(1, ch * a.E), tb = min(a.T, (ch + 1) * a.E);
+    const FsNormTab<R> ntab = fs_stage_normtab<R>(lds + (size_t)a.E * F::NA);
     fs_stage<R, F::NA>(rows, ta - 1, tb - 1, lds);
     if (c >= a.C) return;
     const R* xr = (const R*)((a.sel && a.sel[c]) ? (const void*)a.xb : a.xa) + c;
@@ -320,13 +379,27 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __at
 #pragma unroll
             for (int k = 0; k < D; ++k) xn[k] = xr[((long long)tn * D + k) * C];
         }
-        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + c, C, ev);
+        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + c, C, ev, ntab);
 #pragma unroll
         for (int k = 0; k < D; ++k) {
             u[k] = x[k] + shd * ev[k];
             up[((long long)tu * D + k) * C] = u[k];
         }
         asm volatile("" ::: "memory");
+        // the MH terms of the current state; the rare wave with a non-finite value anywhere redoes them under the per-term policy and masks u for the fold
+        R w[3], um[D];
+        const bool bad = fs_terms_fast<R, D, PO>(row + F::aL, x, xq, u, inv_delta, cst, w);
+#pragma unroll
+        for (int k = 0; k < D; ++k) um[k] = u[k];
+        if (fs_wave_any(bad)) {
+            fs_terms<R, D, PO>(a, row + F::aL, x, xq, u, inv_delta, cst, w);
+#pragma unroll
+            for (int k = 0; k < D; ++k) um[k] = finite_(u[k]) ? u[k] : (R)0;
+        }
+        v0 += (Acc)w[0];
+        v1 += (Acc)w[1];
+        v2 += (Acc)w[2];
+        asm volatile("" ::: "memory");  // keep the fold's LDS reads behind the log-density row's: hoisted together they cost 200 registers
         {  // filter fold (FilterMeanOp::fold, folded rows): h <- Mb h + kc + K[:, :D] u
             R o[D];
 #pragma unroll
@@ -335,18 +408,12 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __at
 #pragma unroll
                 for (int k = 0; k < D; ++k) v += row[F::aM + r * D + k] * h[k];
 #pragma unroll
-                for (int k = 0; k < D; ++k) v += row[F::aK + r * D + k] * (finite_(u[k]) ? u[k] : (R)0);
+                for (int k = 0; k < D; ++k) v += row[F::aK + r * D + k] * um[k];
                 o[r] = v;
             }
 #pragma unroll
             for (int r = 0; r < D; ++r) h[r] = o[r];
         }
-        asm volatile("" ::: "memory");  // keep the log-density row's LDS reads behind the fold: hoisted together they cost 200 registers
-        R w[3];
-        fs_terms<R, D, PO>(a, row + F::aL, x, xq, u, inv_delta, cst, w);
-        v0 += (Acc)w[0];
-        v1 += (Acc)w[1];
-        v2 += (Acc)w[2];
 #pragma unroll
         for (int k = 0; k < D; ++k) xq[k] = x[k];
     }
@@ -367,6 +434,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
     fs_block(a, ch, c);
     const long long C = a.C;
     const int t0 = ch * a.E, ta = max(1, t0), tb = min(a.T, t0 + a.E);
+    const FsNormTab<R> ntab = fs_stage_normtab<R>(lds + (size_t)a.E * F::NC);
     fs_stage<R, F::NC>(rows, t0, tb, lds);
     if (c >= a.C) return;
     const R* up = (const R*)a.u + c;
@@ -425,11 +493,16 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
 #pragma unroll
             for (int k = 0; k < D; ++k) yn[k] = up[((long long)tn * D + k) * C];
         }
-        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + c, C, eps);
+        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + c, C, eps, ntab);
         {  // the affine step of the filtered mean (FilterMeanOp::walk_impl without its innovation / log-likelihood half; a missing auxiliary value counts as 0, as there)
             R o[D];
+            R ysum = y[0];
 #pragma unroll
-            for (int k = 0; k < D; ++k) y[k] = finite_(y[k]) ? y[k] : (R)0;
+            for (int k = 1; k < D; ++k) ysum += y[k];
+            if (fs_wave_any(!finite_(ysum))) {  // (rare: see fs_terms_fast)
+#pragma unroll
+                for (int k = 0; k < D; ++k) y[k] = finite_(y[k]) ? y[k] : (R)0;
+            }
 #pragma unroll
             for (int k = 0; k < D; ++k) {
                 R v = row[F::cKc + k];
@@ -500,7 +573,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
         }
         if (tu + 1 < a.T) {  // (wave-uniform) LogShared row tu: x'_{tu+1} = h given x'_tu = xp, observation and auxiliary terms at tu + 1
             R w[3];
-            fs_terms<R, D, PO>(a, row + F::eL, h, xp, uq, inv_delta, cst, w);
+            if (fs_wave_any(fs_terms_fast<R, D, PO>(row + F::eL, h, xp, uq, inv_delta, cst, w))) fs_terms<R, D, PO>(a, row + F::eL, h, xp, uq, inv_delta, cst, w);
             v0 += (Acc)w[0];
             v1 += (Acc)w[1];
             v2 += (Acc)w[2];
@@ -671,12 +744,12 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
     {
         ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-        hipLaunchKernelGGL((k_fs_a<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NA * sizeof(R), h->stream, a, (const R*)rows_a);
+        hipLaunchKernelGGL((k_fs_a<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NA * sizeof(R) + FsNormTabSel<R>::BYTES, h->stream, a, (const R*)rows_a);
         hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_f, a.pre_f}, (const R*)cprod_f, a.nchunk);
     }
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
-        hipLaunchKernelGGL((k_fs_c<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NC * sizeof(R), h->stream, a, (const R*)rows_c);
+        hipLaunchKernelGGL((k_fs_c<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NC * sizeof(R) + FsNormTabSel<R>::BYTES, h->stream, a, (const R*)rows_c);
         hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_s, a.pre_s}, (const R*)cprod_s, a.nchunk);
     }
     {

@@ -71,24 +71,129 @@ template <typename R> AX_HD void sincos_2pi(R u, R& c, R& s) {
 }
 
 // CONTRACT of the normal transform (restated in oracle/rng_np.py, to rounding): the BITS are pinned (Threefry-2x32-20, Random123 KATs; uniforms are
-// bit-exact against the oracle); the normals are pinned to a TOLERANCE -- fp64: det_log<true> + sqrt + sincos_2pi with explicit fma, within 1e-12 of
-// the oracle's libm / no-fma restatement; fp32 on the DEVICE: the hardware v_log_f32 / v_sqrt_f32 (1 ulp each), within 2e-5 relative / 2e-6 absolute
-// of the oracle (tests/test_rng.py), so device fp32 normals are reproducible on the device only: every bit-exact cSMC / PIT check that uses keyed
-// noise draws it on the device first (csmc/_device.py::key_noise) and hands the arrays to the oracle.
+// bit-exact against the oracle); the normals are pinned to a TOLERANCE -- fp64: the table-driven transform below, within 1e-12 (relative) / 1e-13
+// (absolute) of the oracle's libm restatement (its own error is ~1e-15); fp32 on the DEVICE: the hardware v_log_f32 / v_sqrt_f32 (1 ulp each), within
+// 2e-5 relative / 2e-6 absolute of the oracle (tests/test_rng.py), so device fp32 normals are reproducible on the device only: every bit-exact cSMC /
+// PIT check that uses keyed noise draws it on the device first (csmc/_device.py::key_noise) and hands the arrays to the oracle.
 // Box-Muller on one Threefry block (two 32-bit words) -> TWO normals (cos and sin branch).  Normal number `idx` of a stream
 // is branch (idx & 1) of the block with counter idx >> 1.  fp64: u = (b + 0.5) 2^-32 in (0,1), double math.  fp32:
 // u = ((b >> 8) + 0.5) 2^-24, float math throughout (the cSMC kernels draw N of these per time step).
+//
+// fp64 transform (round 4).  The chain-shared sweep draws four fp64 normals per chain and time step INSIDE its streaming passes, which are bound by
+// vector-instruction issue, not by HBM: the fdlibm-style log (a division + a degree-7 polynomial), the compiler's range-checked sqrt and the quadrant
+// split + two degree-6 polynomials of sincos cost ~108 instructions per Box-Muller pair next to the 72 of its Threefry block.  Both transcendental
+// arguments are 32-bit integers, so a small table does the range reduction and short polynomials the rest (~48 instructions, same accuracy):
+//   radius   u1 = m 2^e, m in [1/2, 1); F_j = (256 + j)/512 the nearest table point, t = (m - F_j)/F_j in [-2^-9, 2^-9];
+//            -2 ln u1 = e (-2 ln 2) + (-2 ln F_j) - 2 log1p(t), log1p by its degree-5 Taylor polynomial (next term 1e-17); near u1 = 1 (e = 0, j = 256)
+//            the first two terms vanish EXACTLY, so small radii keep their relative accuracy; sqrt by v_rsq_f64 + one Goldschmidt + one Newton step
+//            (the argument is in [4.6e-10, 46]: no range scaling);
+//   angle    b1 = 2^24 j + s with s in [-2^23, 2^23): (cos, sin)(2 pi (b1 + 1/2) 2^-32) = rotation of the table point (C_j, S_j) = (cos, sin)(2 pi j/256) by
+//            theta = (s + 1/2) 2 pi 2^-32, |theta| <= pi/256: degree-5 / degree-6 Taylor polynomials (next terms 1e-17 / 1e-20).
+// The tables (rng_tables.h, generated: tools/gen_rng_tables.py; 8 KB) are read through a TABLE PROVIDER: NormTabGlobal gathers from global memory (every kernel
+// that is not bound by its draws), NormTabLds from a copy the workgroup staged in LDS (the fused passes).  Same operations either way: same bits.
+#include "rng_tables.h"
+static const double RNG_LOG_TAB_HOST[2 * 257] = AX_RNG_LOG_TAB_INIT;
+static const double RNG_TURN_TAB_HOST[2 * 256] = AX_RNG_TURN_TAB_INIT;
+#if defined(__HIPCC__)
+static __device__ const double __attribute__((aligned(16))) RNG_LOG_TAB_DEV[2 * 257] = AX_RNG_LOG_TAB_INIT;
+static __device__ const double __attribute__((aligned(16))) RNG_TURN_TAB_DEV[2 * 256] = AX_RNG_TURN_TAB_INIT;
+#endif
+constexpr int RNG_TAB_DOUBLES = 2 * 257 + 2 * 256 + 2;  // log table, two doubles of padding (16-byte alignment of the turn table), turn table
+constexpr int RNG_TAB_TURN_OFF = 2 * 257 + 2;
+struct NormTabGlobal {
+    AX_HD void log_entry(int j, double& inv, double& L) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double2 e = reinterpret_cast<const double2*>(RNG_LOG_TAB_DEV)[j];
+        inv = e.x, L = e.y;
+#else
+        inv = RNG_LOG_TAB_HOST[2 * j], L = RNG_LOG_TAB_HOST[2 * j + 1];
+#endif
+    }
+    AX_HD void turn_entry(int j, double& c, double& s) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const double2 e = reinterpret_cast<const double2*>(RNG_TURN_TAB_DEV)[j];
+        c = e.x, s = e.y;
+#else
+        c = RNG_TURN_TAB_HOST[2 * j], s = RNG_TURN_TAB_HOST[2 * j + 1];
+#endif
+    }
+};
+#if defined(__HIPCC__)
+// the workgroup's LDS copy: RNG_TAB_DOUBLES doubles at a 16-byte aligned address, filled by stage() (ends with a barrier)
+struct NormTabLds {
+    const double* p;
+    __device__ __forceinline__ static void stage(double* lds, bool sync = true) {
+        for (int i = threadIdx.x; i < 257; i += blockDim.x) reinterpret_cast<double2*>(lds)[i] = reinterpret_cast<const double2*>(RNG_LOG_TAB_DEV)[i];
+        for (int i = threadIdx.x; i < 256; i += blockDim.x)
+            reinterpret_cast<double2*>(lds + RNG_TAB_TURN_OFF)[i] = reinterpret_cast<const double2*>(RNG_TURN_TAB_DEV)[i];
+        if (sync) __syncthreads();
+    }
+    __device__ __forceinline__ void log_entry(int j, double& inv, double& L) const {
+        const double2 e = reinterpret_cast<const double2*>(p)[j];
+        inv = e.x, L = e.y;
+    }
+    __device__ __forceinline__ void turn_entry(int j, double& c, double& s) const {
+        const double2 e = reinterpret_cast<const double2*>(p + RNG_TAB_TURN_OFF)[j];
+        c = e.x, s = e.y;
+    }
+};
+#endif
+// sqrt of x in [2^-40, 2^6]: no range scaling, no special cases (the compiler's sqrt carries both)
+AX_HD double sqrt_pos(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double e = fma(-h, g, 0.5);
+    g = fma(g, e, g);
+    h = fma(h, e, h);
+    const double d = fma(-g, g, x);
+    return fma(d, h, g);
+#else
+    return sqrt(x);
+#endif
+}
+template <typename TAB> AX_HD void bm_fp64(uint32_t b0, uint32_t b1, const TAB& tab, double& z0, double& z1) {
+    // radius: r = sqrt(-2 ln u1), u1 = (b0 + 1/2) 2^-32
+    const double v = (double)b0 + 0.5;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const double mant = __builtin_amdgcn_frexp_mant(v);
+    const int ex = __builtin_amdgcn_frexp_exp(v);
+#else
+    int ex;
+    const double mant = frexp(v, &ex);
+#endif
+    const double jd = rint(fma(mant, 512.0, -256.0));  // 0 .. 256
+    double inv, Lj;
+    tab.log_entry((int)jd, inv, Lj);
+    const double t = fma(jd, -0.001953125, mant - 0.5) * inv;  // (m - F_j) / F_j: the difference is exact
+    const double dk = (double)(ex - 32);
+    double p = fma(t, -0.4, 0.5);  // -2 log1p(t) = -2 t + t^2 (1 - 2/3 t + 1/2 t^2 - 2/5 t^3)
+    p = fma(p, t, -0.66666666666666663);
+    p = fma(p, t, 1.0);
+    double L = fma(dk, AX_RNG_NEG2LN2, Lj);
+    L = fma(t, -2.0, L);
+    L = fma(p, t * t, L);
+    const double r = sqrt_pos(L);
+    // angle
+    const int jj = (int)((b1 + 0x800000u) >> 24);  // nearest table point (sector 256 = sector 0: the sum wraps)
+    const int sl = (int)(b1 << 8) >> 8;            // b1 = 2^24 jj + sl (mod 2^32), sl in [-2^23, 2^23)
+    double C, S;
+    tab.turn_entry(jj, C, S);
+    const double th = fma((double)sl, AX_RNG_TURN_SCALE, 0.5 * AX_RNG_TURN_SCALE);
+    const double z = th * th;
+    const double sf = fma(th * z, fma(z, 8.3333333333333332e-3, -1.6666666666666666e-1), th);
+    double cf = fma(z, -1.3888888888888889e-3, 4.1666666666666664e-2);
+    cf = fma(cf, z, -0.5);
+    cf = fma(cf, z, 1.0);
+    z0 = r * fma(-S, sf, C * cf);
+    z1 = r * fma(C, sf, S * cf);
+}
 template <typename R> AX_HD void bits_to_normal2(uint32_t b0, uint32_t b1, R& z0, R& z1);
-template <> AX_HD void bits_to_normal2<double>(uint32_t b0, uint32_t b1, double& z0, double& z1) {
-    const double u1 = ((double)b0 + 0.5) * 2.3283064365386963e-10;
-    const double u2 = ((double)b1 + 0.5) * 2.3283064365386963e-10;
-    // det_log: the fdlibm-style sequence of det_math.h (about thirty fp64 operations; libm's log is about sixty on the device, and the
-    // chain-shared scans draw their noise inside memory-bound passes where every fp64 instruction shows).  1-2 ulp, as before.
-    const double r = sqrt(-2.0 * det_log<true>(u1));
-    double c, s;
-    sincos_2pi<double>(u2, c, s);
-    z0 = r * c;
-    z1 = r * s;
+template <> AX_HD void bits_to_normal2<double>(uint32_t b0, uint32_t b1, double& z0, double& z1) { bm_fp64(b0, b1, NormTabGlobal{}, z0, z1); }
+// the same through a table provider (fp32 draws use the hardware functions and no table)
+template <typename R, typename TAB> AX_HD void bits_to_normal2_t(uint32_t b0, uint32_t b1, const TAB& tab, R& z0, R& z1) {
+    if constexpr (sizeof(R) == 8) bm_fp64(b0, b1, tab, z0, z1);
+    else bits_to_normal2<R>(b0, b1, z0, z1);
 }
 template <> AX_HD void bits_to_normal2<float>(uint32_t b0, uint32_t b1, float& z0, float& z1) {
     const float u1 = ((float)(b0 >> 8) + 0.5f) * 5.9604644775390625e-8f;
@@ -134,11 +239,12 @@ template <typename R> AX_HD R stream_uniform(uint32_t k0, uint32_t k1, uint32_t 
     return bits_to_uniform<R>((idx & 1) ? x1 : x0);
 }
 // both numbers of block blk
-template <typename R> AX_HD void stream_normal2(uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long blk, R& z0, R& z1) {
+template <typename R, typename TAB = NormTabGlobal>
+AX_HD void stream_normal2(uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long blk, R& z0, R& z1, const TAB& tab = TAB{}) {
     uint32_t x0, x1;
     stream_counter(stream, blk, x0, x1);
     threefry2x32(k0, k1, x0, x1);
-    bits_to_normal2<R>(x0, x1, z0, z1);
+    bits_to_normal2_t<R>(x0, x1, tab, z0, z1);
 }
 template <typename R> AX_HD void stream_uniform2(uint32_t k0, uint32_t k1, uint32_t stream, unsigned long long blk, R& u0, R& u1) {
     uint32_t x0, x1;
@@ -161,23 +267,43 @@ __device__ __forceinline__ double swap_neighbour(double v) {
     return __hiloint2double(hi, lo);
 }
 #endif
-template <typename R, int D> AX_HD void normals_cm(uint32_t k0, uint32_t k1, long long base, long long stride, R* out) {
+// fp64: the odd lane turns its angle back by a quarter (b1 - 2^30: table point j - 64, whose entry is (S_j, -C_j) EXACTLY, rng_tables.h), so its transform returns
+// (r sin, -r cos) by the very operations that give the even lane (r cos, r sin): both parities keep the first output and send the second, and no value is selected
+// by parity before the exchange (selects on doubles are two instructions each, and indexing `out` by a lane-dependent component cost a compare-select chain per slot).
+template <typename R, int D, typename TAB = NormTabGlobal>
+AX_HD void normals_cm(uint32_t k0, uint32_t k1, long long base, long long stride, R* out, const TAB& tab = TAB{}) {
 #if defined(__HIP_DEVICE_COMPILE__)
     const bool odd = base & 1;
     const long long be = base - (odd ? 1 : 0);  // the even partner's index
+    const uint32_t quarter = odd ? 0x40000000u : 0u, sgn = odd ? 0x80000000u : 0u;
+    auto pair = [&](int kk, R& keep, R& send) {  // the lane's block: keep = its own normal, send = its partner's
+        uint32_t x0, x1;
+        stream_counter(0, (unsigned long long)((be + kk * stride) >> 1), x0, x1);
+        threefry2x32(k0, k1, x0, x1);
+        if constexpr (sizeof(R) == 8) {
+            double kp, sd;
+            bm_fp64(x0, x1 - quarter, tab, kp, sd);
+            keep = kp;
+            send = __hiloint2double(__double2hiint(sd) ^ (int)sgn, __double2loint(sd));
+        } else {
+            R z0, z1;
+            bits_to_normal2<R>(x0, x1, z0, z1);
+            keep = odd ? z1 : z0;
+            send = odd ? z0 : z1;
+        }
+    };
 #pragma unroll
     for (int k = 0; k + 1 < D; k += 2) {
-        const int kk = odd ? k + 1 : k;
-        R z0, z1;
-        stream_normal2<R>(k0, k1, 0, (unsigned long long)((be + kk * stride) >> 1), z0, z1);
-        const R recv = swap_neighbour(odd ? z0 : z1);
-        out[kk] = odd ? z1 : z0;
-        out[odd ? k : k + 1] = recv;
+        R keep, send;
+        pair(odd ? k + 1 : k, keep, send);
+        const R recv = swap_neighbour(send);
+        out[k] = odd ? recv : keep;
+        out[k + 1] = odd ? keep : recv;
     }
     if (D & 1) {
-        R z0, z1;
-        stream_normal2<R>(k0, k1, 0, (unsigned long long)((be + (D - 1) * stride) >> 1), z0, z1);
-        out[D - 1] = odd ? z1 : z0;
+        R keep, send;
+        pair(D - 1, keep, send);
+        out[D - 1] = keep;
     }
 #else
 #pragma unroll

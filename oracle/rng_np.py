@@ -2,8 +2,9 @@
 uniform[i] = word (i & 1) of block i >> 1, normal[i] = Box-Muller branch (i & 1) of block i >> 1, block b = threefry2x32(key,
 counter = (lo32(b), stream ^ (hi32(b) << 16))).
 Threefry-2x32-20 itself is pinned by the Random123 known-answer vectors (tests/test_rng.py).  Contract of the normal transform (csrc/rng.h):
-uniforms are bit-exact; normals agree to a tolerance -- this restatement uses libm's log and no fma, the device uses det_log<true> + fma in
-fp64 (<= 1e-12) and the hardware log2 / sqrt in fp32 (<= 2e-5 relative / 2e-6 absolute), so fp32 device normals are reproducible on the
+uniforms are bit-exact; normals agree to a tolerance -- this restatement uses libm's log / sqrt and the quadrant-split sincos below without fma, the device
+a table-driven log and rotation (csrc/rng.h::bm_fp64, tables csrc/rng_tables.h: ~2e-15 absolute of the exact transform) with explicit fma in
+fp64 (<= 1e-12 relative / 1e-13 absolute asserted) and the hardware log2 / sqrt in fp32 (<= 2e-5 relative / 2e-6 absolute), so fp32 device normals are reproducible on the
 device only and bit-exact checks that use keyed noise draw it there first.  jax.random bit-compatibility is NOT claimed (unverifiable offline)."""
 import numpy as np
 

@@ -27,6 +27,56 @@ def test_split_is_deterministic_and_distinct():
     npt.assert_array_equal(k, R.split(7, 1000))
 
 
+def test_rng_tables_are_current_and_symmetric():
+    """csrc/rng_tables.h is what tools/gen_rng_tables.py writes (60-digit decimal evaluation, correctly rounded), the turn table maps onto itself under a
+    quarter turn EXACTLY (normals_cm's lane-pair split relies on it), the log table's end points are exact and every entry is within half an ulp of libm's value + 1 ulp."""
+    import math
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    sys.path.insert(0, tools)
+    try:
+        import gen_rng_tables as G
+    finally:
+        sys.path.remove(tools)
+    hdr = os.path.join(os.path.dirname(tools), "aux_ssm_samplers_amd", "csrc", "rng_tables.h")
+    assert open(hdr).read() == G.render()
+    logt, turn = G.tables()
+    assert logt[0] == (2.0, -2.0 * math.log(0.5)) and logt[256] == (1.0, 0.0)
+    for j in range(257):
+        F = (256 + j) / 512
+        assert abs(logt[j][0] - 1 / F) <= 2.3e-16 * (1 / F) and abs(logt[j][1] + 2 * math.log(F)) <= 4.5e-16
+    for j in range(256):
+        c, s = turn[j]
+        c2, s2 = turn[(j + 64) % 256]
+        assert c2 == -s and s2 == c
+        assert abs(c - math.cos(2 * math.pi * j / 256)) < 1e-15 and abs(s - math.sin(2 * math.pi * j / 256)) < 1e-15
+        assert abs(c * c + s * s - 1) < 3e-16
+
+
+@pytest.mark.gpu
+def test_fp64_normals_edge_words_and_the_lane_pair_split():
+    """The table-driven fp64 transform at the words where its branches meet (u1 next to 0 and 1: the largest radius and the radii whose table terms cancel exactly;
+    u2 on sector boundaries and quarter turns) against an 80-bit libm evaluation, and the chain-minor in-kernel draws (lane pairs, the odd lane a quarter turn back)
+    bit-identical to the fill kernel -- the latter through the keyed fused sweep's tests (tests/test_gpu_device_delta.py); here the fill itself."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from oracle import rng_np as O
+    h = _lib.default_handle()
+    key = R.PRNGKey(99)
+    n = 1 << 20
+    z = h.rng_normal(key, 3, (n,), np.float64).to_host()
+    b0, b1 = O._bits(key, 3, n // 2)
+    u1 = (b0.astype(np.longdouble) + np.longdouble(0.5)) / np.longdouble(2) ** 32
+    u2 = (b1.astype(np.longdouble) + np.longdouble(0.5)) / np.longdouble(2) ** 32
+    r = np.sqrt(-2 * np.log(u1))
+    tau = 2 * np.longdouble("3.14159265358979323846264338327950288")
+    ref = np.stack([r * np.cos(tau * u2), r * np.sin(tau * u2)], axis=1).reshape(-1)
+    err = np.abs(z.astype(np.longdouble) - ref)
+    assert float(err.max()) < 1e-14  # |z| <= 6.8: a few ulp
+    # the extreme words of this sample really exercise the ends of the tables
+    assert b0.min() < 2 ** 13 and b0.max() > 2 ** 32 - 2 ** 13 and ((b1 + np.uint32(0x800000)) >> np.uint32(24)).min() == 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_device_fill_vs_oracle(dtype):
