@@ -1016,6 +1016,8 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     add(CT * D * sR);                                        // ms
     add(CT * D * D * sR);                                    // Ps
     add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + (size_t)5 * C * sizeof(Acc) + 4096);
+    const bool wide_carrier = wide && !second && C >= 2 && h->share_model;  // (below: the observation pattern said to the chain-shared wide filter)
+    if (wide_carrier) add((size_t)T * D * sR);
     add(wide ? wide_filter_ws(h, dtype, kd, parallel, D, D) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : std::max(ke->logpdf_ws(h, kd), se->sv_logpdf_ws(h, kd)));
@@ -1034,7 +1036,8 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     R* zero = (R*)ws_take(h, (size_t)D * sR);
     R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
     Acc* sums = (Acc*)ws_take(h, (size_t)5 * C * sizeof(Acc));
-    if (!u || !ys1 || !ys2 || !xp || !ms || !Ps || !eye || !Rc || !zero || !sc || !sums) return AUXSSM_ERR_NOMEM;
+    R* wide_mask = wide_carrier ? (R*)ws_take(h, (size_t)T * D * sR) : nullptr;
+    if (!u || !ys1 || !ys2 || !xp || !ms || !Ps || !eye || !Rc || !zero || !sc || !sums || (wide_carrier && !wide_mask)) return AUXSSM_ERR_NOMEM;
     R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
     const size_t mark = h->ws_off;
     const long long tot = (long long)CT * D;
@@ -1076,6 +1079,12 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         hipLaunchKernelGGL((k_scaled_eye<R>), dim3((D * D + 255) / 256), dim3(256), 0, h->stream, D, (R)1, eye);
         hipLaunchKernelGGL((k_fill<R>), dim3(1), dim3(256), 0, h->stream, (long long)D, (R)0, zero);
     }
+    // wide states, first order: the pseudo-observations u + delta/2 grad are finite by construction, so every chain observes every component -- said to the chain-shared
+    // wide filter with a carrier of zeros, which then needs no read-back of the observation patterns (no host synchronisation inside a sweep)
+    if (wide_carrier) {
+        mask_carrier = wide_mask;
+        hipLaunchKernelGGL((k_fill<R>), dim3((unsigned)(((long long)T * D + 255) / 256)), dim3(256), 0, h->stream, (long long)T * D, (R)0, mask_carrier);
+    }
     AX_HIP(hipGetLastError());
     // observation LGSSMs of the two linearisation points (H = I, c = 0; R = delta/2 I or the per-step diagonal Omega)
     auxssm_lgssm g1 = *model;
@@ -1108,7 +1117,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R1A;
-    if (overlap) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
+    if (overlap || wide_carrier) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
     rc = ke->filter(h, fa, parallel, ell1);
     if (rc) return rc;
     h->ws_off = mark;
@@ -1140,6 +1149,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         fa.tab = h->side.last_tab;
         fa.tab_ready = 1;
     }
+    if (wide_carrier) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
     rc = ke->filter(h, fa, parallel, ell2);
     if (rc) return rc;
     h->ws_off = mark;
@@ -1451,6 +1461,7 @@ int auxssm_destroy(auxssm_handle h) {
     auxssm_prof_disable(h);
     if (h->ws) (void)hipFree(h->ws);
     if (h->dblock) (void)hipFree(h->dblock);
+    if (h->cw_dev) (void)hipFree(h->cw_dev);
     if (h->side.streams[0]) {
         for (int p = 0; p < auxssm_ctx::SideStage::NS; ++p) {
             (void)hipStreamSynchronize(h->side.streams[p]);

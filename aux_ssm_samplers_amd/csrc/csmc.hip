@@ -550,7 +550,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
 }  // namespace ax
 
 namespace ax {
-int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a, void* dev_block);  // csmc_wide.hip
+int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a);  // csmc_wide.hip
 }
 using namespace ax;
 
@@ -803,11 +803,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         a.eps_prop = pe;
         a.u_res = pu;
     }
-    if (wide) {
-        void* blk = ws_take(h, ((size_t)3 * D * D + 4 * D + 8) * sR);
-        if (!blk) return AUXSSM_ERR_NOMEM;
-        return run_csmc_wide(h, dtype, fk, a, blk);
-    }
+    if (wide) return run_csmc_wide(h, dtype, fk, a);
 #define AX_CSMC_D(R)                                                        \
     switch (D) {                                                            \
         case 1: return run_csmc<R, 1>(h, fk, hm.data(), a, ctt);                 \

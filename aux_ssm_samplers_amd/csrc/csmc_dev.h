@@ -404,7 +404,9 @@ template <typename R, int NW = 0, bool PAD = false> __device__ __forceinline__ i
         // (ten dependent LDS latencies per search were the longest chain of the forward step)
         int ppos = 0;
         constexpr int S0 = NW * 32;
-        constexpr bool ODD = (NW == 8);  // 9 levels at N = 512: the first one alone
+        static_assert((S0 & (S0 - 1)) == 0, "the two-level descent needs a power-of-two particle count");
+        constexpr int LEVELS = 32 - __builtin_clz((unsigned)S0);  // steps S0, S0 / 2, ..., 1
+        constexpr bool ODD = (LEVELS & 1) != 0;  // an odd number of levels (9 at N = 512, 7 at N = 128): the first one alone, the rest in pairs
         if constexpr (ODD) ppos += c[ppos + (S0 - 1) + ((S0 - 1) >> 5)] < r ? S0 + (S0 >> 5) : 0;
 #pragma unroll
         for (int s = ODD ? S0 / 2 : S0; s >= 2; s >>= 2) {

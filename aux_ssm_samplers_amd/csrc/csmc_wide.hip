@@ -503,7 +503,7 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
 }
 
 // host: the model as one device block [m0 | LP0 | iLP0 | F | b | LQ | iLQ], constants as csmc_dev.h::fill_model computes them
-template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk, CsmcArgs& a, void* dev_block, R* host_block) {
+template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk, CsmcArgs& a, R* host_block) {
     const int D = fk->dx;
     FkW<R> m;
     memset(&m, 0, sizeof(m));
@@ -539,9 +539,27 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
         m.c_obs = -half_log_2pi;
     }
     const size_t nb = (size_t)(p - host_block) * sizeof(R);
-    AX_HIP(hipMemcpyAsync(dev_block, host_block, nb, hipMemcpyHostToDevice, h->stream));
-    AX_HIP(hipStreamSynchronize(h->stream));  // (the host block is the caller's stack vector)
-    const R* d = (const R*)dev_block;
+    {   // the handle's copy of the block: a new upload only when the content differs from the last one (a model that changes between sweeps pays one
+        // stream synchronisation -- earlier sweeps may still be reading the old block -- a fixed model none: include/auxssm.h, auxssm_csmc_sweep)
+        const int hdr[2] = {(int)sizeof(R), D};
+        const bool same = h->cw_dev && h->cw_host.size() == sizeof(hdr) + nb && memcmp(h->cw_host.data(), hdr, sizeof(hdr)) == 0 &&
+                          memcmp(h->cw_host.data() + sizeof(hdr), host_block, nb) == 0;
+        if (!same) {
+            AX_HIP(hipStreamSynchronize(h->stream));
+            if (h->cw_dev_bytes < nb) {
+                if (h->cw_dev) (void)hipFree(h->cw_dev);
+                h->cw_dev = nullptr, h->cw_dev_bytes = 0;
+                h->cw_host.clear();
+                AX_HIP(hipMalloc(&h->cw_dev, nb));
+                h->cw_dev_bytes = nb;
+            }
+            AX_HIP(hipMemcpy(h->cw_dev, host_block, nb, hipMemcpyHostToDevice));
+            h->cw_host.resize(sizeof(hdr) + nb);
+            memcpy(h->cw_host.data(), hdr, sizeof(hdr));
+            memcpy(h->cw_host.data() + sizeof(hdr), host_block, nb);
+        }
+    }
+    const R* d = (const R*)h->cw_dev;
     m.m0 = d; d += D;
     m.LP0 = d; d += D * D;
     m.iLP0 = d; d += D;
@@ -587,12 +605,12 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
     return AUXSSM_OK;
 }
 
-// called by auxssm_csmc_sweep (csmc.hip) for dx > CS_MAXD; dev_block / host_block hold 2 dx^2 + ... reals (csmc_wide_block_reals)
-int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a, void* dev_block) {
+// called by auxssm_csmc_sweep (csmc.hip) for dx > CS_MAXD
+int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a) {
     const int D = fk->dx;
     std::vector<double> host((size_t)3 * D * D + 4 * D + 8);
-    if (dtype == AUXSSM_F32) return run_cw<float>(h, fk, a, dev_block, (float*)host.data());
-    return run_cw<double>(h, fk, a, dev_block, host.data());
+    if (dtype == AUXSSM_F32) return run_cw<float>(h, fk, a, (float*)host.data());
+    return run_cw<double>(h, fk, a, host.data());
 }
 
 }  // namespace ax

@@ -58,6 +58,11 @@ struct auxssm_ctx {
     // filter): forked from `stream` by an event, joined back before the call returns -- never visible to the caller (lazily created)
     hipStream_t fork_stream = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // the wide-state cSMC's model block [m0 | chol P0 | 1/diag | F | b | chol Q | 1/diag] lives on the handle: uploaded (one blocking copy behind the stream's tail)
+    // only when its CONTENT changes, so a sampling loop with a fixed model never synchronises with the host
+    void* cw_dev = nullptr;
+    size_t cw_dev_bytes = 0;
+    std::vector<unsigned char> cw_host;  // {dtype, D, the block as uploaded}
     double* dblock = nullptr;  // {delta, sqrt(delta / 2)} of a sweep whose step size is device-resident (auxssm_kalman_sweep_dd); lazily allocated
     // The MODEL STAGE of a chain-shared sweep -- concatenated observation model, matrix filter on one sequence, gain table: ~0.4 ms of short dependent
     // launches that read the model and the step size only, never a chain -- runs on a second stream with its own double-buffered slab, so that the

@@ -430,24 +430,33 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
         using T = ObsInfoRow<R, D>;
         const UniformRow<R> row = uniform_row<R>((const R*)a.obs_tab + (long long)i * T::NPAD);
         const R inv_hd = (R)1 / ((R)arg_aux_shd(a) * (R)arg_aux_shd(a));
-        R u[D];
-        R q0 = row[T::oK];
 #pragma unroll
         for (int k = 0; k < D; ++k) {
-            u[k] = r.x[k] + (R)arg_aux_shd(a) * r.eps[k];
-            si.g0[k] = u[k] * inv_hd + row[T::oG + k];
-            q0 += u[k] * u[k] * inv_hd;
+            si.u[k] = r.x[k] + (R)arg_aux_shd(a) * r.eps[k];
+            si.g0[k] = row[T::oG + k];
         }
-        if constexpr (WRITE_U) wr<R, D>(a.aux_u, s / a.d.B, (long long)i + 1, s % a.d.B, u);
+        if constexpr (WRITE_U) wr<R, D>(a.aux_u, s / a.d.B, (long long)i + 1, s % a.d.B, si.u);
 #pragma unroll
         for (int k = 0; k < DS; ++k) si.Lam[k] = row[T::oL + k];
-#pragma unroll
-        for (int k = 0; k < D; ++k) si.Lam[sidx_u(D, k, k)] += inv_hd;
-        si.q0 = q0;
+        si.inv_hd = inv_hd;  // the auxiliary block stays apart: step_predict_solve evaluates it around the predicted mean (StepInfo)
+        si.q0 = row[T::oK];
         si.ldR = row[T::oLd];
         si.dim = row[T::oDim];
         si.ok = row[T::oOk] != (R)0;
     }
+    // (the down pass hands the log-likelihood back chunk by chunk: k_scan_down_cm)
+    static AX_HD void write_out(const Args& a, int s, int i, const Pre& p) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        wr<R, D>(a.ms, c, (long long)i + 1, b, p.b);
+        if (a.ps_packed) {
+            wr<R, symsize(D)>(a.Ps, c, (long long)i + 1, b, p.C);
+        } else {
+            R Pd[D * D];
+            symunpack<R, D>(p.C, Pd);
+            wr<R, D * D>(a.Ps, c, (long long)i + 1, b, Pd);
+        }
+    }
+    static AX_HD void write_zpart(const Args& a, int s, int ch, int nchunk, R z) { ((R*)a.ellz)[(long long)s * nchunk + ch] = z; }
     static AX_HD void fold(const Args& a, int s, int i, const Raw& r, Full& acc) {
         StepInfo<R, D> si;
         step_info(a, s, i, r, si);

@@ -713,9 +713,15 @@ AX_HD void filter_apply(const FiltPre<R, D>& p, const FiltElem<R, D>& a2, FiltPr
 // combine stays what the aggregate scan runs; this is the chunk-serial part of the scan (kernels.hip.h: k_scan_reduce_cm / k_scan_down_cm
 // of the on-the-fly operator).
 // ------------------------------------------------------------------------------------------------
+// The observation block (Lam, g0, q0) is in information form around the ORIGIN -- harmless for the real observations (|y|^2 / R is a moderate number) -- but the
+// auxiliary block y = u, H = I, R = hd I is kept apart and evaluated around the predicted mean: its information-form pieces |u|^2 / hd, u.m / hd and m.m / hd are
+// ~|x|^2 / hd each (3.7e7 at Lorenz-63 scale with delta = 1e-4) and cancel down to the innovation |u - m|^2 / hd ~ dim; formed separately in fp32 that cancellation
+// cost a bias of +0.024 per step in the log-likelihood (ell of C4's 16 384 steps off by +390, log alpha by ~20: round 4, tools/c4_fp32_diag.py).
 template <typename R, int D> struct StepInfo {
-    R Lam[symsize(D)];  // incl. the auxiliary block's I / hd
+    R Lam[symsize(D)];  // the observation block WITHOUT the auxiliary block's I / hd
     R g0[D];
+    R u[D];             // the auxiliary observation of the step (ignored when inv_hd == 0)
+    R inv_hd = 0;       // 1 / (delta / 2); 0: no auxiliary block (Lam, g0, q0 are the whole observation)
     R q0, ldR, dim;
     bool ok;
 };
@@ -756,15 +762,16 @@ AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInf
         R lm = 0;
 #pragma unroll
         for (int k = 0; k < D; ++k) lm += si.Lam[sidx(D, i, k)] * mb[k];
-        g[i] = si.g0[i] - lm;
-        q += mb[i] * (lm - (R)2 * si.g0[i]);
+        const R dm = si.u[i] - mb[i];  // the auxiliary block around the predicted mean (no cancellation of |u|^2 / hd against u.m / hd)
+        g[i] = (si.g0[i] - lm) + dm * si.inv_hd;
+        q += mb[i] * (lm - (R)2 * si.g0[i]) + dm * dm * si.inv_hd;
 #pragma unroll
         for (int j = 0; j < D; ++j) {
-            R s = (i == j) ? (R)1 : (R)0;
+            R s = ((i == j) ? (R)1 : (R)0) + si.inv_hd * Pp[i * D + j];
 #pragma unroll
             for (int k = 0; k < D; ++k) s += si.Lam[sidx(D, i, k)] * Pp[k * D + j];
             W[i * D + j] = s;
-            B[i * NR + j] = si.Lam[sidx(D, i, j)];
+            B[i * NR + j] = si.Lam[sidx(D, i, j)] + ((i == j) ? si.inv_hd : (R)0);
         }
         B[i * NR + D] = g[i];
     }

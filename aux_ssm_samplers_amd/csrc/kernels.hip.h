@@ -125,6 +125,38 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
 }
 
 
+// The reference's own second pass for the marginal log-likelihood (filtering.py:60-62): increment t from the filtered moments of t - 1 -- predict, then the
+// innovation's log-density around the PREDICTED mean.  fp64 runs read ell off the scan's log-scale instead (FiltElem::z: no pass); in fp32 that scale is the small
+// difference of element scales ~ -|y - H b|^2 / 2S around the dynamics offset (-2.6e5 per step at Lorenz-63 scale) and came back +-20 off over C4's 16 384 steps
+// (round 4, tools/c4_fp32_diag.py), so fp32 runs of the element path take this pass: one lane per step, tile sums in fp64, part[s * ntile + tile].
+template <typename R, int D, int P>
+__global__ void __launch_bounds__(TB_ELEM) k_ell_pass(FilterArgs a, R* __restrict__ part, int ntile) {
+    __shared__ Acc sh[TB_ELEM];
+    int tile, s;
+    decode_tile_seq(a.d.S(), tile, s);
+    if (tile >= ntile) return;
+    const int i = tile * TB_ELEM + threadIdx.x;
+    Acc v = 0;
+    if (i < a.d.n()) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)i + 1;
+        R m[D], Pd[D * D], F[D * D], bd[D], Q[D * D], H[P * D], cv[P], y[P], Rm[P * P];
+        rd<R, D>(a.ms, c, i, b, m);
+        rd_cov<R, D>(a.Ps, c, i, b, a.ps_packed, Pd);
+        rd<R, D * D>(a.Fs, c, i, b, F);
+        rd<R, D>(a.bs, c, i, b, bd);
+        rd<R, D * D>(a.Qs, c, i, b, Q);
+        rd<R, P * D>(a.Hs, c, t, b, H);
+        rd<R, P>(a.cs, c, t, b, cv);
+        rd<R, P>(a.ys, c, t, b, y);
+        rd_upper<R, P>(a.Rs, c, t, b, Rm);
+        kalman_predict<R, D>(m, Pd, F, bd, Q);
+        v = (Acc)kalman_update<R, D, P>(m, Pd, H, cv, Rm, y);
+    }
+    const Acc tot = block_sum<Acc, TB_ELEM>(v, sh);
+    if (threadIdx.x == 0) part[(long long)s * ntile + tile] = (R)tot;
+}
+
 // lanes over i = t - 1; the t = 0 terms are added by lane 0 of tile 0
 template <typename R, int D, int P>
 __global__ void __launch_bounds__(TB_ELEM) k_joint_logpdf(LogpdfArgs a, R* __restrict__ part, int ntile) {
@@ -172,16 +204,16 @@ __global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf(SweepLogpdfArgs a, Acc
 template <typename R>
 __global__ void __launch_bounds__(TB_ELEM) k_reduce_rows(const R* __restrict__ part, const R* __restrict__ add0,
                                                           int B, int ntile, R* __restrict__ out) {
-    __shared__ R sh[TB_ELEM];
+    __shared__ Acc sh[TB_ELEM];  // (summed in fp64 whatever R: the partial sums of an fp32 log-likelihood add up to ~1e5 at C4's size)
     const int c = blockIdx.x;
     const long long base = (long long)c * B * ntile;
     const long long tot_n = (long long)B * ntile;
-    R v = 0;
-    for (long long k = threadIdx.x; k < tot_n; k += TB_ELEM) v += part[base + k];
+    Acc v = 0;
+    for (long long k = threadIdx.x; k < tot_n; k += TB_ELEM) v += (Acc)part[base + k];
     if (add0)
-        for (int b = threadIdx.x; b < B; b += TB_ELEM) v += add0[(long long)c * B + b];
-    const R tot = block_sum<R, TB_ELEM>(v, sh);
-    if (threadIdx.x == 0) out[c] = tot;
+        for (int b = threadIdx.x; b < B; b += TB_ELEM) v += (Acc)add0[(long long)c * B + b];
+    const Acc tot = block_sum<Acc, TB_ELEM>(v, sh);
+    if (threadIdx.x == 0) out[c] = (R)tot;
 }
 
 template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample_init(SampleArgs a) {
@@ -501,6 +533,10 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
             Op::to_pre(id, p);
         }
     }
+    // Folding operators return the log-likelihood as per-chunk sums of the walk's own increments, NOT as the log-scale of the scanned prefix: a chunk aggregate
+    // is a quadratic form in the chunk's start state AROUND THE ORIGIN, its scale is ~ -|x|^2 J / 2 (-2e8 at Lorenz-63 scale with delta = 1e-5), and in fp32 the
+    // aggregate scan returned the total to +-ulp(2e8) = 16 per combine (round 4, tools/c4_accept_probe.py); the increments themselves are O(dim) each.
+    if constexpr (Op::kFold) p.z = 0;
     {
         using Raw = typename Op::Raw;
         Raw nxt;
@@ -520,6 +556,7 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
             Op::write_out(a, s, opaque_uniform(i), p);
         }
     }
+    if constexpr (Op::kFold) Op::write_zpart(a, s, ch, lay.nchunk, p.z);
 }
 
 // ---- generic chunked scan ---------------------------------------------------------------------------------------
@@ -901,7 +938,8 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     // (the time-minor layout is never smaller than the chain-minor one)
     b += (size_t)S * lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + 256;
     b += (size_t)S * sizeof(R) + 256;                           // ell0
-    b += (size_t)S * (std::max(ntiles(n), lay.nchunk) + 1) * sizeof(R) + 256;  // ell partials (per tile, or per chunk)
+    const int nchunk_cm = make_layout(plan_scan(h, S, n, parallel), 1, S).nchunk;
+    b += (size_t)S * (std::max(ntiles(n), std::max(lay.nchunk, nchunk_cm)) + 1) * sizeof(R) + 256;  // ell partials (per tile, or per chunk of either layout)
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
     // chain-shared parameters: the one-sequence matrix filter (elements, scan buffers, moments, mask carrier), the gain table and the
     // per-chain affine scan
@@ -1026,7 +1064,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
         if constexpr (P > D) {
             a.elem = nullptr;
             a.obs_tab = ws_take(h, (size_t)n * ObsInfoRow<R, D>::NPAD * sizeof(R));
-            a.ellz = ws_take(h, (size_t)S * sizeof(R));
+            a.ellz = ws_take(h, (size_t)S * a.lay.nchunk * sizeof(R));  // [sequence][chunk]: the down pass's per-chunk sums of the log-likelihood increments
             if (!a.obs_tab || !a.ellz) return AUXSSM_ERR_NOMEM;
             {
                 ProfScope ps(h, AUXSSM_K_FILTER_TAB);
@@ -1037,7 +1075,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
                 const int rc = run_scan<FilterOp<R, D>, FilterOpFly<R, D, P, false>, FilterOpFly<R, D, P, false>>(h, a, S, n);
                 if (rc) return rc;
             }
-            hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, 1, (R*)ell_out);
+            hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, a.lay.nchunk, (R*)ell_out);
             AX_HIP(hipGetLastError());
             return AUXSSM_OK;
         }
@@ -1059,6 +1097,15 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
             const int rc = run_scan<FilterOp<R, D>>(h, a, S, n);
             if (rc) return rc;
         }
+    }
+    if (sizeof(R) == 4 && !cm && n > 0 && !a.ps_packed) {  // fp32, time-minor element path: ell by the reference's second pass (k_ell_pass) instead of the scan's log-scale
+        const int ntl = ntiles(n);
+        R* part = (R*)ws_take(h, (size_t)S * ntl * sizeof(R));
+        if (!part) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_ell_pass<R, D, P>), dim3(grid_tile_seq(ntl, S)), dim3(TB_ELEM), 0, h->stream, a, part, ntl);
+        hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0, a.d.B, ntl, (R*)ell_out);
+        AX_HIP(hipGetLastError());
+        return AUXSSM_OK;
     }
     hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, n > 0 ? 1 : 0,
                        (R*)ell_out);

@@ -2407,27 +2407,35 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     R* ell0 = (R*)ws_take(h, (size_t)S * sizeof(R));
     R* ell_seq0 = (R*)ws_take(h, 256);
     if (!flag || !tab || !aggA || !aggG || !pre || !ellpart || !ell0 || !ell_seq0) return AUXSSM_ERR_NOMEM;
-    // the one decision that needs the data: do all sequences miss the same observations?  (4 bytes back to the host; the filter call is not inside a sweep loop)
-    AX_HIP(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
-    hipLaunchKernelGGL((wk_mask_check<R>), dim3(std::min<long long>(1024, ((long long)a.d.T * p + 255) / 256)), dim3(256), 0, h->stream, a, flag);
-    int differ = 0;
-    AX_HIP(hipMemcpyAsync(&differ, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    AX_HIP(hipStreamSynchronize(h->stream));
-    if (differ) {
-        h->ws_off = mark;
-        return 1;
+    // the one decision that needs the data: do all sequences miss the same observations?  4 bytes back to the host and one stream synchronisation -- for
+    // auxssm_kalman_filter only (documented there).  A SWEEP never takes it: its caller passes the pattern as a chain-independent carrier (mask_ys; the first-order
+    // SV factory's pseudo-observations are finite by construction), so the sweeps of a sampling loop stay asynchronous.
+    if (!a.mask_ys.ptr) {
+        AX_HIP(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+        hipLaunchKernelGGL((wk_mask_check<R>), dim3(std::min<long long>(1024, ((long long)a.d.T * p + 255) / 256)), dim3(256), 0, h->stream, a, flag);
+        int differ = 0;
+        AX_HIP(hipMemcpyAsync(&differ, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+        AX_HIP(hipStreamSynchronize(h->stream));
+        if (differ) {
+            h->ws_off = mark;
+            return 1;
+        }
     }
     FilterArgs fa = a;
     fa.ell0 = ell0;
-    {
-        ProfScope ps(h, AUXSSM_K_FILTER_INIT);
-        WK_LAUNCH((wk_filter_t0<R>), S, lds_filter_t0(sizeof(R), d, p), fa);  // every sequence's own t = 0 update: ms[., 0], Ps[., 0], its ell term
-    }
-    {   // the matrix filter: sequence 0 through the per-sequence path (its ms / Ps rows are final, its ell is recomputed below with the others')
+    {   // the matrix filter: sequence 0's slots through the per-sequence path, on sequence 0's observations or on the caller's pattern carrier (its Ps rows are
+        // final; its means and its ell are recomputed below with the others')
         FilterArgs a1 = a;
         a1.d = KDims{1, a.d.T, 1};
+        if (a.mask_ys.ptr) a1.ys = a.mask_ys;
+        a1.mask_ys = Arr{nullptr, 0, 0, 0, 1};
         const int rc = run_filter<R>(h, a1, 1, ell_seq0);
         if (rc) return rc;
+    }
+    {
+        ProfScope ps(h, AUXSSM_K_FILTER_INIT);
+        WK_LAUNCH((wk_filter_t0<R>), S, lds_filter_t0(sizeof(R), d, p), fa);  // every sequence's own t = 0 update: ms[., 0], Ps[., 0], its ell term (after the matrix
+                                                                                // filter, whose t = 0 mean on a carrier is not sequence 0's)
     }
     // the other sequences' covariance slots are copies of sequence 0's: pure memory traffic that only needs the matrix filter -- on the fork stream,
     // beside the gain table (matrix cores / latency) and the one-workgroup pass over the chunk composites

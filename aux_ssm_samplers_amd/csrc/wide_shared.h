@@ -129,7 +129,10 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_gain_tab(FilterAr
     img_fetch(rQ, at<R>(a.Qs, 0, i, 0), d * d, tid);
     img_fetch(rR, at<R>(a.Rs, 0, t, 0), p * p, tid);
     const R vb_ = tid < d ? at<R>(a.bs, 0, i, 0)[tid] : (R)0;
-    const R vy_ = tid < p ? at<R>(a.ys, 0, t, 0)[(long long)tid * a.ys.se] : (R)0;
+    // the observation pattern the row is built for: sequence 0's, or the caller's chain-independent carrier (FilterArgs::mask_ys: a sweep whose pseudo-observations
+    // are finite by construction vouches for the pattern, and one diverged chain must not delete rows of everybody's gains)
+    const Arr& my = a.mask_ys.ptr ? a.mask_ys : a.ys;
+    const R vy_ = tid < p ? at<R>(my, 0, t, 0)[(long long)tid * my.se] : (R)0;
     const R vc_ = tid < p ? at<R>(a.cs, 0, t, 0)[tid] : (R)0;
     if (tid == 0) *o.cnt = 0;
     __syncthreads();

@@ -117,8 +117,8 @@ class DeviceChains:
         if self.dx > 4 and chain_minor is None:
             self.chain_minor = False  # dx > 4 runs the wide-state kernels (csrc/wide.hip): a workgroup per time step, dense layout
         self.layout = _lib.LAYOUT_CHAIN_MINOR if self.chain_minor else _lib.LAYOUT_DENSE
-        self.x = handle.to_device(self._to_layout(x), dtype or x.dtype)
-        self.dtype = self.x.dtype
+        self._x = handle.to_device(self._to_layout(x), dtype or x.dtype)
+        self.dtype = self._x.dtype
         self.accepted = handle.zeros((self.C,), np.int32)
         self.logs = handle.zeros((self.C, 5), self.dtype)
         # per-sweep noise, allocated once: no hipMalloc / hipFree (and no stream sync) inside the sweep loop
@@ -135,20 +135,28 @@ class DeviceChains:
     @property
     def eps_aux(self):
         if self._eps_aux is None:
-            self._eps_aux = self.handle.empty(self.x.shape, self.dtype)
+            self._eps_aux = self.handle.empty(self._x.shape, self.dtype)
         return self._eps_aux
 
     @property
     def eps_samp(self):
         if self._eps_samp is None:
-            self._eps_samp = self.handle.empty(self.x.shape, self.dtype)
+            self._eps_samp = self.handle.empty(self._x.shape, self.dtype)
         return self._eps_samp
+
+    @property
+    def x(self):
+        """the resident state as ONE DeviceArray.  After a fused sweep the chains with sel[c] != 0 live in x_alt: reading `x` gathers them first (resolve), so
+        `chains.x.to_host()`, `chains.x.copy_from_host(...)` or handing `chains.x.ptr` to another auxssm_* call never sees stale rows.  The
+        fused sweep itself works on the private pair (_x, x_alt) and does not come through here."""
+        self.resolve()
+        return self._x
 
     def resolve(self):
         """gather the lazy state into x (auxssm_kalman_state_resolve): before anything but a fused sweep reads x"""
         if self.sel is not None and self._lazy_dirty:
             dims = _lib.Dims(self.C, self.T, 1, self.dx, 0)
-            _lib.check(self.handle.lib.auxssm_kalman_state_resolve(self.handle.h, _lib.dtype_code(self.dtype), C.byref(dims), self.x.ptr, self.x_alt.ptr, self.sel.ptr))
+            _lib.check(self.handle.lib.auxssm_kalman_state_resolve(self.handle.h, _lib.dtype_code(self.dtype), C.byref(dims), self._x.ptr, self.x_alt.ptr, self.sel.ptr))
             self._lazy_dirty = False
 
     _lazy_dirty = False
@@ -188,13 +196,13 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
             # pass, no noise buffers).  The library refuses -- before enqueueing anything -- what it cannot run fused; keyed sweeps from then on.
             if chains.fused is not False and eps_aux is None and model.kmodel == _lib.KMODEL_LG_CONCAT and chains.chain_minor:
                 if chains.x_alt is None:
-                    chains.x_alt = handle.empty(chains.x.shape, chains.dtype)
+                    chains.x_alt = handle.empty(chains._x.shape, chains.dtype)
                     chains.sel = handle.zeros((chains.C,), np.int32)
                 rc = handle.lib.auxssm_kalman_sweep_fused(
                     handle.h, _lib.dtype_code(chains.dtype), model.kmodel, C.byref(dims), C.byref(dl.c), C.byref(yarr),
-                    1.0 if dev else float(delta), delta.ptr if dev else None, k6, int(bool(parallel)), pol, chains.layout, chains.x.ptr,
+                    1.0 if dev else float(delta), delta.ptr if dev else None, k6, int(bool(parallel)), pol, chains.layout, chains._x.ptr,
                     chains.x_alt.ptr, chains.sel.ptr, u_acc.ptr, chains.accepted.ptr, chains.logs.ptr)
-                if rc == _lib.ERR_UNSUPPORTED:  # (nothing was enqueued) e.g. AUXSSM_OPT_SHARE_MODEL switched off, moments attached, odd chain count
+                if rc == _lib.ERR_UNSUPPORTED:  # (nothing was enqueued) e.g. AUXSSM_OPT_SHARE_MODEL switched off, odd chain count, per-chain model
                     chains.resolve()
                     if chains.fused is None:    # never ran fused: stop trying, drop the partner buffer
                         chains.fused = False

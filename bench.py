@@ -107,7 +107,7 @@ def resolve_launch(args, argv, environ):
 # workloads
 # ------------------------------------------------------------------------------------------------------------------------
 def build_model(T, d, dtype):
-    from tests.helpers import lg_model
+    from aux_ssm_samplers_amd.workloads import lg_model
     from aux_ssm_samplers_amd.kalman import LGConcatModel
     m = lg_model(T, d, dtype=dtype)
     bt = np.broadcast_to
@@ -480,7 +480,7 @@ def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
 def leg_c4(ctx, total_chains=64, T=16384, N=512, steps=20, warmup=3):
     """BASELINE configs[3] = C4: Lorenz-63 T=16384, aux-Kalman sweep (extended linearisation on device) and cSMC N=512, a FIXED total of
     `total_chains` chains sharded over the ranks (parallel.shard_chains: 64 -> 8 per GPU on 8 GPUs): strong scaling."""
-    from tests.helpers import lorenz_kalman_setup, lorenz_setup
+    from aux_ssm_samplers_amd.workloads import lorenz_kalman_setup, lorenz_setup
     from aux_ssm_samplers_amd import random as R
     from aux_ssm_samplers_amd.parallel import shard_chains, chain_key
     from aux_ssm_samplers_amd.kalman import get_kernel
@@ -548,7 +548,7 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
     """BASELINE configs[4] = C5: dense d = p = 64, T = 8192, fp32 -- the wide-state filter (MFMA d x d combine), one sequence (latency) and
     16 sequences per launch (throughput), resident in HBM.  Roofline = MFMA: SURVEY 8(d)'s K3 flops 2 n 19.3 d^3 per scan / scan time."""
     import ctypes as C
-    from tests.helpers import c5_model
+    from aux_ssm_samplers_amd.workloads import c5_model
     from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
     _lib, handle = ctx.lib, ctx.handle
     u, lg64, x = c5_model(T, d)
@@ -621,7 +621,7 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
 def cpu_baseline_c2(T, d, budget_s=12.0):
     """oracle/kalman_seq.c (the reference's sequential sweep, its CPU code path) on this box's host cores: all cores and one thread."""
     from oracle import kalman_seq as S
-    from tests.helpers import lg_model
+    from aux_ssm_samplers_amd.workloads import lg_model
     m = lg_model(T, d)
     cm = S.Model(m["m0"], m["P0"], m["F"], m["Q"], m["b"], m["Hobs"], m["Robs"], m["cobs"], m["y"])
     ncore = os.cpu_count() or 1

@@ -229,7 +229,9 @@ int auxssm_kalman_sweep_keyed(auxssm_handle h, int dtype, int model_kind, const 
  *                 writes the proposal to the other buffer and acceptance flips sel[c]: no select pass.  auxssm_kalman_state_resolve gathers the
  *                 state into x (and zeroes sel) before anything else reads x.
  * Returns AUXSSM_ERR_UNSUPPORTED -- before enqueueing anything -- when the sweep cannot run fused (other model kinds, dense layout, per-chain
- * parameters, odd chain count, T < 64, parallel == 0, running moments attached): the caller then runs auxssm_kalman_sweep_keyed. */
+ * parameters, AUXSSM_OPT_SHARE_MODEL off, odd chain count, T < 64, parallel == 0, dx > 4 or dy outside 1..4): the caller then runs
+ * auxssm_kalman_sweep_keyed.  Running moments (auxssm_stats_attach) are NOT a refusal: attached to `x` they are folded by the sweep (one extra pass over
+ * the buffer pair; a rejected chain folds a zero jump and its unchanged state), attached to any other state the call returns AUXSSM_ERR_ARG. */
 int auxssm_kalman_sweep_fused(auxssm_handle h, int dtype, int model_kind, const auxssm_dims* dims, const auxssm_lgssm* model,
                               const auxssm_arr* yobs, double delta, const void* delta_dev, const uint32_t* keys, int parallel, int nan_policy,
                               int layout, void* x, void* x_alt, int32_t* sel, void* u_acc, int32_t* accepted, void* logs);

@@ -152,6 +152,20 @@ def lorenz_logpdf(lg, yobs, x, xp, u, par, delta, nan_policy=0, chain_minor=Fals
     return out
 
 
+def fold_aux(dtype, F, Q, bd, Lobs, gobs, qobs, u, inv_hd, ldR, dim, b0, C0):
+    """log-likelihood increment of one information-form step with the auxiliary block folded in around the origin / kept apart (hostsim.cpp::fold_aux_T):
+    returns (zinc_folded, zinc_apart, max |db'|, max |dC'|) in `dtype` arithmetic"""
+    d = len(bd)
+    a = [np.ascontiguousarray(v, np.float64) for v in (F, Q, bd, Lobs, gobs, u, b0, C0)]
+    P = C.POINTER(C.c_double)
+    out = np.zeros(4)
+    rc = lib().hs_fold_aux(C.c_int(1 if np.dtype(dtype) == np.float32 else 0), C.c_int(d), a[0].ctypes.data_as(P), a[1].ctypes.data_as(P), a[2].ctypes.data_as(P),
+                           a[3].ctypes.data_as(P), a[4].ctypes.data_as(P), C.c_double(qobs), a[5].ctypes.data_as(P), C.c_double(inv_hd), C.c_double(ldR),
+                           C.c_double(dim), a[6].ctypes.data_as(P), a[7].ctypes.data_as(P), out.ctypes.data_as(P))
+    assert rc == 0, rc
+    return tuple(out)
+
+
 def fold_check(F, Q, bd, Lam, g0, q0, ldR, dim, acc):
     """max |prefix (+) element(step) - fold(prefix, step)| over all fields (kalman_math.h::filter_fold_step / filter_apply_step vs
     filter_elem_from_lam + filter_combine); Lam packed upper-symmetric, acc = [A | b | C packed | eta | J packed | z]"""

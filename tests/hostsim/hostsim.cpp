@@ -298,7 +298,8 @@ template <int D> static double fold_check_T(const double* F, const double* Q, co
     filter_combine<double, D>(acc, e2, o);
     StepInfo<double, D> si;
     for (int i = 0; i < DS; ++i) si.Lam[i] = Lam[i];
-    for (int i = 0; i < D; ++i) si.g0[i] = g0[i];
+    for (int i = 0; i < D; ++i) si.g0[i] = g0[i], si.u[i] = 0;
+    si.inv_hd = 0;  // (no separate auxiliary block: Lam / g0 / q0 are the whole observation)
     si.q0 = q0, si.ldR = ldR, si.dim = dim, si.ok = true;
     f = acc;
     filter_fold_step<double, D>(F, Q, bd, si, f);
@@ -317,7 +318,55 @@ template <int D> static double fold_check_T(const double* F, const double* Q, co
     return m;
 }
 
+// the log-likelihood increment of one step (filter_apply_step on a prefix with z = 0) with the auxiliary block y = u, H = I, R = hd I given (a) folded into the
+// information form around the origin (Lam + I / hd, g0 + u / hd, q0 + |u|^2 / hd; inv_hd = 0: how the general path formed it up to round 3) and (b) apart
+// (StepInfo::u / inv_hd: evaluated around the predicted mean), in precision R.  out = {zinc (a), zinc (b), max |b' (a) - b' (b)|, max |C' (a) - C' (b)|}
+template <typename R, int D> static void fold_aux_T(const double* F, const double* Q, const double* bd, const double* Lobs, const double* gobs, double qobs,
+                                                    const double* u, double inv_hd, double ldR, double dim, const double* b0, const double* C0, double* out) {
+    constexpr int DS = symsize(D);
+    R Ff[D * D], Qf[D * D], bdf[D];
+    for (int i = 0; i < D * D; ++i) Ff[i] = (R)F[i], Qf[i] = (R)Q[i];
+    for (int i = 0; i < D; ++i) bdf[i] = (R)bd[i];
+    StepInfo<R, D> sa, sb;
+    double q0 = qobs;
+    for (int i = 0; i < DS; ++i) sa.Lam[i] = sb.Lam[i] = (R)Lobs[i];
+    for (int i = 0; i < D; ++i) {
+        sa.Lam[sidx_u(D, i, i)] = (R)((double)sa.Lam[sidx_u(D, i, i)] + inv_hd);
+        sa.g0[i] = (R)(gobs[i] + u[i] * inv_hd);
+        sa.u[i] = 0;
+        q0 += u[i] * u[i] * inv_hd;
+        sb.g0[i] = (R)gobs[i];
+        sb.u[i] = (R)u[i];
+    }
+    sa.inv_hd = 0, sa.q0 = (R)q0;
+    sb.inv_hd = (R)inv_hd, sb.q0 = (R)qobs;
+    sa.ldR = sb.ldR = (R)ldR, sa.dim = sb.dim = (R)dim, sa.ok = sb.ok = true;
+    FiltPre<R, D> pa, pb;
+    for (int i = 0; i < D; ++i) pa.b[i] = pb.b[i] = (R)b0[i];
+    for (int i = 0; i < DS; ++i) pa.C[i] = pb.C[i] = (R)C0[i];
+    pa.z = pb.z = 0;
+    filter_apply_step<R, D>(Ff, Qf, bdf, sa, pa);
+    filter_apply_step<R, D>(Ff, Qf, bdf, sb, pb);
+    out[0] = (double)pa.z, out[1] = (double)pb.z, out[2] = 0, out[3] = 0;
+    for (int i = 0; i < D; ++i) out[2] = std::max(out[2], std::abs((double)pa.b[i] - (double)pb.b[i]));
+    for (int i = 0; i < DS; ++i) out[3] = std::max(out[3], std::abs((double)pa.C[i] - (double)pb.C[i]));
+}
+
 extern "C" {
+
+int hs_fold_aux(int f32, int D, const double* F, const double* Q, const double* bd, const double* Lobs, const double* gobs, double qobs, const double* u,
+                double inv_hd, double ldR, double dim, const double* b0, const double* C0, double* out) {
+#define HS_FA(RR)                                                                                              \
+    switch (D) {                                                                                               \
+        case 1: fold_aux_T<RR, 1>(F, Q, bd, Lobs, gobs, qobs, u, inv_hd, ldR, dim, b0, C0, out); return 0;      \
+        case 2: fold_aux_T<RR, 2>(F, Q, bd, Lobs, gobs, qobs, u, inv_hd, ldR, dim, b0, C0, out); return 0;      \
+        case 3: fold_aux_T<RR, 3>(F, Q, bd, Lobs, gobs, qobs, u, inv_hd, ldR, dim, b0, C0, out); return 0;      \
+        case 4: fold_aux_T<RR, 4>(F, Q, bd, Lobs, gobs, qobs, u, inv_hd, ldR, dim, b0, C0, out); return 0;      \
+    }
+    if (f32) { HS_FA(float) } else { HS_FA(double) }
+#undef HS_FA
+    return -1;
+}
 
 double hs_fold_check(int D, const double* F, const double* Q, const double* bd, const double* Lam, const double* g0, double q0, double ldR, double dim,
                      const double* acc) {

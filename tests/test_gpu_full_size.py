@@ -1,0 +1,134 @@
+"""Full-size property tests of the cSMC and Lorenz legs `bench.py` times: BASELINE configs C3 (T = 65536, N = 1024, fp32) and C4
+(T = 16384, fp32) are far beyond what a CPU oracle finishes in seconds, so at these sizes the checks are size-independent properties of the path:
+
+C3  particle 0 of every step IS the conditioning trajectory and `A_t[0] == 0` (`csmc.py:76,92`, `resamplings.py:36`); a chain-batched sweep is the one-launch
+    sweep bit for bit; the in-kernel Threefry draws are the fill kernels' values (the keyed sweep equals the explicit-noise sweep on `key_noise`'s arrays: same
+    trajectory, same backward indices, same particle system on a strided sample of steps).
+C4  the fp32 auxiliary Kalman sweep of the Lorenz model against the fp64 device sweep on the SAME explicit noise, sweep by sweep from the same state: the MH
+    decisions agree and log alpha agrees to a stated tolerance -- so the acceptance rate `bench.py` prints at its fixed step size (0.078 at delta = 1e-4 in round 3)
+    is the sampler's, not fp32 drift over 16384 steps with 79 of 80 observation rows missing; the step-size scan (`tools/c4_accept_probe.py`) shows the usual
+    monotone acceptance-vs-delta curve of a whole-path Metropolis move, the same in both precisions."""
+import numpy as np
+import numpy.testing as npt
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+Q_SV = 2.0 / (1.0 - 0.9 ** 2)
+
+
+def _c3(T, seed=0):
+    from aux_ssm_samplers_amd.csmc import _device, GaussianInit, LinearGaussianDynamics, SVPotential
+    from aux_ssm_samplers_amd.workloads import sv_setup
+    y, xtrue, _ = sv_setup(T, 1, seed=seed)
+    M0, Mt = GaussianInit(m0=[0.0], P0=[[Q_SV]]), LinearGaussianDynamics(F=[[0.9]], b=[0.0], Q=[[Q_SV]])
+    fk = _device.describe_independent(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), Mt)
+    return fk, xtrue.astype(np.float32)
+
+
+def test_c3_full_size_particle_zero_and_ancestor_zero():
+    from aux_ssm_samplers_amd.csmc import _device
+    T, N, C = 65536, 1024, 2
+    fk, xtrue = _c3(T)
+    rng = np.random.default_rng(3)
+    x0 = (xtrue[None] + 0.3 * rng.standard_normal((C, T, 1))).astype(np.float32)
+    x, anc, hist = _device.sweep(fk, x0, N, False, key=2024, delta=0.5, want_history=True)
+    assert hist["xs"].shape == (C, T, N, 1) and hist["As"].shape == (C, T - 1, N)
+    npt.assert_array_equal(hist["xs"][:, :, 0, :], x0)            # particle 0 = the conditioning path at every step of every chain
+    assert not hist["As"][:, :, 0].any()                           # A_t[0] == 0
+    assert hist["As"].min() >= 0 and hist["As"].max() < N
+    assert np.isfinite(hist["log_ws"]).all()
+    # the returned trajectory is a path through the particle system: x[t] = xs[t, B_t], and consecutive backward indices are linked by the ancestors
+    c = 1
+    t = np.arange(T)
+    npt.assert_array_equal(x[c, :, 0], hist["xs"][c, t, anc[c], 0])
+    npt.assert_array_equal(anc[c, :-1], hist["As"][c, t[:-1], anc[c, 1:]])
+    assert (anc != 0).mean() > 0.5                                 # ... and it moved: most steps left the conditioning path
+
+
+@pytest.mark.parametrize("backward", [True, False])
+def test_c3_full_size_chain_batched_equals_one_launch(backward, monkeypatch):
+    from aux_ssm_samplers_amd.csmc import _device
+    T, N, C = 65536, 1024, 3
+    fk, xtrue = _c3(T, seed=1)
+    x0 = (xtrue[None] + 0.3 * np.random.default_rng(5).standard_normal((C, T, 1))).astype(np.float32)
+    monkeypatch.delenv("AUXSSM_CSMC_BATCH", raising=False)
+    xa, anca, _ = _device.sweep(fk, x0, N, backward, key=77, delta=0.5)
+    monkeypatch.setenv("AUXSSM_CSMC_BATCH", "2")
+    xb, ancb, _ = _device.sweep(fk, x0, N, backward, key=77, delta=0.5)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    assert len({xa[c].tobytes() for c in range(C)}) == C
+
+
+def test_c3_full_size_threefry_equals_explicit_noise():
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.csmc import _device
+    T, N = 65536, 1024
+    fk, xtrue = _c3(T, seed=2)
+    x0 = (xtrue + 0.3 * np.random.default_rng(6).standard_normal((T, 1))).astype(np.float32)
+    key = R.PRNGKey(31337)
+    xa, anca, ha = _device.sweep(fk, x0, N, True, key=key, delta=0.5, want_history=True)
+    noise = _device.key_noise(_lib.default_handle(), key, 1, T, N, 1, np.float32)
+    xb, ancb, hb = _device.sweep(fk, x0, N, True, noise=noise, delta=0.5, want_history=True)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    for t in list(range(0, T, 997)) + [T - 2, T - 1]:              # the particle system itself on a strided sample of steps
+        npt.assert_array_equal(ha["xs"][t], hb["xs"][t])
+        npt.assert_array_equal(ha["log_ws"][t], hb["log_ws"][t])
+    del ha, hb
+
+
+@pytest.mark.parametrize("nan_policy", ["reference", "masked"])
+def test_c4_full_size_fp32_sweep_tracks_the_fp64_sweep(nan_policy):
+    """bench.py's C4 Kalman leg at its own size and step size (T = 16384, dt = 1.25e-4, one observation row in 80, delta = 1e-4), 8 chains (time-minor layout) and 64
+    chains (chain-minor), a few sweeps: the fp32 state is reset to the fp64 chain's before each sweep and both run on the same explicit noise.
+
+    What the acceptance rate bench.py prints IS (round 3: 0.078, "fp32 drift or physics?"): under nan_policy = "reference" -- the reference's own arithmetic -- log alpha
+    has a standard deviation of ~200 in fp64 too, because `posterior_logpdf` drops a whole time step's observation term when ANY component of y_t is NaN
+    (`base.py:159-166`: nansum over steps; `mvn/base.py:49-56`), i.e. the auxiliary term log N(u_t; x_t, delta/2 I) of the 79 steps in 80 without a real observation,
+    while `_get_alpha`'s correction (`kalman/generic.py:100-103`) sums over ALL steps: log alpha = exact ratio - sum over those steps of (|x'_t - u_t|^2 - |x_t - u_t|^2) / delta,
+    two chi-square-like sums over 48 538 coordinates.  With the per-component policy ("masked") the extended-linearisation proposal is accepted with log alpha ~ 1e-5.
+    Round 4 found that fp32 DID add an error of +-20 (time-minor) to +-700 (chain-minor, delta = 1e-5) on top -- information-form scales around the origin,
+    csrc/kalman_math.h::StepInfo, kernels.hip.h::k_ell_pass -- which made the fp32 sampler under "masked" reject half of its exact proposals; fixed, and pinned here."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler, _get_device_kernel
+    from aux_ssm_samplers_amd.workloads import lorenz_kalman_setup
+    T, delta = 16384, 1e-4
+    h = _lib.default_handle()
+    model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
+    init, kernel = _get_device_kernel(model, True, nan_policy=nan_policy)
+    for Cn, S in ((8, 4), (64, 2)):
+        rng = np.random.default_rng(11 + Cn)
+        x0 = np.repeat(xtrue[None], Cn, axis=0)
+        c64, c32 = DeviceChains(h, x0.astype(np.float64)), DeviceChains(h, x0.astype(np.float32))
+        assert c64.chain_minor == (Cn >= 32)
+        agree = n = 0
+        dl, la, a32s = [], [], []
+        for s in range(S):
+            nz = dict(eps_aux=rng.standard_normal((Cn, T, 3)), eps_samp=rng.standard_normal((Cn, T, 3)), u_accept=rng.random(Cn))
+            c32.x.copy_from_host(c32._to_layout(c64.to_host().astype(np.float32)))
+            kernel(None, KalmanSampler(x=c64, updated=None), delta, noise=nz)
+            kernel(None, KalmanSampler(x=c32, updated=None), delta, noise=nz)
+            a64, a32 = c64.accepted.to_host(), c32.accepted.to_host()
+            l64, l32 = c64.logs.to_host(), c32.logs.to_host()
+            assert np.isfinite(l64).all() and np.isfinite(l32).all()
+            same = a64 == a32
+            agree += int(same.sum())
+            n += Cn
+            dl.append(np.abs(l64[:, 0] - l32[:, 0]))
+            la.append(l64[:, 0])
+            a32s.append(a32)
+            both = same & (a64 == 1)
+            if both.any():   # same decision -> same trajectory to fp32 accuracy (|x| <= 50)
+                assert np.abs(c64.to_host()[both] - c32.to_host()[both].astype(np.float64)).max() < 2e-3
+        dl, la = np.concatenate(dl), np.concatenate(la)
+        print(f"C4 {nan_policy} {Cn} chains: decisions agree {agree}/{n}, max |d log alpha| {dl.max():.3g}, log alpha fp64 mean {la.mean():.3g} sd {la.std():.3g}, "
+              f"acceptance fp32 {np.mean(a32s):.3f}")
+        if nan_policy == "reference":
+            assert dl.max() < 1.0 and agree >= n - 1          # measured 0.13 (8 chains) / 0.10 (64); before the fix 15 / 70
+            assert la.std() > 50.0                             # the reference's dropped auxiliary terms: the low, delta-independent acceptance, in fp64 too
+        else:
+            assert dl.max() < 0.15 and agree >= n - 1         # measured 0.03 / 0.024; before the fix 16 / 70
+            assert np.abs(la).max() < 1e-2                     # the exact MH ratio of a proposal whose linearisation error is O(dt |x' - x|^2)
+            assert np.mean(a32s) > 0.97                        # fp32 accepts them too (before the fix: 0.5)

@@ -138,8 +138,65 @@ def test_lazy_state_bookkeeping(dtype):
         npt.assert_array_equal(np.nan_to_num(c2.logs.to_host()), np.nan_to_num(lr), err_msg=mode)
 
 
+def test_x_property_never_shows_stale_rows_after_a_fused_sweep():
+    """DeviceChains.x gathers the lazy state before handing out the DeviceArray: after a fused sweep that accepted, chains.x.to_host() is
+    the state to_host() returns, and a reset through chains.x.copy_from_host takes effect for every chain."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    h = _lib.default_handle()
+    m, model, kernel, x0 = _setup(400, 2, np.float64, 64, seed=5)
+    ch = DeviceChains(h, x0, chain_minor=True)
+    kernel(R.PRNGKey(3), KalmanSampler(x=ch, updated=None), 0.5)
+    assert ch.fused is True and ch.accepted.to_host().sum() > 0 and ch.sel.to_host().sum() > 0   # accepted chains live in x_alt now
+    raw = ch.x.to_host()                                                                          # the property resolves first
+    npt.assert_array_equal(ch.sel.to_host(), 0)
+    npt.assert_array_equal(np.ascontiguousarray(raw.transpose(2, 0, 1)), ch.to_host())
+    assert not np.array_equal(ch.to_host(), x0)
+    kernel(R.PRNGKey(4), KalmanSampler(x=ch, updated=None), 0.5)
+    ch.x.copy_from_host(np.ascontiguousarray(x0.transpose(1, 2, 0)))                              # a reset through the public attribute
+    npt.assert_array_equal(ch.to_host(), x0)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_lazy_state_moments_fold_accepted_and_rejected_chains(dtype):
+    """Running moments attached to the state of a FUSED sweep are folded by it (k_fs_stats), for accepted chains and for a rejected one (a NaN chain: zero
+    jump, unchanged state) alike: bit for bit what auxssm_stats_update gives on the resolved states before / after each sweep."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    h = _lib.default_handle()
+    T, d, Cn = 700, 2, 64
+    m, model, kernel, x0 = _setup(T, d, dtype, Cn, seed=8)
+    x0[7, 300, 0] = np.nan                                            # log alpha NaN: rejected in every sweep
+    ch = DeviceChains(h, x0, chain_minor=True)
+    ref = DeviceChains(h, x0, chain_minor=True)
+    stats = tuple(h.zeros(ch._x.shape, dtype) for _ in range(3))
+    want = tuple(h.zeros(ch._x.shape, dtype) for _ in range(3))
+    prev = h.empty(ch._x.shape, dtype)
+    h.stats_attach(stats, 0, ch.x)
+    try:
+        for i in range(4):
+            key = R.PRNGKey(50 + i)
+            kernel(key, KalmanSampler(x=ch, updated=None), 0.4)       # folds the moments itself
+            assert ch.fused is True
+            prev.copy_from(ref.x)
+            h.stats_attach(None, 0)                                   # (the reference chains are another state: detach while they sweep)
+            kernel(key, KalmanSampler(x=ref, updated=None), 0.4)
+            h.stats_update(i, prev, ref.x, want)
+            h.stats_attach(stats, i + 1, ch._x)
+            acc = ch.accepted.to_host()
+            assert acc[7] == 0 and acc.sum() >= Cn - 2
+    finally:
+        h.stats_attach(None, 0)
+    npt.assert_array_equal(np.nan_to_num(ch.to_host()), np.nan_to_num(ref.to_host()))
+    for a, b, name in zip(stats, want, ("sq_jump", "mean", "sq_mean")):
+        npt.assert_array_equal(np.nan_to_num(a.to_host()), np.nan_to_num(b.to_host()), err_msg=name)
+    sq = ch.stats_to_host(stats[0])
+    assert np.all(np.nan_to_num(sq[7]) == 0) and float(np.nanmax(sq)) > 0   # the rejected chain never jumped
+
+
 def test_refusals_fall_back_to_the_keyed_sweep():
-    """odd chain counts, dense layouts and attached running moments are refused before anything is enqueued; kernel() then runs the keyed sweep"""
+    """odd chain counts and dense layouts are refused before anything is enqueued; kernel() then runs the keyed sweep (attached running moments are NOT a
+    refusal: the fused sweep folds them, test_lazy_state_moments_fold_accepted_and_rejected_chains)"""
     from aux_ssm_samplers_amd import _lib, random as R
     from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
     h = _lib.default_handle()

@@ -220,3 +220,38 @@ def test_fold_step_is_prefix_combined_with_the_steps_element(d, seed):
     F, Q, bd = 0.7 * rng.standard_normal((d, d)), spd(d, 0.2), rng.standard_normal(d)
     acc = np.concatenate([rng.standard_normal(d * d), rng.standard_normal(d), pack(spd(d, 0.1)), rng.standard_normal(d), pack(spd(d, 0.05)), [rng.standard_normal()]])
     assert Hs.fold_check(F, Q, bd, pack(Lam), g0, q0, ldR, float(p), acc) < 1e-10
+
+
+def test_auxiliary_block_around_the_predicted_mean_keeps_its_digits_in_fp32():
+    """The general path's fold takes the step's observation in information form.  For the auxiliary block y = u, H = I, R = delta/2 I that form (|u|^2 / hd,
+    u.m / hd, m.m / hd around the origin) cancels ~|x|^2 / hd down to the innovation: at Lorenz-63 scale (|x| ~ 25, delta = 1e-4: 3.7e7 -> ~3) fp32 lost every digit of
+    the log-likelihood increment (C4: ell of 16 384 steps off by +390, round 4).  Kept apart and evaluated around the predicted mean (StepInfo::u / inv_hd) the fp32
+    increment has the accuracy of its inputs; in fp64 the two forms agree to rounding."""
+    rng = np.random.default_rng(12)
+    d, delta, dt = 3, 1e-4, 1.25e-4
+    hd = delta / 2
+    pack = lambda S: np.array([S[i, j] for i in range(d) for j in range(i, d)])
+    worst32_folded = worst32_apart = 0.0
+    for rep in range(40):
+        x = np.array([1.5, -1.5, 25.0]) + rng.standard_normal(3) * np.array([8.0, 8.0, 8.0])
+        F = np.eye(d) + dt * rng.standard_normal((d, d)) * 20
+        Q = 9 * dt * np.eye(d)
+        bd = x - F @ x + dt * rng.standard_normal(d)                   # so that the predicted mean is x + O(dt)
+        b0 = x + 0.007 * rng.standard_normal(d)
+        C0 = pack(4.8e-5 * np.eye(d))
+        u = x + np.sqrt(hd) * rng.standard_normal(d) + 0.03 * rng.standard_normal(d)
+        obs = rep % 2 == 0                                              # every other step carries a real observation of (x2, x3) with variance 5
+        H = np.array([[0, 1.0, 0], [0, 0, 1.0]])
+        y = H @ x + np.sqrt(5.0) * rng.standard_normal(2)
+        Lobs = pack(H.T @ H / 5.0) if obs else np.zeros(6)
+        gobs = H.T @ y / 5.0 if obs else np.zeros(3)
+        qobs = float(y @ y / 5.0) if obs else 0.0
+        ldR = 0.5 * (d * np.log(hd) + (2 * np.log(5.0) if obs else 0.0))
+        dim = d + (2 if obs else 0)
+        za, zb, db, dC = Hs.fold_aux(np.float64, F, Q, bd, Lobs, gobs, qobs, u, 1 / hd, ldR, dim, b0, C0)
+        assert abs(za - zb) < 1e-6 * max(1.0, abs(zb)) and db < 1e-9 and dC < 1e-12      # fp64: the same step (the folded form already loses 8 of its 16 digits)
+        fa, fb, _, _ = Hs.fold_aux(np.float32, F, Q, bd, Lobs, gobs, qobs, u, 1 / hd, ldR, dim, b0, C0)
+        worst32_folded = max(worst32_folded, abs(fa - zb))
+        worst32_apart = max(worst32_apart, abs(fb - zb))
+    assert worst32_apart < 5e-3, worst32_apart        # fp32 inputs of magnitude 25 carry 1e-6: an innovation of 0.035 to 1e-4 relative, its square over S likewise
+    assert worst32_folded > 20 * worst32_apart, (worst32_folded, worst32_apart)   # what round 3 computed

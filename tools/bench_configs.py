@@ -33,7 +33,7 @@ def timed_sweeps(kernel, chains, delta, steps=5, warmup=2, seed=1):
 
 
 def c3_kalman(order, chains=64, T=65536, chain_minor=None):
-    from tests.helpers import sv_setup
+    from aux_ssm_samplers_amd.workloads import sv_setup
     from aux_ssm_samplers_amd.common import delta_adaptation
     from aux_ssm_samplers_amd.loop import loop
     y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, rho=0.0)
@@ -50,8 +50,8 @@ def c3_kalman(order, chains=64, T=65536, chain_minor=None):
 
 
 def c4(chains=8, T=16384, N=512):
-    from tests.helpers import lorenz_kalman_setup
-    from tests.helpers import lorenz_setup
+    from aux_ssm_samplers_amd.workloads import lorenz_kalman_setup
+    from aux_ssm_samplers_amd.workloads import lorenz_setup
     from aux_ssm_samplers_amd.csmc import _device
     model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
@@ -80,7 +80,7 @@ def c4(chains=8, T=16384, N=512):
 
 
 def c5(T=8192):
-    from tests.helpers import c5_model
+    from aux_ssm_samplers_amd.workloads import c5_model
     import aux_ssm_samplers_amd._primitives.kalman as P
     u, lg64, x = c5_model(T, 64)
     lg = P.LGSSM(*[np.ascontiguousarray(a, np.float32) for a in lg64])
@@ -147,8 +147,8 @@ def loops():
                delta_fn=delta_adaptation, target_alpha=0.5, lr=0.1)
     del ch
     # C4: the (x, theta) Gibbs sampler of the Lorenz example, 8 chains each with its own theta
-    from tests.helpers import lorenz_kalman_setup
-    from tests.helpers import lorenz_setup
+    from aux_ssm_samplers_amd.workloads import lorenz_kalman_setup
+    from aux_ssm_samplers_amd.workloads import lorenz_setup
     T, C = 16384, 8
     model, xtrue = lorenz_kalman_setup(T, every=80, dt=1.25e-4)
     init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
@@ -239,7 +239,7 @@ def c5_batched_scalar(T=8192, B=64):
 def sv30(T=250, D=30, N=25):
     """the reference's own timed stochastic-volatility protocol (examples/stochastic_volatility/experiment.sh:1-10: D = 30, T = 250, cSMC with N = 25
     particles, backward sampling): auxiliary cSMC sweeps per second at several chain counts, classical sweep (csrc/csmc_wide.hip)"""
-    from tests.helpers import sv_setup
+    from aux_ssm_samplers_amd.workloads import sv_setup
     from aux_ssm_samplers_amd.csmc import CsmcChains, CSMCState, get_independent_kernel, GaussianInit, LinearGaussianDynamics, SVPotential
     h = _lib.default_handle()
     y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, D)
@@ -264,7 +264,7 @@ def sv30(T=250, D=30, N=25):
 def sv30_kalman(T=250, D=30, chains=(1, 16, 64)):
     """the other sampler of the same protocol: the auxiliary Kalman sampler with first / second order linearisation of the SV observation model at D = 30
     (examples/stochastic_volatility/auxiliary_kalman.py:22-48), fp64 as the reference runs it, parallel scan; wide-state kernels (dx = 30)"""
-    from tests.helpers import sv_setup
+    from aux_ssm_samplers_amd.workloads import sv_setup
     y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, D)
     h = _lib.default_handle()
     for order in (1, 2):

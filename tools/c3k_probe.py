@@ -5,7 +5,7 @@ import sys
 import numpy as np
 
 sys.path.insert(0, ".")
-from tests.helpers import sv_setup  # noqa: E402
+from aux_ssm_samplers_amd.workloads import sv_setup  # noqa: E402
 from aux_ssm_samplers_amd import _lib, random as R  # noqa: E402
 from aux_ssm_samplers_amd.kalman import get_kernel, SVModel  # noqa: E402
 from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler  # noqa: E402

@@ -6,7 +6,7 @@ import time
 import numpy as np
 
 sys.path.insert(0, ".")
-from tests.helpers import lorenz_kalman_setup  # noqa: E402
+from aux_ssm_samplers_amd.workloads import lorenz_kalman_setup  # noqa: E402
 from aux_ssm_samplers_amd import _lib, random as R  # noqa: E402
 from aux_ssm_samplers_amd.kalman import get_kernel  # noqa: E402
 from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler  # noqa: E402

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aux_ssm_samplers_amd import _lib  # noqa: E402
 from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM  # noqa: E402
-from tests.helpers import c5_model  # noqa: E402
+from aux_ssm_samplers_amd.workloads import c5_model  # noqa: E402
 
 S = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 3

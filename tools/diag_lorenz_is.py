@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aux_ssm_samplers_amd import _lib, random as R  # noqa: E402
 from aux_ssm_samplers_amd.kalman import get_kernel  # noqa: E402
 from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler  # noqa: E402
-from tests.helpers import lorenz_kalman_setup  # noqa: E402
+from aux_ssm_samplers_amd.workloads import lorenz_kalman_setup  # noqa: E402
 
 T, C = 3, 1024
 model, xtrue = lorenz_kalman_setup(T, every=1, dt=0.05, seed=3)

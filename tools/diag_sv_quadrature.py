@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from aux_ssm_samplers_amd import _lib, random as R  # noqa: E402
 from aux_ssm_samplers_amd.kalman import get_kernel, SVModel  # noqa: E402
 from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler  # noqa: E402
-from tests.helpers import sv_setup  # noqa: E402
+from aux_ssm_samplers_amd.workloads import sv_setup  # noqa: E402
 from tests.helpers import sv_posterior_by_quadrature  # noqa: E402
 
 T, d, C = 3, 1, 1024

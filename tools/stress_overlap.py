@@ -4,7 +4,7 @@ import numpy as np, sys, time
 sys.path.insert(0, '.')
 from aux_ssm_samplers_amd import _lib, random as R
 from aux_ssm_samplers_amd.kalman import get_kernel, DeviceChains, KalmanSampler, LGConcatModel
-from tests.helpers import lg_model
+from aux_ssm_samplers_amd.workloads import lg_model
 h = _lib.default_handle()
 T, d, C, NS = (int(sys.argv[1]) if len(sys.argv) > 1 else 16384), 2, 256, 80
 dtype = np.float64

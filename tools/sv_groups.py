@@ -2,7 +2,7 @@ import sys, json, numpy as np
 sys.path.insert(0, '.')
 from aux_ssm_samplers_amd import _lib, random as R
 from aux_ssm_samplers_amd.kalman import get_kernel, DeviceChains, KalmanSampler, SVModel
-from tests.helpers import sv_setup
+from aux_ssm_samplers_amd.workloads import sv_setup
 T = 65536
 y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, rho=0.0)
 h = _lib.default_handle()

@@ -3,7 +3,7 @@ joint log-density per chain through the primitives API; run under rocprofv3 --ke
 import sys, time
 import numpy as np
 sys.path.insert(0, ".")
-from tests.helpers import c5_model
+from aux_ssm_samplers_amd.workloads import c5_model
 import aux_ssm_samplers_amd._primitives.kalman as P
 
 T = int(sys.argv[1]) if len(sys.argv) > 1 else 8192

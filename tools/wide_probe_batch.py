@@ -4,7 +4,7 @@ HIP-event hooks."""
 import sys
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
-from tests.helpers import c5_model
+from aux_ssm_samplers_amd.workloads import c5_model
 from aux_ssm_samplers_amd import _lib
 import aux_ssm_samplers_amd._primitives.kalman as P
 
