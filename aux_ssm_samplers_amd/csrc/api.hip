@@ -96,7 +96,9 @@ int side_open(auxssm_ctx* h, size_t need) {
         }
         s.bytes[p] = want;
         s.end_valid[p] = false;
+        s.memo_use[p] = -1;  // (a new slab holds nobody's tables)
     }
+    ++s.uses[p];
     if (s.end_valid[p]) AX_HIP(hipStreamWaitEvent(s.streams[p], s.sweep_end[p], 0));
     // something other than a staged sweep went through the handle since -- or the caller holds the raw stream and may have queued work on it the
     // library never saw (auxssm_stream): that work comes first
@@ -342,9 +344,46 @@ template <typename R> __global__ void k_delta_block(const R* __restrict__ delta,
     blk[1] = sqrt(0.5 * d);
 }
 
+// ---- model-stage memo (ctx.h::SideStage): the stage's input arrays against the snapshot its slab was built from -------------------------------------------------
+// up to 9 chain-shared arrays (chain stride 0, batch 1), array q = nt[q] time records of rec[q] reals; the snapshot stores them back to back
+struct MemoDesc {
+    Arr a[9];
+    int nt[9], rec[9];
+    long long off[10];  // prefix sums of nt * rec (reals)
+    int n;
+};
+template <typename R> struct MemoBits;
+template <> struct MemoBits<float> { using U = uint32_t; };
+template <> struct MemoBits<double> { using U = unsigned long long; };
+template <typename R> __device__ __forceinline__ const R* memo_src(const MemoDesc& d, long long g) {
+    int q = 0;
+#pragma unroll
+    for (int k = 1; k < 9; ++k) q += (k < d.n && g >= d.off[k]) ? 1 : 0;
+    const long long e = g - d.off[q];
+    const long long t = e / d.rec[q];
+    const int k = (int)(e - t * d.rec[q]);
+    return at<R>(d.a[q], 0, t, 0) + (long long)k * d.a[q].se;
+}
+// rebuild |= (any input element's BIT PATTERN differs from the snapshot): NaNs (missing observations) compare equal to themselves
+template <typename R> __global__ void __launch_bounds__(256) k_memo_check(MemoDesc d, const R* __restrict__ snap, int* __restrict__ rebuild) {
+    using U = typename MemoBits<R>::U;
+    const long long tot = d.off[d.n];
+    bool diff = false;
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < tot; g += (long long)gridDim.x * 256)
+        diff = diff || *reinterpret_cast<const U*>(memo_src<R>(d, g)) != reinterpret_cast<const U*>(snap)[g];
+    if (__builtin_amdgcn_ballot_w64(diff) != 0 && (threadIdx.x & 63) == 0) atomicOr(rebuild, 1);
+}
+template <typename R> __global__ void __launch_bounds__(256) k_memo_snap(MemoDesc d, R* __restrict__ snap, const int* __restrict__ rebuild) {
+    if (*rebuild == 0) return;
+    const long long tot = d.off[d.n];
+    for (long long g = (long long)blockIdx.x * 256 + threadIdx.x; g < tot; g += (long long)gridDim.x * 256) snap[g] = *memo_src<R>(d, g);
+}
+__global__ void k_memo_set(int* rebuild, int v) { *rebuild = v; }
+
 // concatenated observation model of AUXSSM_KMODEL_LG_CONCAT, chain-shared part: H = [I; Hobs], R = blkdiag(d/2 I, Robs), c = [0; cobs]
 template <typename R>
-__global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cobs, R half_delta, const double* dptr, R* Hc, R* Rc, R* cc) {
+__global__ void k_concat_model(int T, int D, int PO, Arr Hobs, Arr Robs, Arr cobs, R half_delta, const double* dptr, R* Hc, R* Rc, R* cc, const int* memo = nullptr) {
+    if (memo_skip_p(memo)) return;
     if (dptr) half_delta = (R)(0.5 * dptr[0]);  // device-resident step size (auxssm_kalman_sweep_dd)
     const int P = D + PO;
     const int per_t = P * D + P * P + P;
@@ -791,11 +830,65 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
         ~SweepEnd() { side_sweep_end(h); }
     } sweep_end{h};
     if (overlap) {
-        const size_t need_side = sl->fused_ws(h, kd) + (size_t)(T + 64) * sR * ((size_t)P * D + (size_t)P * P + P + (size_t)D * D) + (4u << 20);
+        const size_t need_side = sl->fused_ws(h, kd) + (size_t)(T + 64) * sR * ((size_t)P * D + (size_t)P * P + P + (size_t)D * D) + (4u << 20) +
+                                 (size_t)(T + 2) * sR * (3 * (size_t)D * D + 2 * D + (size_t)PO * D + (size_t)PO * PO + 2 * PO);  // (+ the memo's snapshot of the inputs)
         if ((rc = side_open(h, need_side))) return rc;
         overlap = h->side.open;
     }
     R *Hc, *Rc, *cc, *Ps;
+    const int* memo = nullptr;
+    struct MemoGuard {  // a sweep that fails after claiming its slab's tables leaves nobody's tables behind
+        auxssm_ctx* h;
+        int p = -1;
+        bool ok = false;
+        ~MemoGuard() { if (p >= 0 && !ok) h->side.memo_use[p] = -1; }
+    } memo_guard{h};
+    if (overlap) {
+        // MODEL-STAGE MEMO (ctx.h::SideStage): the head of the slab holds the `rebuild` word and a snapshot of the stage's inputs
+        static const bool memo_on = [] { const char* e = getenv("AUXSSM_STAGE_MEMO"); return !(e && atoi(e) == 0); }();
+        SideScope sc(h);
+        auxssm_ctx::SideStage& sd = h->side;
+        const int p = sd.parity;
+        MemoDesc md{};
+        const auxssm_arr* srcs[9] = {&model->m0, &model->P0, &model->Fs, &model->Qs, &model->bs, &model->Hs, &model->Rs, &model->cs, yobs};
+        const int recs[9] = {D, D * D, D * D, D * D, D, PO * D, PO * PO, PO, PO};
+        const int nts[9] = {1, 1, T - 1, T - 1, T - 1, T, T, T, T};
+        md.n = 9;
+        md.off[0] = 0;
+        bool plain = memo_on;
+        for (int q = 0; q < 9; ++q) {
+            md.a[q] = cv(*srcs[q]);
+            md.rec[q] = recs[q];
+            md.nt[q] = md.a[q].st == 0 ? 1 : nts[q];
+            md.off[q + 1] = md.off[q] + (long long)md.nt[q] * md.rec[q];
+            plain = plain && md.a[q].sc == 0;  // (chain-shared arrays only: what the fused sweep accepts anyway)
+        }
+        int* rebuild = (int*)ws_take(h, 256);
+        R* snap = (R*)ws_take(h, (size_t)md.off[9] * sR + 256);
+        if (!rebuild || !snap) return AUXSSM_ERR_NOMEM;
+        if (plain) {
+            // host key: everything the tables depend on besides the arrays' contents
+            std::vector<unsigned char> key;
+            auto put = [&](const void* v, size_t nb) { key.insert(key.end(), (const unsigned char*)v, (const unsigned char*)v + nb); };
+            const int hdr[8] = {(int)sR, C, T, D, PO, nan_policy, 0, 0};  // (the chunk length is a function of C, T and the process's environment)
+            put(hdr, sizeof(hdr));
+            put(&delta, sizeof(delta));
+            for (int q = 0; q < 9; ++q) put(srcs[q], sizeof(auxssm_arr));
+            const bool chain_ok = sd.memo_use[p] == sd.uses[p] - 1 && sd.memo_key[p] == key;
+            const unsigned gmemo = (unsigned)std::min<long long>(1024, (md.off[9] + 255) / 256);
+            if (chain_ok) {  // same key, and this slab's previous stage was a memoised one: compare the inputs with the snapshot on the device
+                hipLaunchKernelGGL(k_memo_set, dim3(1), dim3(1), 0, h->stream, rebuild, 0);
+                hipLaunchKernelGGL((k_memo_check<R>), dim3(gmemo), dim3(256), 0, h->stream, md, (const R*)snap, rebuild);
+            } else {
+                hipLaunchKernelGGL(k_memo_set, dim3(1), dim3(1), 0, h->stream, rebuild, 1);
+            }
+            hipLaunchKernelGGL((k_memo_snap<R>), dim3(gmemo), dim3(256), 0, h->stream, md, snap, (const int*)rebuild);
+            sd.memo_key[p] = std::move(key);
+            sd.memo_use[p] = sd.uses[p];
+            memo_guard.p = p;
+            memo = rebuild;
+        }
+    }
     {
         SideScope sc(h);  // (model stage: the side slab when a stage is open, else the main one)
         Hc = (R*)ws_take(h, (size_t)T * P * D * sR);
@@ -806,7 +899,7 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
         ProfScope ps(h, AUXSSM_K_FACTORY);
         const long long n1 = (long long)T * (P * D + P * P + P);
         hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs), cv(model->Rs), cv(model->cs),
-                           (R)(0.5 * delta), dptr, Hc, Rc, cc);
+                           (R)(0.5 * delta), dptr, Hc, Rc, cc, memo);
     }
     // row 0 of the two normal draws and the acceptance uniforms (the rest is drawn inside passes A and C), then u_0 and [u_0 ; yobs_0]
     launch_rng_sweep<R>(h, keys, (long long)D * C, C, eps0a, eps0s, u_acc);
@@ -846,6 +939,7 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
     la.Hs = cv(model->Hs); la.Rs = cv(model->Rs); la.cs = cv(model->cs); la.ys = cv(*yobs);
     la.x = cm_arr(x, kd, D); la.xp = cm_arr(x_alt, kd, D); la.u = cm_arr(u, kd, D);
     la.delta = delta; la.nan_policy = nan_policy; la.u_fly = 0; la.shd = sqrt(0.5 * delta); la.dptr = dptr;
+    f.memo = memo;
     f.xa = x; f.xb = x_alt; f.sel = sel; f.u = u; f.inc = inc; f.keys = keys; f.eps0s = eps0s; f.u_acc = u_acc; f.accepted = accepted; f.logs = logs;
     if (h->st_mean && (h->st_x != x || h->st_n != (long long)C * T * D || h->st_dtype != (sizeof(R) == 4 ? AUXSSM_F32 : AUXSSM_F64))) {
         set_error("running moments are attached to another state (x=%p, n=%lld, dtype=%d): detach them (auxssm_stats_attach with NULLs) "
@@ -863,6 +957,7 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
         ++h->st_iter;
     }
     AX_HIP(hipGetLastError());
+    memo_guard.ok = true;
     return AUXSSM_OK;
 }
 

@@ -87,6 +87,17 @@ struct auxssm_ctx {
         // behind anything else the caller may have enqueued through the handle (an upload of new parameters, a memset, another kind of call): every
         // entry point counts itself in auxssm_ctx::api_calls, and a stage that is not opened by the call right after the last staged sweep first
         // waits for the tail of `stream` (one sweep without overlap).
+        // MODEL-STAGE MEMO (round 4).  The stage of the fused chain-shared sweep reads the model arrays, the data and the step size only.  In the sampling phase of a
+        // run (fixed step size, fixed model) it rebuilt the same tables every sweep -- ~12 short dependent launches that take 0.7 ms alone and 1.3 ms beside full-chip
+        // passes: as long as the sweep itself.  Each slab now remembers WHAT it was built from: a host key (shapes, pointers, strides, step size, options; memo_key) and a
+        // device snapshot of the input arrays' bytes at the head of the slab.  A later stage on the same slab with the same key launches one comparison kernel
+        // (inputs vs snapshot, bit patterns) that sets the slab's `rebuild` word, and every stage kernel returns at once when it is 0 (kalman_bodies.h::memo_skip).
+        // Exact: the tables are reused only when their inputs are byte for byte the same; nothing is trusted to the caller; no host synchronisation.
+        // `uses` counts the stages a slab has hosted; memo_use is the count at which its tables were last built or validated: a stage of another kind (SV, keyed
+        // sweep) in between breaks the chain and forces a rebuild.
+        std::vector<unsigned char> memo_key[NS];
+        long long uses[NS] = {0, 0, 0};
+        long long memo_use[NS] = {-1, -1, -1};
         const void* last_tab = nullptr;  // gain rows the open stage built (run_filter_shared), for a second filter of the same sweep
         unsigned long long last_call = 0;
         hipEvent_t fence = nullptr;
@@ -191,6 +202,7 @@ struct FusedHost {
     const void* u_acc;
     int32_t* accepted;
     void* logs;
+    const int* memo = nullptr;  // model-stage memo of this sweep's stage (ctx.h::SideStage), or null
 };
 typedef int (*fused_fn)(auxssm_ctx*, FusedHost&);
 typedef size_t (*fused_ws_fn)(const auxssm_ctx*, const KDims&);

@@ -43,6 +43,7 @@ struct FusedArgs {
     double delta, shd;
     const double* dptr;  // device-resident {delta, sqrt(delta / 2)} or null
     int nan_policy;
+    const int* memo;     // model-stage memo (FilterArgs::memo): the stage kernels return at once when *memo == 0
 };
 AX_HD void fs_resolve(FusedArgs& a) {
     const double* p = a.dptr;
@@ -55,6 +56,7 @@ __device__ __forceinline__ bool fs_decode(const FusedArgs& a, int& ch, int& s) {
 
 // ---- model stage: chunk products of the filter's matrices; within-chunk prefix products + chunk products of the sampler's gains ------------
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_fs_fprod(FusedArgs a, R* __restrict__ cprod) {
+    if (memo_skip(a)) return;
     using TG = GainRow<R, D, P>;
     const int ch = blockIdx.x * TB_CM + threadIdx.x;
     if (ch >= a.nchunk) return;
@@ -75,6 +77,7 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_f
     for (int k = 0; k < D * D; ++k) cprod[(long long)ch * D * D + k] = M[k];
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_gpre(FusedArgs a, R* __restrict__ gpre, R* __restrict__ cprod) {
+    if (memo_skip(a)) return;
     using TS = SampShared<R, D>;
     const int ch = blockIdx.x * TB_CM + threadIdx.x;
     if (ch >= a.nchunk) return;
@@ -153,6 +156,7 @@ template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_e(i
 }
 // one thread per destination element: blockIdx.y picks the row family (0 A, 1 C, 2 E), the flat index runs over (t, k)
 template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_rows(FusedArgs a, R* __restrict__ ra, R* __restrict__ rc, R* __restrict__ re) {
+    if (memo_skip(a)) return;
     constexpr int P = D + PO;
     using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>; using TL = LogShared<R, D, PO>;
     const int fam = blockIdx.y;
@@ -175,7 +179,8 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
 // the chain-shared part of log q(x' | u): x'_t | x'_{t+1} = G_t x'_{t+1} + M1_t m_t - gb_t + Lc_t eps_t, so log q = sum_t (-1/2 |eps_t|^2 - sum_i log Lc_t[i][i] - D/2 log 2 pi).
 // Two launches with a fixed shape (one lane per time step, a tree per workgroup, then one workgroup over the partial sums): deterministic, and a few microseconds
 // on the model stage's chain of dependent launches (one workgroup walking all T steps took 0.6 ms there and made the stage the critical path).
-template <typename R, int D> __global__ void __launch_bounds__(256) k_fs_clog_part(int T, const R* __restrict__ samp, Acc* __restrict__ part) {
+template <typename R, int D> __global__ void __launch_bounds__(256) k_fs_clog_part(int T, const R* __restrict__ samp, Acc* __restrict__ part, const int* memo) {
+    if (memo_skip_p(memo)) return;
     using TS = SampShared<R, D>;
     __shared__ Acc sh[256];
     const int t = blockIdx.x * 256 + threadIdx.x;
@@ -193,7 +198,8 @@ template <typename R, int D> __global__ void __launch_bounds__(256) k_fs_clog_pa
     }
     if (threadIdx.x == 0) part[blockIdx.x] = sh[0];
 }
-template <int D> __global__ void __launch_bounds__(256) k_fs_clog_sum(int T, int nb, const Acc* __restrict__ part, Acc* __restrict__ out) {
+template <int D> __global__ void __launch_bounds__(256) k_fs_clog_sum(int T, int nb, const Acc* __restrict__ part, Acc* __restrict__ out, const int* memo) {
+    if (memo_skip_p(memo)) return;
     __shared__ Acc sh[256];
     Acc acc = 0;
     for (int b = threadIdx.x; b < nb; b += 256) acc += part[b];
@@ -685,6 +691,8 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     a.ka0 = f.keys[0]; a.ka1 = f.keys[1]; a.ks0 = f.keys[2]; a.ks1 = f.keys[3];
     a.eps0s = f.eps0s;
     a.delta = f.la.delta; a.shd = f.la.shd; a.dptr = f.la.dptr; a.nan_policy = f.la.nan_policy;
+    a.memo = f.memo;
+    f.fa.memo = f.sa.memo = f.la.memo = f.memo;  // the model stage below; cleared before the chain passes (k_filter_t0 serves both)
     R *cprod_f, *cprod_s, *rows_a, *rows_c, *rows_e;
     {
         // MODEL STAGE (ctx.h::SideStage when the sweep opened one): everything that reads the model and the step size only
@@ -709,8 +717,8 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
         {
             ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
             hipLaunchKernelGGL((k_sample_shared_tab<R, D>), dim3((T + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.sa);
-            hipLaunchKernelGGL((k_fs_clog_part<R, D>), dim3(nclb), dim3(256), 0, h->stream, T, (const R*)f.sa.tab, clog + 32);
-            hipLaunchKernelGGL((k_fs_clog_sum<D>), dim3(1), dim3(256), 0, h->stream, T, nclb, (const Acc*)(clog + 32), clog);
+            hipLaunchKernelGGL((k_fs_clog_part<R, D>), dim3(nclb), dim3(256), 0, h->stream, T, (const R*)f.sa.tab, clog + 32, f.memo);
+            hipLaunchKernelGGL((k_fs_clog_sum<D>), dim3(1), dim3(256), 0, h->stream, T, nclb, (const Acc*)(clog + 32), clog, f.memo);
             hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.la);
             hipLaunchKernelGGL((k_fs_fprod<R, D, P>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod_f);
             hipLaunchKernelGGL((k_fs_gpre<R, D>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, gpre, cprod_s);
@@ -725,6 +733,8 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
         const int rc = side_close(h);
         if (rc) return rc;
     }
+    a.memo = nullptr;
+    f.fa.memo = f.sa.memo = f.la.memo = nullptr;  // (the chain passes are never skipped)
     const size_t npre = (size_t)C * a.nchunk * SampPre<R, D>::NPAD * sizeof(R);
     a.agg_f = ws_take(h, npre); a.pre_f = ws_take(h, npre); a.agg_s = ws_take(h, npre); a.pre_s = ws_take(h, npre);
     a.pa = (Acc*)ws_take(h, (size_t)3 * C * a.nchunk * sizeof(Acc));

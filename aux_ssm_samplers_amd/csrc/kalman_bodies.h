@@ -137,7 +137,12 @@ struct FilterArgs {
     int ps_packed = 0;
     const void* obs_tab = nullptr;  // general chain-minor path with aux_on: one ObsInfoRow per transition (kalman_math.h), elements built on the fly
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
+    // MODEL-STAGE MEMO (ctx.h::SideStage, round 4): non-null inside a memoised stage; *memo == 0 says "the stage's inputs are byte for byte the ones this slab's
+    // tables were built from" and every stage kernel returns at once (memo_skip); non-zero: rebuild.  Null everywhere else.
+    const int* memo = nullptr;
 };
+template <typename A> AX_HD bool memo_skip(const A& a) { return a.memo != nullptr && *a.memo == 0; }
+AX_HD bool memo_skip_p(const int* memo) { return memo != nullptr && *memo == 0; }
 AX_HD Arr dense_arr(const void* p, const KDims& d, long long rec) {
     return Arr{p, (long long)d.T * d.B * rec, (long long)d.B * rec, rec, 1};
 }
@@ -240,6 +245,7 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
 struct ScanBufs {
     void* agg;   // [S][nchunk][Full::NPAD]
     void* pre;   // [S][nchunk][Pre::NPAD]
+    const int* memo = nullptr;  // (model-stage memo: as FilterArgs::memo)
 };
 
 template <typename R_, int D> struct FilterOp {
@@ -500,6 +506,7 @@ struct SampleArgs {
     int eps_gen = 0;          // != 0: eps is generated by the reduce pass from (gen_k0, gen_k1) and written for the down pass (as FilterArgs::aux_gen)
     unsigned int gen_k0 = 0, gen_k1 = 0;
     const void* tab = nullptr;  // then: one SampShared row per time step
+    const int* memo = nullptr;  // model-stage memo (FilterArgs::memo)
 };
 
 template <typename R_, int D> struct SampleOp;
@@ -779,6 +786,7 @@ struct SweepLogpdfArgs {
     Arr eps_aux{};
     double shd = 0;
     const double* dptr = nullptr;  // device-resident {delta, sqrt(delta / 2)}; null: the host values
+    const int* memo = nullptr;     // model-stage memo (FilterArgs::memo)
 };
 // the auxiliary variable of chain c at time t >= 1
 template <typename R, int D> AX_HD void sweep_u(const SweepLogpdfArgs& a, int c, long long t, const R* x, R* u) {

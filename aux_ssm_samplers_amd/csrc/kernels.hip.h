@@ -108,6 +108,7 @@ inline unsigned grid_tile_seq(int ntile, int S) { return (unsigned)(((ntile + 7)
 
 // ---- Kalman elementwise kernels -----------------------------------------------------------------------------
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_t0(FilterArgs a) {
+    if (memo_skip(a)) return;
     const int s = blockIdx.x * TB_ELEM + threadIdx.x;
     if (s < a.d.S()) body_filter_t0<R, D, P>(a, s);
 }
@@ -115,6 +116,7 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
 // grid = ntile * S, sequence index fastest so that workgroups of different chains touching the same time
 // tile (hence the same chain-shared model parameters) are co-scheduled and share them through L2.
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_init(FilterArgs a) {
+    if (memo_skip(a)) return;
     resolve_step(a);
     int tile, s;
     decode_tile_seq(a.d.S(), tile, s);
@@ -267,6 +269,7 @@ template <typename R, int D, int P, int P1> __global__ void __launch_bounds__(TB
     }
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sample_shared_tab(SampleArgs a) {
+    if (memo_skip(a)) return;
     const int t = blockIdx.x * TB_ELEM + threadIdx.x;
     if (t < a.d.T) body_sample_shared_tab<R, D>(a, t);
 }
@@ -331,6 +334,7 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, Ac
 }
 
 template <typename R, int D, int PO> __global__ void __launch_bounds__(TB_ELEM) k_sweep_logpdf_tab(SweepLogpdfArgs a) {
+    if (memo_skip(a)) return;
     const int i = blockIdx.x * TB_ELEM + threadIdx.x;
     if (i < a.d.T - 1) body_sweep_logpdf_tab<R, D, PO>(a, i);
 }
@@ -563,6 +567,7 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
 // one wave = one group of 64 chunks of one sequence; row k of the group is 64 contiguous records (ScanLayout)
 template <class Op>
 __global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, ScanBufs sb, int n) {
+    if (memo_skip(a)) return;
     resolve_step(a);
     using R = typename Op::R;
     using Full = typename Op::Full;
@@ -598,6 +603,7 @@ __global__ void __launch_bounds__(TB_SCAN) k_scan_reduce(typename Op::Args a, Sc
 }
 
 template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanBufs sb, int nchunk) {
+    if (memo_skip(sb)) return;
     using R = typename Op::R;
     using Full = typename Op::Full;
     using Pre = typename Op::Pre;
@@ -654,6 +660,7 @@ template <class Op> __global__ void __launch_bounds__(TB_AGGS) k_scan_aggs(ScanB
 
 template <class Op>
 __global__ void __launch_bounds__(TB_SCAN) k_scan_down(typename Op::Args a, ScanBufs sb, int n) {
+    if (memo_skip(a)) return;
     resolve_step(a);
     using R = typename Op::R;
     using Full = typename Op::Full;
@@ -706,6 +713,7 @@ __device__ __forceinline__ bool decode_aff(int S, int nchunk, int& ch, int& s) {
 inline unsigned grid_aff(int S, int nchunk) { return (unsigned)(((nchunk + 7) / 8) * 8) * (unsigned)((S + TB_CM - 1) / TB_CM); }
 
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_gain_tab(FilterArgs a, const R* __restrict__ Ps1) {
+    if (memo_skip(a)) return;
     const int i = blockIdx.x * TB_ELEM + threadIdx.x;
     if (i < a.d.n()) body_gain_tab<R, D, P>(a, Ps1, i);
 }
@@ -717,7 +725,8 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
     }
 }
 // the mask carrier of the matrix filter when the concatenated observations are built on the fly: [0 ; yobs_t]
-template <typename R> __global__ void k_mask_obs(int T, int D, int P, Arr yobs, R* __restrict__ out) {
+template <typename R> __global__ void k_mask_obs(int T, int D, int P, Arr yobs, R* __restrict__ out, const int* memo = nullptr) {
+    if (memo_skip_p(memo)) return;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)T * P) return;
     const long long t = g / P;
@@ -725,7 +734,8 @@ template <typename R> __global__ void k_mask_obs(int T, int D, int P, Arr yobs, 
     out[g] = k < D ? (R)0 : at<R>(yobs, 0, t, 0)[k - D];
 }
 // dense (T, D, D) covariances of the matrix filter -> chain 0's slot of the caller's (strided) covariance buffer
-template <typename R, int D> __global__ void k_copy_cov(int T, const R* __restrict__ src, Arr dst) {
+template <typename R, int D> __global__ void k_copy_cov(int T, const R* __restrict__ src, Arr dst, const int* memo = nullptr) {
+    if (memo_skip_p(memo)) return;
     const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= (long long)T * D * D) return;
     const long long t = g / (D * D);
@@ -911,7 +921,7 @@ int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
-    ScanBufs sb{nullptr, nullptr};
+    ScanBufs sb{nullptr, nullptr, a.memo};
     const unsigned grid = lay.cm ? (unsigned)((S + TB_CM - 1) / TB_CM) * lay.nchunk : (unsigned)S * lay.ngrp;
     const size_t stage = stage_bytes<R>(Op::Full::NPAD);
     if (lay.nchunk > 1) {
@@ -985,7 +995,7 @@ template <typename R, int D, int P> int build_gain_table(auxssm_ctx* h, FilterAr
         R* ym = (R*)ws_take(h, (size_t)T * P * sizeof(R));
         if (!ym) return AUXSSM_ERR_NOMEM;
         const long long tot = (long long)T * P;
-        hipLaunchKernelGGL((k_mask_obs<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, a.aux_yobs, ym);
+        hipLaunchKernelGGL((k_mask_obs<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, a.aux_yobs, ym, a.memo);
         am.ys = dense_arr(ym, am.d, P);
     } else if (a.mask_ys.ptr) {
         am.ys = a.mask_ys;  // a chain-independent mask carrier
@@ -1004,7 +1014,7 @@ template <typename R, int D, int P> int build_gain_table(auxssm_ctx* h, FilterAr
     hipLaunchKernelGGL((k_gain_tab<R, D, P>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a, (const R*)Ps1);
     if (side.on) h->side.last_tab = a.tab;
     if (!ps_once)  // chain 0's slot of the caller's buffer (the sampler's table reads that one)
-        hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps);
+        hipLaunchKernelGGL((k_copy_cov<R, D>), dim3((unsigned)(((long long)T * D * D + 255) / 256)), dim3(256), 0, h->stream, T, (const R*)Ps1, a.Ps, a.memo);
     return AUXSSM_OK;
 }
 

@@ -149,6 +149,62 @@ def test_model_stage_on_the_side_stream_equals_the_single_stream_sweep(dtype):
     assert not np.array_equal(a[-1][0], x0[0])
 
 
+def test_model_stage_memo_is_exact(monkeypatch):
+    """The fused sweep's model stage is MEMOISED per slab (ctx.h::SideStage, round 4): rebuilt only when its inputs differ byte for byte from the snapshot the slab's
+    tables were built from -- decided on the device, no host synchronisation.  A run of sweeps with a fixed step size (every stage after the first three is skipped),
+    then a new step size, then the DATA and a MODEL MATRIX rewritten in place on the device (same pointers: only the comparison kernel can notice), then the old data
+    back: bit for bit the results of the same run with the memo switched off (AUXSSM_STAGE_MEMO=0, a separate library instance would read the variable once, so the
+    switch here is the single-stream sweep, which has no stage to memoise)."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import LGConcatModel
+    h = _lib.default_handle()
+    dtype = np.float64
+    T, d, C = 1200, 2, 64
+    m = lg_model(T, d, dtype=dtype)
+    full = lambda a, n: np.ascontiguousarray(np.broadcast_to(a, (n,) + a.shape))
+    rng = np.random.default_rng(4)
+    y2 = (m["y"] + 0.5 * rng.standard_normal(m["y"].shape)).astype(dtype)
+    x0 = rng.standard_normal((C, T, d)).astype(dtype) * 0.3
+    deltas = [0.4] * 7 + [0.3] * 4 + [0.4] * 9
+
+    def run(overlap):
+        h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, overlap)
+        model = LGConcatModel(m["m0"], m["P0"], full(m["F"], T - 1), full(m["Q"], T - 1), full(m["b"], T - 1), full(m["Hobs"], T), full(m["Robs"], T),
+                              full(m["cobs"], T), m["y"])
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        ch = DeviceChains(h, x0, chain_minor=True)
+        dl_, ybuf, _ = model.device(h, dtype)
+        yold, ynew = _lib.DeviceArray(h, ybuf.shape, ybuf.dtype), _lib.DeviceArray(h, ybuf.shape, ybuf.dtype)
+        yold.copy_from(ybuf)
+        ynew.copy_from_host(np.ascontiguousarray(y2, dtype=dtype).reshape(ybuf.shape))
+        Fbuf = dl_.bufs["Fs"]
+        F2 = _lib.DeviceArray(h, Fbuf.shape, Fbuf.dtype)
+        F2.copy_from_host((0.9 * Fbuf.to_host()).astype(dtype))
+        out = []
+        for i, dl in enumerate(deltas):
+            if i == 12:
+                ybuf.copy_from(ynew)      # new data behind the same pointer
+            if i == 15:
+                Fbuf.copy_from(F2)        # a model matrix rewritten in place
+            if i == 17:
+                ybuf.copy_from(yold)      # ... and the old data back
+            kernel(R.PRNGKey(2000 + i), KalmanSampler(x=ch, updated=None), dl)
+            assert ch.fused is True
+            if i in (2, 6, 8, 11, 12, 13, 15, 16, 17, 19):
+                out.append((ch.to_host(), ch.accepted.to_host(), ch.logs.to_host()))
+        return out
+
+    try:
+        a = run(1)
+        b = run(0)
+    finally:
+        h.set_option(_lib.OPT_OVERLAP_MODEL_STAGE, 1)
+    for u, v in zip(a, b):
+        for p, q in zip(u, v):
+            npt.assert_array_equal(p, q)
+    assert not np.array_equal(a[3][2], a[4][2])
+
+
 def test_sv_first_order_model_stage_on_the_side_stream_equals_the_single_stream_sweep():
     """The first-order SV factory with chain-shared dynamics: covariances and gain rows depend on the model and the step size only, so the sweep builds
     them once (the reverse filter reuses the proposal filter's rows) on the second stream -- bit for bit the single-stream sweep, over changing step sizes."""
