@@ -436,16 +436,33 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
         using T = ObsInfoRow<R, D>;
         const UniformRow<R> row = uniform_row<R>((const R*)a.obs_tab + (long long)i * T::NPAD);
         const R inv_hd = (R)1 / ((R)arg_aux_shd(a) * (R)arg_aux_shd(a));
+        R u[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) {
-            si.u[k] = r.x[k] + (R)arg_aux_shd(a) * r.eps[k];
-            si.g0[k] = row[T::oG + k];
-        }
-        if constexpr (WRITE_U) wr<R, D>(a.aux_u, s / a.d.B, (long long)i + 1, s % a.d.B, si.u);
+        for (int k = 0; k < D; ++k) u[k] = r.x[k] + (R)arg_aux_shd(a) * r.eps[k];
+        if constexpr (WRITE_U) wr<R, D>(a.aux_u, s / a.d.B, (long long)i + 1, s % a.d.B, u);
 #pragma unroll
         for (int k = 0; k < DS; ++k) si.Lam[k] = row[T::oL + k];
-        si.inv_hd = inv_hd;  // the auxiliary block stays apart: step_predict_solve evaluates it around the predicted mean (StepInfo)
-        si.q0 = row[T::oK];
+        if constexpr (sizeof(R) == 4) {
+            // fp32: the auxiliary block stays apart and step_predict_solve evaluates it around the predicted mean (StepInfo: the folded form below cancels
+            // ~|x|^2 / hd down to the innovation, every digit of an fp32 log-likelihood increment at Lorenz-63 scale)
+#pragma unroll
+            for (int k = 0; k < D; ++k) si.u[k] = u[k], si.g0[k] = row[T::oG + k];
+            si.inv_hd = inv_hd;
+            si.q0 = row[T::oK];
+        } else {
+            // fp64: folded into the information form around the origin (8 of 16 digits to spare; 16 fewer multiply-adds and D fewer live values per step in a
+            // kernel at its register cap: the general filter scan is 13 % faster this way)
+            R q0 = row[T::oK];
+#pragma unroll
+            for (int k = 0; k < D; ++k) {
+                si.g0[k] = u[k] * inv_hd + row[T::oG + k];
+                si.u[k] = 0;
+                q0 += u[k] * u[k] * inv_hd;
+                si.Lam[sidx_u(D, k, k)] += inv_hd;
+            }
+            si.inv_hd = 0;
+            si.q0 = q0;
+        }
         si.ldR = row[T::oLd];
         si.dim = row[T::oDim];
         si.ok = row[T::oOk] != (R)0;

@@ -12,6 +12,7 @@
 // No inter-workgroup communication inside a launch, so no spin-waits and a deterministic combination tree.
 #pragma once
 #include <algorithm>
+#include <type_traits>
 #include <cstdlib>
 
 #include "ctx.h"
@@ -893,10 +894,76 @@ template <class Op, int D> int run_affine(auxssm_ctx* h, const typename Op::Args
     return AUXSSM_OK;
 }
 
+// ---- few sequences: the scan as TILES OF 256 ELEMENTS, Kogge-Stone inside a tile (round 4) -----------------------------------------------------------------
+// The chunked scan above is work-efficient (two combines per element) but DEEP: at one C2 sequence (n = 65535, fp64 d = 4) its three launches walk 11 + (21 + 8 + 21) + 12
+// dependent combines of ~3.5 us each -- 280 us during which one to sixteen waves of a 1024-SIMD chip work.  When the whole problem is at most two tiles per CU, depth is
+// what costs, not work: every element gets a lane, a workgroup scans its 256 elements in eight Kogge-Stone levels (LDS exchange, as k_scan_aggs), the tile totals are
+// scanned by k_scan_aggs (eight more levels, one workgroup per sequence) and a third launch applies each tile's exclusive prefix to the elements' local prefixes:
+// 8 + 8 + 1 combines deep, n log2(256) combines of work.  Same operator, another (fixed, deterministic) association order: results agree with the chunked scan to rounding.
+constexpr int TB_KS = 256;
+inline bool use_ks_scan(const auxssm_ctx* h, int S, int n, int parallel) {
+    static const int mode = [] { const char* e = getenv("AUXSSM_KS_SCAN"); return e ? atoi(e) : 1; }();  // 0 off, 1 auto, 2 always (tests)
+    if (!parallel || mode == 0 || n < 2 * TB_KS) return false;
+    const long long tiles = (long long)S * ((n + TB_KS - 1) / TB_KS);
+    return mode == 2 || tiles <= 2ll * h->num_cu;
+}
+template <class Op>
+__global__ void __launch_bounds__(TB_KS) k_ks_tile(typename Op::Args a, typename Op::R* __restrict__ incl, typename Op::R* __restrict__ tagg, int n, int ntile) {
+    if (memo_skip(a)) return;
+    resolve_step(a);
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    R* lds = (R*)smem;
+    const int s = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+    const int tid = threadIdx.x;
+    const int i = tile * TB_KS + tid;
+    const bool live = i < n;
+    Full acc;
+    Op::identity(acc);
+    if (live) Op::load_elem(a, s, i, acc);
+    for (int off = 1; off < TB_KS; off <<= 1) {
+        Op::store_rec(lds + tid * Full::NPAD, acc);
+        __syncthreads();
+        Full left;
+        if (tid >= off) Op::load_rec(lds + (tid - off) * Full::NPAD, left);
+        __syncthreads();
+        if (tid >= off) {
+            Full o;
+            Op::combine(left, acc, o);
+            acc = o;
+        }
+    }
+    if (live) Op::store_rec(incl + ((long long)s * n + i) * Full::NPAD, acc);
+    if (tid == TB_KS - 1) Op::store_rec(tagg + ((long long)s * ntile + tile) * Full::NPAD, acc);  // (dead lanes hold the identity: the last tile's total is its last live prefix)
+}
+template <class Op>
+__global__ void __launch_bounds__(TB_KS) k_ks_down(typename Op::Args a, const typename Op::R* __restrict__ incl, const typename Op::R* __restrict__ tpre, int n, int ntile) {
+    if (memo_skip(a)) return;
+    resolve_step(a);
+    using R = typename Op::R;
+    using Full = typename Op::Full;
+    using Pre = typename Op::Pre;
+    const int s = blockIdx.x / ntile, tile = blockIdx.x % ntile;
+    const int i = tile * TB_KS + threadIdx.x;
+    if (i >= n) return;
+    Pre p, o;
+    Full e;
+    Op::load_pre(tpre + ((long long)s * ntile + tile) * Pre::NPAD, p);
+    Op::load_rec(incl + ((long long)s * n + i) * Full::NPAD, e);
+    Op::apply(p, e, o);
+    Op::write_out(a, s, i, o);
+}
+
 template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
     const ScanPlan pl = plan_scan(h, S, n, parallel);
-    if (pl.nchunk <= 1) return 0;
-    return (size_t)S * pl.nchunk * (Op::Full::NPAD + Op::Pre::NPAD) * sizeof(typename Op::R) + 512;
+    size_t b = 0;
+    if (use_ks_scan(h, S, n, parallel)) {
+        const size_t ntile = (size_t)(n + TB_KS - 1) / TB_KS;
+        b += ((size_t)S * n * Op::Full::NPAD + (size_t)S * ntile * (Op::Full::NPAD + Op::Pre::NPAD)) * sizeof(typename Op::R) + 1024;
+    }
+    if (pl.nchunk <= 1) return b;
+    return b + (size_t)S * pl.nchunk * (Op::Full::NPAD + Op::Pre::NPAD) * sizeof(typename Op::R) + 512;
 }
 inline ScanLayout make_layout(const ScanPlan& pl, int cm, int S) {
     const int W = pl.nchunk < 64 ? pl.nchunk : 64;
@@ -921,6 +988,20 @@ int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
+    if (!lay.cm && std::is_same<Op, DownOp>::value && std::is_same<Op, ReduceOp>::value && use_ks_scan(h, S, n, lay.nchunk > 1)) {
+        // few sequences: tiles of 256 elements, Kogge-Stone inside a tile (above)
+        const int ntile = (n + TB_KS - 1) / TB_KS;
+        R* incl = (R*)ws_take(h, (size_t)S * n * Op::Full::NPAD * sizeof(R));
+        ScanBufs tb{ws_take(h, (size_t)S * ntile * Op::Full::NPAD * sizeof(R)), ws_take(h, (size_t)S * ntile * Op::Pre::NPAD * sizeof(R)), a.memo};
+        if (!incl || !tb.agg || !tb.pre) return AUXSSM_ERR_NOMEM;
+        const size_t lds = (size_t)TB_KS * Op::Full::NPAD * sizeof(R);
+        static_assert(TB_KS == TB_AGGS, "k_scan_aggs shares the tile's LDS plan");
+        hipLaunchKernelGGL((k_ks_tile<Op>), dim3((unsigned)S * ntile), dim3(TB_KS), lds, h->stream, a, incl, (R*)tb.agg, n, ntile);
+        hipLaunchKernelGGL((k_scan_aggs<Op>), dim3(S), dim3(TB_AGGS), lds, h->stream, tb, ntile);
+        hipLaunchKernelGGL((k_ks_down<Op>), dim3((unsigned)S * ntile), dim3(TB_KS), 0, h->stream, a, (const R*)incl, (const R*)tb.pre, n, ntile);
+        AX_HIP(hipGetLastError());
+        return AUXSSM_OK;
+    }
     ScanBufs sb{nullptr, nullptr, a.memo};
     const unsigned grid = lay.cm ? (unsigned)((S + TB_CM - 1) / TB_CM) * lay.nchunk : (unsigned)S * lay.ngrp;
     const size_t stage = stage_bytes<R>(Op::Full::NPAD);

@@ -588,6 +588,39 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
                 pass
         out["runs"].append(ent)
         del dl, yd, ms, Ps, ell
+    # "benchmark both" -- the same grid as the reference's spatial example actually runs it (examples/spatial/model.py:103-112, auxiliary_kalman.py:18-28):
+    # B = 64 INDEPENDENT scalar LGSSMs on the batch axis, dx = dy = 1, through the per-lane register kernels.  HBM-bound: K3 bytes of SURVEY 8(d) with d = 1
+    # (read 3 d^2 + 2 d, write d^2 + d reals per element and sequence) against the filter scan's launch-group time.
+    out["batched_scalar"] = []
+    try:
+        from aux_ssm_samplers_amd.workloads import c5_batched_model
+        for Tb, Cb in ((1024, 64), (T, 16)):
+            ub, lgb, xb = c5_batched_model(Tb)
+            B = ub.shape[1]
+            dlb = DeviceLGSSM(handle, tuple(lgb), 1, Tb, B, 1, 1, True, f32)    # parameters shared by the Cb sequences of observations (chain stride 0), batch axis B
+            ysb = (ub[None] + np.concatenate([np.zeros((1, Tb, B, 1)), 0.3 * np.random.default_rng(5).standard_normal((Cb - 1, Tb, B, 1))])).astype(f32)
+            ydb = handle.to_device(ysb)
+            yarrb = ydb.arr(Tb * B, B, 1)
+            msb, Psb, ellb = handle.empty((Cb, Tb, B, 1), f32), handle.empty((Cb, Tb, B, 1, 1), f32), handle.empty((Cb,), f32)
+            dimsb = _lib.Dims(Cb, Tb, B, 1, 1)
+
+            def stepb(k):
+                _lib.check(handle.lib.auxssm_kalman_filter(handle.h, _lib.F32, C.byref(dimsb), C.byref(dlb.c), C.byref(yarrb), 1, msb.ptr, Psb.ptr, ellb.ptr))
+
+            el, groups = ctx.timed(stepb, max(steps, 5), 1)
+            nst = max(steps, 5)
+            scan = groups.get("filter_scan", (0, 0.0))[1] / nst
+            alg = Cb * B * (Tb - 1) * (5 + 2) * 4                                # K3 at d = 1: (3 + 2) reals read, (1 + 1) written, fp32
+            ent = dict(sequences=Cb, batch=B, T=Tb, scalar_filters_per_s=round(Cb * B * ctx.world * nst / el, 1), ms_per_call=round(el / nst * 1e3, 4),
+                       kernels={g: round(t / nst, 4) for g, (n, t) in groups.items()})
+            if scan:
+                ent["roofline"] = dict(bound="hbm", achieved=round(alg / (scan * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
+                                       frac=round(alg / (scan * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None, kernel="filter scan, d = 1 (k_scan_reduce / k_scan_aggs / k_scan_down)",
+                                       avg_launch_ms=round(scan, 4), algorithmic_bytes_per_launch=alg)
+            out["batched_scalar"].append(ent)
+            del dlb, ydb, msb, Psb, ellb
+    except Exception as e:
+        out["batched_scalar"] = {"error": f"{type(e).__name__}: {e}"}
     # one whole pass of the path on one chain (filter -> pathwise sampler -> joint log-density, what a sweep of this size strings together):
     # device time of each launch group (HIP events), host <-> device copies of the NumPy front end excluded
     try:

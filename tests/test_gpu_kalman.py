@@ -130,6 +130,54 @@ def test_all_scan_levels_time_varying(P, d, T, dtype):
         npt.assert_allclose(seq[2], ell, rtol=1e-10)
 
 
+@pytest.mark.parametrize("d,T", [(2, 4097), (4, 3000)])
+def test_tile_scan_of_few_sequences_equals_the_chunked_scan(P, d, T):
+    """Few sequences take the Kogge-Stone tile scan (kernels.hip.h::k_ks_tile: at most two tiles of 256 elements per CU), many the chunked three-launch scan: the same
+    model as ONE sequence (tile scan) and as 48 copies on the chain axis (chunked scan: 48 x 17 tiles > 512) gives the same filter and the same pathwise sample to rounding,
+    NaN rows included; the sequential recursion agrees with both."""
+    rng = np.random.default_rng(T + d)
+    p = d + 1
+    Fs = 0.6 * rng.standard_normal((T - 1, d, d)) / np.sqrt(d)
+    A = rng.standard_normal((T - 1, d, 2 * d))
+    Qs = A @ A.transpose(0, 2, 1) / (2 * d) + 0.1 * np.eye(d)
+    bs = rng.standard_normal((T - 1, d))
+    Hs = rng.standard_normal((T, p, d))
+    Rs = np.broadcast_to(0.3 * np.eye(p), (T, p, p))
+    cs = rng.standard_normal((T, p))
+    ys = rng.standard_normal((T, p))
+    ys[rng.random(T) < 0.1] = np.nan
+    ys[0] = rng.standard_normal(p)
+    lg = P.LGSSM(rng.standard_normal(d), np.eye(d), Fs, Qs, bs, Hs, Rs, cs)
+    ms1, Ps1, ell1 = P.filtering(ys, lg, True)                               # one sequence: tiles
+    seq = P.filtering(ys, lg, False)
+    npt.assert_allclose(ms1, seq[0], rtol=1e-9, atol=1e-10)
+    npt.assert_allclose(Ps1, seq[1], rtol=1e-9, atol=1e-10)
+    npt.assert_allclose(ell1, seq[2], rtol=1e-10)
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    import ctypes as C
+    h = _lib.default_handle()
+    Cn = 48
+    dl = DeviceLGSSM(h, tuple(lg), 1, T, 1, d, p, False, np.float64)
+    yd = h.to_device(np.ascontiguousarray(np.broadcast_to(ys, (Cn, T, p))))
+    yarr = yd.arr(T * p, p, 0)
+    ms, Ps, ell = h.empty((Cn, T, 1, d), np.float64), h.empty((Cn, T, 1, d, d), np.float64), h.empty((Cn,), np.float64)
+    dims = _lib.Dims(Cn, T, 1, d, p)
+    h.set_option(_lib.OPT_SHARE_MODEL, 0)                                    # (per-sequence matrix recursions: the general scan, not the gain form)
+    try:
+        _lib.check(h.lib.auxssm_kalman_filter(h.h, _lib.F64, C.byref(dims), C.byref(dl.c), C.byref(yarr), 1, ms.ptr, Ps.ptr, ell.ptr))
+    finally:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    msh, Psh, ellh = ms.to_host(), Ps.to_host(), ell.to_host()
+    for c in (0, 17, 47):
+        npt.assert_allclose(msh[c, :, 0], ms1, rtol=1e-9, atol=1e-10)
+        npt.assert_allclose(Psh[c, :, 0], Ps1, rtol=1e-9, atol=1e-10)
+        npt.assert_allclose(ellh[c], ell1, rtol=1e-10)
+    eps = rng.standard_normal((T, d))
+    x1 = P.sampling(None, ms1, Ps1, lg, True, eps=eps)
+    npt.assert_allclose(x1, P.sampling(None, ms1, Ps1, lg, False, eps=eps), rtol=1e-8, atol=1e-9)
+
+
 def _lg_concat(T, d, dtype=np.float64):
     from aux_ssm_samplers_amd.kalman import LGConcatModel
     m = lg_model(T, d, dtype=dtype)
