@@ -605,6 +605,10 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     // chain-shared parameters: the filtered covariances do not depend on the chain and are stored once, (T, D, D) dense with chain stride 0
     const bool shared_mode = !wide && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0);
     const bool aux_fly = cm && T > 1 && !wide && aux_fly_enabled();  // u and the concatenated observations of t >= 1 are formed inside the filter
+    // a time-invariant real observation model (time stride 0 on Hs, Rs, cs: the broadcast views of a constant model) gives a time-invariant concatenated one: ONE
+    // record with time stride 0 instead of T of them (C2 at one chain: 54 MB written and read back per sweep, 27 of its 240 us)
+    const bool tinv = model->Hs.st == 0 && model->Rs.st == 0 && model->cs.st == 0;
+    const int Tm = tinv ? 1 : T;
     // Chain-shared sweep with a host step size: the MODEL STAGE (concatenated observation model here, matrix filter + gain table in
     // run_filter_shared) reads neither a chain nor anything the previous sweep wrote, so it goes to the side stream with its own double-buffered
     // slab (ctx.h::SideStage) and overlaps the chain passes of the sweep before; its products -- Hc, Rc, cc, the shared covariances, the gain
@@ -660,10 +664,10 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     }
     {
         ProfScope ps(h, AUXSSM_K_FACTORY);
-        const long long n1 = (long long)T * (P * D + P * P + P);
+        const long long n1 = (long long)Tm * (P * D + P * P + P);
         {
             SideScope sc(h);  // (model stage)
-            hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO,
+            hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, Tm, D, PO,
                                cv(model->Hs), cv(model->Rs), cv(model->cs), (R)(0.5 * delta), dptr, Hc, Rc, cc);
         }
         const int Tc = aux_fly ? 1 : T;
@@ -672,9 +676,9 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
                            xA, epsauxA, (R)sqrt(0.5 * delta), dptr, cv(*yobs), uA, yscA, cm);
     }
     auxssm_lgssm gc = *model;
-    gc.Hs = auxssm_arr{Hc, 0, (int64_t)P * D, 0};
-    gc.Rs = auxssm_arr{Rc, 0, (int64_t)P * P, 0};
-    gc.cs = auxssm_arr{cc, 0, (int64_t)P, 0};
+    gc.Hs = auxssm_arr{Hc, 0, tinv ? 0 : (int64_t)P * D, 0};
+    gc.Rs = auxssm_arr{Rc, 0, tinv ? 0 : (int64_t)P * P, 0};
+    gc.cs = auxssm_arr{cc, 0, tinv ? 0 : (int64_t)P, 0};
     const auxssm_arr ysc_dummy{ysc, (int64_t)T * P, (int64_t)P, 0};
     auxssm_dims dc = *dims;
     dc.dy = P;
@@ -836,6 +840,8 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
         overlap = h->side.open;
     }
     R *Hc, *Rc, *cc, *Ps;
+    const bool tinv = model->Hs.st == 0 && model->Rs.st == 0 && model->cs.st == 0;  // time-invariant observation model: one concatenated record (sweep_lg_concat)
+    const int Tm = tinv ? 1 : T;
     const int* memo = nullptr;
     struct MemoGuard {  // a sweep that fails after claiming its slab's tables leaves nobody's tables behind
         auxssm_ctx* h;
@@ -897,8 +903,8 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
         Ps = (R*)ws_take(h, (size_t)T * D * D * sR);
         if (!Hc || !Rc || !cc || !Ps) return AUXSSM_ERR_NOMEM;
         ProfScope ps(h, AUXSSM_K_FACTORY);
-        const long long n1 = (long long)T * (P * D + P * P + P);
-        hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, T, D, PO, cv(model->Hs), cv(model->Rs), cv(model->cs),
+        const long long n1 = (long long)Tm * (P * D + P * P + P);
+        hipLaunchKernelGGL((k_concat_model<R>), dim3((unsigned)((n1 + 255) / 256)), dim3(256), 0, h->stream, Tm, D, PO, cv(model->Hs), cv(model->Rs), cv(model->cs),
                            (R)(0.5 * delta), dptr, Hc, Rc, cc, memo);
     }
     // row 0 of the two normal draws and the acceptance uniforms (the rest is drawn inside passes A and C), then u_0 and [u_0 ; yobs_0]
@@ -907,9 +913,9 @@ static int sweep_lg_concat_fused(auxssm_ctx* h, int dtype, const auxssm_dims* di
                        (const R*)eps0a, (R)sqrt(0.5 * delta), dptr, cv(*yobs), u, ysc0);
     FusedHost f{};
     auxssm_lgssm gc = *model;
-    gc.Hs = auxssm_arr{Hc, 0, (int64_t)P * D, 0};
-    gc.Rs = auxssm_arr{Rc, 0, (int64_t)P * P, 0};
-    gc.cs = auxssm_arr{cc, 0, (int64_t)P, 0};
+    gc.Hs = auxssm_arr{Hc, 0, tinv ? 0 : (int64_t)P * D, 0};
+    gc.Rs = auxssm_arr{Rc, 0, tinv ? 0 : (int64_t)P * P, 0};
+    gc.cs = auxssm_arr{cc, 0, tinv ? 0 : (int64_t)P, 0};
     const auxssm_arr ysc_dummy{ysc0, (int64_t)P, (int64_t)P, 0};
     auxssm_dims dc = *dims;
     dc.dy = P;

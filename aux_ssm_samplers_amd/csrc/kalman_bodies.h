@@ -200,7 +200,7 @@ template <typename R> AX_HD UniformRow<R> uniform_row(const R* p) { return p; }
 template <typename R_, int D> struct FilterOp;
 // ---- scan element for transition i -> i+1 (filtering.py:188-250) ---------------------------------
 template <typename R, int D, int P, class IO, int P1 = 0>
-AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool valid) {
+AX_HD void filter_build_elem(const FilterArgs& a, IO& io, int s, int i, bool valid, FiltElem<R, D>& e) {
     const int c = s / a.d.B, b = s % a.d.B;
     const long long t = (long long)i + 1;
     R F[D * D], bd[D], m_[D], P_[D * D], H[P * D], cv[P], y[P], Rm[P * P];
@@ -235,10 +235,14 @@ AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool vali
 #pragma unroll
         for (int k = 0; k < D; ++k) m_[k] = bd[k];
     }
-    FiltElem<R, D> e;
     if constexpr (P1 > 0 && P1 < P) filter_elem_blk<R, D, P, P1>(F, bd, m_, P_, H, cv, Rm, y, e);
     else filter_elem<R, D, P>(F, bd, m_, P_, H, cv, Rm, y, e);
-    FilterOp<R, D>::store_elem(a, s, i, e);
+}
+template <typename R, int D, int P, class IO, int P1 = 0>
+AX_HD void body_filter_init(const FilterArgs& a, IO& io, int s, int i, bool valid) {
+    FiltElem<R, D> e;
+    filter_build_elem<R, D, P, IO, P1>(a, io, s, i, valid, e);
+    if (valid) FilterOp<R, D>::store_elem(a, s, i, e);
 }
 
 // ---- scan operator: parallel filter ----------------------------------------------------------------

@@ -955,6 +955,15 @@ __global__ void __launch_bounds__(TB_KS) k_ks_down(typename Op::Args a, const ty
     Op::write_out(a, s, i, o);
 }
 
+// the tile scan's filter operator builds its elements itself (filtering.py:188-250 inside k_ks_tile: no k_filter_init launch, no element buffer written and read back)
+template <typename R_, int D, int P, int P1> struct FilterOpBuild : FilterOp<R_, D> {
+    using Full = typename FilterOp<R_, D>::Full;
+    static __device__ __forceinline__ void load_elem(const FilterArgs& a, int s, int i, Full& e) {
+        DirectIO io;
+        filter_build_elem<R_, D, P, DirectIO, P1>(a, io, s, i, true, e);
+    }
+};
+
 template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
     const ScanPlan pl = plan_scan(h, S, n, parallel);
     size_t b = 0;
@@ -1084,11 +1093,12 @@ template <typename R, int D, int P> int build_gain_table(auxssm_ctx* h, FilterAr
         am.ys = Arr{a.ys.ptr, 0, a.ys.st, 0, a.ys.se};  // chain 0's observations
     }
     am.lay = make_layout(plan_scan(h, 1, n, 1), 0, 1);
-    am.elem = ws_take(h, (size_t)am.lay.total_reals(n, 1, FiltElem<R, D>::NPAD) * sizeof(R));
-    if (!am.elem) return AUXSSM_ERR_NOMEM;
+    const bool ks1 = n > 0 && use_ks_scan(h, 1, n, am.lay.nchunk > 1);  // (one sequence: the tile scan builds its own elements)
+    am.elem = ks1 ? nullptr : ws_take(h, (size_t)am.lay.total_reals(n, 1, FiltElem<R, D>::NPAD) * sizeof(R));
+    if (!ks1 && !am.elem) return AUXSSM_ERR_NOMEM;
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3(1), dim3(TB_ELEM), 0, h->stream, am);
-    hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(ntiles(n), 1)), dim3(TB_ELEM), 0, h->stream, am);
-    const int rc = run_scan<FilterOp<R, D>>(h, am, 1, n);
+    if (!ks1) hipLaunchKernelGGL((k_filter_init<R, D, P>), dim3(grid_tile_seq(ntiles(n), 1)), dim3(TB_ELEM), 0, h->stream, am);
+    const int rc = ks1 ? run_scan<FilterOpBuild<R, D, P, 0>>(h, am, 1, n) : run_scan<FilterOp<R, D>>(h, am, 1, n);
     if (rc) return rc;
     a.tab = ws_take(h, (size_t)n * GainRow<R, D, P>::NPAD * sizeof(R));
     if (!a.tab) return AUXSSM_ERR_NOMEM;
@@ -1171,12 +1181,17 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
             return AUXSSM_OK;
         }
     }
-    a.elem = ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
+    const bool ks = !cm && n > 0 && use_ks_scan(h, S, n, a.lay.nchunk > 1);  // few sequences: the tile scan, which builds its own elements (FilterOpBuild)
+    a.elem = ks ? nullptr : ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final
     // pass writes it per sequence; the reference's second pass over the filtered moments (filtering.py:60-62) does not exist here
     a.ellz = ws_take(h, (size_t)S * sizeof(R));
     const int nt = cm ? a.lay.nchunk : ntiles(n);
-    if (n > 0) {
+    if (ks) {
+        ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+        const int rc = blk ? run_scan<FilterOpBuild<R, D, P, (P > D ? D : 0)>>(h, a, S, n) : run_scan<FilterOpBuild<R, D, P, 0>>(h, a, S, n);
+        if (rc) return rc;
+    } else if (n > 0) {
         {
             ProfScope ps(h, AUXSSM_K_FILTER_INIT);
             if (cm && blk) hipLaunchKernelGGL((k_filter_init_cm<R, D, P, (P > D ? D : 0)>), dim3(grid_cm(S, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, TI_CM);
@@ -1193,6 +1208,8 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
         const int ntl = ntiles(n);
         R* part = (R*)ws_take(h, (size_t)S * ntl * sizeof(R));
         if (!part) return AUXSSM_ERR_NOMEM;
+        // (tried: this pass on a fork stream beside the sampler / the next filter -- nothing reads ell before the accept step.  The two event hops per filter cost
+        // more than the 16 us they hide: C4 at 8 chains 37.9k -> 35.0k sweeps/s.  Not kept.)
         hipLaunchKernelGGL((k_ell_pass<R, D, P>), dim3(grid_tile_seq(ntl, S)), dim3(TB_ELEM), 0, h->stream, a, part, ntl);
         hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)part, (const R*)a.ell0, a.d.B, ntl, (R*)ell_out);
         AX_HIP(hipGetLastError());
@@ -1243,6 +1260,15 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
         a.elem = nullptr;
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
         const int rc = run_scan<SampleOp<R, D>, SampleOpFly<R, D>, SampleOpFly<R, D>>(h, a, S, T);
+        if (rc) return rc;
+        AX_HIP(hipGetLastError());
+        return AUXSSM_OK;
+    }
+    if (!cm && !a.ps_packed && use_ks_scan(h, S, T, a.lay.nchunk > 1)) {
+        // few sequences: the tile scan builds its own elements (SampleOpFly::load_elem): no k_sample_init launch, no element buffer
+        a.elem = nullptr;
+        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
+        const int rc = run_scan<SampleOpFly<R, D>>(h, a, S, T);
         if (rc) return rc;
         AX_HIP(hipGetLastError());
         return AUXSSM_OK;
