@@ -3,15 +3,19 @@
 // What the chain-shared sweep of affine_shared.h moved per chain and time step (reals of d components; 8.06 GB at C2 / 256 chains, fp64):
 //   filter reduce  r x, w eps_aux | filter down r x, r eps_aux, w ms | sampler reduce r ms, w eps_samp | sampler down r ms, r eps_samp, w x'
 //   log-density r x, r x', r eps_aux | select r x', w x                                                  = 15 d
-// Here (7 d = 3.76 GB):
-//   A  (k_fs_a)  r x            w u      filter fold of the chunk; draws eps_aux, u = x + sqrt(delta/2) eps; the MH terms of the CURRENT state x
-//                                         (prior, observation, auxiliary: kalman/generic.py:88-89, :103-105) where x and eps are in registers
-//   C  (k_fs_c)  r u            w inc    filter walk (means; the marginal log-likelihood comes from an identity, see k_fs_accept) AND, in the same ascending walk, the
-//                                         sampler's increments inc_t = M1_t m_t - gb_t + Lc_t eps_t (sampling.py:108-112; draws eps_samp) together with
-//                                         the sampler's chunk aggregate e = sum_t (G_ta ... G_{t-1}) inc_t -- the composition of the reverse affine maps
-//                                         x_t = G_t x_{t+1} + inc_t (sampling.py:51-55) accumulated FORWARD in time against a chain-shared table of the
-//                                         within-chunk prefix products of the gains (k_fs_gpre), so the filtered means never go to memory
-//   E  (k_fs_e)  r inc, r u     w x'     sampler walk (descending), the MH terms of the PROPOSAL x' where it is in registers
+// Round 3 (7 d = 3.76 GB): A (r x, w u), C (r u, w inc), E (r inc, r u, w x').  Round 4 (6 d = 3.22 GB): passes A and C are ONE pass --
+//   AC (k_fs_ac) r x            w u, inc0  draws eps_aux, u = x + sqrt(delta/2) eps; the MH terms of the CURRENT state x (prior, observation, auxiliary:
+//                                         kalman/generic.py:88-89, :103-105); the filter's chunk fold h_t = Mb h_{t-1} + kc + K u_t FROM A ZERO START (the chunk's first
+//                                         mean is not known yet), which is at the same time the chunk-LOCAL filtered mean: m_t = h_t + Phi_t m_start with the
+//                                         chain-shared prefix product Phi_t of the chunk's Mb (k_fs_fprod); and, in the same walk, the sampler's LOCAL increments
+//                                         inc0_t = M1_t h_t - gb_t + Lc_t eps_t (sampling.py:108-112; draws eps_samp) with their chunk aggregate
+//                                         e0 = sum_t (G_ta ... G_{t-1}) inc0_t against the table of within-chunk gain products (k_fs_gpre)
+//   --  (k_aff_aggs, k_fs_esfix)          m_start of every (chain, chunk) by the aggregate scan of the folds; the sampler's aggregates completed by the part that is
+//                                         linear in m_start: e = e0 + Psi_chunk m_start, Psi = sum_t (G_ta ... G_{t-1}) M1_t Phi_t (chain-shared, k_fs_psi)
+//   E  (k_fs_e)  r inc0, r u    w x'      sampler walk (descending) x'_t = G_t x'_{t+1} + inc0_t + N_t m_start, N_t = M1_t Phi_t (in the pass's coefficient row), and the MH
+//                                         terms of the PROPOSAL x' where it is in registers
+// The filtered means never go to memory, u is written once and read once, and the chain passes are two kernels bound by HBM (AC: 3 d at 615 instructions per
+// chain-step; E: 3 d) instead of three.
 // plus the two aggregate scans (k_aff_aggs, unchanged), one lane per chain for the t = 0 terms (k_fs_head) and the accept step (k_fs_accept).
 // There is no select pass: with a `sel` array the state is LAZY -- chain c lives in buffer sel[c] of a ping-pong pair, reads its x from there, writes
 // its proposal to the other buffer, and acceptance flips sel[c] (auxssm_kalman_sweep_lazy); without one, x' goes to a scratch buffer and the
@@ -26,7 +30,7 @@ struct FusedArgs {
     const void* xa;      // (T, D, C) chain-minor; chain c reads its state from xa (sel null or sel[c] == 0) or xb,
     void* xb;            //                         and writes its proposal to the other one
     const int32_t* sel;
-    void* u;             // (T, D, C): row 0 written by the caller, rows >= 1 by k_fs_a
+    void* u;             // (T, D, C): row 0 written by the caller, rows >= 1 by k_fs_ac
     void* inc;           // (T, D, C)
     const void* gain;    // n rows GainRow<R, D, P>      (transition i -> i + 1)
     const void* samp;    // T rows SampShared<R, D>
@@ -55,15 +59,19 @@ AX_HD void fs_resolve(FusedArgs& a) {
 __device__ __forceinline__ bool fs_decode(const FusedArgs& a, int& ch, int& s) { return decode_aff(a.C, a.nchunk, ch, s); }
 
 // ---- model stage: chunk products of the filter's matrices; within-chunk prefix products + chunk products of the sampler's gains ------------
-template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_fs_fprod(FusedArgs a, R* __restrict__ cprod) {
+template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_fs_fprod(FusedArgs a, R* __restrict__ cprod, R* __restrict__ fpre) {
     if (memo_skip(a)) return;
     using TG = GainRow<R, D, P>;
     const int ch = blockIdx.x * TB_CM + threadIdx.x;
     if (ch >= a.nchunk) return;
-    const int ta = max(1, ch * a.E), tb = min(a.T, (ch + 1) * a.E);
+    const int t0 = ch * a.E, ta = max(1, t0), tb = min(a.T, t0 + a.E);
     R M[D * D];
 #pragma unroll
     for (int k = 0; k < D * D; ++k) M[k] = (k / D == k % D) ? (R)1 : (R)0;
+    if (ch == 0) {
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) fpre[k] = 0;  // t = 0
+    }
     for (int t = ta; t < tb; ++t) {
         const R* row = (const R*)a.gain + (long long)(t - 1) * TG::NPAD;
         R G[D * D], o[D * D];
@@ -72,12 +80,15 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_CM) k_f
         mm<R, D, D, D>(G, M, o);
 #pragma unroll
         for (int k = 0; k < D * D; ++k) M[k] = o[k];
+        // Phi_t = Mb_{t-1} ... Mb_{ta-1}: what the chunk's (unknown) first mean contributes to the mean at t.  Chunk 0 starts from the true m_0: nothing to add.
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) fpre[(long long)t * D * D + k] = ch == 0 ? (R)0 : M[k];
     }
 #pragma unroll
     for (int k = 0; k < D * D; ++k) cprod[(long long)ch * D * D + k] = M[k];
 }
 template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_gpre(FusedArgs a, R* __restrict__ gpre, R* __restrict__ cprod) {
-    if (memo_skip(a)) return;
+    if (memo_skip(a)) return;  // (k_fs_psi below completes the chain-shared tables)
     using TS = SampShared<R, D>;
     const int ch = blockIdx.x * TB_CM + threadIdx.x;
     if (ch >= a.nchunk) return;
@@ -101,6 +112,52 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_gpre(
     for (int k = 0; k < D * D; ++k) cprod[(long long)(a.nchunk - 1 - ch) * D * D + k] = M[k];
 }
 
+// N_t = M1_t Phi_t (the sampler increment's dependence on the chunk's first mean) and Psi_chunk = sum_t (G_ta ... G_{t-1}) N_t (the same for the sampler's chunk aggregate)
+template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_psi(FusedArgs a, const R* __restrict__ gpre, const R* __restrict__ fpre, R* __restrict__ ntab,
+                                                                              R* __restrict__ psi) {
+    if (memo_skip(a)) return;
+    using TS = SampShared<R, D>;
+    const int ch = blockIdx.x * TB_CM + threadIdx.x;
+    if (ch >= a.nchunk) return;
+    const int t0 = ch * a.E, tb = min(a.T, t0 + a.E);
+    R Ps[D * D];
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) Ps[k] = 0;
+    for (int t = t0; t < tb; ++t) {
+        const R* row = (const R*)a.samp + (long long)t * TS::NPAD;
+        R M1[D * D], Ph[D * D], Gp[D * D], Nt[D * D], o[D * D];
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) M1[k] = row[TS::oM + k], Ph[k] = fpre[(long long)t * D * D + k], Gp[k] = gpre[(long long)t * D * D + k];
+        mm<R, D, D, D>(M1, Ph, Nt);
+        mm<R, D, D, D>(Gp, Nt, o);
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) ntab[(long long)t * D * D + k] = Nt[k], Ps[k] += o[k];
+    }
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) psi[(long long)ch * D * D + k] = Ps[k];
+}
+// the sampler's chunk aggregates completed: e(chain, chunk) += Psi_chunk m_start(chain, chunk) (the scan position of the sampler is reversed time)
+template <typename R, int D> __global__ void __launch_bounds__(256) k_fs_esfix(int C, int nchunk, const R* __restrict__ psi, const R* __restrict__ pre_f, R* __restrict__ agg_s) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (long long)C * nchunk) return;
+    const int ch = (int)(g / C), c = (int)(g % C);
+    if (ch == 0) return;  // (Psi_0 = 0)
+    R m[D], e[D], Ps[D * D];
+    ldv<R, D>(pre_f + ((long long)c * nchunk + ch) * SampPre<R, D>::NPAD, m);
+    R* q = agg_s + ((long long)c * nchunk + (nchunk - 1 - ch)) * SampPre<R, D>::NPAD;
+    ldv<R, D>(q, e);
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) Ps[k] = psi[(long long)ch * D * D + k];
+#pragma unroll
+    for (int i = 0; i < D; ++i) {
+        R v = e[i];
+#pragma unroll
+        for (int k = 0; k < D; ++k) v += Ps[i * D + k] * m[k];
+        e[i] = v;
+    }
+    stv<R, D>(q, e);
+}
+
 // ---- compact per-pass rows (model stage) ----------------------------------------------------------------------------------------------------
 // The passes wait for their chain-shared coefficients more than they compute: read straight from the tables with scalar loads every chunk streams ~1 KB
 // of rows per step through the scalar cache with no reuse, i.e. a dozen dependent L2 round trips per step (measured: pass C 0.92 ms against a VALU
@@ -111,29 +168,19 @@ template <typename R, int D, int PO> struct FsRows {
     using TL = LogShared<R, D, PO>;
     static constexpr int VEC = 16 / sizeof(R);
     static constexpr int pad(int n) { return (n + VEC - 1) / VEC * VEC; }
-    // pass A, row i = t - 1 (t >= 1): [Mb | kc | K[:, :D] | LogShared row i]
-    static constexpr int aM = 0, aKc = D * D, aK = aKc + D, aL = aK + D * D, NA = pad(aL + TL::N);
-    // pass C, row t (t >= 0; the filter part of row 0 is zero): [Mb | kc | K[:, :D] | M1 | gb | Lc (lower, packed) | gpre]   (no innovation coefficients: the
-    // log-likelihood is not walked, k_fs_accept)
-    static constexpr int cM = 0, cKc = D * D, cK = cKc + D, cM1 = cK + D * D, cGb = cM1 + D * D, cL = cGb + D, cGp = cL + symsize(D), NC = pad(cGp + D * D);
-    // pass E, row t: [G_t | LogShared row t (transition t -> t + 1, observation at t + 1; zero for t = T - 1)]
-    static constexpr int eG = 0, eL = D * D, NE = pad(eL + TL::N);
+    // pass AC, row t (t >= 0): [Mb | kc | K[:, :D] of transition t - 1 -> t | M1_t | gb_t | Lc_t (lower, packed) | gpre_t | LogShared row t - 1]; the filter and
+    // log-density parts of row 0 are zero (no transition into t = 0)
+    static constexpr int cM = 0, cKc = D * D, cK = cKc + D, cM1 = cK + D * D, cGb = cM1 + D * D, cL = cGb + D, cGp = cL + symsize(D), cLg = cGp + D * D,
+                         NC = pad(cLg + TL::N);
+    // pass E, row t: [G_t | N_t = M1_t Phi_t | LogShared row t (transition t -> t + 1, observation at t + 1; zero for t = T - 1)]
+    static constexpr int eG = 0, eN = D * D, eL = 2 * D * D, NE = pad(eL + TL::N);
 };
 // where element k of a compact row comes from: {table (0 gain row t - 1, 1 sampler row t, 2 log-density row t - 1, 3 gpre row t, 4 log-density row t,
-// -1 zero), offset}.  Evaluated per element by one thread, so that consecutive threads write consecutive reals of the destination rows.
+// 5 N row t, -1 zero), offset}.  Evaluated per element by one thread, so that consecutive threads write consecutive reals of the destination rows.
 struct FsSrc { int tab, off; };
-template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_a(int k) {
-    constexpr int P = D + PO;
-    using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TL = LogShared<R, D, PO>;
-    if (k < F::aKc) return {0, TG::oM + k};
-    if (k < F::aK) return {0, TG::oKc + (k - F::aKc)};
-    if (k < F::aL) { const int q = k - F::aK; return {0, TG::oK + (q / D) * P + (q % D)}; }
-    if (k < F::aL + TL::N) return {2, k - F::aL};
-    return {-1, 0};
-}
 template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_c(int k) {
     constexpr int P = D + PO;
-    using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>;
+    using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>; using TL = LogShared<R, D, PO>;
     if (k < F::cKc) return {0, TG::oM + k};
     if (k < F::cK) return {0, TG::oKc + (k - F::cKc)};
     if (k < F::cM1) { const int q = k - F::cK; return {0, TG::oK + (q / D) * P + (q % D)}; }
@@ -145,35 +192,36 @@ template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_c(i
         while (lidx(i + 1, 0) <= q) ++i;
         return {1, TS::oL + i * D + (q - lidx(i, 0))};
     }
-    if (k < F::cGp + D * D) return {3, k - F::cGp};
+    if (k < F::cLg) return {3, k - F::cGp};
+    if (k < F::cLg + TL::N) return {2, k - F::cLg};
     return {-1, 0};
 }
 template <typename R, int D, int PO> __device__ __forceinline__ FsSrc fs_src_e(int k) {
     using F = FsRows<R, D, PO>; using TS = SampShared<R, D>; using TL = LogShared<R, D, PO>;
-    if (k < F::eL) return {1, TS::oG + k};
+    if (k < F::eN) return {1, TS::oG + k};
+    if (k < F::eL) return {5, k - F::eN};
     if (k < F::eL + TL::N) return {4, k - F::eL};
     return {-1, 0};
 }
-// one thread per destination element: blockIdx.y picks the row family (0 A, 1 C, 2 E), the flat index runs over (t, k)
-template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_rows(FusedArgs a, R* __restrict__ ra, R* __restrict__ rc, R* __restrict__ re) {
+// one thread per destination element: blockIdx.y picks the row family (0 AC, 1 E), the flat index runs over (t, k)
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_rows(FusedArgs a, const R* __restrict__ ntab, R* __restrict__ rc, R* __restrict__ re) {
     if (memo_skip(a)) return;
     constexpr int P = D + PO;
     using F = FsRows<R, D, PO>; using TG = GainRow<R, D, P>; using TS = SampShared<R, D>; using TL = LogShared<R, D, PO>;
     const int fam = blockIdx.y;
-    const int N = fam == 0 ? F::NA : fam == 1 ? F::NC : F::NE;
+    const int N = fam == 0 ? F::NC : F::NE;
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
-    const long long rows = fam == 0 ? a.T - 1 : a.T;
-    if (g >= rows * N) return;
-    const int r = (int)(g / N), k = (int)(g % N);
-    const int t = fam == 0 ? r + 1 : r;
-    const FsSrc sc = fam == 0 ? fs_src_a<R, D, PO>(k) : fam == 1 ? fs_src_c<R, D, PO>(k) : fs_src_e<R, D, PO>(k);
+    if (g >= (long long)a.T * N) return;
+    const int t = (int)(g / N), k = (int)(g % N);
+    const FsSrc sc = fam == 0 ? fs_src_c<R, D, PO>(k) : fs_src_e<R, D, PO>(k);
     R v = 0;
     if (sc.tab == 0) { if (t >= 1) v = ((const R*)a.gain)[(long long)(t - 1) * TG::NPAD + sc.off]; }
     else if (sc.tab == 1) v = ((const R*)a.samp)[(long long)t * TS::NPAD + sc.off];
-    else if (sc.tab == 2) v = ((const R*)a.logt)[(long long)(t - 1) * TL::NPAD + sc.off];
+    else if (sc.tab == 2) { if (t >= 1) v = ((const R*)a.logt)[(long long)(t - 1) * TL::NPAD + sc.off]; }
     else if (sc.tab == 3) v = ((const R*)a.gpre)[(long long)t * D * D + sc.off];
     else if (sc.tab == 4) { if (t + 1 < a.T) v = ((const R*)a.logt)[(long long)t * TL::NPAD + sc.off]; }
-    (fam == 0 ? ra : fam == 1 ? rc : re)[g] = v;
+    else if (sc.tab == 5) v = ntab[(long long)t * D * D + sc.off];
+    (fam == 0 ? rc : re)[g] = v;
 }
 
 // the chain-shared part of log q(x' | u): x'_t | x'_{t+1} = G_t x'_{t+1} + M1_t m_t - gb_t + Lc_t eps_t, so log q = sum_t (-1/2 |eps_t|^2 - sum_i log Lc_t[i][i] - D/2 log 2 pi).
@@ -343,95 +391,11 @@ __device__ __forceinline__ bool fs_terms_fast(const R* row, const R* v, const R*
 }
 __device__ __forceinline__ bool fs_wave_any(bool flag) { return __builtin_amdgcn_ballot_w64(flag) != 0; }
 
-// ---- pass A ---------------------------------------------------------------------------------------------------------------------------
+// ---- pass AC --------------------------------------------------------------------------------------------------------------------------
 #ifndef AUXSSM_FS_WPE_A
 #define AUXSSM_FS_WPE_A 2
 #endif
-template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUXSSM_FS_WPE_A))) k_fs_a(FusedArgs a, const R* __restrict__ rows) {
-    using F = FsRows<R, D, PO>;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    R* lds = (R*)smem;
-    fs_resolve(a);
-    int ch, c;
-    fs_block(a, ch, c);
-    const long long C = a.C;
-    const int ta = max(1, ch * a.E), tb = min(a.T, (ch + 1) * a.E);
-    const FsNormTab<R> ntab = fs_stage_normtab<R>(lds + (size_t)a.E * F::NA);
-    fs_stage<R, F::NA>(rows, ta - 1, tb - 1, lds);
-    if (c >= a.C) return;
-    const R* xr = (const R*)((a.sel && a.sel[c]) ? (const void*)a.xb : a.xa) + c;
-    R* up = (R*)a.u + c;
-    R h[D], xq[D];
-#pragma unroll
-    for (int k = 0; k < D; ++k) {
-        h[k] = ch == 0 ? ((const R*)a.m0p)[k * C + c] : (R)0;
-        xq[k] = xr[((long long)(ta - 1) * D + k) * C];
-    }
-    const R shd = (R)a.shd, inv_delta = (R)1 / (R)a.delta;
-    const R cst = (R)-0.5 * (R)D * log_((R)(0.5 * a.delta)) - (R)(0.5 * LOG_2PI) * (R)D;
-    Acc v0 = 0, v1 = 0, v2 = 0;
-    R xn[D];  // the next step's state, fetched one step ahead
-#pragma unroll
-    for (int k = 0; k < D; ++k) xn[k] = xr[((long long)ta * D + k) * C];
-#pragma unroll 1
-    for (int t = ta; t < tb; ++t) {
-        const int tu = opaque_uniform(t);
-        const R* row = lds + (tu - ta) * F::NA;
-        R x[D], ev[D], u[D];
-#pragma unroll
-        for (int k = 0; k < D; ++k) x[k] = xn[k];
-        if (t + 1 < tb) {
-            const int tn = opaque_uniform(t + 1);
-#pragma unroll
-            for (int k = 0; k < D; ++k) xn[k] = xr[((long long)tn * D + k) * C];
-        }
-        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + c, C, ev, ntab);
-#pragma unroll
-        for (int k = 0; k < D; ++k) {
-            u[k] = x[k] + shd * ev[k];
-            up[((long long)tu * D + k) * C] = u[k];
-        }
-        asm volatile("" ::: "memory");
-        // the MH terms of the current state; the rare wave with a non-finite value anywhere redoes them under the per-term policy and masks u for the fold
-        R w[3], um[D];
-        const bool bad = fs_terms_fast<R, D, PO>(row + F::aL, x, xq, u, inv_delta, cst, w);
-#pragma unroll
-        for (int k = 0; k < D; ++k) um[k] = u[k];
-        if (fs_wave_any(bad)) {
-            fs_terms<R, D, PO>(a, row + F::aL, x, xq, u, inv_delta, cst, w);
-#pragma unroll
-            for (int k = 0; k < D; ++k) um[k] = finite_(u[k]) ? u[k] : (R)0;
-        }
-        v0 += (Acc)w[0];
-        v1 += (Acc)w[1];
-        v2 += (Acc)w[2];
-        asm volatile("" ::: "memory");  // keep the fold's LDS reads behind the log-density row's: hoisted together they cost 200 registers
-        {  // filter fold (FilterMeanOp::fold, folded rows): h <- Mb h + kc + K[:, :D] u
-            R o[D];
-#pragma unroll
-            for (int r = 0; r < D; ++r) {
-                R v = row[F::aKc + r];
-#pragma unroll
-                for (int k = 0; k < D; ++k) v += row[F::aM + r * D + k] * h[k];
-#pragma unroll
-                for (int k = 0; k < D; ++k) v += row[F::aK + r * D + k] * um[k];
-                o[r] = v;
-            }
-#pragma unroll
-            for (int r = 0; r < D; ++r) h[r] = o[r];
-        }
-#pragma unroll
-        for (int k = 0; k < D; ++k) xq[k] = x[k];
-    }
-    stv<R, D>((R*)a.agg_f + ((long long)c * a.nchunk + ch) * SampPre<R, D>::NPAD, h);
-    a.pa[((long long)0 * C + c) * a.nchunk + ch] = v0;
-    a.pa[((long long)1 * C + c) * a.nchunk + ch] = v1;
-    a.pa[((long long)2 * C + c) * a.nchunk + ch] = v2;
-}
-
-// ---- pass C ---------------------------------------------------------------------------------------------------------------------------
-template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_c(FusedArgs a, const R* __restrict__ rows) {
-    constexpr int P = D + PO;
+template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUXSSM_FS_WPE_A))) k_fs_ac(FusedArgs a, const R* __restrict__ rows) {
     using F = FsRows<R, D, PO>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     R* lds = (R*)smem;
@@ -443,19 +407,21 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
     const FsNormTab<R> ntab = fs_stage_normtab<R>(lds + (size_t)a.E * F::NC);
     fs_stage<R, F::NC>(rows, t0, tb, lds);
     if (c >= a.C) return;
-    const R* up = (const R*)a.u + c;
+    const R* xr = (const R*)((a.sel && a.sel[c]) ? (const void*)a.xb : a.xa) + c;
+    R* up = (R*)a.u + c;
     R* ip = (R*)a.inc + c;
-    R m[D], es[D];
-    if (ch == 0) {
+    R h[D], xq[D], es[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) m[k] = ((const R*)a.m0p)[k * C + c];
-    } else {
-        ldv<R, D>((const R*)a.pre_f + ((long long)c * a.nchunk + ch) * SampPre<R, D>::NPAD, m);
+    for (int k = 0; k < D; ++k) {
+        h[k] = ch == 0 ? ((const R*)a.m0p)[k * C + c] : (R)0;  // chunk 0 folds from the true m_0; the others from zero (their first mean comes from the aggregate scan)
+        xq[k] = xr[((long long)(ta - 1) * D + k) * C];
+        es[k] = 0;
     }
-#pragma unroll
-    for (int k = 0; k < D; ++k) es[k] = 0;
-    // one sampler increment: inc = M1 m - gb + Lc eps (SampleAffOp::step without the G h term), stored, and folded into the chunk aggregate
-    R se = 0;  // sum |eps|^2 over the chunk's steps: the data part of log q(x' | u)
+    const R shd = (R)a.shd, inv_delta = (R)1 / (R)a.delta;
+    const R cst = (R)-0.5 * (R)D * log_((R)(0.5 * a.delta)) - (R)(0.5 * LOG_2PI) * (R)D;
+    Acc v0 = 0, v1 = 0, v2 = 0;
+    R se = 0;  // sum |eps_samp|^2 over the chunk's steps: the data part of log q(x' | u)
+    // one LOCAL sampler increment: inc0 = M1 h - gb + Lc eps (SampleAffOp::step without the G term, with the chunk-local mean h), stored, and folded into the chunk aggregate
     auto emit = [&](int tu, const R* row, const R* eps) {
         R inc[D];
 #pragma unroll
@@ -464,7 +430,7 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
         for (int i = 0; i < D; ++i) {
             R v = -row[F::cGb + i];
 #pragma unroll
-            for (int k = 0; k < D; ++k) v += row[F::cM1 + i * D + k] * m[k];
+            for (int k = 0; k < D; ++k) v += row[F::cM1 + i * D + k] * h[k];
 #pragma unroll
             for (int k = 0; k <= i; ++k) v += row[F::cL + lidx(i, k)] * eps[k];
             inc[i] = v;
@@ -484,46 +450,68 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
         for (int k = 0; k < D; ++k) eps[k] = ((const R*)a.eps0s)[k * C + c];
         emit(0, lds, eps);
     }
-    R yn[D];  // the next step's auxiliary variable, fetched one step ahead
+    R xn[D];  // the next step's state, fetched one step ahead
 #pragma unroll
-    for (int k = 0; k < D; ++k) yn[k] = ta < tb ? up[((long long)ta * D + k) * C] : (R)0;
+    for (int k = 0; k < D; ++k) xn[k] = ta < tb ? xr[((long long)ta * D + k) * C] : (R)0;
 #pragma unroll 1
     for (int t = ta; t < tb; ++t) {
         const int tu = opaque_uniform(t);
         const R* row = lds + (tu - t0) * F::NC;
-        R y[D], eps[D];
+        R x[D], ev[D], u[D];
 #pragma unroll
-        for (int k = 0; k < D; ++k) y[k] = yn[k];
+        for (int k = 0; k < D; ++k) x[k] = xn[k];
         if (t + 1 < tb) {
             const int tn = opaque_uniform(t + 1);
 #pragma unroll
-            for (int k = 0; k < D; ++k) yn[k] = up[((long long)tn * D + k) * C];
+            for (int k = 0; k < D; ++k) xn[k] = xr[((long long)tn * D + k) * C];
         }
-        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + c, C, eps, ntab);
-        {  // the affine step of the filtered mean (FilterMeanOp::walk_impl without its innovation / log-likelihood half; a missing auxiliary value counts as 0, as there)
+        normals_cm<R, D>(a.ka0, a.ka1, (long long)tu * D * C + c, C, ev, ntab);
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            u[k] = x[k] + shd * ev[k];
+            up[((long long)tu * D + k) * C] = u[k];
+        }
+        asm volatile("" ::: "memory");
+        // the MH terms of the current state; the rare wave with a non-finite value anywhere redoes them under the per-term policy and masks u for the fold
+        R w[3], um[D];
+        const bool bad = fs_terms_fast<R, D, PO>(row + F::cLg, x, xq, u, inv_delta, cst, w);
+#pragma unroll
+        for (int k = 0; k < D; ++k) um[k] = u[k];
+        if (fs_wave_any(bad)) {
+            fs_terms<R, D, PO>(a, row + F::cLg, x, xq, u, inv_delta, cst, w);
+#pragma unroll
+            for (int k = 0; k < D; ++k) um[k] = finite_(u[k]) ? u[k] : (R)0;
+        }
+        v0 += (Acc)w[0];
+        v1 += (Acc)w[1];
+        v2 += (Acc)w[2];
+        asm volatile("" ::: "memory");  // keep the fold's LDS reads behind the log-density row's: hoisted together they cost 200 registers
+        {  // filter fold (FilterMeanOp::fold, folded rows): h <- Mb h + kc + K[:, :D] u -- the chunk aggregate at the end, the chunk-local filtered mean on the way
             R o[D];
-            R ysum = y[0];
 #pragma unroll
-            for (int k = 1; k < D; ++k) ysum += y[k];
-            if (fs_wave_any(!finite_(ysum))) {  // (rare: see fs_terms_fast)
+            for (int r = 0; r < D; ++r) {
+                R v = row[F::cKc + r];
 #pragma unroll
-                for (int k = 0; k < D; ++k) y[k] = finite_(y[k]) ? y[k] : (R)0;
+                for (int k = 0; k < D; ++k) v += row[F::cM + r * D + k] * h[k];
+#pragma unroll
+                for (int k = 0; k < D; ++k) v += row[F::cK + r * D + k] * um[k];
+                o[r] = v;
             }
 #pragma unroll
-            for (int k = 0; k < D; ++k) {
-                R v = row[F::cKc + k];
-#pragma unroll
-                for (int j = 0; j < D; ++j) v += row[F::cM + k * D + j] * m[j];
-#pragma unroll
-                for (int l = 0; l < D; ++l) v += row[F::cK + k * D + l] * y[l];
-                o[k] = v;
-            }
-#pragma unroll
-            for (int k = 0; k < D; ++k) m[k] = o[k];
+            for (int r = 0; r < D; ++r) h[r] = o[r];
         }
+        asm volatile("" ::: "memory");
+        R eps[D];
+        normals_cm<R, D>(a.ks0, a.ks1, (long long)tu * D * C + c, C, eps, ntab);
         emit(tu, row, eps);
+#pragma unroll
+        for (int k = 0; k < D; ++k) xq[k] = x[k];
     }
+    stv<R, D>((R*)a.agg_f + ((long long)c * a.nchunk + ch) * SampPre<R, D>::NPAD, h);
     stv<R, D>((R*)a.agg_s + ((long long)c * a.nchunk + (a.nchunk - 1 - ch)) * SampPre<R, D>::NPAD, es);
+    a.pa[((long long)0 * C + c) * a.nchunk + ch] = v0;
+    a.pa[((long long)1 * C + c) * a.nchunk + ch] = v1;
+    a.pa[((long long)2 * C + c) * a.nchunk + ch] = v2;
     ((R*)a.pell)[(long long)c * a.nchunk + ch] = (R)-0.5 * se;
 }
 
@@ -542,7 +530,13 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
     R* xw = (R*)((a.sel && a.sel[c]) ? const_cast<void*>(a.xa) : a.xb) + c;
     const R* up = (const R*)a.u + c;
     const R* ip = (const R*)a.inc + c;
-    R h[D], uq[D];
+    R h[D], uq[D], mst[D];  // mst: the chunk's first filtered mean (aggregate scan of the folds): the part of the increments pass AC could not know
+    if (ch > 0) {
+        ldv<R, D>((const R*)a.pre_f + ((long long)c * a.nchunk + ch) * SampPre<R, D>::NPAD, mst);
+    } else {
+#pragma unroll
+        for (int k = 0; k < D; ++k) mst[k] = 0;
+    }
     if (ch == a.nchunk - 1) {
 #pragma unroll
         for (int k = 0; k < D; ++k) h[k] = 0, uq[k] = 0;  // G_{T-1} = 0: the first position ignores the incoming state
@@ -572,6 +566,8 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
 #pragma unroll
         for (int i = 0; i < D; ++i) {
             R v = inc[i];
+#pragma unroll
+            for (int k = 0; k < D; ++k) v += row[F::eN + i * D + k] * mst[k];
 #pragma unroll
             for (int k = 0; k < D; ++k) v += row[F::eG + i * D + k] * h[k];
             xp[i] = v;
@@ -677,7 +673,7 @@ template <typename R, int D, int PO> size_t fused_ws(const auxssm_ctx* h, const 
     // model stage (side slab when the stage overlaps, else this one): matrix filter, gain / sampler / log-density tables, chunk products
     b += filter_ws<R, D, P>(h, KDims{1, d.T, 1}, 1);
     b += (size_t)d.T * (SampShared<R, D>::NPAD + LogShared<R, D, PO>::NPAD + (size_t)D * D) * sizeof(R) + (size_t)2 * nchunk * D * D * sizeof(R) + 10 * 256 + ((size_t)d.T / 256 + 2) * sizeof(Acc);
-    b += (size_t)d.T * (FsRows<R, D, PO>::NA + FsRows<R, D, PO>::NC + FsRows<R, D, PO>::NE) * sizeof(R) + 4 * 256;
+    b += (size_t)d.T * (FsRows<R, D, PO>::NC + FsRows<R, D, PO>::NE + 2 * (size_t)D * D) * sizeof(R) + (size_t)nchunk * D * D * sizeof(R) + 8 * 256;
     return b;
 }
 template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHost& f) {
@@ -693,7 +689,7 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     a.delta = f.la.delta; a.shd = f.la.shd; a.dptr = f.la.dptr; a.nan_policy = f.la.nan_policy;
     a.memo = f.memo;
     f.fa.memo = f.sa.memo = f.la.memo = f.memo;  // the model stage below; cleared before the chain passes (k_filter_t0 serves both)
-    R *cprod_f, *cprod_s, *rows_a, *rows_c, *rows_e;
+    R *cprod_f, *cprod_s, *rows_c, *rows_e, *psi;
     {
         // MODEL STAGE (ctx.h::SideStage when the sweep opened one): everything that reads the model and the step size only
         {
@@ -706,12 +702,14 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
         R* gpre = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
         cprod_f = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
         cprod_s = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
-        rows_a = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NA * sizeof(R));
         rows_c = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NC * sizeof(R));
         rows_e = (R*)ws_take(h, (size_t)T * FsRows<R, D, PO>::NE * sizeof(R));
+        R* fpre = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+        R* ntab = (R*)ws_take(h, (size_t)T * D * D * sizeof(R));
+        psi = (R*)ws_take(h, (size_t)a.nchunk * D * D * sizeof(R));
         const int nclb = (T + 255) / 256;
         Acc* clog = (Acc*)ws_take(h, 256 + (size_t)nclb * sizeof(Acc));  // [0] the sum, [32 ...) the partial sums
-        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s || !rows_a || !rows_c || !rows_e || !clog) return AUXSSM_ERR_NOMEM;
+        if (!f.sa.tab || !f.la.tab || !gpre || !cprod_f || !cprod_s || !rows_c || !rows_e || !fpre || !ntab || !psi || !clog) return AUXSSM_ERR_NOMEM;
         a.clog = clog;
         a.gain = f.fa.tab; a.samp = f.sa.tab; a.logt = f.la.tab; a.gpre = gpre;
         {
@@ -720,12 +718,13 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
             hipLaunchKernelGGL((k_fs_clog_part<R, D>), dim3(nclb), dim3(256), 0, h->stream, T, (const R*)f.sa.tab, clog + 32, f.memo);
             hipLaunchKernelGGL((k_fs_clog_sum<D>), dim3(1), dim3(256), 0, h->stream, T, nclb, (const Acc*)(clog + 32), clog, f.memo);
             hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, f.la);
-            hipLaunchKernelGGL((k_fs_fprod<R, D, P>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod_f);
+            hipLaunchKernelGGL((k_fs_fprod<R, D, P>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, cprod_f, fpre);
             hipLaunchKernelGGL((k_fs_gpre<R, D>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, gpre, cprod_s);
+            hipLaunchKernelGGL((k_fs_psi<R, D>), dim3((a.nchunk + TB_CM - 1) / TB_CM), dim3(TB_CM), 0, h->stream, a, (const R*)gpre, (const R*)fpre, ntab, psi);
             {
                 using F = FsRows<R, D, PO>;
-                const long long nmax = (long long)T * (F::NC > F::NA ? (F::NC > F::NE ? F::NC : F::NE) : (F::NA > F::NE ? F::NA : F::NE));
-                hipLaunchKernelGGL((k_fs_rows<R, D, PO>), dim3((unsigned)((nmax + 255) / 256), 3), dim3(256), 0, h->stream, a, rows_a, rows_c, rows_e);
+                const long long nmax = (long long)T * (F::NC > F::NE ? F::NC : F::NE);
+                hipLaunchKernelGGL((k_fs_rows<R, D, PO>), dim3((unsigned)((nmax + 255) / 256), 2), dim3(256), 0, h->stream, a, (const R*)ntab, rows_c, rows_e);
             }
         }
     }
@@ -753,13 +752,16 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     const unsigned grid = (unsigned)a.nchunk * (unsigned)((C + TBF - 1) / TBF);
     const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
     {
+        const size_t lds_ac = (size_t)a.E * F::NC * sizeof(R) + FsNormTabSel<R>::BYTES;
+        if (lds_ac > 64 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_fs_ac<R, D, PO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ac));
         ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
-        hipLaunchKernelGGL((k_fs_a<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NA * sizeof(R) + FsNormTabSel<R>::BYTES, h->stream, a, (const R*)rows_a);
-        hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_f, a.pre_f}, (const R*)cprod_f, a.nchunk);
+        hipLaunchKernelGGL((k_fs_ac<R, D, PO>), dim3(grid), dim3(TBF), lds_ac, h->stream, a, (const R*)rows_c);
     }
     {
-        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
-        hipLaunchKernelGGL((k_fs_c<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NC * sizeof(R) + FsNormTabSel<R>::BYTES, h->stream, a, (const R*)rows_c);
+        ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);  // the two aggregate scans: first means of the chunks, then (completed by Psi m_start) the sampler's chunk starts
+        hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_f, a.pre_f}, (const R*)cprod_f, a.nchunk);
+        hipLaunchKernelGGL((k_fs_esfix<R, D>), dim3((unsigned)(((long long)C * a.nchunk + 255) / 256)), dim3(256), 0, h->stream, C, a.nchunk, (const R*)psi, (const R*)a.pre_f,
+                           (R*)a.agg_s);
         hipLaunchKernelGGL((k_aff_aggs<R, D>), dim3(C), dim3(TB_AGGS), lds, h->stream, ScanBufs{a.agg_s, a.pre_s}, (const R*)cprod_s, a.nchunk);
     }
     {
