@@ -140,7 +140,7 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_fs_psi(F
 template <typename R, int D> __global__ void __launch_bounds__(256) k_fs_esfix(int C, int nchunk, const R* __restrict__ psi, const R* __restrict__ pre_f, R* __restrict__ agg_s) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= (long long)C * nchunk) return;
-    const int ch = (int)(g / C), c = (int)(g % C);
+    const int c = (int)(g / nchunk), ch = (int)(g % nchunk);  // (consecutive lanes: consecutive chunks of one chain -- the records of a chain are contiguous)
     if (ch == 0) return;  // (Psi_0 = 0)
     R m[D], e[D], Ps[D * D];
     ldv<R, D>(pre_f + ((long long)c * nchunk + ch) * SampPre<R, D>::NPAD, m);

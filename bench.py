@@ -195,7 +195,8 @@ class Ctx:
             self.barrier()
             self.handle.prof_enable(self.lib.K_ALL, 64 * (pp + 1))
             for k in range(pp):
-                step(k)
+                step(warmup + steps + k)  # its own step indices: a sampler must not see a key twice (the C4 leg replayed its warm-up keys here up to round 3, which
+                                          # drove the chains of the reference's NaN-policy kernel into a corner where they reject: the 0.078 of BENCH_r03)
             self.barrier()
             prof_pass = self.handle.prof_read_groups()
             self.handle.prof_disable()
@@ -240,16 +241,17 @@ def kalman_group_reals(mode, d, po):
     samp = 3 * d * d + d                                           # one SampShared row: G, M1, gb, Lc
     logrow = sym(d) + d * d + d + 1 + po * d + po + 1               # one LogShared row: WQ, WF, wb, cQ, WH, yw, cR
     if mode == "fused":
-        # the chain-shared sweep in three streaming passes on a lazy state (csrc/fused_shared.h, auxssm_kalman_sweep_fused): the library's profiler
-        # files pass A (+ the filter's aggregate scan) under filter_scan, pass C (+ the sampler's aggregate scan) under sample_scan, pass E under
-        # logpdf, the t = 0 terms + accept step under select; no noise buffers, no select pass
+        # the chain-shared sweep in TWO streaming passes on a lazy state (csrc/fused_shared.h, auxssm_kalman_sweep_fused; round 4: passes A and C of round 3 merged):
+        # the library's profiler files pass AC under filter_scan, the two aggregate scans (+ the Psi m_start completion between them) under sample_scan, pass E under
+        # logpdf, the t = 0 terms + accept step under select; no noise buffers, no filtered-mean buffer, no select pass
+        ntab = d * d                                                  # N_t = M1_t Phi_t: the first mean's contribution to an increment
         return {
             "factory": (0, 0, par),
             "filter_tab": (0, 0, par + gain + d * d),
-            "sample_init": (0, 0, 2 * d * d + d + samp + logrow + d * d),  # sampler / log-density tables, within-chunk gain products
-            "filter_scan": (d, d, gain + logrow),                     # pass A: x in, u out (eps_aux drawn in registers; MH terms of x)
-            "sample_scan": (d, d, gain + samp + d * d),               # pass C: u in, sampler increments out (eps_samp drawn in registers; ell)
-            "logpdf": (2 * d, d, samp + logrow),                      # pass E: increments and u in, x' out (MH terms of x')
+            "sample_init": (0, 0, 2 * d * d + d + samp + logrow + 3 * d * d),  # sampler / log-density tables, within-chunk products (gains, filter matrices), N_t
+            "filter_scan": (d, 2 * d, gain + samp + d * d + logrow),  # pass AC: x in, u and the local increments out (eps_aux, eps_samp drawn in registers; MH terms of x)
+            "sample_scan": (0, 0, 0),                                 # aggregate scans: O(C nchunk) work
+            "logpdf": (2 * d, d, samp + ntab + logrow),               # pass E: increments and u in, x' out (MH terms of x')
             "select": (0, 0, 0),                                      # t = 0 terms, accept, selector flip: O(C) work
         }
     if mode == "shared":
@@ -286,8 +288,8 @@ def model_stage_overlapped(mode):
     return mode in ("shared", "fused") and os.environ.get("AUXSSM_OVERLAP_TAB", "1") != "0"
 
 
-FUSED_PASS_NAMES = {"filter_scan": "pass A: k_fs_a (x -> u, filter fold, MH terms of x) + k_aff_aggs",
-                    "sample_scan": "pass C: k_fs_c (u -> sampler increments, filter walk, ell) + k_aff_aggs",
+FUSED_PASS_NAMES = {"filter_scan": "pass AC: k_fs_ac (x -> u, local sampler increments; filter fold = chunk-local means; draws; MH terms of x)",
+                    "sample_scan": "k_aff_aggs x 2 + k_fs_esfix (first means of the chunks, sampler chunk starts)",
                     "logpdf": "pass E: k_fs_e (increments, u -> x', MH terms of x')"}
 
 
@@ -315,7 +317,7 @@ def kalman_rooflines(groups, mode, C, T, d, po, s, steps):
 def pmc_traffic(key):
     """HBM bytes per launch group measured with the PMC counters (profiles/r02_traffic.json, written from committed rocprofv3 --pmc
     passes by tools/pmc_traffic.py); None when no pass exists for these kernels."""
-    for name in ("r03_traffic.json", "r02_traffic.json"):
+    for name in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", name)))
             ent = tj.get(key)
@@ -343,13 +345,13 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
     chains, kernel = chains_obj
     state = KalmanSampler(x=chains, updated=None)
     handle.set_option(_lib.OPT_SHARE_MODEL, int(share))
-    keys = R.split(R.PRNGKey(2024 + ctx.rank + (0 if share else 7919)), steps + warmup + 1)
+    keys = R.split(R.PRNGKey(2024 + ctx.rank + (0 if share else 7919)), steps + warmup + 4)  # (+ the profile pass's own keys: timed())
     delta = 0.5
     mode_hint = "shared" if share and chains.chain_minor and C > 1 else "general"
     # the roofline kernel of either path is the filter's scan (the parallel-in-time scan north_star names; on the shared path it and the sampler's
     # scan are within a few per cent of each other, the model stage is off the critical path)
     def focus(ps):
-        if getattr(chains, "fused", None):  # three streaming passes: the roofline kernel is the longest of them
+        if getattr(chains, "fused", None):  # two streaming passes: the roofline kernel is the longer of them
             cand = {g: v for g, v in ps.items() if g in FUSED_PASS_NAMES}
             if cand:
                 return max(cand, key=cand.get)
@@ -376,14 +378,14 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
                         traffic=traffic, traffic_source=src, kernel=(FUSED_PASS_NAMES[g] if mode == "fused" else f"{g} ({mode} path)"), avg_launch_ms=k["ms_per_step"],
                         launches=int(groups[g][0]), algorithmic_bytes_per_launch=k["algorithmic_bytes_per_step"],
                         share_of_step=round(k["ms_per_step"] / (el / steps * 1e3), 3))
-            if mode == "fused":  # the three passes' VALU-issue fractions from the committed SQ counter passes of this command (tools/pmc_sq.sh): passes A and C
-                # are bound by instruction issue (fp64 Threefry + Box-Muller inside the pass), pass E by HBM -- the HBM fraction alone does not say that
+            if mode == "fused":  # the passes' VALU-issue fractions from the committed SQ counter passes of this command (tools/pmc_sq.sh, tools/sq_fused_summary.py): pass AC
+                # is bound by instruction issue (fp64 Threefry + Box-Muller inside the pass), pass E by HBM -- the HBM fraction alone does not say that
                 try:
-                    tj = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json")))
-                    vi = {q: {kk: tj[f"fused_C2_sq_{q}"][kk] for kk in ("valu_issue_frac", "valu_per_chain_step", "us_per_launch")}
-                          for q in ("pass_A", "pass_C", "pass_E") if f"fused_C2_sq_{q}" in tj}
+                    tj = json.load(open(os.path.join(ROOT, "profiles", "r04_traffic.json")))
+                    vi = {q: {kk: tj[f"fused_C2_sq_{q}"].get(kk) for kk in ("valu_issue_frac", "valu_per_chain_step", "us_per_launch", "waves_per_simd", "core_clock_GHz")}
+                          for q in ("pass_AC", "pass_E") if f"fused_C2_sq_{q}" in tj}
                     if vi and args.dtype == "f64" and (T, d, C) == (65536, 4, 256):
-                        roof["valu_issue"] = dict(vi, source=tj["fused_C2_sq_pass_A"]["source"])
+                        roof["valu_issue"] = dict(vi, source=tj["fused_C2_sq_pass_AC"]["source"])
                 except Exception:
                     pass
             if mode == "general" and g == "filter_scan":
@@ -399,7 +401,7 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
         if tot:
             gbps = tot / (el / steps) / 1e9
             roof["whole_sweep"] = dict(algorithmic_bytes_per_step=int(tot), achieved=round(gbps, 1), frac=round(gbps / HBM_PEAK_GBPS, 4), unit="GB/s",
-                                       note="three chain passes' algorithmic bytes / wall time of a step")
+                                       note="the chain passes' algorithmic bytes (AC + E: six array passes) / wall time of a step")
     out["roofline"] = roof
     return out
 
@@ -421,7 +423,7 @@ def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
     yd = fk.ydev(handle, dtype)
     shd = handle.to_device(np.full(T, np.sqrt(0.25)), dtype)
     m = fk.struct(handle, dtype, T)
-    keys = R.split(R.PRNGKey(77 + ctx.rank), steps + warmup + 1)
+    keys = R.split(R.PRNGKey(77 + ctx.rank), steps + warmup + 4)
 
     def step(k):
         nz = _lib.CsmcNoise()
@@ -502,7 +504,7 @@ def leg_c4(ctx, total_chains=64, T=16384, N=512, steps=20, warmup=3):
         """both samplers on Cn resident chains; `total` chains are what the rate is scaled to (all ranks run the same number of chains)"""
         ch = DeviceChains(handle, np.repeat(xtrue[None], Cn, axis=0).astype(np.float32))
         st = KalmanSampler(x=ch, updated=None)
-        keys = R.split(chain_key(R.PRNGKey(4), lo), ksteps + kwarm + 1)  # the rank's stream is folded from its first global chain id
+        keys = R.split(chain_key(R.PRNGKey(4), lo), ksteps + kwarm + 4)  # the rank's stream is folded from its first global chain id
         el, groups = ctx.timed(lambda k: kernel(keys[k], st, 1e-4), ksteps, kwarm)
         acc = ctx.sum_over_ranks(float(ch.accepted.to_host().sum())) / total
         # fused-sweep lower bound of SURVEY 8(d): x, eps_aux, eps_samp read, x' written per chain-step (the linearised F_t, b_t are functions of x)
@@ -517,7 +519,7 @@ def leg_c4(ctx, total_chains=64, T=16384, N=512, steps=20, warmup=3):
         del ch, st
         cc = CsmcChains(handle, np.repeat(xt[None], Cn, axis=0).astype(np.float32))
         cst = CSMCState(x=cc, updated=None)
-        ckeys = R.split(chain_key(R.PRNGKey(5), lo), 8)
+        ckeys = R.split(chain_key(R.PRNGKey(5), lo), 12)
         el, groups = ctx.timed(lambda k: ck(ckeys[k], cst), csteps, 1)
         alg = Cn * T * N * (d * s + s)
         fwd = groups.get("csmc_fwd", (0, 0.0))[1] / csteps

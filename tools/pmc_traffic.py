@@ -28,12 +28,15 @@ GENERAL = {
     "logpdf": [r"^k_sweep_logpdf_cm<"],
     "filter_tab": [r"^k_obs_info_tab<"],
 }
-# round 3: the chain-shared sweep in three streaming passes (csrc/fused_shared.h); k_aff_aggs runs once for the filter's and once for the sampler's aggregates
+# round 4: the chain-shared sweep in TWO streaming passes (csrc/fused_shared.h: k_fs_ac, k_fs_e) + the two aggregate scans and the Psi completion between them; the
+# model stage is memoised (its kernels return at once in the steady state: their bytes here are what the few REBUILT stages of the profiled run moved, per sweep)
+STAGE_FILTER = [r"^k_filter_t0<", r"^k_filter_init<", r"^k_scan_reduce<ax::FilterOp", r"^k_scan_aggs<ax::FilterOp", r"^k_scan_down<ax::FilterOp", r"^k_ks_tile<ax::FilterOp",
+                r"^k_ks_down<ax::FilterOp", r"^k_gain_tab<", r"^k_mask_obs<", r"^k_copy_cov<", r"^k_memo_"]
 FUSED = {
-    "filter_tab": SHARED["filter_tab"],
-    "sample_init": [r"^k_sample_shared_tab<", r"^k_sweep_logpdf_tab<", r"^k_fs_fprod<", r"^k_fs_gpre<", r"^k_fs_rows<"],
-    "filter_scan": [r"^k_fs_a<", (r"^k_aff_aggs<", 0.5)],
-    "sample_scan": [r"^k_fs_c<", (r"^k_aff_aggs<", 0.5)],
+    "filter_tab": STAGE_FILTER,
+    "sample_init": [r"^k_sample_shared_tab<", r"^k_sweep_logpdf_tab<", r"^k_fs_fprod<", r"^k_fs_gpre<", r"^k_fs_psi<", r"^k_fs_rows<", r"^k_fs_clog"],
+    "filter_scan": [r"^k_fs_ac<"],
+    "sample_scan": [r"^k_aff_aggs<", r"^k_fs_esfix<"],
     "logpdf": [r"^k_fs_e<"],
     "select": [r"^k_fs_head<", r"^k_fs_accept<"],
     "factory": [r"^k_concat_model<", r"^k_fs_concat0<"],
@@ -97,10 +100,10 @@ def mfma_busy(path, key, out_path):
 def main():
     if "--mfma" in sys.argv:  # python tools/pmc_traffic.py --mfma <counter_collection.csv> <key> [--out ...]
         i = sys.argv.index("--mfma")
-        return mfma_busy(sys.argv[i + 1], sys.argv[i + 2], sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r03_traffic.json")
+        return mfma_busy(sys.argv[i + 1], sys.argv[i + 2], sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r04_traffic.json")
     fetch, write, prefix = per_kernel(sys.argv[1]), per_kernel(sys.argv[2]), sys.argv[3]
     cfg = sys.argv[sys.argv.index("--config") + 1] if "--config" in sys.argv else "c2"
-    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r03_traffic.json"
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else "profiles/r04_traffic.json"
     src = f"{sys.argv[1]} + {sys.argv[2]} (FETCH_SIZE x2 per the gfx950 rule, + WRITE_SIZE; mean per dispatch x dispatches per sweep)"
     try:
         out = json.load(open(out_path))
