@@ -901,11 +901,17 @@ template <class Op, int D> int run_affine(auxssm_ctx* h, const typename Op::Args
 // scanned by k_scan_aggs (eight more levels, one workgroup per sequence) and a third launch applies each tile's exclusive prefix to the elements' local prefixes:
 // 8 + 8 + 1 combines deep, n log2(256) combines of work.  Same operator, another (fixed, deterministic) association order: results agree with the chunked scan to rounding.
 constexpr int TB_KS = 256;
-inline bool use_ks_scan(const auxssm_ctx* h, int S, int n, int parallel) {
+// `weight`: the operator's combine relative to the fp32 d = 3 filter combine (measured: that one still gains at four tiles per CU -- C4 at 16 chains 42.6k -> 55.8k
+// sweeps/s -- the fp64 d = 4 one, 4.2 times the record and twice the width, at one tile per CU (C2 at one chain 2.05k -> 4.3k) but not at 16: 14.0k -> 12.1k)
+inline bool use_ks_scan(const auxssm_ctx* h, int S, int n, int parallel, double weight) {
     static const int mode = [] { const char* e = getenv("AUXSSM_KS_SCAN"); return e ? atoi(e) : 1; }();  // 0 off, 1 auto, 2 always (tests)
     if (!parallel || mode == 0 || n < 2 * TB_KS) return false;
     const long long tiles = (long long)S * ((n + TB_KS - 1) / TB_KS);
-    return mode == 2 || tiles <= 2ll * h->num_cu;
+    return mode == 2 || (double)tiles * weight <= 10.0 * h->num_cu;
+}
+template <class Op> inline bool use_ks(const auxssm_ctx* h, int S, int n, int parallel) {
+    const double r = (double)Op::Full::NPAD / 28.0;
+    return use_ks_scan(h, S, n, parallel, (double)sizeof(typename Op::R) / 4.0 * r * sqrt(r));
 }
 template <class Op>
 __global__ void __launch_bounds__(TB_KS) k_ks_tile(typename Op::Args a, typename Op::R* __restrict__ incl, typename Op::R* __restrict__ tagg, int n, int ntile) {
@@ -967,7 +973,7 @@ template <typename R_, int D, int P, int P1> struct FilterOpBuild : FilterOp<R_,
 template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
     const ScanPlan pl = plan_scan(h, S, n, parallel);
     size_t b = 0;
-    if (use_ks_scan(h, S, n, parallel)) {
+    if (use_ks<Op>(h, S, n, parallel)) {
         const size_t ntile = (size_t)(n + TB_KS - 1) / TB_KS;
         b += ((size_t)S * n * Op::Full::NPAD + (size_t)S * ntile * (Op::Full::NPAD + Op::Pre::NPAD)) * sizeof(typename Op::R) + 1024;
     }
@@ -997,7 +1003,7 @@ int run_scan(auxssm_ctx* h, const typename Op::Args& a, int S, int n) {
     using R = typename Op::R;
     if (n <= 0 || S <= 0) return AUXSSM_OK;
     const ScanLayout lay = Op::layout(a);
-    if (!lay.cm && std::is_same<Op, DownOp>::value && std::is_same<Op, ReduceOp>::value && use_ks_scan(h, S, n, lay.nchunk > 1)) {
+    if (!lay.cm && std::is_same<Op, DownOp>::value && std::is_same<Op, ReduceOp>::value && use_ks<Op>(h, S, n, lay.nchunk > 1)) {
         // few sequences: tiles of 256 elements, Kogge-Stone inside a tile (above)
         const int ntile = (n + TB_KS - 1) / TB_KS;
         R* incl = (R*)ws_take(h, (size_t)S * n * Op::Full::NPAD * sizeof(R));
@@ -1093,7 +1099,7 @@ template <typename R, int D, int P> int build_gain_table(auxssm_ctx* h, FilterAr
         am.ys = Arr{a.ys.ptr, 0, a.ys.st, 0, a.ys.se};  // chain 0's observations
     }
     am.lay = make_layout(plan_scan(h, 1, n, 1), 0, 1);
-    const bool ks1 = n > 0 && use_ks_scan(h, 1, n, am.lay.nchunk > 1);  // (one sequence: the tile scan builds its own elements)
+    const bool ks1 = n > 0 && use_ks<FilterOp<R, D>>(h, 1, n, am.lay.nchunk > 1);  // (one sequence: the tile scan builds its own elements)
     am.elem = ks1 ? nullptr : ws_take(h, (size_t)am.lay.total_reals(n, 1, FiltElem<R, D>::NPAD) * sizeof(R));
     if (!ks1 && !am.elem) return AUXSSM_ERR_NOMEM;
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3(1), dim3(TB_ELEM), 0, h->stream, am);
@@ -1181,7 +1187,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
             return AUXSSM_OK;
         }
     }
-    const bool ks = !cm && n > 0 && use_ks_scan(h, S, n, a.lay.nchunk > 1);  // few sequences: the tile scan, which builds its own elements (FilterOpBuild)
+    const bool ks = !cm && n > 0 && use_ks<FilterOp<R, D>>(h, S, n, a.lay.nchunk > 1);  // few sequences: the tile scan, which builds its own elements (FilterOpBuild)
     a.elem = ks ? nullptr : ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final
     // pass writes it per sequence; the reference's second pass over the filtered moments (filtering.py:60-62) does not exist here
@@ -1264,7 +1270,7 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
         AX_HIP(hipGetLastError());
         return AUXSSM_OK;
     }
-    if (!cm && !a.ps_packed && use_ks_scan(h, S, T, a.lay.nchunk > 1)) {
+    if (!cm && !a.ps_packed && use_ks<SampleOp<R, D>>(h, S, T, a.lay.nchunk > 1)) {
         // few sequences: the tile scan builds its own elements (SampleOpFly::load_elem): no k_sample_init launch, no element buffer
         a.elem = nullptr;
         ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
