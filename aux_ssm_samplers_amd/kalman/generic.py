@@ -192,7 +192,7 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
             if dev and (delta.dtype != np.dtype(chains.dtype) or delta.size < 1):
                 raise ValueError("a device-resident delta must be a DeviceArray of one scalar of the chains' dtype")
             k6 = (C.c_uint32 * 6)(*[int(v) for k in keys for v in np.asarray(k, np.uint32).reshape(2)])
-            # chain-shared linear-Gaussian model on chain-minor resident chains: the sweep in three streaming passes on a LAZY state (no select
+            # chain-shared linear-Gaussian model on chain-minor resident chains: the sweep in two streaming passes on a LAZY state (no select
             # pass, no noise buffers).  The library refuses -- before enqueueing anything -- what it cannot run fused; keyed sweeps from then on.
             if chains.fused is not False and eps_aux is None and model.kmodel == _lib.KMODEL_LG_CONCAT and chains.chain_minor:
                 if chains.x_alt is None:

@@ -394,7 +394,7 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
                 roof["k3_equivalent_GBps"] = round(k3 / (k["ms_per_step"] * 1e-3) / 1e9, 1)
                 roof["k3_equivalent_frac"] = round(roof["k3_equivalent_GBps"] / HBM_PEAK_GBPS, 4)
     if roof is not None and mode == "fused":
-        # the whole sweep against the same peak: the algorithmic bytes of all launch groups on the chains' stream (the three passes) over the step time -- beside the
+        # the whole sweep against the same peak: the algorithmic bytes of all launch groups on the chains' stream (the two passes) over the step time -- beside the
         # dominant pass's own fraction, which says little while that pass is bound by instruction issue (valu_issue above)
         chain_groups = [q for q in FUSED_PASS_NAMES if q in kernels]
         tot = sum(kernels[q].get("algorithmic_bytes_per_step", 0) for q in chain_groups)

@@ -218,10 +218,11 @@ int auxssm_kalman_sweep_keyed(auxssm_handle h, int dtype, int model_kind, const 
                               const uint32_t* keys, int parallel, int nan_policy, int layout, void* x, void* eps_aux, void* eps_samp,
                               void* u_acc, int32_t* accepted, void* logs);
 
-/* The keyed LG_CONCAT sweep for chain-shared model parameters in THREE streaming passes over the chains (csrc/fused_shared.h): the draws, the
- * filter, the pathwise sampler and every log-density of the MH ratio (kalman/generic.py:53-106) are folded into a forward pass over x, a forward
- * pass over the auxiliary variables and a backward pass that emits x' -- 7 instead of 15 reads / writes of a (C, T, dx) array per sweep, no
- * eps_aux / eps_samp buffers at all.  Same keys -> same draws as auxssm_kalman_sweep_keyed; x' and the five log terms agree with it to rounding
+/* The keyed LG_CONCAT sweep for chain-shared model parameters in TWO streaming passes over the chains (csrc/fused_shared.h; three up to round 3): the draws, the
+ * filter, the pathwise sampler and every log-density of the MH ratio (kalman/generic.py:53-106) are folded into a forward pass over x that emits the auxiliary
+ * variables and the sampler's chunk-local increments, and a backward pass that emits x' -- 6 instead of 15 reads / writes of a (C, T, dx) array per sweep, no
+ * eps_aux / eps_samp buffers at all.  The chain-independent model stage of the sweep is memoised on the device: rebuilt only when the model arrays, the data or the
+ * step size differ byte for byte from what its tables were built from (no host synchronisation).  Same keys -> same draws as auxssm_kalman_sweep_keyed; x' and the five log terms agree with it to rounding
  * (the per-chain totals are summed in a different order).
  *   x, x_alt : two (T, dx, C) chain-minor buffers.
  *   sel == NULL : x is the state (in / out), x_alt scratch for the proposals (accepted chains are copied back by the usual select pass).
