@@ -97,6 +97,7 @@ def load():
         "auxssm_prof_disable": ([vp], C.c_int),
         "auxssm_kalman_filter": ([vp, i32, P(Dims), P(Lgssm), P(Arr), i32, vp, vp, vp], C.c_int),
         "auxssm_kalman_sample": ([vp, i32, P(Dims), P(Lgssm), vp, vp, vp, i32, vp], C.c_int),
+        "auxssm_kalman_dnc_sample": ([vp, i32, P(Dims), P(Lgssm), vp, vp, vp, vp], C.c_int),
         "auxssm_kalman_joint_logpdf": ([vp, i32, P(Dims), P(Lgssm), P(Arr), P(Arr), i32, vp], C.c_int),
         "auxssm_kalman_sweep": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), dbl, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),
         "auxssm_kalman_sweep_dd": ([vp, i32, i32, P(Dims), P(Lgssm), P(Arr), vp, i32, i32, i32, vp, vp, vp, vp, vp, vp], C.c_int),

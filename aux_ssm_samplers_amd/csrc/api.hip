@@ -1799,6 +1799,27 @@ int auxssm_kalman_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, co
     return e->sample(h, a, parallel);
 }
 
+int auxssm_kalman_dnc_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm, const void* ms, const void* Ps, const void* eps, void* xs) {
+    AX_NEED_H(h);
+    int rc;
+    if ((rc = check_dtype(dtype)) || (rc = check_dims(dims, false))) return rc;
+    if (!lgssm || !ms || !Ps || !eps || !xs || (dims->T > 1 && (!lgssm->Fs.ptr || !lgssm->Qs.ptr || !lgssm->bs.ptr))) {
+        set_error("lgssm(Fs,Qs,bs)/ms/Ps/eps/xs must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    if (dims->B != 1) {  // dnc_sampling.py:42-43
+        set_error("Batched sampling is not supported for this function. Use auxssm_kalman_sample instead.");
+        return AUXSSM_ERR_ARG;
+    }
+    if (dims->dx > MAX_D) {
+        set_error("the divide-and-conquer sampler is instantiated for dx <= %d (dx = %d)", MAX_D, dims->dx);
+        return AUXSSM_ERR_UNSUPPORTED;
+    }
+    const KDims kd{dims->C, dims->T, 1};
+    return run_dnc(h, dtype, dims->C, dims->T, dims->dx, cv(lgssm->Fs), cv(lgssm->Qs), cv(lgssm->bs), dense_arr(ms, kd, dims->dx),
+                   dense_arr(Ps, kd, (long long)dims->dx * dims->dx), eps, xs);
+}
+
 int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
                                const auxssm_arr* ys, const auxssm_arr* xs, int nan_policy, void* out) {
     AX_NEED_H(h);

@@ -117,6 +117,8 @@ void* ws_take(auxssm_ctx* h, size_t bytes);
 // model stage on the side stream (see auxssm_ctx::SideStage).  side_open: next parity, slab of at least `need` bytes, the side stream waits for the
 // last sweep that read it; SideScope: launches and ws_take inside the scope go to the side stream / slab (no-op unless a stage is open);
 // side_close: `stream` waits for the stage; side_sweep_end: marks the end of the sweep that consumed it.
+// dnc.hip: the reference's divide-and-conquer pathwise sampler (dx <= 4, B = 1)
+int run_dnc(auxssm_ctx* h, int dtype, int C, int T, int D, const Arr& Fs, const Arr& Qs, const Arr& bs, const Arr& ms, const Arr& Ps, const void* eps, void* xs);
 int side_open(auxssm_ctx* h, size_t need);
 int side_close(auxssm_ctx* h);
 void side_sweep_end(auxssm_ctx* h);

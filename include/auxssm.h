@@ -149,6 +149,13 @@ int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, co
 int auxssm_kalman_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm,
                          const void* ms, const void* Ps, const void* eps, int parallel, void* xs);
 
+/* auxssm_kalman_dnc_sample == dnc_sampling.sampling(key, ms, Ps, lgssm) (_primitives/kalman/dnc_sampling.py:17-77: the divide-and-conquer pathwise sampler --
+ *   leaves _init_elems :128-137, pairwise combination _combination_operator_impl :104-118 with the odd interval carried up :140-169, the two ends :46-68, the
+ *   mid-points level by level :70-86) with the N(0, I) draws given explicitly: eps (C,T,dx) dense, time index t is sampled with eps[:, t].  The reference calls it a
+ *   proof of concept (:38-41); same distribution as auxssm_kalman_sample.  dx <= 4, B must be 1 (:42-43: AUXSSM_ERR_ARG).  -> xs (C,T,dx) dense.
+ *   One stream synchronisation per call (the tree's index plan is uploaded). */
+int auxssm_kalman_dnc_sample(auxssm_handle h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* lgssm, const void* ms, const void* Ps, const void* eps, void* xs);
+
 /* auxssm_kalman_joint_logpdf == log_likelihood(ys, xs, lgssm) + prior_logpdf(xs, lgssm)
  *   (_primitives/kalman/base.py:99-166); posterior_logpdf (:72-96) is this minus ell.
  *   xs (C,T,B,dx) described by an auxssm_arr; out (C). */

@@ -498,3 +498,52 @@ def explicit_smoother(ms, Ps, Fs, Qs, bs):
         sm[t] = ms[t] + K @ (sm[t + 1] - mp)
         sP[t] = Ps[t] + K @ (sP[t + 1] - Pp) @ K.T
     return sm, sP
+
+
+# ---- divide-and-conquer pathwise sampler (reference: _primitives/kalman/dnc_sampling.py) -------------------------------------------------
+def _dnc_init(m, P, F, Q, b):
+    """_init_elems :128-137"""
+    E = np.linalg.solve(F @ P @ F.T + Q, F @ P).T
+    return E, m - E @ (F @ m + b), P - E @ F @ P
+
+
+def _dnc_combine(e1, e2):
+    """_combination_operator_impl :104-118"""
+    E1, g1, L1 = e1
+    E2, g2, L2 = e2
+    E, g, L = E1 @ E2, g1 + E1 @ g2, L1 + E1 @ L2 @ E1.T
+    G = np.linalg.solve(L, E1 @ L2).T
+    return (E, g, L), (G, E2 - G @ E, g2 - G @ g, L2 - G @ L @ G.T)
+
+
+def dnc_sampling(eps, ms, Ps, lgssm):
+    """sampling(key, ms, Ps, lgssm) of dnc_sampling.py:17-77 with explicit noise: time index t is drawn with eps[t] (the reference splits its key per tree level).
+    Tree: make_dnc_tree :172-186 / _combine_elements :140-169 (pairs of neighbouring intervals, the odd last interval carried up unchanged)."""
+    m0, P0, Fs, Qs, bs = lgssm[:5]
+    ms, Ps, eps = np.asarray(ms, np.float64), np.asarray(Ps, np.float64), np.asarray(eps, np.float64)
+    T = ms.shape[0]
+    xs = np.zeros_like(ms)
+    xs[-1] = ms[-1] + np.linalg.cholesky(Ps[-1]) @ eps[-1]
+    if T == 1:
+        return xs
+    elems = [_dnc_init(ms[t], Ps[t], np.asarray(Fs[t], np.float64), np.asarray(Qs[t], np.float64), np.asarray(bs[t], np.float64)) for t in range(T - 1)]
+    iv = [(t, t + 1) for t in range(T - 1)]
+    tree = []
+    while len(elems) > 1:
+        ne, nxt_e, nxt_iv, level = len(elems), [], [], []
+        for p in range(ne // 2):
+            new, aux = _dnc_combine(elems[2 * p], elems[2 * p + 1])
+            nxt_e.append(new)
+            nxt_iv.append((iv[2 * p][0], iv[2 * p + 1][1]))
+            level.append((iv[2 * p][0], iv[2 * p][1], iv[2 * p + 1][1], aux))
+        if ne % 2:
+            nxt_e.append(elems[-1])
+            nxt_iv.append(iv[-1])
+        elems, iv = nxt_e, nxt_iv
+        tree.append(level)
+    E, g, L = elems[0]
+    xs[0] = E @ xs[-1] + g + np.linalg.cholesky(L) @ eps[0]
+    for level in tree[::-1]:
+        for left, mid, right, (G, Gm, w, V) in level:
+            xs[mid] = G @ xs[left] + Gm @ xs[right] + w + np.linalg.cholesky(V) @ eps[mid]
+    return xs

@@ -178,6 +178,57 @@ def test_tile_scan_of_few_sequences_equals_the_chunked_scan(P, d, T):
     npt.assert_allclose(x1, P.sampling(None, ms1, Ps1, lg, False, eps=eps), rtol=1e-8, atol=1e-9)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("T,dx", [(1, 2), (2, 1), (3, 2), (5, 3), (8, 4), (33, 2), (100, 1), (257, 4), (1000, 3)])
+def test_dnc_sampler_device_vs_oracle(T, dx, dtype):
+    """auxssm_kalman_dnc_sample (csrc/dnc.hip: the reference's divide-and-conquer sampler, dnc_sampling.py:17-186) against its NumPy restatement on explicit noise:
+    every tree shape incl. odd interval counts on several levels; same warning, batched input refused as the reference does (:42-43)."""
+    import warnings
+    import aux_ssm_samplers_amd._primitives.kalman as P
+    from aux_ssm_samplers_amd._primitives.kalman import dnc_sampling
+    rng = np.random.default_rng(T * 10 + dx)
+    Fs = 0.7 * rng.standard_normal((max(T - 1, 1), dx, dx)) / np.sqrt(dx)
+    A = rng.standard_normal((max(T - 1, 1), dx, 2 * dx))
+    Qs = A @ A.transpose(0, 2, 1) / (2 * dx) + 0.2 * np.eye(dx)
+    bs = rng.standard_normal((max(T - 1, 1), dx))
+    Hs, Rs, cs = rng.standard_normal((T, 2, dx)), np.broadcast_to(0.5 * np.eye(2), (T, 2, 2)), np.zeros((T, 2))
+    lg = (rng.standard_normal(dx), np.eye(dx), Fs[:T - 1], Qs[:T - 1], bs[:T - 1], Hs, Rs, cs)
+    ms, Ps, _ = K.filtering(rng.standard_normal((T, 2)), lg, False)
+    eps = rng.standard_normal((T, dx))
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        xs = dnc_sampling.sampling(None, ms.astype(dtype), Ps.astype(dtype), P.LGSSM(*[a.astype(dtype) for a in lg]), eps=eps.astype(dtype))
+    assert any("proof-of-concept" in str(x.message) for x in w)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == np.float64 else dict(rtol=5e-4, atol=5e-4)
+    npt.assert_allclose(xs, K.dnc_sampling(eps, ms, Ps, lg), **tol)
+    with pytest.raises(ValueError):
+        dnc_sampling.sampling(None, np.zeros((3, 2, 2)), np.zeros((3, 2, 2, 2)), P.LGSSM(*lg))
+
+
+def test_dnc_sampler_reference_statistical_test():
+    """test_sampling.py::test_parallel_vs_sequential with mode = "dnc" (:23-68) on the device: 200 000 chains in one call (the C entry point takes a chain axis), keyed
+    device noise, against the RTS smoother (`explicit_kalman_smoothing`) at the reference's tolerance (atol = rtol = 1e-2)."""
+    import ctypes as C
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    T, dx, n = 5, 2, 200_000
+    ys, lg = ref_lgssm_inputs(42, T, dx, 3)
+    ms, Ps, _ = K.filtering(ys, lg, False)
+    sm, sP = K.explicit_smoother(ms, Ps, lg[2], lg[3], lg[4])
+    h = _lib.default_handle()
+    dl = DeviceLGSSM(h, list(lg[:5]) + [None, None, None], 1, T, 1, dx, 1, False, np.float64)
+    msd = h.to_device(np.ascontiguousarray(np.broadcast_to(ms, (n, T, dx))))
+    Psd = h.to_device(np.ascontiguousarray(np.broadcast_to(Ps, (n, T, dx, dx))))
+    eps = h.rng_normal(R.PRNGKey(3), 0, (n, T, dx), np.float64)
+    xs = h.empty((n, T, dx), np.float64)
+    dims = _lib.Dims(n, T, 1, dx, 1)
+    _lib.check(h.lib.auxssm_kalman_dnc_sample(h.h, _lib.F64, C.byref(dims), C.byref(dl.c), msd.ptr, Psd.ptr, eps.ptr, xs.ptr))
+    X = xs.to_host()
+    npt.assert_allclose(X.mean(0), sm, atol=1e-2, rtol=1e-2)
+    for t in range(T):
+        npt.assert_allclose(np.cov(X[:, t].T), sP[t], atol=1e-2, rtol=1e-2)
+
+
 def _lg_concat(T, d, dtype=np.float64):
     from aux_ssm_samplers_amd.kalman import LGConcatModel
     m = lg_model(T, d, dtype=dtype)

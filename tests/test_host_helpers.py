@@ -121,21 +121,25 @@ def test_result_files_have_the_reference_schema(tmp_path):
 
 
 @pytest.mark.gpu
-def test_dnc_sampling_mode_reference_statistical_test():
-    """test_sampling.py::test_parallel_vs_sequential (:23-68) runs `dnc` as a third mode against the RTS smoother; so does this"""
+def test_dnc_sampling_keyed_through_the_reference_module_path():
+    """the reference's import path and signature (`aux_samplers._primitives.kalman.dnc_sampling.sampling(key, ms, Ps, lgssm)`, dnc_sampling.py:17) with a KEY: the draw is
+    the explicit-noise draw on the device fill's values for that key, a fresh key gives a fresh draw, and the draws centre on the smoother (the 200 000-draw statistical
+    test at the reference's tolerance is tests/test_gpu_kalman.py::test_dnc_sampler_reference_statistical_test)."""
     from aux_samplers._primitives.kalman import dnc_sampling
     import aux_ssm_samplers_amd._primitives.kalman as P
+    from aux_ssm_samplers_amd import _lib, random as R
     from oracle import kalman_np as K
     from tests.helpers import ref_lgssm_inputs
     ys, lg = ref_lgssm_inputs(42, 5, 2, 3)
     ms, Ps, ell = P.filtering(ys, P.LGSSM(*lg), True)
     sm, sP = K.explicit_smoother(ms, Ps, lg[2], lg[3], lg[4])
-    n = 20000
-    rng = np.random.default_rng(0)
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
-        xs = np.stack([dnc_sampling.sampling(None, ms, Ps, P.LGSSM(*lg), eps=rng.standard_normal(ms.shape)) for _ in range(200)])
+        xs = np.stack([dnc_sampling.sampling(R.PRNGKey(k), ms, Ps, P.LGSSM(*lg)) for k in range(200)])
+        eps = _lib.default_handle().rng_normal(R.PRNGKey(7), 0, (1, 5, 2), np.float64).to_host()[0]
+        npt.assert_array_equal(xs[7], dnc_sampling.sampling(None, ms, Ps, P.LGSSM(*lg), eps=eps))
     assert any("proof-of-concept" in str(x.message) for x in w)
+    assert len({x.tobytes() for x in xs}) == 200
     npt.assert_allclose(xs.mean(0), sm, atol=0.35)
     with pytest.raises(ValueError):
         dnc_sampling.sampling(None, np.zeros((3, 2, 2)), np.zeros((3, 2, 2, 2)), P.LGSSM(*lg))

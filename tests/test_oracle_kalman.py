@@ -137,3 +137,27 @@ def test_posterior_logpdf_is_a_normalised_density_ratio():
     my = Hbig @ mean + cs.ravel()
     Sy = Hbig @ cov @ Hbig.T + block_diag(*Rs)
     npt.assert_allclose(ell, multivariate_normal.logpdf(ys.ravel(), my, Sy), rtol=1e-9)
+
+
+@pytest.mark.parametrize("seed,T,dx", [(42, 3, 1), (666, 5, 2), (7, 6, 3), (8, 9, 2)])
+def test_dnc_sampler_restatement_targets_the_smoother(seed, T, dx):
+    """The divide-and-conquer sampler (dnc_sampling.py:17-186, restated in oracle/kalman_np.py::dnc_sampling) draws from the same joint smoothing distribution as the
+    reference's other two samplers: test_sampling.py:23-68 checks all three modes against `explicit_kalman_smoothing` (means and per-step covariances, atol 1e-2 over
+    500 000 draws).  The restatement is affine in its noise given the tree, x = x(0) + A eps, so its law is known EXACTLY from T dx + 1 evaluations: x(0) must be the smoothed
+    mean, the diagonal blocks of A A^T the smoothed covariances, and the whole of A A^T (cross-time blocks too, which a wrong mid-point conditional would break while
+    leaving the marginals alone) the sequential sampler's joint covariance."""
+    from tests.helpers import ref_lgssm_inputs
+    ys, lg = ref_lgssm_inputs(seed, T, dx, 2)
+    ms, Ps, _ = K.filtering(ys, lg, False)
+    sm, sP = K.explicit_smoother(ms, Ps, lg[2], lg[3], lg[4])
+    x0 = K.dnc_sampling(np.zeros((T, dx)), ms, Ps, lg)
+    A = np.stack([K.dnc_sampling(np.eye(T * dx)[k].reshape(T, dx), ms, Ps, lg) - x0 for k in range(T * dx)], axis=-1).reshape(T * dx, T * dx)
+    npt.assert_allclose(x0, sm, rtol=1e-9, atol=1e-10)                      # eps = 0 gives the smoothed mean exactly
+    cov = A @ A.T                                                            # the sampler's exact joint covariance
+    for t in range(T):
+        npt.assert_allclose(cov[t * dx:(t + 1) * dx, t * dx:(t + 1) * dx], sP[t], rtol=1e-8, atol=1e-10)
+    # joint law = the sequential sampler's (sampling.py:34-57): same affine-in-noise structure, same covariance
+    y0 = K.sampling(np.zeros((T, dx)), ms, Ps, lg, False)
+    B = np.stack([K.sampling(np.eye(T * dx)[k].reshape(T, dx), ms, Ps, lg, False) - y0 for k in range(T * dx)], axis=-1).reshape(T * dx, T * dx)
+    npt.assert_allclose(cov, B @ B.T, rtol=1e-8, atol=1e-10)
+    npt.assert_allclose(x0, y0, rtol=1e-9, atol=1e-10)
