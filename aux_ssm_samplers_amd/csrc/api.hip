@@ -1110,10 +1110,15 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     const KDims kd{C, T, 1};
     const size_t sR = sizeof(R), CT = (size_t)C * T;
     const bool second = order == 2;
+    // Per-chain observation model in the chain-minor layout (second order, or first order without chain-shared dynamics): no observation arrays -- the
+    // scan passes and the log-density pass re-form the pseudo-observations from (x, u, y) (FilterArgs::sv_order; AUXSSM_SV_FLY=0: the array path)
+    static const bool sv_fly_on = [] { const char* e = getenv("AUXSSM_SV_FLY"); return e ? atoi(e) != 0 : true; }();
+    const bool fly = sv_fly_on && cm && !wide && T > 1 &&
+                     !(!second && chain_shared_mode(h, cm, C, T, model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0));
     size_t need = 0;
     auto add = [&](size_t b) { need += b + 256; };
-    for (int q = 0; q < 4; ++q) add(CT * D * sR);            // u, ys1, ys2, x_prop
-    if (second) add(2 * CT * D * D * sR);                    // Rs1, Rs2
+    for (int q = 0; q < (fly ? 2 : 4); ++q) add(CT * D * sR);   // u, x_prop (, ys1, ys2)
+    if (second && !fly) add(2 * CT * D * D * sR);              // Rs1, Rs2
     add(CT * D * sR);                                        // ms
     add(CT * D * D * sR);                                    // Ps
     add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + (size_t)5 * C * sizeof(Acc) + 4096);
@@ -1125,11 +1130,11 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     int rc = ws_reserve(h, need);
     if (rc) return rc;
     R* u = (R*)ws_take(h, CT * D * sR);
-    R* ys1 = (R*)ws_take(h, CT * D * sR);
-    R* ys2 = (R*)ws_take(h, CT * D * sR);
+    R* ys1 = fly ? u : (R*)ws_take(h, CT * D * sR);  // (fly: never read; non-null for the checks below)
+    R* ys2 = fly ? u : (R*)ws_take(h, CT * D * sR);
     R* xp = (R*)ws_take(h, CT * D * sR);
-    R* Rs1 = second ? (R*)ws_take(h, CT * D * D * sR) : nullptr;
-    R* Rs2 = second ? (R*)ws_take(h, CT * D * D * sR) : nullptr;
+    R* Rs1 = second && !fly ? (R*)ws_take(h, CT * D * D * sR) : nullptr;
+    R* Rs2 = second && !fly ? (R*)ws_take(h, CT * D * D * sR) : nullptr;
     R* ms = (R*)ws_take(h, CT * D * sR);
     R* Ps = (R*)ws_take(h, CT * D * D * sR);
     R* eye = (R*)ws_take(h, (size_t)D * D * sR);
@@ -1145,8 +1150,8 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     const unsigned gb = (unsigned)((tot + 255) / 256);
     auto arr = [&](const void* p, long long rec) { return cm ? cm_arr(p, kd, rec) : dense_arr(p, kd, rec); };
     const Arr xA = arr(x, D), xpA = arr(xp, D), uA = arr(u, D), y1A = arr(ys1, D), y2A = arr(ys2, D);
-    const Arr R1A = second ? arr(Rs1, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
-    const Arr R2A = second ? arr(Rs2, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
+    const Arr R1A = Rs1 ? arr(Rs1, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
+    const Arr R2A = Rs2 ? arr(Rs2, (long long)D * D) : Arr{nullptr, 0, 0, 0, 1};
 
     // First-order factory with chain-shared dynamics: the filtered covariances and the gain rows depend on the model and the step size only (the
     // pseudo-observations are finite whatever the data: every component is observed), the same for the proposal and the reverse filter.  That MODEL
@@ -1206,7 +1211,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     const Arr PsA = ps_shared ? Arr{Ps, 0, (long long)D * D, 0, 1} : arr(Ps, (long long)D * D);
 
     // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
-    {
+    if (!fly) {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)x, (const R*)eps_aux,
                            (R)sqrt(0.5 * delta), (R)delta, dptr, cv(*yobs), u, ys1, Rs1);
@@ -1218,6 +1223,10 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R1A;
+    if (fly) {
+        fa.sv_order = order; fa.sv_delta = delta; fa.aux_shd = sqrt(0.5 * delta); fa.dptr = dptr;
+        fa.aux_x = xA; fa.aux_eps = arr(eps_aux, D); fa.aux_u = uA; fa.aux_yobs = cv(*yobs);
+    }
     if (overlap || wide_carrier) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
     rc = ke->filter(h, fa, parallel, ell1);
     if (rc) return rc;
@@ -1234,7 +1243,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     if (rc) return rc;
     h->ws_off = mark;
     // reverse move: observations linearised at x_prop, filter for its marginal likelihood (generic.py:67)
-    {
+    if (!fly) {
         ProfScope ps(h, AUXSSM_K_FACTORY);
         hipLaunchKernelGGL((k_sv_obs<R>), dim3(gb), dim3(256), 0, h->stream, tot, C, T, D, order, cm, (const R*)xp, (const R*)nullptr, (R)0,
                            (R)delta, dptr, cv(*yobs), u, ys2, Rs2);
@@ -1245,6 +1254,11 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     fa.Ps = PsA;
     fa.lay.cm = cm;
     if (second) fa.Rs = R2A;
+    if (fly) {  // (only ell2 is used: generic.py:67)
+        fa.sv_order = order; fa.sv_delta = delta; fa.aux_shd = sqrt(0.5 * delta); fa.dptr = dptr;
+        fa.aux_x = xpA; fa.aux_eps = Arr{nullptr, 0, 0, 0, 1}; fa.aux_u = uA; fa.aux_yobs = cv(*yobs);
+        fa.no_moments = 1;
+    }
     if (overlap && h->side.last_tab) {  // the proposal filter's gain rows (same model, step size and mask)
         fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
         fa.tab = h->side.last_tab;
@@ -1263,6 +1277,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         la.x = xA; la.xp = xpA; la.u = uA; la.ys1 = y1A; la.ys2 = y2A; la.R1 = R1A; la.R2 = R2A;
         la.delta = delta;
         la.dptr = dptr;
+        la.fly_order = fly ? order : 0;
         rc = se->sv_logpdf(h, la, sums);  // [5][C] = jp_prop, jp_rev, lt_prop, lt_rev, corr
         if (rc) return rc;
         h->ws_off = mark;

@@ -136,6 +136,14 @@ struct FilterArgs {
     // fused sweep, which the pathwise sampler reads twice (SampleArgs::ps_packed)
     int ps_packed = 0;
     const void* obs_tab = nullptr;  // general chain-minor path with aux_on: one ObsInfoRow per transition (kalman_math.h), elements built on the fly
+    // sv_order = 1 / 2 (chain-minor SV sweep, per-chain observation model): NO observation arrays exist -- the pseudo-observations of the SV factories
+    // (examples/stochastic_volatility/auxiliary_kalman.py:28-46) are functions of the linearisation point aux_x, the auxiliary variable (aux_u, or
+    // aux_x + aux_shd * aux_eps when aux_eps is set, then written to aux_u by the final pass) and the data aux_yobs, and both scan passes form them step by
+    // step in information form (FilterOpFlySV below).  sv_delta = the step size; no_moments: the pass is run for its log-likelihood only (the reverse filter
+    // of a sweep): ms / Ps rows t >= 1 are not written.
+    int sv_order = 0;
+    double sv_delta = 0;
+    int no_moments = 0;
     int dx = 0, dy = 0;  // runtime sizes, read by the wide-state path (wide.hip) only
     // MODEL-STAGE MEMO (ctx.h::SideStage, round 4): non-null inside a memoised stage; *memo == 0 says "the stage's inputs are byte for byte the ones this slab's
     // tables were built from" and every stage kernel returns at once (memo_skip); non-zero: rebuild.  Null everywhere else.
@@ -484,15 +492,19 @@ template <typename R_, int D, int P, bool WRITE_U> struct FilterOpFly : FilterOp
         }
     }
     static AX_HD void write_zpart(const Args& a, int s, int ch, int nchunk, R z) { ((R*)a.ellz)[(long long)s * nchunk + ch] = z; }
-    static AX_HD void fold(const Args& a, int s, int i, const Raw& r, Full& acc) {
+    // Carry: what a chunk's walk keeps beside the prefix -- the running product of the steps' 1 / |det W| (kalman_math.h::LogProd), turned into the chunk's
+    // log-determinant sum by ONE logarithm when the chunk ends (carry_flush)
+    using Carry = LogProd<R>;
+    static AX_HD void carry_flush(const Carry& cy, R& z) { z += (R)0.5 * cy.log(); }
+    static AX_HD void fold(const Args& a, int s, int i, const Raw& r, Full& acc, Carry& cy) {
         StepInfo<R, D> si;
         step_info(a, s, i, r, si);
-        filter_fold_step<R, D>(r.F, r.Q, r.bd, si, acc);
+        filter_fold_step<R, D, true>(r.F, r.Q, r.bd, si, acc, &cy);
     }
-    static AX_HD void walk(const Args& a, int s, int i, const Raw& r, Pre& p) {
+    static AX_HD void walk(const Args& a, int s, int i, const Raw& r, Pre& p, Carry& cy) {
         StepInfo<R, D> si;
         step_info(a, s, i, r, si);
-        filter_apply_step<R, D>(r.F, r.Q, r.bd, si, p);
+        filter_apply_step<R, D, true>(r.F, r.Q, r.bd, si, p, &cy);
     }
 };
 // table row of transition i -> i + 1 (time t = i + 1) from the concatenated model arrays and the data
@@ -510,6 +522,153 @@ template <typename R, int D, int P> AX_HD void body_obs_info_tab(const FilterArg
     obs_info_row<R, D, P>(H, cv, Rm, y, (R)arg_aux_shd(a) * (R)arg_aux_shd(a), row);
     stv<R, T::NPAD>((R*)a.obs_tab + (long long)i * T::NPAD, row);
 }
+
+// ---- the SV factories without observation arrays (FilterArgs::sv_order) -----------------------------------------------------------------
+// Per component k (the factories are diagonal: H = I, c = 0, R = diag): w = y^2 e^{-x}, grad = nan_to_num((w - 1) / 2), hess = -w / 2, a = 2 / delta.
+//   first order  (auxiliary_kalman.py:28-35): ys = u + (delta / 2) grad, R = delta / 2          -> precision a,        information a ys
+//   second order (:37-46):                    Om^-1 = -hess + a, ys = Om (a u + grad - hess x)  -> precision -hess + a, information a u + (grad - hess x)
+// which is exactly StepInfo's split (kalman_math.h): an auxiliary block (u', a) evaluated around the predicted mean plus a "model" block (Lam, g0) around the
+// origin: first order u' = ys, Lam = 0; second order u' = u, Lam = diag(-hess), g0 = grad - hess x, q0 = ys^2 / Om - a u^2 in a form without the |u|^2 a
+// cancellation, ldR = -log(-hess + a) / 2.  A NaN datum (second order) makes that component's ys NaN = unobserved (k_sv_obs + the element path do the same
+// component by component): the step then takes the folded form with that component's precision and information zero.
+template <typename R, int D> AX_HD void sv_step_info(const FilterArgs& a, const R* x, const R* u, const R* y, StepInfo<R, D>& si) {
+    const R delta = (R)a.sv_delta, av = (R)2 / delta;
+    const bool second = a.sv_order != 1;
+    R lam[D], g[D], grad[D];
+    bool miss[D], any = false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R w = y[k] * y[k] * exp_(-x[k]);
+        grad[k] = nan_to_num<R>((R)0.5 * (w - (R)1));
+        lam[k] = second ? (R)0.5 * w : (R)0;
+        g[k] = second ? grad[k] + lam[k] * x[k] : (R)0;
+        miss[k] = second && !finite_(w);   // (k_sv_obs: ys = om (...) is NaN exactly when w is NaN or infinite)
+        any = any || miss[k];
+    }
+    // (every field is assigned exactly once, outside the branches: written per branch, the struct went through scratch memory)
+    R q0 = 0, rd = 1;   // rd = 1 / det Om = prod (lam_k + a): log(rd) / 2 = -log(det Om) / 2, taken with the chunk's other determinants (StepInfo::rdet)
+    int dim = 0;
+    R Ld[D], G0[D], U[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R tot = lam[k] + av;
+        if (!second) {
+            Ld[k] = 0, G0[k] = 0;
+            U[k] = u[k] + (R)0.5 * delta * grad[k];
+            dim += 1;
+        } else if (!any) {
+            const R e = u[k] - x[k];
+            Ld[k] = lam[k], G0[k] = g[k], U[k] = u[k];
+            // (a u + g)^2 / (lam + a) - a u^2 = [2 a u grad + a lam (x^2 - (u - x)^2) + g^2] / (lam + a)
+            q0 += ((R)2 * av * u[k] * grad[k] + av * lam[k] * (x[k] * x[k] - e * e) + g[k] * g[k]) / tot;
+            rd *= tot;
+            dim += 1;
+        } else {
+            const R gi = av * u[k] + g[k];
+            Ld[k] = miss[k] ? (R)0 : tot;
+            G0[k] = miss[k] ? (R)0 : gi;
+            U[k] = 0;
+            q0 += miss[k] ? (R)0 : gi * gi / tot;
+            rd *= miss[k] ? (R)1 : tot;
+            dim += miss[k] ? 0 : 1;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < symsize(D); ++k) si.Lam[k] = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) si.Lam[sidx_u(D, k, k)] = Ld[k], si.g0[k] = G0[k], si.u[k] = U[k];
+    si.inv_hd = (second && any) ? (R)0 : av;
+    si.q0 = q0;
+    si.ldR = second ? (R)0 : (R)D * log_(sqrt_((R)0.5 * delta));
+    si.rdet = rd;
+    si.dim = (R)dim;
+    si.ok = true;
+}
+// the t = 0 update of the same model: the pseudo-observation of (x_0, u_0) as k_sv_obs forms it, then the plain update (filtering.py:52)
+template <typename R, int D> AX_HD void body_filter_t0_sv(const FilterArgs& a, int s) {
+    const int c = s / a.d.B, b = s % a.d.B;
+    R m[D], Pd[D * D], H[D * D], cv[D], ys[D], Rm[D * D], x[D], u[D], y[D];
+    rd<R, D>(a.m0, c, 0, b, m);
+    rd<R, D * D>(a.P0, c, 0, b, Pd);
+    rd<R, D>(a.aux_x, c, 0, b, x);
+    rd<R, D>(a.aux_yobs, 0, 0, 0, y);
+    if (a.aux_eps.ptr) {
+        R eps[D];
+        rd<R, D>(a.aux_eps, c, 0, b, eps);
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] = x[k] + (R)a.aux_shd * eps[k];
+        wr<R, D>(a.aux_u, c, 0, b, u);
+    } else {
+        rd<R, D>(a.aux_u, c, 0, b, u);
+    }
+    const R delta = (R)a.sv_delta;
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) H[k] = (k / D == k % D) ? (R)1 : (R)0, Rm[k] = 0;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        const R w = y[k] * y[k] * exp_(-x[k]);
+        const R grad = nan_to_num<R>((R)0.5 * (w - (R)1));
+        cv[k] = 0;
+        if (a.sv_order == 1) {
+            ys[k] = u[k] + (R)0.5 * delta * grad;
+            Rm[k * D + k] = (R)0.5 * delta;
+        } else {
+            const R hess = (R)-0.5 * w;
+            const R om = (R)1 / (-hess + (R)2 / delta);
+            ys[k] = om * ((R)2 * u[k] / delta + grad - hess * x[k]);
+            Rm[k * D + k] = om;
+        }
+    }
+    const R ell = kalman_update<R, D, D>(m, Pd, H, cv, Rm, ys);
+    wr<R, D>(a.ms, c, 0, b, m);
+    wr_cov<R, D>(a.Ps, c, 0, b, a.ps_packed, Pd);
+    ((R*)a.ell0)[s] = ell;
+}
+// The folding operator: FilterOpFly's passes (init_acc / init_pre / write_zpart are its own) with the step's information built by sv_step_info.
+template <typename R_, int D, bool WRITE_U> struct FilterOpFlySV : FilterOpFly<R_, D, D + 1, false> {
+    using R = R_;
+    using Base = FilterOpFly<R_, D, D + 1, false>;
+    using Full = typename Base::Full;
+    using Pre = typename Base::Pre;
+    using Args = FilterArgs;
+    struct Raw {
+        R F[D * D], Q[D * D], bd[D], x[D], ue[D], y[D];
+    };
+    static AX_HD void load_raw(const Args& a, int s, int i, Raw& r) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)i + 1;
+        rd<R, D>(a.aux_x, c, t, b, r.x);
+        if (a.aux_eps.ptr) rd<R, D>(a.aux_eps, c, t, b, r.ue);
+        else rd<R, D>(a.aux_u, c, t, b, r.ue);
+        rd<R, D>(a.aux_yobs, 0, t, 0, r.y);
+        rd<R, D * D>(a.Fs, c, i, b, r.F);
+        rd<R, D>(a.bs, c, i, b, r.bd);
+        rd<R, D * D>(a.Qs, c, i, b, r.Q);
+    }
+    static AX_HD void step_info(const Args& a, int s, int i, const Raw& r, StepInfo<R, D>& si) {
+        R u[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) u[k] = a.aux_eps.ptr ? r.x[k] + (R)a.aux_shd * r.ue[k] : r.ue[k];
+        if constexpr (WRITE_U) {
+            if (a.aux_eps.ptr) wr<R, D>(a.aux_u, s / a.d.B, (long long)i + 1, s % a.d.B, u);
+        }
+        sv_step_info<R, D>(a, r.x, u, r.y, si);
+    }
+    static AX_HD void write_out(const Args& a, int s, int i, const Pre& p) {
+        if (!a.no_moments) Base::write_out(a, s, i, p);
+    }
+    using Carry = typename Base::Carry;
+    static AX_HD void fold(const Args& a, int s, int i, const Raw& r, Full& acc, Carry& cy) {
+        StepInfo<R, D> si;
+        step_info(a, s, i, r, si);
+        filter_fold_step<R, D, true>(r.F, r.Q, r.bd, si, acc, &cy);
+    }
+    static AX_HD void walk(const Args& a, int s, int i, const Raw& r, Pre& p, Carry& cy) {
+        StepInfo<R, D> si;
+        step_info(a, s, i, r, si);
+        filter_apply_step<R, D, true>(r.F, r.Q, r.bd, si, p, &cy);
+    }
+};
 
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SampleArgs {
@@ -1045,6 +1204,7 @@ struct SvLogpdfArgs {
     Arr R1, R2;              // (C, T, D, D), ptr null for the first-order factory
     double delta;
     const double* dptr = nullptr;  // device-resident {delta, sqrt(delta / 2)}; null: the host value
+    int fly_order = 0;             // 1 / 2: ys1, ys2, R1, R2 do not exist (FilterArgs::sv_order): the pseudo-observations are re-formed from (x, xp, u, yobs)
 };
 // Kernels call resolve_step(a) on their by-value argument struct first: a device-resident step size (dptr) is read ONCE, into the host fields, and the
 // pointer cleared, so that arg_delta / arg_shd / arg_aux_shd are loop-invariant scalars in every per-step body.  (Left to the bodies, the conditional
@@ -1053,7 +1213,7 @@ template <typename A> AX_HD void resolve_step(A&) {}
 AX_HD void resolve_step(FilterArgs& a) {
     const double* p = a.dptr;
     a.dptr = nullptr;
-    if (p) a.aux_shd = p[1];
+    if (p) a.aux_shd = p[1], a.sv_delta = p[0];
 }
 AX_HD void resolve_step(SweepLogpdfArgs& a) {
     const double* p = a.dptr;
@@ -1065,38 +1225,83 @@ AX_HD void resolve_step(SvLogpdfArgs& a) {
     a.dptr = nullptr;
     if (p) a.delta = p[0];
 }
+// The logarithms of the step (the two auxiliary variances, the transition's determinant) are NOT taken here: fac[k] > 0 is the factor whose log / 2 ADDS to
+// o5[k] (k < 4; 1 where the term was dropped by the nansum rule) -- the chain-minor kernel multiplies them up over its time tile (kalman_math.h::LogProd), the
+// one-step-per-lane kernel takes the logarithm at once.
 template <typename R, int D>
-AX_HD void sv_step_terms(const SvLogpdfArgs& a, int c, long long t, const R* x, const R* xp, R* o5) {
+AX_HD void sv_step_terms(const SvLogpdfArgs& a, int c, long long t, const R* x, const R* xp, R* o5, R* fac) {
     R u[D], y[D], y1[D], y2[D];
     rd<R, D>(a.u, c, t, 0, u);
     rd<R, D>(a.yobs, 0, t, 0, y);
-    rd<R, D>(a.ys1, c, t, 0, y1);
-    rd<R, D>(a.ys2, c, t, 0, y2);
-    R pp = 0, px = 0, l1 = 0, l2 = 0, cr = 0;
+    if (!a.fly_order) {
+        rd<R, D>(a.ys1, c, t, 0, y1);
+        rd<R, D>(a.ys2, c, t, 0, y2);
+    }
+    const R delta = (R)arg_delta(a), a2 = (R)2 / delta;
+    R pp = 0, px = 0, l1 = 0, l2 = 0, cr = 0, f1 = 1, f2 = 1;
 #pragma unroll
     for (int k = 0; k < D; ++k) {
         const R av = xp[k], bv = x[k];
-        pp += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * av - (R)0.5 * y[k] * y[k] * exp_(-av));
-        px += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * bv - (R)0.5 * y[k] * y[k] * exp_(-bv));
-        const R r1 = a.R1.ptr ? at<R>(a.R1, c, t, 0)[(long long)(k * D + k) * a.R1.se] : (R)(0.5 * arg_delta(a));
-        const R r2 = a.R2.ptr ? at<R>(a.R2, c, t, 0)[(long long)(k * D + k) * a.R2.se] : (R)(0.5 * arg_delta(a));
-        const R s1 = sqrt_(r1), s2 = sqrt_(r2);
-        const R z1 = (y1[k] - av) / s1, z2 = (y2[k] - bv) / s2;
-        l1 += (R)-0.5 * z1 * z1 - log_(s1) - (R)(0.5 * LOG_2PI);
-        l2 += (R)-0.5 * z2 * z2 - log_(s2) - (R)(0.5 * LOG_2PI);
+        // the two exponentials serve the potentials and (fly) the pseudo-observations: 0.5 * (y y e) is (0.5 y) y e bit for bit (scaling by a power of two)
+        const R wb = y[k] * y[k] * exp_(-bv), wa = y[k] * y[k] * exp_(-av);
+        pp += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * av - (R)0.5 * wa);
+        px += nan_to_num<R>((R)(-0.5 * LOG_2PI) - (R)0.5 * bv - (R)0.5 * wb);
+        R t1, t2;   // the auxiliary precisions 1 / R1_kk, 1 / R2_kk
+        if (a.fly_order) {
+            // k_sv_obs's pseudo-observations, re-formed: the proposal's are linearised at x (and scored at xp), the reverse move's at xp
+            const R gb = nan_to_num<R>((R)0.5 * (wb - (R)1)), ga = nan_to_num<R>((R)0.5 * (wa - (R)1));
+            if (a.fly_order == 1) {
+                y1[k] = u[k] + (R)0.5 * delta * gb;
+                y2[k] = u[k] + (R)0.5 * delta * ga;
+                t1 = t2 = a2;
+            } else {
+                const R hb = (R)-0.5 * wb, ha = (R)-0.5 * wa;
+                t1 = -hb + a2;
+                t2 = -ha + a2;
+                const R iv = (R)1 / (t1 * t2);   // one division for the two variances Om = 1 / t
+                y1[k] = (t2 * iv) * (a2 * u[k] + gb - hb * bv);
+                y2[k] = (t1 * iv) * (a2 * u[k] + ga - ha * av);
+            }
+        } else {
+            t1 = a.R1.ptr ? (R)1 / at<R>(a.R1, c, t, 0)[(long long)(k * D + k) * a.R1.se] : a2;
+            t2 = a.R2.ptr ? (R)1 / at<R>(a.R2, c, t, 0)[(long long)(k * D + k) * a.R2.se] : a2;
+        }
+        const R d1 = y1[k] - av, d2 = y2[k] - bv;
+        l1 += (R)-0.5 * d1 * d1 * t1 - (R)(0.5 * LOG_2PI);
+        l2 += (R)-0.5 * d2 * d2 * t2 - (R)(0.5 * LOG_2PI);
+        f1 *= t1;
+        f2 *= t2;
         const R e1 = av - u[k], e2 = bv - u[k];
-        cr += (e1 * e1 - e2 * e2) / (R)arg_delta(a);
+        cr += (e1 * e1 - e2 * e2) * ((R)0.5 * a2);
     }
-    o5[0] = isnan_(l1) ? (R)0 : l1;
-    o5[1] = isnan_(l2) ? (R)0 : l2;
+    // (a non-positive or non-finite variance made log(sqrt(R)) NaN in the term-by-term form: the step is dropped, as there)
+    const bool k1 = !isnan_(l1) && f1 > (R)0 && finite_(f1), k2 = !isnan_(l2) && f2 > (R)0 && finite_(f2);
+    o5[0] = k1 ? l1 : (R)0;
+    o5[1] = k2 ? l2 : (R)0;
     o5[2] = pp;
     o5[3] = px;
     o5[4] = cr;
+    fac[0] = k1 ? f1 : (R)1;
+    fac[1] = k2 ? f2 : (R)1;
+    fac[2] = 1;
+    fac[3] = 1;
+}
+template <typename R> AX_HD void sv_add_prior(R pr_p, R pr_x, R fq, bool kp, bool kx, R* out5, R* fac) {
+    out5[0] += pr_p;
+    out5[1] += pr_x;
+    out5[2] += pr_p;
+    out5[3] += pr_x;
+    fac[0] *= kp ? fq : (R)1;
+    fac[1] *= kx ? fq : (R)1;
+    fac[2] *= kp ? fq : (R)1;
+    fac[3] *= kx ? fq : (R)1;
 }
 // lanes indexed by i = t - 1 (t >= 1)
-template <typename R, int D> AX_HD void body_sv_logpdf(const SvLogpdfArgs& a, int c, int i, bool valid, R* out5) {
+template <typename R, int D> AX_HD void body_sv_logpdf(const SvLogpdfArgs& a, int c, int i, bool valid, R* out5, R* fac) {
 #pragma unroll
     for (int k = 0; k < 5; ++k) out5[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) fac[k] = 1;
     if (!valid) return;
     const long long t = (long long)i + 1;
     R x[D], xp[D], xq[D], xpq[D], F[D * D], bd[D], Q[D * D];
@@ -1107,33 +1312,29 @@ template <typename R, int D> AX_HD void body_sv_logpdf(const SvLogpdfArgs& a, in
     rd<R, D * D>(a.Fs, c, i, 0, F);
     rd<R, D>(a.bs, c, i, 0, bd);
     rd<R, D * D>(a.Qs, c, i, 0, Q);
-    sv_step_terms<R, D>(a, c, t, x, xp, out5);
-    R r1[D], r2[D], m1[D], m2[D], pr_p, pr_x;
+    sv_step_terms<R, D>(a, c, t, x, xp, out5, fac);
+    R r1[D], r2[D], m1[D], m2[D], pr_p, pr_x, fq;
+    bool kp, kx;
     mv<R, D, D>(F, xpq, m1);
     mv<R, D, D>(F, xq, m2);
 #pragma unroll
     for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
-    gauss_logpdf2<R, D>(r1, r2, Q, nullptr, pr_p, pr_x);
-    out5[0] += pr_p;
-    out5[1] += pr_x;
-    out5[2] += pr_p;
-    out5[3] += pr_x;
+    gauss_logpdf2_lp<R, D>(r1, r2, Q, pr_p, pr_x, fq, kp, kx);
+    sv_add_prior<R>(pr_p, pr_x, fq, kp, kx, out5, fac);
 }
-template <typename R, int D> AX_HD void body_sv_logpdf_head(const SvLogpdfArgs& a, int c, R* out5) {
+template <typename R, int D> AX_HD void body_sv_logpdf_head(const SvLogpdfArgs& a, int c, R* out5, R* fac) {
     R x[D], xp[D], m0[D], P0m[D * D];
     rd<R, D>(a.x, c, 0, 0, x);
     rd<R, D>(a.xp, c, 0, 0, xp);
     rd<R, D>(a.m0, c, 0, 0, m0);
     rd<R, D * D>(a.P0, c, 0, 0, P0m);
-    sv_step_terms<R, D>(a, c, 0, x, xp, out5);
-    R r1[D], r2[D], pr_p, pr_x;
+    sv_step_terms<R, D>(a, c, 0, x, xp, out5, fac);
+    R r1[D], r2[D], pr_p, pr_x, fq;
+    bool kp, kx;
 #pragma unroll
     for (int k = 0; k < D; ++k) r1[k] = xp[k] - m0[k], r2[k] = x[k] - m0[k];
-    gauss_logpdf2<R, D>(r1, r2, P0m, nullptr, pr_p, pr_x);
-    out5[0] += pr_p;
-    out5[1] += pr_x;
-    out5[2] += pr_p;
-    out5[3] += pr_x;
+    gauss_logpdf2_lp<R, D>(r1, r2, P0m, pr_p, pr_x, fq, kp, kx);
+    sv_add_prior<R>(pr_p, pr_x, fq, kp, kx, out5, fac);
 }
 
 // ---- the same pass with chain-shared parameters: Cholesky factors and log-determinants of Q_{t-1}, Robs_t once per time step ---

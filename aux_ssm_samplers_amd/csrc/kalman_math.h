@@ -717,17 +717,46 @@ AX_HD void filter_apply(const FiltPre<R, D>& p, const FiltElem<R, D>& a2, FiltPr
 // auxiliary block y = u, H = I, R = hd I is kept apart and evaluated around the predicted mean: its information-form pieces |u|^2 / hd, u.m / hd and m.m / hd are
 // ~|x|^2 / hd each (3.7e7 at Lorenz-63 scale with delta = 1e-4) and cancel down to the innovation |u - m|^2 / hd ~ dim; formed separately in fp32 that cancellation
 // cost a bias of +0.024 per step in the log-likelihood (ell of C4's 16 384 steps off by +390, log alpha by ~20: round 4, tools/c4_fp32_diag.py).
+// Running product of positive factors as (mantissa in [0.5, 1), exponent): the log-determinant terms of a chunk's steps are multiplied up and ONE logarithm is
+// taken per chunk (an fp64 log is ~55 instructions, a step of the d = 1 filter ~120 without it); the product's rounding error grows like sqrt(steps) ulp, below
+// that of the sum of as many rounded logarithms.  A zero, negative, infinite or NaN factor ends in the logarithm of the same (-inf / NaN), as the sum would.
+template <typename R> struct LogProd {
+    R m = 1;
+    int e = 0;
+    AX_HD void mul(R f) {
+        m *= f;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if constexpr (sizeof(R) == 8) {
+            e += __builtin_amdgcn_frexp_exp(m);
+            m = __builtin_amdgcn_frexp_mant(m);
+        } else {
+            e += __builtin_amdgcn_frexp_expf(m);
+            m = __builtin_amdgcn_frexp_mantf(m);
+        }
+#else
+        if (m - m == 0 && m != 0) {  // (the hardware's frexp passes inf / NaN / 0 through with exponent 0)
+            int k;
+            m = (R)frexp((double)m, &k);
+            e += k;
+        }
+#endif
+    }
+    AX_HD R log() const { return log_(m) + (R)e * (R)0.6931471805599453094; }
+};
 template <typename R, int D> struct StepInfo {
     R Lam[symsize(D)];  // the observation block WITHOUT the auxiliary block's I / hd
     R g0[D];
     R u[D];             // the auxiliary observation of the step (ignored when inv_hd == 0)
     R inv_hd = 0;       // 1 / (delta / 2); 0: no auxiliary block (Lam, g0, q0 are the whole observation)
     R q0, ldR, dim;
+    R rdet = 1;         // DEFER only: a positive factor whose logarithm / 2 ADDS to the step's log-likelihood (1 / det R of a per-step observation covariance)
     bool ok;
 };
 // shared front end: predict + solve; returns through references.  Cp = packed C of the prefix.
-template <typename R, int D>
-AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, const R* bprev, const R* Cp, R* mb, R* Pp, R* M, R* v, R& zinc) {
+// DEFER: the -log|W| / 2 of the step is NOT in zinc; 1 / |det W| (times si.rdet) is multiplied into *lp instead (LogProd: one logarithm per chunk)
+template <typename R, int D, bool DEFER = false>
+AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, const R* bprev, const R* Cp, R* mb, R* Pp, R* M, R* v, R& zinc,
+                              LogProd<R>* lp = nullptr) {
     R FC[D * D];
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -775,7 +804,16 @@ AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInf
         }
         B[i * NR + D] = g[i];
     }
-    const R ldw = lu_solve_logdet<R, D, NR>(W, B);
+    R ldw = 0;
+    if constexpr (DEFER) {
+        R pr[(D + 1) / 2];
+        lu_solve_logdet<R, D, NR, true>(W, B, pr);
+        pr[0] *= si.rdet;
+#pragma unroll
+        for (int k = 0; k < (D + 1) / 2; ++k) lp->mul(pr[k]);
+    } else {
+        ldw = lu_solve_logdet<R, D, NR>(W, B);
+    }
     R corr = 0;
 #pragma unroll
     for (int i = 0; i < D; ++i) {
@@ -792,10 +830,10 @@ AX_HD void step_predict_solve(const R* F, const R* Q, const R* bd, const StepInf
         for (int j = 0; j < D; ++j) M[i * D + j] = si.ok ? ((i == j) ? B[i * NR + i] : (R)0.5 * (B[i * NR + j] + B[j * NR + i])) : r_nan<R>();
     }
 }
-template <typename R, int D>
-AX_HD void filter_fold_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltElem<R, D>& acc) {
+template <typename R, int D, bool DEFER = false>
+AX_HD void filter_fold_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltElem<R, D>& acc, LogProd<R>* lp = nullptr) {
     R mb[D], Pp[D * D], M[D * D], v[D], zinc;
-    step_predict_solve<R, D>(F, Q, bd, si, acc.b, acc.C, mb, Pp, M, v, zinc);
+    step_predict_solve<R, D, DEFER>(F, Q, bd, si, acc.b, acc.C, mb, Pp, M, v, zinc, lp);
     R FA[D * D], PM[D * D], MFA[D * D];
     mm<R, D, D, D>(F, acc.A, FA);
     mm<R, D, D, D>(Pp, M, PM);
@@ -830,10 +868,10 @@ AX_HD void filter_fold_step(const R* F, const R* Q, const R* bd, const StepInfo<
     acc.z += zinc;
 }
 // the (b, C, z) half: one Kalman step in information form
-template <typename R, int D>
-AX_HD void filter_apply_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltPre<R, D>& p) {
+template <typename R, int D, bool DEFER = false>
+AX_HD void filter_apply_step(const R* F, const R* Q, const R* bd, const StepInfo<R, D>& si, FiltPre<R, D>& p, LogProd<R>* lp = nullptr) {
     R mb[D], Pp[D * D], M[D * D], v[D], zinc;
-    step_predict_solve<R, D>(F, Q, bd, si, p.b, p.C, mb, Pp, M, v, zinc);
+    step_predict_solve<R, D, DEFER>(F, Q, bd, si, p.b, p.C, mb, Pp, M, v, zinc, lp);
     R PM[D * D];
     mm<R, D, D, D>(Pp, M, PM);
 #pragma unroll
@@ -1105,6 +1143,51 @@ AX_HD void gauss_logpdf2(const R* r1, const R* r2, const R* __restrict__ cov, co
     }
     if (bad1 || isnan_(o1)) o1 = 0;
     if (bad2 || isnan_(o2)) o2 = 0;
+}
+
+// gauss_logpdf2 with the log-determinant DEFERRED (LogProd): o1 / o2 lack the -sum log L_kk, which is log(fac), fac = prod 1 / L_kk; keep1 / keep2 say whether the
+// value survived the nansum rule (a dropped one is 0 and must not receive the determinant either)
+template <typename R, int N>
+AX_HD void gauss_logpdf2_lp(const R* r1, const R* r2, const R* __restrict__ cov, R& o1, R& o2, R& fac, bool& keep1, bool& keep2) {
+    R a[N], b[N];
+    bool bad1 = false, bad2 = false;
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        a[k] = r1[k];
+        b[k] = r2[k];
+        bad1 = bad1 || !finite_(a[k]);
+        bad2 = bad2 || !finite_(b[k]);
+    }
+    bool ok = true;
+    if constexpr (N == 1) {
+        const R iv = (R)1 / cov[0];   // (z^2 = r^2 / cov; -log sqrt(cov) = log(1 / cov) / 2: the factor carries the square)
+        o1 = (R)-0.5 * a[0] * a[0] * iv - (R)(0.5 * LOG_2PI);
+        o2 = (R)-0.5 * b[0] * b[0] * iv - (R)(0.5 * LOG_2PI);
+        fac = iv;
+    } else {
+        R L[symsize(N)], invd[N];
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+#pragma unroll
+            for (int j = i; j < N; ++j) L[lidx(j, i)] = cov[i * N + j];
+        ok = chol_inplace<R, N>(L, invd, nullptr);
+        R f = 1;
+#pragma unroll
+        for (int k = 0; k < N; ++k) f *= invd[k];
+        lsolve<R, N>(L, invd, a);
+        lsolve<R, N>(L, invd, b);
+        R q1 = 0, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < N; ++k) q1 += a[k] * a[k], q2 += b[k] * b[k];
+        o1 = (R)-0.5 * q1 - (R)(0.5 * LOG_2PI) * (R)N;
+        o2 = (R)-0.5 * q2 - (R)(0.5 * LOG_2PI) * (R)N;
+        fac = f * f;   // (N > 1: the factor is squared so that every caller adds log(fac) / 2, as for N = 1)
+    }
+    const bool fbad = !(fac > (R)0) || !finite_(fac) || !ok;   // (a failed factorisation, sqrt of a negative: NaN in gauss_logpdf2)
+    keep1 = !(bad1 || isnan_(o1) || fbad);
+    keep2 = !(bad2 || isnan_(o2) || fbad);
+    if (!keep1) o1 = 0;
+    if (!keep2) o2 = 0;
 }
 
 // Two residuals against one covariance whose Cholesky factor (packed lower L, reciprocal diagonal invd) and additive constant

@@ -114,6 +114,12 @@ template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k
     if (s < a.d.S()) body_filter_t0<R, D, P>(a, s);
 }
 
+template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_filter_t0_sv(FilterArgs a) {
+    resolve_step(a);
+    const int s = blockIdx.x * TB_ELEM + threadIdx.x;
+    if (s < a.d.S()) body_filter_t0_sv<R, D>(a, s);
+}
+
 // grid = ntile * S, sequence index fastest so that workgroups of different chains touching the same time
 // tile (hence the same chain-shared model parameters) are co-scheduled and share them through L2.
 template <typename R, int D, int P> __global__ void __launch_bounds__(TB_ELEM) k_filter_init(FilterArgs a) {
@@ -437,13 +443,19 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_ELEM) k_sv_log
     if (tile >= ntile) return;
     const int n = a.d.T - 1;
     const int i = tile * TB_ELEM + threadIdx.x;
-    R v[5];
-    body_sv_logpdf<R, D>(a, c, i, i < n, v);
+    R v[5], f[4];
+    body_sv_logpdf<R, D>(a, c, i, i < n, v, f);
     if (tile == 0 && threadIdx.x == 0) {
-        R h[5];
-        body_sv_logpdf_head<R, D>(a, c, h);
+        R h[5], fh[4];
+        body_sv_logpdf_head<R, D>(a, c, h, fh);
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += h[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += (R)0.5 * log_(fh[k]);
+    }
+    if (i < n) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] += (R)0.5 * log_(f[k]);   // (one step per lane: nothing to multiply up)
     }
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
@@ -456,19 +468,26 @@ template <typename R, int D> __global__ void __launch_bounds__(TB_CM) k_sv_logpd
     const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
     if (!c.live) return;
     Acc v[5] = {0, 0, 0, 0, 0};
+    LogProd<R> lp[4];   // the tile's determinants: one logarithm per sum and tile instead of three per step
     if (c.tt == 0) {
-        R h[5];
-        body_sv_logpdf_head<R, D>(a, c.s, h);
+        R h[5], fh[4];
+        body_sv_logpdf_head<R, D>(a, c.s, h, fh);
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lp[k].mul(fh[k]);
     }
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
-        R w[5];
-        body_sv_logpdf<R, D>(a, c.s, opaque_uniform(i), true, w);
+        R w[5], f[4];
+        body_sv_logpdf<R, D>(a, c.s, opaque_uniform(i), true, w, f);
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lp[k].mul(f[k]);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += (Acc)((R)0.5 * lp[k].log());
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
@@ -492,11 +511,13 @@ __global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, S
         // the operator folds raw steps onto the prefix itself (no element is formed); the next step's reads fly during the fold
         Op::init_acc(a, s, ch, acc);
         Op::load_raw(a, s, i0, nxt);
+        typename Op::Carry cy;
         for (int i = i0; i < i1; ++i) {
             const Raw cur = nxt;
             if (i + 1 < i1) Op::load_raw(a, s, opaque_uniform(i + 1), nxt);
-            Op::fold(a, s, opaque_uniform(i), cur, acc);
+            Op::fold(a, s, opaque_uniform(i), cur, acc, cy);
         }
+        Op::carry_flush(cy, acc.z);
     } else {
         Op::load_elem(a, s, i0, acc);
         if (i0 + 1 < i1) Op::load_raw(a, s, i0 + 1, nxt);
@@ -511,6 +532,8 @@ __global__ void __launch_bounds__(TB_CM) k_scan_reduce_cm(typename Op::Args a, S
     }
     Op::store_rec((R*)sb.agg + ((long long)s * lay.nchunk + ch) * Full::NPAD, acc);
 }
+template <class Op, typename = void> struct CarryOf { struct type {}; };
+template <class Op> struct CarryOf<Op, std::void_t<typename Op::Carry>> { using type = typename Op::Carry; };
 // (operators may ask for two waves per SIMD in the down pass -- Op::kDownWaves -- when their walk is within a few registers of that budget)
 template <class Op, typename = void> struct DownWaves { static constexpr int value = 1; };
 template <class Op> struct DownWaves<Op, decltype((void)Op::kDownWaves)> { static constexpr int value = Op::kDownWaves; };
@@ -542,6 +565,7 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
     // is a quadratic form in the chunk's start state AROUND THE ORIGIN, its scale is ~ -|x|^2 J / 2 (-2e8 at Lorenz-63 scale with delta = 1e-5), and in fp32 the
     // aggregate scan returned the total to +-ulp(2e8) = 16 per combine (round 4, tools/c4_accept_probe.py); the increments themselves are O(dim) each.
     if constexpr (Op::kFold) p.z = 0;
+    typename CarryOf<Op>::type cy;
     {
         using Raw = typename Op::Raw;
         Raw nxt;
@@ -550,7 +574,7 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
             const Raw cur = nxt;
             if (i + 1 < i1) Op::load_raw(a, s, opaque_uniform(i + 1), nxt);
             if constexpr (Op::kFold) {
-                Op::walk(a, s, opaque_uniform(i), cur, p);
+                Op::walk(a, s, opaque_uniform(i), cur, p, cy);
             } else {
                 Full e;
                 Pre o;
@@ -561,7 +585,10 @@ __global__ void __launch_bounds__(TB_CM, DownWaves<Op>::value) k_scan_down_cm(ty
             Op::write_out(a, s, opaque_uniform(i), p);
         }
     }
-    if constexpr (Op::kFold) Op::write_zpart(a, s, ch, lay.nchunk, p.z);
+    if constexpr (Op::kFold) {
+        Op::carry_flush(cy, p.z);
+        Op::write_zpart(a, s, ch, lay.nchunk, p.z);
+    }
 }
 
 // ---- generic chunked scan ---------------------------------------------------------------------------------------
@@ -1158,6 +1185,33 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
                         a.Rs.sc == 0 && a.cs.sc == 0 && a.P0.sc == 0;
     a.ell0 = ws_take(h, (size_t)S * sizeof(R));
     if (!a.ell0) return AUXSSM_ERR_NOMEM;
+    if (a_in.sv_order != 0) {
+        // SV factories, chain-minor, per-chain observation model: no observation arrays and no elements -- both scan passes fold the steps in information
+        // form from (x_lin, u, y) (kalman_bodies.h::FilterOpFlySV); the down pass of the proposal filter writes u and the filtered moments, the reverse
+        // filter's (no_moments) only the log-likelihood increments
+        if constexpr (P == D) {
+            if (!cm || a.d.B != 1) {
+                set_error("internal: the array-free SV filter needs the chain-minor layout");
+                return AUXSSM_ERR_ARG;
+            }
+            hipLaunchKernelGGL((k_filter_t0_sv<R, D>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
+            if (n > 0) {
+                a.elem = nullptr;
+                a.ellz = ws_take(h, (size_t)S * a.lay.nchunk * sizeof(R));
+                if (!a.ellz) return AUXSSM_ERR_NOMEM;
+                ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+                const int rc = a.aux_eps.ptr ? run_scan<FilterOp<R, D>, FilterOpFlySV<R, D, true>, FilterOpFlySV<R, D, false>>(h, a, S, n)
+                                             : run_scan<FilterOp<R, D>, FilterOpFlySV<R, D, false>, FilterOpFlySV<R, D, false>>(h, a, S, n);
+                if (rc) return rc;
+            }
+            hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, n > 0 ? a.lay.nchunk : 0, (R*)ell_out);
+            AX_HIP(hipGetLastError());
+            return AUXSSM_OK;
+        } else {
+            set_error("internal: the SV factories observe every state component (dy == dx)");
+            return AUXSSM_ERR_ARG;
+        }
+    }
     if (shared) return run_filter_shared<R, D, P>(h, a, parallel, ell_out);
     hipLaunchKernelGGL((k_filter_t0<R, D, P>), dim3((S + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, a);
     // general chain-minor path on the concatenated auxiliary model: elements are built on the fly inside both scan passes

@@ -284,10 +284,11 @@ template <typename R, int N, int NC> AX_HD void cho_solve_col(const R* L, const 
 }
 
 // ---- LU with partial pivoting, W [D][D] destroyed, RHS [D][NR] overwritten by W^{-1} RHS -----------------
-template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B);
+template <typename R, int D, int NR, bool RDET = false> AX_HD R lu_solve_logdet(R* W, R* B, R* pr = nullptr);
 template <typename R, int D, int NR> AX_HD void lu_solve(R* W, R* B) { (void)lu_solve_logdet<R, D, NR>(W, B); }
-// returns log |det W|
-template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B) {
+// returns log |det W|.  RDET: no logarithm -- pr[(D + 1) / 2] receives the products of PAIRS of reciprocal pivots (1 / |det W| = their product), returns 0: the
+// chunk-serial filter passes multiply them into a running (mantissa, exponent) pair and take ONE logarithm per chunk (kalman_math.h::LogProd)
+template <typename R, int D, int NR, bool RDET> AX_HD R lu_solve_logdet(R* W, R* B, R* pr) {
     R ipiv[D];
     R ld_ = 0, pp = 1;  // log|det| from products of PAIRS of reciprocal pivots: half the logarithms, no under/overflow in practice
 #pragma unroll
@@ -313,7 +314,8 @@ template <typename R, int D, int NR> AX_HD R lu_solve_logdet(R* W, R* B) {
         ipiv[k] = inv;
         pp *= abs_(inv);
         if ((k & 1) == 1 || k == D - 1) {
-            ld_ -= log_(pp);
+            if constexpr (RDET) pr[k >> 1] = pp;
+            else ld_ -= log_(pp);
             pp = 1;
         }
 #pragma unroll

@@ -210,14 +210,18 @@ static int sv_logpdf_T(int C, int T, const HsArr* g, const void* yobs, const voi
     };
     a.x = view(x, D); a.xp = view(xp, D); a.u = view(u, D); a.ys1 = view(ys1, D); a.ys2 = view(ys2, D);
     a.R1 = view(R1, D * D); a.R2 = view(R2, D * D);
-    for (int c = 0; c < C; ++c) {
-        R tot[5];
-        body_sv_logpdf_head<R, D>(a, c, tot);
+    for (int c = 0; c < C; ++c) {   // (as k_sv_logpdf_cm: the determinants multiplied up over the chain's steps, one logarithm per sum)
+        R tot[5], f[4];
+        LogProd<R> lp[4];
+        body_sv_logpdf_head<R, D>(a, c, tot, f);
+        for (int k = 0; k < 4; ++k) lp[k].mul(f[k]);
         for (int i = 0; i < T - 1; ++i) {
             R w[5];
-            body_sv_logpdf<R, D>(a, c, i, true, w);
+            body_sv_logpdf<R, D>(a, c, i, true, w, f);
             for (int k = 0; k < 5; ++k) tot[k] += w[k];
+            for (int k = 0; k < 4; ++k) lp[k].mul(f[k]);
         }
+        for (int k = 0; k < 4; ++k) tot[k] += (R)0.5 * lp[k].log();
         for (int k = 0; k < 5; ++k) ((R*)out)[(size_t)k * C + c] = tot[k];
     }
     return 0;
@@ -315,6 +319,26 @@ template <int D> static double fold_check_T(const double* F, const double* Q, co
     for (int i = 0; i < DS; ++i) upd(o.C[i], f.C[i]), upd(o.J[i], f.J[i]), upd(o.C[i], pre.C[i]);
     upd(o.z, f.z);
     upd(o.z, pre.z);
+    // the same two steps with the log-determinant DEFERRED into a running product (LogProd: what the chunk-serial passes do, one logarithm per chunk), the
+    // observation's own log-determinant handed over as the factor rdet = exp(-2 ldR) instead of the additive ldR
+    {
+        StepInfo<double, D> sd = si;
+        sd.ldR = 0;
+        sd.rdet = std::exp(-2 * ldR);
+        LogProd<double> lf, lw;
+        lf.mul(3.5), lw.mul(0.02);  // (a chunk's product so far)
+        FiltElem<double, D> fd = acc;
+        filter_fold_step<double, D, true>(F, Q, bd, sd, fd, &lf);
+        FiltPre<double, D> pd;
+        for (int i = 0; i < D; ++i) pd.b[i] = acc.b[i];
+        for (int i = 0; i < DS; ++i) pd.C[i] = acc.C[i];
+        pd.z = acc.z;
+        filter_apply_step<double, D, true>(F, Q, bd, sd, pd, &lw);
+        upd(o.z, fd.z + 0.5 * (lf.log() - std::log(3.5)));
+        upd(o.z, pd.z + 0.5 * (lw.log() - std::log(0.02)));
+        for (int i = 0; i < D; ++i) upd(f.b[i], fd.b[i]), upd(pre.b[i], pd.b[i]);
+        for (int i = 0; i < DS; ++i) upd(f.C[i], fd.C[i]), upd(f.J[i], fd.J[i]);
+    }
     return m;
 }
 
