@@ -157,7 +157,7 @@ AffPlan plan_aff(const auxssm_ctx* h, int S, int N, int parallel, int waves) {
     return p;
 }
 
-ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
+ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel, int waves) {
     ScanPlan p;
     if (!parallel || n <= 2) {
         p.E = n > 0 ? n : 1;
@@ -166,7 +166,7 @@ ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel) {
     }
     // one wave per SIMD: the fp64 d=4 combine needs ~400 unified registers, so that is the residency anyway, and fewer,
     // longer chunks halve the aggregate-scan work (measured on C2 x 64 chains: E = 64 beats 16/32/48/96)
-    const long long target = (long long)h->num_cu * 4 * 64;
+    const long long target = (long long)h->num_cu * 4 * 64 * (waves < 1 ? 1 : waves > SCAN_WAVES_MAX ? SCAN_WAVES_MAX : waves);
     long long E = ((long long)S * n + target - 1) / target;
     // few sequences (the chip is not full at any E): the lane-serial walk over a chunk dominates, the aggregate scan is cheap -- measured
     // optimum E = 12 at n = 65535 (1 and 8 sequences, fp64 d = 4) and E = 8 at n = 16383 (8 sequences, fp32 d = 3): E ~ sqrt(n / 450)

@@ -168,7 +168,10 @@ struct ScanPlan {
     int E;       // elements per thread chunk
     int nchunk;  // chunks per sequence
 };
-ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel);
+// waves: how many waves per SIMD the scan passes of the caller's operator can keep resident (1: the fp64 d = 4 operators; the chain-minor d = 1, 2 operators
+// hold 4 / 2 and are issue-bound, so shorter chunks -- more lanes -- pay until the chip holds that many; kernels.hip.h::scan_waves)
+constexpr int SCAN_WAVES_MAX = 4;
+ScanPlan plan_scan(const auxssm_ctx* h, int S, int n, int parallel, int waves = 1);
 struct AffPlan {  // chunking of the chain-shared affine scans (kernels.hip.h: run_affine)
     int E, nchunk;
 };

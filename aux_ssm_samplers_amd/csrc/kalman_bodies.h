@@ -990,10 +990,14 @@ template <typename R, int D, int PO> struct LogShared {
 };
 
 // the observation + auxiliary blocks at one time step for (xp, x); returns via references
+// fo (optional): the log-determinant of the observation block is NOT taken; fo[0..3] receive the factors whose log / 2 ADDS to cc_p, cc_x, ob_p, ob_x (1 where
+// the nansum rule dropped the term) -- the chain-minor kernels multiply them up over a time tile (kalman_math.h::LogProd: one logarithm per tile and sum)
 template <typename R, int D, int PO>
 AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, const R* u, const R* H, const R* cv, const R* y,
-                           const R* Rm, R& cc_p, R& cc_x, R& ob_p, R& ob_x, R& corr) {
+                           const R* Rm, R& cc_p, R& cc_x, R& ob_p, R& ob_x, R& corr, R* fo = nullptr) {
     bool badobs_x = false, badobs_p = false;
+    R fR = 1;
+    bool kp = true, kx = true;
     {
         R r1[PO], r2[PO];
         bool skip[PO];
@@ -1008,7 +1012,8 @@ AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, co
             badobs_p = badobs_p || (!skip[k] && !finite_(r1[k]));
             badobs_x = badobs_x || (!skip[k] && !finite_(r2[k]));
         }
-        gauss_logpdf2<R, PO>(r1, r2, Rm, a.nan_policy == 1 ? skip : nullptr, ob_p, ob_x);
+        if (fo) gauss_logpdf2_lp<R, PO>(r1, r2, Rm, ob_p, ob_x, fR, kp, kx, a.nan_policy == 1 ? skip : nullptr);
+        else gauss_logpdf2<R, PO>(r1, r2, Rm, a.nan_policy == 1 ? skip : nullptr, ob_p, ob_x);
     }
     R ax_x, ax_p;
     bool b1 = false, b2 = false;
@@ -1034,20 +1039,34 @@ AX_HD void sweep_obs_terms(const SweepLogpdfArgs& a, const R* x, const R* xp, co
     // reference policy (jnp.nansum over per-step logpdfs): a non-finite component anywhere in the stacked residual
     // [u - x ; y - H x - c] drops the whole step of the concatenated model; the target only sees the observation block.
     const bool ref = a.nan_policy == 0;
-    cc_p = (ref && (b1 || badobs_p)) ? (R)0 : ax_p + ob_p;
-    cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
+    const bool dp = ref && (b1 || badobs_p), dx_ = ref && (b2 || badobs_x);
+    cc_p = dp ? (R)0 : ax_p + ob_p;
+    cc_x = dx_ ? (R)0 : ax_x + ob_x;
+    if (fo) {
+        fo[2] = kp ? fR : (R)1;
+        fo[3] = kx ? fR : (R)1;
+        fo[0] = dp ? (R)1 : fo[2];
+        fo[1] = dx_ ? (R)1 : fo[3];
+    }
 }
 
 // the five terms of one time step t >= 1 from values in registers: x, xp at t; u_in = u_t (or eps_t when a.u_fly); xq, xpq at t - 1;
 // the real observation model at t (Rm: upper triangle) and the transition t - 1 -> t
+// the prior pair's factor joins the four sums' factors (fac[0..3]; sweep_obs_terms)
+template <typename R> AX_HD void sweep_join_prior(R fq, bool kp, bool kx, R* fac) {
+    fac[0] *= kp ? fq : (R)1;
+    fac[1] *= kx ? fq : (R)1;
+    fac[2] *= kp ? fq : (R)1;
+    fac[3] *= kx ? fq : (R)1;
+}
 template <typename R, int D, int PO>
 AX_HD void sweep_logpdf_core(const SweepLogpdfArgs& a, const R* x, const R* xp, const R* u_in, const R* xq, const R* xpq, const R* H, const R* cv,
-                             const R* y, const R* Rm, const R* F, const R* bd, const R* Q, R* out5) {
+                             const R* y, const R* Rm, const R* F, const R* bd, const R* Q, R* out5, R* fac = nullptr) {
     R u[D];
 #pragma unroll
     for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)arg_shd(a) * u_in[k] : u_in[k];
     R cc_p, cc_x, ob_p, ob_x, corr;
-    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
+    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr, fac);
     R pr_p, pr_x;
     {
         R r1[D], r2[D], m1[D], m2[D];
@@ -1055,7 +1074,14 @@ AX_HD void sweep_logpdf_core(const SweepLogpdfArgs& a, const R* x, const R* xp, 
         mv<R, D, D>(F, xq, m2);
 #pragma unroll
         for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
-        gauss_logpdf2<R, D>(r1, r2, Q, nullptr, pr_p, pr_x);
+        if (fac) {
+            R fq;
+            bool kp, kx;
+            gauss_logpdf2_lp<R, D>(r1, r2, Q, pr_p, pr_x, fq, kp, kx);
+            sweep_join_prior<R>(fq, kp, kx, fac);
+        } else {
+            gauss_logpdf2<R, D>(r1, r2, Q, nullptr, pr_p, pr_x);
+        }
     }
     out5[0] = cc_p + pr_p;
     out5[1] = cc_x + pr_x;
@@ -1138,10 +1164,11 @@ template <typename R> AX_HD void lorenz_lin_F(const R* th, R dt, const R* x, R* 
 // per chain the five sums  [0] joint of the auxiliary LGSSM linearised at x, evaluated at x'   [1] the one linearised at x', evaluated at x
 //                          [2] target(x')   [3] target(x)   [4] the MH correction;  the linearised transition F_t z + b_t is rebuilt from the
 // linearisation point (F_t = I + dt J(x_t), b_t = mean(x_t) - F_t x_t), so no F / b array is read.  lanes indexed by i = t - 1.
-template <typename R, int PO> AX_HD void body_lorenz_logpdf(const SweepLogpdfArgs& a, int c, int i, bool valid, R* out5) {
+template <typename R, int PO> AX_HD void body_lorenz_logpdf(const SweepLogpdfArgs& a, int c, int i, bool valid, R* out5, R* fac = nullptr) {
     constexpr int D = 3;
 #pragma unroll
     for (int k = 0; k < 5; ++k) out5[k] = 0;
+    if (fac) fac[0] = fac[1] = fac[2] = fac[3] = 1;
     if (!valid) return;
     const long long t = (long long)i + 1;
     const R* par = (const R*)a.lor_par + (long long)c * a.lor_psc;
@@ -1159,7 +1186,7 @@ template <typename R, int PO> AX_HD void body_lorenz_logpdf(const SweepLogpdfArg
     rd_upper<R, PO>(a.Rs, c, t, 0, Rm);
     rd<R, D * D>(a.Qs, c, i, 0, Q);
     R cc_p, cc_x, ob_p, ob_x, corr;
-    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr);
+    sweep_obs_terms<R, D, PO>(a, x, xp, u, H, cv, y, Rm, cc_p, cc_x, ob_p, ob_x, corr, fac);
     R mx[D], mp[D], F1[D * D], F2[D * D], dl[D], f1[D], f2[D];
     lorenz_mean<R>(th, dt, xq, mx);
     lorenz_mean<R>(th, dt, xpq, mp);
@@ -1177,8 +1204,19 @@ template <typename R, int PO> AX_HD void body_lorenz_logpdf(const SweepLogpdfArg
         rp[k] = xp[k] - mp[k];
         rx[k] = x[k] - mx[k];
     }
-    gauss_logpdf2<R, D>(r1, r2, Q, nullptr, l1, l2);
-    gauss_logpdf2<R, D>(rp, rx, Q, nullptr, tp, tx);
+    if (fac) {
+        R fq, fq2;
+        bool k1, k2, k3, k4;
+        gauss_logpdf2_lp<R, D>(r1, r2, Q, l1, l2, fq, k1, k2);
+        gauss_logpdf2_lp<R, D>(rp, rx, Q, tp, tx, fq2, k3, k4);   // (the same factorisation: the compiler merges the two)
+        fac[0] *= k1 ? fq : (R)1;
+        fac[1] *= k2 ? fq : (R)1;
+        fac[2] *= k3 ? fq2 : (R)1;
+        fac[3] *= k4 ? fq2 : (R)1;
+    } else {
+        gauss_logpdf2<R, D>(r1, r2, Q, nullptr, l1, l2);
+        gauss_logpdf2<R, D>(rp, rx, Q, nullptr, tp, tx);
+    }
     out5[0] = cc_p + l1;
     out5[1] = cc_x + l2;
     out5[2] = ob_p + tp;

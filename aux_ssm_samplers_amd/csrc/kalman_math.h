@@ -1148,15 +1148,18 @@ AX_HD void gauss_logpdf2(const R* r1, const R* r2, const R* __restrict__ cov, co
 // gauss_logpdf2 with the log-determinant DEFERRED (LogProd): o1 / o2 lack the -sum log L_kk, which is log(fac), fac = prod 1 / L_kk; keep1 / keep2 say whether the
 // value survived the nansum rule (a dropped one is 0 and must not receive the determinant either)
 template <typename R, int N>
-AX_HD void gauss_logpdf2_lp(const R* r1, const R* r2, const R* __restrict__ cov, R& o1, R& o2, R& fac, bool& keep1, bool& keep2) {
+AX_HD void gauss_logpdf2_lp(const R* r1, const R* r2, const R* __restrict__ cov, R& o1, R& o2, R& fac, bool& keep1, bool& keep2, const bool* skip = nullptr) {
     R a[N], b[N];
+    int dim = 0;
     bool bad1 = false, bad2 = false;
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        a[k] = r1[k];
-        b[k] = r2[k];
+        const bool sk = skip ? skip[k] : false;
+        a[k] = sk ? (R)0 : r1[k];
+        b[k] = sk ? (R)0 : r2[k];
         bad1 = bad1 || !finite_(a[k]);
         bad2 = bad2 || !finite_(b[k]);
+        dim += sk ? 0 : 1;
     }
     bool ok = true;
     if constexpr (N == 1) {
@@ -1164,23 +1167,24 @@ AX_HD void gauss_logpdf2_lp(const R* r1, const R* r2, const R* __restrict__ cov,
         o1 = (R)-0.5 * a[0] * a[0] * iv - (R)(0.5 * LOG_2PI);
         o2 = (R)-0.5 * b[0] * b[0] * iv - (R)(0.5 * LOG_2PI);
         fac = iv;
+        if (skip && skip[0]) o1 = o2 = 0, fac = 1;   // (gauss_logpdf2: a masked component contributes 0 -- and is kept, as a 0)
     } else {
         R L[symsize(N)], invd[N];
 #pragma unroll
         for (int i = 0; i < N; ++i)
 #pragma unroll
             for (int j = i; j < N; ++j) L[lidx(j, i)] = cov[i * N + j];
-        ok = chol_inplace<R, N>(L, invd, nullptr);
+        ok = chol_inplace<R, N>(L, invd, skip);
         R f = 1;
 #pragma unroll
-        for (int k = 0; k < N; ++k) f *= invd[k];
+        for (int k = 0; k < N; ++k) f *= (skip && skip[k]) ? (R)1 : invd[k];
         lsolve<R, N>(L, invd, a);
         lsolve<R, N>(L, invd, b);
         R q1 = 0, q2 = 0;
 #pragma unroll
         for (int k = 0; k < N; ++k) q1 += a[k] * a[k], q2 += b[k] * b[k];
-        o1 = (R)-0.5 * q1 - (R)(0.5 * LOG_2PI) * (R)N;
-        o2 = (R)-0.5 * q2 - (R)(0.5 * LOG_2PI) * (R)N;
+        o1 = (R)-0.5 * q1 - (R)(0.5 * LOG_2PI) * (R)dim;
+        o2 = (R)-0.5 * q2 - (R)(0.5 * LOG_2PI) * (R)dim;
         fac = f * f;   // (N > 1: the factor is squared so that every caller adds log(fac) / 2, as for N = 1)
     }
     const bool fbad = !(fac > (R)0) || !finite_(fac) || !ok;   // (a failed factorisation, sqrt of a negative: NaN in gauss_logpdf2)

@@ -310,6 +310,7 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, Ac
     rd<R, D>(a.x, c.s, (long long)c.i0 + 1, 0, xn);
     rd<R, D>(a.xp, c.s, (long long)c.i0 + 1, 0, xpn);
     rd<R, D>(ua, c.s, (long long)c.i0 + 1, 0, un);
+    LogProd<R> lp[4];   // the tile's determinants (Q_t and R_t per step and chain): one logarithm per sum and tile instead of D + PO per step
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
         R xc[D], xpc[D], uc[D];
@@ -330,12 +331,17 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm(SweepLogpdfArgs a, Ac
         rd<R, D * D>(a.Fs, c.s, iu, 0, F);
         rd<R, D>(a.bs, c.s, iu, 0, bd);
         rd<R, D * D>(a.Qs, c.s, iu, 0, Q);
-        sweep_logpdf_core<R, D, PO>(a, xc, xpc, uc, xq, xpq, H, cv, y, Rm, F, bd, Q, w);
+        R f[4];
+        sweep_logpdf_core<R, D, PO>(a, xc, xpc, uc, xq, xpq, H, cv, y, Rm, F, bd, Q, w, f);
 #pragma unroll
         for (int k = 0; k < D; ++k) xq[k] = xc[k], xpq[k] = xpc[k];
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lp[k].mul(f[k]);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += (Acc)((R)0.5 * lp[k].log());
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
@@ -422,13 +428,18 @@ template <typename R, int PO> __global__ void __launch_bounds__(TB_CM) k_lorenz_
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
     }
+    LogProd<R> lp[4];
 #pragma unroll 1
     for (int i = c.i0; i < c.i1; ++i) {
-        R w[5];
-        body_lorenz_logpdf<R, PO>(a, c.s, opaque_uniform(i), true, w);
+        R w[5], f[4];
+        body_lorenz_logpdf<R, PO>(a, c.s, opaque_uniform(i), true, w, f);
 #pragma unroll
         for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) lp[k].mul(f[k]);
     }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] += (Acc)((R)0.5 * lp[k].log());
 #pragma unroll
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
@@ -997,8 +1008,11 @@ template <typename R_, int D, int P, int P1> struct FilterOpBuild : FilterOp<R_,
     }
 };
 
+// waves per SIMD of the chain-minor scan passes by element size (plan_scan): measured on the SV second-order sweep (fp64 d = 1: 256 chains 130k -> 161k sweeps/s
+// with chunks of 64 instead of 256 steps; 1024 chains the same from 64 to 256); the d >= 3 operators keep the one-wave plan they were tuned with
+template <typename R, int D> constexpr int scan_waves() { return D == 1 ? 4 : D == 2 ? 2 : 1; }
 template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
-    const ScanPlan pl = plan_scan(h, S, n, parallel);
+    const ScanPlan pl = plan_scan(h, S, n, parallel, SCAN_WAVES_MAX);  // (the most chunks any plan of this shape has)
     size_t b = 0;
     if (use_ks<Op>(h, S, n, parallel)) {
         const size_t ntile = (size_t)(n + TB_KS - 1) / TB_KS;
@@ -1071,7 +1085,7 @@ template <typename R, int D, int P> size_t filter_ws(const auxssm_ctx* h, const 
     // (the time-minor layout is never smaller than the chain-minor one)
     b += (size_t)S * lay.seq_records() * FiltElem<R, D>::NPAD * sizeof(R) + 256;
     b += (size_t)S * sizeof(R) + 256;                           // ell0
-    const int nchunk_cm = make_layout(plan_scan(h, S, n, parallel), 1, S).nchunk;
+    const int nchunk_cm = make_layout(plan_scan(h, S, n, parallel, SCAN_WAVES_MAX), 1, S).nchunk;
     b += (size_t)S * (std::max(ntiles(n), std::max(lay.nchunk, nchunk_cm)) + 1) * sizeof(R) + 256;  // ell partials (per tile, or per chunk of either layout)
     b += scan_ws_bytes<FilterOp<R, D>>(h, S, n, parallel);
     // chain-shared parameters: the one-sequence matrix filter (elements, scan buffers, moments, mask carrier), the gain table and the
@@ -1178,7 +1192,7 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
     // block-diagonal R with a leading dx x dx block (the concatenated auxiliary observations): information form
     static const bool blk_on = [] { const char* e = getenv("AUXSSM_INFO_BLOCKS"); return e ? atoi(e) != 0 : true; }();
     const bool blk = blk_on && P > D && a_in.pblk == D;
-    a.lay = make_layout(plan_scan(h, S, n, parallel), cm, S);
+    a.lay = make_layout(plan_scan(h, S, n, parallel, cm ? scan_waves<R, D>() : 1), cm, S);
     // chain-shared model parameters (the factories of a linear-Gaussian model): what jax.vmap leaves unbatched in the reference
     const bool shared_on = h->share_model != 0;
     const bool shared = shared_on && cm && n > 0 && a.d.B == 1 && a.d.C > 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0 && a.Hs.sc == 0 &&
@@ -1292,7 +1306,7 @@ template <typename R, int D> int run_sample(auxssm_ctx* h, const SampleArgs& a_i
     SampleArgs a = a_in;
     const int S = a.d.S(), T = a.d.T;
     const int cm = a_in.lay.cm;
-    a.lay = make_layout(plan_scan(h, S, T, parallel), cm, S);
+    a.lay = make_layout(plan_scan(h, S, T, parallel, cm ? scan_waves<R, D>() : 1), cm, S);
     static const bool fly = [] { const char* e = getenv("AUXSSM_SAMPLE_FLY"); return e ? atoi(e) != 0 : true; }();
     const bool shared_on = h->share_model != 0;
     if (cm && shared_on && a.ps_shared && a.d.B == 1 && a.Fs.sc == 0 && a.Qs.sc == 0 && a.bs.sc == 0) {

@@ -251,10 +251,21 @@ static int lorenz_logpdf_T(int C, int T, const HsArr* g, const void* yobs, const
     for (int c = 0; c < C; ++c) {
         R tot[5];
         body_lorenz_logpdf_head<R, PO>(a, c, tot);
-        for (int i = 0; i < T - 1; ++i) {
-            R w[5];
-            body_lorenz_logpdf<R, PO>(a, c, i, true, w);
-            for (int k = 0; k < 5; ++k) tot[k] += w[k];
+        if (cm) {   // the chain-minor kernel's form: determinants multiplied up, one logarithm per sum (k_lorenz_logpdf_cm)
+            LogProd<R> lp[4];
+            for (int i = 0; i < T - 1; ++i) {
+                R w[5], f[4];
+                body_lorenz_logpdf<R, PO>(a, c, i, true, w, f);
+                for (int k = 0; k < 5; ++k) tot[k] += w[k];
+                for (int k = 0; k < 4; ++k) lp[k].mul(f[k]);
+            }
+            for (int k = 0; k < 4; ++k) tot[k] += (R)0.5 * lp[k].log();
+        } else {
+            for (int i = 0; i < T - 1; ++i) {
+                R w[5];
+                body_lorenz_logpdf<R, PO>(a, c, i, true, w);
+                for (int k = 0; k < 5; ++k) tot[k] += w[k];
+            }
         }
         for (int k = 0; k < 5; ++k) ((R*)out)[(size_t)k * C + c] = tot[k];
     }
