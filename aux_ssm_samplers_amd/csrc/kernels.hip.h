@@ -1009,8 +1009,9 @@ template <typename R_, int D, int P, int P1> struct FilterOpBuild : FilterOp<R_,
 };
 
 // waves per SIMD of the chain-minor scan passes by element size (plan_scan): measured on the SV second-order sweep (fp64 d = 1: 256 chains 130k -> 161k sweeps/s
-// with chunks of 64 instead of 256 steps; 1024 chains the same from 64 to 256); the d >= 3 operators keep the one-wave plan they were tuned with
-template <typename R, int D> constexpr int scan_waves() { return D == 1 ? 4 : D == 2 ? 2 : 1; }
+// with chunks of 64 instead of 256 steps; 1024 chains the same from 64 to 256) and on the Lorenz sweep (fp32 d = 3, chunk length swept at 64 / 256 / 1024 chains:
+// best 12 / 16 / 32 steps = 4 waves, +15 / +17 / +28 % over the one-wave plan); the fp64 d >= 3 operators (264 .. 352 registers) keep the one-wave plan
+template <typename R, int D> constexpr int scan_waves() { return sizeof(R) == 4 ? (D <= 3 ? 4 : 2) : (D == 1 ? 4 : D == 2 ? 2 : 1); }
 template <class Op> size_t scan_ws_bytes(const auxssm_ctx* h, int S, int n, int parallel) {
     const ScanPlan pl = plan_scan(h, S, n, parallel, SCAN_WAVES_MAX);  // (the most chunks any plan of this shape has)
     size_t b = 0;
@@ -1031,6 +1032,15 @@ inline int ti_cm() {
     return v;
 }
 #define TI_CM ti_cm()
+// ... of the per-chain log-density passes: longer runs once the grid holds ~32 waves per SIMD anyway (their per-tile costs -- the t - 1 reads, one logarithm per
+// sum -- amortise; SV second order, 1024 chains x 65536 steps: 244k -> 267k sweeps/s at 64 steps, Lorenz 256 chains x 16384: best at 16); never below TI_CM,
+// which sizes the partial-sum buffers
+inline int ti_cm_for(const auxssm_ctx* h, int C, int n) {
+    static const bool forced = getenv("AUXSSM_TI") != nullptr;
+    if (forced) return TI_CM;
+    const long long t = (long long)C * n / ((long long)64 * h->num_cu * 4 * 32);
+    return (int)std::min<long long>(64, std::max<long long>(TI_CM, t));
+}
 // ... and of the chain-shared log-density pass (run_sweep_logpdf; AUXSSM_TI_SHARED overrides)
 inline int ti_shared() {
     static int v = [] { const char* e = getenv("AUXSSM_TI_SHARED"); const int t = e ? atoi(e) : 64; return t >= 1 && t <= 1024 ? t : 64; }();
@@ -1393,7 +1403,7 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
                         a.cs.sc == 0 && a.ys.sc == 0;
     // time steps per lane: the streamed shared pass (52 scalars per step from its table) likes longer runs than the per-chain pass -- measured at C2,
     // two runs each: 0.41-0.44 / 0.39 / 0.38-0.41 / 0.38-0.40 ms at 16 / 32 / 48 / 64 steps; the per-chain pass 1.28 / 1.31 / 1.37 / 1.34 ms
-    const int TI = shared ? ti_shared() : TI_CM;
+    const int TI = shared ? ti_shared() : ti_cm_for(h, a.d.C, n);
     const int C = a.d.C, nt = cm ? ((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
@@ -1410,7 +1420,7 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
             if (rc) return rc;
         }
         hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, as, part, nt, TI);
-    } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+    } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, a, part, nt, TI);
     else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
@@ -1424,10 +1434,11 @@ template <typename R, int D> size_t sv_logpdf_ws(const auxssm_ctx*, const KDims&
 template <typename R, int D> int run_sv_logpdf(auxssm_ctx* h, const SvLogpdfArgs& a, void* out) {
     const bool cm = a.xp.se != 1;
     const int n = a.d.T - 1, C = a.d.C;
-    const int nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
+    const int TI = ti_cm_for(h, C, n);
+    const int nt = cm ? ((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    if (cm) hipLaunchKernelGGL((k_sv_logpdf_cm<R, D>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+    if (cm) hipLaunchKernelGGL((k_sv_logpdf_cm<R, D>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, a, part, nt, TI);
     else hipLaunchKernelGGL((k_sv_logpdf<R, D>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
@@ -1438,10 +1449,11 @@ template <typename R, int D> int run_sv_logpdf(auxssm_ctx* h, const SvLogpdfArgs
 template <typename R, int PO> int run_lorenz_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
     const bool cm = a.xp.se != 1;
     const int n = a.d.T - 1, C = a.d.C;
-    const int nt = cm ? ((n + TI_CM - 1) / TI_CM > 0 ? (n + TI_CM - 1) / TI_CM : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
+    const int TI = ti_cm_for(h, C, n);
+    const int nt = cm ? ((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    if (cm) hipLaunchKernelGGL((k_lorenz_logpdf_cm<R, PO>), dim3(grid_cm(C, n, TI_CM)), dim3(TB_CM), 0, h->stream, a, part, nt, TI_CM);
+    if (cm) hipLaunchKernelGGL((k_lorenz_logpdf_cm<R, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, a, part, nt, TI);
     else hipLaunchKernelGGL((k_lorenz_logpdf<R, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
