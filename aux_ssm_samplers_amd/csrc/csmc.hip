@@ -550,7 +550,7 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
 }  // namespace ax
 
 namespace ax {
-int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a);  // csmc_wide.hip
+int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a, void* ctt);  // csmc_wide.hip
 }
 using namespace ax;
 
@@ -647,8 +647,8 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         set_error("dx=%d: the cSMC kernels cover 1 <= dx <= 32", D);
         return AUXSSM_ERR_UNSUPPORTED;
     }
-    if (wide && (N > 64 || fk->F_t || fk->b_t || fk->chol_Q_t || fk->gradient || fk->transition != AUXSSM_TRANS_LINEAR)) {
-        set_error("dx=%d runs the wide-state cSMC kernels: N <= 64 particles, time-invariant linear-Gaussian transitions, no gradient proposals", D);
+    if (wide && (N > 64 || fk->transition != AUXSSM_TRANS_LINEAR)) {
+        set_error("dx=%d runs the wide-state cSMC kernels: N <= 64 particles, linear-Gaussian transitions", D);
         return AUXSSM_ERR_UNSUPPORTED;
     }
     if (fk->proposal != AUXSSM_PROP_BOOTSTRAP_LG && fk->proposal != AUXSSM_PROP_AUX_INDEPENDENT) {
@@ -803,7 +803,7 @@ extern "C" int auxssm_csmc_sweep(auxssm_handle h, int dtype, const auxssm_fk_mod
         a.eps_prop = pe;
         a.u_res = pu;
     }
-    if (wide) return run_csmc_wide(h, dtype, fk, a);
+    if (wide) return run_csmc_wide(h, dtype, fk, a, ctt);
 #define AX_CSMC_D(R)                                                        \
     switch (D) {                                                            \
         case 1: return run_csmc<R, 1>(h, fk, hm.data(), a, ctt);                 \

@@ -5,9 +5,11 @@
 // ballot-counted single draw, reciprocal Cholesky diagonals, det_exp / det_log, explicit fma) and the same oracle (oracle/csmc_ref.c, MAXD = 32) as the
 // register kernels of csmc.hip -- what changes is where a particle lives (the register kernels keep R x[D], eps[D], mu[D], z[D] per lane and the model BY VALUE
 // in the kernel arguments, which stops at dx = 4): here a particle's dx components sit ACROSS the 32 lanes of a half-wave, two particles per wave, 16 waves per
-// chain while there are CUs to spare (8 beyond), the model's matrices in LDS.  Linear-Gaussian transitions, every potential / proposal of the family; no
-// time-varying rows, no gradient proposals (AUXSSM_ERR_UNSUPPORTED).  (The first version of this file -- one wave per chain, one lane per particle walking
-// its dx x dx products alone: 30.5 ms per sweep of the SV protocol against 2.6 now -- is in the history)
+// chain while there are CUs to spare (8 beyond), the model's matrices in LDS.  Linear-Gaussian transitions, every potential / proposal of the family,
+// gradient-informed proposals (csmc/independent.py:57-75 gradient=True, :173-190, :252-268; both AUXSSM_GRAD_* weightings: the reference's own SV protocol
+// exposes --gradient at D = 30) and time-varying transitions (the step's F_t, b_t, chol Q_t re-staged into LDS before the step's first barrier) since round 4.
+// (The first version of this file -- one wave per chain, one lane per particle walking its dx x dx products alone: 30.5 ms per sweep of the SV protocol against
+// 2.6 now -- is in the history)
 //
 // In-kernel draws (AUXSSM_NOISE_THREEFRY) use the NATURAL flat indices of the explicit arrays -- eps_prop[c][t][n][k] = normal ((c T + t) N + n) dx + k of
 // stream 2, u_res[c][s][n] = uniform (c (T-1) + s) N + n of stream 3, u_bwd[c][t] = uniform c T + t of stream 4 -- not the two-steps-per-block packing
@@ -25,7 +27,18 @@ template <typename R> struct FkW {
     int proposal, potential, D;
     const R *m0, *LP0, *iLP0, *F, *b, *LQ, *iLQ;  // device arrays, matrices row-major with leading dimension D
     R c_init, c_trans, c_obs, inv_sig_y;
+    int gradient;                          // AUXSSM_GRAD_*
+    const R *Ft, *bt, *LQt, *ctt, *idt;    // time-varying transitions (csmc_dev.h::FkDev: row t = transition t -> t + 1), or null
 };
+// the transition t -> t + 1 in global memory (gradient kernel; the sweep kernels read it from LDS)
+template <typename R> struct TransW {
+    const R *F, *b, *LQ;
+};
+template <typename R> __device__ __forceinline__ TransW<R> trans_w(const FkW<R>& m, long long t) {
+    const long long D = m.D;
+    if (m.Ft) return TransW<R>{m.Ft + t * D * D, m.bt + t * D, m.LQt + t * D * D};
+    return TransW<R>{m.F, m.b, m.LQ};
+}
 
 // e_i = exp(lw_i - max lw) over ONE wave (csmc_dev.h::block_expmax)
 template <typename R> __device__ __forceinline__ R wave_expmax(R lw, R* m_out) {
@@ -65,6 +78,83 @@ template <typename R> __global__ void k_cw_potbound(int T, FkW<R> m, const R* __
         }
     }
     gb[t] = b;
+}
+
+// additive constants and reciprocal diagonals of the time-varying transition densities (csmc_dev.h::k_csmc_ctrans with a runtime dimension, same operations)
+template <typename R> __global__ void k_cw_ctrans(int n, int D, const R* __restrict__ LQt, R* __restrict__ ct, R* __restrict__ idt) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    R c = 0;
+    for (int k = 0; k < D; ++k) {
+        const R l = LQt[((long long)t * D + k) * D + k];
+        c -= det_log(l);
+        idt[(long long)t * D + k] = (R)1 / l;
+    }
+    ct[t] = c - (R)D * (R)0.91893853320467274178;
+}
+// w <- (L L^T)^-1 r (csmc_dev.h::cho_solve_fixed, runtime dimension, leading dimension D)
+template <typename R> __device__ __forceinline__ void cho_solve_w(int D, const R* L, const R* r, R* w) {
+    R z[CSW_MAXD];
+    for (int k = 0; k < D; ++k) {
+        R acc = r[k];
+        for (int j = 0; j < k; ++j) acc = fma_(-L[k * D + j], z[j], acc);
+        z[k] = acc / L[k * D + k];
+    }
+    for (int k = D - 1; k >= 0; --k) {
+        R acc = z[k];
+        for (int j = k + 1; j < D; ++j) acc = fma_(-L[j * D + k], w[j], acc);
+        w[k] = acc / L[k * D + k];
+    }
+}
+// the gradient of the model's joint log-density at u (csmc_dev.h::k_csmc_grad, same operations in the same order; one thread per (chain, time step):
+// C T threads of O(dx^2) work, once per sweep -- 0.5 M multiply-adds at the SV protocol's size)
+template <typename R> __global__ void k_cw_grad(CsmcArgs a, FkW<R> m) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)a.C * a.T) return;
+    const int D = m.D;
+    const long long t = g % a.T;
+    const R* u = (const R*)a.u + g * D;
+    R gr[CSW_MAXD], r[CSW_MAXD], w[CSW_MAXD];
+    const R* yv = (const R*)a.y;
+    for (int k = 0; k < D; ++k) {
+        const R y = yv ? yv[t * D + k] : (R)0;
+        R v = 0;
+        if (m.potential == 1 || (m.potential == 3 && y - y == 0)) v = ((y - u[k]) * m.inv_sig_y) * m.inv_sig_y;
+        else if (m.potential == 2) {
+            const R e = det_exp(-u[k]);
+            v = (R)0.5 * fma_(y * y, e, (R)-1);
+            v = (v == v) ? v : (R)0;
+        }
+        gr[k] = v;
+    }
+    if (t == 0) {
+        for (int k = 0; k < D; ++k) r[k] = u[k] - m.m0[k];
+        cho_solve_w<R>(D, m.LP0, r, w);
+    } else {
+        const TransW<R> tr = trans_w<R>(m, t - 1);
+        for (int k = 0; k < D; ++k) {
+            R acc = tr.b[k];
+            for (int j = 0; j < D; ++j) acc = fma_(tr.F[k * D + j], u[j - D], acc);
+            r[k] = u[k] - acc;
+        }
+        cho_solve_w<R>(D, tr.LQ, r, w);
+    }
+    for (int k = 0; k < D; ++k) gr[k] = gr[k] - w[k];
+    if (t + 1 < a.T) {
+        const TransW<R> tr = trans_w<R>(m, t);
+        for (int k = 0; k < D; ++k) {
+            R acc = tr.b[k];
+            for (int j = 0; j < D; ++j) acc = fma_(tr.F[k * D + j], u[j], acc);
+            r[k] = u[D + k] - acc;
+        }
+        cho_solve_w<R>(D, tr.LQ, r, w);
+        for (int k = 0; k < D; ++k) {
+            R acc = 0;
+            for (int j = 0; j < D; ++j) acc = fma_(tr.F[j * D + k], w[j], acc);
+            gr[k] = gr[k] + acc;
+        }
+    }
+    for (int k = 0; k < D; ++k) ((R*)a.grad)[g * D + k] = gr[k];
 }
 
 // =================================================================================================================================================
@@ -123,6 +213,33 @@ template <typename R> __device__ __forceinline__ void cw2_stage(const FkW<R>& m,
     }
     __syncthreads();
 }
+// time-varying transitions: the rows of transition tt -> tt + 1 replace the staged model (same layout; called by every thread between the two barriers that
+// separate the particle sections of consecutive steps, so no section reads a half-written model)
+template <typename R> __device__ __forceinline__ void cw2_stage_t(const FkW<R>& m, Cw2Lds<R>& L, long long tt, int tid, int nt) {
+    const int D = m.D, S = L.S;
+    const R* F = m.Ft + tt * D * D;
+    const R* LQ = m.LQt + tt * D * D;
+    const R* b = m.bt + tt * D;
+    const R* iL = m.idt + tt * D;
+    for (int i = tid; i < D * S; i += nt) {
+        const int r = i / S, q = i - r * S;
+        L.F[i] = q < D ? F[r * D + q] : (R)0;
+        L.LQ[i] = q < D ? LQ[r * D + q] : (R)0;
+    }
+    for (int i = tid; i < D; i += nt) L.b[i] = b[i], L.iL[i] = iL[i];
+    if (tid < 96) {
+        const int bq = tid / 12, e = tid - 12 * bq, jb = 4 * bq;
+        const int rr[6] = {1, 2, 2, 3, 3, 3}, cc[6] = {0, 0, 1, 0, 1, 2};
+        R v = 0;
+        if (e < 6) {
+            const int r = jb + rr[e], q = jb + cc[e];
+            v = r < D ? LQ[r * D + q] : (R)0;
+        } else if (e < 10) {
+            v = jb + e - 6 < D ? iL[jb + e - 6] : (R)0;
+        }
+        L.blk[tid] = v;
+    }
+}
 // value of lane J of MY half-wave: ds_swizzle in bit mode (lane' = (lane & and) | or inside each group of 32 lanes, and = 0, or = J) -- one LDS-crossbar
 // instruction, no memory, no scalar round trip (two v_readlane + two v_mov + a select before: the component loops are bound by the CU's instruction issue,
 // thirteen waves of one chain walk them together)
@@ -139,6 +256,19 @@ template <int J, int N, typename F> __device__ __forceinline__ void static_for(F
         f(std::integral_constant<int, J>{});
         static_for<J + 1, N>(f);
     }
+}
+// sum_k ((x_k - pm_k)^2 - (x_k - u_k)^2) / (2 s^2) of the particle whose component k this lane holds (csmc_dev.h::grad_correction: the two multiply-adds per
+// component, in component order, from broadcasts of the lanes' differences; components beyond D add fma(0, 0, acc) = acc)
+template <typename R> __device__ __forceinline__ R grad_corr_half(int D, int k, R xk, R uk, R pmk, R s) {
+    const R d1 = k < D ? xk - uk : (R)0, d2 = k < D ? xk - pmk : (R)0;
+    R acc = 0;
+    static_for<0, CSW_MAXD>([&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        const R b2 = half_bcast<R, j>(d2), b1 = half_bcast<R, j>(d1);
+        acc = fma_(b2, b2, acc);
+        acc = fma_(-b1, b1, acc);
+    });
+    return acc * ((R)0.5 / (s * s));
 }
 // log N(x; mean, L L^T) of the particle whose component k this lane holds (x - mean in `acc`), column-oriented substitution; L: lane k's row pointer with
 // element stride 1 (L[j] = L_kj), iLk = 1 / L_kk.  Every lane of the half-wave returns the same value.
@@ -262,15 +392,17 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
     const int ch = a.c0 + blockIdx.x;
     const R* xstar = (const R*)a.x + (long long)ch * T * D;
     const R* uaux = (const R*)a.u + (long long)ch * T * D;
+    const bool grad = m.gradient != 0 && m.proposal == 1, tv = m.Ft != nullptr;
+    const R* gaux = grad ? (const R*)a.grad + (long long)ch * T * D : uaux;
     const R* yv = (const R*)a.y;
     R* xs = (R*)a.xs + (long long)ch * T * N * D;
     R* lws = (R*)a.lws + (long long)ch * T * N;
     int32_t* As = a.As ? a.As + (long long)ch * (T - 1) * N : nullptr;
     R* fmax = a.fmax ? (R*)a.fmax + (long long)ch * T : nullptr;
     const R* gbp = (const R*)a.gb;
-    const bool bmode = gbp != nullptr;
+    const bool bmode = gbp != nullptr && !(grad && m.gradient == 2);  // (the exact-gradient correction is unbounded in x: csmc.hip)
     const R ninf = -INFINITY;
-    const R iLk = k < D ? L.iL[k] : (R)0, bk = k < D ? L.b[k] : (R)0;
+    R bk = k < D ? L.b[k] : (R)0;
     const R* Frow = L.F + (k < D ? k : 0) * S;
     const R* Lrow = L.LQ + (k < D ? k : 0) * S;
 
@@ -281,14 +413,16 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
         const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
         const bool pl = i < N;  // (uniform per half-wave)
         const int ir = pl ? i : 0;
-        R xk = 0, acc0 = 0;
+        R xk = 0, acc0 = 0, pmk = 0;
         if (k < D) {
             if (m.proposal == 0) {
                 R acc = m.m0[k];
                 for (int j = 0; j <= k; ++j) acc = fma_(m.LP0[k * D + j], L.eps[ir * S + j], acc);
                 xk = acc;
-            } else {
-                xk = fma_(((const R*)a.shd)[0], L.eps[ir * S + k], uaux[k]);
+            } else {  // AuxiliaryM0: N(u_0 [+ delta_0 / 2 grad_0], delta_0 / 2 I)  (independent.py:143-158)
+                const R s0 = ((const R*)a.shd)[0];
+                pmk = grad ? fma_(s0 * s0, gaux[k], uaux[k]) : uaux[k];
+                xk = fma_(s0, L.eps[ir * S + k], pmk);
             }
             if (i == 0) xk = xstar[k];
             acc0 = xk - m.m0[k];
@@ -296,6 +430,7 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
         const R yk = (yv && k < D) ? yv[k] : (R)0;
         R g = potential_half<R>(m, k, hi, xk, yk);
         if (m.proposal == 1) g = g + gauss_half<R>(D, k, hi, acc0, m.LP0 + (long long)(k < D ? k : 0) * D, k < D ? m.iLP0[k] : (R)0, m.c_init);  // AuxiliaryG0
+        if (grad) g = g + grad_corr_half<R>(D, k, xk, k < D ? uaux[k] : (R)0, pmk, ((const R*)a.shd)[0]);  // GradientAuxiliaryG0 (:173-190)
         if (pl && k < D) {
             L.xa[i * S + k] = xk;
             xs[(long long)i * D + k] = xk;
@@ -314,12 +449,15 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
         const R st = m.proposal != 0 ? ((const R*)a.shd)[t] : (R)0;
         const R uk = (m.proposal != 0 && k < D) ? uaux[(long long)t * D + k] : (R)0;
         const R xsk = k < D ? xstar[(long long)t * D + k] : (R)0;
+        const R gk = (grad && k < D) ? gaux[(long long)t * D + k] : (R)0;
+        const R ctr = tv ? m.ctt[t - 1] : m.c_trans;  // the transition t - 1 -> t (time-varying: row t - 1)
+        if (tv) cw2_stage_t<R>(m, L, t - 1, tid, NT_);  // (the previous step's particle section is behind its barrier)
         if (wv == 0) {
             // weights of step t - 1 and the conditional multinomial resampling (resamplings.py:14-37), one lane per particle
             const bool live = lane < N;
             const R lw = live ? L.lwv[lane] : ninf;
             const int tp = t - 1;
-            R Mb = (bmode ? gbp[tp] : (R)0) + (m.proposal == 1 ? m.c_trans : (R)0);
+            R Mb = (bmode ? gbp[tp] : (R)0) + (m.proposal == 1 ? (tv && tp >= 1 ? m.ctt[tp - 1] : m.c_trans) : (R)0);
             const bool used_bound = bmode && tp >= 1 && tp < T - 1 && (Mb - Mb == 0);
             R mstep, w;
             if (used_bound) {
@@ -349,6 +487,7 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
             cw2_draw<R>(a, L, ch, t, tid, NT_);
         }
         __syncthreads();
+        if (tv) bk = k < D ? L.b[k] : (R)0;
         for (int s = 0; s < nslot; ++s) {
             const int i = s * 2 * NW2 + 2 * wv + (hi ? 1 : 0);
             const bool pl = i < N;
@@ -360,21 +499,25 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
 #pragma unroll
                 for (int j = 0; j < CSW_MAXD; ++j) mu = fma_(Frow[j], xp[j], mu);  // (columns beyond D are zeros on both sides: fma(0, 0, mu) = mu)
             }
-            R xk = 0;
+            R xk = 0, pmk = 0;
             if (k < D) {
                 if (m.proposal == 0) {
                     R acc = mu;
 #pragma unroll
                     for (int j = 0; j < CSW_MAXD; ++j) acc = j <= k ? fma_(Lrow[j], L.eps[ir * S + j], acc) : acc;
                     xk = acc;
-                } else {
-                    xk = fma_(st, L.eps[ir * S + k], uk);
+                } else {  // AuxiliaryMtDynamics: N(u_t [+ delta_t / 2 grad_t], delta_t / 2 I) (independent.py:192-198)
+                    pmk = grad ? fma_(st * st, gk, uk) : uk;
+                    xk = fma_(st, L.eps[ir * S + k], pmk);
                 }
                 if (i == 0) xk = xsk;
             }
             // weights (csmc.py:95-96)
             R g = potential_half<R>(m, k, hi, xk, yk);
-            if (m.proposal == 1) g = gauss_half_blk<R>(D, k, xk - mu, Lrow, L.blk, m.c_trans) + g;  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
+            if (m.proposal == 1) g = gauss_half_blk<R>(D, k, xk - mu, Lrow, L.blk, ctr) + g;  // AuxiliaryGt = Mt.logpdf + Gt (independent.py:238-248)
+            // GradientAuxiliaryGt (:252-268): summed over the particles in the reference, i.e. a constant of the step (AUXSSM_GRAD_REFERENCE: nothing to add);
+            // AUXSSM_GRAD_EXACT applies it per particle
+            if (grad && m.gradient == 2) g = g + grad_corr_half<R>(D, k, xk, uk, pmk, st);
             if (pl && k < D) {
                 xcur[i * S + k] = xk;
                 xs[((long long)t * N + i) * D + k] = xk;
@@ -416,7 +559,8 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
     int32_t* anc = a.anc + (long long)ch * T;
     const R* fmax = (const R*)a.fmax + (long long)ch * T;
     const R ninf = -INFINITY;
-    const R iLk = k < D ? L.iL[k] : (R)0, bk = k < D ? L.b[k] : (R)0;
+    const bool tv = m.Ft != nullptr;
+    R bk = k < D ? L.b[k] : (R)0;
     const R* Frow = L.F + (k < D ? k : 0) * S;
     const R* Lrow = L.LQ + (k < D ? k : 0) * S;
     // B_T ~ choice(w_T) by wave 0
@@ -454,6 +598,12 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
     }
     for (int t = T - 2; t >= 0; --t) {
         __syncthreads();  // (the draw of the step before has been read by everybody)
+        const R ctr = tv ? m.ctt[t] : m.c_trans;  // the transition t -> t + 1 (time-varying: row t)
+        if (tv) {
+            cw2_stage_t<R>(m, L, t, tid, NT_);
+            __syncthreads();
+            bk = k < D ? L.b[k] : (R)0;
+        }
 #pragma unroll
         for (int s = 0; s < NSL; ++s) {
             if (s >= nslot) break;
@@ -473,14 +623,14 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
 #pragma unroll
                 for (int j = 0; j < CSW_MAXD; ++j) mu = fma_(Frow[j], xi[j], mu);
             }
-            const R lwt = gauss_half_blk<R>(D, k, xn - mu, Lrow, L.blk, m.c_trans) + lwik;  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
+            const R lwt = gauss_half_blk<R>(D, k, xn - mu, Lrow, L.blk, ctr) + lwik;  // Pt.logpdf(x_{t+1}, xs_t) + log_ws_t (csmc.py:136)
             if (pl && k == 0) L.lwv[i] = lwt;
         }
         __syncthreads();
         if (wv == 0) {
             const bool live = lane < N;
             const R lw = live ? L.lwv[lane] : ninf;
-            R Mb = fmax[t] + m.c_trans;
+            R Mb = fmax[t] + ctr;
             if (!(Mb - Mb == 0)) Mb = 0;
             R w = det_exp(lw - Mb);
             R cv = wave_scan_dpp(w);
@@ -503,11 +653,12 @@ template <typename R, int NW2> __global__ void __launch_bounds__(64 * NW2) k_cw2
 }
 
 // host: the model as one device block [m0 | LP0 | iLP0 | F | b | LQ | iLQ], constants as csmc_dev.h::fill_model computes them
-template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk, CsmcArgs& a, R* host_block) {
+template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk, CsmcArgs& a, R* host_block, void* ctt) {
     const int D = fk->dx;
     FkW<R> m;
     memset(&m, 0, sizeof(m));
     m.proposal = fk->proposal; m.potential = fk->potential; m.D = D;
+    m.gradient = fk->gradient;
     R* p = host_block;
     R* hm0 = p; p += D;
     R* hLP0 = p; p += D * D;
@@ -567,10 +718,22 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
     m.b = d; d += D;
     m.LQ = d; d += D * D;
     m.iLQ = d;
+    if (fk->F_t && a.T > 1) {  // time-varying transitions: device rows + their constants and reciprocal diagonals (csmc.hip::run_csmc does the same for dx <= 4)
+        m.Ft = (const R*)fk->F_t;
+        m.bt = (const R*)fk->b_t;
+        m.LQt = (const R*)fk->chol_Q_t;
+        m.ctt = (const R*)ctt;
+        m.idt = (const R*)ctt + (a.T - 1);
+        hipLaunchKernelGGL((k_cw_ctrans<R>), dim3((a.T - 1 + 255) / 256), dim3(256), 0, h->stream, a.T - 1, D, m.LQt, (R*)ctt, (R*)ctt + (a.T - 1));
+    }
     if (a.gb) hipLaunchKernelGGL((k_cw_potbound<R>), dim3((a.T + 255) / 256), dim3(256), 0, h->stream, a.T, m, (const R*)a.y, (R*)a.gb);
     if (fk->proposal == 1) {
         const long long total = (long long)a.C * a.T * D;
         hipLaunchKernelGGL((k_csmc_aux<R>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, h->stream, a, D);
+        if (fk->gradient) {
+            const long long tot = (long long)a.C * a.T;
+            hipLaunchKernelGGL((k_cw_grad<R>), dim3((unsigned)((tot + 63) / 64)), dim3(64), 0, h->stream, a, m);
+        }
     }
     const size_t lds = Cw2Lds<R>::bytes(D);
     if (lds > 48 * 1024) {
@@ -606,11 +769,11 @@ template <typename R> static int run_cw(auxssm_ctx* h, const auxssm_fk_model* fk
 }
 
 // called by auxssm_csmc_sweep (csmc.hip) for dx > CS_MAXD
-int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a) {
+int run_csmc_wide(auxssm_ctx* h, int dtype, const auxssm_fk_model* fk, CsmcArgs& a, void* ctt) {
     const int D = fk->dx;
     std::vector<double> host((size_t)3 * D * D + 4 * D + 8);
-    if (dtype == AUXSSM_F32) return run_cw<float>(h, fk, a, (float*)host.data());
-    return run_cw<double>(h, fk, a, host.data());
+    if (dtype == AUXSSM_F32) return run_cw<float>(h, fk, a, (float*)host.data(), ctt);
+    return run_cw<double>(h, fk, a, host.data(), ctt);
 }
 
 }  // namespace ax

@@ -105,7 +105,7 @@ def _pot(kind, y, sig=0.7):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("d,N,T", [(1, 64, 9), (2, 100, 33), (3, 256, 20), (4, 65, 12)])
+@pytest.mark.parametrize("d,N,T", [(1, 64, 9), (2, 100, 33), (3, 256, 20), (4, 65, 12), (5, 64, 11), (6, 25, 14), (17, 33, 8), (30, 25, 9), (32, 64, 5)])  # d > 4: csrc/csmc_wide.hip
 @pytest.mark.parametrize("proposal", [O.BOOTSTRAP_LG, O.AUX_INDEPENDENT])
 @pytest.mark.parametrize("backward", [True, False])
 def test_time_varying_transitions_bit_exact_vs_oracle(dtype, d, N, T, proposal, backward):
@@ -141,7 +141,7 @@ def test_time_varying_transitions_bit_exact_vs_oracle(dtype, d, N, T, proposal, 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("d,N,T", [(1, 64, 9), (2, 100, 33), (3, 512, 20)])
+@pytest.mark.parametrize("d,N,T", [(1, 64, 9), (2, 100, 33), (3, 512, 20), (5, 33, 12), (8, 64, 7), (30, 25, 10), (32, 17, 6)])  # d > 4: the wide-state kernels (round 4)
 @pytest.mark.parametrize("potential", [O.POT_FLAT, O.POT_GAUSS_OBS, O.POT_SV])
 @pytest.mark.parametrize("gradient", [True, "exact"])
 @pytest.mark.parametrize("tv", [False, True])

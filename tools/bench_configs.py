@@ -244,21 +244,22 @@ def sv30(T=250, D=30, N=25):
     h = _lib.default_handle()
     y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, D)
     M0, Mt = GaussianInit(m0=m0, P0=P0), LinearGaussianDynamics(F=F, b=b, Q=Q)
-    init, kernel = get_independent_kernel(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), N, backward=True, Pt=Mt)
-    for chains in (1, 256, 4096):
-        cc = CsmcChains(h, np.repeat(xtrue[None], chains, axis=0).astype(np.float32))
-        st = CSMCState(x=cc, updated=None)
-        kernel(0, st, 0.05)
-        h.sync()
-        reps = 5
-        t0 = time.perf_counter()
-        for k in range(reps):
-            kernel(1 + k, st, None)
-        h.sync()
-        el = time.perf_counter() - t0
-        print(json.dumps(dict(config=f"SV protocol D={D} T={T}, aux-cSMC N={N} independent proposals + backward sampling, fp32, resident chains", chains=chains,
-                              sweeps_per_s=round(chains * reps / el, 1), ms_per_sweep_call=round(el / reps * 1e3, 3),
-                              updated=float((cc.ancestors.to_host() != 0).mean()))))
+    for gradient in (False, True, "exact"):  # (--gradient of the protocol: experiment.py:18-57; "exact" = the per-particle weighting, AUXSSM_GRAD_EXACT)
+        init, kernel = get_independent_kernel(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), N, backward=True, Pt=Mt, gradient=gradient)
+        for chains in (1, 256, 4096):
+            cc = CsmcChains(h, np.repeat(xtrue[None], chains, axis=0).astype(np.float32))
+            st = CSMCState(x=cc, updated=None)
+            kernel(0, st, 0.05)
+            h.sync()
+            reps = 5
+            t0 = time.perf_counter()
+            for k in range(reps):
+                kernel(1 + k, st, None)
+            h.sync()
+            el = time.perf_counter() - t0
+            print(json.dumps(dict(config=f"SV protocol D={D} T={T}, aux-cSMC N={N} independent proposals (gradient={gradient}) + backward sampling, fp32, resident chains",
+                                  chains=chains, sweeps_per_s=round(chains * reps / el, 1), ms_per_sweep_call=round(el / reps * 1e3, 3),
+                                  updated=float((cc.ancestors.to_host() != 0).mean()))), flush=True)
 
 
 def sv30_kalman(T=250, D=30, chains=(1, 16, 64)):
