@@ -1778,6 +1778,10 @@ int auxssm_kalman_filter(auxssm_handle h, int dtype, const auxssm_dims* dims, co
     if ((rc = ws_reserve(h, wsb + 4096))) return rc;
     FilterArgs a;
     fill_filter_args(a, dims, lgssm, ys, ms, Ps);
+    // a wide batch axis (the reference's spatial example: B = 64 scalar LGSSMs side by side, examples/spatial/model.py:103-112): lanes <-> (c, b) sequences, which
+    // are contiguous along b in every (C, T, B, .) array -- no element buffer, the sequential recursion inside each time chunk (kernels.hip.h::run_filter)
+    static const int lanes_b = [] { const char* e = getenv("AUXSSM_FILTER_BATCH_LANES"); return e ? atoi(e) : 32; }();
+    if (!is_wide(dims->dx, dims->dy) && lanes_b > 0 && dims->B >= lanes_b && (long long)dims->C * dims->B >= 256) a.lay.cm = 1;
     return e->filter(h, a, parallel, ell);
 }
 

@@ -670,6 +670,79 @@ template <typename R_, int D, bool WRITE_U> struct FilterOpFlySV : FilterOpFly<R
     }
 };
 
+// ---- many sequences, any model (lanes <-> sequences, the arrays read through their strides: e.g. the dense (C, T, B, .) layout with the batch index fastest:
+// the reference's spatial example is B = 64 scalar LGSSMs, examples/spatial/model.py:103-112) -----------------------------------------------------------------
+// No element buffer.  Reduce pass: a chunk's composite from elements built in registers (filter_build_elem: the dense S = H P H^T + R form, any R) and combined
+// as they come.  Final pass: from the chunk's prefix -- the filtering distribution at the chunk's first step -- the reference's SEQUENTIAL recursion itself
+// (predict + sequential_update, filtering.py:66-130), so moments and log-likelihood increments are the sequential filter's given the prefix; the increments are
+// summed per chunk (nansum, filtering.py:62).  One chunk (parallel = 0, or few steps): exactly the sequential filter, one sequence per lane.
+template <typename R_, int D, int P, int P1> struct FilterOpBuildCm : FilterOp<R_, D> {
+    using R = R_;
+    using Full = typename FilterOp<R_, D>::Full;
+    using Args = FilterArgs;
+    using Raw = Full;
+    static AX_HD void load_elem(const Args& a, int s, int i, Full& e) {
+        DirectIO io;
+        filter_build_elem<R, D, P, DirectIO, P1>(a, io, s, i, true, e);
+    }
+    static AX_HD void load_raw(const Args& a, int s, int i, Raw& r) { load_elem(a, s, i, r); }
+    static AX_HD void build(const Args&, int, int, const Raw& r, Full& e) { e = r; }
+};
+template <typename R_, int D, int P> struct FilterOpSeqWalk : FilterOp<R_, D> {
+    using R = R_;
+    using Full = typename FilterOp<R_, D>::Full;
+    using Pre = typename FilterOp<R_, D>::Pre;
+    using Args = FilterArgs;
+    static constexpr bool kFold = true;
+    struct Raw {
+        R F[D * D], Q[D * D], bd[D], H[P * D], cv[P], y[P], Rm[P * P];
+    };
+    struct Carry {};
+    static AX_HD void carry_flush(const Carry&, R&) {}
+    static AX_HD void load_raw(const Args& a, int s, int i, Raw& r) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        const long long t = (long long)i + 1;
+        rd<R, D * D>(a.Fs, c, i, b, r.F);
+        rd<R, D>(a.bs, c, i, b, r.bd);
+        rd<R, D * D>(a.Qs, c, i, b, r.Q);
+        rd<R, P * D>(a.Hs, c, t, b, r.H);
+        rd<R, P>(a.cs, c, t, b, r.cv);
+        rd<R, P>(a.ys, c, t, b, r.y);
+        rd_upper<R, P>(a.Rs, c, t, b, r.Rm);
+    }
+    static AX_HD void init_pre(const Args& a, int s, Pre& p) {
+        R P0p[D * D];
+        rd<R, D>(a.ms, s / a.d.B, 0, s % a.d.B, p.b);
+        rd_cov<R, D>(a.Ps, s / a.d.B, 0, s % a.d.B, a.ps_packed, P0p);
+        sympack<R, D>(P0p, p.C);
+        p.z = 0;
+    }
+    static AX_HD void walk(const Args&, int, int, const Raw& r, Pre& p, Carry&) {
+        R Pd[D * D], m_[D], FP[D * D], Pn[D * D];
+        symunpack<R, D>(p.C, Pd);
+        mv<R, D, D>(r.F, p.b, m_);
+        mm<R, D, D, D>(r.F, Pd, FP);
+        mmt<R, D, D, D>(FP, r.F, Pn);
+#pragma unroll
+        for (int k = 0; k < D; ++k) m_[k] += r.bd[k];
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) Pn[k] += r.Q[k];
+        const R ell = kalman_update<R, D, P>(m_, Pn, r.H, r.cv, r.Rm, r.y);
+#pragma unroll
+        for (int k = 0; k < D; ++k) p.b[k] = m_[k];
+        sympack<R, D>(Pn, p.C);
+        p.z += isnan_(ell) ? (R)0 : ell;
+    }
+    static AX_HD void write_out(const Args& a, int s, int i, const Pre& p) {
+        const int c = s / a.d.B, b = s % a.d.B;
+        wr<R, D>(a.ms, c, (long long)i + 1, b, p.b);
+        R Pd[D * D];
+        symunpack<R, D>(p.C, Pd);
+        wr_cov<R, D>(a.Ps, c, (long long)i + 1, b, a.ps_packed, Pd);
+    }
+    static AX_HD void write_zpart(const Args& a, int s, int ch, int nchunk, R z) { ((R*)a.ellz)[(long long)s * nchunk + ch] = z; }
+};
+
 // ---- sampler ------------------------------------------------------------------------------------------
 struct SampleArgs {
     KDims d;

@@ -1265,6 +1265,23 @@ template <typename R, int D, int P> int run_filter(auxssm_ctx* h, const FilterAr
             return AUXSSM_OK;
         }
     }
+    // lanes <-> sequences on any model (the caller's arrays through their strides): no element buffer -- composites from elements built in registers, then the
+    // sequential recursion from each chunk's prefix (kalman_bodies.h::FilterOpBuildCm / FilterOpSeqWalk).  AUXSSM_CM_ELEM=1: the materialised-element passes.
+    static const bool cm_elem = [] { const char* e = getenv("AUXSSM_CM_ELEM"); return e && atoi(e) != 0; }();
+    if (cm && n > 0 && !cm_elem && !a.ps_packed) {
+        a.elem = nullptr;
+        a.ellz = ws_take(h, (size_t)S * a.lay.nchunk * sizeof(R));
+        if (!a.ellz) return AUXSSM_ERR_NOMEM;
+        {
+            ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+            const int rc = blk ? run_scan<FilterOp<R, D>, FilterOpSeqWalk<R, D, P>, FilterOpBuildCm<R, D, P, (P > D ? D : 0)>>(h, a, S, n)
+                               : run_scan<FilterOp<R, D>, FilterOpSeqWalk<R, D, P>, FilterOpBuildCm<R, D, P, 0>>(h, a, S, n);
+            if (rc) return rc;
+        }
+        hipLaunchKernelGGL((k_reduce_rows<R>), dim3(a.d.C), dim3(TB_ELEM), 0, h->stream, (const R*)a.ellz, (const R*)a.ell0, a.d.B, a.lay.nchunk, (R*)ell_out);
+        AX_HIP(hipGetLastError());
+        return AUXSSM_OK;
+    }
     const bool ks = !cm && n > 0 && use_ks<FilterOp<R, D>>(h, S, n, a.lay.nchunk > 1);  // few sequences: the tile scan, which builds its own elements (FilterOpBuild)
     a.elem = ks ? nullptr : ws_take(h, (size_t)a.lay.total_reals(n, S, FiltElem<R, D>::NPAD) * sizeof(R));
     // the marginal log-likelihood of t = 1..T-1 is the log-scale of the scan's total product (kalman_math.h::FiltElem::z): the final

@@ -617,7 +617,7 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
                        kernels={g: round(t / nst, 4) for g, (n, t) in groups.items()})
             if scan:
                 ent["roofline"] = dict(bound="hbm", achieved=round(alg / (scan * 1e-3) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s",
-                                       frac=round(alg / (scan * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None, kernel="filter scan, d = 1 (k_scan_reduce / k_scan_aggs / k_scan_down)",
+                                       frac=round(alg / (scan * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4), traffic=None, kernel="filter scan, d = 1, one sequence per lane (k_scan_reduce_cm<FilterOpBuildCm> / k_scan_aggs / k_scan_down_cm<FilterOpSeqWalk>: no element buffer)",
                                        avg_launch_ms=round(scan, 4), algorithmic_bytes_per_launch=alg)
             out["batched_scalar"].append(ent)
             del dlb, ydb, msb, Psb, ellb

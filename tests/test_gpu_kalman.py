@@ -56,6 +56,44 @@ def test_filter_batched_model(P, seed, T, dx, dy, parallel):
     npt.assert_allclose(bell, oell, **TOL64)
 
 
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("T,B", [(1, 300), (2, 256), (7, 300), (130, 257), (1000, 64)])
+@pytest.mark.parametrize("dx,dy", [(1, 1), (2, 3), (3, 1)])
+@pytest.mark.parametrize("parallel", [True, False])
+def test_filter_wide_batch_axis_runs_one_sequence_per_lane(P, T, B, dx, dy, parallel, dtype):
+    """B >= 32 independent models side by side (the reference's spatial example: 64 scalar LGSSMs, examples/spatial/model.py:103-112): `auxssm_kalman_filter` maps
+    lanes to (c, b) sequences -- no element buffer, composites from elements built in registers, then the SEQUENTIAL recursion from every chunk's prefix
+    (kernels.hip.h::run_filter, kalman_bodies.h::FilterOpSeqWalk).  Against the oracle's batched filter, with missing observations and several sequences of
+    observations on shared parameters."""
+    Cn = 2 if T <= 130 else 4
+    (bys, blg), _ = ref_batched_inputs(5 + T + B, max(T, 2), dx, dy, B)
+    blg = list(blg)
+    blg[2] = 0.6 * blg[2] / np.sqrt(dx)                      # contracting transitions: T = 1000 steps stay in range
+    blg = [a[:T - 1] if k in (2, 3, 4) else (a[:T] if k >= 5 else a) for k, a in enumerate(blg)]
+    rng = np.random.default_rng(T * B)
+    ys = bys[None, :T] + 0.3 * rng.standard_normal((Cn, T, B, dy))
+    ys[rng.random(ys.shape) < 0.1] = np.nan                 # missing components, whole missing observations among them
+    if T > 2:
+        ys[:, 2] = np.nan
+    import ctypes as C
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd._primitives.kalman.base import DeviceLGSSM
+    h = _lib.default_handle()
+    dl = DeviceLGSSM(h, tuple(blg), 1, T, B, dx, dy, True, dtype)           # parameters shared by the Cn sequences of observations (chain stride 0)
+    yd = h.to_device(ys.astype(dtype))
+    msd, Psd, elld = h.empty((Cn, T, B, dx), dtype), h.empty((Cn, T, B, dx, dx), dtype), h.empty((Cn,), dtype)
+    dims = _lib.Dims(Cn, T, B, dx, dy)
+    yarr = yd.arr(T * B * dy, B * dy, dy)
+    _lib.check(h.lib.auxssm_kalman_filter(h.h, _lib.dtype_code(dtype), C.byref(dims), C.byref(dl.c), C.byref(yarr), int(parallel), msd.ptr, Psd.ptr, elld.ptr))
+    ms, Ps, ell = msd.to_host(), Psd.to_host(), elld.to_host()
+    tol = TOL64 if dtype == np.float64 else dict(rtol=2e-3, atol=2e-3)
+    for c in range(Cn):
+        oms, oPs, oell = K.filtering(ys[c], blg, parallel)
+        npt.assert_allclose(ms[c], oms, **tol)
+        npt.assert_allclose(Ps[c], oPs, **tol)
+        npt.assert_allclose(ell[c], oell, rtol=tol["rtol"], atol=tol["atol"] * T * B * 0.05 + tol["atol"])
+
+
 @pytest.mark.parametrize("seed", [42, 666])
 @pytest.mark.parametrize("T", [3, 5, 300])
 @pytest.mark.parametrize("dx", [1, 2])
