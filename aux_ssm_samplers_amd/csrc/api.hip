@@ -547,6 +547,16 @@ template <typename R> static int launch_select(auxssm_ctx* h, int C, int T, int 
     return AUXSSM_OK;
 }
 
+// the observation pattern of the concatenated model, chain-independent: [0 (D) ; yobs_t] (the auxiliary block is always observed).  Handed to the chain-shared
+// wide filter as FilterArgs::mask_ys it needs no read-back of the chains' patterns (no host synchronisation inside a sweep)
+template <typename R> __global__ void k_concat_carrier(int T, int D, int P, Arr yobs, R* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (long long)T * P) return;
+    const long long t = g / P;
+    const int k = (int)(g % P);
+    out[g] = k < D ? (R)0 : at<R>(yobs, 0, t, 0)[k - D];
+}
+
 template <typename R>
 static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, const auxssm_lgssm* model, const auxssm_arr* yobs,
                            double delta, const double* dptr, const uint32_t* keys, int parallel, int nan_policy, int layout, void* x, const void* eps_aux, const void* eps_samp,
@@ -585,6 +595,7 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     add(CT * D * D * sR);                              // Ps
     add(CT * D * sR);                                  // x_prop
     add((size_t)C * sR + (size_t)5 * C * sizeof(Acc) + 2048);  // ell, the five totals
+    if (wide) add((size_t)T * P * sR);                 // the observation-pattern carrier of the chain-shared wide filter
     add(wide ? wide_filter_ws(h, dtype, kd, parallel, D, P) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : sl->ws(h, kd));
@@ -641,9 +652,13 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
     static const bool ps_pack_on = [] { const char* e = getenv("AUXSSM_PS_PACK"); return e ? atoi(e) != 0 : true; }();
     static const bool samp_fly_on = [] { const char* e = getenv("AUXSSM_SAMPLE_FLY"); return e ? atoi(e) != 0 : true; }();
     const bool ps_pack = ps_pack_on && samp_fly_on && cm && !shared_mode && !wide;
-    const Arr PsA = shared_mode ? Arr{Ps, 0, (long long)D * D, 0, 1}
-                    : cm        ? cm_arr(Ps, kd, ps_pack ? (long long)symsize(D) : (long long)D * D)
-                                : dense_arr(Ps, kd, (long long)D * D);
+    // wide states, several chains on one model: ONE copy of the filtered covariances (chain stride 0) -- the chain-shared wide filter then skips its broadcast to
+    // the chains' slots and the sampler builds its gain / factor tables once (wide.hip::run_sample_shared); the pattern carrier below replaces the filter's read-back
+    const bool wide_shared = wide && C >= 2 && h->share_model && model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0 &&
+                             model->Hs.sc == 0 && model->Rs.sc == 0 && model->cs.sc == 0 && yobs->sc == 0;
+    const Arr PsA = (shared_mode || wide_shared) ? Arr{Ps, 0, (long long)D * D, 0, 1}
+                    : cm                         ? cm_arr(Ps, kd, ps_pack ? (long long)symsize(D) : (long long)D * D)
+                                                 : dense_arr(Ps, kd, (long long)D * D);
     const Arr xpA = cm ? cm_arr(xp, kd, D) : dense_arr(xp, kd, D);
     const Arr xA = cm ? cm_arr(x, kd, D) : dense_arr(x, kd, D);
     const Arr epsauxA = cm ? cm_arr(eps_aux, kd, D) : dense_arr(eps_aux, kd, D);
@@ -703,6 +718,13 @@ static int sweep_lg_concat(auxssm_ctx* h, int dtype, const auxssm_dims* dims, co
         fa.aux_shd = sqrt(0.5 * delta);
         fa.dptr = dptr;
         if (gen) fa.aux_gen = 1, fa.gen_k0 = keys[0], fa.gen_k1 = keys[1];
+    }
+    if (wide_shared) {
+        R* carrier = (R*)ws_take(h, (size_t)T * P * sR);
+        if (!carrier) return AUXSSM_ERR_NOMEM;
+        const long long tot = (long long)T * P;
+        hipLaunchKernelGGL((k_concat_carrier<R>), dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, h->stream, T, D, P, cv(*yobs), carrier);
+        fa.mask_ys = Arr{carrier, 0, (long long)P, 0, 1};
     }
     rc = ke->filter(h, fa, parallel, ell);
     if (rc) return rc;

@@ -1814,7 +1814,8 @@ template <typename R> __device__ __forceinline__ void chol_blk_n2n(R* X, int ld,
         }
     __syncthreads();
 }
-template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(SampleArgs a, R* __restrict__ elem) {
+// ltab (optional): the factor Lc of every position goes to ltab[j] (d x d) as well -- the shared sampler's second table (wide_shared.h)
+template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(SampleArgs a, R* __restrict__ elem, R* __restrict__ ltab) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, d = a.dx, T = a.d.T;
     const int s = blockIdx.x / T, j = blockIdx.x - s * T, c = s / a.d.B, b = s % a.d.B;
@@ -1846,6 +1847,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
             for (int q = tid & 63; q < d; q += 64) X[r * ldd + q] = r == q ? P[r * ldd + r] : (R)0.5 * (P[r * ldd + q] + P[q * ldd + r]);
         __syncthreads();
         chol_blk_n2n<R>(X, ldd, d, Z, ldz, rowbuf, piv, invd, dg, flag, tid);
+        if (ltab) store_mat<R>(ltab + (long long)j * d * d, X, ldd, d, d, tid);
         for (int r = tid / 64; r < d; r += NWV)
             for (int q = tid & 63; q < d; q += 64) e[r * d + q] = 0;
         gemv<R, false>(d, d, X, ldd, eps, tv, (R)1, (R)0, tid);  // Lc eps (the factor's upper part is zero)
@@ -1881,6 +1883,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_sample_init(Sampl
     gemm<false, true>(d, d, d, T1, ldd, G, ldd, X, ldd, (R)-1, (R)1, tid);
     symmetrise<R>(X, ldd, d, tid);
     chol_blk_n2n<R>(X, ldd, d, Z, ldz, rowbuf, piv, invd, dg, flag, tid);
+    if (ltab) store_mat<R>(ltab + (long long)j * d * d, X, ldd, d, d, tid);
     // inc = m - G (F m + b) + Lc eps  (:108-112)
     gemv<R, false>(d, d, F, ldd, m, pm, (R)1, (R)0, tid);
     for (int k = tid; k < d; k += NT) pm[k] += bd[k];
@@ -2441,7 +2444,9 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     // beside the gain table (matrix cores / latency) and the one-workgroup pass over the chunk composites
     bool forked = false;
     const bool prof_all = h->prof.kernel_id == AUXSSM_K_ALL && h->prof.max_launches > 0;
-    if (!prof_all && !getenv("AUXSSM_WIDE_NO_FORK")) {
+    const bool ps_once = a.Ps.sc == 0 && a.Ps.sb == 0;  // the caller keeps ONE copy of the covariances (the matrix filter wrote it): nothing to broadcast
+    if (ps_once) {
+    } else if (!prof_all && !getenv("AUXSSM_WIDE_NO_FORK")) {
         if (!h->fork_stream) {
             AX_HIP(hipStreamCreateWithFlags(&h->fork_stream, hipStreamNonBlocking));
             AX_HIP(hipEventCreateWithFlags(&h->fork_ev, hipEventDisableTiming));
@@ -2484,8 +2489,74 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     return AUXSSM_OK;
 }
 
+// chunks of the shared sampler's vector scan: the chunk walks (twice E = T / nchunk dependent products) against the one-workgroup pass over the nchunk
+// composites -- nchunk ~ sqrt(2 T) balances them (T = 250: 22 chunks of 12; the filter's plan would make 250 chunks of one step and a 250-step serial pass)
+static WPlan samp_plan(int T, int parallel) {
+    WPlan p{};
+    p.E = T > 0 ? T : 1;
+    p.nchunk = 1;
+    p.cnt[0] = 1;
+    if (!parallel || T <= 3) return p;
+    long long nchunk = std::max(1ll, (long long)std::sqrt(2.0 * T));
+    if (const char* ev = getenv("AUXSSM_WIDE_SAMP_NCHUNK")) {
+        const long long v = atoll(ev);
+        if (v >= 1 && v <= T) nchunk = v;
+    }
+    p.E = (int)((T + nchunk - 1) / nchunk);
+    p.nchunk = (T + p.E - 1) / p.E;
+    p.cnt[0] = p.nchunk;
+    return p;
+}
+// column blocks of the shared sampler: as many sequences per workgroup as keep the grid at two rounds of workgroups
+static int samp_cb(const auxssm_ctx* h, int S, int nchunk) {
+    int CB = 64;
+    while (CB > 16 && (long long)((S + CB - 1) / CB) * nchunk < 2ll * h->num_cu && CB / 2 >= 8) CB /= 2;
+    return std::min(CB, std::max(S, 1));
+}
+// sequences sharing the model AND the filtered covariances (Ps with chain / batch stride 0: what the shared filter leaves when its caller asks for one copy):
+// the gain / factor tables once, the sequences as columns (wide_shared.h).  Returns 1 when not applicable.
+template <typename R> static int run_sample_shared(auxssm_ctx* h, const SampleArgs& a, int parallel) {
+    const int S = a.d.S(), T = a.d.T, d = a.dx;
+    static const bool off = getenv("AUXSSM_WIDE_SHARED") && atoi(getenv("AUXSSM_WIDE_SHARED")) == 0;
+    if (off || !h->share_model || S < 2 || T < 2) return 1;
+    for (const Arr* q : {&a.Ps, &a.Fs, &a.Qs, &a.bs})
+        if (q->sc != 0 || q->sb != 0) return 1;
+    const WPlan pl = samp_plan(T, parallel);
+    const int CB = samp_cb(h, S, pl.nchunk), ncb = (S + CB - 1) / CB;
+    const size_t l_e = lds_samp_evec(sizeof(R), d, CB), l_s = lds_samp_scan(sizeof(R), d, CB);
+    if (std::max(l_e, l_s) > LDS_BUDGET) return 1;
+    const size_t ne = (size_t)d * d + d;
+    R* gtab = (R*)ws_take(h, (size_t)T * ne * sizeof(R));
+    R* ltab = (R*)ws_take(h, (size_t)T * d * d * sizeof(R));
+    R* ec = (R*)ws_take(h, (size_t)T * S * d * sizeof(R));
+    R* gagg = (R*)ws_take(h, (size_t)pl.nchunk * ne * sizeof(R));
+    R* eagg = (R*)ws_take(h, (size_t)pl.nchunk * S * d * sizeof(R));
+    R* pre = (R*)ws_take(h, (size_t)pl.nchunk * S * d * sizeof(R));
+    if (!gtab || !ltab || !ec || !gagg || !eagg || !pre) return AUXSSM_ERR_NOMEM;
+    {
+        ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
+        SampleArgs a1 = a;  // the tables: sequence 0's records (its own increments come out of the column pass like everybody's)
+        a1.d = KDims{1, T, 1};
+        WK_LAUNCH((wk_sample_init<R>), (long long)T, lds_sample_init(sizeof(R), d), a1, gtab, ltab);
+        WK_LAUNCH((wk_samp_evec<R>), (long long)T * ncb, l_e, a, (const R*)gtab, (const R*)ltab, ec, ncb, CB);
+    }
+    ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
+    if (pl.nchunk > 1) {
+        WK_LAUNCH((wk_sscan_reduce<R>), (long long)pl.nchunk, lds_sample_scan(sizeof(R), d), (const R*)gtab, gagg, T, pl.E, pl.nchunk, d);
+        WK_LAUNCH((wk_samp_reduce<R>), (long long)pl.nchunk * ncb, l_s, (const R*)gtab, (const R*)ec, eagg, T, pl.E, pl.nchunk, d, S, ncb, CB);
+        WK_LAUNCH((wk_samp_aggs<R>), (long long)ncb, l_s, (const R*)gagg, (const R*)eagg, pre, pl.nchunk, d, S, CB);
+    }
+    WK_LAUNCH((wk_samp_down<R>), (long long)pl.nchunk * ncb, l_s, a, (const R*)gtab, (const R*)ec, (const R*)pre, pl.E, pl.nchunk, ncb, CB);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
 template <typename R> int run_sample(auxssm_ctx* h, const SampleArgs& a, int parallel) {
     const int S = a.d.S(), T = a.d.T, d = a.dx;
+    if (S >= 2) {
+        const int rc = run_sample_shared<R>(h, a, parallel);
+        if (rc != 1) return rc;
+    }
     const WPlan pl = plan(h, S, T, parallel);
     const size_t ne = (size_t)d * d + d;
     R* elem = (R*)ws_take(h, (size_t)S * T * ne * sizeof(R));
@@ -2494,7 +2565,7 @@ template <typename R> int run_sample(auxssm_ctx* h, const SampleArgs& a, int par
     if (!elem || !aggs || !pre) return AUXSSM_ERR_NOMEM;
     {
         ProfScope ps(h, AUXSSM_K_SAMPLE_INIT);
-        WK_LAUNCH((wk_sample_init<R>), (long long)S * T, lds_sample_init(sizeof(R), d), a, elem);
+        WK_LAUNCH((wk_sample_init<R>), (long long)S * T, lds_sample_init(sizeof(R), d), a, elem, (R*)nullptr);
     }
     ProfScope ps(h, AUXSSM_K_SAMPLE_SCAN);
     const size_t ls = lds_sample_scan(sizeof(R), d);
@@ -2522,6 +2593,25 @@ template <typename R> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs&
     R* part = (R*)ws_take(h, (size_t)5 * C * T * sizeof(R));
     if (!part) return AUXSSM_ERR_NOMEM;
     ProfScope ps(h, AUXSSM_K_LOGPDF);
+    // chains on one model: the covariances' inverses and log-determinants once per time step, the chains as columns (wide_shared.h::wk_lp_tab / wk_lp_cols)
+    static const bool sh_off = getenv("AUXSSM_WIDE_SHARED") && atoi(getenv("AUXSSM_WIDE_SHARED")) == 0;
+    bool shared = !sh_off && h->share_model && C >= 2 && !a.u_fly && NT == 1024 && spd_fits(std::max(a.dx, a.po), 2 * std::max(a.dx, a.po));
+    for (const Arr* q : {&a.m0, &a.P0, &a.Fs, &a.Qs, &a.bs, &a.Hs, &a.Rs, &a.cs, &a.ys})
+        if (q->sc != 0 || q->sb != 0) shared = false;
+    if (shared) {
+        int CB = std::min(64, C);
+        while (CB > 8 && lds_lp_cols(sizeof(R), a.dx, a.po, CB) > LDS_BUDGET) CB /= 2;
+        const size_t l_tab = lds_lp_tab(sizeof(R), a.dx, a.po), l_cols = lds_lp_cols(sizeof(R), a.dx, a.po, CB);
+        R* tab = (R*)ws_take(h, (size_t)T * lp_row(a.dx, a.po) * sizeof(R));
+        if (tab && l_tab <= LDS_BUDGET && l_cols <= LDS_BUDGET) {
+            const int ncb = (C + CB - 1) / CB;
+            WK_LAUNCH((wk_lp_tab<R>), (long long)T, l_tab, a, tab);
+            WK_LAUNCH((wk_lp_cols<R>), (long long)T * ncb, l_cols, a, (const R*)tab, part, ncb, CB);
+            hipLaunchKernelGGL((wk_reduce<R, Acc>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (Acc*)out);
+            AX_HIP(hipGetLastError());
+            return AUXSSM_OK;
+        }
+    }
     WK_LAUNCH((wk_sweep_logpdf<R>), (long long)C * T, lds_sweep_logpdf(sizeof(R), a.dx, a.po), a, part);
     hipLaunchKernelGGL((wk_reduce<R, Acc>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (Acc*)out);
     AX_HIP(hipGetLastError());
@@ -2538,9 +2628,14 @@ size_t wide_sample_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int paral
     const size_t s = dtype == AUXSSM_F32 ? 4 : 8;
     const wide::WPlan p = wide::plan(h, kd.S(), kd.T, parallel);
     const size_t ne = (size_t)d * d + d;
-    return ((size_t)kd.S() * kd.T * ne + (size_t)kd.S() * p.nchunk * (ne + d)) * s + 4096;
+    const size_t per_seq = ((size_t)kd.S() * kd.T * ne + (size_t)kd.S() * p.nchunk * (ne + d)) * s + 4096;
+    const wide::WPlan p1 = wide::samp_plan(kd.T, parallel);  // shared form: two tables, the increments, the chunk composites
+    const size_t shared = ((size_t)kd.T * (ne + (size_t)d * d + (size_t)kd.S() * d) + (size_t)p1.nchunk * (ne + 2 * (size_t)kd.S() * d)) * s + 8 * 256;
+    return std::max(per_seq, shared);
 }
-size_t wide_logpdf_ws(int dtype, const KDims& kd) { return (size_t)5 * kd.S() * kd.T * (dtype == AUXSSM_F32 ? 4 : 8) + 4096; }
+size_t wide_logpdf_ws(int dtype, const KDims& kd) {  // (+ the shared form's table: Q^-1 of at most 85 x 85 and R^-1 of at most 128 x 128 per time step -- wide_fits)
+    return ((size_t)5 * kd.S() * kd.T + (size_t)kd.T * (85 * 85 + 128 * 128 + 8)) * (dtype == AUXSSM_F32 ? 4 : 8) + 4096;
+}
 
 static size_t ws_unused_f(const auxssm_ctx*, const KDims&, int) { return 0; }
 static size_t ws_unused_l(const auxssm_ctx*, const KDims&) { return 0; }

@@ -584,3 +584,374 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_ps_bcast(FilterAr
         }
     }
 }
+
+// =================================================================================================================================================
+// The pathwise SAMPLER of sequences that share the model and the filtered covariances (sampling.py:60-124): the gains
+// G_t = P_t (S_t^-1 F)^T and the factors Lc_t = chol(P_t - G_t S_t G_t^T) depend on neither the sequence's means nor its noise, so wk_sample_init runs ONCE
+// per time step (on sequence 0: its [G | e] records are the G table, Lc goes to a second table) instead of once per (sequence, time step), the products of
+// the gains over a chunk are formed once (wk_sscan_reduce on that one table), and the sequences carry only d-vectors: their increments
+// e_t = m_t - G_t (F m_t + b) + Lc_t eps_t and the recursion x_t = G_t x_{t+1} + e_t, with the sequences as the COLUMNS of d x CB matrices -- every step of
+// every pass is one d x d by d x CB product on the matrix cores.  Scan position j <-> time T - 1 - j, as in wide.hip.  ec: [T][S][d].
+// =================================================================================================================================================
+static size_t lds_samp_evec(size_t s, int d, int CB) { return 3 * al16(d * (size_t)ldp_(d) * s) + 5 * al16(d * (size_t)ldp_(CB) * s) + al16(d * s) + 64; }
+template <typename R> __global__ void __launch_bounds__(NT) wk_samp_evec(SampleArgs a, const R* __restrict__ gtab, const R* __restrict__ ltab, R* __restrict__ ec, int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, T = a.d.T, S = a.d.S();
+    const int j = blockIdx.x / ncb, cb = blockIdx.x - j * ncb, s0 = cb * CB, nc = min(CB, S - s0);
+    const long long t = (long long)T - 1 - j;
+    const int ldd = ldp_(d), ldc = ldp_(CB);
+    const long long ne = (long long)d * d + d;
+    Bump L{smem};
+    R* G = L.take<R>(d * ldd);
+    R* Lc = L.take<R>(d * ldd);
+    R* F = L.take<R>(d * ldd);
+    R* M = L.take<R>(d * ldc);
+    R* Ee = L.take<R>(d * ldc);
+    R* PM = L.take<R>(d * ldc);
+    R* TV = L.take<R>(d * ldc);
+    R* LE = L.take<R>(d * ldc);
+    R* bd = L.take<R>(d);
+    // the sequences' means and noise of this time step as columns
+    for (int e = tid; e < d * nc; e += NT) {
+        const int q = e / d, k = e - q * d, sq = s0 + q;
+        M[k * ldc + q] = at<R>(a.ms, sq / a.d.B, t, sq % a.d.B)[k];
+        Ee[k * ldc + q] = at<R>(a.eps, sq / a.d.B, t, sq % a.d.B)[k];
+    }
+    load_mat<R>(Lc, ldd, ltab + (long long)j * d * d, d, d, tid);
+    gemm<false, false>(d, nc, d, Lc, ldd, Ee, ldc, LE, ldc, (R)1, (R)0, tid);  // Lc eps (the factor's upper part is zero)
+    R* out = ec + ((long long)j * S + s0) * d;
+    if (j == 0) {  // _sample_last_step :115-124: e = m + Lc eps
+        for (int e = tid; e < d * nc; e += NT) {
+            const int q = e / d, k = e - q * d;
+            out[(long long)q * d + k] = M[k * ldc + q] + LE[k * ldc + q];
+        }
+        return;
+    }
+    load_mat<R>(G, ldd, gtab + (long long)j * ne, d, d, tid);
+    load_mat<R>(F, ldd, at<R>(a.Fs, 0, t, 0), d, d, tid);
+    load_vec<R>(bd, at<R>(a.bs, 0, t, 0), d, tid);
+    // inc = m - G (F m + b) + Lc eps  (:108-112)
+    gemm<false, false>(d, nc, d, F, ldd, M, ldc, PM, ldc, (R)1, (R)0, tid);
+    for (int e = tid; e < d * nc; e += NT) {
+        const int q = e / d, k = e - q * d;
+        PM[k * ldc + q] += bd[k];
+    }
+    __syncthreads();
+    gemm<false, false>(d, nc, d, G, ldd, PM, ldc, TV, ldc, (R)1, (R)0, tid);
+    for (int e = tid; e < d * nc; e += NT) {
+        const int q = e / d, k = e - q * d;
+        out[(long long)q * d + k] = M[k * ldc + q] - TV[k * ldc + q] + LE[k * ldc + q];
+    }
+}
+// E (d x nc) <- the increments of position i, sequences s0 .. s0 + nc
+template <typename R> __device__ __forceinline__ void samp_load_cols(R* E, int ldc, const R* __restrict__ src, int d, int nc, int tid) {
+    for (int e = tid; e < d * nc; e += NT) {
+        const int q = e / d, k = e - q * d;
+        E[k * ldc + q] = src[(long long)q * d + k];
+    }
+    __syncthreads();
+}
+static size_t lds_samp_scan(size_t s, int d, int CB) { return al16(d * (size_t)ldp_(d) * s) + 3 * al16(d * (size_t)ldp_(CB) * s) + 64; }
+// a chunk's composite increment of every sequence: E <- G_i E + e_i over the chunk (the product of the gains is the shared table's aggregate)
+template <typename R> __global__ void __launch_bounds__(NT) wk_samp_reduce(const R* __restrict__ gtab, const R* __restrict__ ec, R* __restrict__ eagg, int n, int E_, int nchunk, int d, int S,
+                                                                          int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, ch = blockIdx.x / ncb, cb = blockIdx.x - ch * ncb, s0 = cb * CB, nc = min(CB, S - s0);
+    const int ldd = ldp_(d), ldc = ldp_(CB);
+    const long long ne = (long long)d * d + d;
+    Bump L{smem};
+    R* G = L.take<R>(d * ldd);
+    R* Ea = L.take<R>(d * ldc);
+    R* Eb = L.take<R>(d * ldc);
+    R* Ec = L.take<R>(d * ldc);
+    const int i0 = ch * E_, i1 = min(n, i0 + E_);
+    samp_load_cols<R>(Ea, ldc, ec + ((long long)i0 * S + s0) * d, d, nc, tid);
+    for (int i = i0 + 1; i < i1; ++i) {
+        load_mat<R>(G, ldd, gtab + (long long)i * ne, d, d, tid);
+        samp_load_cols<R>(Ec, ldc, ec + ((long long)i * S + s0) * d, d, nc, tid);
+        gemm<false, false>(d, nc, d, G, ldd, Ea, ldc, Eb, ldc, (R)1, (R)1, tid, Ec, ldc);
+        R* sw = Ea;
+        Ea = Eb;
+        Eb = sw;
+    }
+    R* out = eagg + ((long long)ch * S + s0) * d;
+    for (int e = tid; e < d * nc; e += NT) {
+        const int q = e / d, k = e - q * d;
+        out[(long long)q * d + k] = Ea[k * ldc + q];
+    }
+}
+// the exclusive prefixes of the chunk composites, every sequence of a column block in one workgroup: pre[ch] for ch >= 1 (gagg: the shared gain products)
+template <typename R> __global__ void __launch_bounds__(NT) wk_samp_aggs(const R* __restrict__ gagg, const R* __restrict__ eagg, R* __restrict__ pre, int nchunk, int d, int S, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, s0 = blockIdx.x * CB, nc = min(CB, S - s0);
+    const int ldd = ldp_(d), ldc = ldp_(CB);
+    const long long ne = (long long)d * d + d;
+    Bump L{smem};
+    R* G = L.take<R>(d * ldd);
+    R* Ea = L.take<R>(d * ldc);
+    R* Eb = L.take<R>(d * ldc);
+    R* Ec = L.take<R>(d * ldc);
+    samp_load_cols<R>(Ea, ldc, eagg + (long long)s0 * d, d, nc, tid);
+    for (int ch = 1; ch < nchunk; ++ch) {
+        R* out = pre + ((long long)ch * S + s0) * d;
+        for (int e = tid; e < d * nc; e += NT) {
+            const int q = e / d, k = e - q * d;
+            out[(long long)q * d + k] = Ea[k * ldc + q];
+        }
+        if (ch + 1 < nchunk) {
+            load_mat<R>(G, ldd, gagg + (long long)ch * ne, d, d, tid);
+            samp_load_cols<R>(Ec, ldc, eagg + ((long long)ch * S + s0) * d, d, nc, tid);
+            gemm<false, false>(d, nc, d, G, ldd, Ea, ldc, Eb, ldc, (R)1, (R)1, tid, Ec, ldc);
+            R* sw = Ea;
+            Ea = Eb;
+            Eb = sw;
+        }
+    }
+}
+// the trajectories: from the chunk's prefix, x <- G_i x + e_i position by position; position i is time T - 1 - i
+template <typename R> __global__ void __launch_bounds__(NT) wk_samp_down(SampleArgs a, const R* __restrict__ gtab, const R* __restrict__ ec, const R* __restrict__ pre, int E_, int nchunk,
+                                                                        int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, n = a.d.T, S = a.d.S();
+    const int ch = blockIdx.x / ncb, cb = blockIdx.x - ch * ncb, s0 = cb * CB, nc = min(CB, S - s0);
+    const int ldd = ldp_(d), ldc = ldp_(CB);
+    const long long ne = (long long)d * d + d;
+    Bump L{smem};
+    R* G = L.take<R>(d * ldd);
+    R* Ea = L.take<R>(d * ldc);
+    R* Eb = L.take<R>(d * ldc);
+    R* Ec = L.take<R>(d * ldc);
+    const int i0 = ch * E_, i1 = min(n, i0 + E_);
+    samp_load_cols<R>(Ea, ldc, (ch == 0 ? ec : pre + (long long)ch * S * d) + (long long)s0 * d, d, nc, tid);
+    for (int i = i0; i < i1; ++i) {
+        if (!(ch == 0 && i == 0)) {
+            load_mat<R>(G, ldd, gtab + (long long)i * ne, d, d, tid);
+            samp_load_cols<R>(Ec, ldc, ec + ((long long)i * S + s0) * d, d, nc, tid);
+            gemm<false, false>(d, nc, d, G, ldd, Ea, ldc, Eb, ldc, (R)1, (R)1, tid, Ec, ldc);
+            R* sw = Ea;
+            Ea = Eb;
+            Eb = sw;
+        }
+        for (int e = tid; e < d * nc; e += NT) {
+            const int q = e / d, k = e - q * d, sq = s0 + q;
+            const_cast<R*>(at<R>(a.xs, sq / a.d.B, (long long)n - 1 - i, sq % a.d.B))[k] = Ea[k * ldc + q];
+        }
+        __syncthreads();
+    }
+}
+
+// =================================================================================================================================================
+// The sweep's LOG-DENSITIES for chains that share the model (kalman/generic.py:88-89, :98-106; wk_sweep_logpdf factorises Q_{t-1} and R_t once per (chain, time
+// step)): per time step ONE table row -- Q_{t-1}^-1 (P0^-1 at t = 0), R_t^-1 over the kept components, their half log-determinants -- and the chains as the
+// columns of d x CB matrices: residuals by products with F and H, quadratic forms r^T (S^-1 r) by one more product and a column-wise dot.
+// Row layout: [Qinv d*d | Rinv po*po | hlQ, hlR, dimR, okQ, okR, anynan, 0, 0].
+// =================================================================================================================================================
+__host__ __device__ inline size_t lp_row(int d, int po) { return (size_t)d * d + (size_t)po * po + 8; }
+static size_t lds_lp_tab(size_t s, int d, int po) {
+    const int n = std::max(d, po);
+    return al16(n * (size_t)ldp_(2 * n) * s) + al16(n * s) + al16((2 * (2 * n + 1) + NWV) * s) + al16(n) + 256;
+}
+template <typename R> __global__ void __launch_bounds__(NT) wk_lp_tab(SweepLogpdfArgs a, R* __restrict__ tab) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, po = a.po, t = blockIdx.x, nmax = d > po ? d : po;
+    Bump L{smem};
+    const int ldz = ldp_(2 * nmax);
+    R* Z = L.take<R>(nmax * ldz);
+    R* piv = L.take<R>(nmax);
+    R* rowbuf = L.take<R>(2 * (2 * nmax + 1) + NWV);
+    unsigned char* skip = L.take<unsigned char>(nmax);
+    __shared__ int s_any;
+    R* row = tab + (size_t)t * lp_row(d, po);
+    // transition covariance (P0 at t = 0): Z = [Q | I] -> [. | Q^-1]
+    const R* cov = t == 0 ? at<R>(a.P0, 0, 0, 0) : at<R>(a.Qs, 0, (long long)t - 1, 0);
+    for (int i = tid / 64; i < d; i += NWV)
+        for (int j = tid & 63; j < 2 * d; j += 64) Z[i * ldz + j] = j < d ? cov[(long long)(i >= j ? i : j) * d + (i >= j ? j : i)] : (j - d == i ? (R)1 : (R)0);
+    __syncthreads();
+    R hl = 0;
+    const bool okq = spd_solve<R>(Z, ldz, d, 2 * d, nullptr, rowbuf, piv, &hl, tid, true);
+    for (int i = tid / 64; i < d; i += NWV)
+        for (int j = tid & 63; j < d; j += 64) row[(size_t)i * d + j] = Z[i * ldz + d + j];
+    __syncthreads();
+    // observation covariance over the kept components
+    const R* yg = at<R>(a.ys, 0, t, 0);
+    if (tid == 0) s_any = 0;
+    __syncthreads();
+    int dm = 0;
+    for (int k = tid; k < po; k += NT) {
+        const bool nanv = !finite_(yg[k]);
+        skip[k] = (a.nan_policy == 1) && nanv;
+        if (nanv) atomicOr(&s_any, 1);
+    }
+    __syncthreads();
+    const R* Rg = at<R>(a.Rs, 0, t, 0);
+    for (int i = tid / 64; i < po; i += NWV)
+        for (int j = tid & 63; j < 2 * po; j += 64) {
+            R v;
+            if (j < po) v = (skip[i] || skip[j]) ? (R)0 : Rg[(long long)(i >= j ? i : j) * po + (i >= j ? j : i)];
+            else v = (j - po == i && !skip[i]) ? (R)1 : (R)0;
+            Z[i * ldz + j] = v;
+        }
+    __syncthreads();
+    R hlr = 0;
+    const bool okr = spd_solve<R>(Z, ldz, po, 2 * po, a.nan_policy == 1 ? skip : nullptr, rowbuf, piv, &hlr, tid, true);
+    R* rinv = row + (size_t)d * d;
+    for (int i = tid / 64; i < po; i += NWV)
+        for (int j = tid & 63; j < po; j += 64) rinv[(size_t)i * po + j] = (skip[i] || skip[j]) ? (R)0 : Z[i * ldz + po + j];
+    for (int k = tid; k < po; k += NT) dm += skip[k] ? 0 : 1;
+    const R dimr = block_sum<R>((R)dm, rowbuf, tid);
+    if (tid == 0) {
+        R* sc = rinv + (size_t)po * po;
+        sc[0] = hl, sc[1] = hlr, sc[2] = dimr, sc[3] = okq ? (R)1 : (R)0, sc[4] = okr ? (R)1 : (R)0, sc[5] = s_any ? (R)1 : (R)0, sc[6] = 0, sc[7] = 0;
+    }
+}
+static size_t lds_lp_cols(size_t s, int d, int po, int CB) {
+    const int n = std::max(d, po);
+    return 2 * al16(n * (size_t)ldp_(n) * s) + 9 * al16(n * (size_t)ldp_(CB) * s) + 2 * al16(n * s) + al16(10 * CB * s) + 256;
+}
+// column-wise sum_k A[k][q] B[k][q] for q < nc into out[q] (every lane-group of 16 lanes owns a column: 64 columns per pass)
+template <typename R> __device__ __forceinline__ void col_dots(const R* A, const R* B, int ldc, int n, int nc, R* out, int tid) {
+    const int q = tid >> 4, l = tid & 15;
+    if (q < nc) {
+        R sacc = 0;
+        for (int k = l; k < n; k += 16) sacc += A[k * ldc + q] * B[k * ldc + q];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) sacc += __shfl_xor(sacc, off, 64);
+        if (l == 0) out[q] = sacc;
+    }
+    __syncthreads();
+}
+// any non-finite entry in column q of A (n x nc)?  flags[q]
+template <typename R> __device__ __forceinline__ void col_bad(const R* A, int ldc, int n, int nc, R* flags, int tid) {
+    const int q = tid >> 4, l = tid & 15;
+    if (q < nc) {
+        int b = 0;
+        for (int k = l; k < n; k += 16) b |= finite_(A[k * ldc + q]) ? 0 : 1;
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) b |= __shfl_xor(b, off, 64);
+        if (l == 0) flags[q] = b ? (R)1 : (R)0;
+    }
+    __syncthreads();
+}
+template <typename R> __global__ void __launch_bounds__(NT) wk_lp_cols(SweepLogpdfArgs a, const R* __restrict__ tab, R* __restrict__ part, int ncb, int CB) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, d = a.dx, po = a.po, T = a.d.T, C = a.d.C, nmax = d > po ? d : po;
+    const int t = blockIdx.x / ncb, cb = blockIdx.x - t * ncb, c0 = cb * CB, nc = min(CB, C - c0);
+    const int ldn = ldp_(nmax), ldc = ldp_(CB);
+    Bump L{smem};
+    R* W = L.take<R>(nmax * ldn);    // Qinv / Rinv
+    R* FH = L.take<R>(nmax * ldn);   // F / H
+    R* X = L.take<R>(nmax * ldc);
+    R* XP = L.take<R>(nmax * ldc);
+    R* U = L.take<R>(nmax * ldc);
+    R* XQ = L.take<R>(nmax * ldc);
+    R* XPQ = L.take<R>(nmax * ldc);
+    R* R1 = L.take<R>(nmax * ldc);
+    R* R2 = L.take<R>(nmax * ldc);
+    R* S1 = L.take<R>(nmax * ldc);
+    R* S2 = L.take<R>(nmax * ldc);
+    R* v1 = L.take<R>(nmax);
+    R* v2 = L.take<R>(nmax);
+    R* sc = L.take<R>(10 * CB);  // per column: q_ob1, q_ob2, bad_ob1, bad_ob2, q_pr1, q_pr2, bad_pr1, bad_pr2, (2 spare)
+    const R* row = tab + (size_t)t * lp_row(d, po);
+    const R* tsc = row + (size_t)d * d + (size_t)po * po;
+    const R hlq = tsc[0], hlr = tsc[1], dimr = tsc[2];
+    const bool okq = tsc[3] != (R)0, okr = tsc[4] != (R)0;
+    // the chains' values of this time step (and the one before) as columns
+    for (int e = tid; e < d * nc; e += NT) {
+        const int q = e / d, k = e - q * d, c = c0 + q;
+        X[k * ldc + q] = at<R>(a.x, c, t, 0)[k];
+        XP[k * ldc + q] = at<R>(a.xp, c, t, 0)[k];
+        U[k * ldc + q] = at<R>(a.u, c, t, 0)[k];
+        if (t > 0) {
+            XQ[k * ldc + q] = at<R>(a.x, c, (long long)t - 1, 0)[k];
+            XPQ[k * ldc + q] = at<R>(a.xp, c, (long long)t - 1, 0)[k];
+        }
+    }
+    // ---- observation block: r = y - (H x + c) over the kept components; q = r^T Rinv r
+    load_mat<R>(FH, ldn, at<R>(a.Hs, 0, t, 0), po, d, tid);
+    for (int k = tid; k < po; k += NT) v1[k] = at<R>(a.ys, 0, t, 0)[k], v2[k] = at<R>(a.cs, 0, t, 0)[k];
+    __syncthreads();
+    gemm<false, false>(po, nc, d, FH, ldn, XP, ldc, R1, ldc, (R)1, (R)0, tid);
+    gemm<false, false>(po, nc, d, FH, ldn, X, ldc, R2, ldc, (R)1, (R)0, tid);
+    for (int e = tid; e < po * nc; e += NT) {
+        const int k = e / nc, q = e - k * nc;
+        const bool sk = (a.nan_policy == 1) && !finite_(v1[k]);
+        R1[k * ldc + q] = sk ? (R)0 : v1[k] - (v2[k] + R1[k * ldc + q]);
+        R2[k * ldc + q] = sk ? (R)0 : v1[k] - (v2[k] + R2[k * ldc + q]);
+    }
+    __syncthreads();
+    col_bad<R>(R1, ldc, po, nc, sc + 2 * CB, tid);
+    col_bad<R>(R2, ldc, po, nc, sc + 3 * CB, tid);
+    load_mat<R>(W, ldn, row + (size_t)d * d, po, po, tid);
+    gemm<false, false>(po, nc, po, W, ldn, R1, ldc, S1, ldc, (R)1, (R)0, tid);
+    gemm<false, false>(po, nc, po, W, ldn, R2, ldc, S2, ldc, (R)1, (R)0, tid);
+    col_dots<R>(R1, S1, ldc, po, nc, sc, tid);
+    col_dots<R>(R2, S2, ldc, po, nc, sc + CB, tid);
+    // ---- transition block: r = x_t - (F x_{t-1} + b)  (t = 0: x_0 - m0); q = r^T Qinv r
+    if (t == 0) {
+        for (int k = tid; k < d; k += NT) v1[k] = at<R>(a.m0, 0, 0, 0)[k];
+        __syncthreads();
+        for (int e = tid; e < d * nc; e += NT) {
+            const int k = e / nc, q = e - k * nc;
+            R1[k * ldc + q] = XP[k * ldc + q] - v1[k];
+            R2[k * ldc + q] = X[k * ldc + q] - v1[k];
+        }
+        __syncthreads();
+    } else {
+        load_mat<R>(FH, ldn, at<R>(a.Fs, 0, (long long)t - 1, 0), d, d, tid);
+        for (int k = tid; k < d; k += NT) v1[k] = at<R>(a.bs, 0, (long long)t - 1, 0)[k];
+        __syncthreads();
+        gemm<false, false>(d, nc, d, FH, ldn, XPQ, ldc, R1, ldc, (R)1, (R)0, tid);
+        gemm<false, false>(d, nc, d, FH, ldn, XQ, ldc, R2, ldc, (R)1, (R)0, tid);
+        for (int e = tid; e < d * nc; e += NT) {
+            const int k = e / nc, q = e - k * nc;
+            R1[k * ldc + q] = XP[k * ldc + q] - (R1[k * ldc + q] + v1[k]);
+            R2[k * ldc + q] = X[k * ldc + q] - (R2[k * ldc + q] + v1[k]);
+        }
+        __syncthreads();
+    }
+    col_bad<R>(R1, ldc, d, nc, sc + 6 * CB, tid);
+    col_bad<R>(R2, ldc, d, nc, sc + 7 * CB, tid);
+    load_mat<R>(W, ldn, row, d, d, tid);
+    gemm<false, false>(d, nc, d, W, ldn, R1, ldc, S1, ldc, (R)1, (R)0, tid);
+    gemm<false, false>(d, nc, d, W, ldn, R2, ldc, S2, ldc, (R)1, (R)0, tid);
+    col_dots<R>(R1, S1, ldc, d, nc, sc + 4 * CB, tid);
+    col_dots<R>(R2, S2, ldc, d, nc, sc + 5 * CB, tid);
+    // ---- per chain: the auxiliary block N(u; x, delta / 2 I), the MH correction (generic.py:103-105), the five sums' terms (wk_sweep_logpdf's own rules)
+    if (tid < nc) {
+        const int q = tid, c = c0 + q;
+        const R hd = (R)(0.5 * arg_delta(a)), sd = sqrt_(hd);
+        R q1 = 0, q2 = 0, corr = 0;
+        bool b1 = false, b2 = false;
+        for (int k = 0; k < d; ++k) {
+            const R e1 = U[k * ldc + q] - XP[k * ldc + q], e2 = U[k * ldc + q] - X[k * ldc + q];
+            b1 = b1 || !finite_(e1);
+            b2 = b2 || !finite_(e2);
+            const R z1 = e1 / sd, z2 = e2 / sd;
+            q1 += z1 * z1;
+            q2 += z2 * z2;
+            const R f1 = XP[k * ldc + q] - U[k * ldc + q], f2 = X[k * ldc + q] - U[k * ldc + q];
+            corr += (f1 * f1 - f2 * f2) / (R)arg_delta(a);
+        }
+        const R cst = -(R)d * log_(sd) - (R)(0.5 * LOG_2PI) * (R)d;
+        const R ax_p = b1 ? (R)0 : (R)-0.5 * q1 + cst, ax_x = b2 ? (R)0 : (R)-0.5 * q2 + cst;
+        const bool badobs_p = sc[2 * CB + q] != (R)0, badobs_x = sc[3 * CB + q] != (R)0;
+        const R cr = -hlr - (R)(0.5 * LOG_2PI) * dimr, cq = -hlq - (R)(0.5 * LOG_2PI) * (R)d;
+        R ob_p = okr ? (R)-0.5 * sc[q] + cr : r_nan<R>(), ob_x = okr ? (R)-0.5 * sc[CB + q] + cr : r_nan<R>();
+        if (badobs_p || isnan_(ob_p)) ob_p = 0;
+        if (badobs_x || isnan_(ob_x)) ob_x = 0;
+        R pr_p = okq ? (R)-0.5 * sc[4 * CB + q] + cq : r_nan<R>(), pr_x = okq ? (R)-0.5 * sc[5 * CB + q] + cq : r_nan<R>();
+        if (sc[6 * CB + q] != (R)0 || isnan_(pr_p)) pr_p = 0;
+        if (sc[7 * CB + q] != (R)0 || isnan_(pr_x)) pr_x = 0;
+        const bool ref = a.nan_policy == 0;
+        const R cc_p = (ref && (b1 || badobs_p)) ? (R)0 : ax_p + ob_p;
+        const R cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
+        const long long CT = (long long)C * T, o = (long long)c * T + t;
+        part[o] = cc_p + pr_p;
+        part[CT + o] = cc_x + pr_x;
+        part[2 * CT + o] = ob_p + pr_p;
+        part[3 * CT + o] = ob_x + pr_x;
+        part[4 * CT + o] = corr;
+    }
+}
+

@@ -207,3 +207,51 @@ def test_C5_benchmarked_horizon_16_sequences():
         npt.assert_allclose(Ps[s][idx], Ps1[k][idx], **tol)
         assert abs(float(ell[s]) - float(ell1[k])) / abs(float(ell1[k])) < 1e-4
     print(f"shared wide filter, T=8192 x 16: max|dm| vs fp64 fixture {e_m:.2e}; groups {groups}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d,po,T,C", [(8, 8, 80, 5), (12, 7, 257, 3), (33, 20, 60, 18), (30, 8, 40, 4), (16, 5, 700, 70)])
+def test_wide_lg_sweep_one_covariance_copy_and_shared_sampler_tables(d, po, T, C, dtype):
+    """The LG_CONCAT sweep at dx > 4 with several dense chains on one model: ONE copy of the filtered covariances (the shared filter's
+    broadcast to the chains' slots is gone, its pattern read-back replaced by a carrier), and the pathwise sampler builds its gains / Cholesky factors once per time
+    step, the chains riding as columns of d x CB products (wide.hip::run_sample_shared).  Against the per-chain path (AUXSSM_OPT_SHARE_MODEL = 0) on the same explicit
+    noise, and against the oracle's sweep chain by chain (fp64); missing observations included."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, LGConcatModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    from tests.test_gpu_wide import lg_concat_wide
+    from oracle import kalman_np as K
+    model, xt, y, _ = lg_concat_wide(T, d, po, seed=d)
+    y = y.copy()
+    y[3] = np.nan
+    y[5, : po // 2] = np.nan
+    model = LGConcatModel(model.m0, model.P0, model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs, y)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    rng = np.random.default_rng(d + T)
+    x0 = (xt[None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    res = {}
+    for share in (1, 0):
+        chains = DeviceChains(h, x0)
+        assert not chains.chain_minor
+        h.set_option(_lib.OPT_SHARE_MODEL, share)
+        try:
+            kernel(None, KalmanSampler(x=chains, updated=None), 0.4, noise=noise)
+        finally:
+            h.set_option(_lib.OPT_SHARE_MODEL, 1)
+        res[share] = (chains.to_host(), chains.logs.to_host(), chains.accepted.to_host())
+    tol = dict(rtol=1e-8, atol=1e-9) if dtype == np.float64 else dict(rtol=2e-3, atol=2e-3)
+    npt.assert_allclose(res[1][0], res[0][0], **tol)
+    if dtype == np.float64:
+        npt.assert_allclose(res[1][1][:, 1:], res[0][1][:, 1:], rtol=1e-9)
+        npt.assert_array_equal(res[1][2], res[0][2])
+        # (log alpha is not 0 here: under the reference's NaN policy a step with a missing COMPONENT drops its auxiliary term too -- base.py:159-166, DESIGN 2)
+        for c in range(0, C, 4):
+            lgo = (model.m0, model.P0, model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs)
+            ref = K.kalman_sweep(x0[c].astype(np.float64), 0.4, model.dynamics_factory, model.observations_factory,
+                                 lambda z: K.log_likelihood(y, z, lgo) + K.prior_logpdf(z, lgo), True,
+                                 eps_aux=noise["eps_aux"][c], eps_samp=noise["eps_samp"][c], u_accept=noise["u_accept"][c])
+            assert bool(res[1][2][c]) == ref["accepted"]
+            npt.assert_allclose(res[1][0][c], ref["x"], rtol=1e-8, atol=1e-9)
+            npt.assert_allclose(res[1][1][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
