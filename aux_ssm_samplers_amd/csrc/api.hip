@@ -1090,6 +1090,12 @@ __global__ void __launch_bounds__(256) k_sv_terms(int C, int T, int D, R delta, 
         __syncthreads();
     }
 }
+// out1[c] = (R) in[c], out2[c] = (R) in[C + c]
+template <typename R> __global__ void k_acc_to_real(int C, const Acc* __restrict__ in, R* __restrict__ out1, R* __restrict__ out2) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < C) out1[g] = (R)in[g];
+    else if (g < 2 * C) out2[g - C] = (R)in[g];
+}
 // lt = joint - la + pot (target = prior + potential; joint = auxiliary log-likelihood + prior), then _get_alpha + bernoulli
 template <typename R>
 __global__ void k_sv_accept(int C, const R* j1, const R* j2, const R* ell1, const R* ell2, const R* terms, const R* u_acc, int32_t* accepted, R* logs) {
@@ -1146,6 +1152,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     add((size_t)(D * D + D * D + D) * sR + (size_t)16 * C * sR + (size_t)5 * C * sizeof(Acc) + 4096);
     const bool wide_carrier = wide && !second && C >= 2 && h->share_model;  // (below: the observation pattern said to the chain-shared wide filter)
     if (wide_carrier) add((size_t)T * D * sR);
+    if (wide_carrier) add(wide_gain_tab_bytes(dtype, T, D, D));  // the gain rows: built by the proposal filter, reused by the reverse filter
     add(wide ? wide_filter_ws(h, dtype, kd, parallel, D, D) : ke->filter_ws(h, kd, parallel));
     add(wide ? wide_sample_ws(h, dtype, kd, parallel, D) : se->sample_ws(h, kd, parallel));
     add(wide ? wide_logpdf_ws(dtype, kd) : std::max(ke->logpdf_ws(h, kd), se->sv_logpdf_ws(h, kd)));
@@ -1165,6 +1172,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     R* sc = (R*)ws_take(h, (size_t)16 * C * sR);
     Acc* sums = (Acc*)ws_take(h, (size_t)5 * C * sizeof(Acc));
     R* wide_mask = wide_carrier ? (R*)ws_take(h, (size_t)T * D * sR) : nullptr;
+    void* wide_gtab = wide_carrier ? ws_take(h, wide_gain_tab_bytes(dtype, T, D, D) - 256) : nullptr;
     if (!u || !ys1 || !ys2 || !xp || !ms || !Ps || !eye || !Rc || !zero || !sc || !sums || (wide_carrier && !wide_mask)) return AUXSSM_ERR_NOMEM;
     R* ell1 = sc; R* ell2 = sc + C; R* j1 = sc + 2 * C; R* j2 = sc + 3 * C; R* terms = sc + 4 * C;
     const size_t mark = h->ws_off;
@@ -1229,8 +1237,10 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
     dc.dy = D;
     dc.B = 1;
     const auxssm_arr y1d{ys1, (int64_t)T * D, (int64_t)D, 0}, y2d{ys2, (int64_t)T * D, (int64_t)D, 0};
-    // the filtered covariances do not depend on the chain when neither the dynamics nor R do (first order)
-    const Arr PsA = ps_shared ? Arr{Ps, 0, (long long)D * D, 0, 1} : arr(Ps, (long long)D * D);
+    // the filtered covariances do not depend on the chain when neither the dynamics nor R do (first order); wide states: one copy too -- the chain-shared wide filter
+    // then skips its broadcast to the chains' slots and the sampler builds its gain / factor tables once per time step (wide.hip::run_sample_shared)
+    const bool wide_ps_once = wide_carrier && model->Fs.sc == 0 && model->Qs.sc == 0 && model->bs.sc == 0 && model->P0.sc == 0 && model->m0.sc == 0;
+    const Arr PsA = (ps_shared || wide_ps_once) ? Arr{Ps, 0, (long long)D * D, 0, 1} : arr(Ps, (long long)D * D);
 
     // proposal: observations linearised at x, filter, pathwise sample (generic.py:80-86)
     if (!fly) {
@@ -1250,6 +1260,7 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         fa.aux_x = xA; fa.aux_eps = arr(eps_aux, D); fa.aux_u = uA; fa.aux_yobs = cv(*yobs);
     }
     if (overlap || wide_carrier) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
+    if (wide_ps_once && wide_gtab) fa.pc = wide_gtab;  // (the chain-shared wide filter leaves its gain rows here)
     rc = ke->filter(h, fa, parallel, ell1);
     if (rc) return rc;
     h->ws_off = mark;
@@ -1287,6 +1298,10 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
         fa.tab_ready = 1;
     }
     if (wide_carrier) fa.mask_ys = Arr{mask_carrier, 0, (long long)D, 0, 1};
+    if (wide_ps_once && wide_gtab && parallel && T >= 5) {  // same model, same step size, same pattern: the proposal filter's covariances and gain rows (if it took the shared form:
+        fa.pc = wide_gtab;                                   // it does whenever this one would -- same sizes, same strides)
+        fa.tab_ready = 1;
+    }
     rc = ke->filter(h, fa, parallel, ell2);
     if (rc) return rc;
     h->ws_off = mark;
@@ -1308,15 +1323,39 @@ static int sweep_sv(auxssm_ctx* h, int dtype, int order, const auxssm_dims* dims
                            (R*)logs);
     } else {
         // wide-state path: joint log-densities of both auxiliary models (posterior_logpdf + ell, base.py:72-96), then the SV terms
-        LogpdfArgs la;
-        fill_logpdf_args(la, &dc, &g1, cv(y1d), dense_arr(xp, kd, D), nan_policy);
-        rc = ke->logpdf(h, la, j1);
-        if (rc) return rc;
-        h->ws_off = mark;
-        fill_logpdf_args(la, &dc, &g2, cv(y2d), dense_arr(x, kd, D), nan_policy);
-        rc = ke->logpdf(h, la, j2);
-        if (rc) return rc;
-        h->ws_off = mark;
+        bool both = false;
+        const SweepLogpdfEntry* wsl = wide_sweep_logpdf_entry(dtype);
+        if (wide_ps_once && nan_policy == AUXSSM_NAN_REFERENCE && wsl && wsl->wide_shared) {
+            // first order on one model: both joints from ONE launch pair -- Q_t^-1, R^-1 and their determinants once per time step, the chains as columns, ys1 scored
+            // against x' and ys2 against x (wide_shared.h::wk_lp_cols); sums [2] / [3] = observation + transition terms of x' / x
+            SweepLogpdfArgs sl_;
+            sl_.d = kd;
+            sl_.dx = D; sl_.po = D;
+            sl_.m0 = cv(model->m0); sl_.P0 = cv(model->P0); sl_.Fs = cv(model->Fs); sl_.Qs = cv(model->Qs); sl_.bs = cv(model->bs);
+            sl_.Hs = cv(g1.Hs); sl_.Rs = cv(g1.Rs); sl_.cs = cv(g1.cs);
+            sl_.ys = cv(y1d); sl_.ys_x = cv(y2d);
+            sl_.x = dense_arr(x, kd, D); sl_.xp = dense_arr(xp, kd, D); sl_.u = dense_arr(u, kd, D);
+            sl_.delta = delta; sl_.dptr = dptr; sl_.nan_policy = nan_policy; sl_.u_fly = 0; sl_.shd = sqrt(0.5 * delta);
+            rc = wsl->wide_shared(h, sl_, sums);
+            if (rc == AUXSSM_OK) {
+                hipLaunchKernelGGL((k_acc_to_real<R>), dim3((2 * C + 127) / 128), dim3(128), 0, h->stream, C, (const Acc*)(sums + 2 * C), j1, j2);
+                both = true;
+            } else if (rc != 1) {
+                return rc;
+            }
+            h->ws_off = mark;
+        }
+        if (!both) {
+            LogpdfArgs la;
+            fill_logpdf_args(la, &dc, &g1, cv(y1d), dense_arr(xp, kd, D), nan_policy);
+            rc = ke->logpdf(h, la, j1);
+            if (rc) return rc;
+            h->ws_off = mark;
+            fill_logpdf_args(la, &dc, &g2, cv(y2d), dense_arr(x, kd, D), nan_policy);
+            rc = ke->logpdf(h, la, j2);
+            if (rc) return rc;
+            h->ws_off = mark;
+        }
         hipLaunchKernelGGL((k_sv_terms<R>), dim3(C), dim3(256), 0, h->stream, C, T, D, (R)delta, dptr, (const R*)x, (const R*)xp, (const R*)u,
                            cv(*yobs), (const R*)ys1, (const R*)ys2, (const R*)Rs1, (const R*)Rs2, terms);
         hipLaunchKernelGGL((k_sv_accept<R>), dim3((C + 127) / 128), dim3(128), 0, h->stream, C, (const R*)j1, (const R*)j2, (const R*)ell1,

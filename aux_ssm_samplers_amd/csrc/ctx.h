@@ -217,6 +217,7 @@ struct SweepLogpdfEntry {
     sweep_logpdf_fn lorenz = nullptr;  // the Lorenz-63 sweep's fused pass (dx = 3 units only); same workspace as `run`
     fused_fn fused = nullptr;          // the chain-shared LG_CONCAT sweep in three streaming passes (fused_shared.h); null in the wide-state entry
     fused_ws_fn fused_ws = nullptr;
+    sweep_logpdf_fn wide_shared = nullptr;  // wide-state entry only: the chains-as-columns form alone (returns 1 when it does not apply, nothing enqueued)
 };
 typedef int (*sv_logpdf_fn)(auxssm_ctx*, const SvLogpdfArgs&, void* out /*[5][C]*/);
 typedef size_t (*sv_logpdf_ws_fn)(const auxssm_ctx*, const KDims&);
@@ -245,5 +246,6 @@ bool wide_fits(int dtype, int dx, int dy, std::string* why);
 size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d, int p);
 size_t wide_sample_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d);
 size_t wide_logpdf_ws(int dtype, const KDims& kd);
+size_t wide_gain_tab_bytes(int dtype, int T, int d, int p);  // the chain-shared wide filter's per-step gain rows (FilterArgs::pc)
 
 }  // namespace ax

@@ -115,7 +115,8 @@ struct FilterArgs {
     ScanLayout lay;
     int pblk;       // > 0: Rs is block diagonal, first block pblk x pblk (hint; enables the information form of kalman_math.h)
     const void* tab = nullptr;  // chain-shared parameters: one GainRow per transition (affine_shared.h; else null)
-    void* pc = nullptr;         // (unused)
+    void* pc = nullptr;         // wide-state chain-shared filter only (wide.hip::run_filter_shared): the caller's buffer for the per-step gain rows (wide_gain_tab_bytes);
+                                // with tab_ready != 0 it HOLDS this model's rows (and Ps the matrix filter's covariances): the reverse filter of a sweep reuses both
     // Concatenated auxiliary observations built on the fly (sweep of the LG_CONCAT model, shared mode): for t >= 1 the observation
     // is y_t = [u_t ; yobs_t] with u = x + aux_shd * eps (kalman/generic.py:59-63); u is written to aux_u, ys holds row t = 0 only.
     int aux_on = 0;
@@ -1040,6 +1041,9 @@ struct SweepLogpdfArgs {
     double shd = 0;
     const double* dptr = nullptr;  // device-resident {delta, sqrt(delta / 2)}; null: the host values
     const int* memo = nullptr;     // model-stage memo (FilterArgs::memo)
+    // wide-state shared form only (wide_shared.h::wk_lp_cols): ys may be per chain (chain stride != 0; reference NaN policy only), and ys_x -- when set -- is the
+    // observation array scored against x while ys is scored against xp (the SV sweep's two pseudo-observation sets: one launch gives both joint densities)
+    Arr ys_x{nullptr, 0, 0, 0, 1};
 };
 // the auxiliary variable of chain c at time t >= 1
 template <typename R, int D> AX_HD void sweep_u(const SweepLogpdfArgs& a, int c, long long t, const R* x, R* u) {

@@ -2374,6 +2374,7 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     const int S = a.d.S(), n = a.d.n(), d = a.dx, p = a.dy;
     static const bool off = getenv("AUXSSM_WIDE_SHARED") && atoi(getenv("AUXSSM_WIDE_SHARED")) == 0;
     if (off || !h->share_model || a.aux_on || a.tab || p < 1) return 1;
+    if (a.pc && a.tab_ready && !a.mask_ys.ptr) return 1;  // (a reused table was built on the carrier's pattern)
     for (const Arr* q : {&a.P0, &a.Fs, &a.Qs, &a.bs, &a.Hs, &a.Rs, &a.cs})
         if (q->sc != 0 || q->sb != 0) return 1;
     const SPlan sp = shared_plan(h, S, n, d, p, sizeof(R));
@@ -2387,7 +2388,8 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     const size_t Spad = (size_t)sp.ncb * sp.CB;
     const size_t mark = h->ws_off;
     int* flag = (int*)ws_take(h, 256);
-    R* tab = (R*)ws_take(h, (size_t)n * g.size * sizeof(R));
+    R* tab = a.pc ? (R*)a.pc : (R*)ws_take(h, (size_t)n * g.size * sizeof(R));  // (the caller's buffer: a sweep's second filter reuses the rows)
+    const bool reuse = a.pc && a.tab_ready;
     R* aggA = (R*)ws_take(h, (size_t)sp.nchunk * d * ldp_(d) * sizeof(R));
     R* aggG = (R*)ws_take(h, (size_t)sp.nchunk * d * Spad * sizeof(R));
     R* pre = (R*)ws_take(h, (size_t)sp.nchunk * d * Spad * sizeof(R));
@@ -2426,9 +2428,11 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
     }
     FilterArgs fa = a;
     fa.ell0 = ell0;
-    {   // the matrix filter: sequence 0's slots through the per-sequence path, on sequence 0's observations or on the caller's pattern carrier (its Ps rows are
+    if (!reuse) {   // the matrix filter: sequence 0's slots through the per-sequence path, on sequence 0's observations or on the caller's pattern carrier (its Ps rows are
         // final; its means and its ell are recomputed below with the others')
         FilterArgs a1 = a;
+        a1.pc = nullptr;
+        a1.tab_ready = 0;
         a1.d = KDims{1, a.d.T, 1};
         if (a.mask_ys.ptr) a1.ys = a.mask_ys;
         a1.mask_ys = Arr{nullptr, 0, 0, 0, 1};
@@ -2461,7 +2465,7 @@ template <typename R> static int run_filter_shared(auxssm_ctx* h, const FilterAr
         ProfScope ps(h, AUXSSM_K_SELECT);  // (profiled runs keep everything on the one stream: the group times then add up)
         hipLaunchKernelGGL((wk_ps_bcast<R>), dim3(n), dim3(NT), 0, h->stream, fa);
     }
-    {
+    if (!reuse) {
         ProfScope ps(h, AUXSSM_K_FILTER_TAB);
         WK_LAUNCH((wk_gain_tab<R>), n, l_tab, fa, tab);
     }
@@ -2588,30 +2592,43 @@ template <typename R> int run_logpdf(auxssm_ctx* h, const LogpdfArgs& a, void* o
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }
+// chains on one model: the covariances' inverses and log-determinants once per time step, the chains as columns (wide_shared.h::wk_lp_tab / wk_lp_cols).
+// The observations may be per chain under the reference NaN policy (SweepLogpdfArgs::ys_x).  Returns 1 when the form does not apply (nothing enqueued).
+template <typename R> int run_sweep_logpdf_shared(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
+    const int C = a.d.C, T = a.d.T;
+    static const bool sh_off = getenv("AUXSSM_WIDE_SHARED") && atoi(getenv("AUXSSM_WIDE_SHARED")) == 0;
+    if (sh_off || !h->share_model || C < 2 || a.u_fly || NT != 1024 || !spd_fits(std::max(a.dx, a.po), 2 * std::max(a.dx, a.po))) return 1;
+    for (const Arr* q : {&a.m0, &a.P0, &a.Fs, &a.Qs, &a.bs, &a.Hs, &a.Rs, &a.cs})
+        if (q->sc != 0 || q->sb != 0) return 1;
+    if ((a.ys.sc != 0 || a.ys_x.ptr) && a.nan_policy != 0) return 1;
+    int CB = std::min(64, C);
+    while (CB > 8 && lds_lp_cols(sizeof(R), a.dx, a.po, CB) > LDS_BUDGET) CB /= 2;
+    const size_t l_tab = lds_lp_tab(sizeof(R), a.dx, a.po), l_cols = lds_lp_cols(sizeof(R), a.dx, a.po, CB);
+    if (l_tab > LDS_BUDGET || l_cols > LDS_BUDGET) return 1;
+    const size_t mark = h->ws_off;
+    R* part = (R*)ws_take(h, (size_t)5 * C * T * sizeof(R));
+    R* tab = (R*)ws_take(h, (size_t)T * lp_row(a.dx, a.po) * sizeof(R));
+    if (!part || !tab) {
+        h->ws_off = mark;
+        return 1;
+    }
+    ProfScope ps(h, AUXSSM_K_LOGPDF);
+    const int ncb = (C + CB - 1) / CB;
+    WK_LAUNCH((wk_lp_tab<R>), (long long)T, l_tab, a, tab);
+    WK_LAUNCH((wk_lp_cols<R>), (long long)T * ncb, l_cols, a, (const R*)tab, part, ncb, CB);
+    hipLaunchKernelGGL((wk_reduce<R, Acc>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (Acc*)out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
 template <typename R> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs& a, void* out) {
     const int C = a.d.C, T = a.d.T;
+    {
+        const int rc = run_sweep_logpdf_shared<R>(h, a, out);
+        if (rc != 1) return rc;
+    }
     R* part = (R*)ws_take(h, (size_t)5 * C * T * sizeof(R));
     if (!part) return AUXSSM_ERR_NOMEM;
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    // chains on one model: the covariances' inverses and log-determinants once per time step, the chains as columns (wide_shared.h::wk_lp_tab / wk_lp_cols)
-    static const bool sh_off = getenv("AUXSSM_WIDE_SHARED") && atoi(getenv("AUXSSM_WIDE_SHARED")) == 0;
-    bool shared = !sh_off && h->share_model && C >= 2 && !a.u_fly && NT == 1024 && spd_fits(std::max(a.dx, a.po), 2 * std::max(a.dx, a.po));
-    for (const Arr* q : {&a.m0, &a.P0, &a.Fs, &a.Qs, &a.bs, &a.Hs, &a.Rs, &a.cs, &a.ys})
-        if (q->sc != 0 || q->sb != 0) shared = false;
-    if (shared) {
-        int CB = std::min(64, C);
-        while (CB > 8 && lds_lp_cols(sizeof(R), a.dx, a.po, CB) > LDS_BUDGET) CB /= 2;
-        const size_t l_tab = lds_lp_tab(sizeof(R), a.dx, a.po), l_cols = lds_lp_cols(sizeof(R), a.dx, a.po, CB);
-        R* tab = (R*)ws_take(h, (size_t)T * lp_row(a.dx, a.po) * sizeof(R));
-        if (tab && l_tab <= LDS_BUDGET && l_cols <= LDS_BUDGET) {
-            const int ncb = (C + CB - 1) / CB;
-            WK_LAUNCH((wk_lp_tab<R>), (long long)T, l_tab, a, tab);
-            WK_LAUNCH((wk_lp_cols<R>), (long long)T * ncb, l_cols, a, (const R*)tab, part, ncb, CB);
-            hipLaunchKernelGGL((wk_reduce<R, Acc>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (Acc*)out);
-            AX_HIP(hipGetLastError());
-            return AUXSSM_OK;
-        }
-    }
     WK_LAUNCH((wk_sweep_logpdf<R>), (long long)C * T, lds_sweep_logpdf(sizeof(R), a.dx, a.po), a, part);
     hipLaunchKernelGGL((wk_reduce<R, Acc>), dim3(5 * C), dim3(NT), 0, h->stream, (const R*)part, (const R*)nullptr, 1, (long long)T, (Acc*)out);
     AX_HIP(hipGetLastError());
@@ -2624,6 +2641,7 @@ template <typename R> int run_sweep_logpdf(auxssm_ctx* h, const SweepLogpdfArgs&
 size_t wide_filter_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d, int p) {
     return dtype == AUXSSM_F32 ? wide::filter_ws_d<float>(h, kd, parallel, d, p) : wide::filter_ws_d<double>(h, kd, parallel, d, p);
 }
+size_t wide_gain_tab_bytes(int dtype, int T, int d, int p) { return (size_t)std::max(T - 1, 1) * (size_t)wide::GRow(d, p).size * (dtype == AUXSSM_F32 ? 4 : 8) + 256; }
 size_t wide_sample_ws(const auxssm_ctx* h, int dtype, const KDims& kd, int parallel, int d) {
     const size_t s = dtype == AUXSSM_F32 ? 4 : 8;
     const wide::WPlan p = wide::plan(h, kd.S(), kd.T, parallel);
@@ -2651,8 +2669,16 @@ const SampleEntry* wide_sample_entry(int dtype) {
     return dtype == AUXSSM_F32 ? &f32 : &f64;
 }
 const SweepLogpdfEntry* wide_sweep_logpdf_entry(int dtype) {
-    static const SweepLogpdfEntry f32{&wide::run_sweep_logpdf<float>, &ws_unused_l};
-    static const SweepLogpdfEntry f64{&wide::run_sweep_logpdf<double>, &ws_unused_l};
+    static const SweepLogpdfEntry f32 = [] {
+        SweepLogpdfEntry e{&wide::run_sweep_logpdf<float>, &ws_unused_l};
+        e.wide_shared = &wide::run_sweep_logpdf_shared<float>;
+        return e;
+    }();
+    static const SweepLogpdfEntry f64 = [] {
+        SweepLogpdfEntry e{&wide::run_sweep_logpdf<double>, &ws_unused_l};
+        e.wide_shared = &wide::run_sweep_logpdf_shared<double>;
+        return e;
+    }();
     return dtype == AUXSSM_F32 ? &f32 : &f64;
 }
 bool wide_fits(int dtype, int dx, int dy, std::string* why) {

@@ -778,7 +778,7 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_lp_tab(SweepLogpd
     __syncthreads();
     int dm = 0;
     for (int k = tid; k < po; k += NT) {
-        const bool nanv = !finite_(yg[k]);
+        const bool nanv = a.ys.sc == 0 && !finite_(yg[k]);   // (per-chain observations come with the reference policy: nothing is deleted)
         skip[k] = (a.nan_policy == 1) && nanv;
         if (nanv) atomicOr(&s_any, 1);
     }
@@ -869,15 +869,25 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_lp_cols(SweepLogp
     }
     // ---- observation block: r = y - (H x + c) over the kept components; q = r^T Rinv r
     load_mat<R>(FH, ldn, at<R>(a.Hs, 0, t, 0), po, d, tid);
-    for (int k = tid; k < po; k += NT) v1[k] = at<R>(a.ys, 0, t, 0)[k], v2[k] = at<R>(a.cs, 0, t, 0)[k];
+    const bool ypc = a.ys.sc != 0;                       // per-chain observations (reference NaN policy: a non-finite residual drops the term, nothing is deleted)
+    const Arr& ysx = a.ys_x.ptr ? a.ys_x : a.ys;          // the observations scored against x
+    for (int k = tid; k < po; k += NT) v1[k] = ypc ? (R)0 : at<R>(a.ys, 0, t, 0)[k], v2[k] = at<R>(a.cs, 0, t, 0)[k];
+    if (ypc) {
+        for (int e = tid; e < po * nc; e += NT) {
+            const int q = e / po, k = e - q * po, c = c0 + q;
+            S1[k * ldc + q] = at<R>(a.ys, c, t, 0)[k];
+            S2[k * ldc + q] = at<R>(ysx, c, t, 0)[k];
+        }
+    }
     __syncthreads();
     gemm<false, false>(po, nc, d, FH, ldn, XP, ldc, R1, ldc, (R)1, (R)0, tid);
     gemm<false, false>(po, nc, d, FH, ldn, X, ldc, R2, ldc, (R)1, (R)0, tid);
     for (int e = tid; e < po * nc; e += NT) {
         const int k = e / nc, q = e - k * nc;
-        const bool sk = (a.nan_policy == 1) && !finite_(v1[k]);
-        R1[k * ldc + q] = sk ? (R)0 : v1[k] - (v2[k] + R1[k * ldc + q]);
-        R2[k * ldc + q] = sk ? (R)0 : v1[k] - (v2[k] + R2[k * ldc + q]);
+        const bool sk = !ypc && (a.nan_policy == 1) && !finite_(v1[k]);
+        const R y1 = ypc ? S1[k * ldc + q] : v1[k], y2 = ypc ? S2[k * ldc + q] : v1[k];
+        R1[k * ldc + q] = sk ? (R)0 : y1 - (v2[k] + R1[k * ldc + q]);
+        R2[k * ldc + q] = sk ? (R)0 : y2 - (v2[k] + R2[k * ldc + q]);
     }
     __syncthreads();
     col_bad<R>(R1, ldc, po, nc, sc + 2 * CB, tid);
