@@ -64,7 +64,7 @@ def parse_args(argv=None):
                     help="headline on the general per-chain path (AUXSSM_OPT_SHARE_MODEL = 0)")
     ap.add_argument("--no-general-leg", action="store_true", help="skip the extra run of the general per-chain path")
     ap.add_argument("--no-secondary", action="store_true", help="skip the C3 / C4 / C5 legs")
-    ap.add_argument("--secondary", default="c3,c4,c5", help="comma list of secondary legs to run")
+    ap.add_argument("--secondary", default="c3,c4,c5,sv", help="comma list of secondary legs to run")
     ap.add_argument("--small-secondary", action="store_true", help="shrink the secondary legs (contract tests): not the BASELINE sizes")
     ap.add_argument("--workload", default="kalman", choices=["kalman", "csmc"],
                     help="kalman = BASELINE configs[1] (C2, the headline); csmc = configs[2] (C3) as the only workload")
@@ -546,6 +546,36 @@ def leg_c4(ctx, total_chains=64, T=16384, N=512, steps=20, warmup=3):
     return out
 
 
+def leg_sv_kalman(ctx, T=65536, chains=1024, steps=5, warmup=2):
+    """The general per-chain path on a real nonlinear model: the SV model of C3 with the auxiliary KALMAN sampler, second-order
+    observations (R_t depends on the chain's state: examples/stochastic_volatility/auxiliary_kalman.py:37-46), fp64, chain-minor.  Every chain folds its own steps in
+    information form straight from (x, u, y) -- no observation arrays, no elements (csrc/kalman_bodies.h::FilterOpFlySV).  Fixed step size 0.0567 (what the reference's
+    adaptation rule settles at for this model, tools/bench_configs.py c3k)."""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd.kalman import get_kernel, SVModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    from aux_ssm_samplers_amd.workloads import sv_setup
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, rho=0.0)
+    out = dict(workload=f"SV d=1 T={T} (the C3 model), auxiliary Kalman sampler with second-order observations, fp64, general per-chain path", chains_per_gpu=chains)
+    for order in (2, 1):
+        model = SVModel(y, m0, P0, F, Q, b, order=order)
+        init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+        ch = DeviceChains(ctx.handle, np.repeat(xtrue[None], chains, axis=0))
+        st = KalmanSampler(x=ch, updated=None)
+        keys = R.split(R.PRNGKey(11 + ctx.rank), steps + warmup + 4)
+        delta = 0.0567 if order == 2 else 0.0212
+        el, groups = ctx.timed(lambda k: kernel(keys[k], st, delta), steps, warmup)
+        # the sweep's own lower bound (SURVEY 8(d), fused form): x, eps_aux, eps_samp read, x' written per chain-step
+        alg = chains * T * 4 * 8
+        ent = dict(value=round(chains * ctx.world * steps / el, 1), unit="sweeps/s", ms_per_step=round(el / steps * 1e3, 4), steps=steps, delta=delta,
+                   accept_rate=round(float(ch.accepted.to_host().mean()), 3), kernels={g: round(ms / steps, 4) for g, (n, ms) in groups.items()},
+                   roofline=dict(bound="hbm", achieved=round(alg / (el / steps) / 1e9, 1), peak=HBM_PEAK_GBPS, unit="GB/s", frac=round(alg / (el / steps) / 1e9 / HBM_PEAK_GBPS, 4),
+                                 traffic=None, kernel="whole sweep against the fused lower bound (x, eps_aux, eps_samp read, x' written)", algorithmic_bytes_per_launch=alg))
+        out["order_2" if order == 2 else "order_1_chain_shared"] = ent
+        del ch, st
+    return out
+
+
 def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
     """BASELINE configs[4] = C5: dense d = p = 64, T = 8192, fp32 -- the wide-state filter (MFMA d x d combine), one sequence (latency) and
     16 sequences per launch (throughput), resident in HBM.  Roofline = MFMA: SURVEY 8(d)'s K3 flops 2 n 19.3 d^3 per scan / scan time."""
@@ -581,8 +611,15 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
             ent["roofline"] = dict(bound="mfma", achieved=round(tf, 2), peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s", frac=round(tf / MFMA_F32_PEAK_TFLOPS, 4),
                                    traffic=None, kernel="wide filter scan (wk_fold_reduce + tree of wk_scan_reduce / wk_scan_aggs / wk_scan_down_pre + wk_fold_down)", avg_launch_ms=round(scan, 3),
                                    algorithmic_flops_per_launch=flops)
-            try:  # matrix-core busy fraction of the two level-0 kernels from the committed PMC pass (profiles/r02_traffic.json)
-                mb = json.load(open(os.path.join(ROOT, "profiles", "r02_traffic.json"))).get(f"wide_C5_f32_d{d}_T{T}")
+            try:  # matrix-core busy fractions of the wide kernels from the committed PMC pass of this command (round 4: profiles/r04_e_pmc_mfma_busy_c5.csv -> r04_traffic.json)
+                mb = None
+                for tj in ("r04_traffic.json", "r02_traffic.json"):
+                    try:
+                        mb = json.load(open(os.path.join(ROOT, "profiles", tj))).get(f"wide_C5_f32_d{d}_T{T}")
+                    except Exception:
+                        mb = None
+                    if mb:
+                        break
                 if mb:
                     ent["roofline"]["mfma_busy_pmc"] = mb["mfma_busy"]
                     ent["roofline"]["mfma_busy_source"] = mb["source"]
@@ -623,6 +660,37 @@ def leg_c5(ctx, T=8192, d=64, seqs=(1, 16), steps=3):
             del dlb, ydb, msb, Psb, ellb
     except Exception as e:
         out["batched_scalar"] = {"error": f"{type(e).__name__}: {e}"}
+    # a whole auxiliary Kalman SWEEP of 16 chains on one wide model ("the C5 16-sequence full pass >= 1 000 passes/s"): d = 60 states + 4 real
+    # observations = 64 concatenated observations (the blocked eliminations hold n <= 64), chain-shared matrix filter, ONE covariance copy, the sampler's gain / factor
+    # tables and the log-densities' inverse tables once per time step with the chains as columns (wide.hip::run_sample_shared, wide_shared.h::wk_lp_cols)
+    try:
+        from aux_ssm_samplers_amd import random as R
+        from aux_ssm_samplers_amd.kalman import get_kernel, LGConcatModel
+        from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+        ds, pos, Cs = (60, 4, 16) if d == 64 else (max(d - 4, 6), 4, 4)
+        rng = np.random.default_rng(0)
+        Fw = 0.9 * np.eye(ds) + 0.04 * (np.eye(ds, k=1) + np.eye(ds, k=-1))
+        Hw = rng.standard_normal((pos, ds)) / np.sqrt(ds)
+        xw = np.zeros((T, ds))
+        xw[0] = rng.standard_normal(ds)
+        for t in range(1, T):
+            xw[t] = Fw @ xw[t - 1] + np.sqrt(0.2) * rng.standard_normal(ds)
+        yw = xw @ Hw.T + np.sqrt(0.5) * rng.standard_normal((T, pos))
+        bt = np.broadcast_to
+        wmodel = LGConcatModel(np.zeros(ds), np.eye(ds), bt(Fw, (T - 1, ds, ds)), bt(0.2 * np.eye(ds), (T - 1, ds, ds)), bt(np.zeros(ds), (T - 1, ds)),
+                               bt(Hw, (T, pos, ds)), bt(0.5 * np.eye(pos), (T, pos, pos)), bt(np.zeros(pos), (T, pos)), yw)
+        winit, wkernel = get_kernel(wmodel.dynamics_factory, wmodel.observations_factory, wmodel.log_likelihood_fn, True)
+        wch = DeviceChains(handle, (xw[None] + 0.3 * rng.standard_normal((Cs, T, ds))).astype(f32))
+        wst = KalmanSampler(x=wch, updated=None)
+        wkeys = R.split(R.PRNGKey(21 + ctx.rank), 16)
+        nst = max(steps, 3)
+        el, groups = ctx.timed(lambda k: wkernel(wkeys[k], wst, 0.3), nst, 1)
+        out["sweep_16_chains"] = dict(workload=f"auxiliary Kalman sweep, dense LG-SSM d={ds} + {pos} observations, T={T}, {Cs} chains on one model, fp32", chains=Cs,
+                                      chain_sweeps_per_s=round(Cs * ctx.world * nst / el, 1), ms_per_sweep_call=round(el / nst * 1e3, 3),
+                                      accept_rate=float(wch.accepted.to_host().mean()), kernels={g: round(ms / nst, 3) for g, (n, ms) in groups.items()})
+        del wch, wst
+    except Exception as e:
+        out["sweep_16_chains"] = {"error": f"{type(e).__name__}: {e}"}
     # one whole pass of the path on one chain (filter -> pathwise sampler -> joint log-density, what a sweep of this size strings together):
     # device time of each launch group (HIP events), host <-> device copies of the NumPy front end excluded
     try:
@@ -746,6 +814,8 @@ def main(argv=None):
                 secondary["C4_lorenz"] = leg_c4(ctx, 8, 1040, 64, 3, 1) if small else leg_c4(ctx)
             elif name == "c5":
                 secondary["C5_wide"] = leg_c5(ctx, 96, 64, (1, 2), 2) if small else leg_c5(ctx)
+            elif name == "sv":
+                secondary["SV_kalman_general_path"] = leg_sv_kalman(ctx, 2048, 64, 2, 1) if small else leg_sv_kalman(ctx)
         except Exception as e:  # a secondary leg never takes the headline down; the failure is reported in the line
             secondary[name] = {"error": f"{type(e).__name__}: {e}"}
             ctx.barrier()

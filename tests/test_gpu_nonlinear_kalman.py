@@ -343,3 +343,54 @@ def test_tiny_horizons_chain_minor_equals_dense(T, kind):
                          eps_samp=noise["eps_samp"][0], u_accept=noise["u_accept"][0])
     npt.assert_allclose(outs[True][0][0], ref["x"], rtol=1e-8, atol=1e-9)
     npt.assert_allclose(outs[True][2][0, 0], ref["log_alpha"], rtol=1e-6, atol=1e-7)
+
+
+@pytest.mark.parametrize("order", [1, 2])
+@pytest.mark.parametrize("d,T,C", [(1, 300, 40), (3, 129, 64)])
+@pytest.mark.parametrize("share", [1, 0])
+def test_sv_chain_minor_array_free_filter_missing_data_and_fp32(order, d, T, C, share):
+    """The array-free SV filter (round 4: csrc/kalman_bodies.h::FilterOpFlySV -- both scan passes fold the steps in information form from (x, u, y), the
+    log-determinants multiplied up per chunk; the log-density pass re-forms the pseudo-observations) where its special cases live: MISSING data (a NaN y_t makes the
+    second-order pseudo-observation of that component NaN = unobserved; whole missing steps are pure prediction steps), the device step size (sweep_dd) and fp32
+    (auxiliary block around the predicted mean).  fp64: every chain against the oracle's sweep and the dense-layout sweep; fp32: against the fp64 device sweep on
+    the same noise."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, SVModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, d, seed=11)
+    y = y.copy()
+    y[5] = np.nan
+    y[9, 0] = np.nan
+    y[T - 1, d - 1] = np.nan
+    model = SVModel(y, m0, P0, F, Q, b, order=order)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    rng = np.random.Generator(np.random.PCG64(70 + d))
+    x0 = xtrue[None] + 0.2 * rng.standard_normal((C, T, d))
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    h.set_option(_lib.OPT_SHARE_MODEL, share)
+    try:
+        outs = {}
+        for key, cmin, dt in (("cm64", True, np.float64), ("dense64", False, np.float64), ("cm32", True, np.float32)):
+            chains = DeviceChains(h, x0.astype(dt), chain_minor=cmin)
+            kernel(None, KalmanSampler(x=chains, updated=None), 0.3, noise=noise)
+            outs[key] = (chains.to_host(), chains.accepted.to_host(), chains.logs.to_host())
+    finally:
+        h.set_option(_lib.OPT_SHARE_MODEL, 1)
+    npt.assert_allclose(outs["cm64"][0], outs["dense64"][0], rtol=1e-9, atol=1e-10)
+    npt.assert_array_equal(outs["cm64"][1], outs["dense64"][1])
+    npt.assert_allclose(outs["cm64"][2][:, 1:], outs["dense64"][2][:, 1:], rtol=1e-9)
+    for c in range(0, C, 9):
+        ref = K.kalman_sweep(x0[c], 0.3, model.dynamics_factory, model.observations_factory, oracle_target(model), True,
+                             eps_aux=noise["eps_aux"][c], eps_samp=noise["eps_samp"][c], u_accept=noise["u_accept"][c])
+        npt.assert_allclose(outs["cm64"][2][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
+        assert bool(outs["cm64"][1][c]) == ref["accepted"]
+        npt.assert_allclose(outs["cm64"][0][c], ref["x"], rtol=1e-9, atol=1e-10)
+    # fp32: log alpha within 2e-2 of the fp64 sweep's (sums of T d terms of size ~1), the same decisions except at the margin, accepted trajectories to fp32 accuracy
+    la64, la32 = outs["cm64"][2][:, 0], outs["cm32"][2][:, 0].astype(np.float64)
+    assert np.abs(la64 - la32).max() < 5e-2, np.abs(la64 - la32).max()
+    same = outs["cm64"][1] == outs["cm32"][1]
+    assert same.mean() > 0.9
+    both = same & (outs["cm64"][1] == 1)
+    if both.any():
+        npt.assert_allclose(outs["cm32"][0][both], outs["cm64"][0][both], rtol=2e-3, atol=2e-3)
