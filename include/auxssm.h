@@ -183,6 +183,10 @@ int auxssm_kalman_joint_logpdf(auxssm_handle h, int dtype, const auxssm_dims* di
  *         chain-shared model parameters are wave-uniform loads; there is no transposition anywhere in the sweep.  This is the
  *         layout to use with >= 32 chains (bench.py); results are identical up to the combination tree of the scan.  LG_CONCAT and the
  *         SV and LORENZ63_EXT factories (dx <= 4) take it; the wide-state sizes (dx > 4) are dense only.
+ * Chain-minor SV sweeps whose observation model differs per chain (second order; first order without chain-shared dynamics) materialise neither the
+ * pseudo-observations nor scan elements: the passes fold every step from (x, u, y) (csrc/kalman_bodies.h::FilterOpFlySV).  Wide-state sweeps (dx > 4)
+ * of C >= 2 chains on one model (chain stride 0 on every model array) keep ONE copy of the filtered covariances and build the sampler's gains / factors
+ * and the log-densities' inverses once per time step, the chains as columns (csrc/wide_shared.h); no sweep synchronises with the host.
  */
 typedef enum {
     AUXSSM_KMODEL_LG_CONCAT = 1,
