@@ -1033,6 +1033,7 @@ struct SweepLogpdfArgs {
     int nan_policy;
     int dx = 0, po = 0;  // runtime sizes (wide.hip only)
     const void* tab = nullptr;  // chain-shared parameters: per time step the Cholesky rows of Q_{t-1} and Robs_t (else null)
+    int tab_semi = 0;           // the table is built for the SEMI-shared pass (Q, H, R, c, y chain-shared; F, b per chain or rebuilt): its WF / wb entries are not formed
     const void* lor_par = nullptr;  // Lorenz-63 sweep: rows [theta1, theta2, theta3, dt], chain stride lor_psc (Fs / bs are not read then)
     long long lor_psc = 0;
     // u_fly != 0: rows t >= 1 of u are not materialised (the filter built them on the fly, FilterArgs::aux_*): u_t = x_t + shd eps_t
@@ -1475,8 +1476,15 @@ template <typename R, int D, int PO> AX_HD void body_sweep_logpdf_tab(const Swee
     rd<R, PO>(a.ys, 0, t, 0, y);
     rd<R, PO * D>(a.Hs, 0, t, 0, H);
     rd<R, PO>(a.cs, 0, t, 0, cv);
-    rd<R, D * D>(a.Fs, 0, i, 0, F);
-    rd<R, D>(a.bs, 0, i, 0, bd);
+    if (a.tab_semi) {
+#pragma unroll
+        for (int k = 0; k < D * D; ++k) F[k] = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) bd[k] = 0;
+    } else {
+        rd<R, D * D>(a.Fs, 0, i, 0, F);
+        rd<R, D>(a.bs, 0, i, 0, bd);
+    }
     bool skip[PO];
 #pragma unroll
     for (int k = 0; k < PO; ++k) skip[k] = (a.nan_policy == 1) && !finite_(y[k]);
@@ -1597,6 +1605,134 @@ AX_HD void body_sweep_logpdf_shared(const SweepLogpdfArgs& a, int i, const R* x,
     out5[1] = cc_x + pr_x;
     out5[2] = ob_p + pr_p;
     out5[3] = ob_x + pr_x;
+    out5[4] = corr;
+}
+
+// ---- SEMI-shared pass ("drop the per-chain Cholesky of Q and R ... when those are chain-shared even though F and b are not: the SV and
+// Lorenz case"): the covariances, the observation model and the data are the chains' common ones -- their whitening rows come from the LogShared table -- while the
+// transition's mean is the chain's own (per-chain F_t, b_t, or the Lorenz-63 step rebuilt from the chain's state).  Same rules as body_sweep_logpdf_shared.
+template <typename R, int D, int PO, typename RowP>
+AX_HD void semi_obs_terms(const SweepLogpdfArgs& a, RowP row, const R* x, const R* xp, const R* u, R& cc_p, R& cc_x, R& ob_p, R& ob_x, R& corr) {
+    using T = LogShared<R, D, PO>;
+    bool badobs_x = false, badobs_p = false;
+    {
+        R q1 = 0, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < PO; ++k) {
+            R z1 = row[T::oYw + k], z2 = z1;
+#pragma unroll
+            for (int j = 0; j < D; ++j) z1 -= row[T::oWH + k * D + j] * xp[j], z2 -= row[T::oWH + k * D + j] * x[j];
+            badobs_p = badobs_p || !finite_(z1);
+            badobs_x = badobs_x || !finite_(z2);
+            q1 += z1 * z1;
+            q2 += z2 * z2;
+        }
+        ob_p = (R)-0.5 * q1 + row[T::oCR];
+        ob_x = (R)-0.5 * q2 + row[T::oCR];
+        if (badobs_p || isnan_(ob_p)) ob_p = 0;
+        if (badobs_x || isnan_(ob_x)) ob_x = 0;
+    }
+    R ax_x, ax_p;
+    bool b1 = false, b2 = false;
+    {
+        const R hd = (R)(0.5 * arg_delta(a));
+        const R inv_delta = (R)1 / (R)arg_delta(a);
+        R q1 = 0, q2 = 0;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const R d1 = u[k] - xp[k], d2 = u[k] - x[k];
+            b1 = b1 || !finite_(d1);
+            b2 = b2 || !finite_(d2);
+            q1 += d1 * d1;
+            q2 += d2 * d2;
+        }
+        corr = (q1 - q2) * inv_delta;
+        const R cst = (R)-0.5 * (R)D * log_(hd) - (R)(0.5 * LOG_2PI) * (R)D;
+        ax_p = b1 ? (R)0 : -q1 * inv_delta + cst;
+        ax_x = b2 ? (R)0 : -q2 * inv_delta + cst;
+    }
+    const bool ref = a.nan_policy == 0;
+    cc_p = (ref && (b1 || badobs_p)) ? (R)0 : ax_p + ob_p;
+    cc_x = (ref && (b2 || badobs_x)) ? (R)0 : ax_x + ob_x;
+}
+// log N(r; 0, Q) of two residuals from the table's W_Q = chol(Q)^-1 and c_Q
+template <typename R, int D, int PO, typename RowP> AX_HD void semi_prior(RowP row, const R* r1, const R* r2, R& o1, R& o2) {
+    using T = LogShared<R, D, PO>;
+    R q1 = 0, q2 = 0;
+    bool bad1 = false, bad2 = false;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        R z1 = 0, z2 = 0;
+#pragma unroll
+        for (int l = 0; l <= k; ++l) z1 += row[T::oWQ + lidx(k, l)] * r1[l], z2 += row[T::oWQ + lidx(k, l)] * r2[l];
+        bad1 = bad1 || !finite_(z1);
+        bad2 = bad2 || !finite_(z2);
+        q1 += z1 * z1;
+        q2 += z2 * z2;
+    }
+    o1 = (R)-0.5 * q1 + row[T::oCQ];
+    o2 = (R)-0.5 * q2 + row[T::oCQ];
+    if (bad1 || isnan_(o1)) o1 = 0;
+    if (bad2 || isnan_(o2)) o2 = 0;
+}
+// linear transitions with the chain's own F, b
+template <typename R, int D, int PO>
+AX_HD void body_sweep_logpdf_semi(const SweepLogpdfArgs& a, int i, const R* x, const R* xp, const R* u_in, const R* xq, const R* xpq, const R* F, const R* bd, R* out5) {
+    using T = LogShared<R, D, PO>;
+    const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
+    R u[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)arg_shd(a) * u_in[k] : u_in[k];
+    R cc_p, cc_x, ob_p, ob_x, corr, pr_p, pr_x;
+    semi_obs_terms<R, D, PO>(a, row, x, xp, u, cc_p, cc_x, ob_p, ob_x, corr);
+    R r1[D], r2[D], m1[D], m2[D];
+    mv<R, D, D>(F, xpq, m1);
+    mv<R, D, D>(F, xq, m2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) r1[k] = xp[k] - (m1[k] + bd[k]), r2[k] = x[k] - (m2[k] + bd[k]);
+    semi_prior<R, D, PO>(row, r1, r2, pr_p, pr_x);
+    out5[0] = cc_p + pr_p;
+    out5[1] = cc_x + pr_x;
+    out5[2] = ob_p + pr_p;
+    out5[3] = ob_x + pr_x;
+    out5[4] = corr;
+}
+// the Lorenz-63 sweep (body_lorenz_logpdf with the table's rows)
+template <typename R, int PO> AX_HD void body_lorenz_logpdf_semi(const SweepLogpdfArgs& a, int c, int i, const R* x, const R* xp, const R* u_in, const R* xq, const R* xpq, R* out5) {
+    constexpr int D = 3;
+    using T = LogShared<R, D, PO>;
+    const UniformRow<R> row = uniform_row<R>((const R*)a.tab + (long long)i * T::NPAD);
+    const R* par = (const R*)a.lor_par + (long long)c * a.lor_psc;
+    const R th[3] = {par[0], par[1], par[2]};
+    const R dt = par[3];
+    R u[D];
+#pragma unroll
+    for (int k = 0; k < D; ++k) u[k] = a.u_fly ? x[k] + (R)arg_shd(a) * u_in[k] : u_in[k];
+    R cc_p, cc_x, ob_p, ob_x, corr;
+    semi_obs_terms<R, D, PO>(a, row, x, xp, u, cc_p, cc_x, ob_p, ob_x, corr);
+    R mx[D], mp[D], F1[D * D], F2[D * D], dl[D], f1[D], f2[D];
+    lorenz_mean<R>(th, dt, xq, mx);
+    lorenz_mean<R>(th, dt, xpq, mp);
+    lorenz_lin_F<R>(th, dt, xq, F1);
+    lorenz_lin_F<R>(th, dt, xpq, F2);
+#pragma unroll
+    for (int k = 0; k < D; ++k) dl[k] = xpq[k] - xq[k];
+    mv<R, D, D>(F1, dl, f1);
+    mv<R, D, D>(F2, dl, f2);
+    R r1[D], r2[D], rp[D], rx[D], l1, l2, tp, tx;
+#pragma unroll
+    for (int k = 0; k < D; ++k) {
+        r1[k] = xp[k] - (mx[k] + f1[k]);
+        r2[k] = x[k] - (mp[k] - f2[k]);
+        rp[k] = xp[k] - mp[k];
+        rx[k] = x[k] - mx[k];
+    }
+    semi_prior<R, D, PO>(row, r1, r2, l1, l2);
+    semi_prior<R, D, PO>(row, rp, rx, tp, tx);
+    out5[0] = cc_p + l1;
+    out5[1] = cc_x + l2;
+    out5[2] = ob_p + tp;
+    out5[3] = ob_x + tx;
     out5[4] = corr;
 }
 

@@ -393,6 +393,56 @@ __global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_shared(SweepLogpdfArg
     for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
 }
 
+// SEMI-shared per-chain passes (kalman_bodies.h): the table's whitening rows, the chain's own transition mean.  LORENZ: the Lorenz-63 step instead of (F, b).
+template <typename R, int D, int PO, bool LORENZ>
+__global__ void __launch_bounds__(TB_CM) k_sweep_logpdf_cm_semi(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile, int TI) {
+    resolve_step(a);
+    const CmTile c = decode_cm(a.d.C, a.d.T - 1, TI);
+    if (!c.live) return;
+    Acc v[5] = {0, 0, 0, 0, 0};
+    if (c.tt == 0) {
+        R h[5];
+        body_sweep_logpdf_head<R, D, PO>(a, c.s, h);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] = (Acc)h[k];
+    }
+    const Arr& ua = a.u_fly ? a.eps_aux : a.u;
+    R xq[D], xpq[D], xn[D], xpn[D], un[D];
+    rd<R, D>(a.x, c.s, c.i0, 0, xq);
+    rd<R, D>(a.xp, c.s, c.i0, 0, xpq);
+    rd<R, D>(a.x, c.s, (long long)c.i0 + 1, 0, xn);
+    rd<R, D>(a.xp, c.s, (long long)c.i0 + 1, 0, xpn);
+    rd<R, D>(ua, c.s, (long long)c.i0 + 1, 0, un);
+#pragma unroll 1
+    for (int i = c.i0; i < c.i1; ++i) {
+        R xc[D], xpc[D], uc[D];
+#pragma unroll
+        for (int k = 0; k < D; ++k) xc[k] = xn[k], xpc[k] = xpn[k], uc[k] = un[k];
+        const int iu = opaque_uniform(i);
+        if (i + 1 < c.i1) {
+            const long long tn = (long long)iu + 2;
+            rd<R, D>(a.x, c.s, tn, 0, xn);
+            rd<R, D>(a.xp, c.s, tn, 0, xpn);
+            rd<R, D>(ua, c.s, tn, 0, un);
+        }
+        R w[5];
+        if constexpr (LORENZ) {
+            body_lorenz_logpdf_semi<R, PO>(a, c.s, iu, xc, xpc, uc, xq, xpq, w);
+        } else {
+            R F[D * D], bd[D];
+            rd<R, D * D>(a.Fs, c.s, iu, 0, F);
+            rd<R, D>(a.bs, c.s, iu, 0, bd);
+            body_sweep_logpdf_semi<R, D, PO>(a, iu, xc, xpc, uc, xq, xpq, F, bd, w);
+        }
+#pragma unroll
+        for (int k = 0; k < D; ++k) xq[k] = xc[k], xpq[k] = xpc[k];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) v[k] += (Acc)w[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 5; ++k) part[((long long)k * a.d.C + c.s) * ntile + c.tt] = v[k];
+}
+
 // the Lorenz sweep's five per-chain sums (kalman_bodies.h::body_lorenz_logpdf); part layout [5][C][ntile]
 template <typename R, int PO> __global__ void __launch_bounds__(TB_ELEM) k_lorenz_logpdf(SweepLogpdfArgs a, Acc* __restrict__ part, int ntile) {
     resolve_step(a);
@@ -1420,6 +1470,9 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
                         a.cs.sc == 0 && a.ys.sc == 0;
     // time steps per lane: the streamed shared pass (52 scalars per step from its table) likes longer runs than the per-chain pass -- measured at C2,
     // two runs each: 0.41-0.44 / 0.39 / 0.38-0.41 / 0.38-0.40 ms at 16 / 32 / 48 / 64 steps; the per-chain pass 1.28 / 1.31 / 1.37 / 1.34 ms
+    // the SEMI-shared form: covariances, observation model and data common to the chains (chain stride 0), whatever the transition's F, b (AUXSSM_LOGPDF_SEMI=0: off)
+    static const bool semi_on = [] { const char* e = getenv("AUXSSM_LOGPDF_SEMI"); return e ? atoi(e) != 0 : true; }();
+    const bool semi = semi_on && cm && !shared && n > 0 && a.d.C > 1 && a.Qs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 && a.cs.sc == 0 && a.ys.sc == 0;
     const int TI = shared ? ti_shared() : ti_cm_for(h, a.d.C, n);
     const int C = a.d.C, nt = cm ? ((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
@@ -1437,6 +1490,13 @@ template <typename R, int D, int PO> int run_sweep_logpdf(auxssm_ctx* h, const S
             if (rc) return rc;
         }
         hipLaunchKernelGGL((k_sweep_logpdf_cm_shared<R, D, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, as, part, nt, TI);
+    } else if (cm && semi) {  // the chains' common covariances / observation model: their whitening rows once per time step, the transition mean per chain
+        SweepLogpdfArgs as = a;
+        as.tab_semi = 1;
+        as.tab = ws_take(h, (size_t)n * LogShared<R, D, PO>::NPAD * sizeof(R));
+        if (!as.tab) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_sweep_logpdf_tab<R, D, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, as);
+        hipLaunchKernelGGL((k_sweep_logpdf_cm_semi<R, D, PO, false>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, as, part, nt, TI);
     } else if (cm) hipLaunchKernelGGL((k_sweep_logpdf_cm<R, D, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, a, part, nt, TI);
     else hipLaunchKernelGGL((k_sweep_logpdf<R, D, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
@@ -1470,7 +1530,16 @@ template <typename R, int PO> int run_lorenz_logpdf(auxssm_ctx* h, const SweepLo
     const int nt = cm ? ((n + TI - 1) / TI > 0 ? (n + TI - 1) / TI : 1) : (ntiles(n) > 0 ? ntiles(n) : 1);
     Acc* part = (Acc*)ws_take(h, (size_t)5 * C * nt * sizeof(Acc));
     ProfScope ps(h, AUXSSM_K_LOGPDF);
-    if (cm) hipLaunchKernelGGL((k_lorenz_logpdf_cm<R, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, a, part, nt, TI);
+    static const bool semi_on = [] { const char* e = getenv("AUXSSM_LOGPDF_SEMI"); return e ? atoi(e) != 0 : true; }();
+    const bool semi = semi_on && cm && n > 0 && C > 1 && a.Qs.sc == 0 && a.Hs.sc == 0 && a.Rs.sc == 0 && a.cs.sc == 0 && a.ys.sc == 0;
+    if (semi) {
+        SweepLogpdfArgs as = a;
+        as.tab_semi = 1;
+        as.tab = ws_take(h, (size_t)n * LogShared<R, 3, PO>::NPAD * sizeof(R));
+        if (!as.tab) return AUXSSM_ERR_NOMEM;
+        hipLaunchKernelGGL((k_sweep_logpdf_tab<R, 3, PO>), dim3((n + TB_ELEM - 1) / TB_ELEM), dim3(TB_ELEM), 0, h->stream, as);
+        hipLaunchKernelGGL((k_sweep_logpdf_cm_semi<R, 3, PO, true>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, as, part, nt, TI);
+    } else if (cm) hipLaunchKernelGGL((k_lorenz_logpdf_cm<R, PO>), dim3(grid_cm(C, n, TI)), dim3(TB_CM), 0, h->stream, a, part, nt, TI);
     else hipLaunchKernelGGL((k_lorenz_logpdf<R, PO>), dim3(grid_tile_seq(nt, C)), dim3(TB_ELEM), 0, h->stream, a, part, nt);
     hipLaunchKernelGGL((k_reduce_rows<Acc>), dim3(5 * C), dim3(TB_ELEM), 0, h->stream, (const Acc*)part, (const Acc*)nullptr, 1, nt, (Acc*)out);
     AX_HIP(hipGetLastError());
