@@ -838,6 +838,27 @@ __device__ __forceinline__ bool spd_solve(R* Z, int ld, int n, int nct, const un
     if (n <= NWV * 4) return spd_solve_t<R, 4>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid, z_free);
     return spd_solve_t<R, 8>(Z, ld, n, nct, skip, rowbuf, piv, half_logdet, tid, z_free);
 }
+// 64 < n <= 128 (round 4: the concatenated observation of a d = 64 sweep is 64 + po wide): the blocked elimination holds one panel row per lane, i.e. n <= 64 --
+// beyond it the unblocked path pays one barrier per pivot with eight rows per lane (the d = 64, po = 4 gain table: 12.4 ms against 1.5 at n = 64).  One level of
+// block elimination brings both halves back under 64:  S = [A B; B^T C]:  [B | R1] <- A^-1 [B | R1] (blocked, n1 = 64: the right-hand sides B and R1 are
+// contiguous columns of the top rows);  [C | R2] -= B^T (A^-1 [B | R1]) (one product: C becomes the Schur complement);  R2 <- Sc^-1 R2;  R1 -= (A^-1 B) R2.
+// log|S| = log|A| + log|Sc|; a deleted index is a unit row in its own half, as before.  In place: the solution ends in columns n .. nct, as spd_solve's does.
+// A SEPARATE function called by the one kernel that needs it (wk_gain_tab): inlined into every caller of spd_solve it cost each of them 40 registers and 250 bytes
+// of scratch per lane (tests/test_kernel_resources.py), and the fp64 kernels at the register cap then produced wrong results.
+template <typename R>
+__device__ __forceinline__ bool spd_solve_split(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid) {
+    constexpr int N1 = 64;
+    const int n2 = n - N1, nr = nct - n;  // nr right-hand sides
+    R hl1 = 0, hl2 = 0;
+    const bool ok1 = spd_solve_t<R, 4>(Z, ld, N1, nct, skip, rowbuf, piv, &hl1, tid, true);  // the top rows as a system of 64 unknowns with nct columns: [A | B | R1]
+    R* Zb = Z + N1 * ld;                                                                      // bottom rows: [B^T | C | R2]
+    gemm<false, false>(n2, nct - N1, N1, Zb, ld, Z + N1, ld, Zb + N1, ld, (R)-1, (R)1, tid);
+    const bool ok2 = spd_solve_t<R, 4>(Zb + N1, ld, n2, nct - N1, skip ? skip + N1 : nullptr, rowbuf, piv + N1, &hl2, tid, false);  // (unblocked: its scratch would leave the image)
+    gemm<false, false>(N1, nr, n2, Z + N1, ld, Zb + N1 + n2, ld, Z + n, ld, (R)-1, (R)1, tid);
+    if (half_logdet) *half_logdet = hl1 + hl2;
+    return ok1 && ok2;
+}
+__host__ __device__ inline bool spd_split_fits(int n, int nct, int ld) { return NWV == 16 && n > 64 && n <= 128 && nct - 64 <= 256 && nct <= 256 && blk_scratch(64, nct) <= (size_t)64 * ld; }
 
 template <typename R> __device__ __forceinline__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
     // blocked variant: one panel row per lane, and its scratch (panel, D, published rows, positions) must fit the LDS image of Z

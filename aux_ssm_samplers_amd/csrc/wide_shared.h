@@ -208,7 +208,8 @@ template <typename R> __global__ void __launch_bounds__(NT) wk_gain_tab(FilterAr
     if (AUXSSM_GT_PHASE == 3) return;
 #endif
     R hl;
-    const bool ok = spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
+    const bool ok = spd_split_fits(p, nct, ldz) ? spd_solve_split<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid)
+                                                : spd_solve<R>(Z, ldz, p, nct, o.nan, rowbuf, piv, &hl, tid, true);
 #if defined(AUXSSM_GT_PHASE)
     if (AUXSSM_GT_PHASE == 4) return;
 #endif

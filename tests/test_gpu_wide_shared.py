@@ -255,3 +255,44 @@ def test_wide_lg_sweep_one_covariance_copy_and_shared_sampler_tables(d, po, T, C
             assert bool(res[1][2][c]) == ref["accepted"]
             npt.assert_allclose(res[1][0][c], ref["x"], rtol=1e-8, atol=1e-9)
             npt.assert_allclose(res[1][1][c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
+
+
+@pytest.mark.parametrize("d,po,T,C,dtype", [(62, 6, 40, 3, np.float32), (64, 4, 33, 2, np.float32), (34, 34, 30, 3, np.float64), (20, 50, 25, 2, np.float64)])
+def test_more_than_64_observations_split_elimination(d, po, T, C, dtype):
+    """d + po > 64 concatenated observations (a d = 64 sweep with any real observation): the SPD eliminations of the gain table, the t = 0 update and the information
+    rows are split once by a Schur complement so that both halves run the blocked (n <= 64) elimination (wide.hip::spd_solve).  The sweep against the oracle's, chain
+    by chain, on explicit noise -- fp64 at 1e-8, fp32 at its accuracy -- with a missing observation row and a missing component."""
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.kalman import get_kernel, LGConcatModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    from tests.test_gpu_wide import lg_concat_wide
+    from oracle import kalman_np as K
+    model, xt, y, _ = lg_concat_wide(T, d, po, seed=d + po)
+    y = y.copy()
+    y[2] = np.nan
+    y[4, 0] = np.nan
+    model = LGConcatModel(model.m0, model.P0, model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs, y)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    rng = np.random.default_rng(d * po)
+    x0 = (xt[None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
+    noise = dict(eps_aux=rng.standard_normal((C, T, d)), eps_samp=rng.standard_normal((C, T, d)), u_accept=rng.random(C))
+    h = _lib.default_handle()
+    try:
+        chains = DeviceChains(h, x0)
+        kernel(None, KalmanSampler(x=chains, updated=None), 0.4, noise=noise)
+    except ValueError as e:
+        if "LDS" in str(e):
+            pytest.skip(str(e))
+        raise
+    xs, logs, acc = chains.to_host(), chains.logs.to_host(), chains.accepted.to_host()
+    lgo = (model.m0, model.P0, model.Fs, model.Qs, model.bs, model.Hobs, model.Robs, model.cobs)
+    tol = dict(rtol=1e-8, atol=1e-9) if dtype == np.float64 else dict(rtol=5e-3, atol=5e-3)
+    for c in range(C):
+        ref = K.kalman_sweep(x0[c].astype(np.float64), 0.4, model.dynamics_factory, model.observations_factory,
+                             lambda z: K.log_likelihood(y, z, lgo) + K.prior_logpdf(z, lgo), True,
+                             eps_aux=noise["eps_aux"][c], eps_samp=noise["eps_samp"][c], u_accept=noise["u_accept"][c])
+        if dtype == np.float64:
+            assert bool(acc[c]) == ref["accepted"]
+            npt.assert_allclose(logs[c, 1:], [ref["lp_prop"], ref["lp_rev"], ref["lt_prop"], ref["lt_rev"]], rtol=1e-9)
+        if bool(acc[c]) == ref["accepted"]:
+            npt.assert_allclose(xs[c], ref["x"], **tol)
