@@ -845,6 +845,43 @@ __device__ __forceinline__ bool spd_solve(R* Z, int ld, int n, int nct, const un
 // log|S| = log|A| + log|Sc|; a deleted index is a unit row in its own half, as before.  In place: the solution ends in columns n .. nct, as spd_solve's does.
 // A SEPARATE function called by the one kernel that needs it (wk_gain_tab): inlined into every caller of spd_solve it cost each of them 40 registers and 250 bytes
 // of scratch per lane (tests/test_kernel_resources.py), and the fp64 kernels at the register cap then produced wrong results.
+// Gauss-Jordan without pivoting on a SMALL SPD block held in LDS (n2 < 32 rows of `ncols` columns, leading dimension ld): right-hand sides <- S^-1 right-hand sides in
+// place, two barriers per pivot, every lane a share of the (row, column) updates.  A deleted index (zero row / column on entry) is a unit row.  (Not spd_solve_t: a
+// second call site of it with these arguments changed the code generated for EVERY kernel of the unit that inlines it -- fp64 kernels 288 -> 384 bytes of scratch,
+// the SV protocol's Kalman sweep 30.0k -> 16.9k sweeps/s; tests/test_kernel_resources.py.)
+template <typename R>
+__device__ __forceinline__ bool spd_small_inplace(R* Zs, int ld, int n2, int ncols, const unsigned char* skip, R* piv, R* colbuf, R* half_logdet, int tid) {
+    for (int k = 0; k < n2; ++k) {
+        __syncthreads();
+        if (tid < n2) colbuf[tid] = Zs[tid * ld + k];
+        __syncthreads();
+        const bool sk = skip && skip[k];
+        const R p = sk ? (R)1 : colbuf[k];
+        if (tid == 0) piv[k] = p;
+        const R ip = (R)1 / p;
+        const int w = ncols - (k + 1);
+        for (int e = tid; e < n2 * w; e += NT) {
+            const int i = e / w, c = k + 1 + (e - i * w);
+            if (i != k) Zs[i * ld + c] -= (colbuf[i] * ip) * Zs[k * ld + c];
+        }
+    }
+    __syncthreads();
+    int bad = 0;
+    R hl = 0;
+    for (int k = tid; k < n2; k += NT)
+        if (!(skip && skip[k])) {
+            bad |= !(piv[k] > (R)0);
+            hl += (R)0.5 * log_(piv[k]);
+        }
+    const bool ok = !__syncthreads_or(bad);
+    if (half_logdet) *half_logdet = block_sum<R>(hl, colbuf + 32, tid);
+    for (int e = tid; e < n2 * (ncols - n2); e += NT) {
+        const int i = e / (ncols - n2), c = n2 + (e - i * (ncols - n2));
+        Zs[i * ld + c] *= (R)1 / piv[i];
+    }
+    __syncthreads();
+    return ok;
+}
 template <typename R>
 __device__ __forceinline__ bool spd_solve_split(R* Z, int ld, int n, int nct, const unsigned char* skip, R* rowbuf, R* piv, R* half_logdet, int tid) {
     constexpr int N1 = 64;
@@ -853,12 +890,15 @@ __device__ __forceinline__ bool spd_solve_split(R* Z, int ld, int n, int nct, co
     const bool ok1 = spd_solve_t<R, 4>(Z, ld, N1, nct, skip, rowbuf, piv, &hl1, tid, true);  // the top rows as a system of 64 unknowns with nct columns: [A | B | R1]
     R* Zb = Z + N1 * ld;                                                                      // bottom rows: [B^T | C | R2]
     gemm<false, false>(n2, nct - N1, N1, Zb, ld, Z + N1, ld, Zb + N1, ld, (R)-1, (R)1, tid);
-    const bool ok2 = spd_solve_t<R, 4>(Zb + N1, ld, n2, nct - N1, skip ? skip + N1 : nullptr, rowbuf, piv + N1, &hl2, tid, false);  // (unblocked: its scratch would leave the image)
+    const bool ok2 = spd_small_inplace<R>(Zb + N1, ld, n2, nct - N1, skip ? skip + N1 : nullptr, piv + N1, rowbuf, &hl2, tid);  // (n2 < 32: spd_split_fits)
     gemm<false, false>(N1, nr, n2, Z + N1, ld, Zb + N1 + n2, ld, Z + n, ld, (R)-1, (R)1, tid);
     if (half_logdet) *half_logdet = hl1 + hl2;
     return ok1 && ok2;
 }
-__host__ __device__ inline bool spd_split_fits(int n, int nct, int ld) { return NWV == 16 && n > 64 && n <= 128 && nct - 64 <= 256 && nct <= 256 && blk_scratch(64, nct) <= (size_t)64 * ld; }
+// (the second half stays below the blocked path's n >= 32: its scratch is carved from the image's first reals, which for a sub-image starting at column 64 would
+// run past the image's end; every call passes z_free = true, as all callers of spd_solve_t do -- one caller with `false` changed the code generated for ALL of them:
+// fp64 kernels 288 -> 384 bytes of scratch, the SV protocol's Kalman sweep 30.0k -> 16.9k sweeps/s)
+__host__ __device__ inline bool spd_split_fits(int n, int nct, int ld) { return NWV == 16 && n > 64 && n < 96 && nct <= 256 && blk_scratch(64, nct) <= (size_t)64 * ld; }
 
 template <typename R> __device__ __forceinline__ void lu_solve(R* Z, int ld, int n, int nct, R* rowbuf, R* pinv, int* iperm, unsigned int* key, int tid) {
     // blocked variant: one panel row per lane, and its scratch (panel, D, published rows, positions) must fit the LDS image of Z
