@@ -529,3 +529,60 @@ def test_fused_sweep_noise_draw_equals_the_three_fills(dtype, n, nu):
     npt.assert_array_equal(ea.to_host(), h.rng_normal(ka, 0, (n,), dtype).to_host())
     npt.assert_array_equal(es.to_host(), h.rng_normal(ks, 0, (n,), dtype).to_host())
     npt.assert_array_equal(ua.to_host(), h.rng_uniform(kc, 0, (nu,), dtype).to_host())
+
+
+@pytest.mark.parametrize("parallel", [True, False])
+@pytest.mark.parametrize("order", [1, 2])
+def test_batched_model_through_get_kernel_as_the_spatial_example(parallel, order):
+    """The reference's spatial example (examples/spatial/auxiliary_kalman.py:10-66) runs the generic sampler on a BATCHED model: the state is (T, d, 1), every array of the
+    factories carries the batch axis d (d independent scalar LGSSMs coupled only through the potential).  The same call shapes through `get_kernel` with Python
+    factories (the host-factory path: filter / sampler / log-density primitives on the batch axis, here wide enough -- 300 -- for the one-sequence-per-lane filter),
+    first- and second-order observation factories with a spatially coupled potential, against the oracle's sweep on the same noise."""
+    from aux_ssm_samplers_amd.kalman import get_kernel
+    T, d = 30, 300
+    rng = np.random.default_rng(17 + order)
+    y = rng.standard_normal((T, d))
+    lam, s2 = 0.3, 0.8
+    m0, P0 = np.zeros((d, 1)), np.ones((d, 1, 1))
+    F, Q, b = np.full((d, 1, 1), 0.9), np.full((d, 1, 1), 0.5), np.zeros((d, 1))
+    eyes, zeros = np.ones((T, d, 1, 1)), np.zeros((T, d, 1))
+
+    def log_potential(x):          # x (T, d): Gaussian observations + a nearest-neighbour coupling across the batch ("space")
+        return float(np.sum(-0.5 * (y - x) ** 2 / s2) - lam * np.sum((x[:, 1:] - x[:, :-1]) ** 2))
+
+    def grad_potential(x):
+        g = (y - x) / s2
+        dx = x[:, 1:] - x[:, :-1]
+        g[:, 1:] -= 2 * lam * dx
+        g[:, :-1] += 2 * lam * dx
+        return g
+
+    hess_diag = -(1.0 / s2 + 4 * lam) * np.ones(d)            # the example's diagonal Hessian approximation (:44)
+
+    def dynamics_factory(_x):
+        return m0, P0, np.tile(F[None], (T - 1, 1, 1, 1)), np.tile(Q[None], (T - 1, 1, 1, 1)), np.tile(b[None], (T - 1, 1, 1))
+
+    def first_order(x, u, delta):
+        g = np.nan_to_num(grad_potential(x.reshape(-1, d))).reshape(T, d, 1)
+        return u + 0.5 * delta * g, eyes, 0.5 * delta * eyes, zeros
+
+    def second_order(x, u, delta):
+        g = grad_potential(x.reshape(-1, d)).reshape(T, d, 1)
+        Om = 1.0 / (-hess_diag[None, :, None, None] + 2 * eyes / delta)
+        return Om[..., 0] * (2 * u / delta + g - hess_diag[None, :, None] * x), eyes, Om, zeros
+
+    def log_likelihood_fn(x):
+        out = np.sum(-0.5 * (x[0] - m0) ** 2 / P0[:, 0] - 0.5 * np.log(2 * np.pi * P0[:, 0]))
+        pred = F[None, :, 0] * x[:-1] + b[None]
+        out += np.sum(-0.5 * (x[1:] - pred) ** 2 / Q[None, :, 0] - 0.5 * np.log(2 * np.pi * Q[None, :, 0]))
+        return float(out) + log_potential(x.reshape(-1, d))
+
+    obs = first_order if order == 1 else second_order
+    init, kernel = get_kernel(dynamics_factory, obs, log_likelihood_fn, parallel)
+    x = rng.standard_normal((T, d, 1))
+    noise = dict(eps_aux=rng.standard_normal((T, d, 1)), eps_samp=rng.standard_normal((T, d, 1)), u_accept=rng.random())
+    out = kernel(None, init(x), 0.2, noise=noise)
+    ref = K.kalman_sweep(x, 0.2, dynamics_factory, obs, log_likelihood_fn, parallel, **noise)
+    assert out.updated == ref["accepted"]
+    npt.assert_allclose(out.x, ref["x"], rtol=1e-9, atol=1e-10)
+    npt.assert_allclose(out.log_alpha, ref["log_alpha"], rtol=1e-7, atol=1e-7)
