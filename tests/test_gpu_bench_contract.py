@@ -45,6 +45,8 @@ def test_bench_full_line_with_general_leg_secondary_legs_and_cpu_baseline():
     assert sec["C3_csmc"]["value"] > 0 and sec["C3_csmc"]["roofline"]["bound"] == "hbm"
     assert sec["C4_lorenz"]["kalman"]["value"] > 0 and sec["C4_lorenz"]["csmc"]["value"] > 0 and sec["C4_lorenz"]["scaling"] == "strong"
     assert all(r["roofline"]["bound"] == "mfma" for r in sec["C5_wide"]["runs"])
+    assert sec["C5_wide"]["sweep_16_chains"]["chain_sweeps_per_s"] > 0 and all(b["scalar_filters_per_s"] > 0 for b in sec["C5_wide"]["batched_scalar"])
+    assert sec["SV_kalman_general_path"]["order_2"]["value"] > 0 and sec["SV_kalman_general_path"]["order_1_chain_shared"]["value"] > 0   # round 4: the general per-chain path on a real model
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["single_thread_value"] > 0
 

@@ -25,7 +25,7 @@ SHARED = {
 GENERAL = {
     "filter_scan": [r"^k_scan_reduce_cm<ax::FilterOpFly<", r"^k_scan_down_cm<ax::FilterOpFly<"],
     "sample_scan": [r"^k_scan_reduce_cm<ax::SampleOpFly<", r"^k_scan_down_cm<ax::SampleOpFly<"],
-    "logpdf": [r"^k_sweep_logpdf_cm<"],
+    "logpdf": [r"^k_sweep_logpdf_cm<", r"^k_sweep_logpdf_cm_semi<", r"^k_sweep_logpdf_tab<"],
     "filter_tab": [r"^k_obs_info_tab<"],
 }
 # round 4: the chain-shared sweep in TWO streaming passes (csrc/fused_shared.h: k_fs_ac, k_fs_e) + the two aggregate scans and the Psi completion between them; the
@@ -111,7 +111,7 @@ def main():
         out = {}
     if cfg == "c2":
         cnt = lambda pre: next((n for k, (n, _) in fetch.items() if re.match(pre, k)), 0)
-        n_sh, n_ge, n_fu = cnt(r"k_sweep_logpdf_cm_shared<"), cnt(r"k_sweep_logpdf_cm<"), cnt(r"k_fs_e<")
+        n_sh, n_ge, n_fu = cnt(r"k_sweep_logpdf_cm_shared<"), cnt(r"k_sweep_logpdf_cm<") or cnt(r"k_sweep_logpdf_cm_semi<"), cnt(r"k_fs_e<")
         if n_fu:  # (a run of fused sweeps only: bench.py --no-general-leg)
             tot = 0
             for g, pats in FUSED.items():
