@@ -1,9 +1,9 @@
 """reference: aux_samplers/_primitives/math/mvn/base.py.
 
 `logpdf` runs on the device (auxssm_mvn_logpdf; inside the filter / log-density kernels the same function is
-csrc/kalman_math.h::gauss_logpdf).  `rvs` draws its normals with the device Threefry generator.  `tril_log_det` and
-`get_optimal_covariance` are set-up-time host helpers (NumPy): the latter is never called on the sampler path
-(SURVEY 8(f) rank 4)."""
+csrc/kalman_math.h::gauss_logpdf).  `rvs` draws its normals with the device Threefry generator.  `get_optimal_covariance` runs on the
+device too (auxssm_mvn_optimal_covariance).  `tril_log_det` of a host array is a set-up-time one-liner (the device
+form lives inside k_mvn_logpdf and the log-density kernels)."""
 import numpy as np
 
 from .... import _lib
@@ -58,15 +58,25 @@ def tril_log_det(chol):
         return np.nansum(np.log(np.abs(d)))
 
 
-def get_optimal_covariance(chol_P, chol_Sig):
+def get_optimal_covariance(chol_P, chol_Sig, handle=None):
     """Cholesky factor of the dominating covariance of Section 3 of the paper (mvn/base.py:78-105): with Y = chol_P^-1 chol_Sig,
-    eigen-decompose Y^T Y = V diag(w) V^T, clip w at 1 and return chol(L L^T), L = chol_Sig V diag(min(w, 1)^-1/2)."""
+    eigen-decompose Y^T Y = V diag(w) V^T, clip w at 1 and return chol(L L^T), L = chol_Sig V diag(min(w, 1)^-1/2) -- on the device
+    (auxssm_mvn_optimal_covariance: one workgroup, cyclic Jacobi eigen-decomposition in LDS), dim <= 64.  Scalars / vectors take the
+    reference's elementwise-maximum branch (:94-95)."""
+    handle = handle or _lib.default_handle()
     chol_P, chol_Sig = np.asarray(chol_P), np.asarray(chol_Sig)
-    if (chol_P.ndim < 2 and chol_Sig.ndim < 2) or chol_P.shape[0] == 1:
-        return np.maximum(chol_P, chol_Sig)
-    from scipy.linalg import solve_triangular
-    right_Y = solve_triangular(chol_P, chol_Sig, lower=True)
-    w, v = np.linalg.eigh(right_Y.T @ right_Y)
-    w = np.minimum(w, 1.0)
-    left_Q = chol_Sig @ (v * (1.0 / np.sqrt(w))[None, :])
-    return np.linalg.cholesky(left_Q @ left_Q.T)
+    dtype = np.dtype(np.float32) if chol_P.dtype == np.float32 and chol_Sig.dtype == np.float32 else np.dtype(np.float64)
+    vector = (chol_P.ndim < 2 and chol_Sig.ndim < 2) or chol_P.shape[0] == 1
+    if vector:
+        shape = np.broadcast_shapes(chol_P.shape, chol_Sig.shape)
+        a, b = (np.ascontiguousarray(np.broadcast_to(v, shape), dtype).reshape(-1) for v in (chol_P, chol_Sig))
+        n = a.size
+    else:
+        if chol_P.ndim != 2 or chol_P.shape[0] != chol_P.shape[1] or chol_Sig.shape != chol_P.shape:
+            raise ValueError(f"chol_P {chol_P.shape} and chol_Sig {chol_Sig.shape} must be the same square shape")
+        shape, n = chol_P.shape, chol_P.shape[0]
+        a, b = np.ascontiguousarray(chol_P, dtype), np.ascontiguousarray(chol_Sig, dtype)
+    ad, bd, out = handle.to_device(a), handle.to_device(b), handle.empty(a.shape, dtype)
+    _lib.check(handle.lib.auxssm_mvn_optimal_covariance(handle.h, _lib.dtype_code(dtype), n, int(vector), ad.ptr, bd.ptr, out.ptr))
+    res = out.to_host().reshape(shape)
+    return res if shape else res[()]

@@ -165,6 +165,216 @@ __global__ void k_mvn_logpdf(long long n, int dim, const R* __restrict__ x, long
     out[g] = (R)-0.5 * nrm - (logdet + (R)0.5 * (R)nfin * (R)1.8378770664093453);
 }
 
+// ---- mvn.get_optimal_covariance (_primitives/math/mvn/base.py:78-105): the dominating covariance of Section 3 of the paper ---------------------------------
+// Y = chol_P^-1 chol_Sig (forward substitution, :98), (w, V) = eigh(Y^T Y) (:99), w <- min(w, 1), L = chol_Sig V diag(w^-1/2) (:100-103), out = chol(L L^T) (:104).
+// One workgroup, dim <= 64, four dim x dim images in LDS.  The symmetric eigen-decomposition is a cyclic Jacobi iteration (rotations (p, q) in row order, every lane a
+// row / column index; the result -- chol of L L^T -- depends on neither the order nor the signs of the eigenvectors); convergence: off-diagonal mass below
+// eps^2 x the diagonal's, at most 40 sweeps.  vector != 0: the scalar / diagonal branch (:94-95), out = max(chol_P, chol_Sig) elementwise over `dim` entries.
+template <typename R> __global__ void __launch_bounds__(256) k_opt_cov(int n, int vector, const R* __restrict__ LPg, const R* __restrict__ LSg, R* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) char smem_oc[];
+    const int tid = threadIdx.x, NTH = 256;
+    if (vector) {
+        for (int k = tid; k < n; k += NTH) out[k] = LPg[k] > LSg[k] ? LPg[k] : LSg[k];
+        return;
+    }
+    R* A = (R*)smem_oc;      // chol_P, then Y^T Y (rotated to diagonal), then L L^T and its factor
+    R* LS = A + n * n;       // chol_Sig
+    R* Y = LS + n * n;       // Y, then L
+    R* V = Y + n * n;        // eigenvectors
+    __shared__ R red[256];
+    for (int e = tid; e < n * n; e += NTH) {
+        const int i = e / n, j = e - i * n;
+        A[e] = j <= i ? LPg[e] : (R)0;
+        LS[e] = j <= i ? LSg[e] : (R)0;
+        V[e] = i == j ? (R)1 : (R)0;
+    }
+    __syncthreads();
+    // Y = chol_P^-1 chol_Sig: lane j solves column j
+    for (int j = tid; j < n; j += NTH)
+        for (int i = 0; i < n; ++i) {
+            R acc = LS[i * n + j];
+            for (int k = 0; k < i; ++k) acc -= A[i * n + k] * Y[k * n + j];
+            Y[i * n + j] = acc / A[i * n + i];
+        }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NTH) {  // A = Y^T Y
+        const int i = e / n, j = e - i * n;
+        R acc = 0;
+        for (int k = 0; k < n; ++k) acc += Y[k * n + i] * Y[k * n + j];
+        A[e] = acc;
+    }
+    __syncthreads();
+    const R eps = sizeof(R) == 4 ? (R)1.2e-7 : (R)2.3e-16;
+    for (int sweep = 0; sweep < 40; ++sweep) {
+        R off = 0, dg = 0;
+        for (int e = tid; e < n * n; e += NTH) {
+            const int i = e / n, j = e - i * n;
+            if (i == j) dg += A[e] * A[e];
+            else off += A[e] * A[e];
+        }
+        red[tid] = off;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        off = red[0];
+        __syncthreads();
+        red[tid] = dg;
+        __syncthreads();
+        for (int w = 128; w > 0; w >>= 1) {
+            if (tid < w) red[tid] += red[tid + w];
+            __syncthreads();
+        }
+        dg = red[0];
+        __syncthreads();
+        if (!(off > eps * eps * dg)) break;
+        for (int p = 0; p < n - 1; ++p)
+            for (int q = p + 1; q < n; ++q) {
+                const R apq = A[p * n + q], app = A[p * n + p], aqq = A[q * n + q];
+                __syncthreads();  // (every lane holds the three entries before anybody rotates)
+                if (apq != (R)0) {
+                    const R theta = (aqq - app) / ((R)2 * apq);
+                    const R t = (theta >= (R)0 ? (R)1 : (R)-1) / (fabs(theta) + sqrt(theta * theta + (R)1));
+                    const R c = (R)1 / sqrt(t * t + (R)1), sn = t * c;
+                    for (int k = tid; k < n; k += NTH) {
+                        const R vkp = V[k * n + p], vkq = V[k * n + q];
+                        V[k * n + p] = c * vkp - sn * vkq;
+                        V[k * n + q] = sn * vkp + c * vkq;
+                        if (k != p && k != q) {
+                            const R akp = A[k * n + p], akq = A[k * n + q];
+                            const R np_ = c * akp - sn * akq, nq_ = sn * akp + c * akq;
+                            A[k * n + p] = np_;
+                            A[p * n + k] = np_;
+                            A[k * n + q] = nq_;
+                            A[q * n + k] = nq_;
+                        }
+                    }
+                    if (tid == 0) {
+                        A[p * n + p] = app - t * apq;
+                        A[q * n + q] = aqq + t * apq;
+                        A[p * n + q] = 0;
+                        A[q * n + p] = 0;
+                    }
+                }
+                __syncthreads();
+            }
+    }
+    // L = chol_Sig (V diag(min(w, 1)^-1/2))  -> Y
+    for (int e = tid; e < n * n; e += NTH) {
+        const int i = e / n, j = e - i * n;
+        R wj = A[j * n + j];
+        wj = wj < (R)1 ? wj : (R)1;
+        R acc = 0;
+        for (int k = 0; k <= i; ++k) acc += LS[i * n + k] * V[k * n + j];
+        Y[e] = acc / sqrt(wj);
+    }
+    __syncthreads();
+    for (int e = tid; e < n * n; e += NTH) {  // A = L L^T
+        const int i = e / n, j = e - i * n;
+        R acc = 0;
+        for (int k = 0; k < n; ++k) acc += Y[i * n + k] * Y[j * n + k];
+        A[e] = acc;
+    }
+    __syncthreads();
+    for (int j = 0; j < n; ++j) {  // Cholesky, column by column (jnp.linalg.cholesky: a failed factorisation is NaN)
+        if (tid == 0) A[j * n + j] = sqrt(A[j * n + j]);
+        __syncthreads();
+        const R d = A[j * n + j];
+        for (int i = j + 1 + tid; i < n; i += NTH) A[i * n + j] /= d;
+        __syncthreads();
+        for (int e = tid; e < (n - j - 1) * (n - j - 1); e += NTH) {
+            const int i = j + 1 + e / (n - j - 1), k = j + 1 + e % (n - j - 1);
+            if (k <= i) A[i * n + k] -= A[i * n + j] * A[k * n + j];
+        }
+        __syncthreads();
+    }
+    for (int e = tid; e < n * n; e += NTH) {
+        const int i = e / n, j = e - i * n;
+        out[e] = j <= i ? A[e] : (R)0;
+    }
+}
+
+// ---- effective sample size (examples/rare_event/ess.py:28-160: BlackJAX's estimator with the option of dividing by the TRUE variance) ----------------------------
+// a: (M chains, N draws, K series) dense.  Means per chain, the biased autocovariances of every lag averaged over the chains (direct sums in double: the reference's
+// FFT gives the same numbers to rounding), then Geyer's initial positive / monotone sequence per series (one lane per series: a scan over N / 2 pairs).
+template <typename R> __global__ void __launch_bounds__(256) k_ess_mean(long long M, long long N, long long K, const R* __restrict__ a, double* __restrict__ cm) {
+    __shared__ double red[256];
+    const long long mk = blockIdx.x, m = mk / K, k = mk - m * K;
+    double acc = 0;
+    for (long long i = threadIdx.x; i < N; i += 256) acc += (double)a[(m * N + i) * K + k];
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) cm[mk] = red[0] / (double)N;
+}
+template <typename R>
+__global__ void __launch_bounds__(256) k_ess_acov(long long M, long long N, long long K, long long nlag, const R* __restrict__ a, const double* __restrict__ cm, double* __restrict__ acov) {
+    __shared__ double red[256];
+    const long long l = blockIdx.x, k = blockIdx.y;
+    double acc = 0;
+    for (long long m = 0; m < M; ++m) {
+        const double mu = cm[m * K + k];
+        const R* am = a + m * N * K + k;
+        for (long long i = threadIdx.x; i + l < N; i += 256) acc += ((double)am[i * K] - mu) * ((double)am[(i + l) * K] - mu);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+        if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) acov[l * K + k] = red[0] / (double)N / (double)M;
+}
+template <typename R>
+__global__ void k_ess_geyer(long long M, long long N, long long K, const double* __restrict__ cm, const double* __restrict__ acov, const R* __restrict__ var, R* __restrict__ out) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= K) return;
+    const long long n_even = N - N % 2, J = n_even / 2;
+    double var0 = acov[k] * (double)N / ((double)N - 1.0);
+    double wvar = var0 * ((double)N - 1.0) / (double)N;
+    if (M > 1) {  // + the variance of the chain means (ddof = 1)
+        double mu = 0, ss = 0;
+        for (long long m = 0; m < M; ++m) mu += cm[m * K + k];
+        mu /= (double)M;
+        for (long long m = 0; m < M; ++m) ss += (cm[m * K + k] - mu) * (cm[m * K + k] - mu);
+        wvar += ss / ((double)M - 1.0);
+    }
+    if (var) wvar = (double)var[k], var0 = wvar;
+    auto rho = [&](long long l) { return l == 0 ? 1.0 : 1.0 - (var0 - acov[l * K + k]) / wvar; };
+    // pass 1: the length of the initial positive run of P_j = rho_2j + rho_2j+1
+    long long L = J;
+    for (long long j = 0; j < J; ++j)
+        if (!(rho(2 * j) + rho(2 * j + 1) > 0.0)) {
+            L = j;
+            break;
+        }
+    const long long last = L > 0 ? L - 1 : 0;
+    // pass 2: truncated terms, the initial monotone sequence, the sum
+    double run = 0, sum = 0, extra = 0;
+    for (long long j = 0; j < J; ++j) {
+        double e = rho(2 * j), o = rho(2 * j + 1);
+        if (j >= L) o = 0.0;
+        bool keep = j < L;
+        if (j == last + 1) keep = e > 0.0;  // "improve estimation": one more even term if it is positive (ess.py:140-146)
+        if (!keep) e = 0.0;
+        const double s = e + o;
+        const double prev = j == 0 ? s : run;   // running minimum of the terms before j (the term itself at j = 0)
+        const bool upd = s > prev;
+        run = j == 0 ? s : (s < run ? s : run);
+        const double ef = upd ? run / 2.0 : e, of = upd ? run / 2.0 : o;
+        sum += ef + of;
+        if (j == (last + 1 < J - 1 ? last + 1 : J - 1)) extra = ef;  // (ess.py:156: the gather clamps an out-of-range index to the last even term)
+    }
+    double tau = -1.0 + 2.0 * sum - extra;
+    const double floor_ = 1.0 / log10((double)M * (double)N);
+    tau = tau > floor_ ? tau : floor_;
+    out[k] = (R)((double)M * (double)N / tau);
+}
+
 }  // namespace ax
 
 using namespace ax;
@@ -298,6 +508,60 @@ int auxssm_mvn_logpdf(auxssm_handle h, int dtype, int64_t n, int32_t dim, const 
     else
         hipLaunchKernelGGL((k_mvn_logpdf<double>), dim3(grid), dim3(64), 0, h->stream, (long long)n, dim, (const double*)x, (long long)sx, (const double*)m,
                            (long long)sm, (const double*)chol, (long long)sl, (double*)out);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+int auxssm_mvn_optimal_covariance(auxssm_handle h, int dtype, int32_t dim, int vector, const void* chol_P, const void* chol_Sig, void* out) {
+    AX_NEED_H(h);
+    if (int rc = need_dtype(dtype)) return rc;
+    if (dim < 1 || (!vector && dim > MVN_MAX_DIM)) {
+        set_error("1 <= dim <= %d (got %d)", MVN_MAX_DIM, dim);
+        return AUXSSM_ERR_ARG;
+    }
+    if (!chol_P || !chol_Sig || !out) {
+        set_error("chol_P/chol_Sig/out must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    const size_t s = dtype == AUXSSM_F32 ? 4 : 8, lds = vector ? 0 : (size_t)4 * dim * dim * s;
+    if (dtype == AUXSSM_F32) {
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_opt_cov<float>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_opt_cov<float>), dim3(1), dim3(256), lds, h->stream, dim, vector, (const float*)chol_P, (const float*)chol_Sig, (float*)out);
+    } else {
+        if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_opt_cov<double>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL((k_opt_cov<double>), dim3(1), dim3(256), lds, h->stream, dim, vector, (const double*)chol_P, (const double*)chol_Sig, (double*)out);
+    }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+int auxssm_ess(auxssm_handle h, int dtype, int64_t M, int64_t N, int64_t K, const void* a, const void* var, void* out) {
+    AX_NEED_H(h);
+    if (int rc = need_dtype(dtype)) return rc;
+    if (M < 1 || N < 4 || K < 1 || N > 0x7fffffffLL || K > 65535 || M * K > 0x7fffffffLL) {
+        set_error("need M >= 1 chains, 4 <= N draws, 1 <= K <= 65535 series (got M=%lld N=%lld K=%lld)", (long long)M, (long long)N, (long long)K);
+        return AUXSSM_ERR_ARG;
+    }
+    if (!a || !out) {
+        set_error("a/out must be non-NULL");
+        return AUXSSM_ERR_ARG;
+    }
+    const long long nlag = N - N % 2;
+    if (int rc = ws_reserve(h, (size_t)(M * K + nlag * K) * sizeof(double) + 1024)) return rc;
+    double* cm = (double*)ws_take(h, (size_t)M * K * sizeof(double));
+    double* acov = (double*)ws_take(h, (size_t)nlag * K * sizeof(double));
+    if (!cm || !acov) return AUXSSM_ERR_NOMEM;
+    if (dtype == AUXSSM_F32) {
+        hipLaunchKernelGGL((k_ess_mean<float>), dim3((unsigned)(M * K)), dim3(256), 0, h->stream, (long long)M, (long long)N, (long long)K, (const float*)a, cm);
+        hipLaunchKernelGGL((k_ess_acov<float>), dim3((unsigned)nlag, (unsigned)K), dim3(256), 0, h->stream, (long long)M, (long long)N, (long long)K, nlag, (const float*)a, (const double*)cm, acov);
+        hipLaunchKernelGGL((k_ess_geyer<float>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, h->stream, (long long)M, (long long)N, (long long)K, (const double*)cm, (const double*)acov,
+                           (const float*)var, (float*)out);
+    } else {
+        hipLaunchKernelGGL((k_ess_mean<double>), dim3((unsigned)(M * K)), dim3(256), 0, h->stream, (long long)M, (long long)N, (long long)K, (const double*)a, cm);
+        hipLaunchKernelGGL((k_ess_acov<double>), dim3((unsigned)nlag, (unsigned)K), dim3(256), 0, h->stream, (long long)M, (long long)N, (long long)K, nlag, (const double*)a, (const double*)cm, acov);
+        hipLaunchKernelGGL((k_ess_geyer<double>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, h->stream, (long long)M, (long long)N, (long long)K, (const double*)cm, (const double*)acov,
+                           (const double*)var, (double*)out);
+    }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -1,58 +1,38 @@
-"""Post-processing of sampler output on the host (NumPy): the effective sample size the reference's rare-event experiment reports
-(aux_samplers/examples/rare_event/ess.py:28-160, a BlackJAX derivative with the option of dividing by the TRUE variance) and the
-result files its experiment scripts write (examples/stochastic_volatility/experiment.py:238-246, rare_event/experiment.py:323-328).
-Nothing here is on the sampler path."""
+"""Post-processing of sampler output: the effective sample size the reference's rare-event experiment reports
+(aux_samplers/examples/rare_event/ess.py:28-160, a BlackJAX derivative with the option of dividing by the TRUE variance) -- computed on the
+device (auxssm_ess), from a host array or from draws already resident in HBM -- and the result files its experiment scripts write
+(examples/stochastic_volatility/experiment.py:238-246, rare_event/experiment.py:323-328; host I/O)."""
 import os
 
 import numpy as np
-from scipy.fft import next_fast_len
 
 
-def effective_sample_size(input_array, var=None, chain_axis=0, sample_axis=1):
+def effective_sample_size(input_array, var=None, chain_axis=0, sample_axis=1, handle=None):
     """ESS = M N / tau, tau = -1 + 2 sum_t P_t over Geyer's initial positive, monotone sequence of paired autocorrelations
-    P_t = rho_{2t} + rho_{2t+1}; autocovariances by FFT, averaged over the M chains; `var` replaces the empirical variance estimate
-    (ess.py:28-160; same estimator as Stan's).  Returns the array with the chain and sample axes removed."""
-    a = np.moveaxis(np.asarray(input_array, np.float64), (chain_axis, sample_axis), (0, 1))
-    M, N = a.shape[:2]
-    rest = a.shape[2:]
-    a = a.reshape(M, N, -1)
-    chain_mean = a.mean(axis=1, keepdims=True)
-    c = a - chain_mean
-    m = next_fast_len(2 * N)
-    f = np.fft.rfft(c, n=m, axis=1)
-    acov = np.fft.irfft(f * np.conj(f), n=m, axis=1)[:, :N] / N        # biased autocovariance per chain
-    acov = acov.mean(axis=0)                                           # (N, K)
-    var0 = acov[0] * N / (N - 1.0)
-    wvar = var0 * (N - 1.0) / N
-    if M > 1:
-        wvar = wvar + chain_mean[:, 0].var(axis=0, ddof=1)
+    P_t = rho_{2t} + rho_{2t+1}; autocovariances averaged over the M chains; `var` replaces the empirical variance estimate
+    (ess.py:28-160; same estimator as Stan's) -- on the device (auxssm_ess: means, autocovariances of every lag by direct sums in double, one
+    lane per series for Geyer's sequences).  `input_array`: a NumPy array or a resident `DeviceArray` (then chain_axis = 0, sample_axis = 1).
+    Returns the array with the chain and sample axes removed."""
+    from . import _lib
+    if isinstance(input_array, _lib.DeviceArray):
+        if (chain_axis, sample_axis) != (0, 1):
+            raise ValueError("a resident array must be laid out (chains, draws, ...)")
+        handle, a, shape, dtype = input_array.handle, input_array, input_array.shape, input_array.dtype
+    else:
+        handle = handle or _lib.default_handle()
+        h = np.asarray(input_array)
+        dtype = np.dtype(np.float32) if h.dtype == np.float32 else np.dtype(np.float64)
+        h = np.ascontiguousarray(np.moveaxis(h, (chain_axis, sample_axis), (0, 1)), dtype)
+        shape, a = h.shape, handle.to_device(h)
+    M, N = shape[:2]
+    rest = shape[2:]
+    K = int(np.prod(rest, dtype=np.int64)) if rest else 1
+    vd = None
     if var is not None:
-        wvar = np.broadcast_to(np.asarray(var, np.float64).reshape(-1), wvar.shape).copy()
-        var0 = wvar.copy()
-    n_even = N - N % 2
-    rho = np.concatenate([np.ones((1, a.shape[2])), 1.0 - (var0[None] - acov[1:n_even]) / wvar[None]], axis=0)
-    even, odd = rho[0::2].copy(), rho[1::2].copy()
-    ess = np.empty(a.shape[2])
-    for k in range(a.shape[2]):
-        e, o = even[:, k], odd[:, k]
-        pos = (e + o) > 0.0
-        L = len(pos) if pos.all() else int(np.argmin(pos))            # length of the initial positive run
-        last = max(L - 1, 0)                                          # its last index (0 when the run is empty, as the reference's scan)
-        o[L:] = 0.0
-        keep = np.zeros(len(e), bool)
-        keep[:L] = True
-        if last + 1 < len(e):
-            keep[last + 1] = e[last + 1] > 0                          # "improve estimation": one more even term if it is positive
-        e[~keep] = 0.0
-        s = e + o
-        run = np.minimum.accumulate(s)                                # initial monotone sequence
-        upd = s > np.concatenate([[s[0]], run[:-1]])
-        e_f = np.where(upd, run / 2.0, e)
-        o_f = np.where(upd, run / 2.0, o)
-        extra = e_f[min(last + 1, len(e) - 1)]                        # (ess.py:156: the gather clamps an out-of-range index to the last even term)
-        tau = -1.0 + 2.0 * np.sum(e_f + o_f) - extra
-        tau = max(tau, 1.0 / np.log10(M * N))
-        ess[k] = M * N / tau
+        vd = handle.to_device(np.ascontiguousarray(np.broadcast_to(np.asarray(var, dtype).reshape(-1), (K,))))
+    out = handle.empty((K,), dtype)
+    _lib.check(handle.lib.auxssm_ess(handle.h, _lib.dtype_code(dtype), M, N, K, a.ptr, vd.ptr if vd is not None else None, out.ptr))
+    ess = out.to_host().astype(np.float64)
     return ess.reshape(rest) if rest else float(ess[0])
 
 

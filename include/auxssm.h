@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define AUXSSM_VERSION 107
+#define AUXSSM_VERSION 108
 
 typedef struct auxssm_ctx* auxssm_handle;
 
@@ -401,6 +401,17 @@ int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t rows, int32_t
  * (aux_samplers.mvn.logpdf, reference aux_samplers/__init__.py:3). */
 int auxssm_mvn_logpdf(auxssm_handle h, int dtype, int64_t n, int32_t dim, const void* x, int64_t sx, const void* m, int64_t sm, const void* chol,
                       int64_t sl, void* out);
+
+/* auxssm_mvn_optimal_covariance == mvn.get_optimal_covariance(chol_P, chol_Sig) (_primitives/math/mvn/base.py:78-105): the Cholesky factor of the dominating
+ * covariance of Section 3 of the paper -- Y = chol_P^-1 chol_Sig, (w, V) = eigh(Y^T Y), w <- min(w, 1), L = chol_Sig V diag(w^-1/2), out = chol(L L^T) -- for
+ * dim <= 64 (lower-triangular row-major inputs and output, dim x dim).  vector != 0: the reference's scalar / diagonal branch (:94-95), out = max(chol_P, chol_Sig)
+ * elementwise over dim entries.  The symmetric eigen-decomposition is a cyclic Jacobi iteration; the result does not depend on the eigenvectors' order or signs. */
+int auxssm_mvn_optimal_covariance(auxssm_handle h, int dtype, int32_t dim, int vector, const void* chol_P, const void* chol_Sig, void* out);
+
+/* auxssm_ess == effective_sample_size(input_array, var) (examples/rare_event/ess.py:28-160: BlackJAX's estimator -- Geyer's initial positive, monotone sequence of
+ * paired autocorrelations, autocovariances averaged over the chains -- with the option of dividing by the TRUE variance): a (M chains, N draws, K series) dense,
+ * var (K) or NULL, out (K).  Autocovariances by direct sums in double (the reference's FFT to rounding).  N >= 4, K <= 65535. */
+int auxssm_ess(auxssm_handle h, int dtype, int64_t M, int64_t N, int64_t K, const void* a, const void* var, void* out);
 
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/auxssm.h but not exported"
     assert set(_lib.exported_symbols()) == set(declared), set(_lib.exported_symbols()) ^ set(declared)
-    assert lib.auxssm_version() == 107
+    assert lib.auxssm_version() == 108
 
 
 def test_no_gpu_fails_loudly():

@@ -58,8 +58,21 @@ def test_nonlinear_linearisation_agrees_to_second_order():
         npt.assert_allclose(Q, Qe, atol=1e-5)
 
 
-def test_ess_known_answers():
-    from aux_samplers.diagnostics import effective_sample_size
+def _ess(impl):
+    """the oracle's restatement (CPU) or the product's device estimator (auxssm_ess)"""
+    if impl == "oracle":
+        from oracle.post_np import effective_sample_size
+    else:
+        from aux_samplers.diagnostics import effective_sample_size
+    return effective_sample_size
+
+
+IMPLS = ["oracle", pytest.param("device", marks=pytest.mark.gpu)]
+
+
+@pytest.mark.parametrize("impl", IMPLS)
+def test_ess_known_answers(impl):
+    effective_sample_size = _ess(impl)
     rng = np.random.default_rng(0)
     M, N = 4, 20000
     x = rng.standard_normal((M, N))
@@ -80,11 +93,12 @@ def test_ess_known_answers():
     assert out.shape == (2,) and np.all(out > 0.8 * 3 * N)
 
 
-def test_ess_all_positive_initial_sequence_clamps_like_the_reference():
+@pytest.mark.parametrize("impl", IMPLS)
+def test_ess_all_positive_initial_sequence_clamps_like_the_reference(impl):
     """when the WHOLE initial sequence is positive (max_t + 1 == number of pairs) the reference's gather
     `rho_hat_even_final[indices]` (ess.py:122-123,156) clamps the out-of-range index, so the LAST even term is subtracted -- not 0.
     Hand computation on a short, strongly autocorrelated pair of chains."""
-    from aux_samplers.diagnostics import effective_sample_size
+    effective_sample_size = _ess(impl)
     M, N = 2, 6
     x = np.array([[0.0, 1.0, 2.1, 2.9, 4.2, 5.0], [0.2, 0.9, 2.0, 3.1, 3.9, 5.1]]) + np.array([[0.0], [3.0]])
     # ess.py:60-111 written out for this input
@@ -103,6 +117,40 @@ def test_ess_all_positive_initial_sequence_clamps_like_the_reference():
     tau = -1.0 + 2.0 * np.sum(e_f + o_f) - e_f[-1]            # clamped gather: the last even term
     want = M * N / max(tau, 1.0 / np.log10(M * N))
     npt.assert_allclose(effective_sample_size(x), want, rtol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_ess_device_vs_oracle(dtype):
+    """auxssm_ess against oracle/post_np.py (ess.py:28-160) on the same draws: several chains and series, odd and even N, with and without the TRUE variance,
+    anticorrelated series (the initial positive run ends early), a constant-sign run that reaches the last pair, host and resident input."""
+    from aux_samplers.diagnostics import effective_sample_size
+    from aux_ssm_samplers_amd import _lib
+    from oracle import post_np as O
+    rng = np.random.default_rng(5)
+    for (M, N, K) in [(1, 7, 1), (3, 1001, 5), (4, 4096, 3), (2, 50, 70)]:
+        e = rng.standard_normal((M, N, K))
+        rho = np.linspace(-0.8, 0.95, K)
+        y = np.zeros((M, N, K))
+        y[:, 0] = e[:, 0]
+        for t in range(1, N):
+            y[:, t] = rho * y[:, t - 1] + np.sqrt(1 - rho ** 2) * e[:, t]
+        y = (y + np.arange(M)[:, None, None] * 0.1).astype(dtype)
+        tol = 1e-9 if dtype == np.float64 else 2e-3
+        for var in (None, np.full(K, 1.3)):
+            want = O.effective_sample_size(y.astype(np.float64), var=var)
+            got = effective_sample_size(y, var=var)
+            npt.assert_allclose(got, want, rtol=tol)
+        # resident draws, extra axes
+        h = _lib.default_handle()
+        got = effective_sample_size(h.to_device(y))
+        npt.assert_allclose(got, O.effective_sample_size(y.astype(np.float64)), rtol=tol)
+    z = rng.standard_normal((2, 300, 2, 3)).astype(dtype)
+    got = effective_sample_size(np.moveaxis(z, 1, 3), chain_axis=0, sample_axis=3)
+    assert got.shape == (2, 3)
+    npt.assert_allclose(got, O.effective_sample_size(z.astype(np.float64)), rtol=1e-9 if dtype == np.float64 else 2e-3)
+    with pytest.raises(ValueError):
+        effective_sample_size(np.zeros((2, 3)))
 
 
 def test_result_files_have_the_reference_schema(tmp_path):

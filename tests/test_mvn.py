@@ -26,10 +26,20 @@ def test_tril_log_det_ignores_nonfinite():
     npt.assert_allclose(mvn.tril_log_det(L), K.tril_log_det(L))
 
 
-@pytest.mark.parametrize("d", [1, 2, 3, 5])
-def test_get_optimal_covariance_dominates_both(d):
+def _optcov(impl):
+    if impl == "oracle":
+        from oracle.post_np import get_optimal_covariance
+    else:
+        from aux_ssm_samplers_amd._primitives.math.mvn import get_optimal_covariance
+    return get_optimal_covariance
+
+
+@pytest.mark.parametrize("impl", ["oracle", pytest.param("device", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("d", [1, 2, 3, 5, 30, 64])
+def test_get_optimal_covariance_dominates_both(d, impl):
     """mvn/base.py:78-105 has no reference test; the defining property: Q = L L^T dominates both covariances, and equals P when P >= Sig."""
-    from aux_ssm_samplers_amd._primitives.math import mvn
+    import types
+    mvn = types.SimpleNamespace(get_optimal_covariance=_optcov(impl))
     rng = np.random.default_rng(d)
     A, B = rng.standard_normal((d, d + 2)), rng.standard_normal((d, d + 2))
     P, S = A @ A.T, B @ B.T
@@ -38,10 +48,34 @@ def test_get_optimal_covariance_dominates_both(d):
     if d == 1:
         npt.assert_allclose(LQ, np.maximum(np.linalg.cholesky(P), np.linalg.cholesky(S)))
         return
-    assert np.linalg.eigvalsh(Q - S).min() > -1e-10 and np.linalg.eigvalsh(Q - P).min() > -1e-10
+    tol = 1e-13 * d * np.linalg.norm(Q, 2) + 1e-10
+    assert np.linalg.eigvalsh(Q - S).min() > -tol and np.linalg.eigvalsh(Q - P).min() > -tol
     big = P + S  # dominates S: the optimum is then S's dominating matrix = P + S itself? no: Q(P+S, S) must equal P + S
     LQ2 = mvn.get_optimal_covariance(np.linalg.cholesky(big), np.linalg.cholesky(S))
-    npt.assert_allclose(LQ2 @ LQ2.T, big, rtol=1e-9, atol=1e-10)
+    npt.assert_allclose(LQ2 @ LQ2.T, big, rtol=1e-9, atol=1e-10 * d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("d", [2, 4, 17, 64])
+def test_get_optimal_covariance_device_vs_oracle(d, dtype):
+    """auxssm_mvn_optimal_covariance (Jacobi eigen-decomposition in LDS) against oracle/post_np.py (LAPACK eigh): the factor itself -- the Cholesky factor of
+    L L^T is unique, whatever the order and the signs of the eigenvectors -- incl. repeated eigenvalues (P = Sig), and the vector branch."""
+    from aux_ssm_samplers_amd._primitives.math import mvn
+    from oracle import post_np as O
+    rng = np.random.default_rng(100 + d)
+    A, B = rng.standard_normal((d, 2 * d)), rng.standard_normal((d, 2 * d))
+    LP, LS = np.linalg.cholesky(A @ A.T / d).astype(dtype), np.linalg.cholesky(B @ B.T / d).astype(dtype)
+    tol = dict(rtol=1e-9, atol=1e-10) if dtype == np.float64 else dict(rtol=3e-3, atol=3e-4)
+    got = mvn.get_optimal_covariance(LP, LS)
+    assert got.dtype == dtype and np.all(np.triu(got, 1) == 0)
+    npt.assert_allclose(got, O.get_optimal_covariance(LP.astype(np.float64), LS.astype(np.float64)), **tol)
+    npt.assert_allclose(mvn.get_optimal_covariance(LP, LP), LP, **tol)          # Y = I: every eigenvalue is 1
+    v1, v2 = np.abs(rng.standard_normal(d)).astype(dtype), np.abs(rng.standard_normal(d)).astype(dtype)
+    npt.assert_array_equal(mvn.get_optimal_covariance(v1, v2), np.maximum(v1, v2))
+    assert mvn.get_optimal_covariance(dtype(2.0), dtype(3.0)) == 3.0
+    with pytest.raises(ValueError):
+        mvn.get_optimal_covariance(np.eye(65), np.eye(65))
 
 
 def test_log1mexp_logsubexp():
