@@ -115,6 +115,7 @@ def load():
         "auxssm_lorenz_theta_update": ([vp, i32, C.c_int32, C.c_int32, i32, vp, dbl, dbl, vp, vp, vp], C.c_int),
         "auxssm_mvn_logpdf": ([vp, i32, i64, C.c_int32, vp, i64, vp, i64, vp, i64, vp], C.c_int),
         "auxssm_mvn_optimal_covariance": ([vp, i32, C.c_int32, i32, vp, vp, vp], C.c_int),
+        "auxssm_linearise": ([vp, i32, i32, i32, i32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp], C.c_int),
         "auxssm_ess": ([vp, i32, i64, i64, i64, vp, vp, vp], C.c_int),
         "auxssm_kalman_draw": ([vp, i32, P(u32), i64, i64, vp, vp, vp], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),

@@ -375,9 +375,237 @@ __global__ void k_ess_geyer(long long M, long long N, long long K, const double*
     out[k] = (R)((double)M * (double)N / tau);
 }
 
+
+// ---- statistical / Taylor linearisation on the device (_primitives/linearisation.py: extended :11-44, gauss_hermite :47-75, cubature :78-104,
+// _generic_sigma_points :107-127) for the closed family of conditional means the device knows: AFFINE mean(x) = A x + a (the reference's own
+// test, test_linearisation.py) and LORENZ63 mean(x) = x + dt (phi_0(x) + theta * phi(x)) (examples/lorenz/model.py:10-25); cov(x) = Qc.
+// One lane per linearisation point, D <= 4.  Sigma-point methods: L = chol(P*), points x* + L xi_j, two passes over the points (the mean of the
+// images, then the two covariances around it -- the images are recomputed, not stored), F = (P*^-1 Psi)^T by the two triangular solves of
+// cho_solve, Q = Phi - (F L)(F L)^T + sum_j w_j Qc, b = m_f - F x*.  The 1-D rule (nodes, weights) comes from the host: cubature = the 2 D points
+// +- sqrt(D) e_i with weights 1 / 2D, Gauss-Hermite = the order^D tensor grid of the probabilists' rule.
+struct LinRule { int method, order; double node[8], weight[8]; };
+template <typename R, int DX, int DY> struct LinFn {
+    int kind;              // 0 affine, 1 lorenz63
+    const R *A, *a, *Qc;   // affine: A (DY, DX), a (DY); lorenz63: A = (theta_0..2, dt); Qc (DY, DY)
+    __device__ void mean(const R* x, R* mu) const {
+        if constexpr (DX == 3 && DY == 3) {
+            if (kind == 1) {
+                const R dt = A[3];
+                mu[0] = x[0] + dt * (A[0] * (x[1] - x[0]));
+                mu[1] = x[1] + dt * (A[1] * x[0] - x[1] - x[0] * x[2]);
+                mu[2] = x[2] + dt * (x[0] * x[1] - A[2] * x[2]);
+                return;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DY; ++r) {
+            R acc = a[r];
+#pragma unroll
+            for (int k = 0; k < DX; ++k) acc += A[r * DX + k] * x[k];
+            mu[r] = acc;
+        }
+    }
+    __device__ void jac(const R* x, R* F) const {
+        if constexpr (DX == 3 && DY == 3) {
+            if (kind == 1) {
+                const R dt = A[3];
+                const R J[9] = {-A[0], A[0], 0, A[1] - x[2], (R)-1, -x[0], x[1], x[0], -A[2]};
+#pragma unroll
+                for (int k = 0; k < 9; ++k) F[k] = ((k / 3 == k % 3) ? (R)1 : (R)0) + dt * J[k];
+                return;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < DY * DX; ++k) F[k] = A[k];
+    }
+};
+template <typename R, int D> __device__ inline void lin_point(const LinRule& rule, int j, const R* L, const R* xs, R* dx, R* pt, R* w) {
+    R xi[D];
+    if (rule.method == 1) {  // cubature: j < D: +sqrt(D) e_j, else -sqrt(D) e_{j - D}
+#pragma unroll
+        for (int k = 0; k < D; ++k) xi[k] = (j % D == k) ? (j < D ? (R)rule.node[0] : -(R)rule.node[0]) : (R)0;
+        *w = (R)rule.weight[0];
+    } else {  // Gauss-Hermite: digits of j in base `order`
+        R ww = 1;
+        int q = j;
+#pragma unroll
+        for (int k = 0; k < D; ++k) {
+            const int i = q % rule.order;
+            q /= rule.order;
+            xi[k] = (R)rule.node[i];
+            ww *= (R)rule.weight[i];
+        }
+        *w = ww;
+    }
+#pragma unroll
+    for (int r = 0; r < D; ++r) {
+        R acc = 0;
+#pragma unroll
+        for (int k = 0; k <= r; ++k) acc += L[r * D + k] * xi[k];
+        dx[r] = acc;
+        pt[r] = xs[r] + acc;
+    }
+}
+template <typename R, int DX, int DY>
+__global__ void k_linearise(long long n, LinRule rule, int npts, LinFn<R, DX, DY> fn, const R* __restrict__ xstar, const R* __restrict__ Pstar, long long sP,
+                            R* __restrict__ Fo, R* __restrict__ Qo, R* __restrict__ bo) {
+    const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    R xs[DX], F[DY * DX], Q[DY * DY], b[DY];
+#pragma unroll
+    for (int k = 0; k < DX; ++k) xs[k] = xstar[g * DX + k];
+    if (rule.method == 0) {  // extended: analytic Jacobian in place of jacfwd / jacrev
+        R mu[DY];
+        fn.mean(xs, mu);
+        fn.jac(xs, F);
+#pragma unroll
+        for (int k = 0; k < DY * DY; ++k) Q[k] = fn.Qc[k];
+#pragma unroll
+        for (int r = 0; r < DY; ++r) {
+            R acc = mu[r];
+#pragma unroll
+            for (int k = 0; k < DX; ++k) acc -= F[r * DX + k] * xs[k];
+            b[r] = acc;
+        }
+    } else {
+        R L[DX * DX];
+        const R* P = Pstar + g * sP;
+#pragma unroll
+        for (int k = 0; k < DX * DX; ++k) L[k] = 0;
+#pragma unroll
+        for (int j = 0; j < DX; ++j) {  // Cholesky (a failed factorisation is NaN, as jnp.linalg.cholesky)
+            R dsum = P[j * DX + j];
+#pragma unroll
+            for (int k = 0; k < j; ++k) dsum -= L[j * DX + k] * L[j * DX + k];
+            const R dj = sqrt(dsum);
+            L[j * DX + j] = dj;
+#pragma unroll
+            for (int i = j + 1; i < DX; ++i) {
+                R acc = P[i * DX + j];
+#pragma unroll
+                for (int k = 0; k < j; ++k) acc -= L[i * DX + k] * L[j * DX + k];
+                L[i * DX + j] = acc / dj;
+            }
+        }
+        R mf[DY], wsum = 0;
+#pragma unroll
+        for (int k = 0; k < DY; ++k) mf[k] = 0;
+        for (int j = 0; j < npts; ++j) {
+            R dx[DX], pt[DX], f[DY], w;
+            lin_point<R, DX>(rule, j, L, xs, dx, pt, &w);
+            fn.mean(pt, f);
+            wsum += w;
+#pragma unroll
+            for (int k = 0; k < DY; ++k) mf[k] += w * f[k];
+        }
+        R Psi[DX * DY], Phi[DY * DY];
+#pragma unroll
+        for (int k = 0; k < DX * DY; ++k) Psi[k] = 0;
+#pragma unroll
+        for (int k = 0; k < DY * DY; ++k) Phi[k] = 0;
+        for (int j = 0; j < npts; ++j) {
+            R dx[DX], pt[DX], f[DY], w;
+            lin_point<R, DX>(rule, j, L, xs, dx, pt, &w);
+            fn.mean(pt, f);
+#pragma unroll
+            for (int c = 0; c < DY; ++c) {
+                const R dfc = f[c] - mf[c];
+#pragma unroll
+                for (int r = 0; r < DX; ++r) Psi[r * DY + c] += (dx[r] * w) * dfc;
+#pragma unroll
+                for (int r = 0; r < DY; ++r) Phi[r * DY + c] += ((f[r] - mf[r]) * w) * dfc;
+            }
+        }
+        // F^T = P^-1 Psi (DX x DY): L z = Psi, L^T Ft = z, column by column
+        R Ft[DX * DY];
+#pragma unroll
+        for (int c = 0; c < DY; ++c) {
+            R z[DX];
+#pragma unroll
+            for (int r = 0; r < DX; ++r) {
+                R acc = Psi[r * DY + c];
+#pragma unroll
+                for (int k = 0; k < r; ++k) acc -= L[r * DX + k] * z[k];
+                z[r] = acc / L[r * DX + r];
+            }
+#pragma unroll
+            for (int r = DX - 1; r >= 0; --r) {
+                R acc = z[r];
+#pragma unroll
+                for (int k = r + 1; k < DX; ++k) acc -= L[k * DX + r] * Ft[k * DY + c];
+                Ft[r * DY + c] = acc / L[r * DX + r];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < DY; ++r)
+#pragma unroll
+            for (int c = 0; c < DX; ++c) F[r * DX + c] = Ft[c * DY + r];
+        R FL[DY * DX];
+#pragma unroll
+        for (int r = 0; r < DY; ++r)
+#pragma unroll
+            for (int c = 0; c < DX; ++c) {
+                R acc = 0;
+#pragma unroll
+                for (int k = c; k < DX; ++k) acc += F[r * DX + k] * L[k * DX + c];
+                FL[r * DX + c] = acc;
+            }
+#pragma unroll
+        for (int r = 0; r < DY; ++r)
+#pragma unroll
+            for (int c = 0; c < DY; ++c) {
+                R acc = 0;
+#pragma unroll
+                for (int k = 0; k < DX; ++k) acc += FL[r * DX + k] * FL[c * DX + k];
+                Q[r * DY + c] = Phi[r * DY + c] - acc + wsum * fn.Qc[r * DY + c];
+            }
+#pragma unroll
+        for (int r = 0; r < DY; ++r) {
+            R acc = mf[r];
+#pragma unroll
+            for (int k = 0; k < DX; ++k) acc -= F[r * DX + k] * xs[k];
+            b[r] = acc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < DY * DX; ++k) Fo[g * DY * DX + k] = F[k];
+#pragma unroll
+    for (int k = 0; k < DY * DY; ++k) Qo[g * DY * DY + k] = Q[k];
+#pragma unroll
+    for (int k = 0; k < DY; ++k) bo[g * DY + k] = b[k];
+}
+
 }  // namespace ax
 
 using namespace ax;
+
+template <typename R, int DX, int DY>
+static void launch_linearise(auxssm_ctx* h, int64_t n, const LinRule& rule, int npts, int fn_kind, const void* A, const void* a, const void* Qc, const void* xstar,
+                             const void* Pstar, int64_t sP, void* F, void* Q, void* b) {
+    LinFn<R, DX, DY> fn{fn_kind, (const R*)A, (const R*)a, (const R*)Qc};
+    hipLaunchKernelGGL((k_linearise<R, DX, DY>), dim3((unsigned)((n + 127) / 128)), dim3(128), 0, h->stream, (long long)n, rule, npts, fn, (const R*)xstar,
+                       (const R*)Pstar, (long long)sP, (R*)F, (R*)Q, (R*)b);
+}
+template <typename R, int DX>
+static void launch_linearise_dy(auxssm_ctx* h, int dy, int64_t n, const LinRule& rule, int npts, int fn_kind, const void* A, const void* a, const void* Qc,
+                                const void* xstar, const void* Pstar, int64_t sP, void* F, void* Q, void* b) {
+    switch (dy) {
+        case 1: launch_linearise<R, DX, 1>(h, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b); break;
+        case 2: launch_linearise<R, DX, 2>(h, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b); break;
+        case 3: launch_linearise<R, DX, 3>(h, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b); break;
+        default: launch_linearise<R, DX, 4>(h, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b);
+    }
+}
+template <typename R>
+static void launch_linearise_dx(auxssm_ctx* h, int dx, int dy, int64_t n, const LinRule& rule, int npts, int fn_kind, const void* A, const void* a, const void* Qc,
+                                const void* xstar, const void* Pstar, int64_t sP, void* F, void* Q, void* b) {
+    switch (dx) {
+        case 1: launch_linearise_dy<R, 1>(h, dy, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b); break;
+        case 2: launch_linearise_dy<R, 2>(h, dy, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b); break;
+        case 3: launch_linearise_dy<R, 3>(h, dy, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b); break;
+        default: launch_linearise_dy<R, 4>(h, dy, n, rule, npts, fn_kind, A, a, Qc, xstar, Pstar, sP, F, Q, b);
+    }
+}
 
 extern "C" {
 
@@ -562,6 +790,47 @@ int auxssm_ess(auxssm_handle h, int dtype, int64_t M, int64_t N, int64_t K, cons
         hipLaunchKernelGGL((k_ess_geyer<double>), dim3((unsigned)((K + 63) / 64)), dim3(64), 0, h->stream, (long long)M, (long long)N, (long long)K, (const double*)cm, (const double*)acov,
                            (const double*)var, (double*)out);
     }
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+int auxssm_linearise(auxssm_handle h, int dtype, int method, int order, int fn_kind, int64_t n, int32_t dim, int32_t dim_out, const void* A, const void* a,
+                     const void* Qc, const void* nodes, const void* weights, const void* x_star, const void* P_star, int64_t sP, void* F, void* Q, void* b) {
+    AX_NEED_H(h);
+    if (int rc = need_dtype(dtype)) return rc;
+    if (method < AUXSSM_LIN_EXTENDED || method > AUXSSM_LIN_GAUSS_HERMITE || fn_kind < AUXSSM_FN_AFFINE || fn_kind > AUXSSM_FN_LORENZ63) {
+        set_error("unknown linearisation method %d / function kind %d", method, fn_kind);
+        return AUXSSM_ERR_ARG;
+    }
+    if (n < 0 || dim < 1 || dim > 4 || dim_out < 1 || dim_out > 4 || (fn_kind == AUXSSM_FN_LORENZ63 && (dim != 3 || dim_out != 3))) {
+        set_error("need n >= 0 and 1 <= dim, dim_out <= 4 (3, 3 for LORENZ63); got n=%lld dim=%d dim_out=%d", (long long)n, dim, dim_out);
+        return AUXSSM_ERR_ARG;
+    }
+    if (!A || !Qc || (fn_kind == AUXSSM_FN_AFFINE && !a) || !x_star || !F || !Q || !b || (method != AUXSSM_LIN_EXTENDED && !P_star)) {
+        set_error("NULL argument (A, a [affine], Qc, x_star, P_star [sigma-point methods], F, Q, b)");
+        return AUXSSM_ERR_ARG;
+    }
+    LinRule rule{};
+    rule.method = method;
+    int npts = 0;
+    if (method == AUXSSM_LIN_CUBATURE) {
+        rule.order = 1;
+        rule.node[0] = sqrt((double)dim);
+        rule.weight[0] = 0.5 / dim;
+        npts = 2 * dim;
+    } else if (method == AUXSSM_LIN_GAUSS_HERMITE) {
+        if (order < 1 || order > 8 || !nodes || !weights) {
+            set_error("Gauss-Hermite: 1 <= order <= 8 with its nodes / weights for N(0, 1) as host doubles (got order %d)", order);
+            return AUXSSM_ERR_ARG;
+        }
+        rule.order = order;
+        npts = 1;
+        for (int k = 0; k < dim; ++k) npts *= order;
+        for (int k = 0; k < order; ++k) rule.node[k] = ((const double*)nodes)[k], rule.weight[k] = ((const double*)weights)[k];
+    }
+    if (n == 0) return AUXSSM_OK;
+    if (dtype == AUXSSM_F32) launch_linearise_dx<float>(h, dim, dim_out, n, rule, npts, fn_kind, A, a, Qc, x_star, P_star, sP, F, Q, b);
+    else launch_linearise_dx<double>(h, dim, dim_out, n, rule, npts, fn_kind, A, a, Qc, x_star, P_star, sP, F, Q, b);
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -413,6 +413,19 @@ int auxssm_mvn_optimal_covariance(auxssm_handle h, int dtype, int32_t dim, int v
  * var (K) or NULL, out (K).  Autocovariances by direct sums in double (the reference's FFT to rounding).  N >= 4, K <= 65535. */
 int auxssm_ess(auxssm_handle h, int dtype, int64_t M, int64_t N, int64_t K, const void* a, const void* var, void* out);
 
+/* auxssm_linearise == extended / cubature / gauss_hermite(mean, cov, params, x_star, P_star[, order]) (_primitives/linearisation.py:11-44, :78-104, :47-75 on
+ * _generic_sigma_points :107-127) for n linearisation points at once, for the conditional means the device knows in closed form (cov(x) = Qc):
+ *   AUXSSM_FN_AFFINE    mean(x) = A x + a, A (dim_out, dim), a (dim_out)    (the reference's own test of the three methods, test_linearisation.py:13-48: 4 -> 2)
+ *   AUXSSM_FN_LORENZ63  mean(x) = x + dt (phi_0(x) + theta * phi(x)), A = (theta_0, theta_1, theta_2, dt), a unused, dim = dim_out = 3 (examples/lorenz/model.py:10-25)
+ * x_star (n, dim) dense; P_star (dim, dim) with point stride sP in elements (0 = one matrix for every point; unused by EXTENDED, may be NULL);
+ * GAUSS_HERMITE: `nodes`, `weights` = HOST doubles, the `order`-point rule for N(0, 1) (order <= 8), tensorised on the device (order^dim points);
+ * CUBATURE: the 2 dim points +- sqrt(dim) e_i.  EXTENDED uses the analytic Jacobian where the reference differentiates with jacfwd.
+ * Out: F (n, dim_out, dim), Q (n, dim_out, dim_out), b (n, dim_out) -- what a dynamics_factory hands to get_kernel.  dim, dim_out <= 4; Qc (dim_out, dim_out). */
+typedef enum { AUXSSM_LIN_EXTENDED = 0, AUXSSM_LIN_CUBATURE = 1, AUXSSM_LIN_GAUSS_HERMITE = 2 } auxssm_lin_method;
+typedef enum { AUXSSM_FN_AFFINE = 0, AUXSSM_FN_LORENZ63 = 1 } auxssm_lin_fn;
+int auxssm_linearise(auxssm_handle h, int dtype, int method, int order, int fn_kind, int64_t n, int32_t dim, int32_t dim_out, const void* A, const void* a,
+                     const void* Qc, const void* nodes, const void* weights, const void* x_star, const void* P_star, int64_t sP, void* F, void* Q, void* b);
+
 /* ---- device RNG: Threefry-2x32-20 counter stream -> N(0,1) / U[0,1) fill -----------------------------
  * out[i], i < n, is a pure function of (key0, key1, stream, i) -- number (i & 1) of Threefry block i >> 1: see
  * oracle/rng_np.py for the restatement. */
