@@ -104,16 +104,23 @@ class DeviceChains:
     """C chains' trajectories resident in HBM.  With >= 32 chains (or chain_minor=True) the state and the per-sweep noise
     are stored chain-minor, (T, dx, C): the sweep's lanes then run over chains (AUXSSM_LAYOUT_CHAIN_MINOR, include/auxssm.h)."""
 
-    def __init__(self, handle, x, dtype=None, chain_minor=None, fused=None):
+    def __init__(self, handle, x, dtype=None, chain_minor=None, fused=None, model=None):
         """fused=False: keyed sweeps never take the fused three-pass path (auxssm_kalman_sweep_fused), e.g. to read the drawn noise back from
-        eps_aux / eps_samp afterwards -- the fused sweep has no such buffers."""
+        eps_aux / eps_samp afterwards -- the fused sweep has no such buffers.
+        model: the device model the chains will be swept with (a layout hint only): a chain-shared linear-Gaussian model takes the chain-minor layout -- and with
+        it the fused sweep -- from 4 chains on, not 32 (measured at C2's sizes, profiles/r04_i_low_chain_layout.txt: 8 chains 9.4k -> 17.1k sweeps/s, 16 chains
+        11.3k -> 36.7k; 2 chains are faster time-minor)."""
         x = np.asarray(x)
         if x.ndim == 2:
             x = x[None]
         self.handle = handle
         self.C, self.T, self.dx = x.shape
         env = os.environ.get("AUXSSM_CM")
-        self.chain_minor = bool(int(env)) if env is not None and chain_minor is None else (self.C >= 32 if chain_minor is None else bool(chain_minor))
+        auto = self.C >= 32
+        if (model is not None and getattr(model, "kmodel", None) == _lib.KMODEL_LG_CONCAT and self.C >= 4 and self.C % 2 == 0 and self.T >= 64
+                and self.dx <= 4 and 1 <= getattr(model, "p_obs", 0) <= 4):
+            auto = True   # (the conditions of csrc/api.hip::fused_refusal; anything else keeps the time-minor general path below 32 chains)
+        self.chain_minor = bool(int(env)) if env is not None and chain_minor is None else (auto if chain_minor is None else bool(chain_minor))
         if self.dx > 4 and chain_minor is None:
             self.chain_minor = False  # dx > 4 runs the wide-state kernels (csrc/wide.hip): a workgroup per time step, dense layout
         self.layout = _lib.LAYOUT_CHAIN_MINOR if self.chain_minor else _lib.LAYOUT_DENSE
@@ -243,7 +250,8 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         """state.x: ndarray (T, dx) [one chain], ndarray (C, T, dx) or DeviceChains (resident, updated in place)."""
         resident = isinstance(state.x, DeviceChains)
         handle = state.x.handle if resident else _lib.default_handle()  # resident chains carry their device
-        chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None)
+        chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None,
+                                                       model=model if parallel and noise is None else None)
         keys = None
         if noise is None:  # the keyed sweep: same values as draw() + sweep(), in one call (eps buffers: taken on demand, the fused sweep has none)
             keys = _random.split(key, 3)

@@ -341,7 +341,7 @@ def leg_c2(ctx, args, share, steps, warmup, chains_obj=None):
         init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
         rng = np.random.Generator(np.random.PCG64(1000 + ctx.rank))
         x0 = (m["x_true"][None] + 0.3 * rng.standard_normal((C, T, d))).astype(dtype)
-        chains_obj = (DeviceChains(handle, x0), kernel)
+        chains_obj = (DeviceChains(handle, x0, model=model if share else None), kernel)
     chains, kernel = chains_obj
     state = KalmanSampler(x=chains, updated=None)
     handle.set_option(_lib.OPT_SHARE_MODEL, int(share))

@@ -43,7 +43,7 @@ def main():
             model = LGConcatModel(m["m0"], m["P0"], bt(m["F"], (T - 1, d, d)), bt(m["Q"], (T - 1, d, d)), bt(m["b"], (T - 1, d)), bt(m["Hobs"], (T, d, d)),
                                   bt(m["Robs"], (T, d, d)), bt(m["cobs"], (T, d)), m["y"])
             init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
-            ch = DeviceChains(h, m["x_true"][None] + 0.3 * np.random.default_rng(0).standard_normal((C, T, d)))
+            ch = DeviceChains(h, m["x_true"][None] + 0.3 * np.random.default_rng(0).standard_normal((C, T, d)), model=model)
             run(f"C2 LG-SSM T={T} d={d} fp64", kernel, ch, 0.5)
         elif w.startswith("c4_"):
             C = int(w[3:])
