@@ -272,8 +272,16 @@ template <typename R, int N> __device__ __forceinline__ void fs_stage(const R* _
     constexpr int W = Vec16<R>::W;
     const V* src = reinterpret_cast<const V*>(tab + (long long)r0 * N);
     V* dst = reinterpret_cast<V*>(lds);
-    const int n = (r1 - r0) * (N / W);
-    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    const int n = (r1 - r0) * (N / W), B = blockDim.x;
+    // four loads in flight per trip (one load -> wait -> LDS write per trip left a one-wave workgroup a dozen serial memory latencies before its first step)
+    for (int i = threadIdx.x; i < n; i += 4 * B) {
+        const bool p1 = i + B < n, p2 = i + 2 * B < n, p3 = i + 3 * B < n;
+        const V v0 = src[i], v1 = p1 ? src[i + B] : V{}, v2 = p2 ? src[i + 2 * B] : V{}, v3 = p3 ? src[i + 3 * B] : V{};
+        dst[i] = v0;
+        if (p1) dst[i + B] = v1;
+        if (p2) dst[i + 2 * B] = v2;
+        if (p3) dst[i + 3 * B] = v3;
+    }
     __syncthreads();
 }
 

@@ -123,9 +123,27 @@ struct NormTabGlobal {
 struct NormTabLds {
     const double* p;
     __device__ __forceinline__ static void stage(double* lds, bool sync = true) {
-        for (int i = threadIdx.x; i < 257; i += blockDim.x) reinterpret_cast<double2*>(lds)[i] = reinterpret_cast<const double2*>(RNG_LOG_TAB_DEV)[i];
-        for (int i = threadIdx.x; i < 256; i += blockDim.x)
-            reinterpret_cast<double2*>(lds + RNG_TAB_TURN_OFF)[i] = reinterpret_cast<const double2*>(RNG_TURN_TAB_DEV)[i];
+        // (all of a lane's loads first, then its LDS writes: the two tables are 513 16-byte entries, i.e. up to nine trips of a one-wave workgroup)
+        const double2* s0 = reinterpret_cast<const double2*>(RNG_LOG_TAB_DEV);
+        const double2* s1 = reinterpret_cast<const double2*>(RNG_TURN_TAB_DEV);
+        double2* d0 = reinterpret_cast<double2*>(lds);
+        double2* d1 = reinterpret_cast<double2*>(lds + RNG_TAB_TURN_OFF);
+        const int B = blockDim.x;
+        for (int i = threadIdx.x; i < 257; i += 4 * B) {
+            const bool p1 = i + B < 257, p2 = i + 2 * B < 257, p3 = i + 3 * B < 257;
+            const bool q0 = i < 256, q1 = i + B < 256, q2 = i + 2 * B < 256, q3 = i + 3 * B < 256;
+            const double2 z{0, 0};
+            const double2 a0 = s0[i], a1 = p1 ? s0[i + B] : z, a2 = p2 ? s0[i + 2 * B] : z, a3 = p3 ? s0[i + 3 * B] : z;
+            const double2 b0 = q0 ? s1[i] : z, b1 = q1 ? s1[i + B] : z, b2 = q2 ? s1[i + 2 * B] : z, b3 = q3 ? s1[i + 3 * B] : z;
+            d0[i] = a0;
+            if (p1) d0[i + B] = a1;
+            if (p2) d0[i + 2 * B] = a2;
+            if (p3) d0[i + 3 * B] = a3;
+            if (q0) d1[i] = b0;
+            if (q1) d1[i + B] = b1;
+            if (q2) d1[i + 2 * B] = b2;
+            if (q3) d1[i + 3 * B] = b3;
+        }
         if (sync) __syncthreads();
     }
     __device__ __forceinline__ void log_entry(int j, double& inv, double& L) const {
