@@ -456,10 +456,14 @@ def leg_c3_csmc(ctx, T, N, Cn, steps, warmup, dtype=np.float32, cpu=False):
         # the vector ALUs are -- SQ_INSTS_VALU x 4 cycles over SQ_BUSY_CU_CYCLES x 4 SIMDs -- and how many instructions a wave issues per time step
         sq = {}
         for kk in ("csmc_fwd", "csmc_bwd"):
-            try:
-                ent = json.load(open(os.path.join(ROOT, "profiles", "r03_traffic.json"))).get(f"csmc_C3_sq_k_{kk}")
-            except Exception:
-                ent = None
+            ent = None
+            for tj in ("r04_traffic.json", "r03_traffic.json"):   # (round 4: profiles/r04_j_sq_counters_c3.txt, the same kernels re-measured)
+                try:
+                    ent = json.load(open(os.path.join(ROOT, "profiles", tj))).get(f"csmc_C3_sq_k_{kk}")
+                except Exception:
+                    ent = None
+                if ent:
+                    break
             if ent:
                 sq[kk] = {q: ent.get(q) for q in ("valu_issue_frac", "valu_per_wave_step", "salu_per_wave_step", "lds_per_wave_step", "branch_per_wave_step", "source")}
         if sq:
