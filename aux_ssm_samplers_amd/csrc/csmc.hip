@@ -50,7 +50,18 @@ constexpr int CSMC_ABL = AUXSSM_CSMC_ABLATE;
 
 // ---- forward pass (_csmc, csmc.py:69-107) -------------------------------------------------------------------------------
 // NW = 8 / 16: exactly NW full waves (N = blockDim = 64 NW: the C4 / C3 shapes): no liveness / group-bound selects (csmc_dev.h); NW = 0: any N
-template <typename R, int D, bool TV, bool GRAD, int NW> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
+// SP = 1: the instantiation of config C3's shape -- auxiliary independent proposals, the stochastic-volatility potential, a time-invariant linear transition, draws
+// generated in the kernel, no ancestor trace (backward sampling): the run-time switches on the model kind are folded at compile time (they are wave-uniform
+// branches, two dozen per time step); same operations on the same operands, bit for bit (tests/test_gpu_csmc.py runs both instantiations on C3's model)
+template <typename R, int D, bool TV, bool GRAD, int NW, int SP = 0> __global__ void __launch_bounds__(1024) k_csmc_fwd(CsmcArgs a, FkDev<R> m) {
+    if constexpr (SP == 1) {
+        m.proposal = 1;
+        m.potential = 2;
+        m.transition = 0;
+        a.As = nullptr;
+        a.noise_mode = 1;
+        a.pregen = 0;
+    }
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int TB = blockDim.x, nw = TB >> 6, tid = threadIdx.x, N = a.N, T = a.T;
     // two images of (c, xprev), alternated by time-step parity: readers of step t never race writers of step t+1,
@@ -515,7 +526,15 @@ static int run_csmc(auxssm_ctx* h, const auxssm_fk_model* fk, const double* host
         else if (fullw == 8) AX_FWD1(TVv, GRv, 8); \
         else AX_FWD1(TVv, GRv, 0);      \
     } while (0)
-        if (tv && gr) AX_FWD(true, true);
+        static const bool spec_on = [] { const char* e = getenv("AUXSSM_CSMC_SPEC"); return !(e && atoi(e) == 0); }();   // 0: the generic instantiation (measurement, tests)
+        const bool c3_shape = spec_on && D == 1 && sizeof(R) == 4 && fullw == 16 && !tv && !gr && fk->proposal == 1 && fk->potential == 2 && m.transition == 0 &&
+                              ab.As == nullptr && ab.noise_mode != 0 && !ab.pregen;
+        if (c3_shape) {
+            if constexpr (D == 1 && sizeof(R) == 4) {
+                if (lds > 48 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_csmc_fwd<R, D, false, false, 16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL((k_csmc_fwd<R, D, false, false, 16, 1>), dim3(ab.C), dim3(TB), lds, h->stream, ab, m);
+            }
+        } else if (tv && gr) AX_FWD(true, true);
         else if (tv) AX_FWD(true, false);
         else if (gr) AX_FWD(false, true);
         else AX_FWD(false, false);

@@ -99,6 +99,31 @@ def test_multichain_equals_single_chain_and_threefry_equals_explicit(T):
         npt.assert_array_equal(ancc, ancb[c])
 
 
+def test_c3_shape_instantiation_equals_the_generic_kernel_bit_for_bit(monkeypatch):
+    """config C3's shape (SV potential, d = 1, N = 1024, fp32, independent auxiliary proposals, backward sampling, draws generated inside the forward kernel)
+    runs k_csmc_fwd<float, 1, false, false, 16, SP = 1>, whose model switches are folded at compile time; the same key as explicit arrays runs the generic
+    instantiation: trajectories and ancestors must be identical.  (Few chains would otherwise take the pre-generated draws, i.e. the generic kernel.)"""
+    from aux_ssm_samplers_amd import random as R
+    from aux_ssm_samplers_amd import _lib
+    from aux_ssm_samplers_amd.csmc import _device
+    monkeypatch.setenv("AUXSSM_CSMC_NO_PREGEN", "1")
+    rng = np.random.default_rng(17)
+    d, N, C, T = 1, 1024, 3, 301
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    y[5] = 0.0       # (no finite bound of the potential at y = 0: the exact-maximum branch)
+    G0, Gt = _pot(O.POT_SV, y)
+    fk = _device.describe_independent(M0, G0, Mt, Gt, Mt)
+    x0 = rng.standard_normal((C, T, d)).astype(np.float32)
+    key = R.PRNGKey(123)
+    xa, anca, _ = _device.sweep(fk, x0, N, True, key=key, delta=0.3)
+    noise = _device.key_noise(_lib.default_handle(), key, C, T, N, d, np.float32)
+    xb, ancb, _ = _device.sweep(fk, x0, N, True, noise=noise, delta=0.3)
+    npt.assert_array_equal(xa, xb)
+    npt.assert_array_equal(anca, ancb)
+    assert (anca != 0).mean() > 0.5
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("d,N,T,C", [(1, 64, 2, 3), (1, 100, 7, 2), (3, 512, 8, 4), (2, 33, 65, 5), (4, 1024, 5, 2)])
 @pytest.mark.parametrize("proposal", ["independent", "bootstrap"])
