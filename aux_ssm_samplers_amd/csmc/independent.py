@@ -14,11 +14,38 @@ model family (csrc/csmc.hip::k_csmc_grad).  gradient=True follows the reference 
 proposal enters the weights at t = 0 (GradientAuxiliaryG0, :173-190) while for t >= 1 GradientAuxiliaryGt sums it over ALL particles
 (jnp.sum without an axis, :265-266), i.e. adds a constant that cancels -- no correction.  gradient="exact" applies the per-particle
 correction at every step (the weights the construction intends; AUXSSM_GRAD_EXACT)."""
+from dataclasses import dataclass
+from typing import Any, Optional
+
 import numpy as np
 
-from .._primitives.csmc.base import CSMCState
+from .._primitives.csmc.base import CSMCState, Distribution, UnivariatePotential, Potential, Dynamics
 from . import _device
 from .generic import get_kernel as get_base_kernel, IndependentFactory
+
+
+# The pieces the reference's parallel kernel hands to _primitives/csmc/pit.get_kernel (independent.py:78-118, classes :164-169, :202-225, :239-248): plain records
+# here -- the device kernels evaluate them in closed form, so they carry the model components and the auxiliary variables, not Python densities.
+@dataclass
+class AuxiliaryMtDistribution(Distribution):
+    """proposals N(u_t [+ delta_t / 2 grad_t], delta_t / 2 I): params = (u (T, d), sqrt(delta / 2) scalar or (T,), grad_pi or None)   (independent.py:202-225).
+    A non-None third entry switches the gradient-informed proposals on; the device evaluates the gradient of the model's log-density at u itself
+    (csrc/csmc.hip::k_csmc_grad), the array's values are not read."""
+    params: Any = None
+
+
+@dataclass
+class AuxiliaryG0(UnivariatePotential):
+    """G0(x) + M0.logpdf(x)   (independent.py:164-169)"""
+    M0: Any = None
+    G0: Any = None
+
+
+@dataclass
+class AuxiliaryGt(Potential):
+    """Gt(x_t, x_{t-1}) + Mt.logpdf(x_t | x_{t-1})   (independent.py:239-248)"""
+    Mt: Any = None
+    Gt: Any = None
 
 
 def _get_parallel_kernel(M0, G0, Mt, Gt, N, gmode=0):

@@ -114,6 +114,47 @@ def test_parallel_kernel_targets_the_smoothing_distribution():
     assert out.x.shape == (T, 1) and out.updated.shape == (T,) and out.updated.dtype == bool
 
 
+@pytest.mark.parametrize("gradient", [False, True])
+def test_reference_call_shape_through_pit_get_kernel(gradient):
+    """what independent.py:78-118 does by hand -- draw u, build mt / g0 / gt (/ qt), call `_primitives.csmc.pit.get_kernel(mt, g0, gt, N, qt)` -- against the
+    device sweep on the same auxiliary variables and the same proposal / resampling draws.  x, the step scale and the auxiliary noise are dyadic so that the
+    eps_aux the wrapper recovers from u reproduces u exactly; arbitrary Python objects still raise."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd._primitives.csmc import pit
+    from aux_samplers._primitives.csmc import pit as pit_ref_path  # noqa: F401  (the reference's import path resolves to the same module)
+    from aux_ssm_samplers_amd.csmc import _device
+    from aux_ssm_samplers_amd.csmc.independent import AuxiliaryMtDistribution, AuxiliaryG0, AuxiliaryGt
+    rng = np.random.default_rng(3)
+    d, N, T = 2, 32, 40
+    M0, Mt = _models(d, rng)
+    y = rng.standard_normal((T, d))
+    G0, Gt = _pot(O.POT_SV, y)
+    x = np.round(rng.standard_normal((T, d)) * 64) / 64
+    scale = 0.5
+    eps_aux = np.round(rng.standard_normal((T, d)) * 64) / 64
+    u = x + scale * eps_aux
+    mt = AuxiliaryMtDistribution(params=(u, scale * np.ones(T), np.zeros_like(u) if gradient else None))
+    qt = AuxiliaryMtDistribution(params=(u, scale * np.ones(T), None)) if gradient else None
+    init, kernel = pit.get_kernel(mt, AuxiliaryG0(M0=M0, G0=G0), AuxiliaryGt(Mt=Mt, Gt=Gt), N, qt)
+    key = R.PRNGKey(11)
+    st = init(x)
+    assert st.updated.shape == (T,) and not st.updated.any()
+    out = kernel(key, st)
+    h = _lib.default_handle()
+    k_prop, k_res = R.split(key, 2)
+    noise = dict(eps_aux=eps_aux[None], eps_prop=h.rng_normal(k_prop, 2, (1, T, N, d), np.float64).to_host(), u_res=h.rng_uniform(k_res, 3, (1, T, N), np.float64).to_host())
+    fk = _device.describe_independent(M0, G0, Mt, Gt, None, _lib.GRAD_EXACT if gradient else _lib.GRAD_NONE)
+    xr, ancr = _device.pit_sweep(fk, x, N, noise=noise, delta=2 * scale ** 2)
+    npt.assert_array_equal(out.x, xr)
+    npt.assert_array_equal(out.ancestors, ancr)
+    npt.assert_array_equal(out.updated, ancr != 0)
+    assert ancr.any()
+    with pytest.raises(NotImplementedError):
+        pit.get_kernel(object(), AuxiliaryG0(M0=M0, G0=G0), AuxiliaryGt(Mt=Mt, Gt=Gt), N)
+    with pytest.raises(NotImplementedError):
+        pit.get_kernel(mt, AuxiliaryG0(M0=M0, G0=G0), AuxiliaryGt(Mt=Mt, Gt=Gt), N, None if gradient else mt)
+
+
 def test_argument_errors():
     from aux_ssm_samplers_amd.csmc import _device
     rng = np.random.default_rng(0)
