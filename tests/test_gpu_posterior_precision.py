@@ -44,14 +44,17 @@ def _check(step, read, exact, burn, M):
     return (mean - exact[:, 0]) / sd
 
 
-@pytest.mark.parametrize("which", ["independent_backward", "independent_tracing", "gradient_exact", "bootstrap", "parallel_in_time", "parallel_in_time_gradient"])
+@pytest.mark.parametrize("which", ["independent_backward", "independent_tracing", "gradient_exact", "bootstrap", "parallel_in_time", "parallel_in_time_gradient", "c3_shape_fp32"])
 def test_csmc_kernels_at_one_percent_resolution(which):
     from aux_ssm_samplers_amd import _lib, random as R
     from aux_ssm_samplers_amd.csmc import get_independent_kernel, CsmcChains, CSMCState, GaussianInit, LinearGaussianDynamics, SVPotential
     y, xtrue, (m0, P0, F, Q, b), exact = _truth()
     M0, Mt, G0, Gt = GaussianInit(m0=m0, P0=P0), LinearGaussianDynamics(F=F, b=b, Q=Q), SVPotential(y=y[0]), SVPotential(params=y[1:])
-    delta = 2.0
-    if which == "independent_backward":
+    delta, dtype = 2.0, np.float64
+    if which == "c3_shape_fp32":   # config C3's own kernel instantiation: N = 1024, fp32, backward sampling, draws generated in the forward kernel (>= 256 chains)
+        init, kernel = get_independent_kernel(M0, G0, Mt, Gt, 1024, backward=True, Pt=Mt)
+        dtype = np.float32
+    elif which == "independent_backward":
         init, kernel = get_independent_kernel(M0, G0, Mt, Gt, 16, backward=True, Pt=Mt)
     elif which == "independent_tracing":
         init, kernel = get_independent_kernel(M0, G0, Mt, Gt, 16, backward=False)
@@ -65,12 +68,12 @@ def test_csmc_kernels_at_one_percent_resolution(which):
         init, kernel = get_independent_kernel(M0, G0, Mt, Gt, 32, parallel=True)
     else:
         init, kernel = get_independent_kernel(M0, G0, Mt, Gt, 32, gradient=True, parallel=True)
-    chains = CsmcChains(_lib.default_handle(), np.repeat(xtrue[None], C, 0).astype(np.float64), **({} if delta is None else dict(delta=delta)))
+    chains = CsmcChains(_lib.default_handle(), np.repeat(xtrue[None], C, 0).astype(dtype), **({} if delta is None else dict(delta=delta)))
     state = CSMCState(x=chains, updated=None)
     burn, M = 60, 400
     keys = R.split(R.PRNGKey(23), burn + M)
     step = (lambda i: kernel(keys[i], state)) if delta is None else (lambda i: kernel(keys[i], state, None))
-    _check(step, lambda: chains.to_host()[:, :, 0], exact, burn, M)
+    _check(step, lambda: chains.to_host()[:, :, 0].astype(np.float64), exact, burn, M)
 
 
 @pytest.mark.parametrize("order", [2, 1])
