@@ -790,7 +790,8 @@ def main(argv=None):
 
     general = None
     if share and not args.no_general_leg and not args.no_prof and main_leg["mode"] in ("shared", "fused"):
-        general = leg_c2(ctx, args, False, max(3, args.steps // 2), 1, chains_obj=main_leg["chains_obj"])
+        # (below 32 chains the headline's chains are chain-minor only because the model is chain-shared: the general path keeps its own, time-minor, layout there)
+        general = leg_c2(ctx, args, False, max(3, args.steps // 2), 1, chains_obj=main_leg["chains_obj"] if args.chains >= 32 else None)
 
     # the trivial chain-gather (RCCL): acceptance flags + last log-alphas of every chain to rank 0
     from aux_ssm_samplers_amd.parallel import gather_chains
