@@ -151,6 +151,16 @@ def test_ess_device_vs_oracle(dtype):
     npt.assert_allclose(got, O.effective_sample_size(z.astype(np.float64)), rtol=1e-9 if dtype == np.float64 else 2e-3)
     with pytest.raises(ValueError):
         effective_sample_size(np.zeros((2, 3)))
+    # a constant series: every autocorrelation is 0 / 0, the masks of ess.py:107-127 (jnp.where on comparisons that are false for NaN) drop them all, tau = -1 is
+    # floored at 1 / log10(M N) -- the estimator's answer is M N log10(M N), and the other series of the call are unaffected
+    yc = np.array(y[:, :, :2], dtype)
+    yc[:, :, 0] = 1.5
+    got = effective_sample_size(yc)
+    with np.errstate(all="ignore"):
+        want = O.effective_sample_size(yc.astype(np.float64))
+    Mc, Nc = yc.shape[:2]
+    npt.assert_allclose(want[0], Mc * Nc * np.log10(Mc * Nc))
+    npt.assert_allclose(got, want, rtol=tol)
 
 
 def test_result_files_have_the_reference_schema(tmp_path):
