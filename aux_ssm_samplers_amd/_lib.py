@@ -118,6 +118,7 @@ def load():
         "auxssm_linearise": ([vp, i32, i32, i32, i32, i64, C.c_int32, C.c_int32, vp, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp], C.c_int),
         "auxssm_ess": ([vp, i32, i64, i64, i64, vp, vp, vp], C.c_int),
         "auxssm_kalman_draw": ([vp, i32, P(u32), i64, i64, vp, vp, vp], C.c_int),
+        "auxssm_rng_jax": ([vp, i32, i32, i64, i64, vp, dbl, dbl, vp, i64, i64], C.c_int),
         "auxssm_rng_normal": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
         "auxssm_rng_uniform": ([vp, i32, u32, u32, u32, i64, vp], C.c_int),
     }

@@ -278,6 +278,17 @@ def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, 
         shd = handle.to_device(shd_h, dtype)
     keep = []
     nz = _lib.CsmcNoise()
+    if noise is None and _random.compat() == "jax":
+        # the reference's own draws from this key (random.jax_csmc_noise), as explicit arrays; several chains: one key per chain, `key` (C, 2) or split(key, C)
+        if fk.proposal != _lib.PROP_AUX_INDEPENDENT:
+            raise NotImplementedError('random.set_compat("jax") covers the auxiliary kernels with independent proposals (csmc/independent.py): the bootstrap '
+                                      "kernel's draws are made by the user's own M0.sample / Mt.sample in the reference")
+        kk = np.asarray(key, np.uint32)
+        keys = kk if kk.ndim == 2 else (_random.as_key(key)[None] if Cn == 1 else _random.jax_split(_random.as_key(key), Cn))
+        if keys.shape[0] != Cn:
+            raise ValueError(f"{keys.shape[0]} keys for {Cn} chains")
+        per = [_random.jax_csmc_noise(k_, T, N, d, dtype, bool(backward), handle) for k_ in keys]
+        noise = {name: np.stack([p_[name] for p_ in per]) for name in per[0]}
     if noise is None:
         k = _random.as_key(key)
         nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(k[0]), int(k[1])

@@ -4,6 +4,7 @@
 // aux_samplers/common.py:4-32 (delta_adaptation), examples/lorenz/model.py:59-79 (theta_posterior_mean_and_chol).
 // Built with -ffp-contract=off: the running means are then the NumPy expressions bit for bit.
 #include "ctx.h"
+#include "rng.h"
 
 namespace ax {
 
@@ -575,6 +576,79 @@ __global__ void k_linearise(long long n, LinRule rule, int npts, LinFn<R, DX, DY
     for (int k = 0; k < DY; ++k) bo[g * DY + k] = b[k];
 }
 
+
+// ---- jax.random's own bit stream (threefry2x32, the non-partitionable layout: JAX's default up to 0.4.x, what the reference ran on) ----------------------------
+// jax/_src/prng.py: threefry_2x32(key, iota(m)) splits the counters in two halves (one 0 appended when m is odd), runs one block per pair and concatenates the two
+// output halves -- value i < h = ceil(m / 2) is word 0 of block (i, h + i) [second counter 0 for the appended one], value i >= h is word 1 of block (i - h, i);
+// 64-bit values take m = 2 n counters and are (word 0 << 32) | word 1 of block (i, n + i).  jax/_src/random.py: uniform = (mantissa bits | exponent of 1) - 1, scaled to
+// [minval, maxval) and clamped below; normal = sqrt(2) erfinv(uniform(nextafter(-1, 0), 1)).  One launch fills n values for EACH of nkeys keys (a vmap over keys),
+// written with a key stride and an element stride (dense or chain-minor targets).  oracle/rng_np.py::jax_* restates this on the host, pinned by the values JAX's
+// documentation prints (tests/test_rng.py); erfinv: float32 = XLA's ErfInvF32 polynomials (M. Giles), float64 = the same start + two Newton steps on erf (XLA uses its
+// own rational form there: agreement to rounding).
+template <typename R> struct JaxBits;
+template <> struct JaxBits<float> {
+    static __device__ float unit(uint32_t w0, uint32_t) { return __uint_as_float((w0 >> 9) | 0x3F800000u) - 1.0f; }
+};
+__device__ inline float jax_erfinv(float x) {
+    float w = -log1pf(-x * x);
+    const bool lt = w < 5.0f;
+    w = lt ? w - 2.5f : sqrtf(w) - 3.0f;
+    float p = lt ? 2.81022636e-08f : -0.000200214257f;
+    p = (lt ? 3.43273939e-07f : 0.000100950558f) + p * w;
+    p = (lt ? -3.5233877e-06f : 0.00134934322f) + p * w;
+    p = (lt ? -4.39150654e-06f : -0.00367342844f) + p * w;
+    p = (lt ? 0.00021858087f : 0.00573950773f) + p * w;
+    p = (lt ? -0.00125372503f : -0.0076224613f) + p * w;
+    p = (lt ? -0.00417768164f : 0.00943887047f) + p * w;
+    p = (lt ? 0.246640727f : 1.00167406f) + p * w;
+    p = (lt ? 1.50140941f : 2.83297682f) + p * w;
+    return p * x;
+}
+__device__ inline double jax_erfinv(double x) {
+    double y = (double)jax_erfinv((float)x);
+    if (!(fabs(x) < 1.0)) return x == 1.0 ? (double)INFINITY : (x == -1.0 ? -(double)INFINITY : (double)NAN);
+    // Newton with the second-order (Halley) correction, d/dy erf = 2 / sqrt(pi) exp(-y^2); beyond |x| = 1/2 on erfc(|y|) = 1 - |x| (1 - |x| is exact there and erfc
+    // keeps its RELATIVE accuracy in the tail, where erf(y) - x would lose it to cancellation)
+    const bool tail = fabs(x) > 0.5;
+    const double ax = fabs(x), c = 1.0 - ax;
+    double ya = fabs(y);
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const double d = 1.1283791670955126 * exp(-ya * ya);
+        const double e = tail ? c - erfc(ya) : erf(ya) - ax;   // = erf(ya) - |x| either way
+        const double st = e / d;
+        ya -= st / (1.0 + ya * st);
+    }
+    return x < 0 ? -ya : ya;
+}
+template <typename R>
+__global__ void __launch_bounds__(256) k_rng_jax(int kind, long long nkeys, long long n, const uint32_t* __restrict__ keys, R lo, R hi, R* __restrict__ out,
+                                                 long long skey, long long selem) {
+    const long long per = sizeof(R) == 4 ? (n + 1) / 2 : n;   // blocks per key
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= nkeys * per) return;
+    const long long c = g / per, i = g - c * per;
+    const uint32_t k0 = keys[2 * c], k1 = keys[2 * c + 1];
+    auto finish = [&](R f) {   // f in [0, 1)
+        R v = f * (hi - lo) + lo;
+        v = v > lo ? v : lo;
+        if (kind == 1) v = (R)1.4142135623730951 * jax_erfinv(v);
+        return v;
+    };
+    if constexpr (sizeof(R) == 4) {
+        const long long second = per + i;                 // the value that takes word 1 of this block
+        uint32_t x0 = (uint32_t)i, x1 = second < n ? (uint32_t)second : 0u;
+        threefry2x32(k0, k1, x0, x1);
+        out[c * skey + i * selem] = finish(__uint_as_float((x0 >> 9) | 0x3F800000u) - 1.0f);
+        if (second < n) out[c * skey + second * selem] = finish(__uint_as_float((x1 >> 9) | 0x3F800000u) - 1.0f);
+    } else {
+        uint32_t x0 = (uint32_t)i, x1 = (uint32_t)(n + i);
+        threefry2x32(k0, k1, x0, x1);
+        const unsigned long long b = ((unsigned long long)x0 << 32) | x1;
+        out[c * skey + i * selem] = finish(__longlong_as_double((long long)((b >> 12) | 0x3FF0000000000000ull)) - 1.0);
+    }
+}
+
 }  // namespace ax
 
 using namespace ax;
@@ -831,6 +905,37 @@ int auxssm_linearise(auxssm_handle h, int dtype, int method, int order, int fn_k
     if (n == 0) return AUXSSM_OK;
     if (dtype == AUXSSM_F32) launch_linearise_dx<float>(h, dim, dim_out, n, rule, npts, fn_kind, A, a, Qc, x_star, P_star, sP, F, Q, b);
     else launch_linearise_dx<double>(h, dim, dim_out, n, rule, npts, fn_kind, A, a, Qc, x_star, P_star, sP, F, Q, b);
+    AX_HIP(hipGetLastError());
+    return AUXSSM_OK;
+}
+
+int auxssm_rng_jax(auxssm_handle h, int dtype, int kind, int64_t nkeys, int64_t n, const uint32_t* keys, double minval, double maxval, void* out, int64_t key_stride,
+                   int64_t elem_stride) {
+    AX_NEED_H(h);
+    if (int rc = need_dtype(dtype)) return rc;
+    if (kind < 0 || kind > 1 || nkeys < 0 || n < 0 || (2 * n > 0xffffffffLL) || !keys || !out) {
+        set_error("kind 0 (uniform) / 1 (normal), nkeys, n >= 0, 2 n < 2^32, keys / out non-NULL (got kind=%d nkeys=%lld n=%lld)", kind, (long long)nkeys, (long long)n);
+        return AUXSSM_ERR_ARG;
+    }
+    if (nkeys == 0 || n == 0) return AUXSSM_OK;
+    const long long per = dtype == AUXSSM_F32 ? (n + 1) / 2 : n, tot = nkeys * per;
+    if ((tot + 255) / 256 > 0x7fffffffLL) {
+        set_error("too many values for one launch");
+        return AUXSSM_ERR_ARG;
+    }
+    const unsigned grid = (unsigned)((tot + 255) / 256);
+    ProfScope ps(h, AUXSSM_K_RNG);
+    if (dtype == AUXSSM_F32) {
+        float lo = (float)minval, hi = (float)maxval;
+        if (kind == 1) lo = nextafterf(-1.0f, 0.0f), hi = 1.0f;
+        hipLaunchKernelGGL((k_rng_jax<float>), dim3(grid), dim3(256), 0, h->stream, kind, (long long)nkeys, (long long)n, keys, lo, hi, (float*)out, (long long)key_stride,
+                           (long long)elem_stride);
+    } else {
+        double lo = minval, hi = maxval;
+        if (kind == 1) lo = nextafter(-1.0, 0.0), hi = 1.0;
+        hipLaunchKernelGGL((k_rng_jax<double>), dim3(grid), dim3(256), 0, h->stream, kind, (long long)nkeys, (long long)n, keys, lo, hi, (double*)out, (long long)key_stride,
+                           (long long)elem_stride);
+    }
     AX_HIP(hipGetLastError());
     return AUXSSM_OK;
 }

@@ -55,6 +55,9 @@ def _get_host_kernel(dynamics_factory, observations_factory, log_likelihood_fn, 
         """noise: optional dict(eps_aux, eps_samp, u_accept) of explicit draws (parity tests)."""
         x = np.asarray(state.x)
         handle = _lib.default_handle()
+        if noise is None and _random.compat() == "jax":
+            nz = _random.jax_kalman_noise(_random.as_key(key)[None], x.shape[0], x.shape[1], np.float32 if x.dtype == np.float32 else np.float64, handle)
+            noise = dict(eps_aux=nz["eps_aux"][0], eps_samp=nz["eps_samp"][0], u_accept=float(nz["u_accept"][0]))
         k_aux, k_samp, k_acc = _random.split(key, 3) if noise is None else (None, None, None)
         if noise is None:
             eps_aux = handle.rng_normal(k_aux, 0, x.shape, x.dtype).to_host()
@@ -250,6 +253,17 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
         """state.x: ndarray (T, dx) [one chain], ndarray (C, T, dx) or DeviceChains (resident, updated in place)."""
         resident = isinstance(state.x, DeviceChains)
         handle = state.x.handle if resident else _lib.default_handle()  # resident chains carry their device
+        if noise is None and _random.compat() == "jax":
+            # the reference's own draws from this key (random.jax_kalman_noise: split(key, 3), two normals of x's shape, the acceptance uniform) as explicit arrays;
+            # several chains: one key per chain -- `key` (C, 2), as jax.vmap(kernel) takes them, or split(key, C)
+            Cn = state.x.C if resident else (1 if np.ndim(state.x) == 2 else np.shape(state.x)[0])
+            Tn, dn = (state.x.T, state.x.dx) if resident else np.shape(state.x)[-2:]
+            dt = state.x.dtype if resident else (np.float32 if np.asarray(state.x).dtype == np.float32 else np.float64)
+            kk = np.asarray(key, np.uint32)
+            keys_c = kk if kk.ndim == 2 else (_random.as_key(key)[None] if Cn == 1 else _random.jax_split(_random.as_key(key), Cn))
+            if keys_c.shape[0] != Cn:
+                raise ValueError(f"{keys_c.shape[0]} keys for {Cn} chains")
+            noise = _random.jax_kalman_noise(keys_c, Tn, dn, dt, handle)
         chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None,
                                                        model=model if parallel and noise is None else None)
         keys = None

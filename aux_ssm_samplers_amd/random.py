@@ -2,8 +2,13 @@
 
 Keys are (2,) uint32 arrays, split with Threefry-2x32-20 exactly as csrc/rng.h does on the device; the bulk
 normal / uniform draws themselves are generated on the GPU (auxssm_rng_normal / auxssm_rng_uniform).
-This is NOT bit-compatible with jax.random (JAX is unavailable offline, so that could not be pinned); the parity
-contract of this package is on explicit noise arrays, which every kernel also accepts.
+The default streams are this package's own (csrc/rng.h); the parity contract is on explicit noise arrays, which every kernel also accepts.
+
+jax.random compatibility (round 4): `jax_split / jax_uniform / jax_normal` reproduce jax.random's threefry2x32 implementation in its non-partitionable layout (JAX's
+default up to 0.4.x, what the reference ran on) -- the draws on the device (auxssm_rng_jax), the key arithmetic on the host -- pinned by the values JAX's documentation
+prints (tests/test_rng.py: split(PRNGKey(0)) = [4146024105 967050713] / [2718843009 1272950319], uniform -> 0.41845703, normal -> -0.20584226, ...).  `set_compat("jax")`
+makes the kernels of kalman.get_kernel and the auxiliary particle-Gibbs kernels draw exactly what the reference's code draws from the same key (kalman/generic.py:58-73,
+csmc/generic.py:64-67, _primitives/csmc/csmc.py:71-85, :129-138): the explicit-noise sweeps then run on those arrays.
 """
 import numpy as np
 
@@ -80,3 +85,107 @@ def uniform(key, shape=(), dtype=np.float64, handle=None):
     n = int(np.prod(shape, dtype=np.int64)) if shape else 1
     out = handle.rng_uniform((int(key[0]), int(key[1])), 0, (n,), dtype).to_host()
     return out.reshape(shape) if shape else out[0]
+
+
+# ---- jax.random compatibility -------------------------------------------------------------------------------------------------------------------------------
+_COMPAT = None
+
+
+def set_compat(mode):
+    """None: this package's own streams (default).  "jax": kernels called with a key draw what the reference's code draws from that key with jax.random (threefry2x32,
+    non-partitionable layout).  Returns the previous mode."""
+    global _COMPAT
+    if mode not in (None, "jax"):
+        raise ValueError('mode must be None or "jax"')
+    prev, _COMPAT = _COMPAT, mode
+    return prev
+
+
+def compat():
+    return _COMPAT
+
+
+def _jax_threefry_2x32(key, count):
+    count = np.asarray(count, np.uint32).ravel()
+    odd = count.size % 2
+    c = np.concatenate([count, np.zeros(1, np.uint32)]) if odd else count
+    h = c.size // 2
+    o0, o1 = threefry2x32(key[0], key[1], c[:h], c[h:])
+    out = np.concatenate([o0, o1])
+    return out[:-1] if odd else out
+
+
+def jax_split(key, num=2):
+    """jax.random.split(key, num) -> (num, 2) uint32; `key` may also be (K, 2): -> (K, num, 2) (a vmap over keys)"""
+    key = np.asarray(key, np.uint32)
+    if key.ndim == 2:
+        return np.stack([jax_split(k, num) for k in key])
+    return _jax_threefry_2x32(as_key(key), np.arange(2 * num, dtype=np.uint32)).reshape(num, 2)
+
+
+def _jax_fill(kind, keys, n, dtype, minval, maxval, handle, out=None, key_stride=None, elem_stride=1):
+    from . import _lib
+    handle = handle or _lib.default_handle()
+    keys = np.ascontiguousarray(np.asarray(keys, np.uint32).reshape(-1, 2))
+    kd = handle.to_device(keys)
+    dtype = np.dtype(dtype)
+    if out is None:
+        out = handle.empty((keys.shape[0], n), dtype)
+        key_stride = n
+    _lib.check(handle.lib.auxssm_rng_jax(handle.h, _lib.dtype_code(dtype), kind, keys.shape[0], n, kd.ptr, float(minval), float(maxval), out.ptr, int(key_stride),
+                                         int(elem_stride)))
+    return out
+
+
+def jax_uniform(key, shape=(), dtype=np.float32, minval=0.0, maxval=1.0, handle=None):
+    """jax.random.uniform(key, shape, dtype, minval, maxval); `key` (2,) -> array of `shape`; keys (K, 2) -> (K,) + shape (jax.vmap over the keys)"""
+    key = np.asarray(key, np.uint32)
+    shape = tuple(int(v) for v in np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    out = _jax_fill(0, key, n, dtype, minval, maxval, handle).to_host()
+    return out.reshape(((key.shape[0],) if key.ndim == 2 else ()) + shape)
+
+
+def jax_normal(key, shape=(), dtype=np.float32, handle=None):
+    """jax.random.normal(key, shape, dtype) (sqrt(2) erfinv of a uniform on (-1, 1)); keys (K, 2) -> (K,) + shape"""
+    key = np.asarray(key, np.uint32)
+    shape = tuple(int(v) for v in np.atleast_1d(shape)) if not isinstance(shape, tuple) else shape
+    n = int(np.prod(shape, dtype=np.int64)) if shape else 1
+    out = _jax_fill(1, key, n, dtype, 0.0, 1.0, handle).to_host()
+    return out.reshape(((key.shape[0],) if key.ndim == 2 else ()) + shape)
+
+
+def jax_kalman_noise(keys, T, d, dtype, handle=None):
+    """the draws of the reference's auxiliary Kalman kernel for each key of `keys` (C, 2) (kalman/generic.py:58-61, :73; _primitives/kalman/sampling.py:128):
+    auxiliary_key, sampling_key, accept_key = split(key, 3); normal(auxiliary_key, (T, d)); normal(sampling_key, (T, d)); bernoulli(accept_key, alpha) = uniform < alpha.
+    -> dict(eps_aux (C, T, d), eps_samp (C, T, d), u_accept (C,)) host arrays"""
+    ks = jax_split(np.asarray(keys, np.uint32).reshape(-1, 2), 3)      # (C, 3, 2)
+    return dict(eps_aux=jax_normal(ks[:, 0], (T, d), dtype, handle), eps_samp=jax_normal(ks[:, 1], (T, d), dtype, handle),
+                u_accept=jax_uniform(ks[:, 2], (), dtype, handle=handle))
+
+
+def jax_csmc_noise(key, T, N, d, dtype, backward, handle=None):
+    """the draws of the reference's auxiliary particle-Gibbs kernel with independent proposals for ONE key (csmc/generic.py:64-67; _primitives/csmc/csmc.py:53, :71-85,
+    :111, :129-138; csmc/independent.py:155-158, :194-198; resamplings.py:35: `choice` draws one uniform per index):
+        auxiliary_key, key = split(key); eps_aux = normal(auxiliary_key, (T, d)); key_fwd, key_bwd = split(key); keys = split(key_fwd, T);
+        eps_prop[0] = normal(keys[0], (N, d)); t >= 1: resampling_key, sampling_key = split(keys[t]); u_res[t - 1] = uniform(resampling_key, (N,));
+        eps_prop[t] = normal(sampling_key, (N, d)); backward sampling: kb = split(key_bwd, T), B_{T-1} from uniform(kb[0], ()), B_t from kb[T - 1 - t];
+        ancestor tracing: B_{T-1} from uniform(key_bwd, ()).
+    -> dict(eps_aux (T, d), eps_prop (T, N, d), u_res (T - 1, N), u_bwd (T,)) host arrays"""
+    aux_key, k = jax_split(key, 2)
+    k_fwd, k_bwd = jax_split(k, 2)
+    keys = jax_split(k_fwd, T)
+    eps_prop = np.empty((T, N, d), dtype)
+    eps_prop[0] = jax_normal(keys[0], (N, d), dtype, handle)
+    u_res = np.zeros((max(T - 1, 0), N), dtype)
+    if T > 1:
+        rs = jax_split(keys[1:], 2)                                      # (T - 1, 2, 2)
+        u_res[:] = jax_uniform(rs[:, 0], (N,), dtype, handle=handle)
+        eps_prop[1:] = jax_normal(rs[:, 1], (N, d), dtype, handle)
+    u_bwd = np.zeros((T,), dtype)
+    if backward:
+        kb = jax_split(k_bwd, T)
+        u_bwd[:] = jax_uniform(kb[::-1], (), dtype, handle=handle)
+    else:
+        u_bwd[T - 1] = jax_uniform(k_bwd, (), dtype, handle=handle)
+    return dict(eps_aux=jax_normal(aux_key, (T, d), dtype, handle), eps_prop=eps_prop, u_res=u_res, u_bwd=u_bwd)

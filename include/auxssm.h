@@ -402,6 +402,15 @@ int auxssm_systematic_resample(auxssm_handle h, int dtype, int32_t rows, int32_t
 int auxssm_mvn_logpdf(auxssm_handle h, int dtype, int64_t n, int32_t dim, const void* x, int64_t sx, const void* m, int64_t sm, const void* chol,
                       int64_t sl, void* out);
 
+/* auxssm_rng_jax: jax.random's own draws -- `jax.vmap(lambda k: jax.random.uniform(k, (n,), dtype, minval, maxval))(keys)` (kind 0) or `... jax.random.normal(k, (n,), dtype)`
+ * (kind 1; minval / maxval ignored) for the threefry2x32 implementation in its non-partitionable layout (JAX's default up to 0.4.x; jax/_src/prng.py: threefry_2x32,
+ * threefry_random_bits; jax/_src/random.py: _uniform, _normal_real).  keys: DEVICE (nkeys, 2) uint32 (jax.random.split's rows: aux_ssm_samplers_amd.random.jax_split);
+ * out[c * key_stride + i * elem_stride], strides in elements.  The reference's call sites: kalman/generic.py:58-61 (split(key, 3), normal(k, x.shape)), :73 (bernoulli),
+ * _primitives/kalman/sampling.py:128, csmc/generic.py:64-67, _primitives/csmc/csmc.py:71-85, :129-138 (split per time step; choice = one uniform per index).
+ * Pinned by the values JAX's documentation prints for PRNGKey(0) / PRNGKey(42) (tests/test_rng.py); float64 normals agree with XLA's erfinv to rounding. */
+int auxssm_rng_jax(auxssm_handle h, int dtype, int kind, int64_t nkeys, int64_t n, const uint32_t* keys, double minval, double maxval, void* out, int64_t key_stride,
+                   int64_t elem_stride);
+
 /* auxssm_mvn_optimal_covariance == mvn.get_optimal_covariance(chol_P, chol_Sig) (_primitives/math/mvn/base.py:78-105): the Cholesky factor of the dominating
  * covariance of Section 3 of the paper -- Y = chol_P^-1 chol_Sig, (w, V) = eigh(Y^T Y), w <- min(w, 1), L = chol_Sig V diag(w^-1/2), out = chol(L L^T) -- for
  * dim <= 64 (lower-triangular row-major inputs and output, dim x dim).  vector != 0: the reference's scalar / diagonal branch (:94-95), out = max(chol_P, chol_Sig)
