@@ -280,14 +280,14 @@ def sweep(fk, x, N, backward, *, key=None, noise=None, delta=None, handle=None, 
     nz = _lib.CsmcNoise()
     if noise is None and _random.compat() == "jax":
         # the reference's own draws from this key (random.jax_csmc_noise), as explicit arrays; several chains: one key per chain, `key` (C, 2) or split(key, C)
-        if fk.proposal != _lib.PROP_AUX_INDEPENDENT:
-            raise NotImplementedError('random.set_compat("jax") covers the auxiliary kernels with independent proposals (csmc/independent.py): the bootstrap '
-                                      "kernel's draws are made by the user's own M0.sample / Mt.sample in the reference")
+        # (the plain cSMC kernel: its draws are made by the model's own M0.sample / Mt.sample in the reference -- one normal(key, (N, d)) per call in every model
+        # the reference defines, which is what the device proposal kernels apply their Cholesky factors to)
+        aux = fk.proposal == _lib.PROP_AUX_INDEPENDENT
         kk = np.asarray(key, np.uint32)
         keys = kk if kk.ndim == 2 else (_random.as_key(key)[None] if Cn == 1 else _random.jax_split(_random.as_key(key), Cn))
         if keys.shape[0] != Cn:
             raise ValueError(f"{keys.shape[0]} keys for {Cn} chains")
-        per = [_random.jax_csmc_noise(k_, T, N, d, dtype, bool(backward), handle) for k_ in keys]
+        per = [_random.jax_csmc_noise(k_, T, N, d, dtype, bool(backward), handle, auxiliary=aux) for k_ in keys]
         noise = {name: np.stack([p_[name] for p_ in per]) for name in per[0]}
     if noise is None:
         k = _random.as_key(key)

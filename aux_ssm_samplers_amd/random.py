@@ -164,15 +164,17 @@ def jax_kalman_noise(keys, T, d, dtype, handle=None):
                 u_accept=jax_uniform(ks[:, 2], (), dtype, handle=handle))
 
 
-def jax_csmc_noise(key, T, N, d, dtype, backward, handle=None):
+def jax_csmc_noise(key, T, N, d, dtype, backward, handle=None, auxiliary=True):
     """the draws of the reference's auxiliary particle-Gibbs kernel with independent proposals for ONE key (csmc/generic.py:64-67; _primitives/csmc/csmc.py:53, :71-85,
     :111, :129-138; csmc/independent.py:155-158, :194-198; resamplings.py:35: `choice` draws one uniform per index):
         auxiliary_key, key = split(key); eps_aux = normal(auxiliary_key, (T, d)); key_fwd, key_bwd = split(key); keys = split(key_fwd, T);
         eps_prop[0] = normal(keys[0], (N, d)); t >= 1: resampling_key, sampling_key = split(keys[t]); u_res[t - 1] = uniform(resampling_key, (N,));
         eps_prop[t] = normal(sampling_key, (N, d)); backward sampling: kb = split(key_bwd, T), B_{T-1} from uniform(kb[0], ()), B_t from kb[T - 1 - t];
         ancestor tracing: B_{T-1} from uniform(key_bwd, ()).
-    -> dict(eps_aux (T, d), eps_prop (T, N, d), u_res (T - 1, N), u_bwd (T,)) host arrays"""
-    aux_key, k = jax_split(key, 2)
+    auxiliary=False: the plain cSMC kernel (_primitives/csmc/csmc.py:52-59: no auxiliary split) for models whose M0.sample / Mt.sample draw ONE normal(key, (N, d))
+    per call, as every model of the reference does (test_csmc/common.py:26-28, :42-43; examples/stochastic_volatility/auxiliary_csmc.py:23, :37).
+    -> dict(eps_aux (T, d) [auxiliary], eps_prop (T, N, d), u_res (T - 1, N), u_bwd (T,)) host arrays"""
+    aux_key, k = jax_split(key, 2) if auxiliary else (None, as_key(key))
     k_fwd, k_bwd = jax_split(k, 2)
     keys = jax_split(k_fwd, T)
     eps_prop = np.empty((T, N, d), dtype)
@@ -188,4 +190,7 @@ def jax_csmc_noise(key, T, N, d, dtype, backward, handle=None):
         u_bwd[:] = jax_uniform(kb[::-1], (), dtype, handle=handle)
     else:
         u_bwd[T - 1] = jax_uniform(k_bwd, (), dtype, handle=handle)
-    return dict(eps_aux=jax_normal(aux_key, (T, d), dtype, handle), eps_prop=eps_prop, u_res=u_res, u_bwd=u_bwd)
+    out = dict(eps_prop=eps_prop, u_res=u_res, u_bwd=u_bwd)
+    if auxiliary:
+        out["eps_aux"] = jax_normal(aux_key, (T, d), dtype, handle)
+    return out

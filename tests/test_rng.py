@@ -202,5 +202,20 @@ def test_kernels_draw_what_the_reference_draws_from_the_key_in_jax_mode():
             npt.assert_array_equal(got.x, want.x)
             npt.assert_array_equal(got.updated, want.updated)
             assert got.updated.any()
+        # --- the plain cSMC kernel (bootstrap proposals): key_fwd, key_bwd = split(key) with no auxiliary split (_primitives/csmc/csmc.py:52-59)
+        from aux_ssm_samplers_amd._primitives.csmc import get_kernel as get_csmc_kernel
+        from aux_ssm_samplers_amd.csmc import _device
+        init_b, kern_b = get_csmc_kernel(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), N, backward=True, Pt=Mt)
+        got = kern_b(key, init_b(x0))
+        k_fwd, k_bwd = O.jax_split(key, 2)
+        kt, kb = O.jax_split(k_fwd, Tc), O.jax_split(k_bwd, Tc)
+        noise = dict(eps_prop=np.stack([R.jax_normal(kt[0], (N, d), f32)] + [R.jax_normal(O.jax_split(kt[t], 2)[1], (N, d), f32) for t in range(1, Tc)]),
+                     u_res=np.stack([R.jax_uniform(O.jax_split(kt[t], 2)[0], (N,), f32) for t in range(1, Tc)]),
+                     u_bwd=np.array([R.jax_uniform(kb[Tc - 1 - t], (), f32) for t in range(Tc)], f32))
+        R.set_compat(None)
+        xw, ancw, _ = _device.sweep(_device.describe_bootstrap(M0, SVPotential(y=y[0]), Mt, SVPotential(params=y[1:]), Mt), x0, N, True, noise=noise)
+        R.set_compat("jax")
+        npt.assert_array_equal(got.x, xw)
+        npt.assert_array_equal(got.updated, ancw != 0)
     finally:
         R.set_compat(prev)
