@@ -242,6 +242,13 @@ def pit_sweep(fk, x, N, *, key=None, noise=None, delta=None, handle=None):
     shd = handle.to_device(np.sqrt(0.5 * np.asarray(delta, np.float64)) * np.ones(T), dtype)
     keep = []
     nz = _lib.CsmcNoise()
+    if noise is None and _random.compat() == "jax":   # the reference's own draws from this key (random.jax_pit_noise); several chains: `key` (C, 2) or split(key, C)
+        kk = np.asarray(key, np.uint32)
+        keys = kk if kk.ndim == 2 else (_random.as_key(key)[None] if Cn == 1 else _random.jax_split(_random.as_key(key), Cn))
+        if keys.shape[0] != Cn:
+            raise ValueError(f"{keys.shape[0]} keys for {Cn} chains")
+        per = [_random.jax_pit_noise(k_, T, N, d, dtype, handle) for k_ in keys]
+        noise = {name: np.stack([p_[name] for p_ in per]) for name in per[0]}
     if noise is None:
         k = _random.as_key(key)
         nz.mode, nz.key0, nz.key1 = _lib.NOISE_THREEFRY, int(k[0]), int(k[1])

@@ -194,3 +194,20 @@ def jax_csmc_noise(key, T, N, d, dtype, backward, handle=None, auxiliary=True):
     if auxiliary:
         out["eps_aux"] = jax_normal(aux_key, (T, d), dtype, handle)
     return out
+
+
+def jax_pit_noise(key, T, N, d, dtype, handle=None):
+    """the draws of the reference's PARALLEL-IN-TIME auxiliary kernel for one key (csmc/independent.py:105-110; _primitives/csmc/pit/csmc.py:70-75; pit/operator.py:76-81):
+        auxiliary_key, key = split(key); eps_aux = normal(auxiliary_key, (T, d)); sampling_key, resampling_key = split(key);
+        eps_prop[t] = normal(split(sampling_key, T)[t], (N, d)); the stitch at the boundary (t - 1 | t) resamples with split(resampling_key, T)[t]:
+        N uniforms (conditional multinomial over the N^2 pairs), except the LAST stitch of the tree -- boundary 2^(ceil(log2 T) - 1) -- which is one `choice` of shape ().
+    -> dict(eps_aux (T, d), eps_prop (T, N, d), u_res (T, N)) host arrays"""
+    aux_key, k = jax_split(key, 2)
+    sk, rk = jax_split(k, 2)
+    sks, rks = jax_split(sk, T), jax_split(rk, T)
+    u_res = jax_uniform(rks, (N,), dtype, handle=handle)
+    if T > 1:
+        K = int(np.ceil(np.log2(T)))
+        root = 1 << (K - 1)
+        u_res[root, 0] = jax_uniform(rks[root], (), dtype, handle=handle)
+    return dict(eps_aux=jax_normal(aux_key, (T, d), dtype, handle), eps_prop=jax_normal(sks, (N, d), dtype, handle), u_res=u_res)

@@ -217,5 +217,24 @@ def test_kernels_draw_what_the_reference_draws_from_the_key_in_jax_mode():
         R.set_compat("jax")
         npt.assert_array_equal(got.x, xw)
         npt.assert_array_equal(got.updated, ancw != 0)
+        # --- the parallel-in-time kernel (csmc/independent.py:105-110 + pit/csmc.py:70-75 + pit/operator.py:76-81): T not a power of two, the root stitch's single draw
+        Tp = 21
+        yp, xtp, (m0p, P0p, Fp, Qp, bp) = sv_setup(Tp, d, seed=5, rho=0.0)
+        M0p, Mtp = GaussianInit(m0=m0p, P0=P0p), LinearGaussianDynamics(F=Fp, b=bp, Q=Qp)
+        init_p, kern_p = get_independent_kernel(M0p, SVPotential(y=yp[0]), Mtp, SVPotential(params=yp[1:]), N, parallel=True)
+        xp0 = xtp.astype(np.float32)
+        got = kern_p(key, init_p(xp0), 0.5)
+        aux_key, k = O.jax_split(key, 2)
+        sk, rk = O.jax_split(k, 2)
+        sks, rks = O.jax_split(sk, Tp), O.jax_split(rk, Tp)
+        u_res = np.stack([R.jax_uniform(rks[t], (N,), f32) for t in range(Tp)])
+        u_res[16, 0] = R.jax_uniform(rks[16], (), f32)                       # the last stitch of the tree: boundary 2^(ceil(log2 21) - 1) = 16, one draw of shape ()
+        noise = dict(eps_aux=R.jax_normal(aux_key, (Tp, d), f32), eps_prop=np.stack([R.jax_normal(sks[t], (N, d), f32) for t in range(Tp)]), u_res=u_res)
+        R.set_compat(None)
+        want = kern_p(None, init_p(xp0), 0.5, noise=noise)
+        R.set_compat("jax")
+        npt.assert_array_equal(got.x, want.x)
+        npt.assert_array_equal(got.ancestors, want.ancestors)
+        assert got.ancestors.any()
     finally:
         R.set_compat(prev)
