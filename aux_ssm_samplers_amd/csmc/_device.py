@@ -187,6 +187,9 @@ class CsmcChains:
 
 def sweep_resident(fk, chains, N, backward, key):
     """One Threefry-keyed auxssm_csmc_sweep on resident chains.  Asynchronous."""
+    if _random.compat() == "jax":
+        raise NotImplementedError('random.set_compat("jax") runs the particle kernels on explicit arrays of the reference\'s draws (T x N x d per chain): pass host '
+                                  "states (csmc/_device.py::sweep); resident chains draw inside the kernels from this package's own streams")
     handle, d = chains.handle, chains.dx
     if d != fk.dx:
         raise ValueError(f"state dimension {d} != model dimension {fk.dx}")
@@ -210,6 +213,9 @@ def _fk_struct(fk, handle, dtype, T):
 
 def pit_sweep_resident(fk, chains, N, key):
     """One Threefry-keyed auxssm_csmc_pit_sweep (parallel-in-time cSMC) on resident chains.  Asynchronous."""
+    if _random.compat() == "jax":
+        raise NotImplementedError('random.set_compat("jax") runs the particle kernels on explicit arrays of the reference\'s draws (T x N x d per chain): pass host '
+                                  "states (csmc/_device.py::sweep); resident chains draw inside the kernels from this package's own streams")
     handle = chains.handle
     if chains.dx != fk.dx:
         raise ValueError(f"state dimension {chains.dx} != model dimension {fk.dx}")

@@ -72,7 +72,8 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
     if theta_step is not None and not kalman:
         raise ValueError("theta_step needs Kalman chains")
     handle, dtype = chains.handle, chains.dtype
-    keys = _random.split(key, n_iter)
+    split = _random.jax_split if _random.compat() == "jax" else _random.split   # (experiment.py:90: keys = jax.random.split(key, n_iter))
+    keys = split(key, n_iter)
     stats = tuple(handle.zeros(chains.x.shape, dtype) for _ in range(3))  # fold 0 overwrites: (0 u + v) / 1 = v, as stats_fn(x, x) would
     flags = chains.accepted if kalman else chains.ancestors
     m = 1 if kalman else chains.T
@@ -100,7 +101,7 @@ def loop(key, init_delta, init_state, kernel_fn, delta_fn, n_iter, target_alpha=
     try:
         for i in range(n_iter):
             if kalman:
-                k_sweep, k_theta = (keys[i], None) if theta_step is None else _random.split(keys[i], 2)
+                k_sweep, k_theta = (keys[i], None) if theta_step is None else split(keys[i], 2)
                 state = kernel_fn(k_sweep, state, delta if delta_dev is None else delta_dev)  # folds the moments in its accept step
                 if theta_step is not None:
                     theta_step(k_theta, chains)

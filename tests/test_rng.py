@@ -238,3 +238,34 @@ def test_kernels_draw_what_the_reference_draws_from_the_key_in_jax_mode():
         assert got.ancestors.any()
     finally:
         R.set_compat(prev)
+
+
+@pytest.mark.gpu
+def test_loop_in_jax_mode_splits_keys_as_the_reference_loop_does():
+    """loop() (examples/stochastic_volatility/experiment.py:88-128: keys = jax.random.split(key, n_iter), one sweep per key) on one resident Kalman chain in jax mode
+    == the same sweeps issued by hand with jax_split keys; resident particle chains refuse the mode (their draws are made inside the kernels)."""
+    from aux_ssm_samplers_amd import _lib, random as R
+    from aux_ssm_samplers_amd.kalman import get_kernel, SVModel
+    from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+    from aux_ssm_samplers_amd.loop import loop
+    from aux_ssm_samplers_amd.workloads import sv_setup
+    T = 40
+    y, xtrue, (m0, P0, F, Q, b) = sv_setup(T, 1, seed=3, rho=0.0)
+    model = SVModel(y, m0, P0, F, Q, b, order=2)
+    init, kernel = get_kernel(model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True)
+    h = _lib.default_handle()
+    key = np.array([5, 6], np.uint32)
+    prev = R.set_compat("jax")
+    try:
+        a = DeviceChains(h, xtrue[None])
+        loop(key, 0.5, KalmanSampler(x=a, updated=None), kernel, None, 5)
+        bch = DeviceChains(h, xtrue[None])
+        for k in R.jax_split(key, 5):
+            kernel(k, KalmanSampler(x=bch, updated=None), 0.5)
+        npt.assert_array_equal(a.to_host(), bch.to_host())
+        from aux_ssm_samplers_amd.csmc import get_independent_kernel, CsmcChains, CSMCState, GaussianInit, LinearGaussianDynamics, SVPotential
+        ic, kc = get_independent_kernel(GaussianInit(m0=m0, P0=P0), SVPotential(y=y[0]), LinearGaussianDynamics(F=F, b=b, Q=Q), SVPotential(params=y[1:]), 16)
+        with pytest.raises(NotImplementedError):
+            kc(key, CSMCState(x=CsmcChains(h, xtrue[None].astype(np.float32), delta=0.5), updated=None), None)
+    finally:
+        R.set_compat(prev)
