@@ -44,7 +44,12 @@ class LorenzThetaStep:
         par = self.model.par_device(handle, chains.dtype, chains.C)
         if self._eps is None or self._eps.handle is not handle or self._eps.shape != (chains.C, 3) or self._eps.dtype != chains.dtype:
             self._eps = handle.empty((chains.C, 3), chains.dtype)
-        handle.rng_normal_into(key, 0, self._eps)
+        if _random.compat() == "jax":   # examples/lorenz/experiment.py:115: jax.random.normal(key_theta, (3,)) -- one key per chain (`key` (C, 2) or split(key, C))
+            kk = np.asarray(key, np.uint32)
+            keys = kk if kk.ndim == 2 else (_random.as_key(key)[None] if chains.C == 1 else _random.jax_split(_random.as_key(key), chains.C))
+            self._eps.copy_from_host(_random.jax_normal(keys, (3,), chains.dtype, handle))
+        else:
+            handle.rng_normal_into(key, 0, self._eps)
         handle.lorenz_theta_update(chains.x, self.sigma_theta, self.model.sigma_x, self._eps, par, layout=chains.layout)
 
     def theta(self, chains):
