@@ -263,11 +263,20 @@ def _get_device_kernel(model, parallel, nan_policy="reference"):
             keys_c = kk if kk.ndim == 2 else (_random.as_key(key)[None] if Cn == 1 else _random.jax_split(_random.as_key(key), Cn))
             if keys_c.shape[0] != Cn:
                 raise ValueError(f"{keys_c.shape[0]} keys for {Cn} chains")
-            noise = _random.jax_kalman_noise(keys_c, Tn, dn, dt, handle)
+            jax_keys = _random.jax_split(keys_c, 3)     # (C, 3, 2): auxiliary_key, sampling_key, accept_key of every chain (kalman/generic.py:58)
+        else:
+            jax_keys = None
         chains = state.x if resident else DeviceChains(handle, state.x, chain_minor=False if model.dense_only else None,
-                                                       model=model if parallel and noise is None else None)
+                                                       model=model if parallel and noise is None and jax_keys is None else None)
         keys = None
-        if noise is None:  # the keyed sweep: same values as draw() + sweep(), in one call (eps buffers: taken on demand, the fused sweep has none)
+        if jax_keys is not None:  # the draws go straight into the chains' noise buffers, in their layout (dense (C, T, d): a key's values are contiguous; chain-minor (T, d, C))
+            eps_aux, eps_samp, u_acc = chains.eps_aux, chains.eps_samp, chains.u_acc
+            n = chains.T * chains.dx
+            ks, es = (1, chains.C) if chains.chain_minor else (n, 1)
+            _random._jax_fill(1, jax_keys[:, 0], n, chains.dtype, 0.0, 1.0, handle, out=eps_aux, key_stride=ks, elem_stride=es)
+            _random._jax_fill(1, jax_keys[:, 1], n, chains.dtype, 0.0, 1.0, handle, out=eps_samp, key_stride=ks, elem_stride=es)
+            _random._jax_fill(0, jax_keys[:, 2], 1, chains.dtype, 0.0, 1.0, handle, out=u_acc, key_stride=1, elem_stride=1)
+        elif noise is None:  # the keyed sweep: same values as draw() + sweep(), in one call (eps buffers: taken on demand, the fused sweep has none)
             keys = _random.split(key, 3)
             eps_aux, eps_samp, u_acc = None, None, chains.u_acc
         else:

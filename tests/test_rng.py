@@ -173,6 +173,19 @@ def test_kernels_draw_what_the_reference_draws_from_the_key_in_jax_mode():
         xs = np.stack([x, x + 0.01, x - 0.01])
         outs = kernel(keys, init(xs), 0.02)
         npt.assert_allclose(outs.x[0], kernel(keys[0], init(xs[0]), 0.02).x, rtol=1e-9, atol=1e-10)
+        # resident chains in either layout: the draws are written straight into the chains' noise buffers on the device
+        from aux_ssm_samplers_amd import _lib
+        from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
+        for cm in (False, True):
+            ch = DeviceChains(_lib.default_handle(), xs, chain_minor=cm)
+            kernel(keys, KalmanSampler(x=ch, updated=None), 0.02)
+            npt.assert_allclose(ch.to_host(), outs.x, rtol=1e-9, atol=1e-10)
+            for c in range(3):   # every chain against the oracle's sweep on the oracle's draws for ITS key
+                ka_, ks_, kc_ = O.jax_split(keys[c], 3)
+                nz_ = dict(eps_aux=O.jax_normal(ka_, 3 * T, np.float64).reshape(T, 3), eps_samp=O.jax_normal(ks_, 3 * T, np.float64).reshape(T, 3),
+                           u_accept=float(O.jax_uniform(kc_, 1, np.float64)[0]))
+                rf = K.kalman_sweep(xs[c], 0.02, model.dynamics_factory, model.observations_factory, model.log_likelihood_fn, True, **nz_)
+                npt.assert_allclose(ch.to_host()[c], rf["x"], rtol=1e-8, atol=1e-9)
         ih, kh = get_kernel(lambda z: model.dynamics_factory(z), lambda z, u, dl: model.observations_factory(z, u, dl), lambda z: model.log_likelihood_fn(z), True)
         npt.assert_allclose(kh(key, ih(x), 0.02).x, out.x, rtol=1e-8, atol=1e-9)
         # --- auxiliary particle Gibbs, independent proposals, both backward modes, fp32
