@@ -605,15 +605,28 @@ __device__ inline float jax_erfinv(float x) {
     return p * x;
 }
 __device__ inline double jax_erfinv(double x) {
-    double y = (double)jax_erfinv((float)x);
     if (!(fabs(x) < 1.0)) return x == 1.0 ? (double)INFINITY : (x == -1.0 ? -(double)INFINITY : (double)NAN);
-    // Newton with the second-order (Halley) correction, d/dy erf = 2 / sqrt(pi) exp(-y^2); beyond |x| = 1/2 on erfc(|y|) = 1 - |x| (1 - |x| is exact there and erfc
-    // keeps its RELATIVE accuracy in the tail, where erf(y) - x would lose it to cancellation)
-    const bool tail = fabs(x) > 0.5;
+    // start: the float32 polynomials evaluated in double on w = -log((1 - |x|)(1 + |x|)) (1 - |x| is exact for |x| >= 1/2, so the tails keep their digits: a float
+    // argument would round |x| > 1 - 6e-8 to 1 and start from infinity); beyond float's range (w > 16) they extrapolate to a few per cent, which two more steps absorb
     const double ax = fabs(x), c = 1.0 - ax;
-    double ya = fabs(y);
-#pragma unroll
-    for (int it = 0; it < 2; ++it) {
+    double w = -log(c * (1.0 + ax));
+    const bool lt = w < 5.0, far = w > 16.0;
+    w = lt ? w - 2.5 : sqrt(w) - 3.0;
+    double p = lt ? 2.81022636e-08 : -0.000200214257;
+    p = (lt ? 3.43273939e-07 : 0.000100950558) + p * w;
+    p = (lt ? -3.5233877e-06 : 0.00134934322) + p * w;
+    p = (lt ? -4.39150654e-06 : -0.00367342844) + p * w;
+    p = (lt ? 0.00021858087 : 0.00573950773) + p * w;
+    p = (lt ? -0.00125372503 : -0.0076224613) + p * w;
+    p = (lt ? -0.00417768164 : 0.00943887047) + p * w;
+    p = (lt ? 0.246640727 : 1.00167406) + p * w;
+    p = (lt ? 1.50140941 : 2.83297682) + p * w;
+    double ya = p * ax;
+    // Newton with the second-order (Halley) correction, d/dy erf = 2 / sqrt(pi) exp(-y^2); beyond |x| = 1/2 on erfc(|y|) = 1 - |x| (erfc keeps its RELATIVE accuracy in
+    // the tail, where erf(y) - x would lose it to cancellation)
+    const bool tail = ax > 0.5;
+    const int nit = far ? 4 : 2;
+    for (int it = 0; it < nit; ++it) {
         const double d = 1.1283791670955126 * exp(-ya * ya);
         const double e = tail ? c - erfc(ya) : erf(ya) - ax;   // = erf(ya) - |x| either way
         const double st = e / d;
@@ -627,7 +640,9 @@ __global__ void __launch_bounds__(256) k_rng_jax(int kind, long long nkeys, long
     const long long per = sizeof(R) == 4 ? (n + 1) / 2 : n;   // blocks per key
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= nkeys * per) return;
-    const long long c = g / per, i = g - c * per;
+    // consecutive lanes write consecutive addresses: along the values of a key (dense targets) or along the keys (chain-minor targets: key stride 1)
+    const bool keys_fast = skey < selem;
+    const long long c = keys_fast ? g % nkeys : g / per, i = keys_fast ? g / nkeys : g - (g / per) * per;
     const uint32_t k0 = keys[2 * c], k1 = keys[2 * c + 1];
     auto finish = [&](R f) {   // f in [0, 1)
         R v = f * (hi - lo) + lo;

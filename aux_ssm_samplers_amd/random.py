@@ -118,8 +118,10 @@ def _jax_threefry_2x32(key, count):
 def jax_split(key, num=2):
     """jax.random.split(key, num) -> (num, 2) uint32; `key` may also be (K, 2): -> (K, num, 2) (a vmap over keys)"""
     key = np.asarray(key, np.uint32)
-    if key.ndim == 2:
-        return np.stack([jax_split(k, num) for k in key])
+    if key.ndim == 2:   # the same counters for every key: one vectorised block evaluation (2 num counters: halves (0 .. num) and (num .. 2 num), never odd)
+        x0, x1 = np.arange(num, dtype=np.uint32)[None, :], np.arange(num, 2 * num, dtype=np.uint32)[None, :]
+        o0, o1 = threefry2x32(key[:, :1], key[:, 1:], x0, x1)
+        return np.concatenate([o0, o1], axis=1).reshape(key.shape[0], num, 2)
     return _jax_threefry_2x32(as_key(key), np.arange(2 * num, dtype=np.uint32)).reshape(num, 2)
 
 

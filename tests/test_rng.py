@@ -137,9 +137,17 @@ def test_jax_streams_device_reproduces_the_documented_values_and_the_oracle():
     # shapes: scalar, matrix; one key
     assert np.shape(R.jax_uniform(keys[0], ())) == () and R.jax_normal(keys[0], (7, 3), np.float64).shape == (7, 3)
     npt.assert_array_equal(R.jax_normal(keys[0], (7, 3), np.float64).ravel(), R.jax_normal(keys[0], (21,), np.float64))
-    # moments of a large draw
-    big = R.jax_normal(np.array([1, 2], np.uint32), (1_000_000,), np.float64)
-    assert abs(big.mean()) < 4e-3 and abs(big.std() - 1) < 3e-3 and np.isfinite(big).all()
+    # a large float64 draw reaches the tails (|u| > 1 - 6e-8, where a float32 start of erfinv would be infinite): all finite, the tail counts as expected, and the
+    # extreme values against SciPy's erfinv on the oracle's uniforms
+    kb, nb = np.array([1, 2], np.uint32), 60_000_000
+    big = R.jax_normal(kb, (nb,), np.float64)
+    assert np.isfinite(big).all() and abs(big.mean()) < 6e-4 and abs(big.std() - 1) < 4e-4
+    n5 = int((np.abs(big) > 5.0).sum())
+    assert 10 <= n5 <= 65, n5                                   # expected 34.4
+    ext = np.argsort(-np.abs(big))[:50]
+    from scipy.special import erfinv
+    ub = O.jax_uniform(kb, nb, np.float64, np.nextafter(-1.0, 0.0), 1.0)
+    npt.assert_allclose(big[ext], np.sqrt(2.0) * erfinv(ub[ext]), rtol=1e-13)
 
 
 @pytest.mark.gpu
