@@ -48,6 +48,8 @@ struct FusedArgs {
     const double* dptr;  // device-resident {delta, sqrt(delta / 2)} or null
     int nan_policy;
     const int* memo;     // model-stage memo (FilterArgs::memo): the stage kernels return at once when *memo == 0
+    int pack, cp;        // few chains (PK instantiations of the two chain passes): one wave walks `pack` consecutive chunks side by side, lane = sub * cp + chain, cp = the
+                         // chain count rounded up to a power of two; 1 / 0 otherwise
 };
 AX_HD void fs_resolve(FusedArgs& a) {
     const double* p = a.dptr;
@@ -285,6 +287,27 @@ template <typename R, int N> __device__ __forceinline__ void fs_stage(const R* _
     __syncthreads();
 }
 
+// packed form (few chains): rows [r0, r1) = `pack` consecutive chunks of E rows, each chunk's block shifted by one 16-byte slot more than the one before it -- the lanes
+// of different chunks read the SAME row offset of their own block at the same time, and E N reals is a multiple of the bank count, so without the shift every read
+// would be a `pack`-way bank conflict
+template <typename R, int N> __device__ __forceinline__ void fs_stage_pk(const R* __restrict__ tab, int r0, int r1, int E, R* __restrict__ lds) {
+    using V = typename Vec16<R>::type;
+    constexpr int W = Vec16<R>::W, NV = N / W;
+    const V* src = reinterpret_cast<const V*>(tab + (long long)r0 * N);
+    V* dst = reinterpret_cast<V*>(lds);
+    const int n = (r1 - r0) * NV, B = blockDim.x;
+    for (int i = threadIdx.x; i < n; i += 8 * B) {   // eight loads in flight per trip
+        V v[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) v[q] = i + q * B < n ? src[i + q * B] : V{};
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+            if (i + q * B < n) dst[i + q * B + ((i + q * B) / NV) / E] = v[q];
+    }
+    __syncthreads();
+}
+template <typename R, int N> AX_HD size_t fs_pk_block(int E) { return (size_t)E * N + Vec16<R>::W; }  // reals per chunk block in LDS (packed form)
+
 // the tables of the fp64 normal transform (rng.h) in the workgroup's LDS, behind the pass's coefficient rows; the barrier of fs_stage publishes them.
 // fp32 draws use the hardware functions: no table, no LDS.
 template <typename R> struct FsNormTabSel { using type = NormTabGlobal; static constexpr size_t BYTES = 0; };
@@ -403,17 +426,32 @@ __device__ __forceinline__ bool fs_wave_any(bool flag) { return __builtin_amdgcn
 #ifndef AUXSSM_FS_WPE_A
 #define AUXSSM_FS_WPE_A 2
 #endif
-template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUXSSM_FS_WPE_A))) k_fs_ac(FusedArgs a, const R* __restrict__ rows) {
+// PK (few chains, one wave per workgroup): lane = sub * cp + chain walks chunk blockIdx.x * pack + sub -- the time index is per lane, everything else is the same code
+template <typename R, int D, int PO, bool PK = false>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AUXSSM_FS_WPE_A))) k_fs_ac(FusedArgs a, const R* __restrict__ rows) {
     using F = FsRows<R, D, PO>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     R* lds = (R*)smem;
     fs_resolve(a);
     int ch, c;
-    fs_block(a, ch, c);
+    if constexpr (PK) {
+        const int sub = (int)threadIdx.x / a.cp;
+        c = (int)threadIdx.x - sub * a.cp;
+        ch = blockIdx.x * a.pack + sub;
+    } else {
+        fs_block(a, ch, c);
+    }
     const long long C = a.C;
     const int t0 = ch * a.E, ta = max(1, t0), tb = min(a.T, t0 + a.E);
-    const FsNormTab<R> ntab = fs_stage_normtab<R>(lds + (size_t)a.E * F::NC);
-    fs_stage<R, F::NC>(rows, t0, tb, lds);
+    const FsNormTab<R> ntab = fs_stage_normtab<R>(lds + (PK ? (size_t)a.pack * fs_pk_block<R, F::NC>(a.E) : (size_t)a.E * F::NC));
+    if constexpr (PK) {
+        const int c0 = blockIdx.x * a.pack;
+        fs_stage_pk<R, F::NC>(rows, c0 * a.E, min(a.T, (c0 + a.pack) * a.E), a.E, lds);
+        lds += (size_t)(ch - c0) * fs_pk_block<R, F::NC>(a.E);   // the lane's own chunk block
+        if (ch >= a.nchunk) return;
+    } else {
+        fs_stage<R, F::NC>(rows, t0, tb, lds);
+    }
     if (c >= a.C) return;
     const R* xr = (const R*)((a.sel && a.sel[c]) ? (const void*)a.xb : a.xa) + c;
     R* up = (R*)a.u + c;
@@ -463,13 +501,13 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __at
     for (int k = 0; k < D; ++k) xn[k] = ta < tb ? xr[((long long)ta * D + k) * C] : (R)0;
 #pragma unroll 1
     for (int t = ta; t < tb; ++t) {
-        const int tu = opaque_uniform(t);
+        const int tu = PK ? t : opaque_uniform(t);
         const R* row = lds + (tu - t0) * F::NC;
         R x[D], ev[D], u[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) x[k] = xn[k];
         if (t + 1 < tb) {
-            const int tn = opaque_uniform(t + 1);
+            const int tn = PK ? t + 1 : opaque_uniform(t + 1);
 #pragma unroll
             for (int k = 0; k < D; ++k) xn[k] = xr[((long long)tn * D + k) * C];
         }
@@ -524,16 +562,29 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) __at
 }
 
 // ---- pass E ---------------------------------------------------------------------------------------------------------------------------
-template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs_e(FusedArgs a, const R* __restrict__ rows) {
+template <typename R, int D, int PO, bool PK = false> __global__ void __launch_bounds__(256) k_fs_e(FusedArgs a, const R* __restrict__ rows) {
     using F = FsRows<R, D, PO>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     R* lds = (R*)smem;
     fs_resolve(a);
     int ch, c;
-    fs_block(a, ch, c);
+    if constexpr (PK) {
+        const int sub = (int)threadIdx.x / a.cp;
+        c = (int)threadIdx.x - sub * a.cp;
+        ch = blockIdx.x * a.pack + sub;
+    } else {
+        fs_block(a, ch, c);
+    }
     const long long C = a.C;
     const int t0 = ch * a.E, tb = min(a.T, t0 + a.E);
-    fs_stage<R, F::NE>(rows, t0, tb, lds);
+    if constexpr (PK) {
+        const int c0 = blockIdx.x * a.pack;
+        fs_stage_pk<R, F::NE>(rows, c0 * a.E, min(a.T, (c0 + a.pack) * a.E), a.E, lds);
+        lds += (size_t)(ch - c0) * fs_pk_block<R, F::NE>(a.E);
+        if (ch >= a.nchunk) return;
+    } else {
+        fs_stage<R, F::NE>(rows, t0, tb, lds);
+    }
     if (c >= a.C) return;
     R* xw = (R*)((a.sel && a.sel[c]) ? const_cast<void*>(a.xa) : a.xb) + c;
     const R* up = (const R*)a.u + c;
@@ -561,13 +612,13 @@ template <typename R, int D, int PO> __global__ void __launch_bounds__(256) k_fs
     for (int k = 0; k < D; ++k) incn[k] = ip[((long long)(tb - 1) * D + k) * C], utn[k] = up[((long long)(tb - 1) * D + k) * C];
 #pragma unroll 1
     for (int t = tb - 1; t >= t0; --t) {
-        const int tu = opaque_uniform(t);
+        const int tu = PK ? t : opaque_uniform(t);
         const R* row = lds + (tu - t0) * F::NE;
         R inc[D], ut[D], xp[D];
 #pragma unroll
         for (int k = 0; k < D; ++k) inc[k] = incn[k], ut[k] = utn[k];
         if (t > t0) {
-            const int tn = opaque_uniform(t - 1);
+            const int tn = PK ? t - 1 : opaque_uniform(t - 1);
 #pragma unroll
             for (int k = 0; k < D; ++k) incn[k] = ip[((long long)tn * D + k) * C], utn[k] = up[((long long)tn * D + k) * C];
         }
@@ -655,6 +706,18 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
+// few chains (<= 32): how many chunks one wave walks side by side (lanes = pack x cp), 1 = the plain mapping.  AUXSSM_FS_PACK=0 switches it off, n > 1 caps it (measurement).
+// Measured at C2's sizes (profiles/r04_i_low_chain_layout.txt): 8 chains 18.2k -> 24.4k sweeps/s, 16 chains 40.7k -> 51.1k, 32 chains 78.0k -> 84.5k.
+inline int fs_pack(int C, int* cp_out) {
+    static const int on = [] { const char* e = getenv("AUXSSM_FS_PACK"); return e ? atoi(e) : 1; }();
+    int cp = 2;
+    while (cp < C) cp <<= 1;
+    *cp_out = cp;
+    if (!on || C > 32) return 1;
+    int pack = 64 / cp;
+    const int cap = on > 1 ? on : 8;   // (LDS: pack blocks of E coefficient rows)
+    return pack > cap ? cap : pack;
+}
 inline int fs_chunk_len(const auxssm_ctx* h, int C, int T) {
     static const int waves = [] { const char* e = getenv("AUXSSM_FS_WAVES"); const int v = e ? atoi(e) : 10; return v >= 1 && v <= 64 ? v : 10; }();
     static const int fixedE = [] { const char* e = getenv("AUXSSM_FS_E"); return e ? atoi(e) : 0; }();
@@ -691,6 +754,12 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     a.C = C; a.T = T;
     a.E = fs_chunk_len(h, C, T);
     a.nchunk = (T + a.E - 1) / a.E;
+    a.pack = fs_pack(C, &a.cp);
+    {   // the packed workgroup stages `pack` chunk blocks of coefficient rows: keep them (and the normal tables) within 128 KB of LDS
+        using FR = FsRows<R, D, PO>;
+        constexpr int NMAX = FR::NC > FR::NE ? FR::NC : FR::NE;
+        while (a.pack > 1 && (size_t)a.pack * fs_pk_block<R, NMAX>(a.E) * sizeof(R) + FsNormTabSel<R>::BYTES > (size_t)128 * 1024) a.pack >>= 1;
+    }
     a.xa = f.xa; a.xb = f.xb; a.sel = f.sel; a.u = f.u; a.inc = f.inc;
     a.ka0 = f.keys[0]; a.ka1 = f.keys[1]; a.ks0 = f.keys[2]; a.ks1 = f.keys[3];
     a.eps0s = f.eps0s;
@@ -758,8 +827,14 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     static const int tbf_env = getenv("AUXSSM_FS_TBF") ? atoi(getenv("AUXSSM_FS_TBF")) : 0;
     const int TBF = (tbf_env == 64 || tbf_env == 128 || tbf_env == 256) && C >= tbf_env ? tbf_env : (C >= 256 ? 256 : (C + 63) / 64 * 64);
     const unsigned grid = (unsigned)a.nchunk * (unsigned)((C + TBF - 1) / TBF);
+    const unsigned grid_pk = (unsigned)((a.nchunk + a.pack - 1) / a.pack);
     const size_t lds = (size_t)TB_AGGS * SampElem<R, D>::NPAD * sizeof(R);
-    {
+    if (a.pack > 1) {
+        const size_t lds_ac = (size_t)a.pack * fs_pk_block<R, F::NC>(a.E) * sizeof(R) + FsNormTabSel<R>::BYTES;
+        if (lds_ac > 64 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_fs_ac<R, D, PO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ac));
+        ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
+        hipLaunchKernelGGL((k_fs_ac<R, D, PO, true>), dim3(grid_pk), dim3(a.pack * a.cp), lds_ac, h->stream, a, (const R*)rows_c);
+    } else {
         const size_t lds_ac = (size_t)a.E * F::NC * sizeof(R) + FsNormTabSel<R>::BYTES;
         if (lds_ac > 64 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_fs_ac<R, D, PO>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_ac));
         ProfScope ps(h, AUXSSM_K_FILTER_SCAN);
@@ -774,7 +849,12 @@ template <typename R, int D, int PO> int run_fused_shared(auxssm_ctx* h, FusedHo
     }
     {
         ProfScope ps(h, AUXSSM_K_LOGPDF);
-        hipLaunchKernelGGL((k_fs_e<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NE * sizeof(R), h->stream, a, (const R*)rows_e);
+        if (a.pack > 1) {
+            const size_t lds_e = (size_t)a.pack * fs_pk_block<R, F::NE>(a.E) * sizeof(R);
+            if (lds_e > 64 * 1024) AX_HIP(hipFuncSetAttribute((const void*)k_fs_e<R, D, PO, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_e));
+            hipLaunchKernelGGL((k_fs_e<R, D, PO, true>), dim3(grid_pk), dim3(a.pack * a.cp), lds_e, h->stream, a, (const R*)rows_e);
+        } else
+            hipLaunchKernelGGL((k_fs_e<R, D, PO>), dim3(grid), dim3(TBF), (size_t)a.E * F::NE * sizeof(R), h->stream, a, (const R*)rows_e);
     }
     {
         ProfScope ps(h, AUXSSM_K_SELECT);
