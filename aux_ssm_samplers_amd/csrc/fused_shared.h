@@ -706,15 +706,17 @@ template <typename R> __global__ void __launch_bounds__(TB_ELEM) k_fs_accept(Fus
 }
 
 // ---- host side ------------------------------------------------------------------------------------------------------------------------
-// few chains (<= 32): how many chunks one wave walks side by side (lanes = pack x cp), 1 = the plain mapping.  AUXSSM_FS_PACK=0 switches it off, n > 1 caps it (measurement).
-// Measured at C2's sizes (profiles/r04_i_low_chain_layout.txt): 8 chains 18.2k -> 24.4k sweeps/s, 16 chains 40.7k -> 51.1k, 32 chains 78.0k -> 84.5k.
+// few chains (<= 128): how many chunks one workgroup of up to 256 lanes walks side by side (lanes = pack x cp), 1 = the plain mapping.  AUXSSM_FS_PACK=0 switches it off, n > 1 caps it (measurement).
+// Measured at C2's sizes (profiles/r04_i_low_chain_layout.txt): 8 chains 18.2k -> 23.4k sweeps/s, 16 chains 40.7k -> 51.0k, 32 chains 78.0k -> 91.0k, 64 chains 133.7k -> 152.0k,
+// 128 chains 189.4k -> 218.4k (the chunks of a workgroup share one staging of the normal tables and one barrier).
 inline int fs_pack(int C, int* cp_out) {
     static const int on = [] { const char* e = getenv("AUXSSM_FS_PACK"); return e ? atoi(e) : 1; }();
     int cp = 2;
     while (cp < C) cp <<= 1;
     *cp_out = cp;
-    if (!on || C > 32) return 1;
-    int pack = 64 / cp;
+    static const int lanes = [] { const char* e = getenv("AUXSSM_FS_PACK_LANES"); const int v = e ? atoi(e) : 256; return v == 64 || v == 128 ? v : 256; }();   // lanes per packed workgroup (measured: 256 best from 32 chains on)
+    if (!on || cp > lanes / 2) return 1;
+    int pack = lanes / cp;
     const int cap = on > 1 ? on : 8;   // (LDS: pack blocks of E coefficient rows)
     return pack > cap ? cap : pack;
 }

@@ -30,7 +30,7 @@ def _setup(T, d, dtype, Cn, seed=0):
 @pytest.mark.parametrize("T,d,Cn", [(4096, 4, 64), (1000, 2, 130), (257, 1, 2), (64, 4, 66), (3001, 4, 256),
                                     # few chains: one wave walks several chunks side by side (the PK instantiations of the two passes, csrc/fused_shared.h):
                                     # chain counts that are / are not powers of two, T that is not a multiple of a workgroup's chunks, the shortest T, 2..32 chains
-                                    (1000, 4, 8), (257, 2, 6), (4096, 4, 16), (333, 2, 32), (64, 4, 4), (2048, 4, 30), (513, 4, 2), (777, 1, 12)])
+                                    (1000, 4, 8), (257, 2, 6), (4096, 4, 16), (333, 2, 32), (64, 4, 4), (2048, 4, 30), (513, 4, 2), (777, 1, 12), (1500, 4, 64), (999, 2, 100), (2048, 4, 128)])
 def test_fused_equals_keyed_sweep(dtype, T, d, Cn):
     from aux_ssm_samplers_amd import _lib, random as R
     from aux_ssm_samplers_amd.kalman.generic import DeviceChains, KalmanSampler
