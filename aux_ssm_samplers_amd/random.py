@@ -51,7 +51,9 @@ def as_key(key):
 
 
 def split(key, num=2):
-    """num child keys: child i = threefry(key, counter=(i, 0xFFFFFFFF)) (a counter no fill kernel ever uses)."""
+    """num child keys: child i = threefry(key, counter=(i, 0xFFFFFFFF)) (a counter no fill kernel ever uses).  set_compat("jax"): jax.random.split."""
+    if _COMPAT == "jax":
+        return jax_split(key, num)
     key = as_key(key)
     i = np.arange(num, dtype=np.uint32)
     a, b = threefry2x32(key[0], key[1], i, np.full(num, 0xFFFFFFFF, np.uint32))
@@ -66,7 +68,9 @@ def uniform_scalar(key):
 
 
 def normal(key, shape=(), dtype=np.float64, handle=None):
-    """N(0, 1) draws of `shape`, generated on the device (auxssm_rng_normal, stream 0) and returned as a NumPy array."""
+    """N(0, 1) draws of `shape`, generated on the device (auxssm_rng_normal, stream 0) and returned as a NumPy array.  set_compat("jax"): jax.random.normal."""
+    if _COMPAT == "jax":
+        return jax_normal(key, shape, dtype, handle)
     from . import _lib
     handle = handle or _lib.default_handle()
     key = as_key(key)
@@ -77,7 +81,9 @@ def normal(key, shape=(), dtype=np.float64, handle=None):
 
 
 def uniform(key, shape=(), dtype=np.float64, handle=None):
-    """U[0, 1) draws of `shape`, generated on the device (auxssm_rng_uniform, stream 0) and returned as a NumPy array."""
+    """U[0, 1) draws of `shape`, generated on the device (auxssm_rng_uniform, stream 0) and returned as a NumPy array.  set_compat("jax"): jax.random.uniform."""
+    if _COMPAT == "jax":
+        return jax_uniform(key, shape, dtype, handle=handle)
     from . import _lib
     handle = handle or _lib.default_handle()
     key = as_key(key)

@@ -284,6 +284,10 @@ def test_loop_in_jax_mode_splits_keys_as_the_reference_loop_does():
         for k in R.jax_split(key, 5):
             kernel(k, KalmanSampler(x=bch, updated=None), 0.5)
         npt.assert_array_equal(a.to_host(), bch.to_host())
+        # the module's own split / normal / uniform follow jax.random while the mode is on
+        npt.assert_array_equal(R.split(np.array([0, 0], np.uint32), 2), np.array(JAX_KAT["split0"], np.uint32))
+        npt.assert_allclose(R.normal(np.array([0, 0], np.uint32), (1,), np.float32)[0], JAX_KAT["normal0"], atol=2e-7)
+        npt.assert_allclose(R.uniform(np.array([0, 0], np.uint32), (1,), np.float32)[0], JAX_KAT["uniform0"], atol=6e-8)
         from aux_ssm_samplers_amd.csmc import get_independent_kernel, CsmcChains, CSMCState, GaussianInit, LinearGaussianDynamics, SVPotential
         ic, kc = get_independent_kernel(GaussianInit(m0=m0, P0=P0), SVPotential(y=y[0]), LinearGaussianDynamics(F=F, b=b, Q=Q), SVPotential(params=y[1:]), 16)
         with pytest.raises(NotImplementedError):
